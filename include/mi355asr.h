@@ -1,0 +1,129 @@
+/* mi355asr.h -- C ABI of libmi355asr.so: the MI355X (gfx950) Conformer-CTC hot path of
+ * Z-yq/TensorflowASR (encoder + CTCDecoder + CTC greedy decode) behind plain pointers and sizes.
+ *
+ * The reference has no FFI for this path: it is Keras `Model` objects called from Python
+ * (test_asr.py:186-219) and, in deployment, ONNX sessions called from C++
+ * (Inference/CppInference/onnx/src/core/asr_session.cpp:77-123).  Each entry point below names the
+ * reference interface it stands in for.  INTEGRATION.md shows the ctypes stub (Python reference)
+ * and the C++ `ASR::Session` patch a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MI355ASR_E* code on failure;
+ *     mi355asr_last_error() returns a thread-local message for the last failure on this thread
+ *   - `*_dev` pointers are DEVICE pointers owned by the caller (e.g. torch-ROCm tensors);
+ *     host pointers are marked `_host`
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is enqueued
+ *     asynchronously on it; nothing synchronises the device
+ *   - a handle is not re-entrant: one in-flight call per handle (the reference's C++ Session has the
+ *     same contract, asr_session.h keeps mutable buffers); distinct handles are independent
+ *   - all arithmetic is IEEE fp32 (v_mfma_f32_16x16x4_f32 + fp32 VALU), matching the reference's dtype
+ */
+#ifndef MI355ASR_H
+#define MI355ASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355ASR_OK 0
+#define MI355ASR_EINVAL -1   /* bad argument / unsupported configuration */
+#define MI355ASR_ESTATE -2   /* call order (weights not finalised, ...) */
+#define MI355ASR_EWEIGHT -3  /* unknown / missing / mis-shaped weight */
+#define MI355ASR_EWORKSPACE -4
+#define MI355ASR_EHIP -5     /* HIP runtime error */
+
+typedef struct mi355asr_model mi355asr_model;
+
+/* Constructor arguments of ConformerEncoder / StreamingConformerEncoder / CTCDecoder
+ * (asr/models/conformer_blocks.py:278-294, 386-395, 568-572; values from the YAML files under asr/configs/). */
+typedef struct {
+  int32_t dmodel;            /* model_config.dmodel                       144 | 256            */
+  int32_t num_blocks;        /* model_config.num_blocks                   13  | 4              */
+  int32_t head_size;         /* model_config.head_size                    36  | 64             */
+  int32_t num_heads;         /* model_config.num_heads                    4                    */
+  int32_t kernel_size;       /* model_config.kernel_size                  32  | 5              */
+  float   fc_factor;         /* model_config.fc_factor                    0.5                  */
+  int32_t reduction_factor;  /* model_config.reduction_factor             4                    */
+  int32_t n_mels;            /* speech_config.num_feature_bins            80                   */
+  int32_t sample_rate;       /* speech_config.sample_rate                 16000                */
+  int32_t stride_ms;         /* speech_config.stride_ms                   10                   */
+  int32_t n_dft;             /* hard-coded 1024 in conformer_blocks.py:312                     */
+  int32_t chunk_size;        /* StreamingConformerEncoder.add_chunk_size (samples); 0 = offline */
+  int32_t has_encoder;       /* 1: handle owns a ConformerEncoder; 0: CTCDecoder-only handle  */
+  int32_t num_classes;       /* CTCDecoder num_classes (blank = num_classes-1); 0 = no CTC head */
+  int32_t ctc_num_blocks;    /* model_config.ctcdecoder_num_blocks        1                    */
+  int32_t ctc_kernel_size;   /* model_config.ctcdecoder_kernel_size       32                   */
+  float   ctc_fc_factor;     /* model_config.ctcdecoder_fc_factor         0.5                  */
+} mi355asr_config;
+
+const char* mi355asr_last_error(void);
+const char* mi355asr_version(void);
+
+/* replaces: ConformerEncoder(...)/CTCDecoder(...) construction, test_asr.py:28-75 */
+int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out);
+int mi355asr_destroy(mi355asr_model* m);
+
+/* replaces: model.load_weights(path[, by_name=True]), test_asr.py:95-114.  `name` is the Keras-layout
+ * tensor name (see DESIGN.md "weight names"), data is host fp32 in the Keras layout of that tensor.
+ * May be called again after finalisation to overwrite a tensor (then finalise again). */
+int mi355asr_load_weight(mi355asr_model* m, const char* name, const float* data_host, int32_t rank,
+                         const int64_t* dims);
+/* number of tensors the configuration expects / name of the i-th one (so loaders can iterate) */
+int mi355asr_num_weights(const mi355asr_model* m);
+const char* mi355asr_weight_name(const mi355asr_model* m, int32_t i);
+/* replaces: model._build() (test_asr.py:85-87): checks every tensor is present, packs the matrices into
+ * MFMA fragment order, folds BatchNorm into (scale, shift), uploads to HBM. */
+int mi355asr_finalize_weights(mi355asr_model* m, void* stream);
+
+/* shape helpers: mel frames F = ceil(L/hop), encoder frames T = ceil(ceil(F/2)/2) per block of L samples */
+int mi355asr_out_frames(const mi355asr_model* m, int32_t L, int32_t* mel_frames, int32_t* enc_frames);
+/* bytes of caller-provided device scratch needed by any forward call on [B, L] */
+int mi355asr_workspace_bytes(const mi355asr_model* m, int32_t B, int32_t L, size_t* bytes);
+/* same for the calls that start from encoder frames (ctc_forward, conformer_block): [B, T, dmodel] */
+int mi355asr_ctc_workspace_bytes(const mi355asr_model* m, int32_t B, int32_t T, size_t* bytes);
+
+/* replaces: encoder(wav, training=False) / encoder.inference(wav)  (conformer_blocks.py:343-378, 574-594);
+ *           ASR::Session::EncoderInference (asr_session.cpp:77-98), ONNX "inputs" -> "Identity:0".
+ * wav_dev f32 [B, L] (the reference's trailing channel dim of 1 dropped) -> enc_out_dev f32 [B, T_total, dmodel]
+ * with T_total = (L/chunk_size)*T(chunk_size) when chunk_size>0 else T(L). */
+int mi355asr_encoder_forward(mi355asr_model* m, const float* wav_dev, int32_t B, int32_t L, float* enc_out_dev,
+                             void* ws_dev, size_t ws_bytes, void* stream);
+
+/* replaces: ctc_model(enc, training=False) (conformer_blocks.py:419-424); ASR::Session::CTCInference
+ * (asr_session.cpp:100-123), ONNX "inputs" [B,T,d] -> "Identity:0" [B,T,V].
+ * logits_dev (f32 [B,T,V]) and frame_argmax_dev (i32 [B,T]) may each be NULL.  The argmax is the one
+ * tf.keras.backend.ctc_decode / ctc_greedy_decoder.h:9-20 take per frame (first maximum wins). */
+int mi355asr_ctc_forward(mi355asr_model* m, const float* enc_dev, int32_t B, int32_t T, float* logits_dev,
+                         int32_t* frame_argmax_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* replaces: tf.keras.backend.ctc_decode(probs, input_length)[0][0] greedy (test_asr.py:196-200) and
+ * ctc_greedy_decoder(probs, blank_id, vocab) (ctc_greedy_decoder.h:5-44): merge repeated, drop blank,
+ * dense output padded with -1.  in_len_dev may be NULL (= T for every utterance). Model-independent. */
+int mi355asr_ctc_greedy(const int32_t* frame_argmax_dev, const int32_t* in_len_dev, int32_t B, int32_t T,
+                        int32_t blank, int32_t* ids_dev, int32_t* out_len_dev, void* stream);
+
+/* encoder + CTCDecoder + greedy in one call: wav [B,L] -> ids i32 [B,T_total] (-1 padded), out_len i32 [B].
+ * This is the timed region of bench.py (offline_stt steps 3-5, test_asr.py:191-198). */
+int mi355asr_recognize(mi355asr_model* m, const float* wav_dev, int32_t B, int32_t L, const int32_t* in_len_dev,
+                       int32_t* ids_dev, int32_t* out_len_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* Stage-level entry points (same kernels the calls above run; exposed so that the parity tests can
+ * localise a mismatch to one reference layer):
+ *   melspectrogram   Melspectrogram.call (time_frequency.py:173-189): wav [B,L] -> mel [B,F,n_mels]
+ *   conv_subsampling ConvSubsampling.call (conformer_blocks.py:90-96): mel [B,F,n_mels] -> [B,T,d]
+ *   conformer_block  ConformerBlock.call (conformer_blocks.py:259-265) of block `index` of the encoder
+ *                    (stack 0) or the CTCDecoder (stack 1): x [B,T,d] -> y [B,T,d] */
+int mi355asr_melspectrogram(mi355asr_model* m, const float* wav_dev, int32_t B, int32_t L, float* mel_dev,
+                            void* ws_dev, size_t ws_bytes, void* stream);
+int mi355asr_conv_subsampling(mi355asr_model* m, const float* mel_dev, int32_t B, int32_t F, float* out_dev,
+                              void* ws_dev, size_t ws_bytes, void* stream);
+int mi355asr_conformer_block(mi355asr_model* m, int32_t stack, int32_t index, const float* x_dev, int32_t B,
+                             int32_t T, float* y_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355ASR_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of libmi355asr.so (include/mi355asr.h).  There is no fallback: if the HIP library is
+missing or a call fails, this module raises -- the product path never computes on the CPU."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355asr.so")
+
+
+class Config(ctypes.Structure):
+    """mirror of `mi355asr_config` (include/mi355asr.h)."""
+    _fields_ = [
+        ("dmodel", ctypes.c_int32), ("num_blocks", ctypes.c_int32), ("head_size", ctypes.c_int32),
+        ("num_heads", ctypes.c_int32), ("kernel_size", ctypes.c_int32), ("fc_factor", ctypes.c_float),
+        ("reduction_factor", ctypes.c_int32), ("n_mels", ctypes.c_int32), ("sample_rate", ctypes.c_int32),
+        ("stride_ms", ctypes.c_int32), ("n_dft", ctypes.c_int32), ("chunk_size", ctypes.c_int32),
+        ("has_encoder", ctypes.c_int32), ("num_classes", ctypes.c_int32), ("ctc_num_blocks", ctypes.c_int32),
+        ("ctc_kernel_size", ctypes.c_int32), ("ctc_fc_factor", ctypes.c_float),
+    ]
+
+
+class Mi355AsrError(RuntimeError):
+    pass
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int32
+_SZ = ctypes.c_size_t
+
+# name -> (restype, argtypes): every symbol include/mi355asr.h declares
+SIGNATURES = {
+    "mi355asr_last_error": (ctypes.c_char_p, []),
+    "mi355asr_version": (ctypes.c_char_p, []),
+    "mi355asr_create": (ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(_P)]),
+    "mi355asr_destroy": (ctypes.c_int, [_P]),
+    "mi355asr_load_weight": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _I, ctypes.POINTER(ctypes.c_int64)]),
+    "mi355asr_num_weights": (ctypes.c_int, [_P]),
+    "mi355asr_weight_name": (ctypes.c_char_p, [_P, _I]),
+    "mi355asr_finalize_weights": (ctypes.c_int, [_P, _P]),
+    "mi355asr_out_frames": (ctypes.c_int, [_P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "mi355asr_workspace_bytes": (ctypes.c_int, [_P, _I, _I, ctypes.POINTER(_SZ)]),
+    "mi355asr_ctc_workspace_bytes": (ctypes.c_int, [_P, _I, _I, ctypes.POINTER(_SZ)]),
+    "mi355asr_encoder_forward": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "mi355asr_ctc_forward": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
+    "mi355asr_ctc_greedy": (ctypes.c_int, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "mi355asr_recognize": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "mi355asr_melspectrogram": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "mi355asr_conv_subsampling": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "mi355asr_conformer_block": (ctypes.c_int, [_P, _I, _I, _P, _I, _I, _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libmi355asr.so once.  Raises if it has not been built (python -m tensorflowasr_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mi355AsrError(
+                "libmi355asr.so not found at %s -- build it with `python -m tensorflowasr_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise Mi355AsrError("mi355asr error %d: %s" % (rc, lib().mi355asr_last_error().decode()))

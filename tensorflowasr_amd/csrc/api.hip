@@ -1,0 +1,777 @@
+// libmi355asr.so host side: model object, Keras-layout weight intake + packing into MFMA fragment order,
+// workspace planning and the launch sequences behind the C ABI declared in include/mi355asr.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355asr.h"
+#include "launch.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess) return fail(MI355ASR_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+#define LAUNCH_TRY(expr, what)                                                             \
+  do {                                                                                     \
+    if ((expr) != 0) return fail(MI355ASR_EINVAL, "no kernel instantiation for %s", what); \
+    hipError_t e__ = hipGetLastError();                                                    \
+    if (e__ != hipSuccess) return fail(MI355ASR_EHIP, "launch %s: %s", what, hipGetErrorString(e__)); \
+  } while (0)
+
+constexpr float kLnEps = 1e-3f;  // Keras LayerNormalization default
+constexpr float kBnEps = 1e-3f;  // Keras BatchNormalization default
+
+struct HostTensor {
+  std::vector<float> data;
+  bool set = false;
+};
+struct Expected {
+  std::string name;
+  std::vector<int64_t> dims;  // Keras layout
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto d : dims) n *= d;
+    return n;
+  }
+};
+
+struct BlockDev {
+  // ff_module_1 / ff_module_2
+  const float *ff_ln_g[2], *ff_ln_b[2], *ff_w1p[2], *ff_b1[2], *ff_w2p[2], *ff_b2[2];
+  // mhsa_module
+  const float *att_ln_g, *att_ln_b, *qkv_wp, *qkv_b, *out_wp, *out_b;
+  // conv_module
+  const float *cv_ln_g, *cv_ln_b, *pw1_wp, *pw1_b, *dw_w, *pc_w1p, *pc_b1, *bn_s, *bn_t, *pw2_wp, *pw2_b;
+  // block-final LayerNorm
+  const float *ln_g, *ln_b;
+};
+
+struct Dims {
+  int hop, nbins, NT_dft, NCH_dft, LP, KBm, NTm, F1, F2, st1, pf1, pf2;
+};
+
+}  // namespace
+
+struct mi355asr_model {
+  mi355asr_config cfg;
+  Dims dm;
+  std::vector<Expected> expected;
+  std::map<std::string, HostTensor> host;
+  bool finalized = false;
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  const float *dft_wp = nullptr, *mel_wp = nullptr, *c1_w = nullptr, *c1_b = nullptr, *c2_wp = nullptr,
+              *c2_b = nullptr, *lin_wp = nullptr, *lin_b = nullptr, *proj_wp = nullptr, *proj_b = nullptr,
+              *fc_wp = nullptr, *fc_b = nullptr;
+  int NT_fc = 0;
+  std::vector<BlockDev> enc_blocks, ctc_blocks;
+};
+
+namespace {
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+void same_pad(int n, int k, int s, int* out, int* before) {
+  const int o = ceil_div(n, s);
+  const int tot = std::max((o - 1) * s + k - n, 0);
+  *out = o;
+  *before = tot / 2;
+}
+
+void add_block_expected(std::vector<Expected>& ex, const std::string& p, int d, int H, int hs, int k) {
+  auto ln = [&](const std::string& q) {
+    ex.push_back({q + "/gamma", {d}});
+    ex.push_back({q + "/beta", {d}});
+  };
+  for (const char* ff : {"ff_module_1", "ff_module_2"}) {
+    const std::string q = p + "/" + ff;
+    ln(q + "/ln");
+    ex.push_back({q + "/ffn1/kernel", {d, 4 * d}});
+    ex.push_back({q + "/ffn1/bias", {4 * d}});
+    ex.push_back({q + "/ffn2/kernel", {4 * d, d}});
+    ex.push_back({q + "/ffn2/bias", {d}});
+  }
+  const std::string m = p + "/mhsa_module";
+  ln(m + "/ln");
+  ex.push_back({m + "/mha/query_kernel", {H, d, hs}});
+  ex.push_back({m + "/mha/key_kernel", {H, d, hs}});
+  ex.push_back({m + "/mha/value_kernel", {H, d, hs}});
+  ex.push_back({m + "/mha/projection_kernel", {H, hs, d}});
+  ex.push_back({m + "/mha/projection_bias", {d}});
+  const std::string c = p + "/conv_module";
+  ln(c + "/ln");
+  ex.push_back({c + "/pw_conv_1/kernel", {1, d, 2 * d}});
+  ex.push_back({c + "/pw_conv_1/bias", {2 * d}});
+  ex.push_back({c + "/dw_conv/depthwise_kernel", {k, d, 1}});
+  ex.push_back({c + "/dw_conv/pointwise_kernel", {1, d, 2 * d}});
+  ex.push_back({c + "/dw_conv/bias", {2 * d}});
+  ex.push_back({c + "/bn/gamma", {2 * d}});
+  ex.push_back({c + "/bn/beta", {2 * d}});
+  ex.push_back({c + "/bn/moving_mean", {2 * d}});
+  ex.push_back({c + "/bn/moving_variance", {2 * d}});
+  ex.push_back({c + "/pw_conv_2/kernel", {1, 2 * d, d}});
+  ex.push_back({c + "/pw_conv_2/bias", {d}});
+  ln(p + "/ln");
+}
+
+// W[k][n] (k < K, n < N) -> P16 fragment order [ceil(K/16)][NTpad][64 lanes][4]
+std::vector<float> pack_p16(const std::function<float(int, int)>& f, int K, int N, int NTpad) {
+  const int KBT = ceil_div(K, 16);
+  std::vector<float> out((size_t)KBT * NTpad * 256, 0.f);
+  for (int kb = 0; kb < KBT; ++kb)
+    for (int nt = 0; nt < NTpad; ++nt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, c = lane & 15;
+        for (int j = 0; j < 4; ++j) {
+          const int k = 16 * kb + 4 * g + j, n = 16 * nt + c;
+          if (k < K && n < N) out[(((size_t)kb * NTpad + nt) * 64 + lane) * 4 + j] = f(k, n);
+        }
+      }
+  return out;
+}
+
+struct ArenaBuilder {
+  std::vector<float> buf;
+  size_t put(const std::vector<float>& v) {
+    size_t off = (buf.size() + 63) & ~(size_t)63;  // 256-byte alignment
+    buf.resize(off + v.size());
+    std::memcpy(buf.data() + off, v.data(), v.size() * sizeof(float));
+    return off;
+  }
+  size_t put_padded(const float* p, size_t n, size_t padded) {
+    std::vector<float> v(padded, 0.f);
+    std::memcpy(v.data(), p, n * sizeof(float));
+    return put(v);
+  }
+};
+
+struct BlockOff {
+  size_t ff_ln_g[2], ff_ln_b[2], ff_w1p[2], ff_b1[2], ff_w2p[2], ff_b2[2];
+  size_t att_ln_g, att_ln_b, qkv_wp, qkv_b, out_wp, out_b;
+  size_t cv_ln_g, cv_ln_b, pw1_wp, pw1_b, dw_w, pc_w1p, pc_b1, bn_s, bn_t, pw2_wp, pw2_b;
+  size_t ln_g, ln_b;
+};
+
+BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k) {
+  auto T = [&](const std::string& n) -> const std::vector<float>& { return m->host[n].data; };
+  BlockOff o;
+  const char* ffn[2] = {"ff_module_1", "ff_module_2"};
+  for (int i = 0; i < 2; ++i) {
+    const std::string q = p + "/" + ffn[i];
+    o.ff_ln_g[i] = ab.put(T(q + "/ln/gamma"));
+    o.ff_ln_b[i] = ab.put(T(q + "/ln/beta"));
+    const auto& w1 = T(q + "/ffn1/kernel");
+    const auto& w2 = T(q + "/ffn2/kernel");
+    o.ff_w1p[i] = ab.put(pack_p16([&](int kk, int n) { return w1[(size_t)kk * 4 * d + n]; }, d, 4 * d, 4 * d / 16));
+    o.ff_b1[i] = ab.put(T(q + "/ffn1/bias"));
+    o.ff_w2p[i] = ab.put(pack_p16([&](int kk, int n) { return w2[(size_t)kk * d + n]; }, 4 * d, d, d / 16));
+    o.ff_b2[i] = ab.put(T(q + "/ffn2/bias"));
+  }
+  const std::string a = p + "/mhsa_module";
+  o.att_ln_g = ab.put(T(a + "/ln/gamma"));
+  o.att_ln_b = ab.put(T(a + "/ln/beta"));
+  const auto& qk = T(a + "/mha/query_kernel");
+  const auto& kk_ = T(a + "/mha/key_kernel");
+  const auto& vk = T(a + "/mha/value_kernel");
+  // einsum "BNI,HIO->BNHO": column n = which*d + h*hs + o  <-  kernel[h][i][o]
+  o.qkv_wp = ab.put(pack_p16(
+      [&](int i, int n) {
+        const int which = n / d, r = n % d, h = r / hs, oo = r % hs;
+        const std::vector<float>& w = which == 0 ? qk : (which == 1 ? kk_ : vk);
+        return w[((size_t)h * d + i) * hs + oo];
+      },
+      d, 3 * d, 3 * d / 16));
+  o.qkv_b = ab.put(std::vector<float>(3 * d, 0.f));
+  const auto& pk = T(a + "/mha/projection_kernel");  // [H, hs, d]: row k = h*hs + i
+  o.out_wp = ab.put(pack_p16([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d, d / 16));
+  o.out_b = ab.put(T(a + "/mha/projection_bias"));
+  const std::string c = p + "/conv_module";
+  o.cv_ln_g = ab.put(T(c + "/ln/gamma"));
+  o.cv_ln_b = ab.put(T(c + "/ln/beta"));
+  const auto& pw1 = T(c + "/pw_conv_1/kernel");
+  o.pw1_wp = ab.put(pack_p16([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d, 2 * d / 16));
+  o.pw1_b = ab.put(T(c + "/pw_conv_1/bias"));
+  o.dw_w = ab.put(T(c + "/dw_conv/depthwise_kernel"));  // [k, d, 1] == [k][d]
+  const auto& pc = T(c + "/dw_conv/pointwise_kernel");
+  o.pc_w1p = ab.put(pack_p16([&](int kk, int n) { return pc[(size_t)kk * 2 * d + n]; }, d, 2 * d, 2 * d / 16));
+  o.pc_b1 = ab.put(T(c + "/dw_conv/bias"));
+  {
+    const auto &g = T(c + "/bn/gamma"), &b = T(c + "/bn/beta"), &mu = T(c + "/bn/moving_mean"),
+               &var = T(c + "/bn/moving_variance");
+    std::vector<float> s(2 * d), t(2 * d);
+    for (int i = 0; i < 2 * d; ++i) {
+      s[i] = g[i] / std::sqrt(var[i] + kBnEps);
+      t[i] = b[i] - mu[i] * s[i];
+    }
+    o.bn_s = ab.put(s);
+    o.bn_t = ab.put(t);
+  }
+  const auto& pw2 = T(c + "/pw_conv_2/kernel");
+  o.pw2_wp = ab.put(pack_p16([&](int kk, int n) { return pw2[(size_t)kk * d + n]; }, 2 * d, d, d / 16));
+  o.pw2_b = ab.put(T(c + "/pw_conv_2/bias"));
+  o.ln_g = ab.put(T(p + "/ln/gamma"));
+  o.ln_b = ab.put(T(p + "/ln/beta"));
+  (void)H;
+  (void)k;
+  return o;
+}
+
+BlockDev resolve(const BlockOff& o, const float* base) {
+  BlockDev b;
+  for (int i = 0; i < 2; ++i) {
+    b.ff_ln_g[i] = base + o.ff_ln_g[i];
+    b.ff_ln_b[i] = base + o.ff_ln_b[i];
+    b.ff_w1p[i] = base + o.ff_w1p[i];
+    b.ff_b1[i] = base + o.ff_b1[i];
+    b.ff_w2p[i] = base + o.ff_w2p[i];
+    b.ff_b2[i] = base + o.ff_b2[i];
+  }
+  b.att_ln_g = base + o.att_ln_g; b.att_ln_b = base + o.att_ln_b;
+  b.qkv_wp = base + o.qkv_wp; b.qkv_b = base + o.qkv_b;
+  b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
+  b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
+  b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
+  b.dw_w = base + o.dw_w;
+  b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
+  b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
+  b.pw2_wp = base + o.pw2_wp; b.pw2_b = base + o.pw2_b;
+  b.ln_g = base + o.ln_g; b.ln_b = base + o.ln_b;
+  return b;
+}
+
+// ---- workspace plan (byte offsets, 256-byte aligned) --------------------------------------------------
+struct Plan {
+  size_t xa, xb, qkv, ctx, u, dw, enc, amax, logp, pmax, umax, mel, sub, total;
+};
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Bp = number of independent encoder inputs (utterances, or utterances x blocks when streaming),
+// F mel frames and T encoder frames per input.
+Plan make_plan(const mi355asr_model* m, int Bp, int F, int T) {
+  const int d = m->cfg.dmodel;
+  const size_t M = (size_t)Bp * T;
+  Plan p;
+  size_t o = 0;
+  auto take = [&](size_t floats) {
+    size_t at = o;
+    o = align256(o + floats * 4);
+    return at;
+  };
+  p.xa = take(M * d);
+  p.xb = take(M * d);
+  p.qkv = take(M * 3 * d);
+  p.ctx = take(M * d);
+  p.u = take(M * d);
+  p.dw = take(M * d);
+  p.enc = take(M * d);
+  p.amax = take(M);
+  const int FT = ceil_div(F, 16);
+  p.logp = take((size_t)Bp * F * m->dm.LP);
+  p.pmax = take((size_t)Bp * FT * m->dm.NCH_dft);
+  p.umax = take(Bp);
+  p.mel = take((size_t)Bp * F * m->cfg.n_mels);
+  p.sub = take(M * m->dm.F2 * d);
+  p.total = o;
+  return p;
+}
+
+struct Geometry {
+  int Bp, Lb, F, T1, T, nblk;
+};
+
+int geometry(const mi355asr_model* m, int B, int L, Geometry* g) {
+  const auto& c = m->cfg;
+  if (B <= 0 || L <= 0) return fail(MI355ASR_EINVAL, "B and L must be positive (B=%d, L=%d)", B, L);
+  g->nblk = 1;
+  g->Lb = L;
+  if (c.chunk_size > 0) {
+    if (L % c.chunk_size != 0)
+      return fail(MI355ASR_EINVAL, "streaming encoder: L=%d is not a multiple of chunk_size=%d "
+                  "(the reference reshapes [B,L,1]->[-1,chunk,1], conformer_blocks.py:585)", L, c.chunk_size);
+    g->nblk = L / c.chunk_size;
+    g->Lb = c.chunk_size;
+  }
+  g->Bp = B * g->nblk;
+  g->F = ceil_div(g->Lb, m->dm.hop);
+  g->T1 = ceil_div(g->F, m->dm.st1);
+  g->T = ceil_div(g->T1, 2);
+  return 0;
+}
+
+// ---- launch sequences ---------------------------------------------------------------------------------
+struct Scratch {
+  float *xa, *xb, *qkv, *ctx, *u, *dw;
+};
+
+// One ConformerBlock (conformer_blocks.py:259-265).  Input in sc.xa, output to `out` (or sc.xa if null).
+int run_block(const mi355asr_model* m, const BlockDev& w, int ksz, float fc, const Scratch& sc, int B, int T,
+              float* out, hipStream_t s) {
+  const int d = m->cfg.dmodel, H = m->cfg.num_heads, hs = m->cfg.head_size;
+  const int M = B * T;
+  // ff_module_1: xb = xa + fc * FFN(LN(xa))
+  Chain2Args f1{};
+  f1.x = sc.xa; f1.res = sc.xa; f1.y = sc.xb;
+  f1.ln_g = w.ff_ln_g[0]; f1.ln_b = w.ff_ln_b[0];
+  f1.w1p = w.ff_w1p[0]; f1.b1 = w.ff_b1[0]; f1.w2p = w.ff_w2p[0]; f1.b2 = w.ff_b2[0];
+  f1.scale = fc; f1.eps = kLnEps; f1.M = M;
+  LAUNCH_TRY(launch_chain2(d, 0, f1, s), "ff_module_1");
+  // mhsa: qkv = LN(xb) Wqkv (q pre-scaled)
+  GemmArgs q{};
+  q.x = sc.xb; q.y = sc.qkv; q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.wp = w.qkv_wp; q.bias = w.qkv_b;
+  q.M = M; q.NT = 3 * d / 16; q.ldy = 3 * d; q.n_valid = 3 * d; q.eps = kLnEps;
+  q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
+  LAUNCH_TRY(launch_gemm_rows(d, EPI_QKV, true, q, s), "qkv projection");
+  AttnArgs at{};
+  at.qkv = sc.qkv; at.ctx = sc.ctx; at.B = B; at.T = T; at.H = H; at.D = d; at.ld = 3 * d;
+  LAUNCH_TRY(launch_attention(hs, at, s), "attention");
+  // xa = xb + ctx Wo + bo
+  GemmArgs op{};
+  op.x = sc.ctx; op.y = sc.xa; op.res = sc.xb; op.wp = w.out_wp; op.bias = w.out_b;
+  op.M = M; op.NT = d / 16; op.ldy = d; op.n_valid = d; op.eps = kLnEps;
+  LAUNCH_TRY(launch_gemm_rows(d, EPI_RESIDUAL, false, op, s), "attention out-projection");
+  // conv module: u = GLU(LN(xa) Wpw1 + b)
+  GemmArgs g{};
+  g.x = sc.xa; g.y = sc.u; g.ln_g = w.cv_ln_g; g.ln_b = w.cv_ln_b; g.wp = w.pw1_wp; g.bias = w.pw1_b;
+  g.M = M; g.NT = 2 * d / 16; g.ldy = d; g.n_valid = d; g.eps = kLnEps;
+  LAUNCH_TRY(launch_gemm_rows(d, EPI_GLU, true, g, s), "pw_conv_1 + GLU");
+  DwArgs dwa{};
+  dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
+  dwa.pad_left = (ksz - 1) / 2;  // Keras 'same', stride 1: total k-1, before = (k-1)//2
+  LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv");
+  // xb = xa + pw2( swish( BN( dw Wpc + bpc ) ) ) + b2
+  Chain2Args cv{};
+  cv.x = sc.dw; cv.res = sc.xa; cv.y = sc.xb;
+  cv.w1p = w.pc_w1p; cv.b1 = w.pc_b1; cv.aff_s = w.bn_s; cv.aff_t = w.bn_t; cv.w2p = w.pw2_wp; cv.b2 = w.pw2_b;
+  cv.scale = 1.0f; cv.eps = kLnEps; cv.M = M;
+  LAUNCH_TRY(launch_chain2(d, 1, cv, s), "conv module tail");
+  // ff_module_2 + block LayerNorm
+  Chain2Args f2{};
+  f2.x = sc.xb; f2.res = sc.xb; f2.y = out ? out : sc.xa;
+  f2.ln_g = w.ff_ln_g[1]; f2.ln_b = w.ff_ln_b[1];
+  f2.w1p = w.ff_w1p[1]; f2.b1 = w.ff_b1[1]; f2.w2p = w.ff_w2p[1]; f2.b2 = w.ff_b2[1];
+  f2.fln_g = w.ln_g; f2.fln_b = w.ln_b;
+  f2.scale = fc; f2.eps = kLnEps; f2.M = M;
+  LAUNCH_TRY(launch_chain2(d, 0, f2, s), "ff_module_2 + LayerNorm");
+  return 0;
+}
+
+int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, float* logp, float* pmax,
+            float* umax, float* mel, hipStream_t s) {
+  const auto& c = m->cfg;
+  const int FT = ceil_div(F, 16);
+  int out, before;
+  same_pad(Lb, c.n_dft, m->dm.hop, &out, &before);
+  StftArgs st{};
+  st.wav = wav; st.logp = logp; st.pmax = pmax; st.wp = m->dft_wp;
+  st.B = Bp; st.L = Lb; st.F = F; st.hop = m->dm.hop; st.pad_left = before; st.n_dft = c.n_dft;
+  st.NT = m->dm.NT_dft; st.LP = m->dm.LP; st.nbins = m->dm.nbins; st.FT = FT; st.NCH = m->dm.NCH_dft;
+  st.db10 = 1;
+  LAUNCH_TRY(launch_stft(st, s), "stft");
+  UttMaxArgs um{pmax, umax, FT * m->dm.NCH_dft};
+  LAUNCH_TRY(launch_utt_max(um, Bp, s), "utterance max");
+  MelArgs me{};
+  me.logp = logp; me.umax = umax; me.mel = mel; me.wp = m->mel_wp;
+  me.B = Bp; me.F = F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
+  me.NM = c.n_mels; me.FT = FT; me.floor_db = -80.0f;
+  LAUNCH_TRY(launch_mel(me, s), "dB + mel");
+  return 0;
+}
+
+int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, float* sub, float* out,
+                    hipStream_t s) {
+  const auto& c = m->cfg;
+  const int d = c.dmodel;
+  int T1, pt1, T2, pt2;
+  same_pad(F, 3, m->dm.st1, &T1, &pt1);
+  same_pad(T1, 3, 2, &T2, &pt2);
+  SubConvArgs sa{};
+  sa.mel = mel; sa.out = sub; sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
+  sa.B = Bp; sa.F = F; sa.NM = c.n_mels; sa.T1 = T1; sa.F1 = m->dm.F1; sa.T2 = T2; sa.F2 = m->dm.F2;
+  sa.st1 = m->dm.st1; sa.pt1 = pt1; sa.pf1 = m->dm.pf1; sa.pt2 = pt2; sa.pf2 = m->dm.pf2;
+  LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling");
+  StreamGemmArgs lg{};
+  lg.x = sub; lg.y = out; lg.wp = m->lin_wp; lg.bias = m->lin_b;
+  lg.M = Bp * T2; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.ldy = d; lg.n_valid = d;
+  LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear");
+  return 0;
+}
+
+int check_ready(const mi355asr_model* m, bool need_encoder = false) {
+  if (!m) return fail(MI355ASR_EINVAL, "null model handle");
+  if (!m->finalized) return fail(MI355ASR_ESTATE, "weights not finalised: call mi355asr_finalize_weights first");
+  if (need_encoder && !m->cfg.has_encoder) return fail(MI355ASR_ESTATE, "model was created without an encoder (has_encoder=0)");
+  return 0;
+}
+
+int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const Plan& p, char* ws, float* enc_out,
+                 hipStream_t s) {
+  float* logp = (float*)(ws + p.logp);
+  float* mel = (float*)(ws + p.mel);
+  int rc = run_mel(m, wav, g.Bp, g.Lb, g.F, logp, (float*)(ws + p.pmax), (float*)(ws + p.umax), mel, s);
+  if (rc) return rc;
+  Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
+             (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
+  rc = run_subsampling(m, mel, g.Bp, g.F, (float*)(ws + p.sub), sc.xa, s);
+  if (rc) return rc;
+  const int nb = m->cfg.num_blocks;
+  for (int i = 0; i < nb; ++i) {
+    rc = run_block(m, m->enc_blocks[i], m->cfg.kernel_size, m->cfg.fc_factor, sc, g.Bp, g.T,
+                   i == nb - 1 ? enc_out : nullptr, s);
+    if (rc) return rc;
+  }
+  if (nb == 0) HIP_TRY(hipMemcpyAsync(enc_out, sc.xa, (size_t)g.Bp * g.T * m->cfg.dmodel * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, char* ws, float* logits,
+             int32_t* amax, hipStream_t s) {
+  const int d = m->cfg.dmodel;
+  const int M = B * T;
+  Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
+             (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
+  GemmArgs pr{};
+  pr.x = enc; pr.y = sc.xa; pr.wp = m->proj_wp; pr.bias = m->proj_b;
+  pr.M = M; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
+  LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "ctc project");
+  for (int i = 0; i < m->cfg.ctc_num_blocks; ++i) {
+    int rc = run_block(m, m->ctc_blocks[i], m->cfg.ctc_kernel_size, m->cfg.ctc_fc_factor, sc, B, T, nullptr, s);
+    if (rc) return rc;
+  }
+  GemmArgs hd{};
+  hd.x = sc.xa; hd.y = logits; hd.wp = m->fc_wp; hd.bias = m->fc_b;
+  hd.M = M; hd.NT = m->NT_fc; hd.ldy = m->cfg.num_classes; hd.n_valid = m->cfg.num_classes; hd.eps = kLnEps;
+  hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
+  LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "ctc head");
+  return 0;
+}
+
+}  // namespace
+
+// =======================================================================================================
+// C ABI
+// =======================================================================================================
+extern "C" {
+
+const char* mi355asr_last_error(void) { return g_err; }
+const char* mi355asr_version(void) { return "mi355asr 0.1 (gfx950, fp32 MFMA)"; }
+
+int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
+  if (!cfg || !out) return fail(MI355ASR_EINVAL, "null argument");
+  const auto& c = *cfg;
+  if (c.dmodel != 144 && c.dmodel != 256)
+    return fail(MI355ASR_EINVAL, "dmodel=%d: kernels are instantiated for 144 (ConformerS) and 256 (ConformerM/StreamingS)", c.dmodel);
+  if (c.num_heads * c.head_size != c.dmodel)
+    return fail(MI355ASR_EINVAL, "num_heads*head_size (%d*%d) must equal dmodel (%d)", c.num_heads, c.head_size, c.dmodel);
+  if (c.head_size != 36 && c.head_size != 64)
+    return fail(MI355ASR_EINVAL, "head_size=%d: attention kernel instantiated for 36 and 64", c.head_size);
+  if (c.kernel_size != 32 && c.kernel_size != 5)
+    return fail(MI355ASR_EINVAL, "kernel_size=%d: depthwise kernel instantiated for 32 and 5", c.kernel_size);
+  if (c.num_classes > 0 && c.ctc_kernel_size != 32 && c.ctc_kernel_size != 5)
+    return fail(MI355ASR_EINVAL, "ctc_kernel_size=%d unsupported", c.ctc_kernel_size);
+  if (c.reduction_factor != 4) return fail(MI355ASR_EINVAL, "reduction_factor=%d: only 4 is supported", c.reduction_factor);
+  if (c.n_dft != 1024) return fail(MI355ASR_EINVAL, "n_dft=%d: the reference hard-codes 1024 (conformer_blocks.py:312)", c.n_dft);
+  if (c.n_mels != 80 && c.n_mels != 128) return fail(MI355ASR_EINVAL, "n_mels=%d: mel kernel instantiated for 80 and 128", c.n_mels);
+  if (c.num_blocks < 0 || c.ctc_num_blocks < 0 || c.chunk_size < 0 || c.num_classes < 0)
+    return fail(MI355ASR_EINVAL, "negative count in config");
+  auto* m = new mi355asr_model();
+  m->cfg = c;
+  Dims& dm = m->dm;
+  dm.hop = c.stride_ms * c.sample_rate / 1000;
+  if (dm.hop <= 0) { delete m; return fail(MI355ASR_EINVAL, "stride_ms*sample_rate/1000 must be positive"); }
+  dm.nbins = c.n_dft / 2 + 1;
+  dm.NT_dft = ceil_div(2 * dm.nbins, 16);          // 65 tiles of (re,im)-interleaved columns
+  dm.NT_dft = ceil_div(dm.NT_dft, 13) * 13;
+  dm.NCH_dft = dm.NT_dft / 13;
+  dm.LP = ceil_div(8 * dm.NT_dft, 16) * 16;        // log-power row stride (bins), 16-byte aligned rows
+  dm.KBm = ceil_div(dm.nbins, 16);
+  dm.NTm = c.n_mels / 16;
+  dm.st1 = c.reduction_factor / 2;
+  same_pad(c.n_mels, 3, 2, &dm.F1, &dm.pf1);
+  same_pad(dm.F1, 3, 2, &dm.F2, &dm.pf2);
+  const int d = c.dmodel;
+  auto& ex = m->expected;
+  if (c.has_encoder) {
+    ex.push_back({"mel_layer/real_kernels", {c.n_dft, 1, 1, dm.nbins}});
+    ex.push_back({"mel_layer/imag_kernels", {c.n_dft, 1, 1, dm.nbins}});
+    ex.push_back({"mel_layer/freq2mel", {dm.nbins, c.n_mels}});
+    ex.push_back({"conv_subsampling/conv1/kernel", {3, 3, 1, d}});
+    ex.push_back({"conv_subsampling/conv1/bias", {d}});
+    ex.push_back({"conv_subsampling/conv2/kernel", {3, 3, d, d}});
+    ex.push_back({"conv_subsampling/conv2/bias", {d}});
+    ex.push_back({"conv_subsampling/linear/kernel", {dm.F2 * d, d}});
+    ex.push_back({"conv_subsampling/linear/bias", {d}});
+    for (int i = 0; i < c.num_blocks; ++i)
+      add_block_expected(ex, "conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size, c.kernel_size);
+  }
+  if (c.num_classes > 0) {
+    ex.push_back({"project/kernel", {d, d}});
+    ex.push_back({"project/bias", {d}});
+    for (int i = 0; i < c.ctc_num_blocks; ++i)
+      add_block_expected(ex, "decoder_conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size,
+                         c.ctc_kernel_size);
+    ex.push_back({"fully_connected/kernel", {d, c.num_classes}});
+    ex.push_back({"fully_connected/bias", {c.num_classes}});
+  }
+  *out = m;
+  return 0;
+}
+
+int mi355asr_destroy(mi355asr_model* m) {
+  if (!m) return 0;
+  if (m->arena) (void)hipFree(m->arena);
+  delete m;
+  return 0;
+}
+
+int mi355asr_num_weights(const mi355asr_model* m) { return m ? (int)m->expected.size() : 0; }
+const char* mi355asr_weight_name(const mi355asr_model* m, int32_t i) {
+  if (!m || i < 0 || i >= (int)m->expected.size()) return nullptr;
+  return m->expected[i].name.c_str();
+}
+
+int mi355asr_load_weight(mi355asr_model* m, const char* name, const float* data, int32_t rank, const int64_t* dims) {
+  if (!m || !name || !data || rank < 0 || (rank > 0 && !dims)) return fail(MI355ASR_EINVAL, "null argument");
+  const Expected* e = nullptr;
+  for (const auto& x : m->expected)
+    if (x.name == name) { e = &x; break; }
+  if (!e) return fail(MI355ASR_EWEIGHT, "unknown weight '%s' for this configuration", name);
+  // compare shapes with singleton axes squeezed (Keras keeps [n_dft,1,1,nb], [1,d,2d], [k,d,1])
+  std::vector<int64_t> got, want;
+  int64_t n = 1;
+  for (int i = 0; i < rank; ++i) { n *= dims[i]; if (dims[i] != 1) got.push_back(dims[i]); }
+  for (auto v : e->dims) if (v != 1) want.push_back(v);
+  if (got != want || n != e->numel()) {
+    std::string gs, ws_;
+    for (int i = 0; i < rank; ++i) gs += (i ? "," : "") + std::to_string(dims[i]);
+    for (size_t i = 0; i < e->dims.size(); ++i) ws_ += (i ? "," : "") + std::to_string(e->dims[i]);
+    return fail(MI355ASR_EWEIGHT, "weight '%s': shape [%s] does not match expected [%s]", name, gs.c_str(), ws_.c_str());
+  }
+  HostTensor& t = m->host[name];
+  t.data.assign(data, data + n);
+  t.set = true;
+  m->finalized = false;
+  return 0;
+}
+
+int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
+  if (!m) return fail(MI355ASR_EINVAL, "null model handle");
+  for (const auto& e : m->expected)
+    if (!m->host.count(e.name) || !m->host[e.name].set) return fail(MI355ASR_EWEIGHT, "missing weight '%s'", e.name.c_str());
+  const auto& c = m->cfg;
+  const Dims& dm = m->dm;
+  const int d = c.dmodel;
+  ArenaBuilder ab;
+  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0;
+  std::vector<BlockOff> eo, co;
+  if (c.has_encoder) {
+  const auto& re = m->host["mel_layer/real_kernels"].data;
+  const auto& im = m->host["mel_layer/imag_kernels"].data;
+  const int nb = dm.nbins;
+  // DFT columns interleaved (re, im) per bin so that power = x^2 + y^2 / z^2 + w^2 inside one lane
+  o_dft = ab.put(pack_p16(
+      [&](int k, int n) { const int bin = n >> 1; return (n & 1) ? im[(size_t)k * nb + bin] : re[(size_t)k * nb + bin]; },
+      c.n_dft, 2 * nb, dm.NT_dft));
+  const auto& f2m = m->host["mel_layer/freq2mel"].data;
+  o_mel = ab.put(pack_p16([&](int k, int n) { return f2m[(size_t)k * c.n_mels + n]; }, nb, c.n_mels, dm.NTm));
+  o_c1w = ab.put(m->host["conv_subsampling/conv1/kernel"].data);  // [3][3][1][d] == [(i*3+j)*d + c]
+  o_c1b = ab.put(m->host["conv_subsampling/conv1/bias"].data);
+  const auto& c2 = m->host["conv_subsampling/conv2/kernel"].data;              // [3][3][d][d]
+  // K order (c-block, kt, kf, 16): k' = (cb*9 + q)*16 + r  <->  (q = kt*3+kf, c = 16*cb + r)
+  o_c2w = ab.put(pack_p16(
+      [&](int kp, int n) {
+        const int kb = kp / 16, r = kp % 16, cb = kb / 9, q = kb % 9;
+        return c2[((size_t)q * d + (16 * cb + r)) * d + n];
+      },
+      9 * d, d, d / 16));
+  o_c2b = ab.put(m->host["conv_subsampling/conv2/bias"].data);
+  const auto& lin = m->host["conv_subsampling/linear/kernel"].data;
+  o_lw = ab.put(pack_p16([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d, d / 16));
+  o_lb = ab.put(m->host["conv_subsampling/linear/bias"].data);
+  for (int i = 0; i < c.num_blocks; ++i)
+    eo.push_back(pack_block(m, ab, "conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size, c.kernel_size));
+  }
+  size_t o_pw = 0, o_pb = 0, o_fw = 0, o_fb = 0;
+  if (c.num_classes > 0) {
+    const auto& pj = m->host["project/kernel"].data;
+    o_pw = ab.put(pack_p16([&](int k, int n) { return pj[(size_t)k * d + n]; }, d, d, d / 16));
+    o_pb = ab.put(m->host["project/bias"].data);
+    for (int i = 0; i < c.ctc_num_blocks; ++i)
+      co.push_back(pack_block(m, ab, "decoder_conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size,
+                              c.ctc_kernel_size));
+    const auto& fc = m->host["fully_connected/kernel"].data;
+    const int V = c.num_classes;
+    const int ct = gemm_ct(d, EPI_HEAD);
+    m->NT_fc = ceil_div(ceil_div(V, 16), ct) * ct;
+    o_fw = ab.put(pack_p16([&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, m->NT_fc));
+    o_fb = ab.put_padded(m->host["fully_connected/bias"].data.data(), V, (size_t)m->NT_fc * 16);
+  }
+  if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }
+  HIP_TRY(hipMalloc((void**)&m->arena, ab.buf.size() * sizeof(float)));
+  m->arena_floats = ab.buf.size();
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(m->arena, ab.buf.data(), ab.buf.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // ab.buf is freed on return
+  const float* base = m->arena;
+  m->dft_wp = base + o_dft; m->mel_wp = base + o_mel;
+  m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
+  m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
+  m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
+  m->enc_blocks.clear();
+  m->ctc_blocks.clear();
+  for (auto& o : eo) m->enc_blocks.push_back(resolve(o, base));
+  for (auto& o : co) m->ctc_blocks.push_back(resolve(o, base));
+  m->finalized = true;
+  return 0;
+}
+
+int mi355asr_out_frames(const mi355asr_model* m, int32_t L, int32_t* mel_frames, int32_t* enc_frames) {
+  if (!m) return fail(MI355ASR_EINVAL, "null model handle");
+  Geometry g;
+  int rc = geometry(m, 1, L, &g);
+  if (rc) return rc;
+  if (mel_frames) *mel_frames = g.F * g.nblk;
+  if (enc_frames) *enc_frames = g.T * g.nblk;
+  return 0;
+}
+
+int mi355asr_workspace_bytes(const mi355asr_model* m, int32_t B, int32_t L, size_t* bytes) {
+  if (!m || !bytes) return fail(MI355ASR_EINVAL, "null argument");
+  Geometry g;
+  int rc = geometry(m, B, L, &g);
+  if (rc) return rc;
+  *bytes = make_plan(m, g.Bp, g.F, g.T).total;
+  return 0;
+}
+
+int mi355asr_ctc_workspace_bytes(const mi355asr_model* m, int32_t B, int32_t T, size_t* bytes) {
+  if (!m || !bytes || B <= 0 || T <= 0) return fail(MI355ASR_EINVAL, "bad argument");
+  *bytes = make_plan(m, B, 16, T).logp;
+  return 0;
+}
+
+int mi355asr_encoder_forward(mi355asr_model* m, const float* wav, int32_t B, int32_t L, float* enc_out, void* ws,
+                             size_t ws_bytes, void* stream) {
+  int rc = check_ready(m, true);
+  if (rc) return rc;
+  if (!wav || !enc_out || !ws) return fail(MI355ASR_EINVAL, "null device pointer");
+  Geometry g;
+  rc = geometry(m, B, L, &g);
+  if (rc) return rc;
+  const Plan p = make_plan(m, g.Bp, g.F, g.T);
+  if (ws_bytes < p.total) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total);
+  return encoder_impl(m, wav, g, p, (char*)ws, enc_out, (hipStream_t)stream);
+}
+
+int mi355asr_ctc_forward(mi355asr_model* m, const float* enc, int32_t B, int32_t T, float* logits, int32_t* amax,
+                         void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_ready(m);
+  if (rc) return rc;
+  if (m->cfg.num_classes <= 0) return fail(MI355ASR_ESTATE, "model was created without a CTC head (num_classes=0)");
+  if (!enc || !ws || B <= 0 || T <= 0) return fail(MI355ASR_EINVAL, "bad argument");
+  const Plan p = make_plan(m, B, 16, T);
+  if (ws_bytes < p.logp) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.logp);
+  return ctc_impl(m, enc, B, T, p, (char*)ws, logits, amax, (hipStream_t)stream);
+}
+
+int mi355asr_ctc_greedy(const int32_t* frame_argmax, const int32_t* in_len, int32_t B, int32_t T, int32_t blank,
+                        int32_t* ids, int32_t* out_len, void* stream) {
+  if (!frame_argmax || !ids || !out_len || B <= 0 || T <= 0) return fail(MI355ASR_EINVAL, "bad argument");
+  CollapseArgs ca{frame_argmax, in_len, ids, out_len, B, T, blank};
+  LAUNCH_TRY(launch_collapse(ca, (hipStream_t)stream), "ctc collapse");
+  return 0;
+}
+
+int mi355asr_recognize(mi355asr_model* m, const float* wav, int32_t B, int32_t L, const int32_t* in_len, int32_t* ids,
+                       int32_t* out_len, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_ready(m, true);
+  if (rc) return rc;
+  if (m->cfg.num_classes <= 0) return fail(MI355ASR_ESTATE, "model was created without a CTC head (num_classes=0)");
+  if (!wav || !ids || !out_len || !ws) return fail(MI355ASR_EINVAL, "null device pointer");
+  Geometry g;
+  rc = geometry(m, B, L, &g);
+  if (rc) return rc;
+  const Plan p = make_plan(m, g.Bp, g.F, g.T);
+  if (ws_bytes < p.total) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total);
+  char* w = (char*)ws;
+  hipStream_t s = (hipStream_t)stream;
+  float* enc = (float*)(w + p.enc);
+  rc = encoder_impl(m, wav, g, p, w, enc, s);
+  if (rc) return rc;
+  const int Ttot = g.T * g.nblk;
+  int32_t* amax = (int32_t*)(w + p.amax);
+  rc = ctc_impl(m, enc, B, Ttot, p, w, nullptr, amax, s);
+  if (rc) return rc;
+  CollapseArgs ca{amax, in_len, ids, out_len, B, Ttot, m->cfg.num_classes - 1};
+  LAUNCH_TRY(launch_collapse(ca, s), "ctc collapse");
+  return 0;
+}
+
+int mi355asr_melspectrogram(mi355asr_model* m, const float* wav, int32_t B, int32_t L, float* mel, void* ws,
+                            size_t ws_bytes, void* stream) {
+  int rc = check_ready(m, true);
+  if (rc) return rc;
+  if (!wav || !mel || !ws) return fail(MI355ASR_EINVAL, "null device pointer");
+  Geometry g;
+  rc = geometry(m, B, L, &g);
+  if (rc) return rc;
+  const Plan p = make_plan(m, g.Bp, g.F, g.T);
+  if (ws_bytes < p.total) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total);
+  char* w = (char*)ws;
+  return run_mel(m, wav, g.Bp, g.Lb, g.F, (float*)(w + p.logp), (float*)(w + p.pmax), (float*)(w + p.umax), mel,
+                 (hipStream_t)stream);
+}
+
+int mi355asr_conv_subsampling(mi355asr_model* m, const float* mel, int32_t B, int32_t F, float* out, void* ws,
+                              size_t ws_bytes, void* stream) {
+  int rc = check_ready(m, true);
+  if (rc) return rc;
+  if (!mel || !out || !ws || B <= 0 || F <= 0) return fail(MI355ASR_EINVAL, "bad argument");
+  const int T = ceil_div(ceil_div(F, m->dm.st1), 2);
+  const Plan p = make_plan(m, B, F, T);
+  if (ws_bytes < p.total) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total);
+  return run_subsampling(m, mel, B, F, (float*)((char*)ws + p.sub), out, (hipStream_t)stream);
+}
+
+int mi355asr_conformer_block(mi355asr_model* m, int32_t stack, int32_t index, const float* x, int32_t B, int32_t T,
+                             float* y, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_ready(m);
+  if (rc) return rc;
+  if (!x || !y || !ws || B <= 0 || T <= 0) return fail(MI355ASR_EINVAL, "bad argument");
+  const auto& blocks = stack == 0 ? m->enc_blocks : m->ctc_blocks;
+  if (stack < 0 || stack > 1 || index < 0 || index >= (int)blocks.size())
+    return fail(MI355ASR_EINVAL, "no block %d in stack %d", index, stack);
+  const Plan p = make_plan(m, B, 16, T);
+  if (ws_bytes < p.logp) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.logp);
+  char* w = (char*)ws;
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc{(float*)(w + p.xa), (float*)(w + p.xb), (float*)(w + p.qkv),
+             (float*)(w + p.ctx), (float*)(w + p.u), (float*)(w + p.dw)};
+  HIP_TRY(hipMemcpyAsync(sc.xa, x, (size_t)B * T * m->cfg.dmodel * 4, hipMemcpyDeviceToDevice, s));
+  return run_block(m, blocks[index], stack == 0 ? m->cfg.kernel_size : m->cfg.ctc_kernel_size,
+                   stack == 0 ? m->cfg.fc_factor : m->cfg.ctc_fc_factor, sc, B, T, y, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,351 @@
+// Frontend + subsampling + decode kernels for gfx950.
+//   stft_kernel      Spectrogram._spectrogram_mono (asr/models/layers/time_frequency.py:100-122) as an
+//                    fp32-MFMA GEMM against the model's own DFT kernels + power + log (backend_keras.py:14)
+//   utt_max_kernel   the per-sample K.max over (frames, freq)                   (backend_keras.py:20)
+//   mel_kernel       (dB - max).clamp(-80) @ freq2mel        (backend_keras.py:20-22, time_frequency.py:181)
+//   subconv_kernel   Conv2D(3x3,s2,SAME)+ReLU -> Conv2D(3x3,s2,SAME)+ReLU fused: conv1 is recomputed on the fly
+//                    as the operand of the conv2 implicit GEMM            (conformer_blocks.py:76-92)
+//   stream_gemm      Dense(F2*d -> d) of ConvSubsampling                   (conformer_blocks.py:87,95)
+//   collapse_kernel  CTC greedy merge-repeated / drop-blank / pad -1       (test_asr.py:196-200,
+//                    Inference/CppInference/onnx/src/core/ctc_greedy_decoder.h:22-43)
+#include "common.h"
+#include "launch.h"
+
+// ---------------------------------------------------------------------------------------------------
+// STFT power -> log.  One wave = 16 frames of one utterance x CT column tiles (8 bins per tile, re/im
+// interleaved so that a lane's float4 accumulator is (re,im,re,im) of two adjacent bins).
+// ---------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(BLOCK_THREADS) void stft_kernel(StftArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, g4 = g * 4, c = lane & 15;
+  const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (wid >= a.B * a.FT) return;
+  const int b = wid / a.FT, ft = wid % a.FT;
+  const int chunk = blockIdx.y;
+  const int c0 = chunk * CT;
+  const int f = ft * 16 + c;
+  const int fc = min(f, a.F - 1);
+  const float* __restrict__ wav = a.wav + (size_t)b * a.L;
+  const int sbase = fc * a.hop - a.pad_left + g4;
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + lane;
+  const int KBT = a.n_dft / 16;
+
+  f32x4 acc[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) acc[i] = splat4(0.f);
+
+  for (int kb = 0; kb < KBT; ++kb) {
+    const int s0 = sbase + 16 * kb;
+    f32x4 x;
+    const float* p = wav + s0;
+    if (s0 >= 0 && s0 + 3 < a.L && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+      x = ldg4(p);
+    } else {
+      x.x = (s0 + 0 >= 0 && s0 + 0 < a.L) ? p[0] : 0.f;
+      x.y = (s0 + 1 >= 0 && s0 + 1 < a.L) ? p[1] : 0.f;
+      x.z = (s0 + 2 >= 0 && s0 + 2 < a.L) ? p[2] : 0.f;
+      x.w = (s0 + 3 >= 0 && s0 + 3 < a.L) ? p[3] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      f32x4 w = wp[(size_t)(kb * a.NT + c0 + i) * 64];
+      acc[i] = mma_kblock(w, x, acc[i]);
+    }
+  }
+
+  float mx = -INFINITY;
+  const bool fvalid = f < a.F;
+  float* orow = a.logp + ((size_t)b * a.F + fc) * a.LP;
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    const int bin0 = 8 * (c0 + i) + 2 * g;
+    const float p0 = acc[i].x * acc[i].x + acc[i].y * acc[i].y;
+    const float p1 = acc[i].z * acc[i].z + acc[i].w * acc[i].w;
+    float l0 = logf(fmaxf(p0, 1e-10f));
+    float l1 = logf(fmaxf(p1, 1e-10f));
+    if (a.db10) { l0 = 10.0f * l0 / 2.30258509f; l1 = 10.0f * l1 / 2.30258509f; }
+    else { l0 = l0 / 2.30258509f; l1 = l1 / 2.30258509f; }
+    if (fvalid) {
+      f32x2 o = {l0, l1};
+      *reinterpret_cast<f32x2*>(orow + bin0) = o;
+      if (bin0 < a.nbins) mx = fmaxf(mx, l0);
+      if (bin0 + 1 < a.nbins) mx = fmaxf(mx, l1);
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (lane == 0) a.pmax[(size_t)b * a.FT * a.NCH + ft * a.NCH + chunk] = mx;
+}
+
+int launch_stft(const StftArgs& a, hipStream_t s) {
+  constexpr int CT = 13;
+  if (a.NT % CT != 0 || a.NCH != a.NT / CT) return -1;
+  dim3 grid((a.B * a.FT + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.NCH);
+  hipLaunchKernelGGL((stft_kernel<CT>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  return 0;
+}
+
+__global__ void utt_max_kernel(UttMaxArgs a) {
+  const int b = blockIdx.x;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < a.n; i += 64) mx = fmaxf(mx, a.pmax[(size_t)b * a.n + i]);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (threadIdx.x == 0) a.umax[b] = mx;
+}
+
+int launch_utt_max(const UttMaxArgs& a, int B, hipStream_t s) {
+  hipLaunchKernelGGL(utt_max_kernel, dim3(B), dim3(64), 0, s, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dB normalisation + mel projection.  One wave = 16 frames x all mel tiles.
+// ---------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(BLOCK_THREADS) void mel_kernel(MelArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int g4 = (lane >> 4) * 4, c = lane & 15;
+  const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (wid >= a.B * a.FT) return;
+  const int b = wid / a.FT, ft = wid % a.FT;
+  const int f = ft * 16 + c;
+  const int fc = min(f, a.F - 1);
+  const float* __restrict__ row = a.logp + ((size_t)b * a.F + fc) * a.LP;
+  const bool norm = a.umax != nullptr;
+  const float um = norm ? a.umax[b] : 0.f;
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + lane;
+  f32x4 acc[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) acc[i] = splat4(0.f);
+  for (int kb = 0; kb < a.KBm; ++kb) {
+    const int k = 16 * kb + g4;
+    f32x4 x = (k < a.LP) ? ldg4(row + k) : splat4(0.f);
+    if (norm) {
+      x.x = fmaxf(x.x - um, a.floor_db);
+      x.y = fmaxf(x.y - um, a.floor_db);
+      x.z = fmaxf(x.z - um, a.floor_db);
+      x.w = fmaxf(x.w - um, a.floor_db);
+    }
+    x.x = (k + 0 < a.nbins) ? x.x : 0.f;
+    x.y = (k + 1 < a.nbins) ? x.y : 0.f;
+    x.z = (k + 2 < a.nbins) ? x.z : 0.f;
+    x.w = (k + 3 < a.nbins) ? x.w : 0.f;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      f32x4 w = wp[(size_t)(kb * a.NTm + i) * 64];
+      acc[i] = mma_kblock(w, x, acc[i]);
+    }
+  }
+  if (f < a.F) {
+    float* orow = a.mel + ((size_t)b * a.F + f) * a.NM;
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+      if (16 * i + g4 + 3 < a.NM) stg4(orow + 16 * i + g4, acc[i]);
+  }
+}
+
+int launch_mel(const MelArgs& a, hipStream_t s) {
+  dim3 grid((a.B * a.FT + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+  if (a.NTm == 5) hipLaunchKernelGGL((mel_kernel<5>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  else if (a.NTm == 8) hipLaunchKernelGGL((mel_kernel<8>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  else return -1;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused ConvSubsampling convs.  Implicit GEMM over K = 9*D with rows = output positions (b, t2, f2).
+// The conv2 operand A[(b,t2,f2)][(kt,kf,c)] = relu(conv1)[b, 2*t2+kt-pt2, 2*f2+kf-pf2, c] is evaluated in
+// registers from a 7x7 mel window (49 values per position) -- the [B,T1,F1,D] conv1 activation
+// (737 MB at B=64) is never materialised.  K is ordered (c-block, kt, kf) so one set of conv1 weights
+// (9 float4 + bias) serves nine k-blocks.
+// ---------------------------------------------------------------------------------------------------
+template <int D, int RT>
+__global__ __launch_bounds__(BLOCK_THREADS) void subconv_kernel(SubConvArgs a) {
+  constexpr int KB = D / 16;
+  const int lane = threadIdx.x & 63;
+  const int g4 = (lane >> 4) * 4, c = lane & 15;
+  const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int P = a.B * a.T2 * a.F2;
+  if ((size_t)wid * RT * 16 >= (size_t)P) return;
+
+  int pos[RT];
+  float win[RT][7][7];
+  bool tv[RT][3], fv[RT][3];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    pos[rt] = (wid * RT + rt) * 16 + c;
+    const int p = min(pos[rt], P - 1);
+    const int b = p / (a.T2 * a.F2);
+    const int r = p % (a.T2 * a.F2);
+    const int t2 = r / a.F2, f2 = r % a.F2;
+    const int tm0 = 4 * t2 - 2 * a.pt2 - a.pt1;
+    const int fm0 = 4 * f2 - 2 * a.pf2 - a.pf1;
+    const float* __restrict__ mb = a.mel + (size_t)b * a.F * a.NM;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int tm = tm0 + i;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int fm = fm0 + j;
+        win[rt][i][j] = (tm >= 0 && tm < a.F && fm >= 0 && fm < a.NM) ? mb[(size_t)tm * a.NM + fm] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int t1 = 2 * t2 + k - a.pt2;
+      const int f1 = 2 * f2 + k - a.pf2;
+      tv[rt][k] = (t1 >= 0 && t1 < a.T1);
+      fv[rt][k] = (f1 >= 0 && f1 < a.F1);
+    }
+  }
+
+  f32x4 acc[RT][KB];
+#pragma unroll
+  for (int n = 0; n < KB; ++n) {
+    f32x4 bb = ldg4(a.b2 + 16 * n + g4);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt][n] = bb;
+  }
+  const f32x4* __restrict__ w2 = reinterpret_cast<const f32x4*>(a.w2p) + lane;
+
+#pragma unroll 1
+  for (int cb = 0; cb < KB; ++cb) {
+    f32x4 w1v[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w1v[i][j] = ldg4(a.w1 + (size_t)(i * 3 + j) * D + 16 * cb + g4);
+    const f32x4 b1v = ldg4(a.b1 + 16 * cb + g4);
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+      for (int kf = 0; kf < 3; ++kf) {
+        f32x4 xf[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          f32x4 v = b1v;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v += splat4(win[rt][2 * kt + i][2 * kf + j]) * w1v[i][j];
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          xf[rt] = (tv[rt][kt] && fv[rt][kf]) ? v : splat4(0.f);
+        }
+        const int kbp = cb * 9 + kt * 3 + kf;
+#pragma unroll
+        for (int n = 0; n < KB; ++n) {
+          f32x4 w = w2[(size_t)(kbp * KB + n) * 64];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[rt][n] = mma_kblock(w, xf[rt], acc[rt][n]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    if (pos[rt] < P) {
+      float* orow = a.out + (size_t)pos[rt] * D;
+#pragma unroll
+      for (int n = 0; n < KB; ++n) {
+        f32x4 v = acc[rt][n];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        stg4(orow + 16 * n + g4, v);
+      }
+    }
+  }
+}
+
+template <int D>
+static void launch_subconv_t(const SubConvArgs& a, hipStream_t s) {
+  const int P = a.B * a.T2 * a.F2;
+  const int tiles = (P + 15) / 16;
+  // RT = 2 (two position tiles per wave) spills under hipcc 7.2 (49-value window x 2 + 2x accumulators);
+  // one tile per wave fits in 256 VGPRs with no scratch.
+  hipLaunchKernelGGL((subconv_kernel<D, 1>), dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
+}
+
+int launch_subconv(int D, const SubConvArgs& a, hipStream_t s) {
+  if (D == 144) launch_subconv_t<144>(a, s);
+  else if (D == 256) launch_subconv_t<256>(a, s);
+  else return -1;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stream_gemm: y = x W + b with K too large to keep the input row in registers (K = F2*D = 2880).
+// ---------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(BLOCK_THREADS) void stream_gemm_kernel(StreamGemmArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int g4 = (lane >> 4) * 4, c = lane & 15;
+  const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if ((size_t)wid * 16 >= (size_t)a.M) return;
+  const int tok = wid * 16 + c;
+  const float* __restrict__ xr = a.x + (size_t)min(tok, a.M - 1) * a.K + g4;
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + lane;
+  f32x4 acc[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) acc[i] = ldg4(a.bias + 16 * i + g4);
+  const int KBT = a.K / 16;
+  for (int kb = 0; kb < KBT; ++kb) {
+    const f32x4 x = ldg4(xr + 16 * kb);
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      f32x4 w = wp[(size_t)(kb * a.NT + i) * 64];
+      acc[i] = mma_kblock(w, x, acc[i]);
+    }
+  }
+  if (tok < a.M) {
+    float* orow = a.y + (size_t)tok * a.ldy;
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+      if (16 * i + g4 + 3 < a.n_valid) stg4(orow + 16 * i + g4, acc[i]);
+  }
+}
+
+int launch_stream_gemm(int D, const StreamGemmArgs& a, hipStream_t s) {
+  const int tiles = (a.M + 15) / 16;
+  dim3 grid((tiles + 3) / 4);
+  if (a.K % 16 != 0) return -1;
+  if (D == 144 && a.NT == 9) hipLaunchKernelGGL((stream_gemm_kernel<9>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  else if (D == 256 && a.NT == 16) hipLaunchKernelGGL((stream_gemm_kernel<16>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  else return -1;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CTC greedy collapse: one wave per utterance, ballot + popcount stream compaction.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void collapse_kernel(CollapseArgs a) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int T = a.T;
+  int n = a.in_len ? a.in_len[b] : T;
+  n = max(0, min(n, T));
+  const int32_t* __restrict__ src = a.frame_ids + (size_t)b * T;
+  int32_t* dst = a.ids + (size_t)b * T;
+  int count = 0;
+  int carry = -1;
+  for (int t0 = 0; t0 < n; t0 += 64) {
+    const int t = t0 + lane;
+    const bool valid = t < n;
+    const int id = valid ? src[t] : -2;
+    int prev = __shfl_up(id, 1);
+    if (lane == 0) prev = carry;
+    const bool keep = valid && id != a.blank && id != prev;
+    const unsigned long long mask = __ballot(keep);
+    const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep) dst[pos] = id;
+    count += __popcll(mask);
+    carry = __shfl(id, 63);
+  }
+  for (int t = count + lane; t < T; t += 64) dst[t] = -1;
+  if (lane == 0) a.out_len[b] = count;
+}
+
+int launch_collapse(const CollapseArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(collapse_kernel, dim3(a.B), dim3(64), 0, s, a);
+  return 0;
+}

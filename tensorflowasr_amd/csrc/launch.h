@@ -1,0 +1,116 @@
+// Host-visible launch interface between the kernel translation units and api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_QKV = 2, EPI_GLU = 3, EPI_HEAD = 4 };
+
+// column-chunk width (in 16-wide tiles) a wave accumulates at once, per (dmodel, epilogue).
+// Packed weights are padded to a multiple of this (for GLU: each half).
+static inline int gemm_ct(int D, int epi) {
+  if (epi == EPI_HEAD) return 12;
+  if (epi == EPI_GLU) return D == 144 ? 3 : 4;
+  return D == 144 ? 9 : 8;
+}
+
+struct Chain2Args {
+  const float* x;      // [M, D] GEMM1 input rows
+  const float* res;    // [M, D] residual rows
+  float* y;            // [M, D]
+  const float* ln_g;   // prologue LayerNorm (MODE 0)
+  const float* ln_b;
+  const float* w1p;    // packed [D/16][HT][64][4]
+  const float* b1;     // [HT*16]
+  const float* aff_s;  // hidden affine (MODE 1: folded BatchNorm scale / shift)
+  const float* aff_t;
+  const float* w2p;    // packed [HT][D/16][64][4]
+  const float* b2;     // [D]
+  const float* fln_g;  // optional trailing LayerNorm (block-final LN), nullptr = none
+  const float* fln_b;
+  float scale;
+  float eps;
+  int M;
+};
+
+struct GemmArgs {
+  const float* x;    // [M, D]
+  float* y;          // [M, ldy] (may be nullptr for EPI_HEAD)
+  const float* res;  // [M, ldy] (EPI_RESIDUAL)
+  const float* ln_g;
+  const float* ln_b;
+  const float* wp;   // packed [D/16][NT][64][4]
+  const float* bias; // [NT*16]
+  int M, NT, ldy, n_valid;
+  float eps, qscale;
+  int qtiles;
+  int32_t* argmax_out;  // [M] (EPI_HEAD)
+  float* maxval_out;    // [M] or nullptr
+};
+
+struct AttnArgs {
+  const float* qkv;  // [B*T, ld] : q | k | v, each D = H*HS wide, head-major
+  float* ctx;        // [B*T, D]
+  int B, T, H, D, ld;
+};
+
+struct DwArgs {
+  const float* u;   // [B, T, D]
+  float* y;         // [B, T, D]
+  const float* wd;  // [K, D]
+  int B, T, D, pad_left;
+};
+
+// frontend / subsampling (frontend.hip)
+struct StftArgs {
+  const float* wav;   // [B, L]
+  float* logp;        // [B, F, LP] 10*log10(max(power,1e-10)) (or log10 for 'valid')
+  float* pmax;        // [B, FT * NCH] per-(frame tile, column chunk) maxima
+  const float* wp;    // packed DFT kernels [n_dft/16][NT][64][4], columns interleaved re/im per bin
+  int B, L, F, hop, pad_left, n_dft, NT, LP, nbins, FT, NCH;
+  int db10;           // 1: 10*ln(p)/ln10 ; 0: ln(p)/ln10
+};
+struct UttMaxArgs { const float* pmax; float* umax; int n; };
+struct MelArgs {
+  const float* logp;  // [B, F, LP]
+  const float* umax;  // [B] or nullptr (no max-normalisation / floor: 'valid' chunk frontend)
+  float* mel;         // [B, F, NM]
+  const float* wp;    // packed freq2mel [KBm][NTm][64][4]
+  int B, F, LP, nbins, KBm, NTm, NM, FT;
+  float floor_db;
+};
+struct SubConvArgs {
+  const float* mel;   // [B, F, NM]
+  float* out;         // [B*T2*F2, D]
+  const float* w1;    // conv1 kernel [3][3][D]
+  const float* b1;    // [D]
+  const float* w2p;   // packed conv2 kernel, K order = (cblock, kt, kf, 16) -> [9*D/16][D/16][64][4]
+  const float* b2;    // [D]
+  int B, F, NM, T1, F1, T2, F2;
+  int st1;            // conv1 time stride (reduction_factor/2)
+  int pt1, pf1, pt2, pf2;  // pad-before of conv1 (time,freq) and conv2 (time,freq)
+};
+struct StreamGemmArgs {
+  const float* x;     // [M, K]
+  float* y;           // [M, ldy]
+  const float* wp;    // packed [K/16][NT][64][4]
+  const float* bias;
+  int M, K, NT, ldy, n_valid;
+};
+struct CollapseArgs {
+  const int32_t* frame_ids;  // [B, T]
+  const int32_t* in_len;     // [B] or nullptr (= T)
+  int32_t* ids;              // [B, T] padded with -1
+  int32_t* out_len;          // [B]
+  int B, T, blank;
+};
+
+int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s);
+int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s);
+int launch_attention(int HS, const AttnArgs& a, hipStream_t s);
+int launch_dwconv(int K, const DwArgs& a, hipStream_t s);
+int launch_stft(const StftArgs& a, hipStream_t s);
+int launch_utt_max(const UttMaxArgs& a, int B, hipStream_t s);
+int launch_mel(const MelArgs& a, hipStream_t s);
+int launch_subconv(int D, const SubConvArgs& a, hipStream_t s);
+int launch_stream_gemm(int D, const StreamGemmArgs& a, hipStream_t s);
+int launch_collapse(const CollapseArgs& a, hipStream_t s);

@@ -1,0 +1,524 @@
+"""Host-side mirror of the reference's model objects for the Conformer-CTC path
+(asr/models/conformer_blocks.py): `ConformerEncoder`, `StreamingConformerEncoder`, `CTCDecoder`, plus
+`ConformerCTC`, the fused encoder + CTCDecoder + greedy pipeline that `test_asr.py::ASR.offline_stt` runs
+step by step (test_asr.py:186-200).
+
+Same constructor keywords, `_build()`, `load_weights()`, `__call__(x, training=False)`,
+`set_inference_func()` / `.inference`, `summary()` as the Keras models.  All arithmetic happens in
+libmi355asr.so (hand-written HIP for gfx950); PyTorch-ROCm is used for device buffers and the stream only.
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import frontend_consts
+
+
+def _glorot(rng, shape, fan_in, fan_out):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def default_weights(names_and_shapes, rng, sample_rate=16000, n_dft=1024, n_mels=80):
+    """Keras default initialisers (glorot_uniform kernels, zero biases, gamma=1, beta=0, BN mean 0 / var 1;
+    multihead_attention.py:34,37) for every tensor name the handle expects."""
+    w = {}
+    for name, shape in names_and_shapes:
+        leaf = name.rsplit("/", 1)[-1]
+        if name == "mel_layer/real_kernels":
+            w[name] = frontend_consts.stft_kernels(n_dft)[0]
+        elif name == "mel_layer/imag_kernels":
+            w[name] = frontend_consts.stft_kernels(n_dft)[1]
+        elif name == "mel_layer/freq2mel":
+            w[name] = frontend_consts.freq2mel(sample_rate, n_dft, n_mels)
+        elif leaf in ("gamma", "moving_variance"):
+            w[name] = np.ones(shape, np.float32)
+        elif leaf in ("beta", "moving_mean", "bias", "projection_bias"):
+            w[name] = np.zeros(shape, np.float32)
+        elif leaf in ("query_kernel", "key_kernel", "value_kernel", "projection_kernel"):
+            # Keras glorot on a 3-D shape: receptive field = prod(shape[:-2])
+            rf = int(np.prod(shape[:-2]))
+            w[name] = _glorot(rng, shape, shape[-2] * rf, shape[-1] * rf)
+        else:
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            w[name] = _glorot(rng, shape, shape[-2] * rf, shape[-1] * rf)
+    return w
+
+
+class _Handle:
+    """Owns one `mi355asr_model*` plus its device workspace."""
+
+    def __init__(self, cfg: _lib.Config, device):
+        self.lib = _lib.lib()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.ptr = ctypes.c_void_p()
+        _lib.check(self.lib.mi355asr_create(ctypes.byref(cfg), ctypes.byref(self.ptr)))
+        self._ws = None
+        self.built = False
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.mi355asr_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------------
+    def weight_names(self):
+        n = self.lib.mi355asr_num_weights(self.ptr)
+        return [self.lib.mi355asr_weight_name(self.ptr, i).decode() for i in range(n)]
+
+    def load(self, weights: dict, strict=True):
+        names = set(self.weight_names())
+        for name, arr in weights.items():
+            if name not in names:
+                if strict:
+                    raise _lib.Mi355AsrError("unexpected weight %r" % name)
+                continue
+            a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
+            dims = (ctypes.c_int64 * a.ndim)(*a.shape)
+            _lib.check(self.lib.mi355asr_load_weight(self.ptr, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
+                                                     a.ndim, dims))
+
+    def finalize(self):
+        if self.device.type != "cuda":
+            raise _lib.Mi355AsrError("mi355asr needs a ROCm device (got %s); there is no CPU path" % self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mi355asr_finalize_weights(self.ptr, self._stream()))
+        self.built = True
+
+    # ---- device plumbing -----------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def ws_for_wave(self, B, L):
+        n = ctypes.c_size_t()
+        _lib.check(self.lib.mi355asr_workspace_bytes(self.ptr, B, L, ctypes.byref(n)))
+        return self.workspace(n.value), n.value
+
+    def ws_for_frames(self, B, T):
+        n = ctypes.c_size_t()
+        _lib.check(self.lib.mi355asr_ctc_workspace_bytes(self.ptr, B, T, ctypes.byref(n)))
+        return self.workspace(n.value), n.value
+
+    def out_frames(self, L):
+        f, t = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self.lib.mi355asr_out_frames(self.ptr, L, ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
+
+    def to_device(self, x, dtype=torch.float32):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(x)
+        return x.to(device=self.device, dtype=dtype).contiguous()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()
+
+
+def _wave2d(h, inputs):
+    x = h.to_device(inputs)
+    if x.dim() == 3:
+        if x.shape[-1] != 1:
+            raise ValueError("expected mono input [B, L, 1] (time_frequency.py:71-73), got %s" % (tuple(x.shape),))
+        x = x.reshape(x.shape[0], x.shape[1])
+    if x.dim() != 2:
+        raise ValueError("expected waveform of shape [B, L, 1] or [B, L], got %s" % (tuple(x.shape),))
+    return x.contiguous()
+
+
+class _ModelBase:
+    def _names_and_shapes(self):
+        shapes = self._expected_shapes()
+        return [(n, shapes[n]) for n in self._h.weight_names()]
+
+    def _build(self, seed=0):
+        """Keras `_build()` materialises default-initialised weights; so does this (seeded)."""
+        rng = np.random.default_rng(seed)
+        w = default_weights(self._names_and_shapes(), rng, self.sample_rate, 1024, self.n_mels)
+        self._weights = w
+        self._h.load(w)
+        self._h.finalize()
+        return self
+
+    def load_weights(self, weights, by_name=True, strict=None):
+        """`weights`: path to an .npz of Keras-layout tensors, or a dict name -> array.  (The reference's
+        Keras .h5 checkpoints need h5py, which is not part of this image; see INTEGRATION.md.)"""
+        if isinstance(weights, (str, os.PathLike)):
+            path = str(weights)
+            if path.endswith(".h5"):
+                raise NotImplementedError("Keras .h5 checkpoints: convert to .npz first (INTEGRATION.md)")
+            weights = dict(np.load(path))
+        if strict is None:
+            strict = not by_name
+        if not getattr(self, "_weights", None):
+            self._build()
+        self._weights.update({k: np.asarray(v, np.float32) for k, v in weights.items() if k in self._weights or strict})
+        self._h.load(weights, strict=strict)
+        self._h.finalize()
+        return self
+
+    def get_weights_dict(self):
+        return dict(self._weights)
+
+    def count_params(self):
+        return int(sum(int(np.prod(s)) for _, s in self._names_and_shapes()))
+
+    def summary(self, line_length=100):
+        print("=" * line_length)
+        print("%s  (libmi355asr: %s)" % (self.name, self._h.lib.mi355asr_version().decode()))
+        for n, s in self._names_and_shapes():
+            print("%-*s %s" % (line_length - 20, n, tuple(s)))
+        print("Total params: {:,}".format(self.count_params()))
+        print("=" * line_length)
+
+    def set_inference_func(self):
+        self.inference = lambda *a, **k: self.__call__(*a, training=False, **k)
+
+
+def _block_shapes(p, d, H, hs, k):
+    s = {}
+    for ff in ("ff_module_1", "ff_module_2"):
+        q = "%s/%s" % (p, ff)
+        s[q + "/ln/gamma"] = (d,)
+        s[q + "/ln/beta"] = (d,)
+        s[q + "/ffn1/kernel"] = (d, 4 * d)
+        s[q + "/ffn1/bias"] = (4 * d,)
+        s[q + "/ffn2/kernel"] = (4 * d, d)
+        s[q + "/ffn2/bias"] = (d,)
+    m = p + "/mhsa_module"
+    s[m + "/ln/gamma"] = (d,)
+    s[m + "/ln/beta"] = (d,)
+    for nm in ("query_kernel", "key_kernel", "value_kernel"):
+        s[m + "/mha/" + nm] = (H, d, hs)
+    s[m + "/mha/projection_kernel"] = (H, hs, d)
+    s[m + "/mha/projection_bias"] = (d,)
+    c = p + "/conv_module"
+    s[c + "/ln/gamma"] = (d,)
+    s[c + "/ln/beta"] = (d,)
+    s[c + "/pw_conv_1/kernel"] = (1, d, 2 * d)
+    s[c + "/pw_conv_1/bias"] = (2 * d,)
+    s[c + "/dw_conv/depthwise_kernel"] = (k, d, 1)
+    s[c + "/dw_conv/pointwise_kernel"] = (1, d, 2 * d)
+    s[c + "/dw_conv/bias"] = (2 * d,)
+    for nm in ("gamma", "beta", "moving_mean", "moving_variance"):
+        s[c + "/bn/" + nm] = (2 * d,)
+    s[c + "/pw_conv_2/kernel"] = (1, 2 * d, d)
+    s[c + "/pw_conv_2/bias"] = (d,)
+    s[p + "/ln/gamma"] = (d,)
+    s[p + "/ln/beta"] = (d,)
+    return s
+
+
+def _encoder_shapes(d, H, hs, k, num_blocks, n_mels, n_dft=1024):
+    nb = n_dft // 2 + 1
+    f2 = -(-(-(-n_mels // 2)) // 2)
+    s = {"mel_layer/real_kernels": (n_dft, 1, 1, nb), "mel_layer/imag_kernels": (n_dft, 1, 1, nb),
+         "mel_layer/freq2mel": (nb, n_mels),
+         "conv_subsampling/conv1/kernel": (3, 3, 1, d), "conv_subsampling/conv1/bias": (d,),
+         "conv_subsampling/conv2/kernel": (3, 3, d, d), "conv_subsampling/conv2/bias": (d,),
+         "conv_subsampling/linear/kernel": (f2 * d, d), "conv_subsampling/linear/bias": (d,)}
+    for i in range(num_blocks):
+        s.update(_block_shapes("conformer_block_%d" % i, d, H, hs, k))
+    return s
+
+
+def _ctc_shapes(d, H, hs, k, num_blocks, num_classes):
+    s = {"project/kernel": (d, d), "project/bias": (d,)}
+    for i in range(num_blocks):
+        s.update(_block_shapes("decoder_conformer_block_%d" % i, d, H, hs, k))
+    s["fully_connected/kernel"] = (d, num_classes)
+    s["fully_connected/bias"] = (num_classes,)
+    return s
+
+
+class ConformerEncoder(_ModelBase):
+    """asr/models/conformer_blocks.py:277-384.  `mel_layer_type` must be 'Melspectrogram' (the default of
+    asr/configs/am_data.yml:3); 'leaf' and `add_wav_info=True` are outside this path."""
+
+    def __init__(self, dmodel=144, reduction_factor=4, num_blocks=16, head_size=36, num_heads=4, kernel_size=32,
+                 fc_factor=0.5, dropout=0.0, add_wav_info=False, sample_rate=16000, n_mels=80,
+                 mel_layer_type="leaf", mel_layer_trainable=False, stride_ms=10, name="conformer_encoder",
+                 device="cuda:0", chunk_size=0, **kwargs):
+        if mel_layer_type != "Melspectrogram":
+            raise NotImplementedError("mel_layer_type=%r: only 'Melspectrogram' is on the MI355X hot path" % mel_layer_type)
+        if add_wav_info:
+            raise NotImplementedError("add_wav_info=True (WavePickModel branch) is outside the hot path")
+        self.name = name
+        self.dmodel, self.num_heads, self.head_size = dmodel, num_heads, head_size
+        self.fc_factor, self.dropout = fc_factor, dropout      # dropout is identity at inference
+        self.reduction_factor = reduction_factor
+        self.num_blocks, self.kernel_size = num_blocks, kernel_size
+        self.sample_rate, self.n_mels, self.stride_ms = sample_rate, n_mels, stride_ms
+        self.hop_size = int(stride_ms * sample_rate // 1000) * reduction_factor   # conformer_blocks.py:302
+        self.add_wav_info = add_wav_info
+        self.chunk_size = int(chunk_size)
+        self._device = device
+        self._weights = None
+        self._make_handle()
+
+    def _make_handle(self):
+        cfg = _lib.Config(dmodel=self.dmodel, num_blocks=self.num_blocks, head_size=self.head_size,
+                          num_heads=self.num_heads, kernel_size=self.kernel_size, fc_factor=self.fc_factor,
+                          reduction_factor=self.reduction_factor, n_mels=self.n_mels, sample_rate=self.sample_rate,
+                          stride_ms=self.stride_ms, n_dft=1024, chunk_size=self.chunk_size, has_encoder=1,
+                          num_classes=0, ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5)
+        self._h = _Handle(cfg, self._device)
+
+    def _expected_shapes(self):
+        return _encoder_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks,
+                               self.n_mels)
+
+    def __call__(self, inputs, training=False, **kwargs):
+        """wav [B, L, 1] (or [B, L]) float32 -> torch.Tensor [B, T, dmodel] on the device."""
+        if training:
+            raise NotImplementedError("inference path only (training=False)")
+        h = self._h
+        if not h.built:
+            self._build()
+        x = _wave2d(h, inputs)
+        B, L = x.shape
+        _, T = h.out_frames(L)
+        out = torch.empty((B, T, self.dmodel), dtype=torch.float32, device=h.device)
+        ws, n = h.ws_for_wave(B, L)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_encoder_forward(h.ptr, _p(x), B, L, _p(out), _p(ws), n, h._stream()))
+        return out
+
+    # stage-level access (tests localise mismatches with these)
+    def melspectrogram(self, inputs):
+        h = self._h
+        x = _wave2d(h, inputs)
+        B, L = x.shape
+        F, _ = h.out_frames(L)
+        nblk = L // self.chunk_size if self.chunk_size else 1
+        out = torch.empty((B * nblk, F // nblk, self.n_mels), dtype=torch.float32, device=h.device)
+        ws, n = h.ws_for_wave(B, L)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_melspectrogram(h.ptr, _p(x), B, L, _p(out), _p(ws), n, h._stream()))
+        return out
+
+    def conv_subsampling(self, mel):
+        h = self._h
+        m = h.to_device(mel)
+        B, F, _ = m.shape
+        T = -(-(-(-F // (self.reduction_factor // 2))) // 2)
+        out = torch.empty((B, T, self.dmodel), dtype=torch.float32, device=h.device)
+        hop = int(self.stride_ms * self.sample_rate // 1000)
+        ws, n = h.ws_for_wave(B, self.chunk_size if self.chunk_size else F * hop)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_conv_subsampling(h.ptr, _p(m), B, F, _p(out), _p(ws), n, h._stream()))
+        return out
+
+    def conformer_block(self, index, x, stack=0):
+        h = self._h
+        xd = h.to_device(x)
+        B, T, _ = xd.shape
+        out = torch.empty_like(xd)
+        ws, n = h.ws_for_frames(B, T)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_conformer_block(h.ptr, stack, index, _p(xd), B, T, _p(out), _p(ws), n, h._stream()))
+        return out
+
+
+class StreamingConformerEncoder(ConformerEncoder):
+    """conformer_blocks.py:567-614 (Block Conformer): the waveform is cut into `chunk_size`-sample blocks that
+    go through the ordinary encoder as independent batch entries; outputs are concatenated in time."""
+
+    def __init__(self, *args, name="stream_conformer_encoder", **kwargs):
+        super().__init__(*args, name=name, **kwargs)
+
+    def add_chunk_size(self, chunk_size, mel_size, hop_size):
+        self.chunk_size = int(chunk_size)
+        self.mel_size = mel_size
+        self.mel_length = chunk_size // hop_size if chunk_size % hop_size == 0 else chunk_size // hop_size + 1
+        w = self._weights
+        self._make_handle()
+        if w is not None:
+            self._h.load(w)
+            self._h.finalize()
+
+    def set_inference_func(self):
+        # The reference's override never assigns self.inference (conformer_blocks.py:596-614); the intended
+        # behaviour is the base-class inference applied to one block at a time.
+        self.inference = lambda x, **k: self.__call__(x, training=False)
+
+
+class CTCDecoder(_ModelBase):
+    """asr/models/conformer_blocks.py:385-438: Dense(d->d) + num_blocks ConformerBlocks + Dense(d->num_classes)."""
+
+    def __init__(self, num_classes, dmodel=144, num_blocks=16, head_size=36, num_heads=4, fc_factor=0.5,
+                 dropout=0.0, kernel_size=32, device="cuda:0", name="ctc_decoder", **kwargs):
+        self.name = name
+        self.num_classes, self.dmodel = num_classes, dmodel
+        self.num_blocks, self.head_size, self.num_heads = num_blocks, head_size, num_heads
+        self.fc_factor, self.kernel_size = fc_factor, kernel_size
+        self.sample_rate, self.n_mels = 16000, 80
+        self._weights = None
+        cfg = _lib.Config(dmodel=dmodel, num_blocks=0, head_size=head_size, num_heads=num_heads, kernel_size=32,
+                          fc_factor=0.5, reduction_factor=4, n_mels=80, sample_rate=16000, stride_ms=10, n_dft=1024,
+                          chunk_size=0, has_encoder=0, num_classes=num_classes, ctc_num_blocks=num_blocks,
+                          ctc_kernel_size=kernel_size, ctc_fc_factor=fc_factor)
+        self._h = _Handle(cfg, device)
+
+    def _expected_shapes(self):
+        return _ctc_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks,
+                           self.num_classes)
+
+    def __call__(self, inputs, training=None, mask=None, return_argmax=False):
+        """enc [B, T, dmodel] -> logits [B, T, num_classes] (torch, on device)."""
+        if training:
+            raise NotImplementedError("inference path only")
+        h = self._h
+        if not h.built:
+            self._build()
+        x = h.to_device(inputs)
+        B, T, _ = x.shape
+        logits = torch.empty((B, T, self.num_classes), dtype=torch.float32, device=h.device)
+        amax = torch.empty((B, T), dtype=torch.int32, device=h.device)
+        ws, n = h.ws_for_frames(B, T)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_ctc_forward(h.ptr, _p(x), B, T, _p(logits), _p(amax), _p(ws), n, h._stream()))
+        return (logits, amax) if return_argmax else logits
+
+    def conformer_block(self, index, x):
+        return ConformerEncoder.conformer_block(self, index, x, stack=1)
+
+
+def ctc_greedy_decode(frame_argmax, input_length=None, blank=None, device=None):
+    """tf.keras.backend.ctc_decode(greedy=True)[0][0] on per-frame argmax ids: merge repeated, drop blank,
+    pad with -1 (test_asr.py:196-200).  frame_argmax int32 [B,T] -> (ids int32 [B,T], lengths int32 [B])."""
+    lib = _lib.lib()
+    fa = frame_argmax if torch.is_tensor(frame_argmax) else torch.as_tensor(np.asarray(frame_argmax))
+    dev = torch.device(device) if device is not None else (fa.device if fa.is_cuda else torch.device("cuda:0"))
+    fa = fa.to(device=dev, dtype=torch.int32).contiguous()
+    B, T = fa.shape
+    il = None
+    if input_length is not None:
+        il = torch.as_tensor(np.asarray(input_length) if not torch.is_tensor(input_length) else input_length)
+        il = il.to(device=dev, dtype=torch.int32).contiguous()
+    ids = torch.empty((B, T), dtype=torch.int32, device=dev)
+    lens = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.mi355asr_ctc_greedy(_p(fa), _p(il), B, T, int(blank), _p(ids), _p(lens), st))
+    return ids, lens
+
+
+class ConformerCTC(_ModelBase):
+    """Encoder + CTCDecoder + greedy decode in one handle / one call (`mi355asr_recognize`): the timed region
+    of the benchmark and what `ASR.offline_stt` (test_asr.py:186-200) computes up to the token ids."""
+
+    def __init__(self, num_classes, dmodel=144, reduction_factor=4, num_blocks=13, head_size=36, num_heads=4,
+                 kernel_size=32, fc_factor=0.5, sample_rate=16000, n_mels=80, stride_ms=10, chunk_size=0,
+                 ctcdecoder_num_blocks=1, ctcdecoder_kernel_size=32, ctcdecoder_fc_factor=0.5,
+                 device="cuda:0", name="conformer_ctc", **kwargs):
+        self.name = name
+        self.num_classes, self.dmodel = num_classes, dmodel
+        self.blank = num_classes - 1               # utils/text_featurizers.py:65-70 (blank_at_zero: False)
+        self.num_blocks, self.head_size, self.num_heads, self.kernel_size = num_blocks, head_size, num_heads, kernel_size
+        self.ctc_blocks, self.ctc_kernel = ctcdecoder_num_blocks, ctcdecoder_kernel_size
+        self.sample_rate, self.n_mels, self.stride_ms = sample_rate, n_mels, stride_ms
+        self.reduction_factor, self.chunk_size = reduction_factor, int(chunk_size)
+        self._weights = None
+        cfg = _lib.Config(dmodel=dmodel, num_blocks=num_blocks, head_size=head_size, num_heads=num_heads,
+                          kernel_size=kernel_size, fc_factor=fc_factor, reduction_factor=reduction_factor,
+                          n_mels=n_mels, sample_rate=sample_rate, stride_ms=stride_ms, n_dft=1024,
+                          chunk_size=self.chunk_size, has_encoder=1, num_classes=num_classes,
+                          ctc_num_blocks=ctcdecoder_num_blocks, ctc_kernel_size=ctcdecoder_kernel_size,
+                          ctc_fc_factor=ctcdecoder_fc_factor)
+        self._h = _Handle(cfg, device)
+
+    @classmethod
+    def from_config(cls, config, num_classes, device="cuda:0"):
+        """config: the merged am_data.yml + model yml dict (utils/user_config.py)."""
+        mc, sc = config["model_config"], config["speech_config"]
+        chunk = int(sc["streaming_bucket"] * sc["sample_rate"]) if sc.get("streaming") else 0
+        return cls(num_classes, dmodel=mc["dmodel"], reduction_factor=mc["reduction_factor"],
+                   num_blocks=mc["num_blocks"], head_size=mc["head_size"], num_heads=mc["num_heads"],
+                   kernel_size=mc["kernel_size"], fc_factor=mc["fc_factor"], sample_rate=sc["sample_rate"],
+                   n_mels=sc["num_feature_bins"], stride_ms=sc["stride_ms"], chunk_size=chunk,
+                   ctcdecoder_num_blocks=mc["ctcdecoder_num_blocks"],
+                   ctcdecoder_kernel_size=mc["ctcdecoder_kernel_size"],
+                   ctcdecoder_fc_factor=mc["ctcdecoder_fc_factor"], device=device)
+
+    def _expected_shapes(self):
+        s = _encoder_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks, self.n_mels)
+        s.update(_ctc_shapes(self.dmodel, self.num_heads, self.head_size, self.ctc_kernel, self.ctc_blocks,
+                             self.num_classes))
+        return s
+
+    def out_frames(self, L):
+        return self._h.out_frames(L)[1]
+
+    def prepare(self, B, L):
+        """pre-allocate workspace + outputs for a fixed [B, L] so that recognize() does no allocation."""
+        h = self._h
+        T = h.out_frames(L)[1]
+        ws, n = h.ws_for_wave(B, L)
+        self._ids = torch.empty((B, T), dtype=torch.int32, device=h.device)
+        self._lens = torch.empty((B,), dtype=torch.int32, device=h.device)
+        return T
+
+    def recognize(self, wav, input_length=None):
+        """wav [B,L(,1)] on device -> (ids int32 [B,T] padded -1, lengths int32 [B]).  Asynchronous."""
+        h = self._h
+        if not h.built:
+            self._build()
+        x = _wave2d(h, wav)
+        B, L = x.shape
+        T = h.out_frames(L)[1]
+        ws, n = h.ws_for_wave(B, L)
+        ids = getattr(self, "_ids", None)
+        if ids is None or tuple(ids.shape) != (B, T):
+            self.prepare(B, L)
+        il = None
+        if input_length is not None:
+            il = h.to_device(input_length, torch.int32)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_recognize(h.ptr, _p(x), B, L, _p(il), _p(self._ids), _p(self._lens), _p(ws), n,
+                                                h._stream()))
+        return self._ids, self._lens
+
+    __call__ = recognize
+
+    def encode(self, wav):
+        h = self._h
+        x = _wave2d(h, wav)
+        B, L = x.shape
+        T = h.out_frames(L)[1]
+        out = torch.empty((B, T, self.dmodel), dtype=torch.float32, device=h.device)
+        ws, n = h.ws_for_wave(B, L)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_encoder_forward(h.ptr, _p(x), B, L, _p(out), _p(ws), n, h._stream()))
+        return out
+
+    def ctc_logits(self, enc, return_argmax=False):
+        h = self._h
+        x = h.to_device(enc)
+        B, T, _ = x.shape
+        logits = torch.empty((B, T, self.num_classes), dtype=torch.float32, device=h.device)
+        amax = torch.empty((B, T), dtype=torch.int32, device=h.device)
+        ws, n = h.ws_for_frames(B, T)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_ctc_forward(h.ptr, _p(x), B, T, _p(logits), _p(amax), _p(ws), n, h._stream()))
+        return (logits, amax) if return_argmax else logits
+
+    melspectrogram = ConformerEncoder.melspectrogram
+    conv_subsampling = ConformerEncoder.conv_subsampling
+
+    def conformer_block(self, index, x, stack=0):
+        return ConformerEncoder.conformer_block(self, index, x, stack=stack)

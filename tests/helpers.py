@@ -1,0 +1,55 @@
+"""Shared helpers for the parity tests (test infrastructure: may import oracle/)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import conformer_oracle as co  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_ctc_weights():
+    return dict(np.load(os.path.join(GOLDEN, "ctc_decoder_weights.npz")))
+
+
+def golden_ctc_io():
+    return np.load(os.path.join(GOLDEN, "ctc_decoder_io.npz"))
+
+
+def small_cfg(num_blocks=2, base=None):
+    cfg = dict(base or co.CONFORMER_S)
+    cfg["num_blocks"] = num_blocks
+    return cfg
+
+
+def waves(n, length, start=0):
+    return np.stack([co.synth_wave(start + i, length) for i in range(n)])
+
+
+def encoder_kwargs(cfg, chunk_size=0):
+    return dict(dmodel=cfg["dmodel"], reduction_factor=cfg["reduction_factor"], num_blocks=cfg["num_blocks"],
+                head_size=cfg["head_size"], num_heads=cfg["num_heads"], kernel_size=cfg["kernel_size"],
+                fc_factor=cfg["fc_factor"], sample_rate=cfg["sample_rate"], n_mels=cfg["n_mels"],
+                stride_ms=cfg["stride_ms"], mel_layer_type="Melspectrogram", chunk_size=chunk_size)
+
+
+def maxdiff(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max())
+
+
+def argmax_mismatch_report(gpu_logits, ref_logits):
+    """frames where argmax differs, with the reference's own top-2 margin there."""
+    ga, ra = gpu_logits.argmax(-1), ref_logits.argmax(-1)
+    bad = np.argwhere(ga != ra)
+    out = []
+    for idx in bad:
+        row = np.sort(ref_logits[tuple(idx)])[::-1]
+        out.append((tuple(int(i) for i in idx), float(row[0] - row[1])))
+    return out
