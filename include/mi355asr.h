@@ -123,6 +123,29 @@ int mi355asr_conv_subsampling(mi355asr_model* m, const float* mel_dev, int32_t B
 int mi355asr_conformer_block(mi355asr_model* m, int32_t stack, int32_t index, const float* x_dev, int32_t B,
                              int32_t T, float* y_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Per-kernel timing with HIP events recorded on the launch stream around each kernel (off by default).
+ * profile_read waits for the recorded events, then returns accumulated milliseconds and launch counts per
+ * kernel category below (arrays of at least MI355ASR_NUM_KERNELS); reset != 0 clears the accumulators.
+ * bench.py uses this for the live `roofline.achieved` figure. */
+#define MI355ASR_K_STFT 0         /* stft_kernel          Spectrogram conv2d x2 + power + log           */
+#define MI355ASR_K_UTT_MAX 1      /* utt_max_kernel       per-sample max of the dB spectrogram          */
+#define MI355ASR_K_MEL 2          /* mel_kernel           (dB-max).clamp(-80) @ freq2mel                */
+#define MI355ASR_K_SUBCONV 3      /* subconv_kernel       Conv2D+ReLU -> Conv2D+ReLU (fused)            */
+#define MI355ASR_K_SUBLINEAR 4    /* stream_gemm_kernel   Dense(F2*d -> d)                              */
+#define MI355ASR_K_FFN 5          /* chain2_kernel mode 0 FFModule (+ block LayerNorm on the 2nd one)   */
+#define MI355ASR_K_QKV 6          /* gemm_rows EPI_QKV    LN + q/k/v projections                        */
+#define MI355ASR_K_ATTN 7         /* attention_kernel     softmax(q k^T) v                              */
+#define MI355ASR_K_ATTN_OUT 8     /* gemm_rows EPI_RESIDUAL out-projection + residual                   */
+#define MI355ASR_K_PW1_GLU 9      /* gemm_rows EPI_GLU    LN + pw_conv_1 + GLU                          */
+#define MI355ASR_K_DWCONV 10      /* dwconv_kernel        depthwise conv                                */
+#define MI355ASR_K_CONV_TAIL 11   /* chain2_kernel mode 1 pointwise + BN + swish + pw_conv_2 + residual */
+#define MI355ASR_K_CTC_PROJECT 12 /* gemm_rows EPI_BIAS   CTCDecoder.project                            */
+#define MI355ASR_K_CTC_HEAD 13    /* gemm_rows EPI_HEAD   fully_connected + per-frame argmax            */
+#define MI355ASR_K_COLLAPSE 14    /* collapse_kernel      greedy merge/blank-drop                       */
+#define MI355ASR_NUM_KERNELS 15
+int mi355asr_profile_enable(mi355asr_model* m, int32_t on);
+int mi355asr_profile_read(mi355asr_model* m, double* ms_out, int64_t* count_out, int32_t n, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,7 +47,12 @@ SIGNATURES = {
     "mi355asr_melspectrogram": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "mi355asr_conv_subsampling": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "mi355asr_conformer_block": (ctypes.c_int, [_P, _I, _I, _P, _I, _I, _P, _P, _SZ, _P]),
+    "mi355asr_profile_enable": (ctypes.c_int, [_P, _I]),
+    "mi355asr_profile_read": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), _I, _I]),
 }
+
+KERNEL_NAMES = ["stft", "utt_max", "mel", "subconv", "sublinear", "ffn", "qkv", "attention", "attn_out", "pw1_glu",
+                "dwconv", "conv_tail", "ctc_project", "ctc_head", "collapse"]
 
 _lib = None
 

@@ -87,11 +87,43 @@ struct mi355asr_model {
               *fc_wp = nullptr, *fc_b = nullptr;
   int NT_fc = 0;
   std::vector<BlockDev> enc_blocks, ctc_blocks;
+  // optional per-kernel timing with HIP events on the launch stream (mi355asr_profile_*)
+  mutable bool prof = false;
+  mutable std::vector<hipEvent_t> ev_free;
+  struct Pending { int cat; hipEvent_t e0, e1; };
+  mutable std::vector<Pending> ev_pending;
+  mutable double prof_ms[MI355ASR_NUM_KERNELS] = {0};
+  mutable int64_t prof_cnt[MI355ASR_NUM_KERNELS] = {0};
+  hipEvent_t get_event() const {
+    if (!ev_free.empty()) { hipEvent_t e = ev_free.back(); ev_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
 };
 
 namespace {
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// brackets one kernel launch with events on its stream when profiling is on
+struct ProfScope {
+  const mi355asr_model* m;
+  int cat;
+  hipStream_t s;
+  hipEvent_t e0 = nullptr;
+  ProfScope(const mi355asr_model* m_, int cat_, hipStream_t s_) : m(m_), cat(cat_), s(s_) {
+    if (m->prof) { e0 = m->get_event(); (void)hipEventRecord(e0, s); }
+  }
+  ~ProfScope() {
+    if (m->prof && e0) {
+      hipEvent_t e1 = m->get_event();
+      (void)hipEventRecord(e1, s);
+      m->ev_pending.push_back({cat, e0, e1});
+    }
+  }
+};
+#define PROF(cat) ProfScope prof_scope_##cat(m, cat, s)
 
 void same_pad(int n, int k, int s, int* out, int* before) {
   const int o = ceil_div(n, s);
@@ -337,36 +369,36 @@ int run_block(const mi355asr_model* m, const BlockDev& w, int ksz, float fc, con
   f1.ln_g = w.ff_ln_g[0]; f1.ln_b = w.ff_ln_b[0];
   f1.w1p = w.ff_w1p[0]; f1.b1 = w.ff_b1[0]; f1.w2p = w.ff_w2p[0]; f1.b2 = w.ff_b2[0];
   f1.scale = fc; f1.eps = kLnEps; f1.M = M;
-  LAUNCH_TRY(launch_chain2(d, 0, f1, s), "ff_module_1");
+  { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_chain2(d, 0, f1, s), "ff_module_1"); }
   // mhsa: qkv = LN(xb) Wqkv (q pre-scaled)
   GemmArgs q{};
   q.x = sc.xb; q.y = sc.qkv; q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.wp = w.qkv_wp; q.bias = w.qkv_b;
   q.M = M; q.NT = 3 * d / 16; q.ldy = 3 * d; q.n_valid = 3 * d; q.eps = kLnEps;
   q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
-  LAUNCH_TRY(launch_gemm_rows(d, EPI_QKV, true, q, s), "qkv projection");
+  { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm_rows(d, EPI_QKV, true, q, s), "qkv projection"); }
   AttnArgs at{};
   at.qkv = sc.qkv; at.ctx = sc.ctx; at.B = B; at.T = T; at.H = H; at.D = d; at.ld = 3 * d;
-  LAUNCH_TRY(launch_attention(hs, at, s), "attention");
+  { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
   // xa = xb + ctx Wo + bo
   GemmArgs op{};
   op.x = sc.ctx; op.y = sc.xa; op.res = sc.xb; op.wp = w.out_wp; op.bias = w.out_b;
   op.M = M; op.NT = d / 16; op.ldy = d; op.n_valid = d; op.eps = kLnEps;
-  LAUNCH_TRY(launch_gemm_rows(d, EPI_RESIDUAL, false, op, s), "attention out-projection");
+  { PROF(MI355ASR_K_ATTN_OUT); LAUNCH_TRY(launch_gemm_rows(d, EPI_RESIDUAL, false, op, s), "attention out-projection"); }
   // conv module: u = GLU(LN(xa) Wpw1 + b)
   GemmArgs g{};
   g.x = sc.xa; g.y = sc.u; g.ln_g = w.cv_ln_g; g.ln_b = w.cv_ln_b; g.wp = w.pw1_wp; g.bias = w.pw1_b;
   g.M = M; g.NT = 2 * d / 16; g.ldy = d; g.n_valid = d; g.eps = kLnEps;
-  LAUNCH_TRY(launch_gemm_rows(d, EPI_GLU, true, g, s), "pw_conv_1 + GLU");
+  { PROF(MI355ASR_K_PW1_GLU); LAUNCH_TRY(launch_gemm_rows(d, EPI_GLU, true, g, s), "pw_conv_1 + GLU"); }
   DwArgs dwa{};
   dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
   dwa.pad_left = (ksz - 1) / 2;  // Keras 'same', stride 1: total k-1, before = (k-1)//2
-  LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv");
+  { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
   // xb = xa + pw2( swish( BN( dw Wpc + bpc ) ) ) + b2
   Chain2Args cv{};
   cv.x = sc.dw; cv.res = sc.xa; cv.y = sc.xb;
   cv.w1p = w.pc_w1p; cv.b1 = w.pc_b1; cv.aff_s = w.bn_s; cv.aff_t = w.bn_t; cv.w2p = w.pw2_wp; cv.b2 = w.pw2_b;
   cv.scale = 1.0f; cv.eps = kLnEps; cv.M = M;
-  LAUNCH_TRY(launch_chain2(d, 1, cv, s), "conv module tail");
+  { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_chain2(d, 1, cv, s), "conv module tail"); }
   // ff_module_2 + block LayerNorm
   Chain2Args f2{};
   f2.x = sc.xb; f2.res = sc.xb; f2.y = out ? out : sc.xa;
@@ -374,7 +406,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, int ksz, float fc, con
   f2.w1p = w.ff_w1p[1]; f2.b1 = w.ff_b1[1]; f2.w2p = w.ff_w2p[1]; f2.b2 = w.ff_b2[1];
   f2.fln_g = w.ln_g; f2.fln_b = w.ln_b;
   f2.scale = fc; f2.eps = kLnEps; f2.M = M;
-  LAUNCH_TRY(launch_chain2(d, 0, f2, s), "ff_module_2 + LayerNorm");
+  { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_chain2(d, 0, f2, s), "ff_module_2 + LayerNorm"); }
   return 0;
 }
 
@@ -389,14 +421,14 @@ int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, fl
   st.B = Bp; st.L = Lb; st.F = F; st.hop = m->dm.hop; st.pad_left = before; st.n_dft = c.n_dft;
   st.NT = m->dm.NT_dft; st.LP = m->dm.LP; st.nbins = m->dm.nbins; st.FT = FT; st.NCH = m->dm.NCH_dft;
   st.db10 = 1;
-  LAUNCH_TRY(launch_stft(st, s), "stft");
+  { PROF(MI355ASR_K_STFT); LAUNCH_TRY(launch_stft(st, s), "stft"); }
   UttMaxArgs um{pmax, umax, FT * m->dm.NCH_dft};
-  LAUNCH_TRY(launch_utt_max(um, Bp, s), "utterance max");
+  { PROF(MI355ASR_K_UTT_MAX); LAUNCH_TRY(launch_utt_max(um, Bp, s), "utterance max"); }
   MelArgs me{};
   me.logp = logp; me.umax = umax; me.mel = mel; me.wp = m->mel_wp;
   me.B = Bp; me.F = F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
   me.NM = c.n_mels; me.FT = FT; me.floor_db = -80.0f;
-  LAUNCH_TRY(launch_mel(me, s), "dB + mel");
+  { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel(me, s), "dB + mel"); }
   return 0;
 }
 
@@ -411,11 +443,11 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   sa.mel = mel; sa.out = sub; sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
   sa.B = Bp; sa.F = F; sa.NM = c.n_mels; sa.T1 = T1; sa.F1 = m->dm.F1; sa.T2 = T2; sa.F2 = m->dm.F2;
   sa.st1 = m->dm.st1; sa.pt1 = pt1; sa.pf1 = m->dm.pf1; sa.pt2 = pt2; sa.pf2 = m->dm.pf2;
-  LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling");
+  { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling"); }
   StreamGemmArgs lg{};
   lg.x = sub; lg.y = out; lg.wp = m->lin_wp; lg.bias = m->lin_b;
   lg.M = Bp * T2; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.ldy = d; lg.n_valid = d;
-  LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear");
+  { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear"); }
   return 0;
 }
 
@@ -455,7 +487,7 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   GemmArgs pr{};
   pr.x = enc; pr.y = sc.xa; pr.wp = m->proj_wp; pr.bias = m->proj_b;
   pr.M = M; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
-  LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "ctc project");
+  { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "ctc project"); }
   for (int i = 0; i < m->cfg.ctc_num_blocks; ++i) {
     int rc = run_block(m, m->ctc_blocks[i], m->cfg.ctc_kernel_size, m->cfg.ctc_fc_factor, sc, B, T, nullptr, s);
     if (rc) return rc;
@@ -464,7 +496,7 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   hd.x = sc.xa; hd.y = logits; hd.wp = m->fc_wp; hd.bias = m->fc_b;
   hd.M = M; hd.NT = m->NT_fc; hd.ldy = m->cfg.num_classes; hd.n_valid = m->cfg.num_classes; hd.eps = kLnEps;
   hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
-  LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "ctc head");
+  { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "ctc head"); }
   return 0;
 }
 
@@ -539,8 +571,37 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
   return 0;
 }
 
+int mi355asr_profile_enable(mi355asr_model* m, int32_t on) {
+  if (!m) return fail(MI355ASR_EINVAL, "null model handle");
+  m->prof = on != 0;
+  return 0;
+}
+
+int mi355asr_profile_read(mi355asr_model* m, double* ms_out, int64_t* count_out, int32_t n, int32_t reset) {
+  if (!m || !ms_out || !count_out || n < MI355ASR_NUM_KERNELS)
+    return fail(MI355ASR_EINVAL, "profile_read needs arrays of at least %d entries", MI355ASR_NUM_KERNELS);
+  for (auto& p : m->ev_pending) {
+    HIP_TRY(hipEventSynchronize(p.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p.e0, p.e1));
+    m->prof_ms[p.cat] += ms;
+    m->prof_cnt[p.cat] += 1;
+    m->ev_free.push_back(p.e0);
+    m->ev_free.push_back(p.e1);
+  }
+  m->ev_pending.clear();
+  for (int i = 0; i < MI355ASR_NUM_KERNELS; ++i) {
+    ms_out[i] = m->prof_ms[i];
+    count_out[i] = m->prof_cnt[i];
+    if (reset) { m->prof_ms[i] = 0; m->prof_cnt[i] = 0; }
+  }
+  return 0;
+}
+
 int mi355asr_destroy(mi355asr_model* m) {
   if (!m) return 0;
+  for (auto& p : m->ev_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+  for (auto e : m->ev_free) (void)hipEventDestroy(e);
   if (m->arena) (void)hipFree(m->arena);
   delete m;
   return 0;
@@ -725,7 +786,7 @@ int mi355asr_recognize(mi355asr_model* m, const float* wav, int32_t B, int32_t L
   rc = ctc_impl(m, enc, B, Ttot, p, w, nullptr, amax, s);
   if (rc) return rc;
   CollapseArgs ca{amax, in_len, ids, out_len, B, Ttot, m->cfg.num_classes - 1};
-  LAUNCH_TRY(launch_collapse(ca, s), "ctc collapse");
+  { PROF(MI355ASR_K_COLLAPSE); LAUNCH_TRY(launch_collapse(ca, s), "ctc collapse"); }
   return 0;
 }
 
