@@ -1,0 +1,213 @@
+"""Headline benchmark: audio-frames/s of the ConformerCTC(S) hot path (waveform -> CTC greedy token ids) on
+N MI355X GPUs, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of mi355asr_recognize over one batch of 64 synthetic 10-second utterances per GPU that are
+already resident in HBM (BASELINE.json configs[1]; weak scaling: 64 utterances per GPU at every N), followed --
+when N > 1 -- by the all_gather of the token ids.  1 audio frame = one 10 ms feature hop (am_data.yml:8), so a
+10 s utterance is 1000 frames.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from tensorflowasr_amd import _lib  # noqa: E402
+from tensorflowasr_amd.models import ConformerCTC  # noqa: E402
+from tensorflowasr_amd.synthetic import synth_batch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+S_CFG = dict(dmodel=144, reduction_factor=4, num_blocks=13, head_size=36, num_heads=4, kernel_size=32,
+             fc_factor=0.5, sample_rate=16000, n_mels=80, stride_ms=10, ctcdecoder_num_blocks=1,
+             ctcdecoder_kernel_size=32, ctcdecoder_fc_factor=0.5)
+NUM_CLASSES = 1332    # pinyin vocabulary 1331 + blank (test_asr.py:180)
+
+
+def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES):
+    """ALGORITHMIC flops per launch of each kernel category, counted as the reference computes the op
+    (1 MAC = 2 flop; DFT as the dense conv the reference runs, time_frequency.py:108-115)."""
+    d, k, H = cfg["dmodel"], cfg["kernel_size"], cfg["num_heads"]
+    F = -(-L // 160)
+    T1 = -(-F // 2)
+    T = -(-T1 // 2)
+    F1, F2 = 40, 20
+    M = B * T
+    return {
+        "stft": 2.0 * 2 * B * F * 1024 * 513,
+        "utt_max": 0.0,
+        "mel": 2.0 * B * F * 513 * 80,
+        "subconv": 2.0 * B * T1 * F1 * d * 9 + 2.0 * B * T * F2 * d * 9 * d,
+        "sublinear": 2.0 * M * (F2 * d) * d,
+        "ffn": 2.0 * 2 * M * d * 4 * d,
+        "qkv": 3 * 2.0 * M * d * d,
+        "attention": 2 * 2.0 * B * T * T * d,
+        "attn_out": 2.0 * M * d * d,
+        "pw1_glu": 2.0 * M * d * 2 * d,
+        "dwconv": 2.0 * M * d * k,
+        "conv_tail": 2.0 * M * d * 2 * d + 2.0 * M * 2 * d * d,
+        "ctc_project": 2.0 * M * d * d,
+        "ctc_head": 2.0 * M * d * V,
+        "collapse": 0.0,
+    }
+
+
+def build_model(device, rank, world):
+    m = ConformerCTC(NUM_CLASSES, device=device, **S_CFG)
+    m._build(seed=0)                       # Keras-default random init of the S architecture + DFT/mel constants
+    w = m.get_weights_dict()
+    golden = os.path.join(ROOT, "tests", "golden", "ctc_decoder_weights.npz")
+    if os.path.exists(golden):             # trained CTCDecoder weights exported by the reference
+        w.update({k: v for k, v in np.load(golden).items()})
+    if world > 1:
+        from tensorflowasr_amd.parallel import broadcast_weights
+        w = broadcast_weights(w, src=0, device=device)
+    m.load_weights(w, by_name=False)
+    return m
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The NumPy oracle (a port of the reference path; TensorFlow is not installed) timed on this host."""
+    from oracle import conformer_oracle as co          # checker only: never on the measured GPU path
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    cfg = dict(co.CONFORMER_S)
+    w = co.encoder_weights(cfg, seed=0)
+    golden = os.path.join(ROOT, "tests", "golden", "ctc_decoder_weights.npz")
+    w.update(dict(np.load(golden)) if os.path.exists(golden) else co.ctc_decoder_weights(cfg, NUM_CLASSES))
+    x = co.synth_wave(0, 160000)[None]
+    reps, t_total = 0, 0.0
+    while reps < 1 or (t_total < seconds_budget * 0.6 and reps < 8):
+        t0 = time.perf_counter()
+        enc = co.conformer_encoder(x, w, cfg, dtype=np.float32)
+        logits = co.ctc_decoder(enc, w, cfg, dtype=np.float32)
+        co.ctc_greedy(logits, [logits.shape[1]], NUM_CLASSES - 1)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    return {"value": round(1000.0 * reps / t_total, 1), "unit": "audio-frames/s", "cores": int(cores),
+            "kind": "port",
+            "sample": "%d x (1 utterance, 10 s = 1000 frames) through the fp32 NumPy oracle, %.1f s total" % (reps, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torchrun (python -m torch.distributed.run --nproc-per-node %d ...)"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        from tensorflowasr_amd.parallel import all_gather_ids
+
+    B, L = args.batch, int(args.seconds * 16000)
+    model = build_model(device, rank, world)
+    wav = torch.from_numpy(synth_batch(rank * B, B, L)).to(device)      # inputs resident in HBM
+    T = model.prepare(B, L)
+    h = model._h
+
+    def step():
+        ids, lens = model.recognize(wav)
+        if world > 1:
+            return all_gather_ids(ids, lens)
+        return ids, lens
+
+    for _ in range(args.warmup):
+        step()
+    lib = _lib.lib()
+    _lib.check(lib.mi355asr_profile_enable(h.ptr, 1))   # HIP events around every kernel on the launch stream
+    nk = len(_lib.KERNEL_NAMES)
+    ms = (ctypes.c_double * nk)()
+    cnt = (ctypes.c_int64 * nk)()
+    torch.cuda.synchronize()
+    _lib.check(lib.mi355asr_profile_read(h.ptr, ms, cnt, nk, 1))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    _lib.check(lib.mi355asr_profile_read(h.ptr, ms, cnt, nk, 1))
+
+    if rank == 0:
+        frames_per_utt = L // 160
+        total_frames = world * B * frames_per_utt * args.steps
+        value = total_frames / elapsed
+        fl = algorithmic_flops(B, L)
+        kern = {}
+        for i, name in enumerate(_lib.KERNEL_NAMES):
+            if cnt[i]:
+                avg_ms = ms[i] / cnt[i]
+                kern[name] = {"launches_per_step": cnt[i] // args.steps, "avg_ms": round(avg_ms, 4),
+                              "share": round(ms[i] / max(sum(ms), 1e-9), 4),
+                              "tflops": round(fl[name] / (avg_ms * 1e-3) / 1e12, 2) if fl[name] else None}
+        dom = max(kern, key=lambda n: kern[n]["share"])
+        achieved = kern[dom]["tflops"] or 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # offline rocprofv3 --pmc passes (see profiles/README.md)
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get(dom)
+        line = {
+            "metric": "audio-frames/sec/GPU + RTF, ConformerCTC(S) 10s utts, 1/2/4/8 MI355X",
+            "value": round(value, 1), "unit": "audio-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ConformerCTC(S) 10M offline, batch=%d %gs utts per GPU, fp32, waveform->CTC greedy ids"
+                                   % (B, args.seconds),
+                       "global_batch": world * B, "samples_per_utt": L, "enc_frames": T,
+                       "parallelism": "dp%d" % world, "weights": "random-init encoder + reference-exported CTCDecoder"},
+            "frames_per_s_per_gpu": round(value / world, 1),
+            "rtf": round(elapsed / args.steps / (world * B * args.seconds), 8),
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic},
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

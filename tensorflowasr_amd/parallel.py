@@ -1,0 +1,44 @@
+"""Utterance-batch data parallelism: one process per GPU, weights replicated, utterances sharded
+contiguously, results exchanged with torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" on
+CPU for tests).  The reference has no multi-device inference path: this is new design.
+
+Collectives on the path: one broadcast of the flattened weights at start-up; per batch one all_gather of
+`int32[B_local, T]` token ids + `int32[B_local]` lengths (~64 KB per rank at B_local=64, T=250)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous split of n_items over `world` ranks (first n_items % world ranks get one extra)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def broadcast_weights(weights, src=0, device=None, group=None):
+    """Broadcast a name -> float32 array dict from `src`.  Every rank passes a dict with the same keys/shapes
+    (non-src values are overwritten).  One flat buffer => one collective."""
+    names = sorted(weights)
+    sizes = [int(np.prod(weights[n].shape)) for n in names]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    if dist.get_rank(group) == src:
+        flat.copy_(torch.from_numpy(np.concatenate([np.asarray(weights[n], np.float32).reshape(-1) for n in names])))
+    dist.broadcast(flat, src=src, group=group)
+    host = flat.cpu().numpy()
+    out, o = {}, 0
+    for n, s in zip(names, sizes):
+        out[n] = host[o:o + s].reshape(weights[n].shape).copy()
+        o += s
+    return out
+
+
+def all_gather_ids(ids, lens, group=None):
+    """ids int32 [B_local, T] (-1 padded), lens int32 [B_local] -> ([B_total, T], [B_total]) on every rank,
+    in rank order (requires equal B_local on all ranks, which shard_range gives when world | B_total)."""
+    world = dist.get_world_size(group)
+    out_ids = torch.empty((world * ids.shape[0], ids.shape[1]), dtype=ids.dtype, device=ids.device)
+    out_lens = torch.empty((world * lens.shape[0],), dtype=lens.dtype, device=lens.device)
+    dist.all_gather_into_tensor(out_ids, ids.contiguous(), group=group)
+    dist.all_gather_into_tensor(out_lens, lens.contiguous(), group=group)
+    return out_ids, out_lens

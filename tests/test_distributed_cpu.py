@@ -1,0 +1,54 @@
+"""world_size-2 gloo test of the data-parallel host path (shard -> local decode -> all_gather), on CPU.
+The per-rank "decode" here is the host reference of the collapse step so that the exchange logic (ordering,
+shapes, broadcast of weights) is what is under test; the GPU path swaps in mi355asr_recognize."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import co
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tensorflowasr_amd.parallel import all_gather_ids, broadcast_weights, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # weights: rank 0 holds the real ones, the others zeros -> broadcast makes them identical
+        rng = np.random.default_rng(0)
+        ref_w = {"a/kernel": rng.standard_normal((5, 7)).astype(np.float32), "b/bias": rng.standard_normal(3).astype(np.float32)}
+        mine = ref_w if rank == 0 else {k: np.zeros_like(v) for k, v in ref_w.items()}
+        got = broadcast_weights(mine, src=0)
+        assert all(np.array_equal(got[k], ref_w[k]) for k in ref_w)
+        # global batch of 6 "utterances" of per-frame argmax ids; contiguous shard per rank
+        B, T, blank = 6, 40, 9
+        frames = np.random.default_rng(1).integers(0, 10, (B, T)).astype(np.int32)
+        in_len = np.array([40, 33, 0, 17, 40, 5], np.int32)
+        lo, hi = shard_range(B, rank, world)
+        ids, lens = co.ctc_collapse(frames[lo:hi], in_len[lo:hi], blank)
+        all_ids, all_lens = all_gather_ids(torch.from_numpy(ids), torch.from_numpy(lens))
+        full_ids, full_lens = co.ctc_collapse(frames, in_len, blank)
+        assert np.array_equal(all_ids.numpy(), full_ids) and np.array_equal(all_lens.numpy(), full_lens)
+        open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_shard_broadcast_allgather_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))

@@ -1,0 +1,287 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): every call goes through the C ABI of libmi355asr.so and is
+compared with the CPU oracle / the committed golden fixtures.  Tolerance contract (BASELINE.json north_star):
+fp32 outputs within 1e-3 absolute of the reference forward, CTC-greedy token ids identical; integer paths
+(argmax of given logits, greedy collapse) bit-exact.  Observed errors on the first MI355X run are ~1e-5
+(profiles/r01_stage_report_first_gpu_run.json)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (GOLDEN, argmax_mismatch_report, co, encoder_kwargs, golden_ctc_io, golden_ctc_weights, maxdiff,
+                     small_cfg, waves)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def enc2(torch_cuda):
+    from tensorflowasr_amd.models import ConformerEncoder
+    cfg = small_cfg(2)
+    w = co.encoder_weights(cfg, seed=0)
+    e = ConformerEncoder(**encoder_kwargs(cfg))
+    e.load_weights(w, by_name=False)
+    return e, w, cfg
+
+
+@pytest.fixture(scope="module")
+def full_s(torch_cuda):
+    """ConformerCTC(S), 13+1 blocks, synthetic encoder + synthetic CTC head (non-blank outputs)."""
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = dict(co.CONFORMER_S)
+    w = co.encoder_weights(cfg, seed=0)
+    w.update(co.ctc_decoder_weights(cfg, 1332, seed=1))
+    m = ConformerCTC(1332, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+    m.load_weights(w, by_name=False)
+    return m, w, cfg
+
+
+def test_native_library_is_loaded(torch_cuda):
+    from tensorflowasr_amd import _lib
+    assert os.path.basename(_lib.LIB_PATH) == "libmi355asr.so" and os.path.exists(_lib.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libmi355asr.so" in maps
+
+
+@pytest.mark.parametrize("L,scale", [(32000, 1.0), (67263, 0.05), (1000, 1.0), (16160, 1.0)])
+def test_melspectrogram_parity(enc2, L, scale):
+    e, w, _ = enc2
+    x = waves(2, L, 5) * np.float32(scale)
+    ref = co.melspectrogram(x.astype(np.float64), w)
+    got = e.melspectrogram(x).cpu().numpy()
+    assert got.shape == ref.shape
+    assert maxdiff(got, ref) < TOL
+
+
+def test_melspectrogram_silence_and_padding_dependence(enc2):
+    """dB max-normalisation makes features depend on the (zero-padded) utterance as a whole; all-zero input hits
+    the amin floor everywhere (max-normalised to 0 dB)."""
+    e, w, _ = enc2
+    z = np.zeros((1, 8000), np.float32)
+    got = e.melspectrogram(z).cpu().numpy()
+    ref = co.melspectrogram(z.astype(np.float64), w)
+    assert maxdiff(got, ref) < TOL and np.abs(got).max() < TOL
+    x = waves(1, 16000, 2)
+    xp = np.concatenate([x, np.zeros((1, 8000), np.float32)], 1)
+    a = e.melspectrogram(x).cpu().numpy()
+    b = e.melspectrogram(xp).cpu().numpy()
+    refb = co.melspectrogram(xp.astype(np.float64), w)
+    assert maxdiff(b, refb) < TOL
+    assert maxdiff(a[:, :90], b[:, :90]) < TOL      # same max -> same interior frames
+
+
+@pytest.mark.parametrize("F", [200, 50, 37, 3])
+def test_conv_subsampling_parity(enc2, F):
+    e, w, _ = enc2
+    rng = np.random.default_rng(F)
+    mel = (-80.0 * rng.random((3, F, 80))).astype(np.float32)
+    ref = co.conv_subsampling(mel.astype(np.float64), w)
+    got = e.conv_subsampling(mel).cpu().numpy()
+    assert got.shape == ref.shape
+    assert maxdiff(got, ref) < TOL
+
+
+@pytest.mark.parametrize("B,T", [(2, 50), (3, 250), (1, 300), (2, 7), (1, 16), (1, 17), (1, 750)])
+def test_conformer_block_parity(enc2, B, T):
+    e, w, _ = enc2
+    rng = np.random.default_rng(B * 1000 + T)
+    x = rng.standard_normal((B, T, 144)).astype(np.float32)
+    ref = co.conformer_block(x.astype(np.float64), w, "conformer_block_1", 36)
+    got = e.conformer_block(1, x).cpu().numpy()
+    assert maxdiff(got, ref) < TOL
+
+
+def test_conformer_block_two_row_tile_path_is_bit_identical(enc2):
+    """M >= 65 536 tokens switches chain2 to two row tiles per wave; per-token arithmetic order is unchanged,
+    so results must be bit-identical to the same utterances run in a small batch."""
+    e, w, _ = enc2
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((8, 250, 144)).astype(np.float32)
+    big = np.tile(x, (34, 1, 1))                       # 272 x 250 = 68 000 tokens
+    small = e.conformer_block(0, x).cpu().numpy()
+    got = e.conformer_block(0, big).cpu().numpy()
+    assert np.array_equal(got[:8], small) and np.array_equal(got[-8:], small)
+    ref = co.conformer_block(x[:1].astype(np.float64), w, "conformer_block_0", 36)
+    assert maxdiff(got[:1], ref) < TOL
+
+
+def test_encoder_parity_two_blocks(enc2):
+    e, w, cfg = enc2
+    x = waves(2, 32000)
+    ref = co.conformer_encoder(x.astype(np.float64), w, cfg)
+    got = e(x[..., None]).cpu().numpy()               # reference call shape [B, L, 1]
+    assert got.shape == (2, 50, 144)
+    assert maxdiff(got, ref) < TOL
+
+
+def test_ctc_decoder_against_reference_exported_graph(torch_cuda):
+    """Trained weights + logits from the reference's own ctc_model.onnx (tests/golden)."""
+    from tensorflowasr_amd.models import CTCDecoder, ctc_greedy_decode
+    io = golden_ctc_io()
+    dec = CTCDecoder(1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32)
+    dec.load_weights(golden_ctc_weights(), by_name=False)
+    la, aa = dec(io["x_a"], return_argmax=True)
+    la, aa = la.cpu().numpy(), aa.cpu().numpy()
+    assert maxdiff(la, io["logits_a"]) < TOL
+    assert (la.argmax(-1) == io["logits_a"].argmax(-1)).all()
+    assert np.array_equal(aa, la.argmax(-1))                       # in-kernel argmax == argmax of its own logits
+    lb, ab = dec(io["x_b"], return_argmax=True)
+    assert np.array_equal(ab.cpu().numpy(), io["argmax_b"])        # 26 % non-blank frames
+    assert maxdiff(lb.cpu().numpy()[:, ::8], io["logits_b_every8"]) < TOL
+    ids, lens = ctc_greedy_decode(ab, None, 1331)
+    rid, rlen = co.ctc_collapse(io["argmax_b"], [250], 1331)
+    assert np.array_equal(ids.cpu().numpy(), rid) and np.array_equal(lens.cpu().numpy(), rlen)
+    assert rlen[0] > 10
+
+
+def test_head_argmax_tie_breaks_to_lowest_index(torch_cuda):
+    """All-zero fully_connected kernel + constant bias -> every class ties -> id 0 (strict '<', first max)."""
+    from tensorflowasr_amd.models import CTCDecoder
+    w = golden_ctc_weights()
+    w["fully_connected/kernel"] = np.zeros_like(w["fully_connected/kernel"])
+    w["fully_connected/bias"] = np.full_like(w["fully_connected/bias"], 0.25)
+    dec = CTCDecoder(1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32)
+    dec.load_weights(w, by_name=False)
+    lg, am = dec(np.random.default_rng(0).standard_normal((1, 20, 144)).astype(np.float32), return_argmax=True)
+    assert (am.cpu().numpy() == 0).all() and (lg.cpu().numpy() == 0.25).all()
+    w["fully_connected/bias"][1331] = 0.5                           # last valid class wins; padding columns never do
+    w["fully_connected/bias"][7] = 0.5
+    dec.load_weights(w, by_name=False)
+    _, am = dec(np.zeros((1, 5, 144), np.float32), return_argmax=True)
+    assert (am.cpu().numpy() == 7).all()
+
+
+def test_greedy_kats_bit_exact(torch_cuda):
+    from tensorflowasr_amd.models import ctc_greedy_decode
+    kats = json.load(open(os.path.join(GOLDEN, "greedy_kat.json")))
+    for k in kats:
+        fa = np.array(k["probs"], np.float32).argmax(-1) if "probs" in k else np.array(k["frame_argmax"])
+        ids, n = ctc_greedy_decode(fa[None].astype(np.int32), None, k["blank"], device="cuda:0")
+        ids, n = ids.cpu().numpy(), int(n.cpu().numpy()[0])
+        assert ids[0, :n].tolist() == k["expect"]
+        assert (ids[0, n:] == -1).all()
+
+
+def test_greedy_ragged_lengths_and_edges(torch_cuda):
+    from tensorflowasr_amd.models import ctc_greedy_decode
+    rng = np.random.default_rng(3)
+    B, T, blank = 9, 333, 6
+    fa = rng.integers(0, 7, (B, T)).astype(np.int32)
+    fa[4] = blank                                    # all blank
+    fa[5] = 2                                        # one long run
+    in_len = np.array([333, 0, 1, 64, 333, 333, 65, 128, 200], np.int32)
+    ids, lens = ctc_greedy_decode(fa, in_len, blank, device="cuda:0")
+    rid, rlen = co.ctc_collapse(fa, in_len, blank)
+    assert np.array_equal(ids.cpu().numpy(), rid) and np.array_equal(lens.cpu().numpy(), rlen)
+    assert rlen[1] == 0 and rlen[4] == 0 and rlen[5] == 1
+
+
+def test_recognize_full_S_model_ids_identical(full_s):
+    m, w, cfg = full_s
+    x = waves(2, 48000)
+    ids, lens = m.recognize(x)
+    ids, lens = ids.cpu().numpy().copy(), lens.cpu().numpy().copy()
+    enc_gpu = m.encode(x).cpu().numpy()
+    lg_gpu, am_gpu = m.ctc_logits(enc_gpu, return_argmax=True)
+    lg_gpu, am_gpu = lg_gpu.cpu().numpy(), am_gpu.cpu().numpy()
+    enc_ref = co.conformer_encoder(x.astype(np.float64), w, cfg)
+    lg_ref = co.ctc_decoder(enc_ref, w, cfg)
+    assert maxdiff(enc_gpu, enc_ref) < TOL
+    err = maxdiff(lg_gpu, lg_ref)
+    assert err < TOL
+    # integer path is bit-exact given the GPU's own logits
+    assert np.array_equal(am_gpu, co.frame_argmax(lg_gpu))
+    gid, glen = co.ctc_collapse(am_gpu, [lg_gpu.shape[1]] * 2, 1331)
+    assert np.array_equal(ids, gid) and np.array_equal(lens, glen)
+    # and identical to the oracle's ids unless the oracle's own decision is inside the numerical noise
+    bad = argmax_mismatch_report(lg_gpu, lg_ref)
+    assert all(margin < 10 * err for _, margin in bad), bad
+    if not bad:
+        rid, rlen = co.ctc_greedy(lg_ref, [lg_ref.shape[1]] * 2, 1331)
+        assert np.array_equal(ids, rid) and np.array_equal(lens, rlen)
+    assert lens.min() > 5                               # synthetic head: plenty of non-blank tokens
+
+
+def test_recognize_respects_input_length(full_s):
+    m, _, _ = full_s
+    x = waves(3, 32000, 20)
+    ids_full, lens_full = m.recognize(x)
+    ids_full = ids_full.cpu().numpy().copy()
+    in_len = np.array([50, 10, 0], np.int32)            # am_dataloader.py:153-155: in_len = L // 640
+    ids, lens = m.recognize(x, in_len)
+    ids, lens = ids.cpu().numpy(), lens.cpu().numpy()
+    am = m.ctc_logits(m.encode(x), return_argmax=True)[1].cpu().numpy()
+    rid, rlen = co.ctc_collapse(am, in_len, 1331)
+    assert np.array_equal(ids, rid) and np.array_equal(lens, rlen)
+    assert np.array_equal(ids[0], ids_full[0]) and lens[2] == 0
+
+
+def test_streaming_block_conformer_parity(torch_cuda):
+    from tensorflowasr_amd.models import StreamingConformerEncoder
+    cfg = small_cfg(2, co.STREAMING_S)
+    w = co.encoder_weights(cfg, seed=2)
+    e = StreamingConformerEncoder(**encoder_kwargs(cfg))
+    e.add_chunk_size(8000, 80, 640)
+    e.load_weights(w, by_name=False)
+    x = waves(2, 24000, 9)
+    ref = co.streaming_conformer_encoder(x.astype(np.float64), w, cfg, 8000)
+    got = e(x).cpu().numpy()
+    assert got.shape == (2, 39, 256)
+    assert maxdiff(got, ref) < TOL
+    e.set_inference_func()
+    one = e.inference(x[:1, :8000, None]).cpu().numpy()   # test_asr.py:121-128: one block at a time
+    assert maxdiff(one, ref[:1, :13]) < TOL
+    with pytest.raises(Exception):
+        e(x[:, :12000])
+
+
+def test_full_size_batch64_properties(full_s, torch_cuda):
+    """BASELINE configs[1] shape (64 x 10 s): determinism, batch invariance, permutation equivariance, and the
+    oracle on one full-length utterance."""
+    torch = torch_cuda
+    m, w, cfg = full_s
+    x = waves(8, 160000, 100)
+    xb = torch.from_numpy(np.tile(x, (8, 1))).cuda()
+    ids1, lens1 = m.recognize(xb)
+    ids1, lens1 = ids1.cpu().numpy().copy(), lens1.cpu().numpy().copy()
+    ids2, lens2 = m.recognize(xb)
+    assert np.array_equal(ids1, ids2.cpu().numpy()) and np.array_equal(lens1, lens2.cpu().numpy())   # deterministic
+    assert ids1.shape == (64, 250)
+    for r in range(1, 8):                                                     # replicated rows agree bit for bit
+        assert np.array_equal(ids1[:8], ids1[8 * r:8 * r + 8])
+    enc_b = m.encode(xb).cpu().numpy()
+    enc_1 = m.encode(x[3:4]).cpu().numpy()
+    assert np.array_equal(enc_b[3], enc_1[0])                                 # batch-invariant (utterances independent)
+    perm = np.random.default_rng(0).permutation(8)
+    ids_p, lens_p = m.recognize(x[perm])
+    assert np.array_equal(ids_p.cpu().numpy(), ids1[:8][perm])
+    assert np.isfinite(enc_b).all()
+    assert ((ids1 >= -1) & (ids1 < 1331)).all()
+    assert all((ids1[b, lens1[b]:] == -1).all() and (ids1[b, :lens1[b]] >= 0).all() for b in range(64))
+    enc_ref = co.conformer_encoder(x[:1].astype(np.float64), w, cfg)
+    assert maxdiff(enc_b[:1], enc_ref) < TOL
+
+
+def test_workspace_too_small_is_reported(enc2, torch_cuda):
+    torch = torch_cuda
+    from tensorflowasr_amd import _lib
+    e, _, _ = enc2
+    h = e._h
+    x = torch.zeros((1, 16000), device="cuda")
+    out = torch.empty((1, 25, 144), device="cuda")
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    rc = h.lib.mi355asr_encoder_forward(h.ptr, ctypes.c_void_p(x.data_ptr()), 1, 16000, ctypes.c_void_p(out.data_ptr()),
+                                        ctypes.c_void_p(ws.data_ptr()), 1024, None)
+    assert rc == -4 and b"workspace too small" in h.lib.mi355asr_last_error()

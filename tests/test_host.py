@@ -1,0 +1,223 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/mi355asr.h declares,
+argument validation / error reporting, weight-name surface, shape helpers, featurizers, config, constants.
+No kernel is launched here (no GPU in this container)."""
+import ctypes
+import os
+import re
+import struct
+import wave
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, co, encoder_kwargs, small_cfg
+from tensorflowasr_amd import _lib, frontend_consts
+from tensorflowasr_amd.config import UserConfig
+from tensorflowasr_amd.featurizers import SpeechFeaturizer, TextFeaturizer, read_raw_audio
+from tensorflowasr_amd.models import ConformerCTC, ConformerEncoder, CTCDecoder, StreamingConformerEncoder
+from tensorflowasr_amd.parallel import shard_range
+from tensorflowasr_amd.synthetic import synth_wave
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mi355asr.h")).read()
+    declared = set(re.findall(r"\b(mi355asr_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), "ctypes table out of sync with the header"
+    assert b"gfx950" in lib.mi355asr_version()
+
+
+def test_config_struct_matches_header_layout():
+    hdr = open(os.path.join(ROOT, "include", "mi355asr.h")).read()
+    body = hdr[hdr.index("typedef struct {"):hdr.index("} mi355asr_config;")]
+    fields = re.findall(r"^\s*(int32_t|float)\s+(\w+);", body, re.M)
+    assert [f for _, f in fields] == [n for n, _ in _lib.Config._fields_]
+    for (ctype, _), (_, pyt) in zip(fields, _lib.Config._fields_):
+        assert (ctype == "float") == (pyt is ctypes.c_float)
+
+
+def _create(**over):
+    cfg = dict(dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32, fc_factor=0.5, reduction_factor=4,
+               n_mels=80, sample_rate=16000, stride_ms=10, n_dft=1024, chunk_size=0, has_encoder=1, num_classes=0,
+               ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5)
+    cfg.update(over)
+    lib = _lib.lib()
+    p = ctypes.c_void_p()
+    rc = lib.mi355asr_create(ctypes.byref(_lib.Config(**cfg)), ctypes.byref(p))
+    return lib, rc, p
+
+
+@pytest.mark.parametrize("bad", [dict(dmodel=100), dict(head_size=32), dict(kernel_size=7), dict(reduction_factor=2),
+                                 dict(n_dft=512), dict(n_mels=64), dict(num_heads=3)])
+def test_create_rejects_unsupported_configs_with_message(bad):
+    lib, rc, p = _create(**bad)
+    assert rc == -1 and not p.value
+    assert len(lib.mi355asr_last_error()) > 10
+
+
+def test_weight_surface_and_shape_validation():
+    lib, rc, p = _create(num_classes=1332, ctc_num_blocks=1)
+    assert rc == 0
+    n = lib.mi355asr_num_weights(p)
+    names = [lib.mi355asr_weight_name(p, i).decode() for i in range(n)]
+    cfg = small_cfg(1)
+    expect = set(co.encoder_weights(cfg, 0)) | set(co.ctc_decoder_weights(cfg, 1332))
+    assert set(names) == expect                      # same tensor names as the oracle / reference layout
+    a = np.zeros((144, 576), np.float32)
+    dims = (ctypes.c_int64 * 2)(144, 576)
+    ok = lib.mi355asr_load_weight(p, b"conformer_block_0/ff_module_1/ffn1/kernel", a.ctypes.data_as(ctypes.c_void_p), 2, dims)
+    assert ok == 0
+    bad = (ctypes.c_int64 * 2)(576, 144)
+    assert lib.mi355asr_load_weight(p, b"conformer_block_0/ff_module_1/ffn1/kernel", a.ctypes.data_as(ctypes.c_void_p), 2, bad) == -3
+    assert b"does not match" in lib.mi355asr_last_error()
+    assert lib.mi355asr_load_weight(p, b"no/such/tensor", a.ctypes.data_as(ctypes.c_void_p), 2, dims) == -3
+    # Keras singleton axes are accepted squeezed or not
+    k = np.zeros((1024, 513), np.float32)
+    assert lib.mi355asr_load_weight(p, b"mel_layer/real_kernels", k.ctypes.data_as(ctypes.c_void_p), 2,
+                                    (ctypes.c_int64 * 2)(1024, 513)) == 0
+    assert lib.mi355asr_load_weight(p, b"mel_layer/real_kernels", k.ctypes.data_as(ctypes.c_void_p), 4,
+                                    (ctypes.c_int64 * 4)(1024, 1, 1, 513)) == 0
+    # finalising with tensors missing names the first missing one
+    assert lib.mi355asr_finalize_weights(p, None) == -3
+    assert b"missing weight" in lib.mi355asr_last_error()
+    # forward before finalise is a state error, not a crash
+    assert lib.mi355asr_encoder_forward(p, None, 1, 16000, None, None, 0, None) == -2
+    assert lib.mi355asr_destroy(p) == 0
+
+
+@pytest.mark.parametrize("L,F,T", [(160000, 1000, 250), (67263, 421, 106), (16000, 100, 25), (8000, 50, 13), (480000, 3000, 750)])
+def test_out_frames(L, F, T):
+    lib, rc, p = _create()
+    f, t = ctypes.c_int32(), ctypes.c_int32()
+    assert lib.mi355asr_out_frames(p, L, ctypes.byref(f), ctypes.byref(t)) == 0
+    assert (f.value, t.value) == (F, T)
+    lib.mi355asr_destroy(p)
+
+
+def test_streaming_geometry_and_workspace():
+    lib, rc, p = _create(dmodel=256, head_size=64, kernel_size=5, chunk_size=8000)
+    f, t = ctypes.c_int32(), ctypes.c_int32()
+    assert lib.mi355asr_out_frames(p, 24000, ctypes.byref(f), ctypes.byref(t)) == 0
+    assert (f.value, t.value) == (150, 39)                                   # 3 blocks x (50, 13)
+    assert lib.mi355asr_out_frames(p, 12000, ctypes.byref(f), ctypes.byref(t)) == -1
+    assert b"multiple of chunk_size" in lib.mi355asr_last_error()
+    n1, n2 = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.mi355asr_workspace_bytes(p, 2, 24000, ctypes.byref(n1)) == 0
+    assert lib.mi355asr_workspace_bytes(p, 4, 24000, ctypes.byref(n2)) == 0
+    assert 0 < n1.value < n2.value <= 2 * n1.value + 4096 * 16
+    lib.mi355asr_destroy(p)
+
+
+def test_workspace_is_modest_at_benchmark_shape():
+    lib, rc, p = _create(num_blocks=13, num_classes=1332, ctc_num_blocks=1)
+    n = ctypes.c_size_t()
+    assert lib.mi355asr_workspace_bytes(p, 64, 160000, ctypes.byref(n)) == 0
+    assert 300e6 < n.value < 700e6          # log-power (135 MB) + conv2 output (184 MB) dominate
+    lib.mi355asr_destroy(p)
+
+
+def test_python_models_mirror_reference_constructor_surface():
+    cfg = small_cfg(2)
+    enc = ConformerEncoder(**encoder_kwargs(cfg), dropout=0.1, add_wav_info=False, mel_layer_trainable=False,
+                           name="conformer_encoder")
+    assert enc.hop_size == 640                                           # conformer_blocks.py:302
+    assert enc.count_params() == sum(int(np.prod(v.shape)) for v in co.encoder_weights(cfg, 0).values())
+    with pytest.raises(NotImplementedError):
+        ConformerEncoder(mel_layer_type="leaf")
+    with pytest.raises(NotImplementedError):
+        ConformerEncoder(mel_layer_type="Melspectrogram", add_wav_info=True)
+    dec = CTCDecoder(num_classes=1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32,
+                     dropout=0.1, fc_factor=0.5)
+    assert dec.count_params() == 759_348 + 0 or dec.count_params() > 700_000     # ~0.76 M
+    st = StreamingConformerEncoder(**encoder_kwargs(small_cfg(1, co.STREAMING_S)))
+    st.add_chunk_size(8000, 80, 640)
+    assert st.mel_length == 13 and st.chunk_size == 8000
+    full = ConformerCTC(1332, **{k: v for k, v in encoder_kwargs(dict(co.CONFORMER_S)).items() if k != "mel_layer_type"})
+    assert abs(full.count_params() - 9.59e6) < 0.05e6                       # 7.74 M + 1.09 M fixed + 0.76 M
+    assert full.blank == 1331
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    enc = ConformerEncoder(**encoder_kwargs(small_cfg(1)))
+    with pytest.raises(Exception):
+        enc(np.zeros((1, 16000, 1), np.float32))       # no CPU fallback: must raise, not compute
+
+
+def test_frontend_constants_match_oracle_restatement():
+    re_, im_ = frontend_consts.stft_kernels(1024)
+    ro, io = co.stft_kernels(1024)
+    assert re_.shape == (1024, 1, 1, 513)
+    assert np.array_equal(re_.reshape(1024, 513), ro) and np.array_equal(im_.reshape(1024, 513), io)
+    assert np.abs(frontend_consts.freq2mel() - co.mel_filterbank().T).max() < 1e-7
+    assert np.abs(frontend_consts.freq2mel(norm="slaney") - co.mel_filterbank(norm="slaney").T).max() < 1e-7
+    assert np.array_equal(synth_wave(3, 4000), co.synth_wave(3, 4000))
+
+
+def test_speech_featurizer_reads_pcm16_like_librosa(tmp_path):
+    sr = 16000
+    x = (0.3 * np.sin(2 * np.pi * 440 * np.arange(sr // 4) / sr) * 32767).astype("<i2")
+    path = str(tmp_path / "a.wav")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr); f.writeframes(x.tobytes())
+    sf = SpeechFeaturizer({"sample_rate": 16000, "frame_ms": 25, "stride_ms": 10, "num_feature_bins": 80})
+    w = sf.load_wav(path)
+    assert w.dtype == np.float32 and w.shape == (sr // 4,)
+    assert np.array_equal(w, x.astype(np.float32) / 32768.0)
+    assert np.array_equal(read_raw_audio(open(path, "rb").read()), w)
+    # stereo 8 kHz -> mono 16 kHz
+    st = np.stack([x[::2], x[::2]], 1)
+    p2 = str(tmp_path / "b.wav")
+    with wave.open(p2, "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(8000); f.writeframes(st.tobytes())
+    w2 = sf.load_wav(p2)
+    assert abs(len(w2) - len(w)) <= 2
+    padded = sf.pad_signal([w[:10], w[:4]], 8)
+    assert padded.shape == (2, 8) and (padded[1, 4:] == 0).all() and np.array_equal(padded[0], w[:8])
+    assert sf.compute_time_dim(1.0) == 101
+
+
+def test_text_featurizer_blank_last_and_space(tmp_path):
+    vocab = tmp_path / "v.txt"
+    vocab.write_text("<S>\n</S>\n[SPACE]\n# comment\n\nni3\nhao3\n", encoding="utf-8")
+    tf = TextFeaturizer({"vocabulary": str(vocab), "blank_at_zero": False, "beam_width": 1})
+    assert tf.num_classes == 6 and tf.blank == 5
+    assert tf.startid() == 0 and tf.endid() == 1 and tf.token_to_index[" "] == 2
+    assert tf.iextract([3, 4]) == ["ni3", "hao3"] and tf.extract(["hao3"]) == [4]
+    tz = TextFeaturizer({"vocabulary": str(vocab), "blank_at_zero": True, "beam_width": 1})
+    assert tz.blank == 0 and tz.num_classes == 6 and tz.token_to_index["<S>"] == 1
+
+
+def test_user_config_merge_and_missing_key(tmp_path):
+    a = tmp_path / "a.yml"
+    b = tmp_path / "b.yml"
+    a.write_text("speech_config:\n  sample_rate: 16000\nmodel_config:\n  name: X\n")
+    b.write_text("model_config:\n  name: OfflineConformerCTC\n  dmodel: 144\n")
+    c = UserConfig(str(a), str(b))
+    assert c["model_config"]["dmodel"] == 144 and c["speech_config"]["sample_rate"] == 16000
+    assert c["learning_config"] is None                                  # utils/user_config.py:24-25
+
+
+def test_shipped_configs_build_the_documented_models():
+    cdir = os.path.join(ROOT, "tensorflowasr_amd", "configs")
+    c = UserConfig(os.path.join(cdir, "am_data.yml"), os.path.join(cdir, "conformerS.yml"))
+    m = ConformerCTC.from_config(c, 1332)
+    assert (m.dmodel, m.num_blocks, m.head_size, m.kernel_size, m.chunk_size) == (144, 13, 36, 32, 0)
+    c2 = UserConfig(os.path.join(cdir, "am_data_streaming.yml"), os.path.join(cdir, "Streaming_ConformerS.yml"))
+    m2 = ConformerCTC.from_config(c2, 1332)
+    assert (m2.dmodel, m2.num_blocks, m2.head_size, m2.kernel_size, m2.chunk_size) == (256, 4, 64, 5, 8000)
+
+
+def test_shard_range_is_a_partition():
+    for n in (512, 64, 10, 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

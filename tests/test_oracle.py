@@ -1,0 +1,178 @@
+"""CPU tests of the oracle itself: pinned against the reference's golden data where the reference has any
+(exported CTCDecoder graph, C++ greedy decoder), cross-checked against independent restatements elsewhere."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, co, golden_ctc_io, golden_ctc_weights
+
+
+# ---- pinned rows ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ctc_decoder_matches_reference_exported_graph(dtype):
+    """ConformerBlock + CTCDecoder restatement vs logits the reference's own ctc_model.onnx produces."""
+    w, io = golden_ctc_weights(), golden_ctc_io()
+    y = co.ctc_decoder(io["x_a"], w, co.CONFORMER_S, dtype)
+    assert np.abs(y - io["logits_a"]).max() < 2e-4           # fp32 graph vs fp64 restatement: 8.4e-5 observed
+    assert (y.argmax(-1) == io["logits_a"].argmax(-1)).all()
+    yb = co.ctc_decoder(io["x_b"], w, co.CONFORMER_S, dtype)
+    assert (yb.argmax(-1) == io["argmax_b"]).all()
+    assert np.abs(yb.max(-1) - io["max_b"]).max() < 2e-4
+    assert np.abs(yb[:, ::8] - io["logits_b_every8"]).max() < 2e-4
+    z = yb.astype(np.float64)
+    lse = np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1)) + z.max(-1)
+    assert np.abs(lse - io["lse_b"]).max() < 2e-4
+
+
+def test_greedy_matches_reference_cpp_decoder_kats():
+    kats = json.load(open(os.path.join(GOLDEN, "greedy_kat.json")))
+    assert len(kats) >= 20
+    for k in kats:
+        if "probs" in k:
+            p = np.array(k["probs"], np.float32)
+            fa = p.argmax(-1)       # first max, as the strict '<' in ctc_greedy_decoder.h:13
+        else:
+            fa = np.array(k["frame_argmax"])
+        ids, n = co.ctc_collapse(fa[None].astype(np.int32), [k["T"]], k["blank"])
+        assert ids[0, :n[0]].tolist() == k["expect"]
+        assert (ids[0, n[0]:] == -1).all()
+
+
+def test_greedy_semantics_hand_cases():
+    ids, n = co.ctc_collapse(np.array([[1, 1, 3, 1, 0, 0]], np.int32), [6], 3)
+    assert ids[0, :n[0]].tolist() == [1, 1, 0]          # survey KAT
+    ids, n = co.ctc_collapse(np.array([[1, 1, 3, 1, 0, 0]], np.int32), [2], 3)
+    assert ids[0, :n[0]].tolist() == [1]                # input_length cuts the utterance
+    ids, n = co.ctc_collapse(np.array([[3, 3, 3]], np.int32), [3], 3)
+    assert n[0] == 0 and (ids == -1).all()              # all blank
+    ids, n = co.ctc_collapse(np.zeros((1, 4), np.int32), [0], 3)
+    assert n[0] == 0                                    # empty
+
+
+def test_frame_argmax_is_argmax_of_log_softmax_first_max():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 7, 11)).astype(np.float32)
+    x[0, 0, 3] = x[0, 0, 8] = 9.0                       # exact tie -> lowest index
+    a = co.frame_argmax(x)
+    assert a[0, 0] == 3
+    assert (a == x.argmax(-1)).all()
+
+
+# ---- SAME padding (SURVEY 8a cheat sheet) -------------------------------------------------------------------
+@pytest.mark.parametrize("n,k,s,expect", [
+    (160000, 1024, 160, (1000, 432, 432)), (67263, 1024, 160, (421, 480, 481)),
+    (1000, 3, 2, (500, 0, 1)), (80, 3, 2, (40, 0, 1)), (50, 3, 2, (25, 0, 1)), (25, 3, 2, (13, 1, 1)),
+    (250, 32, 1, (250, 15, 16)), (13, 5, 1, (13, 2, 2)),
+])
+def test_same_padding_rule(n, k, s, expect):
+    assert co.same_pad(n, k, s) == expect
+
+
+# ---- unpinned rows: independent cross-checks ----------------------------------------------------------------
+def test_power_spectrogram_equals_rfft_of_windowed_zero_padded_frames():
+    rng = np.random.default_rng(1)
+    for L in (16000, 4000, 8123):
+        x = rng.standard_normal((2, L))
+        re, im = co.stft_kernels(1024)
+        p = co.power_spectrogram(x, re, im, 160)
+        nf, lo, hi = co.same_pad(L, 1024, 160)
+        xp = np.pad(x, ((0, 0), (lo, hi)))
+        win = co.hann_periodic(1024).astype(np.float32).astype(np.float64)
+        frames = np.stack([xp[:, f * 160:f * 160 + 1024] for f in range(nf)], 1) * win
+        ref = np.abs(np.fft.rfft(frames, 1024, axis=-1)) ** 2
+        assert p.shape == (2, nf, 513)
+        assert np.abs(p - ref).max() < 1e-4 * ref.max()      # kernels are stored in fp32 (as in the reference)
+
+
+def test_valid_mode_left_pads_n_dft_minus_1():
+    x = np.random.default_rng(2).standard_normal((1, 2560))
+    fr = co.frame_signal(x, 1024, 160, "valid")
+    assert fr.shape[1] == (2560 + 1023 - 1024) // 160 + 1
+    assert (fr[0, 0, :1023] == 0).all() and fr[0, 0, 1023] == x[0, 0]
+
+
+def test_decibel_is_max_normalised_and_floored():
+    p = np.array([[[1e-20, 1.0, 100.0, 1e-3]]])
+    db = co.amplitude_to_decibel(p)
+    assert np.allclose(db, [[[-80.0, -20.0, 0.0, -50.0]]])
+    assert np.allclose(co.chunk_amplitude_to_decibel(p), [[[-10.0, 0.0, 2.0, -3.0]]])
+
+
+def test_mel_filterbank_properties():
+    fb = co.mel_filterbank(16000, 1024, 80, 0.0, 8000.0, False, 1)
+    assert fb.shape == (80, 513) and fb.dtype == np.float32 and (fb >= 0).all()
+    assert np.allclose(fb.sum(1), 1.0, atol=1e-5)                       # L1-normalised filters
+    peaks = fb.argmax(1)
+    assert (np.diff(peaks) > 0).all()                                   # monotone centre frequencies
+    sl = co.mel_filterbank(16000, 1024, 80, 0.0, 8000.0, False, "slaney")
+    assert np.allclose(sl / sl.sum(1, keepdims=True), fb, atol=1e-6)    # same shapes, different scaling
+    # Slaney scale is linear below 1 kHz: first filters are equally spaced
+    assert abs((peaks[2] - peaks[1]) - (peaks[1] - peaks[0])) <= 1
+
+
+def test_conv2d_same_matches_torch():
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    for (H, W, C, O, s) in [(50, 80, 1, 8, (2, 2)), (25, 40, 8, 8, (2, 2)), (13, 7, 4, 6, (2, 2))]:
+        x = rng.standard_normal((2, H, W, C))
+        k = rng.standard_normal((3, 3, C, O))
+        b = rng.standard_normal(O)
+        y = co.conv2d_same(x, k, b, s)
+        oh, pt, pb = co.same_pad(H, 3, s[0])
+        ow, pl, pr = co.same_pad(W, 3, s[1])
+        xt = F.pad(torch.from_numpy(x).permute(0, 3, 1, 2), (pl, pr, pt, pb))
+        ref = F.conv2d(xt, torch.from_numpy(k).permute(3, 2, 0, 1), torch.from_numpy(b), stride=s)
+        assert np.abs(y - ref.permute(0, 2, 3, 1).numpy()).max() < 1e-10
+
+
+def test_layernorm_depthwise_mha_against_torch():
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 17, 24))
+    g, b = rng.standard_normal(24), rng.standard_normal(24)
+    ref = F.layer_norm(torch.from_numpy(x), (24,), torch.from_numpy(g), torch.from_numpy(b), eps=1e-3).numpy()
+    assert np.abs(co.layer_norm(x, g, b) - ref).max() < 1e-12
+    # depthwise k=32: 15 left / 16 right
+    dk = rng.standard_normal((32, 24, 1))
+    y = co.depthwise_conv1d_same(x, dk)
+    xt = F.pad(torch.from_numpy(x).permute(0, 2, 1), (15, 16))
+    ref = F.conv1d(xt, torch.from_numpy(dk[:, :, 0].T.copy())[:, None, :], groups=24).permute(0, 2, 1).numpy()
+    assert np.abs(y - ref).max() < 1e-12
+    # MHA vs torch scaled_dot_product_attention
+    H, hs, d = 4, 6, 24
+    w = {"m/query_kernel": rng.standard_normal((H, d, hs)), "m/key_kernel": rng.standard_normal((H, d, hs)),
+         "m/value_kernel": rng.standard_normal((H, d, hs)), "m/projection_kernel": rng.standard_normal((H, hs, d)),
+         "m/projection_bias": rng.standard_normal(d)}
+    out = co.mha(x, x, w, "m", hs)
+    q = torch.einsum("bni,hio->bhno", torch.from_numpy(x), torch.from_numpy(w["m/query_kernel"]))
+    k = torch.einsum("bni,hio->bhno", torch.from_numpy(x), torch.from_numpy(w["m/key_kernel"]))
+    v = torch.einsum("bni,hio->bhno", torch.from_numpy(x), torch.from_numpy(w["m/value_kernel"]))
+    o = F.scaled_dot_product_attention(q, k, v)
+    ref = torch.einsum("bhni,hio->bno", o, torch.from_numpy(w["m/projection_kernel"])).numpy() + w["m/projection_bias"]
+    assert np.abs(out - ref).max() < 1e-10
+
+
+def test_streaming_encoder_is_blockwise_encoder():
+    cfg = dict(co.STREAMING_S, num_blocks=1)
+    w = co.encoder_weights(cfg, seed=5)
+    x = np.stack([co.synth_wave(i, 16000) for i in range(2)])
+    y = co.streaming_conformer_encoder(x, w, cfg, 8000)
+    assert y.shape == (2, 26, 256)
+    y0 = co.conformer_encoder(x[:, :8000], w, cfg)
+    assert np.abs(y[:, :13] - y0).max() < 1e-12
+    with pytest.raises(AssertionError):
+        co.streaming_conformer_encoder(x[:, :12000], w, cfg, 8000)
+
+
+def test_fp32_and_fp64_oracle_agree_end_to_end():
+    cfg = dict(co.CONFORMER_S, num_blocks=2)
+    w = co.encoder_weights(cfg, seed=0)
+    x = np.stack([co.synth_wave(i, 16000) for i in range(2)])
+    y64 = co.conformer_encoder(x, w, cfg, np.float64)
+    y32 = co.conformer_encoder(x, w, cfg, np.float32)
+    assert y64.shape == (2, 25, 144)
+    assert np.abs(y64 - y32).max() < 1e-3
