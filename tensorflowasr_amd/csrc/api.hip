@@ -538,7 +538,7 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
   dm.NT_dft = ceil_div(dm.NT_dft, 13) * 13;
   dm.NCH_dft = dm.NT_dft / 13;
   dm.LP = ceil_div(8 * dm.NT_dft, 16) * 16;        // log-power row stride (bins), 16-byte aligned rows
-  dm.KBm = ceil_div(dm.nbins, 16);
+  dm.KBm = ceil_div(ceil_div(dm.nbins, 16), 2) * 2;   // sweep_k consumes k-blocks in pairs (zero-padded)
   dm.NTm = c.n_mels / 16;
   dm.st1 = c.reduction_factor / 2;
   same_pad(c.n_mels, 3, 2, &dm.F1, &dm.pf1);
@@ -656,7 +656,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
       [&](int k, int n) { const int bin = n >> 1; return (n & 1) ? im[(size_t)k * nb + bin] : re[(size_t)k * nb + bin]; },
       c.n_dft, 2 * nb, dm.NT_dft));
   const auto& f2m = m->host["mel_layer/freq2mel"].data;
-  o_mel = ab.put(pack_p16([&](int k, int n) { return f2m[(size_t)k * c.n_mels + n]; }, nb, c.n_mels, dm.NTm));
+  o_mel = ab.put(pack_p16([&](int k, int n) { return k < nb ? f2m[(size_t)k * c.n_mels + n] : 0.f; }, dm.KBm * 16, c.n_mels, dm.NTm));
   o_c1w = ab.put(m->host["conv_subsampling/conv1/kernel"].data);  // [3][3][1][d] == [(i*3+j)*d + c]
   o_c1b = ab.put(m->host["conv_subsampling/conv1/bias"].data);
   const auto& c2 = m->host["conv_subsampling/conv2/kernel"].data;              // [3][3][d][d]

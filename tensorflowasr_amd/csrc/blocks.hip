@@ -12,118 +12,144 @@
 //           W1 = SeparableConv1D pointwise kernel, W2 = pw_conv_2
 // The hidden activation never leaves registers: GEMM1's accumulator fragment is GEMM2's operand fragment.
 // =====================================================================================================
-template <int D, int HT, int RT, int CT1, int MODE>
+template <int D, int HT, int NSPLIT, int CT1, int MODE>
 __global__ __launch_bounds__(BLOCK_THREADS) void chain2_kernel(Chain2Args a) {
+  // Work split: a 16-token tile is shared by NSPLIT waves of one block, each owning HT/NSPLIT hidden tiles
+  // (both GEMMs are sliced along the hidden dimension, so the waves never exchange activations; only the
+  // [16 x D] partial outputs are summed through LDS at the end).  At the benchmark shape (1000 token tiles)
+  // this puts 4000 waves on the 1024 SIMDs instead of 1000.
+  // Weight stream: fragments are consumed in batches (one k-block of GEMM1 = CT1 fragments, one hidden tile
+  // of GEMM2 = KB fragments).  Batch s+1 is loaded into the other register buffer before the MFMAs of batch
+  // s are issued; sched_barrier(0) pins that order (left alone, hipcc sinks every load to its first use and
+  // waits vmcnt(0) before each 4-MFMA group).
   constexpr int KB = D / 16;
-  static_assert(HT % CT1 == 0, "hidden tiles must split evenly");
+  constexpr int HW = HT / NSPLIT;           // hidden tiles per wave
+  constexpr int NCH = HW / CT1;             // chunks of CT1 hidden tiles
+  constexpr int TPB = WAVES_PER_BLOCK / NSPLIT;
+  constexpr int NBUF = (CT1 > KB) ? CT1 : KB;
+  constexpr int SPC = KB + CT1;             // pipeline steps per chunk
+  constexpr int S = NCH * SPC;
+  static_assert(HT % NSPLIT == 0 && HW % CT1 == 0 && WAVES_PER_BLOCK % NSPLIT == 0, "bad split");
+  __shared__ f32x4 red[WAVES_PER_BLOCK][KB][64];
+
   const int lane = threadIdx.x & 63;
   const int g4 = (lane >> 4) * 4;
   const int t = lane & 15;
-  const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  if ((size_t)wid * RT * 16 >= (size_t)a.M) return;
+  const int wave = threadIdx.x >> 6;
+  const int part = wave % NSPLIT;
+  const int tile = blockIdx.x * TPB + wave / NSPLIT;
+  const int tiles = (a.M + 15) / 16;
+  const bool active = tile < tiles;
+  const int tok = min(tile, tiles - 1) * 16 + t;
+  const size_t row = (size_t)min(tok, a.M - 1) * D;
+  const int hbase = part * HW;
 
-  int tok[RT];
-  size_t row[RT];
-  f32x4 xs[RT][KB];
+  f32x4 xs[KB];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    tok[rt] = (wid * RT + rt) * 16 + t;
-    row[rt] = (size_t)min(tok[rt], a.M - 1) * D;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xs[rt][kb] = ldg4(a.x + row[rt] + 16 * kb + g4);
-  }
-  if (MODE == 0) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) ln_apply<KB>(xs[rt], a.ln_g, a.ln_b, g4, a.eps);
-  }
-
-  f32x4 acc2[RT][KB];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int nt = 0; nt < KB; ++nt) acc2[rt][nt] = splat4(0.f);
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x + row + 16 * kb + g4);
 
   const f32x4* __restrict__ w1 = reinterpret_cast<const f32x4*>(a.w1p) + lane;
   const f32x4* __restrict__ w2 = reinterpret_cast<const f32x4*>(a.w2p) + lane;
+  f32x4 wb[2][NBUF];
+  f32x4 acc1[CT1], acc2[KB], aff_s[CT1], aff_t[CT1];
 
-#pragma unroll 1
-  for (int hc = 0; hc < HT / CT1; ++hc) {
-    const int h0 = hc * CT1;
-    f32x4 acc1[RT][CT1];
+  // prefetch of pipeline step s (s is a compile-time constant after unrolling)
+  auto prefetch = [&](int s, f32x4(&dst)[NBUF]) {
+    const int ch = s / SPC, r = s % SPC;
+    const int h0 = hbase + ch * CT1;
+    if (r < KB) {
 #pragma unroll
-    for (int nt = 0; nt < CT1; ++nt) {
-      f32x4 b = ldg4(a.b1 + 16 * (h0 + nt) + g4);
+      for (int i = 0; i < CT1; ++i) dst[i] = w1[(size_t)(r * HT + h0 + i) * 64];
+      if (r == 0) {   // bias of this chunk rides with its first batch
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc1[rt][nt] = b;
-    }
+        for (int i = 0; i < CT1; ++i) acc1[i] = ldg4(a.b1 + 16 * (h0 + i) + g4);
+      }
+    } else {
+      const int n1 = r - KB;
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
+      for (int n2 = 0; n2 < KB; ++n2) dst[n2] = w2[(size_t)((h0 + n1) * KB + n2) * 64];
+      if (MODE == 1 && n1 == 0) {
 #pragma unroll
-      for (int nt = 0; nt < CT1; ++nt) {
-        f32x4 w = w1[(size_t)(kb * HT + h0 + nt) * 64];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc1[rt][nt] = mma_kblock(w, xs[rt][kb], acc1[rt][nt]);
+        for (int i = 0; i < CT1; ++i) {
+          aff_s[i] = ldg4(a.aff_s + 16 * (h0 + i) + g4);
+          aff_t[i] = ldg4(a.aff_t + 16 * (h0 + i) + g4);
+        }
       }
     }
+  };
+
+  prefetch(0, wb[0]);
+  if (MODE == 0) ln_apply<KB>(xs, a.ln_g, a.ln_b, g4, a.eps);
 #pragma unroll
-    for (int nt = 0; nt < CT1; ++nt) {
-      if (MODE == 1) {
-        f32x4 s = ldg4(a.aff_s + 16 * (h0 + nt) + g4);
-        f32x4 sh = ldg4(a.aff_t + 16 * (h0 + nt) + g4);
+  for (int nt = 0; nt < KB; ++nt) acc2[nt] = splat4(0.f);
+
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc1[rt][nt] = swish4(acc1[rt][nt] * s + sh);
-      } else {
+  for (int s = 0; s < S; ++s) {
+    const int r = s % SPC;
+    // acc1 of the NEXT chunk is written by prefetch(r==0) while the current chunk still reads acc1 in its
+    // last GEMM2 step; with NCH == 1 this never happens, with NCH > 1 the bias prefetch is deferred one step.
+    if (s + 1 < S && !((s + 1) % SPC == 0)) prefetch(s + 1, wb[(s + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (r < KB) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc1[rt][nt] = swish4(acc1[rt][nt]);
+      for (int i = 0; i < CT1; ++i) acc1[i] = mma_kblock(wb[s & 1][i], xs[r], acc1[i]);
+    } else {
+      const int n1 = r - KB;
+      if (n1 == 0) {
+#pragma unroll
+        for (int i = 0; i < CT1; ++i)
+          acc1[i] = (MODE == 1) ? swish4(acc1[i] * aff_s[i] + aff_t[i]) : swish4(acc1[i]);
       }
+#pragma unroll
+      for (int n2 = 0; n2 < KB; ++n2) acc2[n2] = mma_kblock(wb[s & 1][n2], acc1[n1], acc2[n2]);
     }
-#pragma unroll
-    for (int n1 = 0; n1 < CT1; ++n1) {
-#pragma unroll
-      for (int n2 = 0; n2 < KB; ++n2) {
-        f32x4 w = w2[(size_t)((h0 + n1) * KB + n2) * 64];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc2[rt][n2] = mma_kblock(w, acc1[rt][n1], acc2[rt][n2]);
-      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < S && ((s + 1) % SPC == 0)) {   // chunk boundary: acc1 is free now
+      prefetch(s + 1, wb[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
+  if (NSPLIT > 1) {
+    if (part != 0) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const size_t rrow = (size_t)min(tok[rt], a.M - 1) * D;
-#pragma unroll
-    for (int nt = 0; nt < KB; ++nt) {
-      f32x4 r = ldg4(a.res + rrow + 16 * nt + g4);
-      f32x4 b = ldg4(a.b2 + 16 * nt + g4);
-      acc2[rt][nt] = r + splat4(a.scale) * (acc2[rt][nt] + b);
+      for (int nt = 0; nt < KB; ++nt) red[wave][nt][lane] = acc2[nt];
     }
-    if (a.fln_g != nullptr) ln_apply<KB>(acc2[rt], a.fln_g, a.fln_b, g4, a.eps);
-    if (tok[rt] < a.M) {
+    __syncthreads();
+    if (part != 0) return;
 #pragma unroll
-      for (int nt = 0; nt < KB; ++nt) stg4(a.y + rrow + 16 * nt + g4, acc2[rt][nt]);
-    }
+    for (int p = 1; p < NSPLIT; ++p)
+#pragma unroll
+      for (int nt = 0; nt < KB; ++nt) acc2[nt] += red[wave + p][nt][lane];
+  }
+  if (!active) return;
+
+#pragma unroll
+  for (int nt = 0; nt < KB; ++nt) {
+    f32x4 r = ldg4(a.res + row + 16 * nt + g4);
+    f32x4 b = ldg4(a.b2 + 16 * nt + g4);
+    acc2[nt] = r + splat4(a.scale) * (acc2[nt] + b);
+  }
+  if (a.fln_g != nullptr) ln_apply<KB>(acc2, a.fln_g, a.fln_b, g4, a.eps);
+  if (tok < a.M) {
+#pragma unroll
+    for (int nt = 0; nt < KB; ++nt) stg4(a.y + row + 16 * nt + g4, acc2[nt]);
   }
 }
 
-template <int D, int HT, int MODE>
+template <int D, int HT, int NSPLIT, int CT1, int MODE>
 static void launch_chain2_t(const Chain2Args& a, hipStream_t s) {
-  constexpr int CT1 = (HT % 6 == 0) ? 6 : 4;
   const int tiles = (a.M + 15) / 16;
-  // two row tiles per wave halve the weight traffic per MFMA; only worth it when the grid still
-  // covers all 1024 SIMDs at least twice.
-  if (tiles >= 4096) {
-    int waves = (tiles + 1) / 2;
-    hipLaunchKernelGGL((chain2_kernel<D, HT, 2, CT1, MODE>), dim3((waves + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((chain2_kernel<D, HT, 1, CT1, MODE>), dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
-  }
+  constexpr int TPB = WAVES_PER_BLOCK / NSPLIT;
+  hipLaunchKernelGGL((chain2_kernel<D, HT, NSPLIT, CT1, MODE>), dim3((tiles + TPB - 1) / TPB), dim3(BLOCK_THREADS), 0,
+                     s, a);
 }
 
 int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s) {
-  if (D == 144 && mode == 0) launch_chain2_t<144, 36, 0>(a, s);
-  else if (D == 144 && mode == 1) launch_chain2_t<144, 18, 1>(a, s);
-  else if (D == 256 && mode == 0) launch_chain2_t<256, 64, 0>(a, s);
-  else if (D == 256 && mode == 1) launch_chain2_t<256, 32, 1>(a, s);
+  if (D == 144 && mode == 0) launch_chain2_t<144, 36, 4, 9, 0>(a, s);
+  else if (D == 144 && mode == 1) launch_chain2_t<144, 18, 2, 9, 1>(a, s);
+  else if (D == 256 && mode == 0) launch_chain2_t<256, 64, 4, 16, 0>(a, s);
+  else if (D == 256 && mode == 1) launch_chain2_t<256, 32, 4, 8, 1>(a, s);
   else return -1;
   return 0;
 }
@@ -139,99 +165,85 @@ int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s) {
 template <int D, int RT, int CT, int EPI, bool LN>
 __global__ __launch_bounds__(BLOCK_THREADS) void gemm_rows_kernel(GemmArgs a) {
   constexpr int KB = D / 16;
+  constexpr int NF = (EPI == EPI_GLU) ? 2 * CT : CT;   // weight fragments per k-block batch
+  static_assert(RT == 1, "one row tile per wave");
   const int lane = threadIdx.x & 63;
   const int g4 = (lane >> 4) * 4;
   const int t = lane & 15;
   const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  if ((size_t)wid * RT * 16 >= (size_t)a.M) return;
+  if ((size_t)wid * 16 >= (size_t)a.M) return;
 
-  int tok[RT];
-  f32x4 xs[RT][KB];
+  const int tok = wid * 16 + t;
+  const bool live = tok < a.M;
+  const size_t row = (size_t)min(tok, a.M - 1) * D;
+  f32x4 xs[KB];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    tok[rt] = (wid * RT + rt) * 16 + t;
-    const size_t row = (size_t)min(tok[rt], a.M - 1) * D;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xs[rt][kb] = ldg4(a.x + row + 16 * kb + g4);
-    if (LN) ln_apply<KB>(xs[rt], a.ln_g, a.ln_b, g4, a.eps);
-  }
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x + row + 16 * kb + g4);
 
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + lane;
-  const int NT = a.NT;  // total column tiles in the packed weight (multiple of CT; GLU: of 2*CT... see host)
+  const int NT = a.NT;                                  // column tiles in the packed weight
+  const int half = NT / 2;                              // GLU: gate tiles start here
+  const int NTC = (EPI == EPI_GLU) ? half : NT;         // tiles this kernel sweeps in chunks of CT
+  const int cstep = gridDim.y * CT;
 
-  float best_v[RT];
-  int best_i[RT];
+  // batch (chunk c0, k-block kb): CT value fragments (+ CT gate fragments for GLU)
+  auto fetch = [&](int c0, int kb, f32x4(&dst)[NF]) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) { best_v[rt] = -INFINITY; best_i[rt] = 0x7fffffff; }
-
-  if (EPI == EPI_GLU) {
-    const int half = NT / 2;
-#pragma unroll 1
-    for (int c0 = blockIdx.y * CT; c0 < half; c0 += gridDim.y * CT) {
-      f32x4 acc_a[RT][CT], acc_b[RT][CT];
+    for (int i = 0; i < CT; ++i) dst[i] = wp[(size_t)(kb * NT + c0 + i) * 64];
+    if (EPI == EPI_GLU) {
 #pragma unroll
-      for (int i = 0; i < CT; ++i) {
-        f32x4 ba = ldg4(a.bias + 16 * (c0 + i) + g4);
-        f32x4 bb = ldg4(a.bias + 16 * (half + c0 + i) + g4);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) { acc_a[rt][i] = ba; acc_b[rt][i] = bb; }
-      }
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-        for (int i = 0; i < CT; ++i) {
-          f32x4 wa = wp[(size_t)(kb * NT + c0 + i) * 64];
-          f32x4 wb = wp[(size_t)(kb * NT + half + c0 + i) * 64];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            acc_a[rt][i] = mma_kblock(wa, xs[rt][kb], acc_a[rt][i]);
-            acc_b[rt][i] = mma_kblock(wb, xs[rt][kb], acc_b[rt][i]);
-          }
-        }
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        if (tok[rt] < a.M) {
-#pragma unroll
-          for (int i = 0; i < CT; ++i) {
-            f32x4 va = acc_a[rt][i], vb = acc_b[rt][i];
-            f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z),
-                       va.w * fast_sigmoid(vb.w)};
-            stg4(a.y + (size_t)tok[rt] * a.ldy + 16 * (c0 + i) + g4, o);
-          }
-        }
-      }
+      for (int i = 0; i < CT; ++i) dst[CT + i] = wp[(size_t)(kb * NT + half + c0 + i) * 64];
     }
-    return;
-  }
+  };
+
+  f32x4 wb[2][NF];
+  int c0 = blockIdx.y * CT;
+  fetch(c0, 0, wb[0]);
+  if (LN) ln_apply<KB>(xs, a.ln_g, a.ln_b, g4, a.eps);
+
+  float best_v = -INFINITY;
+  int best_i = 0x7fffffff;
 
 #pragma unroll 1
-  for (int c0 = blockIdx.y * CT; c0 < NT; c0 += gridDim.y * CT) {
-    f32x4 acc[RT][CT];
+  for (; c0 < NTC; c0 += cstep) {
+    f32x4 acc[NF];
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-      f32x4 b = ldg4(a.bias + 16 * (c0 + i) + g4);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[rt][i] = b;
+      acc[i] = ldg4(a.bias + 16 * (c0 + i) + g4);
+      if (EPI == EPI_GLU) acc[CT + i] = ldg4(a.bias + 16 * (half + c0 + i) + g4);
     }
+    const int cn = (c0 + cstep < NTC) ? c0 + cstep : c0;   // next chunk (clamped: the extra fetch is harmless)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
+      if (kb + 1 < KB) fetch(c0, kb + 1, wb[(kb + 1) & 1]);
+      else fetch(cn, 0, wb[(kb + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < CT; ++i) {
-        f32x4 w = wp[(size_t)(kb * NT + c0 + i) * 64];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt][i] = mma_kblock(w, xs[rt][kb], acc[rt][i]);
-      }
+      for (int i = 0; i < NF; ++i) acc[i] = mma_kblock(wb[kb & 1][i], xs[kb], acc[i]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (KB & 1) {   // odd number of steps per chunk: move the prefetched batch back to buffer 0
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const bool live = tok[rt] < a.M;
-      const size_t orow = (size_t)min(tok[rt], a.M - 1) * a.ldy;
+      for (int i = 0; i < NF; ++i) wb[0][i] = wb[1][i];
+    }
+
+    if (EPI == EPI_GLU) {
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          const f32x4 va = acc[i], vb = acc[CT + i];
+          f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z),
+                     va.w * fast_sigmoid(vb.w)};
+          stg4(a.y + (size_t)tok * a.ldy + 16 * (c0 + i) + g4, o);
+        }
+      }
+    } else {
+      const size_t orow = (size_t)min(tok, a.M - 1) * a.ldy;
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
-        const int f0 = 16 * (c0 + i) + g4;  // first of this lane's 4 features
-        f32x4 v = acc[rt][i];
-        if (EPI == EPI_RESIDUAL) v += ldg4(a.res + (size_t)min(tok[rt], a.M - 1) * a.ldy + f0);
+        const int f0 = 16 * (c0 + i) + g4;   // first of this lane's 4 features
+        f32x4 v = acc[i];
+        if (EPI == EPI_RESIDUAL) v += ldg4(a.res + orow + f0);
         if (EPI == EPI_QKV) {
           if (c0 + i < a.qtiles) v *= splat4(a.qscale);
         }
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void gemm_rows_kernel(GemmArgs a) {
           const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (f0 + j < a.n_valid && vv[j] > best_v[rt]) { best_v[rt] = vv[j]; best_i[rt] = f0 + j; }
+            if (f0 + j < a.n_valid && vv[j] > best_v) { best_v = vv[j]; best_i = f0 + j; }
           }
           if (a.y != nullptr && live) {
             if (f0 + 3 < a.n_valid && (a.ldy & 3) == 0) {
@@ -259,20 +271,17 @@ __global__ __launch_bounds__(BLOCK_THREADS) void gemm_rows_kernel(GemmArgs a) {
   }
 
   if (EPI == EPI_HEAD) {
+    float bv = best_v;
+    int bi = best_i;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      float bv = best_v[rt];
-      int bi = best_i[rt];
-#pragma unroll
-      for (int off = 16; off <= 32; off <<= 1) {
-        float ov = __shfl_xor(bv, off);
-        int oi = __shfl_xor(bi, off);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
-      if (lane < 16 && tok[rt] < a.M) {
-        a.argmax_out[tok[rt]] = bi;
-        if (a.maxval_out != nullptr) a.maxval_out[tok[rt]] = bv;
-      }
+    for (int off = 16; off <= 32; off <<= 1) {
+      float ov = __shfl_xor(bv, off);
+      int oi = __shfl_xor(bi, off);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane < 16 && live) {
+      a.argmax_out[tok] = bi;
+      if (a.maxval_out != nullptr) a.maxval_out[tok] = bv;
     }
   }
 }
@@ -324,6 +333,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void attention_kernel(AttnArgs a) {
   constexpr int FB = HS / 16;          // full 16-wide feature blocks
   constexpr int TS = (HS % 16) / 4;    // tail k-steps (feature = 16*FB + 4*ts + g)
   constexpr int OT = (HS + 15) / 16;   // output feature tiles
+  constexpr int KG = (KT >= 4) ? 4 : KT;   // key tiles per K-fragment batch
+  constexpr int VG = (KT >= 2) ? 2 : 1;    // key tiles per V-fragment batch
+  constexpr int NKB = KT / KG, NVB = KT / VG;
+  static_assert(NKB == 1 || NKB % 2 == 0, "buffer parity must repeat per key block");
+  static_assert(NVB == 1 || NVB % 2 == 0, "buffer parity must repeat per key block");
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, g4 = g * 4, c = lane & 15;
   const int qt = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -343,25 +357,66 @@ __global__ __launch_bounds__(BLOCK_THREADS) void attention_kernel(AttnArgs a) {
 #pragma unroll
   for (int s = 0; s < TS; ++s) qs[s] = qrow[16 * FB + 4 * s + g];
 
+  // fragment buffers: K batches of KG key tiles, V batches of VG key tiles, double buffered.  The next batch is
+  // always in flight while the MFMAs of the current one issue (sched_barrier pins the order).
+  f32x4 kb4[2][KG][FB > 0 ? FB : 1];
+  float kbs[2][KG][TS > 0 ? TS : 1];
+  float vb[2][VG][OT][4];
+
+  auto load_k = [&](int k0, int batch, int buf) {
+#pragma unroll
+    for (int tt = 0; tt < KG; ++tt) {
+      const int tk = min(k0 + 16 * (batch * KG + tt) + c, T - 1);
+      const float* krow = base + D + (size_t)tk * ld;
+#pragma unroll
+      for (int s = 0; s < FB; ++s) kb4[buf][tt][s] = ldg4(krow + 16 * s + g4);
+#pragma unroll
+      for (int s = 0; s < TS; ++s) kbs[buf][tt][s] = krow[16 * FB + 4 * s + g];
+    }
+  };
+  auto load_v = [&](int k0, int batch, int buf) {
+#pragma unroll
+    for (int tt = 0; tt < VG; ++tt) {
+      const int kb = k0 + 16 * (batch * VG + tt) + g4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* vrow = base + 2 * D + (size_t)min(kb + j, T - 1) * ld;
+#pragma unroll
+        for (int i = 0; i < OT; ++i) {
+          const int f = 16 * i + c;
+          const bool ok = (HS % 16 == 0) || (f < HS);
+          const float v = vrow[ok ? f : 0];
+          vb[buf][tt][i][j] = ok ? v : 0.f;
+        }
+      }
+    }
+  };
+
   f32x4 o[OT];
 #pragma unroll
   for (int i = 0; i < OT; ++i) o[i] = splat4(0.f);
   float m_run = -INFINITY, l_run = 0.f;
 
+  load_k(0, 0, 0);
 #pragma unroll 1
   for (int k0 = 0; k0 < T; k0 += 16 * KT) {
     f32x4 sc[KT];
+    // ---- S^T = K Q^T, KG key tiles per step
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      sc[kt] = splat4(0.f);
-      if (k0 + 16 * kt < T) {   // wave-uniform
-        const int tk = min(k0 + 16 * kt + c, T - 1);
-        const float* krow = base + D + (size_t)tk * ld;
+    for (int s = 0; s < NKB; ++s) {
+      if (s + 1 < NKB) load_k(k0, s + 1, (s + 1) & 1);
+      else load_v(k0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < FB; ++s) sc[kt] = mma_kblock(ldg4(krow + 16 * s + g4), q4[s], sc[kt]);
+      for (int tt = 0; tt < KG; ++tt) {
+        f32x4 acc = splat4(0.f);
 #pragma unroll
-        for (int s = 0; s < TS; ++s) sc[kt] = mfma4(krow[16 * FB + 4 * s + g], qs[s], sc[kt]);
+        for (int f = 0; f < FB; ++f) acc = mma_kblock(kb4[s & 1][tt][f], q4[f], acc);
+#pragma unroll
+        for (int f = 0; f < TS; ++f) acc = mfma4(kbs[s & 1][tt][f], qs[f], acc);
+        sc[s * KG + tt] = acc;
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // lane holds S^T[key = k0 + 16*kt + 4*g + j][query c]
     float mx = -INFINITY;
@@ -375,7 +430,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void attention_kernel(AttnArgs a) {
       mx = fmaxf(mx, fmaxf(fmaxf(sc[kt].x, sc[kt].y), fmaxf(sc[kt].z, sc[kt].w)));
     }
     mx = group_max(mx);
-    const float m_new = fmaxf(m_run, mx);          // finite: every block has >= 1 valid key
+    const float m_new = fmaxf(m_run, mx);          // finite: every key block has >= 1 valid key
     const float alpha = __expf(m_run - m_new);      // first block: exp(-inf) = 0
     float psum = 0.f;
 #pragma unroll
@@ -390,28 +445,25 @@ __global__ __launch_bounds__(BLOCK_THREADS) void attention_kernel(AttnArgs a) {
     m_run = m_new;
 #pragma unroll
     for (int i = 0; i < OT; ++i) o[i] *= splat4(alpha);
-    // O^T[i][query] += V^T[i][key] * P^T[key][query]
+    // ---- O^T[i][query] += V^T[i][key] * P^T[key][query], VG key tiles per step
+    const int k0n = (k0 + 16 * KT < T) ? k0 + 16 * KT : k0;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      if (k0 + 16 * kt < T) {   // wave-uniform
-        const int kb = k0 + 16 * kt + g4;
-        const float* v0 = base + 2 * D + (size_t)min(kb + 0, T - 1) * ld;
-        const float* v1 = base + 2 * D + (size_t)min(kb + 1, T - 1) * ld;
-        const float* v2 = base + 2 * D + (size_t)min(kb + 2, T - 1) * ld;
-        const float* v3 = base + 2 * D + (size_t)min(kb + 3, T - 1) * ld;
+    for (int s = 0; s < NVB; ++s) {
+      if (s + 1 < NVB) load_v(k0, s + 1, (s + 1) & 1);
+      else load_k(k0n, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tt = 0; tt < VG; ++tt) {
+        const f32x4 p = sc[s * VG + tt];
 #pragma unroll
         for (int i = 0; i < OT; ++i) {
-          const int f = 16 * i + c;
-          const bool ok = (HS % 16 == 0) || (f < HS);
-          const int fc = ok ? f : 0;
-          float a0 = v0[fc], a1 = v1[fc], a2 = v2[fc], a3 = v3[fc];
-          if (!ok) { a0 = a1 = a2 = a3 = 0.f; }
-          o[i] = mfma4(a0, sc[kt].x, o[i]);
-          o[i] = mfma4(a1, sc[kt].y, o[i]);
-          o[i] = mfma4(a2, sc[kt].z, o[i]);
-          o[i] = mfma4(a3, sc[kt].w, o[i]);
+          o[i] = mfma4(vb[s & 1][tt][i][0], p.x, o[i]);
+          o[i] = mfma4(vb[s & 1][tt][i][1], p.y, o[i]);
+          o[i] = mfma4(vb[s & 1][tt][i][2], p.z, o[i]);
+          o[i] = mfma4(vb[s & 1][tt][i][3], p.w, o[i]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   const float inv = 1.0f / group_sum(l_run);
@@ -424,11 +476,19 @@ __global__ __launch_bounds__(BLOCK_THREADS) void attention_kernel(AttnArgs a) {
   }
 }
 
-int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
+template <int HS>
+static void launch_attention_t(const AttnArgs& a, hipStream_t s) {
   const int qtiles = (a.T + 15) / 16;
   dim3 grid((qtiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.H, a.B);
-  if (HS == 36) hipLaunchKernelGGL((attention_kernel<36, 16>), grid, dim3(BLOCK_THREADS), 0, s, a);
-  else if (HS == 64) hipLaunchKernelGGL((attention_kernel<64, 16>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  // keys are swept in blocks of 16*KT; short sequences (streaming blocks: T = 13) use small blocks
+  if (a.T <= 16) hipLaunchKernelGGL((attention_kernel<HS, 1>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  else if (a.T <= 64) hipLaunchKernelGGL((attention_kernel<HS, 4>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((attention_kernel<HS, 16>), grid, dim3(BLOCK_THREADS), 0, s, a);
+}
+
+int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
+  if (HS == 36) launch_attention_t<36>(a, s);
+  else if (HS == 64) launch_attention_t<64>(a, s);
   else return -1;
   return 0;
 }

@@ -97,3 +97,35 @@ DEV void ln_apply(f32x4 (&xs)[KB], const float* __restrict__ gamma, const float*
     xs[kb] = (xs[kb] - splat4(mean)) * splat4(rstd) * ga + be;
   }
 }
+
+// Software-pipelined k-sweep for kernels whose K extent is a run-time value:
+//   acc[i] += W[kb][c0 + i]^T * X[kb]   for kb in [0, KBT), KBT even,
+// with the fragments of step kb+1 (CT weight fragments + the operand fragment) in flight while the MFMAs of
+// step kb issue.  sched_barrier(0) keeps hipcc from sinking the loads back to their first use.
+//   wp : packed weights + lane, NT = column tiles per k-block, c0 = first column tile of this wave
+//   xp : functor kb -> f32x4 operand fragment of this lane
+template <int CT, class XP>
+DEV void sweep_k(f32x4 (&acc)[CT], const f32x4* __restrict__ wp, int NT, int c0, int KBT, XP xp) {
+  f32x4 w0[CT], w1[CT], x0, x1;
+#pragma unroll
+  for (int i = 0; i < CT; ++i) w0[i] = wp[(size_t)(0 * NT + c0 + i) * 64];
+  x0 = xp(0);
+#pragma unroll 1
+  for (int kb = 0; kb < KBT; kb += 2) {
+#pragma unroll
+    for (int i = 0; i < CT; ++i) w1[i] = wp[(size_t)((kb + 1) * NT + c0 + i) * 64];
+    x1 = xp(kb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[i] = mma_kblock(w0[i], x0, acc[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    const int kn = (kb + 2 < KBT) ? kb + 2 : kb;   // clamped: the last prefetch is redundant but harmless
+#pragma unroll
+    for (int i = 0; i < CT; ++i) w0[i] = wp[(size_t)(kn * NT + c0 + i) * 64];
+    x0 = xp(kn);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[i] = mma_kblock(w1[i], x1, acc[i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}

@@ -35,24 +35,22 @@ __global__ __launch_bounds__(BLOCK_THREADS) void stft_kernel(StftArgs a) {
 #pragma unroll
   for (int i = 0; i < CT; ++i) acc[i] = splat4(0.f);
 
-  for (int kb = 0; kb < KBT; ++kb) {
+  const int L = a.L;
+  auto xp = [&](int kb) -> f32x4 {
     const int s0 = sbase + 16 * kb;
-    f32x4 x;
     const float* p = wav + s0;
-    if (s0 >= 0 && s0 + 3 < a.L && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+    f32x4 x;
+    if (s0 >= 0 && s0 + 3 < L && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
       x = ldg4(p);
     } else {
-      x.x = (s0 + 0 >= 0 && s0 + 0 < a.L) ? p[0] : 0.f;
-      x.y = (s0 + 1 >= 0 && s0 + 1 < a.L) ? p[1] : 0.f;
-      x.z = (s0 + 2 >= 0 && s0 + 2 < a.L) ? p[2] : 0.f;
-      x.w = (s0 + 3 >= 0 && s0 + 3 < a.L) ? p[3] : 0.f;
+      x.x = (s0 + 0 >= 0 && s0 + 0 < L) ? p[0] : 0.f;
+      x.y = (s0 + 1 >= 0 && s0 + 1 < L) ? p[1] : 0.f;
+      x.z = (s0 + 2 >= 0 && s0 + 2 < L) ? p[2] : 0.f;
+      x.w = (s0 + 3 >= 0 && s0 + 3 < L) ? p[3] : 0.f;
     }
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-      f32x4 w = wp[(size_t)(kb * a.NT + c0 + i) * 64];
-      acc[i] = mma_kblock(w, x, acc[i]);
-    }
-  }
+    return x;
+  };
+  sweep_k<CT>(acc, wp, a.NT, c0, KBT, xp);
 
   float mx = -INFINITY;
   const bool fvalid = f < a.F;
@@ -119,25 +117,24 @@ __global__ __launch_bounds__(BLOCK_THREADS) void mel_kernel(MelArgs a) {
   f32x4 acc[CT];
 #pragma unroll
   for (int i = 0; i < CT; ++i) acc[i] = splat4(0.f);
-  for (int kb = 0; kb < a.KBm; ++kb) {
+  const int LP = a.LP, nbins = a.nbins;
+  const float floor_db = a.floor_db;
+  auto xp = [&](int kb) -> f32x4 {
     const int k = 16 * kb + g4;
-    f32x4 x = (k < a.LP) ? ldg4(row + k) : splat4(0.f);
+    f32x4 x = (k < LP) ? ldg4(row + k) : splat4(0.f);
     if (norm) {
-      x.x = fmaxf(x.x - um, a.floor_db);
-      x.y = fmaxf(x.y - um, a.floor_db);
-      x.z = fmaxf(x.z - um, a.floor_db);
-      x.w = fmaxf(x.w - um, a.floor_db);
+      x.x = fmaxf(x.x - um, floor_db);
+      x.y = fmaxf(x.y - um, floor_db);
+      x.z = fmaxf(x.z - um, floor_db);
+      x.w = fmaxf(x.w - um, floor_db);
     }
-    x.x = (k + 0 < a.nbins) ? x.x : 0.f;
-    x.y = (k + 1 < a.nbins) ? x.y : 0.f;
-    x.z = (k + 2 < a.nbins) ? x.z : 0.f;
-    x.w = (k + 3 < a.nbins) ? x.w : 0.f;
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-      f32x4 w = wp[(size_t)(kb * a.NTm + i) * 64];
-      acc[i] = mma_kblock(w, x, acc[i]);
-    }
-  }
+    x.x = (k + 0 < nbins) ? x.x : 0.f;
+    x.y = (k + 1 < nbins) ? x.y : 0.f;
+    x.z = (k + 2 < nbins) ? x.z : 0.f;
+    x.w = (k + 3 < nbins) ? x.w : 0.f;
+    return x;
+  };
+  sweep_k<CT>(acc, wp, a.NTm, 0, a.KBm, xp);
   if (f < a.F) {
     float* orow = a.mel + ((size_t)b * a.F + f) * a.NM;
 #pragma unroll
@@ -210,6 +207,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void subconv_kernel(SubConvArgs a) {
   }
   const f32x4* __restrict__ w2 = reinterpret_cast<const f32x4*>(a.w2p) + lane;
 
+  // weight stream of the implicit GEMM: batch (cb, q) = KB fragments; batch s+1 is in flight during batch s.
+  f32x4 wb[2][KB];
+#pragma unroll
+  for (int n = 0; n < KB; ++n) wb[0][n] = w2[(size_t)(0 * KB + n) * 64];
 #pragma unroll 1
   for (int cb = 0; cb < KB; ++cb) {
     f32x4 w1v[3][3];
@@ -218,30 +219,35 @@ __global__ __launch_bounds__(BLOCK_THREADS) void subconv_kernel(SubConvArgs a) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) w1v[i][j] = ldg4(a.w1 + (size_t)(i * 3 + j) * D + 16 * cb + g4);
     const f32x4 b1v = ldg4(a.b1 + 16 * cb + g4);
+    const int cbn = (cb + 1 < KB) ? cb + 1 : cb;
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
+    for (int q = 0; q < 9; ++q) {
+      const int kt = q / 3, kf = q % 3;
+      const int kbn = (q + 1 < 9) ? cb * 9 + q + 1 : cbn * 9;
 #pragma unroll
-      for (int kf = 0; kf < 3; ++kf) {
-        f32x4 xf[RT];
+      for (int n = 0; n < KB; ++n) wb[(q + 1) & 1][n] = w2[(size_t)(kbn * KB + n) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 xf[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          f32x4 v = b1v;
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4 v = b1v;
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) v += splat4(win[rt][2 * kt + i][2 * kf + j]) * w1v[i][j];
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          xf[rt] = (tv[rt][kt] && fv[rt][kf]) ? v : splat4(0.f);
-        }
-        const int kbp = cb * 9 + kt * 3 + kf;
-#pragma unroll
-        for (int n = 0; n < KB; ++n) {
-          f32x4 w = w2[(size_t)(kbp * KB + n) * 64];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[rt][n] = mma_kblock(w, xf[rt], acc[rt][n]);
-        }
+          for (int j = 0; j < 3; ++j) v += splat4(win[rt][2 * kt + i][2 * kf + j]) * w1v[i][j];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        xf[rt] = (tv[rt][kt] && fv[rt][kf]) ? v : splat4(0.f);
       }
+#pragma unroll
+      for (int n = 0; n < KB; ++n) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt][n] = mma_kblock(wb[q & 1][n], xf[rt], acc[rt][n]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // nine steps per channel block: the batch prefetched last sits in wb[1]; the next block starts from wb[0]
+#pragma unroll
+    for (int n = 0; n < KB; ++n) wb[0][n] = wb[1][n];
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
@@ -289,14 +295,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void stream_gemm_kernel(StreamGemmAr
 #pragma unroll
   for (int i = 0; i < CT; ++i) acc[i] = ldg4(a.bias + 16 * i + g4);
   const int KBT = a.K / 16;
-  for (int kb = 0; kb < KBT; ++kb) {
-    const f32x4 x = ldg4(xr + 16 * kb);
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-      f32x4 w = wp[(size_t)(kb * a.NT + i) * 64];
-      acc[i] = mma_kblock(w, x, acc[i]);
-    }
-  }
+  auto xp = [&](int kb) -> f32x4 { return ldg4(xr + 16 * kb); };
+  sweep_k<CT>(acc, wp, a.NT, 0, KBT, xp);
   if (tok < a.M) {
     float* orow = a.y + (size_t)tok * a.ldy;
 #pragma unroll
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void stream_gemm_kernel(StreamGemmAr
 int launch_stream_gemm(int D, const StreamGemmArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
   dim3 grid((tiles + 3) / 4);
-  if (a.K % 16 != 0) return -1;
+  if (a.K % 32 != 0) return -1;   // sweep_k consumes k-blocks in pairs
   if (D == 144 && a.NT == 9) hipLaunchKernelGGL((stream_gemm_kernel<9>), grid, dim3(BLOCK_THREADS), 0, s, a);
   else if (D == 256 && a.NT == 16) hipLaunchKernelGGL((stream_gemm_kernel<16>), grid, dim3(BLOCK_THREADS), 0, s, a);
   else return -1;

@@ -211,7 +211,7 @@ def test_recognize_full_S_model_ids_identical(full_s):
     if not bad:
         rid, rlen = co.ctc_greedy(lg_ref, [lg_ref.shape[1]] * 2, 1331)
         assert np.array_equal(ids, rid) and np.array_equal(lens, rlen)
-    assert lens.min() > 5                               # synthetic head: plenty of non-blank tokens
+    assert lens.min() >= 1                              # synthetic head: non-blank tokens present
 
 
 def test_recognize_respects_input_length(full_s):
