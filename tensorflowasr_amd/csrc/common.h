@@ -99,33 +99,47 @@ DEV void ln_apply(f32x4 (&xs)[KB], const float* __restrict__ gamma, const float*
 }
 
 // Software-pipelined k-sweep for kernels whose K extent is a run-time value:
-//   acc[i] += W[kb][c0 + i]^T * X[kb]   for kb in [0, KBT), KBT even,
-// with the fragments of step kb+1 (CT weight fragments + the operand fragment) in flight while the MFMAs of
-// step kb issue.  sched_barrier(0) keeps hipcc from sinking the loads back to their first use.
+//   acc[rt][i] += W[kb][c0 + i]^T * X_rt[kb]   for kb in [0, KBT), KBT even, rt < RT row tiles,
+// with the fragments of step kb+1 (CT weight fragments + RT operand fragments) in flight while the MFMAs of
+// step kb issue.  sched_barrier(0) keeps hipcc from sinking the loads back to their first use.  With RT = 2 one
+// weight fragment feeds two MFMA groups, halving the L2 weight stream per flop.
 //   wp : packed weights + lane, NT = column tiles per k-block, c0 = first column tile of this wave
-//   xp : functor kb -> f32x4 operand fragment of this lane
-template <int CT, class XP>
-DEV void sweep_k(f32x4 (&acc)[CT], const f32x4* __restrict__ wp, int NT, int c0, int KBT, XP xp) {
-  f32x4 w0[CT], w1[CT], x0, x1;
+//   xp : functor (rt, kb) -> f32x4: the raw loads of this lane's operand fragment (branch-free, NO arithmetic on
+//        the loaded values: anything that consumes them would be waited for at issue time)
+//   fx : functor (rt, kb, raw) -> f32x4: masking / normalisation of the raw fragment, applied at use time
+template <int RT, int CT, class XP, class FX>
+DEV void sweep_k(f32x4 (&acc)[RT][CT], const f32x4* __restrict__ wp, int NT, int c0, int KBT, XP xp, FX fx) {
+  f32x4 w0[CT], w1[CT], x0[RT], x1[RT];
 #pragma unroll
   for (int i = 0; i < CT; ++i) w0[i] = wp[(size_t)(0 * NT + c0 + i) * 64];
-  x0 = xp(0);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) x0[rt] = xp(rt, 0);
 #pragma unroll 1
   for (int kb = 0; kb < KBT; kb += 2) {
 #pragma unroll
     for (int i = 0; i < CT; ++i) w1[i] = wp[(size_t)((kb + 1) * NT + c0 + i) * 64];
-    x1 = xp(kb + 1);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) x1[rt] = xp(rt, kb + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < CT; ++i) acc[i] = mma_kblock(w0[i], x0, acc[i]);
+    for (int rt = 0; rt < RT; ++rt) x0[rt] = fx(rt, kb, x0[rt]);
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt][i] = mma_kblock(w0[i], x0[rt], acc[rt][i]);
     __builtin_amdgcn_sched_barrier(0);
     const int kn = (kb + 2 < KBT) ? kb + 2 : kb;   // clamped: the last prefetch is redundant but harmless
 #pragma unroll
     for (int i = 0; i < CT; ++i) w0[i] = wp[(size_t)(kn * NT + c0 + i) * 64];
-    x0 = xp(kn);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) x0[rt] = xp(rt, kn);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < CT; ++i) acc[i] = mma_kblock(w1[i], x1, acc[i]);
+    for (int rt = 0; rt < RT; ++rt) x1[rt] = fx(rt, kb + 1, x1[rt]);
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt][i] = mma_kblock(w1[i], x1[rt], acc[rt][i]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }

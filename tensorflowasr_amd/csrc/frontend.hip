@@ -15,72 +15,90 @@
 // STFT power -> log.  One wave = 16 frames of one utterance x CT column tiles (8 bins per tile, re/im
 // interleaved so that a lane's float4 accumulator is (re,im,re,im) of two adjacent bins).
 // ---------------------------------------------------------------------------------------------------
-template <int CT>
+template <int RT, int CT>
 __global__ __launch_bounds__(BLOCK_THREADS) void stft_kernel(StftArgs a) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, g4 = g * 4, c = lane & 15;
   const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  if (wid >= a.B * a.FT) return;
-  const int b = wid / a.FT, ft = wid % a.FT;
+  const int FTP = (a.FT + RT - 1) / RT;           // groups of RT frame tiles per utterance
+  if (wid >= a.B * FTP) return;
+  const int b = wid / FTP, ftp = wid % FTP;
   const int chunk = blockIdx.y;
   const int c0 = chunk * CT;
-  const int f = ft * 16 + c;
-  const int fc = min(f, a.F - 1);
   const float* __restrict__ wav = a.wav + (size_t)b * a.L;
-  const int sbase = fc * a.hop - a.pad_left + g4;
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + lane;
   const int KBT = a.n_dft / 16;
-
-  f32x4 acc[CT];
-#pragma unroll
-  for (int i = 0; i < CT; ++i) acc[i] = splat4(0.f);
-
   const int L = a.L;
-  auto xp = [&](int kb) -> f32x4 {
-    const int s0 = sbase + 16 * kb;
-    const float* p = wav + s0;
+  int f[RT], fc[RT], sbase[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    f[rt] = (ftp * RT + rt) * 16 + c;
+    fc[rt] = min(f[rt], a.F - 1);
+    sbase[rt] = fc[rt] * a.hop - a.pad_left + g4;
+  }
+
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[rt][i] = splat4(0.f);
+
+  // frame fragment: 4 consecutive samples of the zero-padded signal (TF 'SAME' padding); branch-free so that
+  // the loads can be hoisted a whole k-step ahead of their MFMAs
+  auto xp = [&](int rt, int kb) -> f32x4 {
+    const int s0 = sbase[rt] + 16 * kb;
     f32x4 x;
-    if (s0 >= 0 && s0 + 3 < L && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-      x = ldg4(p);
-    } else {
-      x.x = (s0 + 0 >= 0 && s0 + 0 < L) ? p[0] : 0.f;
-      x.y = (s0 + 1 >= 0 && s0 + 1 < L) ? p[1] : 0.f;
-      x.z = (s0 + 2 >= 0 && s0 + 2 < L) ? p[2] : 0.f;
-      x.w = (s0 + 3 >= 0 && s0 + 3 < L) ? p[3] : 0.f;
-    }
+    x.x = wav[(unsigned)(s0 + 0) < (unsigned)L ? s0 + 0 : 0];
+    x.y = wav[(unsigned)(s0 + 1) < (unsigned)L ? s0 + 1 : 0];
+    x.z = wav[(unsigned)(s0 + 2) < (unsigned)L ? s0 + 2 : 0];
+    x.w = wav[(unsigned)(s0 + 3) < (unsigned)L ? s0 + 3 : 0];
     return x;
   };
-  sweep_k<CT>(acc, wp, a.NT, c0, KBT, xp);
+  auto fx = [&](int rt, int kb, f32x4 x) -> f32x4 {
+    const int s0 = sbase[rt] + 16 * kb;
+    x.x = (unsigned)(s0 + 0) < (unsigned)L ? x.x : 0.f;
+    x.y = (unsigned)(s0 + 1) < (unsigned)L ? x.y : 0.f;
+    x.z = (unsigned)(s0 + 2) < (unsigned)L ? x.z : 0.f;
+    x.w = (unsigned)(s0 + 3) < (unsigned)L ? x.w : 0.f;
+    return x;
+  };
+  sweep_k<RT, CT>(acc, wp, a.NT, c0, KBT, xp, fx);
 
-  float mx = -INFINITY;
-  const bool fvalid = f < a.F;
-  float* orow = a.logp + ((size_t)b * a.F + fc) * a.LP;
 #pragma unroll
-  for (int i = 0; i < CT; ++i) {
-    const int bin0 = 8 * (c0 + i) + 2 * g;
-    const float p0 = acc[i].x * acc[i].x + acc[i].y * acc[i].y;
-    const float p1 = acc[i].z * acc[i].z + acc[i].w * acc[i].w;
-    float l0 = logf(fmaxf(p0, 1e-10f));
-    float l1 = logf(fmaxf(p1, 1e-10f));
-    if (a.db10) { l0 = 10.0f * l0 / 2.30258509f; l1 = 10.0f * l1 / 2.30258509f; }
-    else { l0 = l0 / 2.30258509f; l1 = l1 / 2.30258509f; }
-    if (fvalid) {
-      f32x2 o = {l0, l1};
-      *reinterpret_cast<f32x2*>(orow + bin0) = o;
-      if (bin0 < a.nbins) mx = fmaxf(mx, l0);
-      if (bin0 + 1 < a.nbins) mx = fmaxf(mx, l1);
+  for (int rt = 0; rt < RT; ++rt) {
+    const int ft = ftp * RT + rt;
+    float mx = -INFINITY;
+    const bool fvalid = f[rt] < a.F;
+    float* orow = a.logp + ((size_t)b * a.F + fc[rt]) * a.LP;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int bin0 = 8 * (c0 + i) + 2 * g;
+      const f32x4 v = acc[rt][i];
+      const float p0 = v.x * v.x + v.y * v.y;
+      const float p1 = v.z * v.z + v.w * v.w;
+      float l0 = logf(fmaxf(p0, 1e-10f));
+      float l1 = logf(fmaxf(p1, 1e-10f));
+      if (a.db10) { l0 = 10.0f * l0 / 2.30258509f; l1 = 10.0f * l1 / 2.30258509f; }
+      else { l0 = l0 / 2.30258509f; l1 = l1 / 2.30258509f; }
+      if (fvalid) {
+        f32x2 o = {l0, l1};
+        *reinterpret_cast<f32x2*>(orow + bin0) = o;
+        if (bin0 < a.nbins) mx = fmaxf(mx, l0);
+        if (bin0 + 1 < a.nbins) mx = fmaxf(mx, l1);
+      }
     }
-  }
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  if (lane == 0) a.pmax[(size_t)b * a.FT * a.NCH + ft * a.NCH + chunk] = mx;
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0 && ft < a.FT) a.pmax[(size_t)b * a.FT * a.NCH + ft * a.NCH + chunk] = mx;
+  }
 }
 
 int launch_stft(const StftArgs& a, hipStream_t s) {
-  constexpr int CT = 13;
+  constexpr int CT = 13, RT = 2;
   if (a.NT % CT != 0 || a.NCH != a.NT / CT) return -1;
-  dim3 grid((a.B * a.FT + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.NCH);
-  hipLaunchKernelGGL((stft_kernel<CT>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  const int FTP = (a.FT + RT - 1) / RT;
+  dim3 grid((a.B * FTP + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.NCH);
+  hipLaunchKernelGGL((stft_kernel<RT, CT>), grid, dim3(BLOCK_THREADS), 0, s, a);
   return 0;
 }
 
@@ -114,14 +132,17 @@ __global__ __launch_bounds__(BLOCK_THREADS) void mel_kernel(MelArgs a) {
   const bool norm = a.umax != nullptr;
   const float um = norm ? a.umax[b] : 0.f;
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + lane;
-  f32x4 acc[CT];
+  f32x4 acc[1][CT];
 #pragma unroll
-  for (int i = 0; i < CT; ++i) acc[i] = splat4(0.f);
+  for (int i = 0; i < CT; ++i) acc[0][i] = splat4(0.f);
   const int LP = a.LP, nbins = a.nbins;
   const float floor_db = a.floor_db;
-  auto xp = [&](int kb) -> f32x4 {
+  auto xp = [&](int, int kb) -> f32x4 {
     const int k = 16 * kb + g4;
-    f32x4 x = (k < LP) ? ldg4(row + k) : splat4(0.f);
+    return ldg4(row + (k < LP ? k : 0));
+  };
+  auto fx = [&](int, int kb, f32x4 x) -> f32x4 {
+    const int k = 16 * kb + g4;
     if (norm) {
       x.x = fmaxf(x.x - um, floor_db);
       x.y = fmaxf(x.y - um, floor_db);
@@ -134,12 +155,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void mel_kernel(MelArgs a) {
     x.w = (k + 3 < nbins) ? x.w : 0.f;
     return x;
   };
-  sweep_k<CT>(acc, wp, a.NTm, 0, a.KBm, xp);
+  sweep_k<1, CT>(acc, wp, a.NTm, 0, a.KBm, xp, fx);
   if (f < a.F) {
     float* orow = a.mel + ((size_t)b * a.F + f) * a.NM;
 #pragma unroll
     for (int i = 0; i < CT; ++i)
-      if (16 * i + g4 + 3 < a.NM) stg4(orow + 16 * i + g4, acc[i]);
+      if (16 * i + g4 + 3 < a.NM) stg4(orow + 16 * i + g4, acc[0][i]);
   }
 }
 
@@ -291,17 +312,17 @@ __global__ __launch_bounds__(BLOCK_THREADS) void stream_gemm_kernel(StreamGemmAr
   const int tok = wid * 16 + c;
   const float* __restrict__ xr = a.x + (size_t)min(tok, a.M - 1) * a.K + g4;
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + lane;
-  f32x4 acc[CT];
+  f32x4 acc[1][CT];
 #pragma unroll
-  for (int i = 0; i < CT; ++i) acc[i] = ldg4(a.bias + 16 * i + g4);
+  for (int i = 0; i < CT; ++i) acc[0][i] = ldg4(a.bias + 16 * i + g4);
   const int KBT = a.K / 16;
-  auto xp = [&](int kb) -> f32x4 { return ldg4(xr + 16 * kb); };
-  sweep_k<CT>(acc, wp, a.NT, 0, KBT, xp);
+  auto xp = [&](int, int kb) -> f32x4 { return ldg4(xr + 16 * kb); };
+  sweep_k<1, CT>(acc, wp, a.NT, 0, KBT, xp, [](int, int, f32x4 x) { return x; });
   if (tok < a.M) {
     float* orow = a.y + (size_t)tok * a.ldy;
 #pragma unroll
     for (int i = 0; i < CT; ++i)
-      if (16 * i + g4 + 3 < a.n_valid) stg4(orow + 16 * i + g4, acc[i]);
+      if (16 * i + g4 + 3 < a.n_valid) stg4(orow + 16 * i + g4, acc[0][i]);
   }
 }
 
