@@ -2,6 +2,8 @@
 // GEMMs (QKV, pw_conv_1+GLU, out-projection+residual, CTC project, CTC head+argmax), attention core,
 // depthwise conv.  Reference semantics: asr/models/conformer_blocks.py:107-265,
 // asr/models/layers/multihead_attention.py:151-188 (see DESIGN.md for the kernel <-> reference map).
+#include <cstdlib>
+
 #include "common.h"
 #include "launch.h"
 
@@ -12,57 +14,63 @@
 //           W1 = SeparableConv1D pointwise kernel, W2 = pw_conv_2
 // The hidden activation never leaves registers: GEMM1's accumulator fragment is GEMM2's operand fragment.
 // =====================================================================================================
-template <int D, int HT, int NSPLIT, int CT1, int MODE>
-__global__ __launch_bounds__(BLOCK_THREADS) void chain2_kernel(Chain2Args a) {
-  // Work split: a 16-token tile is shared by NSPLIT waves of one block, each owning HT/NSPLIT hidden tiles
-  // (both GEMMs are sliced along the hidden dimension, so the waves never exchange activations; only the
-  // [16 x D] partial outputs are summed through LDS at the end).  At the benchmark shape (1000 token tiles)
-  // this puts 4000 waves on the 1024 SIMDs instead of 1000.
+template <int D, int HT, int NSPLIT, int CT1, int MODE, int RT>
+__global__ __launch_bounds__(BLOCK_THREADS, ((RT == 1 && D <= 144) ? 2 : 1)) void chain2_kernel(Chain2Args a) {
+  // Work split: a group of RT 16-token tiles is shared by NSPLIT waves of one block, each owning HT/NSPLIT hidden
+  // tiles (both GEMMs are sliced along the hidden dimension, so the waves never exchange activations; only the
+  // [16*RT x D] partial outputs are summed through LDS at the end).
   // Weight stream: fragments are consumed in batches (one k-block of GEMM1 = CT1 fragments, one hidden tile
   // of GEMM2 = KB fragments).  Batch s+1 is loaded into the other register buffer before the MFMAs of batch
   // s are issued; sched_barrier(0) pins that order (left alone, hipcc sinks every load to its first use and
-  // waits vmcnt(0) before each 4-MFMA group).
+  // waits vmcnt(0) before each 4-MFMA group).  With RT = 2 every weight fragment feeds two token tiles, which
+  // halves the L2 -> CU weight stream per flop (the limiter of the RT = 1 form: ~9 TB/s at 46 % MFMA busy).
   constexpr int KB = D / 16;
   constexpr int HW = HT / NSPLIT;           // hidden tiles per wave
   constexpr int NCH = HW / CT1;             // chunks of CT1 hidden tiles
-  constexpr int TPB = WAVES_PER_BLOCK / NSPLIT;
+  constexpr int TPB = WAVES_PER_BLOCK / NSPLIT;   // tile groups per block
   constexpr int NBUF = (CT1 > KB) ? CT1 : KB;
   constexpr int SPC = KB + CT1;             // pipeline steps per chunk
   constexpr int S = NCH * SPC;
   static_assert(HT % NSPLIT == 0 && HW % CT1 == 0 && WAVES_PER_BLOCK % NSPLIT == 0, "bad split");
-  __shared__ f32x4 red[WAVES_PER_BLOCK][KB][64];
+  static_assert(NCH == 1, "one chunk per wave (keeps the pipeline loop fully unrollable)");
+  __shared__ f32x4 red[WAVES_PER_BLOCK][RT][KB][64];
 
   const int lane = threadIdx.x & 63;
   const int g4 = (lane >> 4) * 4;
   const int t = lane & 15;
   const int wave = threadIdx.x >> 6;
   const int part = wave % NSPLIT;
-  const int tile = blockIdx.x * TPB + wave / NSPLIT;
+  const int grp = blockIdx.x * TPB + wave / NSPLIT;   // group of RT token tiles
   const int tiles = (a.M + 15) / 16;
-  const bool active = tile < tiles;
-  const int tok = min(tile, tiles - 1) * 16 + t;
-  const size_t row = (size_t)min(tok, a.M - 1) * D;
   const int hbase = part * HW;
 
-  f32x4 xs[KB];
+  int tok[RT];
+  size_t row[RT];
+  f32x4 xs[RT][KB];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x + row + 16 * kb + g4);
+  for (int rt = 0; rt < RT; ++rt) {
+    tok[rt] = min(grp * RT + rt, tiles - 1) * 16 + t;
+    if (grp * RT + rt >= tiles) tok[rt] = a.M;           // phantom tile: computed on clamped rows, never stored
+    row[rt] = (size_t)min(tok[rt], a.M - 1) * D;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xs[rt][kb] = ldg4(a.x + row[rt] + 16 * kb + g4);
+  }
 
   const f32x4* __restrict__ w1 = reinterpret_cast<const f32x4*>(a.w1p) + lane;
   const f32x4* __restrict__ w2 = reinterpret_cast<const f32x4*>(a.w2p) + lane;
   f32x4 wb[2][NBUF];
-  f32x4 acc1[CT1], acc2[KB], aff_s[CT1], aff_t[CT1];
+  f32x4 acc1[RT][CT1], acc2[RT][KB], b1v[CT1], aff_s[CT1], aff_t[CT1];
 
   // prefetch of pipeline step s (s is a compile-time constant after unrolling)
   auto prefetch = [&](int s, f32x4(&dst)[NBUF]) {
-    const int ch = s / SPC, r = s % SPC;
-    const int h0 = hbase + ch * CT1;
+    const int r = s % SPC;
+    const int h0 = hbase;
     if (r < KB) {
 #pragma unroll
       for (int i = 0; i < CT1; ++i) dst[i] = w1[(size_t)(r * HT + h0 + i) * 64];
       if (r == 0) {   // bias of this chunk rides with its first batch
 #pragma unroll
-        for (int i = 0; i < CT1; ++i) acc1[i] = ldg4(a.b1 + 16 * (h0 + i) + g4);
+        for (int i = 0; i < CT1; ++i) b1v[i] = ldg4(a.b1 + 16 * (h0 + i) + g4);
       }
     } else {
       const int n1 = r - KB;
@@ -79,77 +87,119 @@ __global__ __launch_bounds__(BLOCK_THREADS) void chain2_kernel(Chain2Args a) {
   };
 
   prefetch(0, wb[0]);
-  if (MODE == 0) ln_apply<KB>(xs, a.ln_g, a.ln_b, g4, a.eps);
+  if (MODE == 0) {
 #pragma unroll
-  for (int nt = 0; nt < KB; ++nt) acc2[nt] = splat4(0.f);
+    for (int rt = 0; rt < RT; ++rt) ln_apply<KB>(xs[rt], a.ln_g, a.ln_b, g4, a.eps);
+  }
 
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int r = s % SPC;
-    // acc1 of the NEXT chunk is written by prefetch(r==0) while the current chunk still reads acc1 in its
-    // last GEMM2 step; with NCH == 1 this never happens, with NCH > 1 the bias prefetch is deferred one step.
-    if (s + 1 < S && !((s + 1) % SPC == 0)) prefetch(s + 1, wb[(s + 1) & 1]);
+    if (s + 1 < S) prefetch(s + 1, wb[(s + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);
     if (r < KB) {
+      if (r == 0) {
 #pragma unroll
-      for (int i = 0; i < CT1; ++i) acc1[i] = mma_kblock(wb[s & 1][i], xs[r], acc1[i]);
+        for (int i = 0; i < CT1; ++i)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = b1v[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < CT1; ++i)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = mfma4(wb[s & 1][i][j], xs[rt][r][j], acc1[rt][i]);
     } else {
       const int n1 = r - KB;
       if (n1 == 0) {
 #pragma unroll
-        for (int i = 0; i < CT1; ++i)
-          acc1[i] = (MODE == 1) ? swish4(acc1[i] * aff_s[i] + aff_t[i]) : swish4(acc1[i]);
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+          for (int i = 0; i < CT1; ++i)
+            acc1[rt][i] = (MODE == 1) ? swish4(acc1[rt][i] * aff_s[i] + aff_t[i]) : swish4(acc1[rt][i]);
+          // acc2 starts life here (xs is dead by now, so the allocator can hand its registers over)
+#pragma unroll
+          for (int nt = 0; nt < KB; ++nt) acc2[rt][nt] = splat4(0.f);
+        }
       }
 #pragma unroll
-      for (int n2 = 0; n2 < KB; ++n2) acc2[n2] = mma_kblock(wb[s & 1][n2], acc1[n1], acc2[n2]);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n2 = 0; n2 < KB; ++n2)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc2[rt][n2] = mfma4(wb[s & 1][n2][j], acc1[rt][n1][j], acc2[rt][n2]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 1 < S && ((s + 1) % SPC == 0)) {   // chunk boundary: acc1 is free now
-      prefetch(s + 1, wb[(s + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
   }
 
+  // the epilogue wave fetches residual + bias before the barrier so that their latency overlaps the wait
+  f32x4 rres[RT][KB], rb2[KB];
+  if (part == 0) {
+#pragma unroll
+    for (int nt = 0; nt < KB; ++nt) {
+      rb2[nt] = ldg4(a.b2 + 16 * nt + g4);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) rres[rt][nt] = ldg4(a.res + row[rt] + 16 * nt + g4);
+    }
+  }
   if (NSPLIT > 1) {
     if (part != 0) {
 #pragma unroll
-      for (int nt = 0; nt < KB; ++nt) red[wave][nt][lane] = acc2[nt];
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < KB; ++nt) red[wave][rt][nt][lane] = acc2[rt][nt];
     }
     __syncthreads();
     if (part != 0) return;
 #pragma unroll
     for (int p = 1; p < NSPLIT; ++p)
 #pragma unroll
-      for (int nt = 0; nt < KB; ++nt) acc2[nt] += red[wave + p][nt][lane];
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < KB; ++nt) acc2[rt][nt] += red[wave + p][rt][nt][lane];
   }
-  if (!active) return;
 
 #pragma unroll
-  for (int nt = 0; nt < KB; ++nt) {
-    f32x4 r = ldg4(a.res + row + 16 * nt + g4);
-    f32x4 b = ldg4(a.b2 + 16 * nt + g4);
-    acc2[nt] = r + splat4(a.scale) * (acc2[nt] + b);
-  }
-  if (a.fln_g != nullptr) ln_apply<KB>(acc2, a.fln_g, a.fln_b, g4, a.eps);
-  if (tok < a.M) {
+  for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-    for (int nt = 0; nt < KB; ++nt) stg4(a.y + row + 16 * nt + g4, acc2[nt]);
+    for (int nt = 0; nt < KB; ++nt) acc2[rt][nt] = rres[rt][nt] + splat4(a.scale) * (acc2[rt][nt] + rb2[nt]);
+    if (a.fln_g != nullptr) ln_apply<KB>(acc2[rt], a.fln_g, a.fln_b, g4, a.eps);
+    if (tok[rt] < a.M) {
+#pragma unroll
+      for (int nt = 0; nt < KB; ++nt) stg4(a.y + row[rt] + 16 * nt + g4, acc2[rt][nt]);
+    }
   }
 }
 
-template <int D, int HT, int NSPLIT, int CT1, int MODE>
-static void launch_chain2_t(const Chain2Args& a, hipStream_t s) {
+template <int D, int HT, int NSPLIT, int CT1, int MODE, bool HAS_RT2>
+static void launch_chain2_t(const Chain2Args& a, int rt, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
   constexpr int TPB = WAVES_PER_BLOCK / NSPLIT;
-  hipLaunchKernelGGL((chain2_kernel<D, HT, NSPLIT, CT1, MODE>), dim3((tiles + TPB - 1) / TPB), dim3(BLOCK_THREADS), 0,
-                     s, a);
+  if (HAS_RT2 && rt == 2) {
+    const int groups = (tiles + 1) / 2;
+    hipLaunchKernelGGL((chain2_kernel<D, HT, NSPLIT, CT1, MODE, (HAS_RT2 ? 2 : 1)>), dim3((groups + TPB - 1) / TPB),
+                       dim3(BLOCK_THREADS), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((chain2_kernel<D, HT, NSPLIT, CT1, MODE, 1>), dim3((tiles + TPB - 1) / TPB), dim3(BLOCK_THREADS),
+                       0, s, a);
+  }
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
 }
 
 int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s) {
-  if (D == 144 && mode == 0) launch_chain2_t<144, 36, 4, 9, 0>(a, s);
-  else if (D == 144 && mode == 1) launch_chain2_t<144, 18, 2, 9, 1>(a, s);
-  else if (D == 256 && mode == 0) launch_chain2_t<256, 64, 4, 16, 0>(a, s);
-  else if (D == 256 && mode == 1) launch_chain2_t<256, 32, 4, 8, 1>(a, s);
+  // two token tiles per wave once there are enough tiles to keep every CU busy with tile pairs
+  static const int rt_env = env_int("MI355ASR_CHAIN2_RT", 0);
+  const int tiles = (a.M + 15) / 16;
+  const int rt = rt_env ? rt_env : (tiles >= 512 ? 2 : 1);
+  if (D == 144 && mode == 0) launch_chain2_t<144, 36, 4, 9, 0, true>(a, rt, s);
+  else if (D == 144 && mode == 1) launch_chain2_t<144, 18, 2, 9, 1, true>(a, rt, s);
+  else if (D == 256 && mode == 0) launch_chain2_t<256, 64, 4, 16, 0, false>(a, 1, s);
+  else if (D == 256 && mode == 1) launch_chain2_t<256, 32, 4, 8, 1, false>(a, 1, s);
   else return -1;
   return 0;
 }
@@ -163,7 +213,7 @@ int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s) {
 //   EPI_HEAD      optional logits store + per-token argmax, first max wins (fully_connected + greedy)
 // =====================================================================================================
 template <int D, int RT, int CT, int EPI, bool LN>
-__global__ __launch_bounds__(BLOCK_THREADS) void gemm_rows_kernel(GemmArgs a) {
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm_rows_kernel(GemmArgs a) {
   constexpr int KB = D / 16;
   constexpr int NF = (EPI == EPI_GLU) ? 2 * CT : CT;   // weight fragments per k-block batch
   static_assert(RT == 1, "one row tile per wave");
@@ -218,8 +268,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void gemm_rows_kernel(GemmArgs a) {
       if (kb + 1 < KB) fetch(c0, kb + 1, wb[(kb + 1) & 1]);
       else fetch(cn, 0, wb[(kb + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NF; ++i) acc[i] = mma_kblock(wb[kb & 1][i], xs[kb], acc[i]);
+      mma_batch<NF>(acc, wb[kb & 1], xs[kb]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (KB & 1) {   // odd number of steps per chunk: move the prefetched batch back to buffer 0
@@ -329,7 +378,7 @@ int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s) 
 // online softmax, so any T works.
 // =====================================================================================================
 template <int HS, int KT>
-__global__ __launch_bounds__(BLOCK_THREADS) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a) {
   constexpr int FB = HS / 16;          // full 16-wide feature blocks
   constexpr int TS = (HS % 16) / 4;    // tail k-steps (feature = 16*FB + 4*ts + g)
   constexpr int OT = (HS + 15) / 16;   // output feature tiles
@@ -407,15 +456,24 @@ __global__ __launch_bounds__(BLOCK_THREADS) void attention_kernel(AttnArgs a) {
       if (s + 1 < NKB) load_k(k0, s + 1, (s + 1) & 1);
       else load_v(k0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      // k-step-major issue order: consecutive MFMAs go to different key tiles (independent accumulators)
 #pragma unroll
-      for (int tt = 0; tt < KG; ++tt) {
-        f32x4 acc = splat4(0.f);
+      for (int tt = 0; tt < KG; ++tt) sc[s * KG + tt] = splat4(0.f);
 #pragma unroll
-        for (int f = 0; f < FB; ++f) acc = mma_kblock(kb4[s & 1][tt][f], q4[f], acc);
+      for (int f = 0; f < FB; ++f) {
 #pragma unroll
-        for (int f = 0; f < TS; ++f) acc = mfma4(kbs[s & 1][tt][f], qs[f], acc);
-        sc[s * KG + tt] = acc;
+        for (int tt = 0; tt < KG; ++tt) sc[s * KG + tt] = mfma4(kb4[s & 1][tt][f].x, q4[f].x, sc[s * KG + tt]);
+#pragma unroll
+        for (int tt = 0; tt < KG; ++tt) sc[s * KG + tt] = mfma4(kb4[s & 1][tt][f].y, q4[f].y, sc[s * KG + tt]);
+#pragma unroll
+        for (int tt = 0; tt < KG; ++tt) sc[s * KG + tt] = mfma4(kb4[s & 1][tt][f].z, q4[f].z, sc[s * KG + tt]);
+#pragma unroll
+        for (int tt = 0; tt < KG; ++tt) sc[s * KG + tt] = mfma4(kb4[s & 1][tt][f].w, q4[f].w, sc[s * KG + tt]);
       }
+#pragma unroll
+      for (int f = 0; f < TS; ++f)
+#pragma unroll
+        for (int tt = 0; tt < KG; ++tt) sc[s * KG + tt] = mfma4(kbs[s & 1][tt][f], qs[f], sc[s * KG + tt]);
       __builtin_amdgcn_sched_barrier(0);
     }
     // lane holds S^T[key = k0 + 16*kt + 4*g + j][query c]
@@ -456,12 +514,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void attention_kernel(AttnArgs a) {
       for (int tt = 0; tt < VG; ++tt) {
         const f32x4 p = sc[s * VG + tt];
 #pragma unroll
-        for (int i = 0; i < OT; ++i) {
-          o[i] = mfma4(vb[s & 1][tt][i][0], p.x, o[i]);
-          o[i] = mfma4(vb[s & 1][tt][i][1], p.y, o[i]);
-          o[i] = mfma4(vb[s & 1][tt][i][2], p.z, o[i]);
-          o[i] = mfma4(vb[s & 1][tt][i][3], p.w, o[i]);
-        }
+        for (int i = 0; i < OT; ++i) o[i] = mfma4(vb[s & 1][tt][i][0], p.x, o[i]);
+#pragma unroll
+        for (int i = 0; i < OT; ++i) o[i] = mfma4(vb[s & 1][tt][i][1], p.y, o[i]);
+#pragma unroll
+        for (int i = 0; i < OT; ++i) o[i] = mfma4(vb[s & 1][tt][i][2], p.z, o[i]);
+#pragma unroll
+        for (int i = 0; i < OT; ++i) o[i] = mfma4(vb[s & 1][tt][i][3], p.w, o[i]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -16,7 +16,7 @@
 // interleaved so that a lane's float4 accumulator is (re,im,re,im) of two adjacent bins).
 // ---------------------------------------------------------------------------------------------------
 template <int RT, int CT>
-__global__ __launch_bounds__(BLOCK_THREADS) void stft_kernel(StftArgs a) {
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void stft_kernel(StftArgs a) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, g4 = g * 4, c = lane & 15;
   const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -259,11 +259,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void subconv_kernel(SubConvArgs a) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         xf[rt] = (tv[rt][kt] && fv[rt][kf]) ? v : splat4(0.f);
       }
-#pragma unroll
-      for (int n = 0; n < KB; ++n) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt][n] = mma_kblock(wb[q & 1][n], xf[rt], acc[rt][n]);
-      }
+      mma_batch_rt<RT, KB>(acc, wb[q & 1], xf);
       __builtin_amdgcn_sched_barrier(0);
     }
     // nine steps per channel block: the batch prefetched last sits in wb[1]; the next block starts from wb[0]
