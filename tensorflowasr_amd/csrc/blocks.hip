@@ -7,6 +7,11 @@
 #include "common.h"
 #include "launch.h"
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 // =====================================================================================================
 // chain2: y = res + scale * ( act( pro(x) W1 + b1 ) W2 + b2 )      [optionally followed by LayerNorm]
 //   MODE 0 (FFModule, conformer_blocks.py:126-134): pro = LayerNorm, act = swish
@@ -186,11 +191,6 @@ static void launch_chain2_t(const Chain2Args& a, int rt, hipStream_t s) {
   }
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s) {
   // two token tiles per wave once there are enough tiles to keep every CU busy with tile pairs
   static const int rt_env = env_int("MI355ASR_CHAIN2_RT", 0);
@@ -213,22 +213,26 @@ int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s) {
 //   EPI_HEAD      optional logits store + per-token argmax, first max wins (fully_connected + greedy)
 // =====================================================================================================
 template <int D, int RT, int CT, int EPI, bool LN>
-__global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm_rows_kernel(GemmArgs a) {
+__global__ __launch_bounds__(BLOCK_THREADS, ((RT == 1 || D <= 144) ? 2 : 1)) void gemm_rows_kernel(GemmArgs a) {
   constexpr int KB = D / 16;
   constexpr int NF = (EPI == EPI_GLU) ? 2 * CT : CT;   // weight fragments per k-block batch
-  static_assert(RT == 1, "one row tile per wave");
   const int lane = threadIdx.x & 63;
   const int g4 = (lane >> 4) * 4;
   const int t = lane & 15;
   const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  if ((size_t)wid * 16 >= (size_t)a.M) return;
+  if ((size_t)wid * RT * 16 >= (size_t)a.M) return;
 
-  const int tok = wid * 16 + t;
-  const bool live = tok < a.M;
-  const size_t row = (size_t)min(tok, a.M - 1) * D;
-  f32x4 xs[KB];
+  int tok[RT];
+  bool live[RT];
+  f32x4 xs[RT][KB];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x + row + 16 * kb + g4);
+  for (int rt = 0; rt < RT; ++rt) {
+    tok[rt] = (wid * RT + rt) * 16 + t;
+    live[rt] = tok[rt] < a.M;
+    const size_t row = (size_t)min(tok[rt], a.M - 1) * D;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xs[rt][kb] = ldg4(a.x + row + 16 * kb + g4);
+  }
 
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + lane;
   const int NT = a.NT;                                  // column tiles in the packed weight
@@ -249,18 +253,29 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm_rows_kernel(GemmArgs a)
   f32x4 wb[2][NF];
   int c0 = blockIdx.y * CT;
   fetch(c0, 0, wb[0]);
-  if (LN) ln_apply<KB>(xs, a.ln_g, a.ln_b, g4, a.eps);
+  if (LN) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) ln_apply<KB>(xs[rt], a.ln_g, a.ln_b, g4, a.eps);
+  }
 
-  float best_v = -INFINITY;
-  int best_i = 0x7fffffff;
+  float best_v[RT];
+  int best_i[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) { best_v[rt] = -INFINITY; best_i[rt] = 0x7fffffff; }
 
 #pragma unroll 1
   for (; c0 < NTC; c0 += cstep) {
-    f32x4 acc[NF];
+    f32x4 acc[RT][NF];
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-      acc[i] = ldg4(a.bias + 16 * (c0 + i) + g4);
-      if (EPI == EPI_GLU) acc[CT + i] = ldg4(a.bias + 16 * (half + c0 + i) + g4);
+      const f32x4 bv = ldg4(a.bias + 16 * (c0 + i) + g4);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt][i] = bv;
+      if (EPI == EPI_GLU) {
+        const f32x4 bg = ldg4(a.bias + 16 * (half + c0 + i) + g4);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt][CT + i] = bg;
+      }
     }
     const int cn = (c0 + cstep < NTC) ? c0 + cstep : c0;   // next chunk (clamped: the extra fetch is harmless)
 #pragma unroll
@@ -268,7 +283,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm_rows_kernel(GemmArgs a)
       if (kb + 1 < KB) fetch(c0, kb + 1, wb[(kb + 1) & 1]);
       else fetch(cn, 0, wb[(kb + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-      mma_batch<NF>(acc, wb[kb & 1], xs[kb]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[rt][i] = mfma4(wb[kb & 1][i][j], xs[rt][kb][j], acc[rt][i]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (KB & 1) {   // odd number of steps per chunk: move the prefetched batch back to buffer 0
@@ -276,70 +296,86 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm_rows_kernel(GemmArgs a)
       for (int i = 0; i < NF; ++i) wb[0][i] = wb[1][i];
     }
 
-    if (EPI == EPI_GLU) {
-      if (live) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (EPI == EPI_GLU) {
+        if (live[rt]) {
+#pragma unroll
+          for (int i = 0; i < CT; ++i) {
+            const f32x4 va = acc[rt][i], vb = acc[rt][CT + i];
+            f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z),
+                       va.w * fast_sigmoid(vb.w)};
+            stg4(a.y + (size_t)tok[rt] * a.ldy + 16 * (c0 + i) + g4, o);
+          }
+        }
+      } else {
+        const size_t orow = (size_t)min(tok[rt], a.M - 1) * a.ldy;
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-          const f32x4 va = acc[i], vb = acc[CT + i];
-          f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z),
-                     va.w * fast_sigmoid(vb.w)};
-          stg4(a.y + (size_t)tok * a.ldy + 16 * (c0 + i) + g4, o);
-        }
-      }
-    } else {
-      const size_t orow = (size_t)min(tok, a.M - 1) * a.ldy;
-#pragma unroll
-      for (int i = 0; i < CT; ++i) {
-        const int f0 = 16 * (c0 + i) + g4;   // first of this lane's 4 features
-        f32x4 v = acc[i];
-        if (EPI == EPI_RESIDUAL) v += ldg4(a.res + orow + f0);
-        if (EPI == EPI_QKV) {
-          if (c0 + i < a.qtiles) v *= splat4(a.qscale);
-        }
-        if (EPI == EPI_HEAD) {
-          // running argmax in increasing feature order, strict '>' => first maximum wins
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (f0 + j < a.n_valid && vv[j] > best_v) { best_v = vv[j]; best_i = f0 + j; }
+          const int f0 = 16 * (c0 + i) + g4;   // first of this lane's 4 features
+          f32x4 v = acc[rt][i];
+          if (EPI == EPI_RESIDUAL) v += ldg4(a.res + orow + f0);
+          if (EPI == EPI_QKV) {
+            if (c0 + i < a.qtiles) v *= splat4(a.qscale);
           }
-          if (a.y != nullptr && live) {
-            if (f0 + 3 < a.n_valid && (a.ldy & 3) == 0) {
-              stg4(a.y + orow + f0, v);
-            } else {
+          if (EPI == EPI_HEAD) {
+            // running argmax in increasing feature order, strict '>' => first maximum wins
+            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (f0 + j < a.n_valid) a.y[orow + f0 + j] = vv[j];
+            for (int j = 0; j < 4; ++j) {
+              if (f0 + j < a.n_valid && vv[j] > best_v[rt]) { best_v[rt] = vv[j]; best_i[rt] = f0 + j; }
             }
+            if (a.y != nullptr && live[rt]) {
+              if (f0 + 3 < a.n_valid && (a.ldy & 3) == 0) {
+                stg4(a.y + orow + f0, v);
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  if (f0 + j < a.n_valid) a.y[orow + f0 + j] = vv[j];
+              }
+            }
+          } else if (live[rt]) {
+            if (f0 + 3 < a.n_valid) stg4(a.y + orow + f0, v);
           }
-        } else if (live) {
-          if (f0 + 3 < a.n_valid) stg4(a.y + orow + f0, v);
         }
       }
     }
   }
 
   if (EPI == EPI_HEAD) {
-    float bv = best_v;
-    int bi = best_i;
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      float ov = __shfl_xor(bv, off);
-      int oi = __shfl_xor(bi, off);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane < 16 && live) {
-      a.argmax_out[tok] = bi;
-      if (a.maxval_out != nullptr) a.maxval_out[tok] = bv;
+    for (int rt = 0; rt < RT; ++rt) {
+      float bv = best_v[rt];
+      int bi = best_i[rt];
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        float ov = __shfl_xor(bv, off);
+        int oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (lane < 16 && live[rt]) {
+        a.argmax_out[tok[rt]] = bi;
+        if (a.maxval_out != nullptr) a.maxval_out[tok[rt]] = bv;
+      }
     }
   }
 }
 
-template <int D, int CT, int EPI, bool LN>
+template <int D, int CT, int EPI, bool LN, bool HAS_RT2>
 static void launch_gemm_rows_t(const GemmArgs& a, int ychunks, hipStream_t s) {
+  static const int rt_env = env_int("MI355ASR_GEMM_RT", 0);
   const int tiles = (a.M + 15) / 16;
-  dim3 grid((tiles + 3) / 4, ychunks);
-  hipLaunchKernelGGL((gemm_rows_kernel<D, 1, CT, EPI, LN>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  // two token tiles per wave halve the L2 weight stream per flop, but at the benchmark shape these short
+  // kernels (13-40 us) are bound by ramp-up/tail, and the RT = 2 form measured 10-50 % slower (qkv 40 -> 44 us,
+  // out-projection 15 -> 24 us); it pays only with several waves per SIMD left over, i.e. very large batches.
+  const int rt = rt_env ? rt_env : ((tiles / 2) * ychunks >= 8192 ? 2 : 1);
+  if (HAS_RT2 && rt == 2) {
+    dim3 grid(((tiles + 1) / 2 + 3) / 4, ychunks);
+    hipLaunchKernelGGL((gemm_rows_kernel<D, (HAS_RT2 ? 2 : 1), CT, EPI, LN>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  } else {
+    dim3 grid((tiles + 3) / 4, ychunks);
+    hipLaunchKernelGGL((gemm_rows_kernel<D, 1, CT, EPI, LN>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  }
 }
 
 int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s) {
@@ -348,7 +384,7 @@ int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s) 
   const int ct = gemm_ct(D, epi);
   const int chunks = (epi == EPI_GLU) ? (a.NT / 2) / ct : a.NT / ct;
   const int ych = (epi == EPI_HEAD) ? 1 : chunks;
-#define GO(DD, CT, EPI, LNF) launch_gemm_rows_t<DD, CT, EPI, LNF>(a, ych, s)
+#define GO(DD, CT, EPI, LNF) launch_gemm_rows_t<DD, CT, EPI, LNF, (DD == 144 && EPI != EPI_HEAD)>(a, ych, s)
   if (D == 144) {
     if (epi == EPI_BIAS && !ln) GO(144, 9, EPI_BIAS, false);
     else if (epi == EPI_RESIDUAL && !ln) GO(144, 9, EPI_RESIDUAL, false);
