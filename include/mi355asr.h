@@ -105,6 +105,30 @@ int mi355asr_ctc_forward(mi355asr_model* m, const float* enc_dev, int32_t B, int
 int mi355asr_ctc_greedy(const int32_t* frame_argmax_dev, const int32_t* in_len_dev, int32_t B, int32_t T,
                         int32_t blank, int32_t* ids_dev, int32_t* out_len_dev, void* stream);
 
+/* replaces: ctc_beam_search_decoder_batch(probs_split, vocabulary, beam_size, num_processes, cutoff_prob,
+ * cutoff_top_n, ext_scorer = nullptr) of externals/ctc_decoders (ctc_beam_search_decoder.cpp:18-187, 426-459;
+ * SWIG entry decoders.i) -- the scorer-less CTC prefix beam search.  Blank = class V-1, vocabulary = classes
+ * 0..V-2 (as the reference assigns blank_id = vocabulary.size()).  Token ids are returned instead of the
+ * concatenated vocabulary strings.  Outputs are HOST buffers: ids i32 [B, beam, max_len] (-1 padded, hypotheses
+ * best first), lens i32 [B, beam], scores f32 [B, beam] (log prob), n_hyp i32 [B] (number of valid hypotheses).
+ * Reference quirk kept: with cutoff_prob == 1.0 no class is pruned, whatever cutoff_top_n says
+ * (decoder_utils.cpp:18-31).
+ *   _host : probs_host f32 [B, T, V] on the host; everything runs on the CPU threads (model-independent helper,
+ *           also what the unit tests pin against the reference's own decoder).
+ *   device: x_dev f32 [B, T, V] logits (is_logits != 0: softmax is fused into the selection kernel) or
+ *           probabilities; the per-frame top-cutoff_top_n selection runs on the GPU, the prefix search on
+ *           `num_threads` host threads.  Needs cutoff_prob < 1 and cutoff_top_n <= 128 (otherwise use _host).
+ *           Synchronises `stream` (the search consumes the selection on the host).
+ *           ws_dev: at least B*T*cutoff_top_n*8 bytes. */
+int mi355asr_ctc_prefix_beam_host(const float* probs_host, const int32_t* in_len_host, int32_t B, int32_t T, int32_t V,
+                                  int32_t beam_size, double cutoff_prob, int32_t cutoff_top_n, int32_t num_threads,
+                                  int32_t max_len, int32_t* ids_host, int32_t* lens_host, float* scores_host,
+                                  int32_t* n_hyp_host);
+int mi355asr_ctc_prefix_beam(const float* x_dev, int32_t is_logits, const int32_t* in_len_host, int32_t B, int32_t T,
+                             int32_t V, int32_t beam_size, double cutoff_prob, int32_t cutoff_top_n,
+                             int32_t num_threads, int32_t max_len, int32_t* ids_host, int32_t* lens_host,
+                             float* scores_host, int32_t* n_hyp_host, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* encoder + CTCDecoder + greedy in one call: wav [B,L] -> ids i32 [B,T_total] (-1 padded), out_len i32 [B].
  * This is the timed region of bench.py (offline_stt steps 3-5, test_asr.py:191-198). */
 int mi355asr_recognize(mi355asr_model* m, const float* wav_dev, int32_t B, int32_t L, const int32_t* in_len_dev,

@@ -43,6 +43,9 @@ SIGNATURES = {
     "mi355asr_encoder_forward": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "mi355asr_ctc_forward": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
     "mi355asr_ctc_greedy": (ctypes.c_int, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "mi355asr_ctc_prefix_beam_host": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, ctypes.c_double, _I, _I, _I, _P, _P, _P, _P]),
+    "mi355asr_ctc_prefix_beam": (ctypes.c_int, [_P, _I, _P, _I, _I, _I, _I, ctypes.c_double, _I, _I, _I, _P, _P, _P, _P,
+                                                _P, _SZ, _P]),
     "mi355asr_recognize": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "mi355asr_melspectrogram": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "mi355asr_conv_subsampling": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),

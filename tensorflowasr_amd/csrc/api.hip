@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/mi355asr.h"
+#include "beam.h"
 #include "launch.h"
 
 namespace {
@@ -763,6 +764,46 @@ int mi355asr_ctc_greedy(const int32_t* frame_argmax, const int32_t* in_len, int3
   CollapseArgs ca{frame_argmax, in_len, ids, out_len, B, T, blank};
   LAUNCH_TRY(launch_collapse(ca, (hipStream_t)stream), "ctc collapse");
   return 0;
+}
+
+int mi355asr_ctc_prefix_beam_host(const float* probs, const int32_t* in_len, int32_t B, int32_t T, int32_t V,
+                                  int32_t beam_size, double cutoff_prob, int32_t cutoff_top_n, int32_t num_threads,
+                                  int32_t max_len, int32_t* ids, int32_t* lens, float* scores, int32_t* n_hyp) {
+  if (!probs || !ids || !lens || !scores || !n_hyp) return fail(MI355ASR_EINVAL, "null pointer");
+  if (B <= 0 || T <= 0 || V < 2 || beam_size <= 0 || max_len <= 0 || cutoff_top_n <= 0)
+    return fail(MI355ASR_EINVAL, "bad beam-search argument (B=%d T=%d V=%d beam=%d max_len=%d top_n=%d)", B, T, V,
+                beam_size, max_len, cutoff_top_n);
+  return mi355asr_beam_host_impl(probs, in_len, B, T, V, beam_size, cutoff_prob, cutoff_top_n, num_threads, max_len, ids,
+                                 lens, scores, n_hyp);
+}
+
+int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* in_len, int32_t B, int32_t T, int32_t V,
+                             int32_t beam_size, double cutoff_prob, int32_t cutoff_top_n, int32_t num_threads,
+                             int32_t max_len, int32_t* ids, int32_t* lens, float* scores, int32_t* n_hyp, void* ws,
+                             size_t ws_bytes, void* stream) {
+  if (!x || !ids || !lens || !scores || !n_hyp || !ws) return fail(MI355ASR_EINVAL, "null pointer");
+  if (B <= 0 || T <= 0 || V < 2 || beam_size <= 0 || max_len <= 0 || cutoff_top_n <= 0)
+    return fail(MI355ASR_EINVAL, "bad beam-search argument");
+  if (!(cutoff_prob < 1.0))
+    return fail(MI355ASR_EINVAL, "cutoff_prob >= 1 disables pruning in the reference (every class is visited): use "
+                "mi355asr_ctc_prefix_beam_host for that mode");
+  const int N = std::min(cutoff_top_n, V);
+  if (N > 128) return fail(MI355ASR_EINVAL, "cutoff_top_n=%d: the selection kernel supports up to 128", cutoff_top_n);
+  const size_t frames = (size_t)B * T;
+  const size_t need = frames * N * (sizeof(int32_t) + sizeof(float));
+  if (ws_bytes < need) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* d_idx = (int32_t*)ws;
+  float* d_p = (float*)((char*)ws + frames * N * sizeof(int32_t));
+  if (mi355asr_launch_topn(x, (int)frames, V, N, is_logits, d_idx, d_p, s) != 0)
+    return fail(MI355ASR_EHIP, "top-n kernel launch failed (V=%d needs %zu bytes of LDS)", V, (size_t)V * 4);
+  std::vector<int32_t> h_idx(frames * N);
+  std::vector<float> h_p(frames * N);
+  HIP_TRY(hipMemcpyAsync(h_idx.data(), d_idx, h_idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_p.data(), d_p, h_p.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return mi355asr_beam_topn_impl(h_idx.data(), h_p.data(), in_len, B, T, V, N, beam_size, cutoff_prob, cutoff_top_n,
+                                 num_threads, max_len, ids, lens, scores, n_hyp);
 }
 
 int mi355asr_recognize(mi355asr_model* m, const float* wav, int32_t B, int32_t L, const int32_t* in_len, int32_t* ids,

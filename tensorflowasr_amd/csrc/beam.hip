@@ -1,0 +1,336 @@
+// CTC prefix beam search (scorer-less), the decode step of BASELINE config 5.
+//
+// Reference: externals/ctc_decoders.zip -- ctc_beam_search_decoder.cpp:18-187 (search), decoder_utils.cpp:7-38
+// (get_pruned_log_probs), decoder_utils.h:41-49 (log_sum_exp), decoder_utils.cpp:137-147 (prefix_compare),
+// path_trie.cpp:37-147 (trie), ctc_beam_search_decoder.cpp:426-459 (batch = thread pool over utterances).
+//
+// MI355X split of the work:
+//   GPU  topn_kernel: per frame softmax (when fed logits) + selection of the cutoff_top_n most probable classes in
+//        descending order -- the only part of the algorithm that touches all V classes (9160 for the text decoder).
+//        HBM-bound: one read of the [frames, V] matrix.
+//   CPU  the prefix search itself: pointer-chasing, data-dependent, a few hundred float ops per frame -- it stays on
+//        the host cores, one utterance per task, like the reference's ThreadPool.  Same arithmetic as the reference:
+//        float32 trie scores, log(p + FLT_MIN) taken in double, log_sum_exp<float>.
+// The trie is an index-based arena (no per-node new/delete); the beam is advanced from the touched set instead of a
+// whole-trie DFS per frame (same resulting set: every existing node is either in the beam or was touched this frame).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "beam.h"
+
+namespace {
+
+constexpr float kNegInf = -FLT_MAX;   // NUM_FLT_INF of the reference (decoder_utils.h:9)
+
+inline float log_sum_exp(float x, float y) {   // decoder_utils.h:41-49, T = float
+  if (x <= kNegInf) return y;
+  if (y <= kNegInf) return x;
+  const float m = std::max(x, y);
+  return std::log(std::exp(x - m) + std::exp(y - m)) + m;
+}
+
+struct Node {
+  int ch, parent, first_child, next_sibling;
+  float b_prev, nb_prev, b_cur, nb_cur, score;
+  int stamp;      // frame at which the node was last put on the candidate list
+  bool exists;
+};
+
+class Trie {
+ public:
+  std::vector<Node> nodes;
+  std::vector<int> free_list;
+
+  int make(int ch, int parent) {
+    int id;
+    if (!free_list.empty()) { id = free_list.back(); free_list.pop_back(); }
+    else { id = (int)nodes.size(); nodes.emplace_back(); }
+    Node& n = nodes[id];
+    n.ch = ch; n.parent = parent; n.first_child = -1; n.next_sibling = -1;
+    n.b_prev = n.nb_prev = n.b_cur = n.nb_cur = n.score = kNegInf;
+    n.stamp = -1; n.exists = true;
+    return id;
+  }
+  // PathTrie::get_path_trie (path_trie.cpp:37-91, dictionary-less branch)
+  int child(int p, int c) {
+    for (int k = nodes[p].first_child; k >= 0; k = nodes[k].next_sibling) {
+      if (nodes[k].ch == c) {
+        Node& n = nodes[k];
+        if (!n.exists) {
+          n.exists = true;
+          n.b_prev = n.nb_prev = n.b_cur = n.nb_cur = kNegInf;
+        }
+        return k;
+      }
+    }
+    const int id = make(c, p);
+    nodes[id].next_sibling = nodes[p].first_child;
+    nodes[p].first_child = id;
+    return id;
+  }
+  // PathTrie::remove (path_trie.cpp:129-147)
+  void remove(int id) {
+    nodes[id].exists = false;
+    while (id > 0 && nodes[id].first_child < 0 && !nodes[id].exists) {
+      const int p = nodes[id].parent;
+      int* link = &nodes[p].first_child;
+      while (*link != id) link = &nodes[*link].next_sibling;
+      *link = nodes[id].next_sibling;
+      free_list.push_back(id);
+      id = p;
+    }
+  }
+};
+
+struct Cand { int c; float lp; };
+
+// decoder_utils.cpp:7-38 on a full probability row
+void pruned_from_row(const float* prob, int V, double cutoff_prob, int cutoff_top_n, std::vector<Cand>& out,
+                     std::vector<int>& order) {
+  out.clear();
+  int n = V;
+  order.resize(V);
+  for (int i = 0; i < V; ++i) order[i] = i;
+  if (cutoff_prob < 1.0 || cutoff_top_n < n) {
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return prob[a] > prob[b]; });
+    if (cutoff_prob < 1.0) {
+      double cum = 0.0;
+      n = 0;
+      for (int i = 0; i < V; ++i) {
+        cum += (double)prob[order[i]];
+        ++n;
+        if (cum >= cutoff_prob || n >= cutoff_top_n) break;
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) out.push_back({order[i], (float)std::log((double)prob[order[i]] + (double)FLT_MIN)});
+}
+
+// same, from the GPU's top-n list (already in descending order); only valid when cutoff_prob < 1
+void pruned_from_topn(const int32_t* idx, const float* p, int N, double cutoff_prob, int cutoff_top_n,
+                      std::vector<Cand>& out) {
+  out.clear();
+  double cum = 0.0;
+  int n = 0;
+  for (int i = 0; i < N; ++i) {
+    cum += (double)p[i];
+    ++n;
+    if (cum >= cutoff_prob || n >= cutoff_top_n) break;
+  }
+  for (int i = 0; i < n; ++i) out.push_back({idx[i], (float)std::log((double)p[i] + (double)FLT_MIN)});
+}
+
+struct Search {
+  Trie trie;
+  std::vector<int> prefixes, touched;
+  int beam;
+  int blank;
+
+  void reset(int beam_size, int blank_id) {
+    beam = beam_size;
+    blank = blank_id;
+    trie.nodes.clear();
+    trie.free_list.clear();
+    const int root = trie.make(-1, -1);
+    trie.nodes[root].score = trie.nodes[root].b_prev = 0.0f;
+    prefixes.assign(1, root);
+  }
+
+  bool better(int x, int y) const {   // prefix_compare (decoder_utils.cpp:137-147) + node id as the last word
+    const Node &a = trie.nodes[x], &b = trie.nodes[y];
+    if (a.score != b.score) return a.score > b.score;
+    if (a.ch != b.ch) return a.ch < b.ch;
+    return x < y;
+  }
+
+  void step(int t, const std::vector<Cand>& cands) {
+    touched.clear();
+    for (int p : prefixes) trie.nodes[p].stamp = t;
+    for (const Cand& cd : cands) {
+      const int c = cd.c;
+      const float lp = cd.lp;
+      for (size_t i = 0; i < prefixes.size(); ++i) {
+        const int pi = prefixes[i];
+        if (c == blank) {
+          Node& p = trie.nodes[pi];
+          p.b_cur = log_sum_exp(p.b_cur, lp + p.score);
+          continue;
+        }
+        if (c == trie.nodes[pi].ch) {
+          Node& p = trie.nodes[pi];
+          p.nb_cur = log_sum_exp(p.nb_cur, lp + p.nb_prev);
+        }
+        const int qi = trie.child(pi, c);     // may reallocate trie.nodes
+        const Node& p = trie.nodes[pi];
+        Node& q = trie.nodes[qi];
+        float log_p = kNegInf;
+        if (c == p.ch && p.b_prev > kNegInf) log_p = lp + p.b_prev;
+        else if (c != p.ch) log_p = lp + p.score;
+        q.nb_cur = log_sum_exp(q.nb_cur, log_p);
+        if (q.stamp != t) { q.stamp = t; touched.push_back(qi); }
+      }
+    }
+    // PathTrie::iterate_to_vec (path_trie.cpp:113-127) over every existing node = beam + touched
+    prefixes.insert(prefixes.end(), touched.begin(), touched.end());
+    for (int id : prefixes) {
+      Node& n = trie.nodes[id];
+      n.b_prev = n.b_cur;
+      n.nb_prev = n.nb_cur;
+      n.b_cur = n.nb_cur = kNegInf;
+      n.score = log_sum_exp(n.b_prev, n.nb_prev);
+    }
+    if ((int)prefixes.size() >= beam) {
+      if ((int)prefixes.size() > beam)
+        std::nth_element(prefixes.begin(), prefixes.begin() + beam, prefixes.end(),
+                         [&](int x, int y) { return better(x, y); });
+      for (size_t i = beam; i < prefixes.size(); ++i) trie.remove(prefixes[i]);
+      prefixes.resize(beam);
+    }
+  }
+
+  // -> number of hypotheses written
+  int finish(int max_len, int32_t* ids, int32_t* lens, float* scores) {
+    std::sort(prefixes.begin(), prefixes.end(), [&](int x, int y) { return better(x, y); });
+    const int n = std::min((int)prefixes.size(), beam);
+    std::vector<int> path;
+    for (int i = 0; i < n; ++i) {
+      path.clear();
+      for (int id = prefixes[i]; trie.nodes[id].ch != -1; id = trie.nodes[id].parent) path.push_back(trie.nodes[id].ch);
+      std::reverse(path.begin(), path.end());
+      lens[i] = (int32_t)path.size();
+      scores[i] = trie.nodes[prefixes[i]].score;
+      for (int j = 0; j < max_len; ++j) ids[(size_t)i * max_len + j] = j < (int)path.size() ? path[j] : -1;
+    }
+    for (int i = n; i < beam; ++i) {
+      lens[i] = 0;
+      scores[i] = kNegInf;
+      for (int j = 0; j < max_len; ++j) ids[(size_t)i * max_len + j] = -1;
+    }
+    return n;
+  }
+};
+
+template <class RowFn>
+void run_batch(int B, int num_threads, RowFn&& per_utt) {
+  num_threads = std::max(1, std::min(num_threads, B));
+  if (num_threads == 1) {
+    for (int b = 0; b < B; ++b) per_utt(b);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int w = 0; w < num_threads; ++w)
+    pool.emplace_back([&, w]() {
+      for (int b = w; b < B; b += num_threads) per_utt(b);
+    });
+  for (auto& th : pool) th.join();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GPU: per-frame top-n.  One wave per frame, the frame's V values staged in LDS; n rounds of
+// (per-lane scan, wave arg-max with lowest-index tie break, knock-out).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void topn_kernel(const float* __restrict__ x, int V, int N, int is_logits,
+                                                  int32_t* __restrict__ out_idx, float* __restrict__ out_p) {
+  extern __shared__ float sh[];
+  const int lane = threadIdx.x;
+  const size_t frame = blockIdx.x;
+  const float* row = x + frame * V;
+  float mx = -INFINITY;
+  for (int i = lane; i < V; i += 64) {
+    const float v = row[i];
+    sh[i] = v;
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float denom = 1.f;
+  if (is_logits) {
+    float s = 0.f;
+    for (int i = lane; i < V; i += 64) s += __expf(sh[i] - mx);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
+    denom = s;
+  }
+  for (int n = 0; n < N; ++n) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < V; i += 64) {
+      const float v = sh[i];
+      if (v > best) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float ov = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bi, off);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+      out_idx[frame * N + n] = bi;
+      out_p[frame * N + n] = is_logits ? __expf(best - mx) / denom : best;
+    }
+    if (bi != 0x7fffffff && (bi & 63) == lane) sh[bi] = -INFINITY;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355asr_beam_host_impl(const float* probs, const int32_t* in_len, int B, int T, int V, int beam_size,
+                            double cutoff_prob, int cutoff_top_n, int num_threads, int max_len, int32_t* ids,
+                            int32_t* lens, float* scores, int32_t* n_hyp) {
+  run_batch(B, num_threads, [&](int b) {
+    Search s;
+    s.reset(beam_size, V - 1);
+    std::vector<Cand> cands;
+    std::vector<int> order;
+    const int n = in_len ? std::max(0, std::min(in_len[b], T)) : T;
+    for (int t = 0; t < n; ++t) {
+      pruned_from_row(probs + ((size_t)b * T + t) * V, V, cutoff_prob, cutoff_top_n, cands, order);
+      s.step(t, cands);
+    }
+    n_hyp[b] = s.finish(max_len, ids + (size_t)b * beam_size * max_len, lens + (size_t)b * beam_size,
+                        scores + (size_t)b * beam_size);
+  });
+  return 0;
+}
+
+int mi355asr_beam_topn_impl(const int32_t* top_idx, const float* top_p, const int32_t* in_len, int B, int T, int V,
+                            int N, int beam_size, double cutoff_prob, int cutoff_top_n, int num_threads, int max_len,
+                            int32_t* ids, int32_t* lens, float* scores, int32_t* n_hyp) {
+  run_batch(B, num_threads, [&](int b) {
+    Search s;
+    s.reset(beam_size, V - 1);
+    std::vector<Cand> cands;
+    const int n = in_len ? std::max(0, std::min(in_len[b], T)) : T;
+    for (int t = 0; t < n; ++t) {
+      const size_t o = ((size_t)b * T + t) * N;
+      pruned_from_topn(top_idx + o, top_p + o, N, cutoff_prob, cutoff_top_n, cands);
+      s.step(t, cands);
+    }
+    n_hyp[b] = s.finish(max_len, ids + (size_t)b * beam_size * max_len, lens + (size_t)b * beam_size,
+                        scores + (size_t)b * beam_size);
+  });
+  return 0;
+}
+
+int mi355asr_launch_topn(const float* x_dev, int frames, int V, int N, int is_logits, int32_t* idx_dev, float* p_dev,
+                         hipStream_t s) {
+  const size_t lds = (size_t)V * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)topn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return -2;
+  }
+  hipLaunchKernelGGL(topn_kernel, dim3(frames), dim3(64), lds, s, x_dev, V, N, is_logits, idx_dev, p_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"

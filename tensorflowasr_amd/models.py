@@ -522,3 +522,43 @@ class ConformerCTC(_ModelBase):
 
     def conformer_block(self, index, x, stack=0):
         return ConformerEncoder.conformer_block(self, index, x, stack=stack)
+
+
+def ctc_prefix_beam_decode(x, input_length=None, beam_width=10, cutoff_prob=0.99, cutoff_top_n=40, is_logits=False,
+                           num_threads=None, max_len=None):
+    """Scorer-less CTC prefix beam search of externals/ctc_decoders (ctc_beam_search_decoder_batch).
+
+    x: [B, T, V] probabilities (or logits with is_logits=True), blank = class V-1.  A CUDA tensor goes through the
+    GPU top-n selection kernel + host search (`mi355asr_ctc_prefix_beam`, needs cutoff_prob < 1); a NumPy array / CPU
+    tensor of probabilities runs entirely on the host threads (`mi355asr_ctc_prefix_beam_host`).
+    -> (ids int32 [B, beam, max_len] padded -1, lens int32 [B, beam], scores float32 [B, beam], n_hyp int32 [B])."""
+    lib = _lib.lib()
+    on_gpu = torch.is_tensor(x) and x.is_cuda
+    B, T, V = x.shape
+    max_len = int(max_len or T)
+    nthreads = int(num_threads or min(B, os.cpu_count() or 1))
+    ids = np.empty((B, beam_width, max_len), np.int32)
+    lens = np.empty((B, beam_width), np.int32)
+    scores = np.empty((B, beam_width), np.float32)
+    n_hyp = np.empty((B,), np.int32)
+    il = None
+    if input_length is not None:
+        il = np.ascontiguousarray(input_length.cpu().numpy() if torch.is_tensor(input_length) else input_length, np.int32)
+    ilp = il.ctypes.data_as(ctypes.c_void_p) if il is not None else ctypes.c_void_p()
+    outs = [a.ctypes.data_as(ctypes.c_void_p) for a in (ids, lens, scores, n_hyp)]
+    if on_gpu:
+        xd = x.to(torch.float32).contiguous()
+        N = min(cutoff_top_n, V)
+        ws = torch.empty(B * T * N * 8, dtype=torch.uint8, device=xd.device)
+        with torch.cuda.device(xd.device):
+            st = ctypes.c_void_p(torch.cuda.current_stream(xd.device).cuda_stream)
+            _lib.check(lib.mi355asr_ctc_prefix_beam(_p(xd), int(bool(is_logits)), ilp, B, T, V, beam_width,
+                                                   float(cutoff_prob), cutoff_top_n, nthreads, max_len, *outs,
+                                                   _p(ws), ws.numel(), st))
+    else:
+        if is_logits:
+            raise ValueError("host path takes probabilities (the reference's input); pass is_logits only with CUDA tensors")
+        xh = np.ascontiguousarray(x.numpy() if torch.is_tensor(x) else x, np.float32)
+        _lib.check(lib.mi355asr_ctc_prefix_beam_host(xh.ctypes.data_as(ctypes.c_void_p), ilp, B, T, V, beam_width,
+                                                    float(cutoff_prob), cutoff_top_n, nthreads, max_len, *outs))
+    return ids, lens, scores, n_hyp

@@ -11,6 +11,8 @@ Outputs (all under tests/golden/):
                            (executed by oracle/onnx_mini.py), used to pin the oracle
   greedy_kat.json          known-answer tests produced by the reference's C++
                            ctc_greedy_decoder.h (compiled by oracle/Makefile into oracle/_ref)
+  beam_kat.npz             known-answer tests produced by the reference's scorer-less prefix beam search
+                           (externals/ctc_decoders.zip compiled by oracle/Makefile target ref_beam)
 """
 import ctypes
 import json
@@ -144,6 +146,44 @@ def make_greedy_kats():
     print("greedy KATs:", len(kats), "hand KAT ->", kats[-1]["expect"])
 
 
+def make_beam_kats():
+    """Known-answer tests from the reference's own prefix beam search (scorer-less), oracle/_ref/libref_ctc_beam.so."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_beam"])
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_ctc_beam.so"))
+    lib.ref_ctc_beam_search.restype = ctypes.c_int
+    lib.ref_ctc_beam_search.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(11)
+    cases = [(6, 4, 3, 1.0, 40, 1.0), (20, 8, 5, 1.0, 40, 1.0), (30, 12, 10, 0.99, 5, 1.0), (50, 30, 8, 0.9, 10, 3.0),
+             (40, 60, 20, 1.0, 40, 2.0), (100, 200, 10, 0.999, 40, 4.0), (25, 6, 4, 0.5, 3, 1.0), (15, 5, 100, 1.0, 40, 1.0),
+             (1, 7, 4, 1.0, 40, 1.0), (60, 1332, 10, 0.99, 40, 6.0), (250, 1332, 4, 0.999, 40, 8.0)]
+    out = {}
+    meta = []
+    for k, (T, V, beam, cp, tn, temp) in enumerate(cases):
+        z = rng.standard_normal((T, V)) * temp
+        z[:, -1] += 1.0                                   # blank-leaning, like a CTC model
+        p = np.exp(z - z.max(-1, keepdims=True))
+        p = (p / p.sum(-1, keepdims=True)).astype(np.float32)   # float32-representable probabilities
+        pd = np.ascontiguousarray(p, np.float64)
+        sc = (ctypes.c_double * beam)()
+        ids = (ctypes.c_int * (beam * T))()
+        ln = (ctypes.c_int * beam)()
+        n = lib.ref_ctc_beam_search(pd.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), T, V, beam, cp, tn, T, sc, ids, ln)
+        e_ids = np.full((n, T), -1, np.int32)
+        for i in range(n):
+            e_ids[i, :ln[i]] = [ids[i * T + j] for j in range(ln[i])]
+        out["probs_%d" % k] = p
+        out["ids_%d" % k] = e_ids
+        out["lens_%d" % k] = np.array([ln[i] for i in range(n)], np.int32)
+        out["scores_%d" % k] = np.array([sc[i] for i in range(n)], np.float64)
+        meta.append({"T": T, "V": V, "beam": beam, "cutoff_prob": cp, "cutoff_top_n": tn, "n": n})
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "beam_kat.npz"), **out)
+    print("beam KATs:", len(meta), "cases; best of the last:", out["ids_%d" % (len(cases) - 1)][0][:out["lens_%d" % (len(cases) - 1)][0]][:10])
+
+
 if __name__ == "__main__":
     make_onnx_fixtures()
     make_greedy_kats()
+    make_beam_kats()

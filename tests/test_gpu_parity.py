@@ -285,3 +285,42 @@ def test_workspace_too_small_is_reported(enc2, torch_cuda):
     rc = h.lib.mi355asr_encoder_forward(h.ptr, ctypes.c_void_p(x.data_ptr()), 1, 16000, ctypes.c_void_p(out.data_ptr()),
                                         ctypes.c_void_p(ws.data_ptr()), 1024, None)
     assert rc == -4 and b"workspace too small" in h.lib.mi355asr_last_error()
+
+
+def test_prefix_beam_device_path_matches_reference_kats(torch_cuda):
+    """GPU top-n selection kernel + host search vs the KATs of the reference's own decoder (cases with pruning)."""
+    torch = torch_cuda
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    k = np.load(os.path.join(GOLDEN, "beam_kat.npz"))
+    meta = json.loads(str(k["meta"]))
+    done = 0
+    for i, m in enumerate(meta):
+        if not m["cutoff_prob"] < 1.0:
+            continue
+        p = torch.from_numpy(k["probs_%d" % i][None]).cuda()
+        ids, lens, sc, n = ctc_prefix_beam_decode(p, None, m["beam"], m["cutoff_prob"], m["cutoff_top_n"])
+        assert n[0] == m["n"]
+        assert np.array_equal(lens[0, :m["n"]], k["lens_%d" % i])
+        assert np.array_equal(ids[0, :m["n"]], k["ids_%d" % i])
+        assert np.array_equal(sc[0, :m["n"]].astype(np.float64), k["scores_%d" % i])
+        done += 1
+    assert done >= 5
+
+
+def test_prefix_beam_from_logits_batch(torch_cuda):
+    """is_logits path: fused softmax in the selection kernel; compared with the host path on fp32 softmax."""
+    torch = torch_cuda
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    rng = np.random.default_rng(8)
+    B, T, V, beam = 6, 120, 9160, 8
+    z = (rng.standard_normal((B, T, V)) * 4).astype(np.float32)
+    z[..., -1] += 3
+    in_len = np.array([120, 77, 1, 120, 5, 64], np.int32)
+    zt = torch.from_numpy(z).cuda()
+    a = ctc_prefix_beam_decode(zt, in_len, beam, 0.999, 40, is_logits=True)
+    p = torch.softmax(zt, -1).cpu().numpy()
+    b = ctc_prefix_beam_decode(p, in_len, beam, 0.999, 40)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    assert np.abs(a[2] - b[2]).max() < 1e-3          # v_exp_f32 softmax vs torch softmax
+    with pytest.raises(Exception):
+        ctc_prefix_beam_decode(zt, in_len, beam, 1.0, 40, is_logits=True)     # un-pruned mode is host-only

@@ -221,3 +221,56 @@ def test_shard_range_is_a_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- prefix beam search host path (mi355asr_ctc_prefix_beam_host) vs the reference decoder's KATs -------------------
+def test_prefix_beam_host_matches_reference_kats_bit_exact():
+    import json
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    k = np.load(os.path.join(ROOT, "tests", "golden", "beam_kat.npz"))
+    meta = json.loads(str(k["meta"]))
+    for i, m in enumerate(meta):
+        ids, lens, sc, n = ctc_prefix_beam_decode(k["probs_%d" % i][None], None, m["beam"], m["cutoff_prob"],
+                                                  m["cutoff_top_n"], num_threads=1)
+        assert n[0] == m["n"]
+        assert np.array_equal(lens[0, :m["n"]], k["lens_%d" % i])
+        assert np.array_equal(ids[0, :m["n"]], k["ids_%d" % i])
+        assert np.array_equal(sc[0, :m["n"]].astype(np.float64), k["scores_%d" % i])   # float32 trie scores, same libm
+
+
+def test_prefix_beam_batch_threads_ragged_lengths():
+    import json
+    from oracle import ctc_beam_oracle as bo
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    rng = np.random.default_rng(5)
+    B, T, V, beam = 5, 24, 9, 6
+    z = rng.standard_normal((B, T, V)) * 2
+    p = np.exp(z - z.max(-1, keepdims=True))
+    p = (p / p.sum(-1, keepdims=True)).astype(np.float32)
+    in_len = np.array([24, 1, 0, 13, 24], np.int32)
+    a = ctc_prefix_beam_decode(p, in_len, beam, 0.95, 5, num_threads=3)
+    b = ctc_prefix_beam_decode(p, in_len, beam, 0.95, 5, num_threads=1)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))                      # threading does not change results
+    ids, lens, sc, n = a
+    for u in range(B):
+        ref = bo.ctc_beam_search(p[u, :in_len[u]], beam, 0.95, 5) if in_len[u] else [(np.float32(0.0), [])]
+        assert n[u] == len(ref)
+        for j, (s, path) in enumerate(ref):
+            assert ids[u, j, :lens[u, j]].tolist() == path and abs(float(s) - sc[u, j]) < 1e-4
+    assert n[2] == 1 and lens[2, 0] == 0 and sc[2, 0] == 0.0                    # empty input: the root prefix only
+    # beam 1 with a peaked distribution reproduces greedy decoding
+    fa = p.argmax(-1)
+    onehot = np.full((B, T, V), 1e-6, np.float32)
+    np.put_along_axis(onehot, fa[..., None], 1.0, axis=-1)
+    ids1, lens1, _, _ = ctc_prefix_beam_decode(onehot, None, 1, 1.0, 40, num_threads=2)
+    gid, glen = co.ctc_collapse(fa.astype(np.int32), [T] * B, V - 1)
+    for u in range(B):
+        assert ids1[u, 0, :lens1[u, 0]].tolist() == gid[u, :glen[u]].tolist()
+
+
+def test_prefix_beam_argument_errors():
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    with pytest.raises(_lib.Mi355AsrError):
+        ctc_prefix_beam_decode(np.zeros((1, 3, 1), np.float32), None, 4)        # V < 2
+    with pytest.raises(ValueError):
+        ctc_prefix_beam_decode(np.zeros((1, 3, 4), np.float32), None, 4, is_logits=True)

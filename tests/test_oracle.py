@@ -176,3 +176,33 @@ def test_fp32_and_fp64_oracle_agree_end_to_end():
     y32 = co.conformer_encoder(x, w, cfg, np.float32)
     assert y64.shape == (2, 25, 144)
     assert np.abs(y64 - y32).max() < 1e-3
+
+
+# ---- prefix beam search (row a14): pinned against the reference's own decoder ----------------------------------
+def _beam_kats():
+    k = np.load(os.path.join(GOLDEN, "beam_kat.npz"))
+    meta = json.loads(str(k["meta"]))
+    return k, meta
+
+
+def test_beam_oracle_matches_reference_decoder_kats():
+    from oracle import ctc_beam_oracle as bo
+    k, meta = _beam_kats()
+    assert len(meta) >= 10
+    for i, m in enumerate(meta):
+        if m["T"] * m["V"] > 30000:
+            continue                                  # pure-Python restatement: small cases only
+        res = bo.ctc_beam_search(k["probs_%d" % i], m["beam"], m["cutoff_prob"], m["cutoff_top_n"])
+        assert len(res) == m["n"]
+        for j, (score, ids) in enumerate(res):
+            L = int(k["lens_%d" % i][j])
+            assert ids == k["ids_%d" % i][j, :L].tolist()
+            assert abs(float(score) - k["scores_%d" % i][j]) < 1e-4
+
+
+def test_beam_pruning_quirk_cutoff_prob_one_disables_top_n():
+    from oracle import ctc_beam_oracle as bo
+    p = np.array([0.5, 0.2, 0.15, 0.1, 0.05])
+    assert len(bo.pruned_log_probs(p, 1.0, 2)) == 5           # decoder_utils.cpp:18-31: top-n ignored at cutoff 1.0
+    assert [c for c, _ in bo.pruned_log_probs(p, 0.99, 2)] == [0, 1]
+    assert [c for c, _ in bo.pruned_log_probs(p, 0.6, 40)] == [0, 1]
