@@ -147,6 +147,48 @@ int mi355asr_conv_subsampling(mi355asr_model* m, const float* mel_dev, int32_t B
 int mi355asr_conformer_block(mi355asr_model* m, int32_t stack, int32_t index, const float* x_dev, int32_t B,
                              int32_t T, float* y_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ---- ChunkConformer (asr/models/chunk_conformer_blocks.py:775-822, offline `predict`) ---------------------------
+ * front (valid-padded Melspectrogram + left-padded VALID ConvSubsampling, :400-445, :23-70) -> ChunkConformerEncoder
+ * (band attention [i-win_front, i+win_back], causal depthwise conv, :142-398, :462-560) -> phone_picker
+ * (ChunkCTCDecoder :571-637) -> feature_pick (keep frames whose phone argmax is not the blank, :913-999) ->
+ * ContextHelper (:679-770) -> text ChunkCTCDecoder -> logits [B, T_pick, num_classes].
+ * Values from asr/configs/chunk_conformerS.yml.  All sub-models share dmodel / heads / kernel size here. */
+typedef struct {
+  int32_t dmodel, head_size, num_heads, kernel_size;      /* 144, 36, 4, 32                                 */
+  float   fc_factor;                                      /* 0.5                                            */
+  int32_t n_mels, sample_rate, stride_ms, n_dft;          /* 80, 16000, 10, 1024                            */
+  int32_t reduction_factor;                               /* 4                                              */
+  int32_t enc_num_blocks, enc_win_front, enc_win_back;    /* 15, 36, 0                                      */
+  int32_t picker_num_classes, picker_num_blocks, picker_win_front, picker_win_back;   /* phone+1, 1, 36, 0 */
+  int32_t helper_num_blocks, helper_win_front, helper_win_back;                       /* 2, 36, 0          */
+  int32_t decoder_num_classes, decoder_num_blocks, decoder_win_front, decoder_win_back; /* txt+1, 1, 36, 8 */
+} mi355asr_chunk_config;
+
+/* optional DEVICE outputs of mi355asr_chunk_predict (NULL = not wanted).  Frame-major fp32 unless noted;
+ * T = encoder frames of the utterances, Tp = max over the batch of picked frames (returned on the host). */
+typedef struct {
+  float*   front_out;       /* [B, T, d]                    ChunkConformerFront.call                      */
+  float*   enc_out;         /* [B, T, d]                    ChunkConformerEncoder.call                    */
+  float*   picker_logits;   /* [B, T, picker_num_classes]   phone_picker(...)[0]                          */
+  float*   picker_hidden;   /* [B, T, d]                    phone_picker(...)[1]                          */
+  float*   picked;          /* [B, >=Tp, d] (capacity B*T*d) feature_pick(...)[0], zero padded            */
+  float*   helper_out;      /* [B, >=Tp, d] (capacity B*T*d) helper(picked)                               */
+  float*   text_logits;     /* [B, Tp, decoder_num_classes] (capacity B*T*V) ChunkConformer.predict       */
+  int32_t* text_argmax;     /* i32 [B, Tp] (capacity B*T)   per-frame argmax of text_logits               */
+} mi355asr_chunk_outputs;
+
+/* replaces: ChunkConformer(config, phone, txt) construction (test_chunk_asr.py:40-55).  The handle takes
+ * weights through mi355asr_load_weight / mi355asr_finalize_weights like the other models (names: DESIGN.md). */
+int mi355asr_chunk_create(const mi355asr_chunk_config* cfg, mi355asr_model** out);
+int mi355asr_chunk_out_frames(const mi355asr_model* m, int32_t L, int32_t* mel_frames, int32_t* enc_frames);
+int mi355asr_chunk_workspace_bytes(const mi355asr_model* m, int32_t B, int32_t L, size_t* bytes);
+/* replaces: ChunkConformer.predict(x) (chunk_conformer_blocks.py:815-822).  wav_dev f32 [B, L].
+ * n_picked_host i32 [B] and t_pick_host i32 [1] are HOST outputs (the picked-frame counts size the second half of
+ * the network, so the call synchronises `stream` once in the middle, as the reference's dynamic shapes do). */
+int mi355asr_chunk_predict(mi355asr_model* m, const float* wav_dev, int32_t B, int32_t L,
+                           const mi355asr_chunk_outputs* outs, int32_t* n_picked_host, int32_t* t_pick_host,
+                           void* ws_dev, size_t ws_bytes, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around each kernel (off by default).
  * profile_read waits for the recorded events, then returns accumulated milliseconds and launch counts per
  * kernel category below (arrays of at least MI355ASR_NUM_KERNELS); reset != 0 clears the accumulators.

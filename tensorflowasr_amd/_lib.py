@@ -19,6 +19,24 @@ class Config(ctypes.Structure):
     ]
 
 
+class ChunkConfig(ctypes.Structure):
+    """mirror of `mi355asr_chunk_config` (include/mi355asr.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("dmodel", "head_size", "num_heads", "kernel_size")] + \
+        [("fc_factor", ctypes.c_float)] + \
+        [(n, ctypes.c_int32) for n in (
+            "n_mels", "sample_rate", "stride_ms", "n_dft", "reduction_factor",
+            "enc_num_blocks", "enc_win_front", "enc_win_back",
+            "picker_num_classes", "picker_num_blocks", "picker_win_front", "picker_win_back",
+            "helper_num_blocks", "helper_win_front", "helper_win_back",
+            "decoder_num_classes", "decoder_num_blocks", "decoder_win_front", "decoder_win_back")]
+
+
+class ChunkOutputs(ctypes.Structure):
+    """mirror of `mi355asr_chunk_outputs`."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("front_out", "enc_out", "picker_logits", "picker_hidden", "picked",
+                                               "helper_out", "text_logits", "text_argmax")]
+
+
 class Mi355AsrError(RuntimeError):
     pass
 
@@ -50,6 +68,10 @@ SIGNATURES = {
     "mi355asr_melspectrogram": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "mi355asr_conv_subsampling": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "mi355asr_conformer_block": (ctypes.c_int, [_P, _I, _I, _P, _I, _I, _P, _P, _SZ, _P]),
+    "mi355asr_chunk_create": (ctypes.c_int, [ctypes.POINTER(ChunkConfig), ctypes.POINTER(_P)]),
+    "mi355asr_chunk_out_frames": (ctypes.c_int, [_P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "mi355asr_chunk_workspace_bytes": (ctypes.c_int, [_P, _I, _I, ctypes.POINTER(_SZ)]),
+    "mi355asr_chunk_predict": (ctypes.c_int, [_P, _P, _I, _I, ctypes.POINTER(ChunkOutputs), _P, _P, _P, _SZ, _P]),
     "mi355asr_profile_enable": (ctypes.c_int, [_P, _I]),
     "mi355asr_profile_read": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), _I, _I]),
 }

@@ -73,6 +73,23 @@ struct Dims {
   int hop, nbins, NT_dft, NCH_dft, LP, KBm, NTm, F1, F2, st1, pf1, pf2;
 };
 
+// per-stack block options: ConformerBlock (full attention, 'same' depthwise padding) or ChunkConformerBlock
+// (band attention [win_front, win_back], 'causal' depthwise padding; chunk_conformer_blocks.py:327-398)
+struct BlockOpts {
+  int ksz = 32;
+  float fc = 0.5f;
+  int win_front = -1;   // < 0: full attention
+  int win_back = 0;
+  bool causal = false;
+};
+
+struct StackDev {
+  std::vector<BlockDev> blocks;
+  const float *proj_wp = nullptr, *proj_b = nullptr, *fc_wp = nullptr, *fc_b = nullptr;
+  int NT_fc = 0, num_classes = 0;
+  BlockOpts opts;
+};
+
 }  // namespace
 
 struct mi355asr_model {
@@ -88,6 +105,10 @@ struct mi355asr_model {
               *fc_wp = nullptr, *fc_b = nullptr;
   int NT_fc = 0;
   std::vector<BlockDev> enc_blocks, ctc_blocks;
+  // ChunkConformer (mi355asr_chunk_create): front + encoder / phone picker / context helper / text decoder stacks
+  bool is_chunk = false;
+  mi355asr_chunk_config ccfg;
+  StackDev c_enc, c_picker, c_helper, c_decoder;
   // optional per-kernel timing with HIP events on the launch stream (mi355asr_profile_*)
   mutable bool prof = false;
   mutable std::vector<hipEvent_t> ev_free;
@@ -133,7 +154,8 @@ void same_pad(int n, int k, int s, int* out, int* before) {
   *before = tot / 2;
 }
 
-void add_block_expected(std::vector<Expected>& ex, const std::string& p, int d, int H, int hs, int k) {
+void add_block_expected(std::vector<Expected>& ex, const std::string& p, int d, int H, int hs, int k,
+                        bool keras_mha = false) {
   auto ln = [&](const std::string& q) {
     ex.push_back({q + "/gamma", {d}});
     ex.push_back({q + "/beta", {d}});
@@ -148,11 +170,20 @@ void add_block_expected(std::vector<Expected>& ex, const std::string& p, int d, 
   }
   const std::string m = p + "/mhsa_module";
   ln(m + "/ln");
-  ex.push_back({m + "/mha/query_kernel", {H, d, hs}});
-  ex.push_back({m + "/mha/key_kernel", {H, d, hs}});
-  ex.push_back({m + "/mha/value_kernel", {H, d, hs}});
-  ex.push_back({m + "/mha/projection_kernel", {H, hs, d}});
-  ex.push_back({m + "/mha/projection_bias", {d}});
+  if (keras_mha) {   // tf.keras.layers.MultiHeadAttention (chunk_conformer_blocks.py:147): biased q/k/v/out
+    for (const char* w : {"query", "key", "value"}) {
+      ex.push_back({m + "/mha/" + w + "/kernel", {d, H, hs}});
+      ex.push_back({m + "/mha/" + w + "/bias", {H, hs}});
+    }
+    ex.push_back({m + "/mha/attention_output/kernel", {H, hs, d}});
+    ex.push_back({m + "/mha/attention_output/bias", {d}});
+  } else {
+    ex.push_back({m + "/mha/query_kernel", {H, d, hs}});
+    ex.push_back({m + "/mha/key_kernel", {H, d, hs}});
+    ex.push_back({m + "/mha/value_kernel", {H, d, hs}});
+    ex.push_back({m + "/mha/projection_kernel", {H, hs, d}});
+    ex.push_back({m + "/mha/projection_bias", {d}});
+  }
   const std::string c = p + "/conv_module";
   ln(c + "/ln");
   ex.push_back({c + "/pw_conv_1/kernel", {1, d, 2 * d}});
@@ -207,7 +238,8 @@ struct BlockOff {
   size_t ln_g, ln_b;
 };
 
-BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k) {
+BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k,
+                    bool keras_mha = false) {
   auto T = [&](const std::string& n) -> const std::vector<float>& { return m->host[n].data; };
   BlockOff o;
   const char* ffn[2] = {"ff_module_1", "ff_module_2"};
@@ -225,6 +257,24 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   const std::string a = p + "/mhsa_module";
   o.att_ln_g = ab.put(T(a + "/ln/gamma"));
   o.att_ln_b = ab.put(T(a + "/ln/beta"));
+  if (keras_mha) {
+    // Keras MHA kernels are [d, H, hs] = [d, d] row-major: column n = which*d + h*hs + o
+    const auto &qk = T(a + "/mha/query/kernel"), &kk_ = T(a + "/mha/key/kernel"), &vk = T(a + "/mha/value/kernel");
+    o.qkv_wp = ab.put(pack_p16(
+        [&](int i, int n) {
+          const int which = n / d, r = n % d;
+          const std::vector<float>& w = which == 0 ? qk : (which == 1 ? kk_ : vk);
+          return w[(size_t)i * d + r];
+        },
+        d, 3 * d, 3 * d / 16));
+    std::vector<float> qb(3 * d);
+    const auto &bq = T(a + "/mha/query/bias"), &bk = T(a + "/mha/key/bias"), &bv = T(a + "/mha/value/bias");
+    for (int i = 0; i < d; ++i) { qb[i] = bq[i]; qb[d + i] = bk[i]; qb[2 * d + i] = bv[i]; }
+    o.qkv_b = ab.put(qb);
+    const auto& pk = T(a + "/mha/attention_output/kernel");  // [H, hs, d]: row k = h*hs + i
+    o.out_wp = ab.put(pack_p16([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d, d / 16));
+    o.out_b = ab.put(T(a + "/mha/attention_output/bias"));
+  } else {
   const auto& qk = T(a + "/mha/query_kernel");
   const auto& kk_ = T(a + "/mha/key_kernel");
   const auto& vk = T(a + "/mha/value_kernel");
@@ -240,6 +290,7 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   const auto& pk = T(a + "/mha/projection_kernel");  // [H, hs, d]: row k = h*hs + i
   o.out_wp = ab.put(pack_p16([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d, d / 16));
   o.out_b = ab.put(T(a + "/mha/projection_bias"));
+  }
   const std::string c = p + "/conv_module";
   o.cv_ln_g = ab.put(T(c + "/ln/gamma"));
   o.cv_ln_b = ab.put(T(c + "/ln/beta"));
@@ -360,9 +411,11 @@ struct Scratch {
 };
 
 // One ConformerBlock (conformer_blocks.py:259-265).  Input in sc.xa, output to `out` (or sc.xa if null).
-int run_block(const mi355asr_model* m, const BlockDev& w, int ksz, float fc, const Scratch& sc, int B, int T,
+int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, const Scratch& sc, int B, int T,
               float* out, hipStream_t s) {
   const int d = m->cfg.dmodel, H = m->cfg.num_heads, hs = m->cfg.head_size;
+  const int ksz = bo.ksz;
+  const float fc = bo.fc;
   const int M = B * T;
   // ff_module_1: xb = xa + fc * FFN(LN(xa))
   Chain2Args f1{};
@@ -379,6 +432,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, int ksz, float fc, con
   { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm_rows(d, EPI_QKV, true, q, s), "qkv projection"); }
   AttnArgs at{};
   at.qkv = sc.qkv; at.ctx = sc.ctx; at.B = B; at.T = T; at.H = H; at.D = d; at.ld = 3 * d;
+  at.win_front = bo.win_front; at.win_back = bo.win_back;
   { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
   // xa = xb + ctx Wo + bo
   GemmArgs op{};
@@ -392,7 +446,8 @@ int run_block(const mi355asr_model* m, const BlockDev& w, int ksz, float fc, con
   { PROF(MI355ASR_K_PW1_GLU); LAUNCH_TRY(launch_gemm_rows(d, EPI_GLU, true, g, s), "pw_conv_1 + GLU"); }
   DwArgs dwa{};
   dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
-  dwa.pad_left = (ksz - 1) / 2;  // Keras 'same', stride 1: total k-1, before = (k-1)//2
+  // Keras 'same', stride 1: total k-1, before = (k-1)//2 ; 'causal': all k-1 on the left
+  dwa.pad_left = bo.causal ? ksz - 1 : (ksz - 1) / 2;
   { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
   // xb = xa + pw2( swish( BN( dw Wpc + bpc ) ) ) + b2
   Chain2Args cv{};
@@ -452,9 +507,12 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   return 0;
 }
 
+int finalize_chunk(mi355asr_model* m, hipStream_t s);
+
 int check_ready(const mi355asr_model* m, bool need_encoder = false) {
   if (!m) return fail(MI355ASR_EINVAL, "null model handle");
   if (!m->finalized) return fail(MI355ASR_ESTATE, "weights not finalised: call mi355asr_finalize_weights first");
+  if (m->is_chunk) return fail(MI355ASR_ESTATE, "ChunkConformer handle: use mi355asr_chunk_predict");
   if (need_encoder && !m->cfg.has_encoder) return fail(MI355ASR_ESTATE, "model was created without an encoder (has_encoder=0)");
   return 0;
 }
@@ -471,8 +529,10 @@ int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const P
   if (rc) return rc;
   const int nb = m->cfg.num_blocks;
   for (int i = 0; i < nb; ++i) {
-    rc = run_block(m, m->enc_blocks[i], m->cfg.kernel_size, m->cfg.fc_factor, sc, g.Bp, g.T,
-                   i == nb - 1 ? enc_out : nullptr, s);
+    BlockOpts bo;
+    bo.ksz = m->cfg.kernel_size;
+    bo.fc = m->cfg.fc_factor;
+    rc = run_block(m, m->enc_blocks[i], bo, sc, g.Bp, g.T, i == nb - 1 ? enc_out : nullptr, s);
     if (rc) return rc;
   }
   if (nb == 0) HIP_TRY(hipMemcpyAsync(enc_out, sc.xa, (size_t)g.Bp * g.T * m->cfg.dmodel * 4, hipMemcpyDeviceToDevice, s));
@@ -490,7 +550,10 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   pr.M = M; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
   { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "ctc project"); }
   for (int i = 0; i < m->cfg.ctc_num_blocks; ++i) {
-    int rc = run_block(m, m->ctc_blocks[i], m->cfg.ctc_kernel_size, m->cfg.ctc_fc_factor, sc, B, T, nullptr, s);
+    BlockOpts bo;
+    bo.ksz = m->cfg.ctc_kernel_size;
+    bo.fc = m->cfg.ctc_fc_factor;
+    int rc = run_block(m, m->ctc_blocks[i], bo, sc, B, T, nullptr, s);
     if (rc) return rc;
   }
   GemmArgs hd{};
@@ -642,6 +705,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   if (!m) return fail(MI355ASR_EINVAL, "null model handle");
   for (const auto& e : m->expected)
     if (!m->host.count(e.name) || !m->host[e.name].set) return fail(MI355ASR_EWEIGHT, "missing weight '%s'", e.name.c_str());
+  if (m->is_chunk) return finalize_chunk(m, (hipStream_t)stream);
   const auto& c = m->cfg;
   const Dims& dm = m->dm;
   const int d = c.dmodel;
@@ -872,8 +936,332 @@ int mi355asr_conformer_block(mi355asr_model* m, int32_t stack, int32_t index, co
   Scratch sc{(float*)(w + p.xa), (float*)(w + p.xb), (float*)(w + p.qkv),
              (float*)(w + p.ctx), (float*)(w + p.u), (float*)(w + p.dw)};
   HIP_TRY(hipMemcpyAsync(sc.xa, x, (size_t)B * T * m->cfg.dmodel * 4, hipMemcpyDeviceToDevice, s));
-  return run_block(m, blocks[index], stack == 0 ? m->cfg.kernel_size : m->cfg.ctc_kernel_size,
-                   stack == 0 ? m->cfg.fc_factor : m->cfg.ctc_fc_factor, sc, B, T, y, s);
+  BlockOpts bo;
+  bo.ksz = stack == 0 ? m->cfg.kernel_size : m->cfg.ctc_kernel_size;
+  bo.fc = stack == 0 ? m->cfg.fc_factor : m->cfg.ctc_fc_factor;
+  return run_block(m, blocks[index], bo, sc, B, T, y, s);
+}
+
+}  // extern "C"
+
+// =======================================================================================================
+// ChunkConformer (offline predict)
+// =======================================================================================================
+namespace {
+
+struct ChunkGeom { int F, T1, T; };
+
+int chunk_geometry(const mi355asr_model* m, int B, int L, ChunkGeom* g) {
+  if (B <= 0 || L <= 0) return fail(MI355ASR_EINVAL, "B and L must be positive (B=%d, L=%d)", B, L);
+  // 'valid' Spectrogram: the reference left-pads n_dft-1 zeros, then a VALID strided conv (time_frequency.py:106-107)
+  g->F = (L - 1) / m->dm.hop + 1;
+  // ConvSubsampling(padding='valid'): pad 4 frames in front, VALID 3x3 stride 2, twice (chunk_conformer_blocks.py:60-66)
+  g->T1 = (g->F + 4 - 3) / 2 + 1;
+  g->T = (g->T1 - 3) / 2 + 1;
+  if (g->T < 1) return fail(MI355ASR_EINVAL, "L=%d is too short for the chunk front end", L);
+  return 0;
+}
+
+struct ChunkPlan {
+  size_t xa, xb, qkv, ctx, u, dw, hid, amax, idx, cnt, logp, pmax, mel, sub, total;
+};
+
+ChunkPlan make_chunk_plan(const mi355asr_model* m, int B, int F, int T) {
+  const int d = m->cfg.dmodel;
+  const size_t M = (size_t)B * T;
+  ChunkPlan p;
+  size_t o = 0;
+  auto take = [&](size_t floats) { size_t at = o; o = align256(o + floats * 4); return at; };
+  p.xa = take(M * d); p.xb = take(M * d); p.qkv = take(M * 3 * d); p.ctx = take(M * d);
+  p.u = take(M * d); p.dw = take(M * d); p.hid = take(M * d);
+  p.amax = take(M); p.idx = take(M); p.cnt = take(B);
+  const int FT = ceil_div(F, 16);
+  p.logp = take((size_t)B * F * m->dm.LP);
+  p.pmax = take((size_t)B * FT * m->dm.NCH_dft);
+  p.mel = take((size_t)B * F * m->cfg.n_mels);
+  p.sub = take(M * m->dm.F2 * d);
+  p.total = o;
+  return p;
+}
+
+void add_stack_expected(std::vector<Expected>& ex, const std::string& prefix, const std::string& blk, int nblocks,
+                        int d, int H, int hs, int k, bool project, int num_classes) {
+  if (project) {
+    ex.push_back({prefix + "/project/kernel", {d, d}});
+    ex.push_back({prefix + "/project/bias", {d}});
+  }
+  for (int i = 0; i < nblocks; ++i) add_block_expected(ex, prefix + "/" + blk + std::to_string(i), d, H, hs, k, true);
+  if (num_classes > 0) {
+    ex.push_back({prefix + "/fully_connected/kernel", {d, num_classes}});
+    ex.push_back({prefix + "/fully_connected/bias", {num_classes}});
+  }
+}
+
+struct StackOff {
+  std::vector<BlockOff> blocks;
+  size_t proj_w = 0, proj_b = 0, fc_w = 0, fc_b = 0;
+  int NT_fc = 0;
+};
+
+StackOff pack_stack(mi355asr_model* m, ArenaBuilder& ab, const std::string& prefix, const std::string& blk, int nblocks,
+                    bool project, int V) {
+  const auto& c = m->cfg;
+  const int d = c.dmodel;
+  StackOff so;
+  if (project) {
+    const auto& pj = m->host[prefix + "/project/kernel"].data;
+    so.proj_w = ab.put(pack_p16([&](int k, int n) { return pj[(size_t)k * d + n]; }, d, d, d / 16));
+    so.proj_b = ab.put(m->host[prefix + "/project/bias"].data);
+  }
+  for (int i = 0; i < nblocks; ++i)
+    so.blocks.push_back(pack_block(m, ab, prefix + "/" + blk + std::to_string(i), d, c.num_heads, c.head_size,
+                                   c.kernel_size, true));
+  if (V > 0) {
+    const auto& fc = m->host[prefix + "/fully_connected/kernel"].data;
+    const int ct = gemm_ct(d, EPI_HEAD);
+    so.NT_fc = ceil_div(ceil_div(V, 16), ct) * ct;
+    so.fc_w = ab.put(pack_p16([&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, so.NT_fc));
+    so.fc_b = ab.put_padded(m->host[prefix + "/fully_connected/bias"].data.data(), V, (size_t)so.NT_fc * 16);
+  }
+  return so;
+}
+
+void resolve_stack(StackDev& sd, const StackOff& so, const float* base, bool project, int V) {
+  sd.blocks.clear();
+  for (const auto& o : so.blocks) sd.blocks.push_back(resolve(o, base));
+  if (project) { sd.proj_wp = base + so.proj_w; sd.proj_b = base + so.proj_b; }
+  if (V > 0) { sd.fc_wp = base + so.fc_w; sd.fc_b = base + so.fc_b; sd.NT_fc = so.NT_fc; sd.num_classes = V; }
+}
+
+int finalize_chunk(mi355asr_model* m, hipStream_t s) {
+  const auto& c = m->cfg;
+  const auto& cc = m->ccfg;
+  const Dims& dm = m->dm;
+  const int d = c.dmodel, nb = dm.nbins;
+  ArenaBuilder ab;
+  const auto& re = m->host["front/mel_layer/real_kernels"].data;
+  const auto& im = m->host["front/mel_layer/imag_kernels"].data;
+  const size_t o_dft = ab.put(pack_p16(
+      [&](int k, int n) { const int bin = n >> 1; return (n & 1) ? im[(size_t)k * nb + bin] : re[(size_t)k * nb + bin]; },
+      c.n_dft, 2 * nb, dm.NT_dft));
+  const auto& f2m = m->host["front/mel_layer/freq2mel"].data;
+  const size_t o_mel = ab.put(pack_p16([&](int k, int n) { return k < nb ? f2m[(size_t)k * c.n_mels + n] : 0.f; },
+                                       dm.KBm * 16, c.n_mels, dm.NTm));
+  const size_t o_c1w = ab.put(m->host["front/conv_subsampling/conv1/kernel"].data);
+  const size_t o_c1b = ab.put(m->host["front/conv_subsampling/conv1/bias"].data);
+  const auto& c2 = m->host["front/conv_subsampling/conv2/kernel"].data;
+  const size_t o_c2w = ab.put(pack_p16(
+      [&](int kp, int n) {
+        const int kb = kp / 16, r = kp % 16, cb = kb / 9, q = kb % 9;
+        return c2[((size_t)q * d + (16 * cb + r)) * d + n];
+      },
+      9 * d, d, d / 16));
+  const size_t o_c2b = ab.put(m->host["front/conv_subsampling/conv2/bias"].data);
+  const auto& lin = m->host["front/conv_subsampling/linear/kernel"].data;
+  const size_t o_lw = ab.put(pack_p16([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d, d / 16));
+  const size_t o_lb = ab.put(m->host["front/conv_subsampling/linear/bias"].data);
+  StackOff e = pack_stack(m, ab, "encoder", "chunk_conformer_block_", cc.enc_num_blocks, false, 0);
+  StackOff pk = pack_stack(m, ab, "picker", "block_", cc.picker_num_blocks, true, cc.picker_num_classes);
+  StackOff hp = pack_stack(m, ab, "helper", "block_", cc.helper_num_blocks, false, 0);
+  StackOff dc = pack_stack(m, ab, "decoder", "block_", cc.decoder_num_blocks, true, cc.decoder_num_classes);
+  if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }
+  HIP_TRY(hipMalloc((void**)&m->arena, ab.buf.size() * sizeof(float)));
+  m->arena_floats = ab.buf.size();
+  HIP_TRY(hipMemcpyAsync(m->arena, ab.buf.data(), ab.buf.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const float* base = m->arena;
+  m->dft_wp = base + o_dft; m->mel_wp = base + o_mel;
+  m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
+  m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
+  resolve_stack(m->c_enc, e, base, false, 0);
+  resolve_stack(m->c_picker, pk, base, true, cc.picker_num_classes);
+  resolve_stack(m->c_helper, hp, base, false, 0);
+  resolve_stack(m->c_decoder, dc, base, true, cc.decoder_num_classes);
+  m->finalized = true;
+  return 0;
+}
+
+// Dense(d->d) [+ blocks] [+ Dense(d->V) with argmax]; input rows at `in`, blocks run in sc.xa
+int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int B, int T, const Scratch& sc,
+              float* logits, int32_t* amax, hipStream_t s) {
+  const int d = m->cfg.dmodel;
+  const int M = B * T;
+  if (st.proj_wp) {
+    GemmArgs pr{};
+    pr.x = in; pr.y = sc.xa; pr.wp = st.proj_wp; pr.bias = st.proj_b;
+    pr.M = M; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
+    { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "project"); }
+  } else if (in != sc.xa) {
+    HIP_TRY(hipMemcpyAsync(sc.xa, in, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
+  }
+  for (const auto& blk : st.blocks) {
+    int rc = run_block(m, blk, st.opts, sc, B, T, nullptr, s);
+    if (rc) return rc;
+  }
+  if (st.fc_wp && (logits || amax)) {
+    GemmArgs hd{};
+    hd.x = sc.xa; hd.y = logits; hd.wp = st.fc_wp; hd.bias = st.fc_b;
+    hd.M = M; hd.NT = st.NT_fc; hd.ldy = st.num_classes; hd.n_valid = st.num_classes; hd.eps = kLnEps;
+    hd.argmax_out = amax;
+    { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "fully_connected"); }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355asr_chunk_create(const mi355asr_chunk_config* cfg, mi355asr_model** out) {
+  if (!cfg || !out) return fail(MI355ASR_EINVAL, "null argument");
+  const auto& c = *cfg;
+  if (c.dmodel != 144) return fail(MI355ASR_EINVAL, "ChunkConformer: dmodel=%d, kernels instantiated for 144", c.dmodel);
+  if (c.num_heads * c.head_size != c.dmodel || c.head_size != 36)
+    return fail(MI355ASR_EINVAL, "ChunkConformer: need num_heads*head_size == dmodel and head_size 36");
+  if (c.kernel_size != 32 && c.kernel_size != 5) return fail(MI355ASR_EINVAL, "kernel_size=%d unsupported", c.kernel_size);
+  if (c.reduction_factor != 4 || c.n_dft != 1024 || (c.n_mels != 80 && c.n_mels != 128))
+    return fail(MI355ASR_EINVAL, "ChunkConformer front: reduction_factor 4, n_dft 1024, n_mels 80|128 only");
+  if (c.picker_num_classes < 2 || c.decoder_num_classes < 2) return fail(MI355ASR_EINVAL, "num_classes must be >= 2");
+  if (c.enc_win_front < 0 || c.picker_win_front < 0 || c.helper_win_front < 0 || c.decoder_win_front < 0 ||
+      c.enc_win_back < 0 || c.picker_win_back < 0 || c.helper_win_back < 0 || c.decoder_win_back < 0)
+    return fail(MI355ASR_EINVAL, "window sizes must be non-negative");
+  auto* m = new mi355asr_model();
+  m->is_chunk = true;
+  m->ccfg = c;
+  std::memset(&m->cfg, 0, sizeof(m->cfg));
+  m->cfg.dmodel = c.dmodel; m->cfg.head_size = c.head_size; m->cfg.num_heads = c.num_heads;
+  m->cfg.kernel_size = c.kernel_size; m->cfg.fc_factor = c.fc_factor; m->cfg.reduction_factor = 4;
+  m->cfg.n_mels = c.n_mels; m->cfg.sample_rate = c.sample_rate; m->cfg.stride_ms = c.stride_ms; m->cfg.n_dft = c.n_dft;
+  Dims& dm = m->dm;
+  dm.hop = c.stride_ms * c.sample_rate / 1000;
+  if (dm.hop <= 0) { delete m; return fail(MI355ASR_EINVAL, "stride_ms*sample_rate/1000 must be positive"); }
+  dm.nbins = c.n_dft / 2 + 1;
+  dm.NT_dft = ceil_div(ceil_div(2 * dm.nbins, 16), 13) * 13;
+  dm.NCH_dft = dm.NT_dft / 13;
+  dm.LP = ceil_div(8 * dm.NT_dft, 16) * 16;
+  dm.KBm = ceil_div(ceil_div(dm.nbins, 16), 2) * 2;
+  dm.NTm = c.n_mels / 16;
+  dm.st1 = 2;
+  dm.pf1 = 2; dm.pf2 = 0;                          // tf.pad(..., [2,2]) on the mel axis, then VALID convs
+  dm.F1 = (c.n_mels + 4 - 3) / 2 + 1;
+  dm.F2 = (dm.F1 - 3) / 2 + 1;
+  const int d = c.dmodel;
+  auto& ex = m->expected;
+  ex.push_back({"front/mel_layer/real_kernels", {c.n_dft, 1, 1, dm.nbins}});
+  ex.push_back({"front/mel_layer/imag_kernels", {c.n_dft, 1, 1, dm.nbins}});
+  ex.push_back({"front/mel_layer/freq2mel", {dm.nbins, c.n_mels}});
+  ex.push_back({"front/conv_subsampling/conv1/kernel", {3, 3, 1, d}});
+  ex.push_back({"front/conv_subsampling/conv1/bias", {d}});
+  ex.push_back({"front/conv_subsampling/conv2/kernel", {3, 3, d, d}});
+  ex.push_back({"front/conv_subsampling/conv2/bias", {d}});
+  ex.push_back({"front/conv_subsampling/linear/kernel", {dm.F2 * d, d}});
+  ex.push_back({"front/conv_subsampling/linear/bias", {d}});
+  add_stack_expected(ex, "encoder", "chunk_conformer_block_", c.enc_num_blocks, d, c.num_heads, c.head_size, c.kernel_size, false, 0);
+  add_stack_expected(ex, "picker", "block_", c.picker_num_blocks, d, c.num_heads, c.head_size, c.kernel_size, true, c.picker_num_classes);
+  add_stack_expected(ex, "helper", "block_", c.helper_num_blocks, d, c.num_heads, c.head_size, c.kernel_size, false, 0);
+  add_stack_expected(ex, "decoder", "block_", c.decoder_num_blocks, d, c.num_heads, c.head_size, c.kernel_size, true, c.decoder_num_classes);
+  auto opts = [&](int wf, int wb) { BlockOpts o; o.ksz = c.kernel_size; o.fc = c.fc_factor; o.win_front = wf; o.win_back = wb; o.causal = true; return o; };
+  m->c_enc.opts = opts(c.enc_win_front, c.enc_win_back);
+  m->c_picker.opts = opts(c.picker_win_front, c.picker_win_back);
+  m->c_helper.opts = opts(c.helper_win_front, c.helper_win_back);
+  m->c_decoder.opts = opts(c.decoder_win_front, c.decoder_win_back);
+  *out = m;
+  return 0;
+}
+
+int mi355asr_chunk_out_frames(const mi355asr_model* m, int32_t L, int32_t* mel_frames, int32_t* enc_frames) {
+  if (!m || !m->is_chunk) return fail(MI355ASR_EINVAL, "not a ChunkConformer handle");
+  ChunkGeom g;
+  int rc = chunk_geometry(m, 1, L, &g);
+  if (rc) return rc;
+  if (mel_frames) *mel_frames = g.F;
+  if (enc_frames) *enc_frames = g.T;
+  return 0;
+}
+
+int mi355asr_chunk_workspace_bytes(const mi355asr_model* m, int32_t B, int32_t L, size_t* bytes) {
+  if (!m || !m->is_chunk || !bytes) return fail(MI355ASR_EINVAL, "not a ChunkConformer handle / null argument");
+  ChunkGeom g;
+  int rc = chunk_geometry(m, B, L, &g);
+  if (rc) return rc;
+  *bytes = make_chunk_plan(m, B, g.F, g.T).total;
+  return 0;
+}
+
+int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32_t L, const mi355asr_chunk_outputs* outs,
+                           int32_t* n_picked, int32_t* t_pick, void* ws_, size_t ws_bytes, void* stream) {
+  if (!m || !m->is_chunk) return fail(MI355ASR_EINVAL, "not a ChunkConformer handle");
+  if (!m->finalized) return fail(MI355ASR_ESTATE, "weights not finalised: call mi355asr_finalize_weights first");
+  if (!wav || !outs || !n_picked || !t_pick || !ws_) return fail(MI355ASR_EINVAL, "null argument");
+  ChunkGeom g;
+  int rc = chunk_geometry(m, B, L, &g);
+  if (rc) return rc;
+  const ChunkPlan p = make_chunk_plan(m, B, g.F, g.T);
+  if (ws_bytes < p.total) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total);
+  char* ws = (char*)ws_;
+  hipStream_t s = (hipStream_t)stream;
+  const auto& c = m->cfg;
+  const int d = c.dmodel, T = g.T;
+  const size_t act = (size_t)B * T * d * 4;
+  Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
+             (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
+  // ---- front: valid Melspectrogram (log10, no max-normalisation) + left-padded VALID ConvSubsampling
+  {
+    const int FT = ceil_div(g.F, 16);
+    StftArgs st{};
+    st.wav = wav; st.logp = (float*)(ws + p.logp); st.pmax = (float*)(ws + p.pmax); st.wp = m->dft_wp;
+    st.B = B; st.L = L; st.F = g.F; st.hop = m->dm.hop; st.pad_left = c.n_dft - 1; st.n_dft = c.n_dft;
+    st.NT = m->dm.NT_dft; st.LP = m->dm.LP; st.nbins = m->dm.nbins; st.FT = FT; st.NCH = m->dm.NCH_dft;
+    st.db10 = 0;                                    // chunk_amplitude_to_decibel: log10 only (backend_keras.py:25-37)
+    { PROF(MI355ASR_K_STFT); LAUNCH_TRY(launch_stft(st, s), "stft (valid)"); }
+    MelArgs me{};
+    me.logp = st.logp; me.umax = nullptr; me.mel = (float*)(ws + p.mel); me.wp = m->mel_wp;
+    me.B = B; me.F = g.F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
+    me.NM = c.n_mels; me.FT = FT; me.floor_db = 0.f;
+    { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel(me, s), "mel (valid)"); }
+    SubConvArgs sa{};
+    sa.mel = me.mel; sa.out = (float*)(ws + p.sub); sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
+    sa.B = B; sa.F = g.F; sa.NM = c.n_mels; sa.T1 = g.T1; sa.F1 = m->dm.F1; sa.T2 = T; sa.F2 = m->dm.F2;
+    sa.st1 = 2; sa.pt1 = 4; sa.pf1 = 2; sa.pt2 = 0; sa.pf2 = 0;
+    { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling (valid)"); }
+    StreamGemmArgs lg{};
+    lg.x = sa.out; lg.y = sc.xa; lg.wp = m->lin_wp; lg.bias = m->lin_b;
+    lg.M = B * T; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.ldy = d; lg.n_valid = d;
+    { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear"); }
+  }
+  if (outs->front_out) HIP_TRY(hipMemcpyAsync(outs->front_out, sc.xa, act, hipMemcpyDeviceToDevice, s));
+  // ---- encoder
+  rc = run_stack(m, m->c_enc, sc.xa, B, T, sc, nullptr, nullptr, s);
+  if (rc) return rc;
+  if (outs->enc_out) HIP_TRY(hipMemcpyAsync(outs->enc_out, sc.xa, act, hipMemcpyDeviceToDevice, s));
+  // ---- phone picker: logits (optional) + per-frame argmax, hidden = block output
+  int32_t* amax = (int32_t*)(ws + p.amax);
+  rc = run_stack(m, m->c_picker, sc.xa, B, T, sc, outs->picker_logits, amax, s);
+  if (rc) return rc;
+  float* hid = (float*)(ws + p.hid);
+  HIP_TRY(hipMemcpyAsync(hid, sc.xa, act, hipMemcpyDeviceToDevice, s));
+  if (outs->picker_hidden) HIP_TRY(hipMemcpyAsync(outs->picker_hidden, sc.xa, act, hipMemcpyDeviceToDevice, s));
+  // ---- feature_pick
+  int32_t* idx = (int32_t*)(ws + p.idx);
+  int32_t* cnt = (int32_t*)(ws + p.cnt);
+  PickArgs pa{amax, idx, cnt, B, T, m->ccfg.picker_num_classes - 1};
+  LAUNCH_TRY(launch_pick(pa, s), "feature_pick compaction");
+  HIP_TRY(hipMemcpyAsync(n_picked, cnt, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));    // the batch maximum sizes everything downstream (dynamic shape in the reference)
+  int Tp = 0;
+  for (int b = 0; b < B; ++b) Tp = std::max(Tp, n_picked[b]);
+  *t_pick = Tp;
+  if (Tp == 0) return 0;               // nothing picked: the reference would build [B, 0, V] logits
+  GatherArgs ga{hid, idx, cnt, sc.xa, B, T, Tp, d};
+  LAUNCH_TRY(launch_gather(ga, s), "feature_pick gather");
+  const size_t actp = (size_t)B * Tp * d * 4;
+  if (outs->picked) HIP_TRY(hipMemcpyAsync(outs->picked, sc.xa, actp, hipMemcpyDeviceToDevice, s));
+  // ---- context helper, text decoder
+  rc = run_stack(m, m->c_helper, sc.xa, B, Tp, sc, nullptr, nullptr, s);
+  if (rc) return rc;
+  if (outs->helper_out) HIP_TRY(hipMemcpyAsync(outs->helper_out, sc.xa, actp, hipMemcpyDeviceToDevice, s));
+  rc = run_stack(m, m->c_decoder, sc.xa, B, Tp, sc, outs->text_logits, outs->text_argmax ? outs->text_argmax : amax, s);
+  return rc;
 }
 
 }  // extern "C"

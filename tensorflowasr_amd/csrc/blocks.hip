@@ -482,9 +482,23 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a)
   for (int i = 0; i < OT; ++i) o[i] = splat4(0.f);
   float m_run = -INFINITY, l_run = 0.f;
 
-  load_k(0, 0, 0);
+  // visible key range of this lane's query, and the key blocks the query tile has to sweep
+  const bool band = a.win_front >= 0;
+  int klo = 0, khi = T - 1, kbeg = 0, kend = T;
+  if (band) {
+    const int iq = min(tq, T - 1);
+    klo = min(max(iq - a.win_front, 0), T - a.win_back);
+    khi = max(min(iq + a.win_back, T), a.win_back);
+    const int i0 = qt * 16, i1 = min(qt * 16 + 15, T - 1);
+    const int lo0 = min(max(i0 - a.win_front, 0), T - a.win_back);        // lo() and hi() are non-decreasing in i
+    const int hi1 = min(max(min(i1 + a.win_back, T), a.win_back), T - 1);
+    kbeg = (max(lo0, 0) / 16) * 16;
+    kend = hi1 + 1;
+  }
+
+  load_k(kbeg, 0, 0);
 #pragma unroll 1
-  for (int k0 = 0; k0 < T; k0 += 16 * KT) {
+  for (int k0 = kbeg; k0 < kend; k0 += 16 * KT) {
     f32x4 sc[KT];
     // ---- S^T = K Q^T, KG key tiles per step
 #pragma unroll
@@ -517,14 +531,18 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a)
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       const int kb = k0 + 16 * kt + g4;
-      sc[kt].x = (kb + 0 < T) ? sc[kt].x : -INFINITY;
-      sc[kt].y = (kb + 1 < T) ? sc[kt].y : -INFINITY;
-      sc[kt].z = (kb + 2 < T) ? sc[kt].z : -INFINITY;
-      sc[kt].w = (kb + 3 < T) ? sc[kt].w : -INFINITY;
+      // keys outside [klo, khi] (band mask; Keras adds -1e9 there, i.e. exp() == 0 in fp32) or beyond T
+      sc[kt].x = (kb + 0 < T && kb + 0 >= klo && kb + 0 <= khi) ? sc[kt].x : -INFINITY;
+      sc[kt].y = (kb + 1 < T && kb + 1 >= klo && kb + 1 <= khi) ? sc[kt].y : -INFINITY;
+      sc[kt].z = (kb + 2 < T && kb + 2 >= klo && kb + 2 <= khi) ? sc[kt].z : -INFINITY;
+      sc[kt].w = (kb + 3 < T && kb + 3 >= klo && kb + 3 <= khi) ? sc[kt].w : -INFINITY;
       mx = fmaxf(mx, fmaxf(fmaxf(sc[kt].x, sc[kt].y), fmaxf(sc[kt].z, sc[kt].w)));
     }
     mx = group_max(mx);
-    const float m_new = fmaxf(m_run, mx);          // finite: every key block has >= 1 valid key
+    // a key block can be entirely outside one query's band: keep the running max finite-or-zero so that
+    // exp(-inf - m) is 0 instead of exp(-inf + inf) = NaN
+    const float m_cand = fmaxf(m_run, mx);
+    const float m_new = (m_cand == -INFINITY) ? 0.f : m_cand;
     const float alpha = __expf(m_run - m_new);      // first block: exp(-inf) = 0
     float psum = 0.f;
 #pragma unroll
@@ -536,11 +554,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a)
       psum += (sc[kt].x + sc[kt].y) + (sc[kt].z + sc[kt].w);
     }
     l_run = l_run * alpha + psum;   // per-lane partial; the 4 groups are summed once at the end
-    m_run = m_new;
+    m_run = m_cand;
 #pragma unroll
     for (int i = 0; i < OT; ++i) o[i] *= splat4(alpha);
     // ---- O^T[i][query] += V^T[i][key] * P^T[key][query], VG key tiles per step
-    const int k0n = (k0 + 16 * KT < T) ? k0 + 16 * KT : k0;
+    const int k0n = (k0 + 16 * KT < kend) ? k0 + 16 * KT : k0;
 #pragma unroll
     for (int s = 0; s < NVB; ++s) {
       if (s + 1 < NVB) load_v(k0, s + 1, (s + 1) & 1);
@@ -575,9 +593,11 @@ template <int HS>
 static void launch_attention_t(const AttnArgs& a, hipStream_t s) {
   const int qtiles = (a.T + 15) / 16;
   dim3 grid((qtiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.H, a.B);
-  // keys are swept in blocks of 16*KT; short sequences (streaming blocks: T = 13) use small blocks
-  if (a.T <= 16) hipLaunchKernelGGL((attention_kernel<HS, 1>), grid, dim3(BLOCK_THREADS), 0, s, a);
-  else if (a.T <= 64) hipLaunchKernelGGL((attention_kernel<HS, 4>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  // keys are swept in blocks of 16*KT; short sequences (streaming blocks: T = 13) and band attention
+  // (win_front + win_back + 16 keys per query tile) use small blocks
+  const int span = a.win_front >= 0 ? min(a.T, a.win_front + a.win_back + 31) : a.T;
+  if (span <= 16) hipLaunchKernelGGL((attention_kernel<HS, 1>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  else if (span <= 96) hipLaunchKernelGGL((attention_kernel<HS, 4>), grid, dim3(BLOCK_THREADS), 0, s, a);
   else hipLaunchKernelGGL((attention_kernel<HS, 16>), grid, dim3(BLOCK_THREADS), 0, s, a);
 }
 

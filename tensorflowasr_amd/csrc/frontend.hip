@@ -8,6 +8,8 @@
 //   stream_gemm      Dense(F2*d -> d) of ConvSubsampling                   (conformer_blocks.py:87,95)
 //   collapse_kernel  CTC greedy merge-repeated / drop-blank / pad -1       (test_asr.py:196-200,
 //                    Inference/CppInference/onnx/src/core/ctc_greedy_decoder.h:22-43)
+#include <algorithm>
+
 #include "common.h"
 #include "launch.h"
 
@@ -364,5 +366,50 @@ __global__ __launch_bounds__(64) void collapse_kernel(CollapseArgs a) {
 
 int launch_collapse(const CollapseArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(collapse_kernel, dim3(a.B), dim3(64), 0, s, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// feature_pick (chunk_conformer_blocks.py:913-999): keep the frames whose phone argmax is not the blank,
+// compacted per utterance and zero-padded to the batch maximum.  pick_kernel = stream compaction of the
+// frame indices (one wave per utterance, ballot + popcount); gather_kernel = row gather.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pick_kernel(PickArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int32_t* __restrict__ src = a.frame_ids + (size_t)b * a.T;
+  int32_t* dst = a.idx + (size_t)b * a.T;
+  int count = 0;
+  for (int t0 = 0; t0 < a.T; t0 += 64) {
+    const int t = t0 + lane;
+    const bool keep = t < a.T && src[t] != a.blank;
+    const unsigned long long mask = __ballot(keep);
+    if (keep) dst[count + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+    count += __popcll(mask);
+  }
+  if (lane == 0) a.cnt[b] = count;
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
+  const int d4n = a.D / 4;
+  const size_t total = (size_t)a.B * a.Tp * d4n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % d4n) * 4;
+    const int j = (int)((i / d4n) % a.Tp);
+    const int b = (int)(i / ((size_t)d4n * a.Tp));
+    f32x4 v = splat4(0.f);
+    if (j < a.cnt[b]) v = ldg4(a.src + ((size_t)b * a.T + a.idx[(size_t)b * a.T + j]) * a.D + c4);
+    stg4(a.dst + ((size_t)b * a.Tp + j) * a.D + c4, v);
+  }
+}
+
+int launch_pick(const PickArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(pick_kernel, dim3(a.B), dim3(64), 0, s, a);
+  return 0;
+}
+int launch_gather(const GatherArgs& a, hipStream_t s) {
+  const size_t total = (size_t)a.B * a.Tp * (a.D / 4);
+  if (total == 0) return 0;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, a);
   return 0;
 }

@@ -51,6 +51,9 @@ struct AttnArgs {
   const float* qkv;  // [B*T, ld] : q | k | v, each D = H*HS wide, head-major
   float* ctx;        // [B*T, D]
   int B, T, H, D, ld;
+  // band attention of the ChunkConformer (chunk_conformer_blocks.py:158-176): query i sees keys
+  // [min(max(i-win_front,0), T-win_back), max(min(i+win_back,T), win_back)]; win_front < 0 = full attention
+  int win_front, win_back;
 };
 
 struct DwArgs {
@@ -104,6 +107,21 @@ struct CollapseArgs {
   int B, T, blank;
 };
 
+struct PickArgs {
+  const int32_t* frame_ids;  // [B, T] phone argmax
+  int32_t* idx;              // [B, T] indices of kept frames (first cnt[b] entries valid)
+  int32_t* cnt;              // [B]
+  int B, T, blank;
+};
+struct GatherArgs {
+  const float* src;          // [B, T, D]
+  const int32_t* idx;        // [B, T]
+  const int32_t* cnt;        // [B]
+  float* dst;                // [B, Tp, D] zero padded
+  int B, T, Tp, D;
+};
+int launch_pick(const PickArgs& a, hipStream_t s);
+int launch_gather(const GatherArgs& a, hipStream_t s);
 int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s);
 int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s);
 int launch_attention(int HS, const AttnArgs& a, hipStream_t s);

@@ -35,9 +35,13 @@ def default_weights(names_and_shapes, rng, sample_rate=16000, n_dft=1024, n_mels
             w[name] = frontend_consts.stft_kernels(n_dft)[1]
         elif name == "mel_layer/freq2mel":
             w[name] = frontend_consts.freq2mel(sample_rate, n_dft, n_mels)
+        elif name.startswith("front/mel_layer/"):
+            w[name] = {"real_kernels": frontend_consts.stft_kernels(n_dft)[0],
+                       "imag_kernels": frontend_consts.stft_kernels(n_dft)[1],
+                       "freq2mel": frontend_consts.freq2mel(sample_rate, n_dft, n_mels)}[leaf]
         elif leaf in ("gamma", "moving_variance"):
             w[name] = np.ones(shape, np.float32)
-        elif leaf in ("beta", "moving_mean", "bias", "projection_bias"):
+        elif leaf in ("beta", "moving_mean", "bias", "projection_bias"):  # includes the Keras-MHA [H, hs] biases
             w[name] = np.zeros(shape, np.float32)
         elif leaf in ("query_kernel", "key_kernel", "value_kernel", "projection_kernel"):
             # Keras glorot on a 3-D shape: receptive field = prod(shape[:-2])
@@ -52,12 +56,13 @@ def default_weights(names_and_shapes, rng, sample_rate=16000, n_dft=1024, n_mels
 class _Handle:
     """Owns one `mi355asr_model*` plus its device workspace."""
 
-    def __init__(self, cfg: _lib.Config, device):
+    def __init__(self, cfg, device):
         self.lib = _lib.lib()
         self.cfg = cfg
         self.device = torch.device(device)
         self.ptr = ctypes.c_void_p()
-        _lib.check(self.lib.mi355asr_create(ctypes.byref(cfg), ctypes.byref(self.ptr)))
+        create = self.lib.mi355asr_chunk_create if isinstance(cfg, _lib.ChunkConfig) else self.lib.mi355asr_create
+        _lib.check(create(ctypes.byref(cfg), ctypes.byref(self.ptr)))
         self._ws = None
         self.built = False
 
@@ -562,3 +567,115 @@ def ctc_prefix_beam_decode(x, input_length=None, beam_width=10, cutoff_prob=0.99
         _lib.check(lib.mi355asr_ctc_prefix_beam_host(xh.ctypes.data_as(ctypes.c_void_p), ilp, B, T, V, beam_width,
                                                     float(cutoff_prob), cutoff_top_n, nthreads, max_len, *outs))
     return ids, lens, scores, n_hyp
+
+
+def _chunk_block_shapes(p, d, H, hs, k):
+    s = _block_shapes(p, d, H, hs, k)
+    m = p + "/mhsa_module/mha"
+    for nm in ("query_kernel", "key_kernel", "value_kernel", "projection_kernel", "projection_bias"):
+        del s[m + "/" + nm]
+    for nm in ("query", "key", "value"):
+        s[m + "/" + nm + "/kernel"] = (d, H, hs)
+        s[m + "/" + nm + "/bias"] = (H, hs)
+    s[m + "/attention_output/kernel"] = (H, hs, d)
+    s[m + "/attention_output/bias"] = (d,)
+    return s
+
+
+class ChunkConformer(_ModelBase):
+    """asr/models/chunk_conformer_blocks.py:775-822, offline `predict`: front -> ChunkConformerEncoder -> phone
+    picker -> feature_pick -> ContextHelper -> text decoder.  `config` is the reference's model YAML as a dict
+    (asr/configs/chunk_conformerS.yml); `phone` / `txt` are the two vocabularies' num_classes."""
+
+    def __init__(self, config, phone, txt, device="cuda:0", name="chunk_conformer"):
+        mc = config["model_config"]
+        fr, en = mc["ChunkConformerFront"], mc["ChunkConformerEncoder"]
+        pk, dc, hp = mc["ChunkCTCPicker"], mc["ChunkCTCDecoder"], mc["ContextHelper"]
+        for sub in (pk, dc, hp):
+            for key in ("dmodel", "head_size", "num_heads", "kernel_size"):
+                if sub[key] != en[key]:
+                    raise NotImplementedError("sub-models with different %s are not supported" % key)
+        if en.get("padding", "causal") != "causal":
+            raise NotImplementedError("ChunkConformerEncoder padding=%r: only 'causal'" % en.get("padding"))
+        self.name = name
+        self.dmodel, self.num_heads, self.head_size, self.kernel_size = en["dmodel"], en["num_heads"], en["head_size"], en["kernel_size"]
+        self.sample_rate, self.n_mels = fr["sample_rate"], fr["n_mels"]
+        self.phone_num_classes, self.txt_num_classes = phone, txt
+        self.blocks = {"encoder": en["num_blocks"], "picker": pk["num_blocks"], "helper": hp["num_blocks"], "decoder": dc["num_blocks"]}
+        self._weights = None
+        cfg = _lib.ChunkConfig(
+            dmodel=en["dmodel"], head_size=en["head_size"], num_heads=en["num_heads"], kernel_size=en["kernel_size"],
+            fc_factor=en["fc_factor"], n_mels=fr["n_mels"], sample_rate=fr["sample_rate"], stride_ms=fr["stride_ms"],
+            n_dft=1024, reduction_factor=fr["reduction_factor"],
+            enc_num_blocks=en["num_blocks"], enc_win_front=en["win_front"], enc_win_back=en["win_back"],
+            picker_num_classes=phone, picker_num_blocks=pk["num_blocks"], picker_win_front=pk["win_front"], picker_win_back=pk["win_back"],
+            helper_num_blocks=hp["num_blocks"], helper_win_front=hp["win_front"], helper_win_back=hp["win_back"],
+            decoder_num_classes=txt, decoder_num_blocks=dc["num_blocks"], decoder_win_front=dc["win_front"], decoder_win_back=dc["win_back"])
+        self._h = _Handle(cfg, device)
+
+    def _expected_shapes(self):
+        d, H, hs, k = self.dmodel, self.num_heads, self.head_size, self.kernel_size
+        f2 = ((self.n_mels + 4 - 3) // 2 + 1 - 3) // 2 + 1
+        s = {"front/mel_layer/real_kernels": (1024, 1, 1, 513), "front/mel_layer/imag_kernels": (1024, 1, 1, 513),
+             "front/mel_layer/freq2mel": (513, self.n_mels),
+             "front/conv_subsampling/conv1/kernel": (3, 3, 1, d), "front/conv_subsampling/conv1/bias": (d,),
+             "front/conv_subsampling/conv2/kernel": (3, 3, d, d), "front/conv_subsampling/conv2/bias": (d,),
+             "front/conv_subsampling/linear/kernel": (f2 * d, d), "front/conv_subsampling/linear/bias": (d,)}
+        for i in range(self.blocks["encoder"]):
+            s.update(_chunk_block_shapes("encoder/chunk_conformer_block_%d" % i, d, H, hs, k))
+        for prefix, V in (("picker", self.phone_num_classes), ("helper", 0), ("decoder", self.txt_num_classes)):
+            if prefix != "helper":
+                s[prefix + "/project/kernel"] = (d, d)
+                s[prefix + "/project/bias"] = (d,)
+            for i in range(self.blocks[prefix]):
+                s.update(_chunk_block_shapes("%s/block_%d" % (prefix, i), d, H, hs, k))
+            if V:
+                s[prefix + "/fully_connected/kernel"] = (d, V)
+                s[prefix + "/fully_connected/bias"] = (V,)
+        return s
+
+    def out_frames(self, L):
+        f, t = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self._h.lib.mi355asr_chunk_out_frames(self._h.ptr, L, ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
+
+    def predict(self, x, stages=False):
+        """x [B, L(,1)] -> text logits torch [B, T_pick, txt_num_classes] (+ counts).  With stages=True returns a dict
+        with every intermediate the reference's predict() produces."""
+        h = self._h
+        if not h.built:
+            self._build()
+        xd = _wave2d(h, x)
+        B, L = xd.shape
+        _, T = self.out_frames(L)
+        d, V = self.dmodel, self.txt_num_classes
+        n = ctypes.c_size_t()
+        _lib.check(h.lib.mi355asr_chunk_workspace_bytes(h.ptr, B, L, ctypes.byref(n)))
+        ws = h.workspace(n.value)
+        dev = h.device
+        bufs = {"text_logits": torch.empty((B, T, V), dtype=torch.float32, device=dev),
+                "text_argmax": torch.empty((B, T), dtype=torch.int32, device=dev)}
+        if stages:
+            for k in ("front_out", "enc_out", "picker_hidden", "picked", "helper_out"):
+                bufs[k] = torch.empty((B, T, d), dtype=torch.float32, device=dev)
+            bufs["picker_logits"] = torch.empty((B, T, self.phone_num_classes), dtype=torch.float32, device=dev)
+        outs = _lib.ChunkOutputs(**{k: v.data_ptr() for k, v in bufs.items()})
+        counts = np.zeros(B, np.int32)
+        tp = ctypes.c_int32()
+        with torch.cuda.device(dev):
+            _lib.check(h.lib.mi355asr_chunk_predict(h.ptr, _p(xd), B, L, ctypes.byref(outs),
+                                                   counts.ctypes.data_as(ctypes.c_void_p), ctypes.byref(tp),
+                                                   _p(ws), n.value, h._stream()))
+        Tp = tp.value
+        logits = bufs["text_logits"].view(-1)[:B * Tp * V].view(B, Tp, V)
+        if not stages:
+            return logits, counts
+        r = {"text_logits": logits, "counts": counts,
+             "text_argmax": bufs["text_argmax"].view(-1)[:B * Tp].view(B, Tp),
+             "front": bufs["front_out"], "enc": bufs["enc_out"], "picker_logits": bufs["picker_logits"],
+             "picker_hidden": bufs["picker_hidden"],
+             "picked": bufs["picked"].view(-1)[:B * Tp * d].view(B, Tp, d),
+             "helper": bufs["helper_out"].view(-1)[:B * Tp * d].view(B, Tp, d)}
+        return r
+
+    __call__ = predict

@@ -53,3 +53,21 @@ def argmax_mismatch_report(gpu_logits, ref_logits):
         row = np.sort(ref_logits[tuple(idx)])[::-1]
         out.append((tuple(int(i) for i in idx), float(row[0] - row[1])))
     return out
+
+
+def chunk_config_dict(cfg):
+    """oracle-style flat chunk config -> the reference's nested model YAML (asr/configs/chunk_conformerS.yml)."""
+    common = dict(dmodel=cfg["dmodel"], head_size=cfg["head_size"], num_heads=cfg["num_heads"],
+                  kernel_size=cfg["kernel_size"], fc_factor=cfg["fc_factor"], dropout=0.0)
+    return {"model_config": {
+        "name": "ChunkConformer",
+        "ChunkConformerFront": dict(dmodel=cfg["dmodel"], reduction_factor=4, dropout=0.0, sample_rate=cfg["sample_rate"],
+                                    n_mels=cfg["n_mels"], mel_layer_trainable=False, stride_ms=cfg["stride_ms"], chunk_num=16),
+        "ChunkConformerEncoder": dict(common, num_blocks=cfg["enc_num_blocks"], win_front=cfg["enc_win_front"],
+                                      win_back=cfg["enc_win_back"], padding="causal", name="chunk_conformer_encoder"),
+        "ChunkCTCPicker": dict(common, num_classes=cfg["picker_num_classes"], num_blocks=cfg["picker_num_blocks"],
+                               win_front=cfg["picker_win_front"], win_back=cfg["picker_win_back"]),
+        "ChunkCTCDecoder": dict(common, num_classes=cfg["decoder_num_classes"], num_blocks=cfg["decoder_num_blocks"],
+                                win_front=cfg["decoder_win_front"], win_back=cfg["decoder_win_back"]),
+        "ContextHelper": dict(common, num_classes=cfg["picker_num_classes"], num_blocks=cfg["helper_num_blocks"],
+                              win_front=cfg["helper_win_front"], win_back=cfg["helper_win_back"])}}

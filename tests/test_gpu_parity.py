@@ -10,8 +10,8 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (GOLDEN, argmax_mismatch_report, co, encoder_kwargs, golden_ctc_io, golden_ctc_weights, maxdiff,
-                     small_cfg, waves)
+from helpers import (GOLDEN, argmax_mismatch_report, chunk_config_dict, co, encoder_kwargs, golden_ctc_io,
+                     golden_ctc_weights, maxdiff, small_cfg, waves)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -324,3 +324,78 @@ def test_prefix_beam_from_logits_batch(torch_cuda):
     assert np.abs(a[2] - b[2]).max() < 1e-3          # v_exp_f32 softmax vs torch softmax
     with pytest.raises(Exception):
         ctc_prefix_beam_decode(zt, in_len, beam, 1.0, 40, is_logits=True)     # un-pruned mode is host-only
+
+
+# ---- row a15: ChunkConformer offline predict (parity unpinned in the reference; oracle = restatement) ----------------
+def _chunk_model(cfg, w):
+    from tensorflowasr_amd.models import ChunkConformer
+    m = ChunkConformer(chunk_config_dict(cfg), cfg["picker_num_classes"], cfg["decoder_num_classes"])
+    m.load_weights(w, by_name=False)
+    return m
+
+
+def _pick_bias_for_ragged_counts(cfg, w, x):
+    """choose the picker's blank bias so that roughly half of the frames are kept (ragged counts)."""
+    r = co.chunk_predict(x.astype(np.float64), w, cfg)
+    z = r["picker_logits"]
+    gap = np.sort(z[..., :-1].max(-1) - z[..., -1], axis=None)
+    return float(gap[gap.size // 2])
+
+
+@pytest.mark.parametrize("L", [24000, 50000])
+def test_chunk_conformer_predict_stage_parity(torch_cuda, L):
+    cfg = dict(co.CHUNK_S, enc_num_blocks=2, decoder_num_classes=300)
+    w = co.chunk_weights(cfg, seed=3)
+    x = waves(3, L, 40)
+    w["picker/fully_connected/bias"][-1] = _pick_bias_for_ragged_counts(cfg, w, x)
+    ref = co.chunk_predict(x.astype(np.float64), w, cfg)
+    m = _chunk_model(cfg, w)
+    got = m.predict(x, stages=True)
+    for k in ("front", "enc", "picker_logits", "picker_hidden"):
+        assert maxdiff(got[k].cpu().numpy(), ref[k]) < TOL, k
+    bad = argmax_mismatch_report(got["picker_logits"].cpu().numpy(), ref["picker_logits"])
+    assert not bad, bad                                   # feature_pick is driven by this argmax
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert 0 < ref["counts"].min() < ref["counts"].max() < ref["front"].shape[1]      # ragged, non-trivial
+    for k in ("picked", "helper", "text_logits"):
+        assert got[k].shape == ref[k].shape, k
+        assert maxdiff(got[k].cpu().numpy(), ref[k]) < TOL, k
+    assert np.array_equal(got["text_argmax"].cpu().numpy(), got["text_logits"].cpu().numpy().argmax(-1))
+    logits, counts = m.predict(x)
+    assert np.array_equal(logits.cpu().numpy(), got["text_logits"].cpu().numpy())      # deterministic
+
+
+def test_chunk_band_attention_matches_keras_mask_semantics(torch_cuda):
+    """win_back > 0 (text decoder, 36/8) at a length that is not a multiple of 16 and shorter than the window."""
+    cfg = dict(co.CHUNK_S, enc_num_blocks=1, decoder_num_classes=64, enc_win_front=5, enc_win_back=3,
+               picker_win_front=2, picker_win_back=0, helper_win_front=36, helper_win_back=0)
+    w = co.chunk_weights(cfg, seed=9, picker_blank_bias=-50.0)      # keep every frame
+    x = waves(2, 8000, 3)
+    ref = co.chunk_predict(x.astype(np.float64), w, cfg)
+    got = _chunk_model(cfg, w).predict(x, stages=True)
+    assert ref["front"].shape[1] == 12
+    for k in ("front", "enc", "picker_logits", "picked", "helper", "text_logits"):
+        assert maxdiff(got[k].cpu().numpy(), ref[k]) < TOL, k
+
+
+def test_chunk_conformer_full_S_config_10s(torch_cuda):
+    """chunk_conformerS.yml dimensions (15 + 1 + 2 + 1 blocks, 277 / 9171 classes) on one 10 s utterance, and the
+    prefix beam search on the text logits (BASELINE config 5 path end to end)."""
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    cfg = dict(co.CHUNK_S)
+    w = co.chunk_weights(cfg, seed=5)
+    x = waves(1, 160000, 77)
+    w["picker/fully_connected/bias"][-1] = _pick_bias_for_ragged_counts(cfg, w, x)
+    ref = co.chunk_predict(x.astype(np.float64), w, cfg)
+    m = _chunk_model(cfg, w)
+    got = m.predict(x, stages=True)
+    assert ref["front"].shape[1] == 250
+    assert maxdiff(got["enc"].cpu().numpy(), ref["enc"]) < TOL
+    assert np.array_equal(got["counts"], ref["counts"])
+    err = maxdiff(got["text_logits"].cpu().numpy(), ref["text_logits"])
+    assert err < TOL
+    # beam search from the GPU logits (fused softmax + top-n) vs the host path on an fp32 softmax of the same logits
+    import torch
+    a = ctc_prefix_beam_decode(got["text_logits"], got["counts"], 8, 0.999, 40, is_logits=True)
+    b = ctc_prefix_beam_decode(torch.softmax(got["text_logits"], -1).cpu().numpy(), got["counts"], 8, 0.999, 40)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
