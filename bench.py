@@ -61,6 +61,10 @@ def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES):
         "ctc_project": 2.0 * M * d * d,
         "ctc_head": 2.0 * M * d * V,
         "collapse": 0.0,
+        # block-level fused kernels (dmodel 144): sums of the layers they contain
+        "ff1_qkv": 2.0 * 2 * M * d * 4 * d + 3 * 2.0 * M * d * d,
+        "out_glu": 2.0 * M * d * d + 2.0 * M * d * 2 * d,
+        "tail_ff2": 2.0 * M * d * 2 * d + 2.0 * M * 2 * d * d + 2.0 * 2 * M * d * 4 * d,
     }
 
 

@@ -208,7 +208,10 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav_dev, int32_t B, i
 #define MI355ASR_K_CTC_PROJECT 12 /* gemm_rows EPI_BIAS   CTCDecoder.project                            */
 #define MI355ASR_K_CTC_HEAD 13    /* gemm_rows EPI_HEAD   fully_connected + per-frame argmax            */
 #define MI355ASR_K_COLLAPSE 14    /* collapse_kernel      greedy merge/blank-drop                       */
-#define MI355ASR_NUM_KERNELS 15
+#define MI355ASR_K_FF1_QKV 15     /* ff1_qkv_kernel       FFModule 1 + LN + q/k/v projections (fused, dmodel 144)     */
+#define MI355ASR_K_OUT_GLU 16     /* out_glu_kernel       out-projection + residual + LN + pw_conv_1 + GLU (fused)    */
+#define MI355ASR_K_TAIL_FF2 17    /* tail_ff2_kernel      ConvModule tail + FFModule 2 + block LayerNorm (fused)      */
+#define MI355ASR_NUM_KERNELS 18
 int mi355asr_profile_enable(mi355asr_model* m, int32_t on);
 int mi355asr_profile_read(mi355asr_model* m, double* ms_out, int64_t* count_out, int32_t n, int32_t reset);
 

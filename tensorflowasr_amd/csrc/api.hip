@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -417,6 +418,40 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, c
   const int ksz = bo.ksz;
   const float fc = bo.fc;
   const int M = B * T;
+  static const bool fused_env = [] { const char* v = getenv("MI355ASR_FUSED"); return v ? atoi(v) != 0 : true; }();
+  if (d == 144 && fused_env) {
+    // token-local runs of layers in one launch each (fused.hip); attention and the depthwise conv mix tokens
+    const float qscale = 1.0f / std::sqrt((float)hs);
+    Ff1QkvArgs k1{};
+    k1.x0 = sc.xa; k1.x1 = sc.xb; k1.qkv = sc.qkv;
+    k1.ff_ln_g = w.ff_ln_g[0]; k1.ff_ln_b = w.ff_ln_b[0]; k1.ff_w1p = w.ff_w1p[0]; k1.ff_b1 = w.ff_b1[0];
+    k1.ff_w2p = w.ff_w2p[0]; k1.ff_b2 = w.ff_b2[0];
+    k1.att_ln_g = w.att_ln_g; k1.att_ln_b = w.att_ln_b; k1.qkv_wp = w.qkv_wp; k1.qkv_b = w.qkv_b;
+    k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M;
+    { PROF(MI355ASR_K_FF1_QKV); LAUNCH_TRY(launch_ff1_qkv(k1, s), "ff_module_1 + qkv"); }
+    AttnArgs at{};
+    at.qkv = sc.qkv; at.ctx = sc.ctx; at.B = B; at.T = T; at.H = H; at.D = d; at.ld = 3 * d;
+    at.win_front = bo.win_front; at.win_back = bo.win_back;
+    { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
+    OutGluArgs k2{};
+    k2.ctx = sc.ctx; k2.x1 = sc.xb; k2.x2 = sc.xa; k2.u = sc.u;
+    k2.out_wp = w.out_wp; k2.out_b = w.out_b; k2.cv_ln_g = w.cv_ln_g; k2.cv_ln_b = w.cv_ln_b;
+    k2.pw1_wp = w.pw1_wp; k2.pw1_b = w.pw1_b; k2.eps = kLnEps; k2.M = M;
+    { PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU"); }
+    DwArgs dwa{};
+    dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
+    dwa.pad_left = bo.causal ? ksz - 1 : (ksz - 1) / 2;
+    { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
+    TailFf2Args k4{};
+    k4.dw = sc.dw; k4.x2 = sc.xa; k4.y = out ? out : sc.xb;
+    k4.pc_w1p = w.pc_w1p; k4.pc_b1 = w.pc_b1; k4.bn_s = w.bn_s; k4.bn_t = w.bn_t; k4.pw2_wp = w.pw2_wp; k4.pw2_b = w.pw2_b;
+    k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];
+    k4.ff_w2p = w.ff_w2p[1]; k4.ff_b2 = w.ff_b2[1]; k4.ln_g = w.ln_g; k4.ln_b = w.ln_b;
+    k4.fc = fc; k4.eps = kLnEps; k4.M = M;
+    { PROF(MI355ASR_K_TAIL_FF2); LAUNCH_TRY(launch_tail_ff2(k4, s), "conv tail + ff_module_2"); }
+    if (!out) HIP_TRY(hipMemcpyAsync(sc.xa, sc.xb, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
   // ff_module_1: xb = xa + fc * FFN(LN(xa))
   Chain2Args f1{};
   f1.x = sc.xa; f1.res = sc.xa; f1.y = sc.xb;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((RT == 1 && D <= 144) ? 2 : 1)) voi
     const int h0 = hbase;
     if (r < KB) {
 #pragma unroll
-      for (int i = 0; i < CT1; ++i) dst[i] = w1[(size_t)(r * HT + h0 + i) * 64];
+      for (int i = 0; i < CT1; ++i) dst[i] = w1[(size_t)((r * HT + h0) * a.dbg_wmul + i) * 64];
       if (r == 0) {   // bias of this chunk rides with its first batch
 #pragma unroll
         for (int i = 0; i < CT1; ++i) b1v[i] = ldg4(a.b1 + 16 * (h0 + i) + g4);
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((RT == 1 && D <= 144) ? 2 : 1)) voi
     } else {
       const int n1 = r - KB;
 #pragma unroll
-      for (int n2 = 0; n2 < KB; ++n2) dst[n2] = w2[(size_t)((h0 + n1) * KB + n2) * 64];
+      for (int n2 = 0; n2 < KB; ++n2) dst[n2] = w2[(size_t)((h0 + n1) * KB * a.dbg_wmul + n2) * 64];
       if (MODE == 1 && n1 == 0) {
 #pragma unroll
         for (int i = 0; i < CT1; ++i) {
@@ -191,7 +191,10 @@ static void launch_chain2_t(const Chain2Args& a, int rt, hipStream_t s) {
   }
 }
 
-int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s) {
+int launch_chain2(int D, int mode, const Chain2Args& a_in, hipStream_t s) {
+  static const int wmul_env = env_int("MI355ASR_DEBUG_WMUL", 1);
+  Chain2Args a = a_in;
+  a.dbg_wmul = wmul_env;
   // two token tiles per wave once there are enough tiles to keep every CU busy with tile pairs
   static const int rt_env = env_int("MI355ASR_CHAIN2_RT", 0);
   const int tiles = (a.M + 15) / 16;

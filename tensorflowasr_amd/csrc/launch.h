@@ -30,6 +30,7 @@ struct Chain2Args {
   float scale;
   float eps;
   int M;
+  int dbg_wmul;        // 1 normally; 0 = (debug, wrong results) every weight batch re-reads batch 0: isolates the L2 weight stream
 };
 
 struct GemmArgs {
@@ -120,6 +121,30 @@ struct GatherArgs {
   float* dst;                // [B, Tp, D] zero padded
   int B, T, Tp, D;
 };
+// block-level fused kernels (fused.hip, dmodel 144)
+struct Ff1QkvArgs {
+  const float* x0; float* x1; float* qkv;
+  const float *ff_ln_g, *ff_ln_b, *ff_w1p, *ff_b1, *ff_w2p, *ff_b2;
+  const float *att_ln_g, *att_ln_b, *qkv_wp, *qkv_b;
+  float fc, qscale, eps;
+  int M;
+};
+struct OutGluArgs {
+  const float* ctx; const float* x1; float* x2; float* u;
+  const float *out_wp, *out_b, *cv_ln_g, *cv_ln_b, *pw1_wp, *pw1_b;
+  float eps;
+  int M;
+};
+struct TailFf2Args {
+  const float* dw; const float* x2; float* y;
+  const float *pc_w1p, *pc_b1, *bn_s, *bn_t, *pw2_wp, *pw2_b;
+  const float *ff_ln_g, *ff_ln_b, *ff_w1p, *ff_b1, *ff_w2p, *ff_b2, *ln_g, *ln_b;
+  float fc, eps;
+  int M;
+};
+int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s);
+int launch_out_glu(const OutGluArgs& a, hipStream_t s);
+int launch_tail_ff2(const TailFf2Args& a, hipStream_t s);
 int launch_pick(const PickArgs& a, hipStream_t s);
 int launch_gather(const GatherArgs& a, hipStream_t s);
 int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s);
