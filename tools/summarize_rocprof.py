@@ -1,6 +1,6 @@
 """Turns rocprofv3 CSV output (gpurun_out/prof_*) into the committed summaries under profiles/.
 
-  python tools/summarize_rocprof.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>]
+  python tools/summarize_rocprof.py <round-tag> <stats_dir> [<fetch_dir> <write_dir> [<mfma_dir>]]
 
   profiles/<tag>_kernel_stats.csv   copy of rocprofv3 --kernel-trace --stats kernel_stats
   profiles/<tag>_summary.md         per-kernel table (calls, avg us, share) + PMC bytes per launch
@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CATEGORY = [
     ("stft_kernel", "stft"), ("utt_max_kernel", "utt_max"), ("mel_kernel", "mel"), ("subconv_kernel", "subconv"),
     ("stream_gemm_kernel", "sublinear"), ("attention_kernel", "attention"), ("dwconv_kernel", "dwconv"),
-    ("collapse_kernel", "collapse"),
+    ("collapse_kernel", "collapse"), ("ff1_qkv_kernel", "ff1_qkv"), ("out_glu_kernel", "out_glu"),
+    ("tail_ff2_kernel", "tail_ff2"), ("topn_kernel", "topn"), ("pick_kernel", "pick"), ("gather_kernel", "gather"),
 ]
 
 
@@ -64,15 +65,20 @@ def main():
     ks = one(os.path.join(stats_dir, "**", "*kernel_stats.csv"))
     shutil.copy(ks, os.path.join(out, tag + "_kernel_stats.csv"))
     rows = list(csv.DictReader(open(ks)))
-    fetch = write = {}
+    fetch = write = busy = gui = {}
     if len(sys.argv) >= 5:
         fetch, write = pmc_avg(sys.argv[3], "FETCH_SIZE"), pmc_avg(sys.argv[4], "WRITE_SIZE")
+    if len(sys.argv) >= 6:
+        busy, gui = pmc_avg(sys.argv[5], "SQ_VALU_MFMA_BUSY_CYCLES"), pmc_avg(sys.argv[5], "GRBM_GUI_ACTIVE")
     lines = ["# rocprofv3 summary `%s`" % tag, "",
              "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 "
              "--no-cpu-baseline` (B=64 x 10 s, ConformerCTC(S), fp32); PMC columns from separate "
              "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (FETCH doubled per MI355X_MICROARCH.md, HBM section).", "",
-             "| kernel | category | calls | avg us | share % | FETCH MB/launch (x2) | WRITE MB/launch | HBM MB/launch |",
-             "|---|---|---|---|---|---|---|---|"]
+             "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), from a separate pass; "
+             "GRBM_GUI_ACTIVE carries ~25k cycles of per-dispatch overhead under PMC, so the figure is pessimistic "
+             "for kernels shorter than ~100 us.", "",
+             "| kernel | category | calls | avg us | share % | FETCH MB/launch (x2) | WRITE MB/launch | HBM MB/launch | MFMA busy % |",
+             "|---|---|---|---|---|---|---|---|---|"]
     traffic = {}
     for r in rows:
         name = r["Name"]
@@ -81,10 +87,12 @@ def main():
         wb = write.get(name, 0.0) * 1024
         if name in fetch or name in write:
             traffic[cat] = round(fb + wb)
-        lines.append("| `%s` | %s | %s | %.1f | %s | %s | %s | %s |" % (
-            name.replace("void ", ""), cat, r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"],
+        mb = ("%.0f" % (100.0 * busy[name] / (1024.0 * gui[name] / 8.0))) if name in busy and gui.get(name) else "-"
+        lines.append("| `%s` | %s | %s | %.1f | %s | %s | %s | %s | %s |" % (
+            name.replace("void ", "").replace("(anonymous namespace)::", ""), cat, r["Calls"],
+            float(r["AverageNs"]) / 1e3, r["Percentage"],
             ("%.1f" % (fb / 1e6)) if name in fetch else "-", ("%.1f" % (wb / 1e6)) if name in write else "-",
-            ("%.1f" % ((fb + wb) / 1e6)) if (name in fetch or name in write) else "-"))
+            ("%.1f" % ((fb + wb) / 1e6)) if (name in fetch or name in write) else "-", mb))
     open(os.path.join(out, tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
     if traffic:
         json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
