@@ -33,6 +33,8 @@ def category(name):
     for key, cat in CATEGORY:
         if key in name:
             return cat
+    if "<" not in name:
+        return name
     args = [a.strip() for a in name[name.index("<") + 1:name.index(">")].split(",")]
     if "chain2_kernel" in name:
         return "ffn" if args[-1] == "0" else "conv_tail"
