@@ -412,7 +412,9 @@ struct Scratch {
 };
 
 // One ConformerBlock (conformer_blocks.py:259-265).  Input in sc.xa, output to `out` (or sc.xa if null).
-int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, const Scratch& sc, int B, int T,
+// Input in sc.xa; output to `out`, or (out == nullptr) left in sc.xa -- the fused path ping-pongs xa/xb by swapping
+// the two pointers in `sc` instead of copying.
+int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int B, int T,
               float* out, hipStream_t s) {
   const int d = m->cfg.dmodel, H = m->cfg.num_heads, hs = m->cfg.head_size;
   const int ksz = bo.ksz;
@@ -449,7 +451,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, c
     k4.ff_w2p = w.ff_w2p[1]; k4.ff_b2 = w.ff_b2[1]; k4.ln_g = w.ln_g; k4.ln_b = w.ln_b;
     k4.fc = fc; k4.eps = kLnEps; k4.M = M;
     { PROF(MI355ASR_K_TAIL_FF2); LAUNCH_TRY(launch_tail_ff2(k4, s), "conv tail + ff_module_2"); }
-    if (!out) HIP_TRY(hipMemcpyAsync(sc.xa, sc.xb, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
+    if (!out) std::swap(sc.xa, sc.xb);
     return 0;
   }
   // ff_module_1: xb = xa + fc * FFN(LN(xa))
@@ -1117,7 +1119,8 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
 }
 
 // Dense(d->d) [+ blocks] [+ Dense(d->V) with argmax]; input rows at `in`, blocks run in sc.xa
-int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int B, int T, const Scratch& sc,
+// On return the stack's hidden output is in sc.xa (sc is updated: the blocks ping-pong xa/xb).
+int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int B, int T, Scratch& sc,
               float* logits, int32_t* amax, hipStream_t s) {
   const int d = m->cfg.dmodel;
   const int M = B * T;
