@@ -36,9 +36,11 @@ S_CFG = dict(dmodel=144, reduction_factor=4, num_blocks=13, head_size=36, num_he
 NUM_CLASSES = 1332    # pinyin vocabulary 1331 + blank (test_asr.py:180)
 
 
-def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES):
+def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES, stft_mode=0):
     """ALGORITHMIC flops per launch of each kernel category, counted as the reference computes the op
-    (1 MAC = 2 flop; DFT as the dense conv the reference runs, time_frequency.py:108-115)."""
+    (1 MAC = 2 flop).  The STFT is priced by what the selected kernel executes: the dense DFT conv
+    the reference runs (time_frequency.py:108-115) for stft_mode 0, the two 32-point DFT stages of the 32x32
+    Cooley-Tukey kernel for stft_mode 1 (8x fewer flops for the same spectrum -- not credited as dense flops)."""
     d, k, H = cfg["dmodel"], cfg["kernel_size"], cfg["num_heads"]
     F = -(-L // 160)
     T1 = -(-F // 2)
@@ -46,7 +48,7 @@ def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES):
     F1, F2 = 40, 20
     M = B * T
     return {
-        "stft": 2.0 * 2 * B * F * 1024 * 513,
+        "stft": 2.0 * 2 * B * F * 1024 * 513 if stft_mode == 0 else 2.0 * B * F * (32 * 32 * 64 + 32 * 64 * 32),
         "utt_max": 0.0,
         "mel": 2.0 * B * F * 513 * 80,
         "subconv": 2.0 * B * T1 * F1 * d * 9 + 2.0 * B * T * F2 * d * 9 * d,
@@ -192,7 +194,7 @@ def main():
         frames_per_utt = L // 160
         total_frames = world * B * frames_per_utt * args.steps
         value = total_frames / elapsed
-        fl = algorithmic_flops(B, L)
+        fl = algorithmic_flops(B, L, stft_mode=int(lib.mi355asr_stft_mode(h.ptr)))
         kern = {}
         for i, name in enumerate(_lib.KERNEL_NAMES):
             if cnt[i]:

@@ -77,6 +77,10 @@ const char* mi355asr_weight_name(const mi355asr_model* m, int32_t i);
 /* replaces: model._build() (test_asr.py:85-87): checks every tensor is present, packs the matrices into
  * MFMA fragment order, folds BatchNorm into (scale, shift), uploads to HBM. */
 int mi355asr_finalize_weights(mi355asr_model* m, void* stream);
+/* which STFT kernel mi355asr_finalize_weights selected: 1 = 32x32 Cooley-Tukey on the matrix cores (the loaded
+ * mel_layer/{real,imag}_kernels are window[n]*exp(-2*pi*i*k*n/1024), as backend.py:27-69 builds them), 0 = dense DFT
+ * GEMM with the kernels as loaded (a checkpoint changed them), -1 = no frontend / not finalized. */
+int mi355asr_stft_mode(const mi355asr_model* m);
 
 /* shape helpers: mel frames F = ceil(L/hop), encoder frames T = ceil(ceil(F/2)/2) per block of L samples */
 int mi355asr_out_frames(const mi355asr_model* m, int32_t L, int32_t* mel_frames, int32_t* enc_frames);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mi355asr_destroy": (ctypes.c_int, [_P]),
     "mi355asr_load_weight": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _I, ctypes.POINTER(ctypes.c_int64)]),
     "mi355asr_num_weights": (ctypes.c_int, [_P]),
+    "mi355asr_stft_mode": (ctypes.c_int, [_P]),
     "mi355asr_weight_name": (ctypes.c_char_p, [_P, _I]),
     "mi355asr_finalize_weights": (ctypes.c_int, [_P, _P]),
     "mi355asr_out_frames": (ctypes.c_int, [_P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),

@@ -105,6 +105,9 @@ struct mi355asr_model {
               *c2_b = nullptr, *lin_wp = nullptr, *lin_b = nullptr, *proj_wp = nullptr, *proj_b = nullptr,
               *fc_wp = nullptr, *fc_b = nullptr;
   int NT_fc = 0;
+  // FFT-as-GEMM STFT operands; fft_ok only when the loaded DFT kernels are window * exp(-2 pi i k n / N) (pack_fft)
+  bool fft_ok = false;
+  const float *fft_w1p = nullptr, *fft_w2p = nullptr, *fft_twc = nullptr, *fft_tws = nullptr, *fft_win = nullptr;
   std::vector<BlockDev> enc_blocks, ctc_blocks;
   // ChunkConformer (mi355asr_chunk_create): front + encoder / phone picker / context helper / text decoder stacks
   bool is_chunk = false;
@@ -231,6 +234,53 @@ struct ArenaBuilder {
     return put(v);
   }
 };
+
+// The DFT kernels are model variables (time_frequency.py:62-75 creates them from backend.py:27-69 and a checkpoint
+// may overwrite them).  When they are exactly window[n] * (cos, -+sin)(2 pi k n / 1024) the STFT runs as a
+// 32 x 32 Cooley-Tukey factorisation (fft_stft.hip); otherwise the dense DFT GEMM stays.  MI355ASR_FFT=0 forces dense.
+struct FftOff { bool ok = false; size_t w1 = 0, w2 = 0, twc = 0, tws = 0, win = 0; };
+FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vector<float>& im, int n_dft, int nb) {
+  FftOff o;
+  const char* env = std::getenv("MI355ASR_FFT");
+  if (env && std::atoi(env) == 0) return o;
+  if (n_dft != 1024 || nb != 513) return o;
+  const double two_pi = 6.283185307179586476925286766559;
+  std::vector<double> ct(1024), st(1024);
+  for (int i = 0; i < 1024; ++i) { ct[i] = std::cos(two_pi * i / 1024.0); st[i] = std::sin(two_pi * i / 1024.0); }
+  std::vector<float> win(1024);
+  for (int n = 0; n < 1024; ++n) win[n] = re[(size_t)n * nb];   // bin 0: cos = 1
+  const double tol = 1e-6;
+  bool neg = true, pos = true;   // imag = -w sin (reference) or +w sin: the power spectrum does not care
+  for (int n = 0; n < 1024; ++n)
+    for (int k = 0; k < nb; ++k) {
+      const int a = (int)(((int64_t)k * n) & 1023);
+      const double w = win[n];
+      if (std::fabs(re[(size_t)n * nb + k] - w * ct[a]) > tol) return o;
+      const double iv = im[(size_t)n * nb + k];
+      if (std::fabs(iv + w * st[a]) > tol) neg = false;
+      if (std::fabs(iv - w * st[a]) > tol) pos = false;
+      if (!neg && !pos) return o;
+    }
+  // stage 1: K = n1 (32), columns [Re k1 (32) | Im k1 (32)] of W32^(n1 k1)
+  o.w1 = ab.put(pack_p16(
+      [&](int k, int n) { const int a = ((k * (n & 31)) & 31) * 32; return (float)(n < 32 ? ct[a] : -st[a]); }, 32, 64, 4));
+  // stage 2: K = [Re n2 (32) | Im n2 (32)], columns [Re k2 (16) | Im k2 (16)] of W32^(n2 k2)
+  o.w2 = ab.put(pack_p16(
+      [&](int k, int n) {
+        const int a = (((k & 31) * (n & 15)) & 31) * 32;
+        if (k < 32) return (float)(n < 16 ? ct[a] : -st[a]);
+        return (float)(n < 16 ? st[a] : ct[a]);
+      },
+      64, 32, 2));
+  std::vector<float> tc(1024), ts(1024);
+  for (int k1 = 0; k1 < 32; ++k1)
+    for (int n2 = 0; n2 < 32; ++n2) { tc[k1 * 32 + n2] = (float)ct[k1 * n2]; ts[k1 * 32 + n2] = (float)st[k1 * n2]; }
+  o.twc = ab.put(tc);
+  o.tws = ab.put(ts);
+  o.win = ab.put(win);
+  o.ok = true;
+  return o;
+}
 
 struct BlockOff {
   size_t ff_ln_g[2], ff_ln_b[2], ff_w1p[2], ff_b1[2], ff_w2p[2], ff_b2[2];
@@ -375,7 +425,7 @@ Plan make_plan(const mi355asr_model* m, int Bp, int F, int T) {
   p.amax = take(M);
   const int FT = ceil_div(F, 16);
   p.logp = take((size_t)Bp * F * m->dm.LP);
-  p.pmax = take((size_t)Bp * FT * m->dm.NCH_dft);
+  p.pmax = take((size_t)Bp * std::max(FT * m->dm.NCH_dft, F));
   p.umax = take(Bp);
   p.mel = take((size_t)Bp * F * m->cfg.n_mels);
   p.sub = take(M * m->dm.F2 * d);
@@ -514,8 +564,17 @@ int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, fl
   st.B = Bp; st.L = Lb; st.F = F; st.hop = m->dm.hop; st.pad_left = before; st.n_dft = c.n_dft;
   st.NT = m->dm.NT_dft; st.LP = m->dm.LP; st.nbins = m->dm.nbins; st.FT = FT; st.NCH = m->dm.NCH_dft;
   st.db10 = 1;
-  { PROF(MI355ASR_K_STFT); LAUNCH_TRY(launch_stft(st, s), "stft"); }
-  UttMaxArgs um{pmax, umax, FT * m->dm.NCH_dft};
+  int npart = FT * m->dm.NCH_dft;
+  if (m->fft_ok) {
+    FftStftArgs fa{wav, logp, pmax, m->fft_w1p, m->fft_w2p, m->fft_twc, m->fft_tws, m->fft_win,
+                   Bp, Lb, F, m->dm.hop, before, m->dm.LP, 1};
+    { PROF(MI355ASR_K_STFT); LAUNCH_TRY(launch_fft_stft(fa, s), "stft (fft)"); }
+    npart = F;
+  } else {
+    PROF(MI355ASR_K_STFT);
+    LAUNCH_TRY(launch_stft(st, s), "stft");
+  }
+  UttMaxArgs um{pmax, umax, npart};
   { PROF(MI355ASR_K_UTT_MAX); LAUNCH_TRY(launch_utt_max(um, Bp, s), "utterance max"); }
   MelArgs me{};
   me.logp = logp; me.umax = umax; me.mel = mel; me.wp = m->mel_wp;
@@ -708,6 +767,10 @@ int mi355asr_destroy(mi355asr_model* m) {
   return 0;
 }
 
+int mi355asr_stft_mode(const mi355asr_model* m) {
+  if (!m || !m->finalized || (!m->is_chunk && !m->cfg.has_encoder)) return -1;
+  return m->fft_ok ? 1 : 0;
+}
 int mi355asr_num_weights(const mi355asr_model* m) { return m ? (int)m->expected.size() : 0; }
 const char* mi355asr_weight_name(const mi355asr_model* m, int32_t i) {
   if (!m || i < 0 || i >= (int)m->expected.size()) return nullptr;
@@ -748,6 +811,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   const int d = c.dmodel;
   ArenaBuilder ab;
   size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0;
+  FftOff fo;
   std::vector<BlockOff> eo, co;
   if (c.has_encoder) {
   const auto& re = m->host["mel_layer/real_kernels"].data;
@@ -757,6 +821,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   o_dft = ab.put(pack_p16(
       [&](int k, int n) { const int bin = n >> 1; return (n & 1) ? im[(size_t)k * nb + bin] : re[(size_t)k * nb + bin]; },
       c.n_dft, 2 * nb, dm.NT_dft));
+  fo = pack_fft(ab, re, im, c.n_dft, nb);
   const auto& f2m = m->host["mel_layer/freq2mel"].data;
   o_mel = ab.put(pack_p16([&](int k, int n) { return k < nb ? f2m[(size_t)k * c.n_mels + n] : 0.f; }, dm.KBm * 16, c.n_mels, dm.NTm));
   o_c1w = ab.put(m->host["conv_subsampling/conv1/kernel"].data);  // [3][3][1][d] == [(i*3+j)*d + c]
@@ -799,6 +864,9 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   HIP_TRY(hipStreamSynchronize(s));  // ab.buf is freed on return
   const float* base = m->arena;
   m->dft_wp = base + o_dft; m->mel_wp = base + o_mel;
+  m->fft_ok = fo.ok;
+  m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;
+  m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
@@ -1014,7 +1082,7 @@ ChunkPlan make_chunk_plan(const mi355asr_model* m, int B, int F, int T) {
   p.amax = take(M); p.idx = take(M); p.cnt = take(B);
   const int FT = ceil_div(F, 16);
   p.logp = take((size_t)B * F * m->dm.LP);
-  p.pmax = take((size_t)B * FT * m->dm.NCH_dft);
+  p.pmax = take((size_t)B * std::max(FT * m->dm.NCH_dft, F));
   p.mel = take((size_t)B * F * m->cfg.n_mels);
   p.sub = take(M * m->dm.F2 * d);
   p.total = o;
@@ -1081,6 +1149,7 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   const size_t o_dft = ab.put(pack_p16(
       [&](int k, int n) { const int bin = n >> 1; return (n & 1) ? im[(size_t)k * nb + bin] : re[(size_t)k * nb + bin]; },
       c.n_dft, 2 * nb, dm.NT_dft));
+  const FftOff fo = pack_fft(ab, re, im, c.n_dft, nb);
   const auto& f2m = m->host["front/mel_layer/freq2mel"].data;
   const size_t o_mel = ab.put(pack_p16([&](int k, int n) { return k < nb ? f2m[(size_t)k * c.n_mels + n] : 0.f; },
                                        dm.KBm * 16, c.n_mels, dm.NTm));
@@ -1108,6 +1177,9 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   HIP_TRY(hipStreamSynchronize(s));
   const float* base = m->arena;
   m->dft_wp = base + o_dft; m->mel_wp = base + o_mel;
+  m->fft_ok = fo.ok;
+  m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;
+  m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   resolve_stack(m->c_enc, e, base, false, 0);
@@ -1251,7 +1323,15 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     st.B = B; st.L = L; st.F = g.F; st.hop = m->dm.hop; st.pad_left = c.n_dft - 1; st.n_dft = c.n_dft;
     st.NT = m->dm.NT_dft; st.LP = m->dm.LP; st.nbins = m->dm.nbins; st.FT = FT; st.NCH = m->dm.NCH_dft;
     st.db10 = 0;                                    // chunk_amplitude_to_decibel: log10 only (backend_keras.py:25-37)
-    { PROF(MI355ASR_K_STFT); LAUNCH_TRY(launch_stft(st, s), "stft (valid)"); }
+    if (m->fft_ok) {
+      FftStftArgs fa{wav, st.logp, st.pmax, m->fft_w1p, m->fft_w2p, m->fft_twc, m->fft_tws, m->fft_win,
+                     B, L, g.F, m->dm.hop, c.n_dft - 1, m->dm.LP, 0};
+      PROF(MI355ASR_K_STFT);
+      LAUNCH_TRY(launch_fft_stft(fa, s), "stft (valid, fft)");
+    } else {
+      PROF(MI355ASR_K_STFT);
+      LAUNCH_TRY(launch_stft(st, s), "stft (valid)");
+    }
     MelArgs me{};
     me.logp = st.logp; me.umax = nullptr; me.mel = (float*)(ws + p.mel); me.wp = m->mel_wp;
     me.B = B; me.F = g.F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;

@@ -1,0 +1,177 @@
+// STFT power spectrum through a 32 x 32 Cooley-Tukey factorisation of the 1024-point DFT, both stages on the
+// fp32 matrix cores.  Same result as stft_kernel (the reference's dense DFT convolution,
+// asr/models/layers/time_frequency.py:100-122) with 128 instead of 1040 MFMAs per frame; it is only selected when
+// the model's DFT kernels are window[n] * exp(-2*pi*i*k*n/1024) (checked at mi355asr_finalize_weights: the
+// kernels are Keras variables and may come from a checkpoint; anything else runs the dense kernel).
+//
+//   n = 32*n1 + n2,  k = k1 + 32*k2:
+//   A[k1][n2] = sum_n1 xw[32 n1 + n2] W32^(n1 k1)            stage 1: tokens = n2 (two 16-tiles), K = n1 (32)
+//   B[k1][n2] = A[k1][n2] * W1024^(n2 k1)                    twiddle, in registers
+//   X[k1 + 32 k2] = sum_n2 B[k1][n2] W32^(n2 k2)             stage 2: tokens = k1, K = (re,im) of n2 (64), k2 < 16
+// One wave owns whole frames; the 32 x 32 complex transpose between the stages goes through 9 KB of wave-private
+// LDS (no block barrier).  Bin 512 (k1 = 0, k2 = 16) is the alternating sum of A[0][:].
+// The stage weights (cos/sin of 32-point DFTs), the twiddles and the window live in registers for the whole kernel.
+#include "common.h"
+#include "launch.h"
+
+namespace {
+
+constexpr int LDW = 36;   // LDS row stride in floats (16-byte aligned rows, 4 floats of padding)
+
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_kernel(FftStftArgs a) {
+  __shared__ float lds[WAVES_PER_BLOCK][2][32 * LDW];
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, g4 = g * 4, c = lane & 15;
+  const int wave = threadIdx.x >> 6;
+  float* Lre = lds[wave][0];
+  float* Lim = lds[wave][1];
+  const int wid = blockIdx.x * WAVES_PER_BLOCK + wave;
+  const int nwaves = gridDim.x * WAVES_PER_BLOCK;
+  const int total = a.B * a.F;
+
+  // ---- frame-independent operands -> registers
+  const f32x4* __restrict__ w1p = reinterpret_cast<const f32x4*>(a.w1p) + lane;   // [2 kb][4 nt]
+  const f32x4* __restrict__ w2p = reinterpret_cast<const f32x4*>(a.w2p) + lane;   // [4 kb][2 nt]
+  f32x4 w1[2][4], w2[4][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) w1[kb][nt] = w1p[(kb * 4 + nt) * 64];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) w2[kb][nt] = w2p[(kb * 2 + nt) * 64];
+  f32x4 hw[2][2], twc[2][2], tws[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int n2 = 16 * rt + c;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      // window at n = 32*n1 + n2, n1 = 16*kb + 4*g + j
+      hw[rt][kb].x = a.window[32 * (16 * kb + g4 + 0) + n2];
+      hw[rt][kb].y = a.window[32 * (16 * kb + g4 + 1) + n2];
+      hw[rt][kb].z = a.window[32 * (16 * kb + g4 + 2) + n2];
+      hw[rt][kb].w = a.window[32 * (16 * kb + g4 + 3) + n2];
+      // twiddle W1024^(n2*k1), k1 = 16*kb + 4*g + j  (kb doubles as the re-tile index here)
+      twc[rt][kb].x = a.tw_c[(16 * kb + g4 + 0) * 32 + n2]; tws[rt][kb].x = a.tw_s[(16 * kb + g4 + 0) * 32 + n2];
+      twc[rt][kb].y = a.tw_c[(16 * kb + g4 + 1) * 32 + n2]; tws[rt][kb].y = a.tw_s[(16 * kb + g4 + 1) * 32 + n2];
+      twc[rt][kb].z = a.tw_c[(16 * kb + g4 + 2) * 32 + n2]; tws[rt][kb].z = a.tw_s[(16 * kb + g4 + 2) * 32 + n2];
+      twc[rt][kb].w = a.tw_c[(16 * kb + g4 + 3) * 32 + n2]; tws[rt][kb].w = a.tw_s[(16 * kb + g4 + 3) * 32 + n2];
+    }
+  }
+  const int L = a.L;
+
+#pragma unroll 1
+  for (int fidx = wid; fidx < total; fidx += nwaves) {
+    const int b = fidx / a.F, f = fidx - b * a.F;
+    const float* __restrict__ wav = a.wav + (size_t)b * L;
+    const int base = f * a.hop - a.pad_left;
+    // ---- stage-1 operand: xw[32*n1 + n2], zero outside the signal (TF SAME / left-padded VALID framing)
+    f32x4 xf[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int s0 = base + 32 * (16 * kb + g4) + 16 * rt + c;
+        const bool o0 = (unsigned)(s0) < (unsigned)L, o1 = (unsigned)(s0 + 32) < (unsigned)L;
+        const bool o2 = (unsigned)(s0 + 64) < (unsigned)L, o3 = (unsigned)(s0 + 96) < (unsigned)L;
+        f32x4 v;
+        v.x = wav[o0 ? s0 : 0]; v.y = wav[o1 ? s0 + 32 : 0]; v.z = wav[o2 ? s0 + 64 : 0]; v.w = wav[o3 ? s0 + 96 : 0];
+        v.x = o0 ? v.x : 0.f; v.y = o1 ? v.y : 0.f; v.z = o2 ? v.z : 0.f; v.w = o3 ? v.w : 0.f;
+        xf[rt][kb] = v * hw[rt][kb];
+      }
+    // ---- stage 1: A = F32 * Xw   (acc1[rt][nt]: nt 0,1 = Re k1 0..31 ; nt 2,3 = Im k1 0..31)
+    f32x4 acc1[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc1[rt][nt] = splat4(0.f);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc1[rt][nt] = mfma4(w1[kb][nt][j], xf[rt][kb][j], acc1[rt][nt]);
+    // ---- bin 512: sum_n2 (-1)^n2 A_re[0][n2]   (A_re[0][n2] sits in lanes g == 0, tile 0, reg 0)
+    float nyq = (g == 0) ? ((c & 1) ? -1.f : 1.f) * (acc1[0][0].x + acc1[1][0].x) : 0.f;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) nyq += __shfl_xor(nyq, off);
+    // ---- twiddle + transpose through wave-private LDS: L[k1][n2]
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int n2 = 16 * rt + c;
+#pragma unroll
+      for (int nr = 0; nr < 2; ++nr) {
+        const f32x4 are = acc1[rt][nr], aim = acc1[rt][2 + nr];
+        const f32x4 bre = are * twc[rt][nr] + aim * tws[rt][nr];
+        const f32x4 bim = aim * twc[rt][nr] - are * tws[rt][nr];
+        const int k1 = 16 * nr + g4;
+        Lre[(k1 + 0) * LDW + n2] = bre.x; Lre[(k1 + 1) * LDW + n2] = bre.y;
+        Lre[(k1 + 2) * LDW + n2] = bre.z; Lre[(k1 + 3) * LDW + n2] = bre.w;
+        Lim[(k1 + 0) * LDW + n2] = bim.x; Lim[(k1 + 1) * LDW + n2] = bim.y;
+        Lim[(k1 + 2) * LDW + n2] = bim.z; Lim[(k1 + 3) * LDW + n2] = bim.w;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- stage 2: X[k1][k2] = sum_n2 B[k1][n2] W32^(n2 k2); tokens = k1 = 16*rt + c, K = [Re n2 | Im n2]
+    f32x4 acc2[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      acc2[rt][0] = splat4(0.f);
+      acc2[rt][1] = splat4(0.f);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      f32x4 yf[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float* src = (kb < 2 ? Lre : Lim) + (16 * rt + c) * LDW + 16 * (kb & 1) + g4;
+        yf[rt] = *reinterpret_cast<const f32x4*>(src);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc2[rt][nt] = mfma4(w2[kb][nt][j], yf[rt][j], acc2[rt][nt]);
+    }
+    // ---- power, log, store, per-frame max.  lane holds bins k1 + 32*k2, k1 = 16*rt + c, k2 = 4*g + j
+    float mx = -INFINITY;
+    float* orow = a.logp + ((size_t)b * a.F + f) * a.LP;
+    const float kscale = a.db10 ? (10.0f * 0.69314718f / 2.30258509f) : (0.69314718f / 2.30258509f);   // log2 -> dB / log10
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const f32x4 re = acc2[rt][0], im = acc2[rt][1];
+      const f32x4 p = re * re + im * im;
+      const float pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float l = __log2f(fmaxf(pv[j], 1e-10f)) * kscale;
+        orow[16 * rt + c + 32 * (g4 + j)] = l;
+        mx = fmaxf(mx, l);
+      }
+    }
+    if (lane == 0) {
+      const float l = __log2f(fmaxf(nyq * nyq, 1e-10f)) * kscale;
+      orow[512] = l;
+      mx = fmaxf(mx, l);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) a.pmax[fidx] = mx;
+  }
+}
+
+}  // namespace
+
+int launch_fft_stft(const FftStftArgs& a, hipStream_t s) {
+  const int total = a.B * a.F;
+  // enough waves for 4 per SIMD (their VALU / LDS phases hide under each other's MFMAs), each looping over frames
+  const int waves = std::min(total, 4096);
+  hipLaunchKernelGGL(fft_stft_kernel, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
+  return 0;
+}

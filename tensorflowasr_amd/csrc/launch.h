@@ -73,6 +73,20 @@ struct StftArgs {
   int B, L, F, hop, pad_left, n_dft, NT, LP, nbins, FT, NCH;
   int db10;           // 1: 10*ln(p)/ln10 ; 0: ln(p)/ln10
 };
+// 32 x 32 Cooley-Tukey STFT (fft_stft.hip); n_dft = 1024 only
+struct FftStftArgs {
+  const float* wav;     // [B, L]
+  float* logp;          // [B, F, LP]
+  float* pmax;          // [B, F] per-frame maxima
+  const float* w1p;     // stage-1 DFT-32 [2][4][64][4]
+  const float* w2p;     // stage-2 DFT-32 on (re | im) [4][2][64][4]
+  const float* tw_c;    // cos(2 pi k1 n2 / 1024) [32 k1][32 n2]
+  const float* tw_s;    // sin(...)
+  const float* window;  // [1024]
+  int B, L, F, hop, pad_left, LP;
+  int db10;
+};
+int launch_fft_stft(const FftStftArgs& a, hipStream_t s);
 struct UttMaxArgs { const float* pmax; float* umax; int n; };
 struct MelArgs {
   const float* logp;  // [B, F, LP]

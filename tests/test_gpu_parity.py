@@ -82,6 +82,53 @@ def test_melspectrogram_silence_and_padding_dependence(enc2):
     assert maxdiff(a[:, :90], b[:, :90]) < TOL      # same max -> same interior frames
 
 
+def test_stft_kernel_selection_and_dense_fallback(enc2, torch_cuda):
+    """The DFT kernels are model variables: the analytic ones (backend.py:27-69) select the Cooley-Tukey kernel, a
+    checkpoint that changed them (here: a Hamming-like window plus a detuned bin) must run the dense DFT GEMM with
+    the kernels as loaded.  Both against the oracle's dense DFT."""
+    from tensorflowasr_amd.models import ConformerEncoder
+    e, w, cfg = enc2
+    assert e._h.lib.mi355asr_stft_mode(e._h.ptr) == 1
+    w2 = dict(w)
+    n = np.arange(1024)
+    ham = (0.54 - 0.46 * np.cos(2 * np.pi * n / 1024)) / np.maximum(0.5 - 0.5 * np.cos(2 * np.pi * n / 1024), 0.05)
+    shp = w["mel_layer/real_kernels"].shape
+    hcol = ham.astype(np.float32).reshape((-1,) + (1,) * (len(shp) - 1))
+    re = w["mel_layer/real_kernels"] * hcol
+    im = w["mel_layer/imag_kernels"] * hcol
+    re[..., 37] *= 0.5
+    w2["mel_layer/real_kernels"], w2["mel_layer/imag_kernels"] = re, im
+    e2 = ConformerEncoder(**encoder_kwargs(cfg))
+    e2.load_weights(w2, by_name=False)
+    assert e2._h.lib.mi355asr_stft_mode(e2._h.ptr) == 0
+    x = waves(2, 24000, 11)
+    ref2 = co.melspectrogram(x.astype(np.float64), w2)
+    got2 = e2.melspectrogram(x).cpu().numpy()
+    assert maxdiff(got2, ref2) < TOL
+    ref1 = co.melspectrogram(x.astype(np.float64), w)
+    assert maxdiff(e.melspectrogram(x).cpu().numpy(), ref1) < TOL
+    assert maxdiff(ref1, ref2) > 0.1          # the two kernel sets really give different features
+
+
+def test_fft_and_dense_stft_agree(torch_cuda):
+    """MI355ASR_FFT=0 forces the dense DFT GEMM on the analytic kernels: same features as the Cooley-Tukey path."""
+    from tensorflowasr_amd.models import ConformerEncoder
+    cfg = small_cfg(1)
+    w = co.encoder_weights(cfg, seed=3)
+    x = waves(3, 48000, 4)
+    outs = []
+    for flag, mode in (("0", 0), ("1", 1)):
+        os.environ["MI355ASR_FFT"] = flag
+        try:
+            e = ConformerEncoder(**encoder_kwargs(cfg))
+            e.load_weights(w, by_name=False)
+        finally:
+            os.environ.pop("MI355ASR_FFT")
+        assert e._h.lib.mi355asr_stft_mode(e._h.ptr) == mode
+        outs.append(e.melspectrogram(x).cpu().numpy())
+    assert maxdiff(outs[0], outs[1]) < 5e-4      # each is ~2.4e-4 from the fp64 oracle on the dB scale
+
+
 @pytest.mark.parametrize("F", [200, 50, 37, 3])
 def test_conv_subsampling_parity(enc2, F):
     e, w, _ = enc2
