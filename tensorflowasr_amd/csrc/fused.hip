@@ -8,12 +8,21 @@
 //   ff1_qkv_kernel    x0 -> x1 = x0 + fc*FFN1(LN(x0))  ;  qkv = LN(x1) Wqkv (+b), q scaled      (3 GEMMs)
 //   out_glu_kernel    x2 = x1 + ctx Wo + bo            ;  u = GLU(LN(x2) Wpw1 + b)                (2 GEMMs)
 //   tail_ff2_kernel   x3 = x2 + pw2(swish(BN(dw Wpc + b))) + b ; y = LN(x3 + fc*FFN2(LN(x3)))    (4 GEMMs)
-// One wave = 16 tokens, no LDS, no barriers.  Weight fragments are fetched one k-block ahead and the fetches are
-// interleaved with the MFMAs at tile-pair granularity (2 loads, 8 MFMAs, fenced): the micro-benchmark shows that
-// schedule holding 131-145 TFLOP/s whether one or several waves share a SIMD, where batch-granular prefetch
-// (all loads, then all MFMAs) falls to ~100 as soon as two waves are co-resident.
+// One wave = 16 tokens and (at 16 000 tokens) one wave per SIMD, so nothing hides a stall: every load a wave
+// waits for is matrix-pipe idle time.  Hence
+//   * weight fragments are fetched one k-block ahead, interleaved with the MFMAs at tile-pair granularity
+//     (2 loads, 8 MFMAs, fenced) -- the micro-benchmark holds 124-138 TFLOP/s with that schedule at this shape;
+//   * every small parameter vector of the kernel (biases, LayerNorm gamma/beta, folded BatchNorm) is copied to
+//     LDS once per workgroup at kernel start and read from there (~100 cycles, issued a fence group ahead of its
+//     use) instead of from L2 (~700 cycles, exposed at each of the 8-10 stage boundaries of a kernel);
+//   * bias + activation of hidden tile n+1 runs inside the fenced MFMA region of tile n (v_exp / v_rcp in the
+//     matrix pipe's shadow), the residual input stays in registers;
+//   * the kernels fit 256 registers (__launch_bounds__(256, 2)), so hipcc keeps the accumulators in VGPRs; with
+//     the 512-register budget it parks them in AGPRs and moves them back and forth around every MFMA group.
 // Reference semantics: asr/models/conformer_blocks.py:126-134 (FFModule), :164-170 + multihead_attention.py:151-188
 // (MHSA), :209-219 (ConvModule), :259-265 (block).
+#include <type_traits>
+
 #include "common.h"
 #include "launch.h"
 
@@ -21,102 +30,148 @@ namespace {
 
 constexpr int D = 144;
 constexpr int KB = D / 16;   // 9
+constexpr int NB = KB;       // fragments per batch (dmodel 144: every batch on the path is 9 fragments)
 
-// The weight stream of a kernel is one sequence of 9-fragment batches that runs across GEMM and stage
-// boundaries: every GEMM routine enters with its first batch already in `wc` (fetched by whoever ran before it)
-// and leaves with the batch at `next` in `wc`, fetched during its own last k-step -- so a stage never starts with
-// an exposed load.  Loads are interleaved with the MFMAs at tile-pair granularity (2 loads, 8 MFMAs, fenced).
-constexpr int NB = KB;   // fragments per batch (dmodel 144: every batch on the path is 9 fragments)
-
-DEV void load_batch(f32x4 (&w)[NB], const f32x4* __restrict__ p) {
-#pragma unroll
-  for (int i = 0; i < NB; ++i) w[i] = p[(size_t)i * 64];
-}
-
-// acc[i] += W[kb][n0 + i]^T * x[kb], i < 9, kb < KBI;  W packed [KBI][NT] fragments.
-template <int KBI>
-DEV void wave_gemm(f32x4 (&acc)[NB], const f32x4 (&x)[KBI], const f32x4* __restrict__ wp, int NT, int n0,
-                   f32x4 (&wc)[NB], const f32x4* __restrict__ next) {
-  f32x4 wn[NB];
-#pragma unroll
-  for (int kb = 0; kb < KBI; ++kb) {
-    const f32x4* src = (kb + 1 < KBI) ? wp + (size_t)((kb + 1) * NT + n0) * 64 : next;
-#pragma unroll
-    for (int i0 = 0; i0 < NB; i0 += 2) {
-#pragma unroll
-      for (int i = i0; i < i0 + 2 && i < NB; ++i) wn[i] = src[(size_t)i * 64];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = i0; i < i0 + 2 && i < NB; ++i) acc[i] = mfma4(wc[i][j], x[kb][j], acc[i]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) wc[i] = wn[i];
+// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, class F>
+DEV void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
   }
 }
 
-// acc2[n2] += W2[h0 + n1][n2]^T * act(h[n1])  for n1 < 9 hidden tiles, n2 < 9 output tiles (second GEMM of a chain).
-// The activation of hidden tile n1+1 is evaluated inside the fenced MFMA region of tile n1, so its VALU work
-// (v_exp, v_rcp) issues under the matrix pipe's shadow instead of between the two GEMMs.
-template <class ACT>
-DEV void wave_gemm2(f32x4 (&acc2)[NB], f32x4 (&h)[NB], const f32x4* __restrict__ wp, int h0, f32x4 (&wc)[NB],
-                    const f32x4* __restrict__ next, ACT act) {
-  f32x4 wn[NB];
-  h[0] = act(0, h[0]);
+// ---- parameter stash --------------------------------------------------------------------------------------
+DEV void stash(float* dst, const float* __restrict__ src, int n) {
+  for (int i = threadIdx.x; i < n; i += BLOCK_THREADS) dst[i] = src[i];
+}
+// this lane's float4 of tile `tile` of a stashed vector (lanes of one 16-lane group read the same address)
+DEV f32x4 lds4(const float* v, int tile, int g4) { return *reinterpret_cast<const f32x4*>(v + 16 * tile + g4); }
+
+// ---- weight stream ----------------------------------------------------------------------------------------
+// The weight stream of a kernel is one sequence of 9-fragment batches (one k-block x 9 column tiles) that runs
+// across GEMM and stage boundaries.  Two register buffers wb[0], wb[1] hold it: while batch t is consumed from
+// wb[CUR] (five fenced groups of 2+2+2+2+1 tiles), the slots a group has just finished with are refilled with the
+// same fragments of batch t+2, and wb[CUR^1] holds batch t+1.  A fragment is therefore requested ~16 fragments
+// = 64 MFMAs = ~2000 cycles before its first use, with no more registers than plain double buffering; fetching
+// only one batch ahead (~1100 cycles) left 17 % of the wave's cycles in s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES,
+// profiles/r01c_pmc_probe.csv) because one wave per SIMD has nothing else to run while it waits on L2.
+// Invariant on entry to batch t with CUR: wb[CUR] = batch t (all 9 issued), wb[CUR^1] = batch t+1 slots 0..7.
+// Addresses are (uniform batch pointer in SGPRs) + (lane * 16 bytes in one VGPR): no per-load vector address math.
+struct WStream {
+  f32x4 wb[2][NB];
+  unsigned lane16;   // lane * 16 bytes
+};
+DEV f32x4 ldw(const f32x4* __restrict__ batch, int frag, unsigned lane16) {
+  // pin the (uniform) fragment address to an SGPR pair so that the load is `global_load v, v_lane16, s[..]`;
+  // left alone, hipcc folds the lane offset into a 64-bit VGPR base and spends two VALU adds per fragment
+  unsigned long long p = reinterpret_cast<unsigned long long>(batch + frag * 64);
+  asm("" : "+s"(p));     // opaque SGPR pair: keeps LLVM from re-associating the lane offset into the base
+  typedef const __attribute__((address_space(1))) char* gptr;
+  gptr sp = (gptr)p;
+  return *(const __attribute__((address_space(1))) f32x4*)(sp + lane16);
+}
+DEV void stream_begin(WStream& s, const f32x4* __restrict__ b0, const f32x4* __restrict__ b1) {
 #pragma unroll
-  for (int n1 = 0; n1 < NB; ++n1) {
-    const f32x4* src = (n1 + 1 < NB) ? wp + (size_t)((h0 + n1 + 1) * KB) * 64 : next;
+  for (int i = 0; i < NB; ++i) s.wb[0][i] = ldw(b0, i, s.lane16);
 #pragma unroll
-    for (int i0 = 0; i0 < NB; i0 += 2) {
-#pragma unroll
-      for (int i = i0; i < i0 + 2 && i < NB; ++i) wn[i] = src[(size_t)i * 64];
-      __builtin_amdgcn_sched_barrier(0);
-      if (i0 == 0 && n1 + 1 < NB) h[n1 + 1] = act(n1 + 1, h[n1 + 1]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = i0; i < i0 + 2 && i < NB; ++i) acc2[i] = mfma4(wc[i][j], h[n1][j], acc2[i]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) wc[i] = wn[i];
-  }
+  for (int i = 0; i < NB - 1; ++i) s.wb[1][i] = ldw(b1, i, s.lane16);
 }
 
-// y = W2 act( W1 xin + b1 )  with the hidden dimension swept in chunks of 9 tiles.
-//   AFF: act = swish(s * . + t) (folded BatchNorm), else act = swish
-// enters with W1's first batch (k-block 0, hidden tiles 0..8) in wc; leaves with the batch at `next` in wc.
+// acc[i] += wb[CUR][i]^T * x  (one k-block, 9 column tiles); p1 / p2 = addresses of batches t+1 / t+2.
+// hook(gi) runs inside fence group gi: a place for VALU / LDS work that should issue under the MFMAs.
+template <int CUR, class HOOK>
+DEV void batch_step(f32x4 (&acc)[NB], const f32x4 x, WStream& s, unsigned l16, const f32x4* __restrict__ p1,
+                    const f32x4* __restrict__ p2, HOOK&& hook) {
+  static_for<0, 5>([&](auto GI) {
+    constexpr int gi = decltype(GI)::value;
+    if constexpr (gi == 0) {
+      s.wb[CUR ^ 1][NB - 1] = ldw(p1, NB - 1, l16);
+    } else {
+      s.wb[CUR][2 * gi - 2] = ldw(p2, 2 * gi - 2, l16);
+      s.wb[CUR][2 * gi - 1] = ldw(p2, 2 * gi - 1, l16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 2 * gi; i < 2 * gi + 2 && i < NB; ++i) acc[i] = mfma4(s.wb[CUR][i][j], x[j], acc[i]);
+    hook(GI);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+struct NoHook {
+  template <class T, class G> DEV void operator()(T, G) const {}
+};
+
+// acc[i] += W[t]^T * x[t] for the 9 batches own(0..8) of one GEMM; next0 / next1 = the two batches that follow it
+// in the kernel's stream.  Enters with CUR, leaves with CUR^1 (9 is odd).  hook(T, GI) as in batch_step.
+template <int CUR, class OWN, class HOOK>
+DEV void wave_gemm(f32x4 (&acc)[NB], const f32x4 (&x)[KB], WStream& s, OWN&& own, const f32x4* __restrict__ next0,
+                   const f32x4* __restrict__ next1, HOOK&& hook) {
+  // the 32-bit lane offset is re-materialised (opaquely) in the block that uses it: the `saddr + zext(voffset)`
+  // addressing mode is only selected when the zero-extension is visible in the same basic block
+  unsigned l16 = s.lane16;
+  asm volatile("" : "+v"(l16));
+  static_for<0, KB>([&](auto T) {
+    constexpr int t = decltype(T)::value;
+    const f32x4* p1 = (t + 1 < KB) ? own(t + 1) : next0;
+    const f32x4* p2 = (t + 2 < KB) ? own(t + 2) : (t + 2 == KB ? next0 : next1);
+    batch_step<(CUR + t) & 1>(acc, x[t], s, l16, p1, p2, [&](auto GI) { hook(T, GI); });
+  });
+}
+
+// Bias / folded-BatchNorm / swish of one hidden tile, split in two so that the LDS reads are issued one fence
+// group before the VALU work that consumes them.
+template <bool AFF>
+struct Act {
+  const float *b1, *as, *at;   // LDS
+  int g4;
+  f32x4 pb, ps, pt;
+  DEV void fetch(int tile) {
+    pb = lds4(b1, tile, g4);
+    if (AFF) { ps = lds4(as, tile, g4); pt = lds4(at, tile, g4); }
+  }
+  DEV f32x4 apply(f32x4 v) const {
+    v = v + pb;
+    if (AFF) v = v * ps + pt;
+    return swish4(v);
+  }
+};
+
+// y += W2 act( W1 xin + b1 )  with the hidden dimension swept in chunks of 9 tiles; b1 / aff_* are LDS pointers.
+//   AFF: act = swish(s * (. + b1) + t) (folded BatchNorm), else act = swish(. + b1)
+// Stream: per chunk 9 batches of W1 (k-block t, hidden tiles h0..h0+8) then 9 batches of W2 (hidden tile h0+t as
+// the k-block); next0 / next1 = the two batches after the chain.  Enters and leaves with CUR = 0.
 template <int HT, bool AFF>
-DEV void wave_chain(f32x4 (&y)[KB], const f32x4 (&xin)[KB], const f32x4* __restrict__ w1, const float* __restrict__ b1,
-                    const float* __restrict__ aff_s, const float* __restrict__ aff_t, const f32x4* __restrict__ w2,
-                    int g4, f32x4 (&wc)[NB], const f32x4* __restrict__ next) {
+DEV void wave_chain(f32x4 (&y)[KB], const f32x4 (&xin)[KB], const f32x4* __restrict__ w1, const float* b1,
+                    const float* aff_s, const float* aff_t, const f32x4* __restrict__ w2, int g4, WStream& s,
+                    const f32x4* __restrict__ next0, const f32x4* __restrict__ next1) {
   static_assert(HT % NB == 0, "hidden tiles must split evenly");
-#pragma unroll
-  for (int i = 0; i < KB; ++i) y[i] = splat4(0.f);
+  Act<AFF> act{b1, aff_s, aff_t, g4, {}, {}, {}};
 #pragma unroll 1
   for (int c = 0; c < HT / NB; ++c) {
     const int h0 = c * NB;
     f32x4 h[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) h[i] = ldg4(b1 + 16 * (h0 + i) + g4);
-    f32x4 as[AFF ? NB : 1], at[AFF ? NB : 1];           // folded-BN scale/shift: fetched now, used after GEMM1
-    if (AFF) {
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        as[i] = ldg4(aff_s + 16 * (h0 + i) + g4);
-        at[i] = ldg4(aff_t + 16 * (h0 + i) + g4);
-      }
-    }
-    // GEMM1 of this chunk, then GEMM2; the stream continues into the next chunk's GEMM1 (or `next`)
-    wave_gemm<KB>(h, xin, w1, HT, h0, wc, w2 + (size_t)(h0 * KB) * 64);
-    const f32x4* after = (c + 1 < HT / NB) ? w1 + (size_t)(0 * HT + h0 + NB) * 64 : next;
-    auto act = [&](int i, f32x4 v) -> f32x4 {
-      if (AFF) return swish4(v * as[AFF ? i : 0] + at[AFF ? i : 0]);
-      return swish4(v);
-    };
-    wave_gemm2(y, h, w2, h0, wc, after, act);
+    for (int i = 0; i < NB; ++i) h[i] = splat4(0.f);
+    auto own1 = [&](int t) { return w1 + (size_t)(t * HT + h0) * 64; };
+    auto own2 = [&](int t) { return w2 + (size_t)((h0 + t) * KB) * 64; };
+    // GEMM1: hidden tile 0 is complete after group 0 of the last batch and is activated two groups later
+    wave_gemm<0>(h, xin, s, own1, own2(0), own2(1), [&](auto T, auto GI) {
+      if constexpr (decltype(T)::value == KB - 1 && decltype(GI)::value == 1) act.fetch(h0);
+      if constexpr (decltype(T)::value == KB - 1 && decltype(GI)::value == 2) h[0] = act.apply(h[0]);
+    });
+    // GEMM2: hidden tile t+1 is activated inside the fenced MFMA region of tile t
+    const bool last = (c + 1 == HT / NB);
+    const f32x4* a0 = last ? next0 : w1 + (size_t)(0 * HT + h0 + NB) * 64;
+    const f32x4* a1 = last ? next1 : w1 + (size_t)(1 * HT + h0 + NB) * 64;
+    wave_gemm<1>(y, h, s, own2, a0, a1, [&](auto T, auto GI) {
+      constexpr int t = decltype(T)::value;
+      if constexpr (t + 1 < NB && decltype(GI)::value == 0) act.fetch(h0 + t + 1);
+      if constexpr (t + 1 < NB && decltype(GI)::value == 1) h[t + 1] = act.apply(h[t + 1]);
+    });
   }
 }
 
@@ -133,78 +188,102 @@ DEV WaveCtx wave_ctx(int M) {
   const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   c.tok = wid * 16 + c.t;
   c.live = c.tok < M;
-  c.row = (size_t)min(c.tok, M - 1) * D;
+  c.row = (size_t)min(c.tok, M - 1) * D;     // waves past the end recompute the last token and store nothing
   return c;
 }
 
+// LayerNorm with gamma / beta in LDS
+DEV void ln_lds(f32x4 (&xs)[KB], const float* ga, const float* be, int g4, float eps) {
+  float mean, rstd;
+  ln_stats<KB>(xs, eps, mean, rstd);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = (xs[kb] - splat4(mean)) * splat4(rstd) * lds4(ga, kb, g4) + lds4(be, kb, g4);
+}
+
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK_THREADS) void ff1_qkv_kernel(Ff1QkvArgs a) {
-  if ((size_t)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16 >= (size_t)a.M) return;
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void ff1_qkv_kernel(Ff1QkvArgs a) {
+  __shared__ __attribute__((aligned(16))) float p_ln1g[D], p_ln1b[D], p_b1[4 * D], p_b2[D], p_ln2g[D], p_ln2b[D], p_qb[3 * D];
   const WaveCtx c = wave_ctx(a.M);
-  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.ff_w1p) + c.lane;
-  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.ff_w2p) + c.lane;
-  const f32x4* wq = reinterpret_cast<const f32x4*>(a.qkv_wp) + c.lane;
+  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.ff_w1p);
+  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.ff_w2p);
+  const f32x4* wq = reinterpret_cast<const f32x4*>(a.qkv_wp);
   f32x4 xs[KB], y[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + c.row + 16 * kb + c.g4);
-  f32x4 wc[NB];
-  load_batch(wc, w1);                                   // first batch rides under the LayerNorm
-  ln_apply<KB>(xs, a.ff_ln_g, a.ff_ln_b, c.g4, a.eps);
-  wave_chain<4 * KB, false>(y, xs, w1, a.ff_b1, nullptr, nullptr, w2, c.g4, wc, wq);
+  WStream ws;
+  ws.lane16 = (unsigned)c.lane * 16u;
+  stream_begin(ws, w1, w1 + (size_t)(4 * KB) * 64);    // first two batches ride under the stash + LayerNorm
+  stash(p_ln1g, a.ff_ln_g, D); stash(p_ln1b, a.ff_ln_b, D); stash(p_b1, a.ff_b1, 4 * D); stash(p_b2, a.ff_b2, D);
+  stash(p_ln2g, a.att_ln_g, D); stash(p_ln2b, a.att_ln_b, D); stash(p_qb, a.qkv_b, 3 * D);
+  __syncthreads();
+  // the residual rides in the accumulator: y = x0/fc + b2 + W2 h, x1 = fc*y (fc = 0.5 in every reference
+  // config, so the scaling is exact); keeping x0 in registers across the chain would cost 36 VGPRs
+  const float inv_fc = 1.0f / a.fc;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) y[kb] = lds4(p_b2, kb, c.g4) + splat4(inv_fc) * xs[kb];
+  ln_lds(xs, p_ln1g, p_ln1b, c.g4, a.eps);
+  wave_chain<4 * KB, false>(y, xs, w1, p_b1, nullptr, nullptr, w2, c.g4, ws, wq, wq + (size_t)(3 * KB) * 64);
   // x1 = x0 + fc * (ffn + b2)
 #pragma unroll
-  for (int i = 0; i < KB; ++i)
-    xs[i] = ldg4(a.x0 + c.row + 16 * i + c.g4) + splat4(a.fc) * (y[i] + ldg4(a.ff_b2 + 16 * i + c.g4));
+  for (int i = 0; i < KB; ++i) xs[i] = splat4(a.fc) * y[i];
   if (c.live) {
 #pragma unroll
     for (int i = 0; i < KB; ++i) stg4(a.x1 + c.row + 16 * i + c.g4, xs[i]);
   }
   // qkv = LN(x1) Wqkv + b, query tiles scaled
-  ln_apply<KB>(xs, a.att_ln_g, a.att_ln_b, c.g4, a.eps);
+  ln_lds(xs, p_ln2g, p_ln2b, c.g4, a.eps);
   float* qrow = a.qkv + (size_t)min(c.tok, a.M - 1) * (3 * D);
-#pragma unroll 1
-  for (int q = 0; q < 3; ++q) {
+  static_for<0, 3>([&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    constexpr int qn = q < 2 ? q + 1 : 2;                 // after the last GEMM the stream idles on valid addresses
     f32x4 acc[KB];
 #pragma unroll
-    for (int i = 0; i < KB; ++i) acc[i] = ldg4(a.qkv_b + 16 * (q * KB + i) + c.g4);
-    wave_gemm<KB>(acc, xs, wq, 3 * KB, q * KB, wc, wq + (size_t)(min(q + 1, 2) * KB) * 64);
+    for (int i = 0; i < KB; ++i) acc[i] = lds4(p_qb, q * KB + i, c.g4);
+    wave_gemm<q & 1>(acc, xs, ws, [&](int t) { return wq + (size_t)(t * 3 * KB + q * KB) * 64; },
+                     wq + (size_t)(qn * KB) * 64, wq + (size_t)(3 * KB + qn * KB) * 64, NoHook());
     const float sc = (q == 0) ? a.qscale : 1.0f;
     if (c.live) {
 #pragma unroll
       for (int i = 0; i < KB; ++i) stg4(qrow + 16 * (q * KB + i) + c.g4, acc[i] * splat4(sc));
     }
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK_THREADS) void out_glu_kernel(OutGluArgs a) {
-  if ((size_t)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16 >= (size_t)a.M) return;
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void out_glu_kernel(OutGluArgs a) {
+  __shared__ __attribute__((aligned(16))) float p_ob[D], p_lng[D], p_lnb[D], p_pb[2 * D];
   const WaveCtx c = wave_ctx(a.M);
-  const f32x4* wo = reinterpret_cast<const f32x4*>(a.out_wp) + c.lane;
-  const f32x4* wg = reinterpret_cast<const f32x4*>(a.pw1_wp) + c.lane;
+  const f32x4* wo = reinterpret_cast<const f32x4*>(a.out_wp);
+  const f32x4* wg = reinterpret_cast<const f32x4*>(a.pw1_wp);
   f32x4 xs[KB], acc[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + c.row + 16 * kb + c.g4);
+  WStream ws;
+  ws.lane16 = (unsigned)c.lane * 16u;
+  stream_begin(ws, wo, wo + (size_t)KB * 64);
 #pragma unroll
-  for (int i = 0; i < KB; ++i) acc[i] = ldg4(a.out_b + 16 * i + c.g4);
-  f32x4 wc[NB];
-  load_batch(wc, wo);
-  wave_gemm<KB>(acc, xs, wo, KB, 0, wc, wg);
+  for (int kb = 0; kb < KB; ++kb) acc[kb] = ldg4(a.x1 + c.row + 16 * kb + c.g4);  // residual rides in the accumulator
+  stash(p_ob, a.out_b, D); stash(p_lng, a.cv_ln_g, D); stash(p_lnb, a.cv_ln_b, D); stash(p_pb, a.pw1_b, 2 * D);
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < KB; ++i) xs[i] = ldg4(a.x1 + c.row + 16 * i + c.g4) + acc[i];     // x2 = x1 + attention
+  for (int i = 0; i < KB; ++i) acc[i] += lds4(p_ob, i, c.g4);
+  wave_gemm<0>(acc, xs, ws, [&](int t) { return wo + (size_t)(t * KB) * 64; }, wg, wg + (size_t)(2 * KB) * 64, NoHook());
+#pragma unroll
+  for (int i = 0; i < KB; ++i) xs[i] = acc[i];                                      // x2 = x1 + attention
   if (c.live) {
 #pragma unroll
     for (int i = 0; i < KB; ++i) stg4(a.x2 + c.row + 16 * i + c.g4, xs[i]);
   }
-  ln_apply<KB>(xs, a.cv_ln_g, a.cv_ln_b, c.g4, a.eps);
+  ln_lds(xs, p_lng, p_lnb, c.g4, a.eps);
   f32x4 gate[KB];
 #pragma unroll
   for (int i = 0; i < KB; ++i) {
-    acc[i] = ldg4(a.pw1_b + 16 * i + c.g4);
-    gate[i] = ldg4(a.pw1_b + 16 * (KB + i) + c.g4);
+    acc[i] = lds4(p_pb, i, c.g4);
+    gate[i] = lds4(p_pb, KB + i, c.g4);
   }
-  wave_gemm<KB>(acc, xs, wg, 2 * KB, 0, wc, wg + (size_t)KB * 64);
-  wave_gemm<KB>(gate, xs, wg, 2 * KB, KB, wc, wg);
+  wave_gemm<1>(acc, xs, ws, [&](int t) { return wg + (size_t)(t * 2 * KB) * 64; }, wg + (size_t)KB * 64,
+               wg + (size_t)(3 * KB) * 64, NoHook());
+  wave_gemm<0>(gate, xs, ws, [&](int t) { return wg + (size_t)(t * 2 * KB + KB) * 64; }, wg, wg, NoHook());
   if (c.live) {
 #pragma unroll
     for (int i = 0; i < KB; ++i) {
@@ -216,29 +295,40 @@ __global__ __launch_bounds__(BLOCK_THREADS) void out_glu_kernel(OutGluArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK_THREADS) void tail_ff2_kernel(TailFf2Args a) {
-  if ((size_t)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16 >= (size_t)a.M) return;
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void tail_ff2_kernel(TailFf2Args a) {
+  __shared__ __attribute__((aligned(16))) float p_pcb[2 * D], p_bns[2 * D], p_bnt[2 * D], p_pw2b[D], p_lng[D], p_lnb[D], p_b1[4 * D],
+      p_b2[D], p_fg[D], p_fb[D];
   const WaveCtx c = wave_ctx(a.M);
-  const f32x4* wpc = reinterpret_cast<const f32x4*>(a.pc_w1p) + c.lane;
-  const f32x4* wp2 = reinterpret_cast<const f32x4*>(a.pw2_wp) + c.lane;
-  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.ff_w1p) + c.lane;
-  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.ff_w2p) + c.lane;
-  f32x4 xs[KB], y[KB], x3[KB];
+  const f32x4* wpc = reinterpret_cast<const f32x4*>(a.pc_w1p);
+  const f32x4* wp2 = reinterpret_cast<const f32x4*>(a.pw2_wp);
+  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.ff_w1p);
+  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.ff_w2p);
+  f32x4 xs[KB], y[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
-  f32x4 wc[NB];
-  load_batch(wc, wpc);
-  wave_chain<2 * KB, true>(y, xs, wpc, a.pc_b1, a.bn_s, a.bn_t, wp2, c.g4, wc, w1);
+  WStream ws;
+  ws.lane16 = (unsigned)c.lane * 16u;
+  stream_begin(ws, wpc, wpc + (size_t)(2 * KB) * 64);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + c.row + 16 * kb + c.g4);     // residuals ride in the accumulators
+  stash(p_pcb, a.pc_b1, 2 * D); stash(p_bns, a.bn_s, 2 * D); stash(p_bnt, a.bn_t, 2 * D); stash(p_pw2b, a.pw2_b, D);
+  stash(p_lng, a.ff_ln_g, D); stash(p_lnb, a.ff_ln_b, D); stash(p_b1, a.ff_b1, 4 * D); stash(p_b2, a.ff_b2, D);
+  stash(p_fg, a.ln_g, D); stash(p_fb, a.ln_b, D);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < KB; ++i) y[i] += lds4(p_pw2b, i, c.g4);
+  wave_chain<2 * KB, true>(y, xs, wpc, p_pcb, p_bns, p_bnt, wp2, c.g4, ws, w1, w1 + (size_t)(4 * KB) * 64);
+  const float inv_fc = 1.0f / a.fc;
 #pragma unroll
   for (int i = 0; i < KB; ++i) {
-    x3[i] = ldg4(a.x2 + c.row + 16 * i + c.g4) + (y[i] + ldg4(a.pw2_b + 16 * i + c.g4));   // conv module residual
-    xs[i] = x3[i];
+    xs[i] = y[i];                                                                    // x3 = x2 + conv module
+    y[i] = lds4(p_b2, i, c.g4) + splat4(inv_fc) * y[i];                              // x3/fc + b2 (+ W2 h): see ff1_qkv
   }
-  ln_apply<KB>(xs, a.ff_ln_g, a.ff_ln_b, c.g4, a.eps);
-  wave_chain<4 * KB, false>(y, xs, w1, a.ff_b1, nullptr, nullptr, w2, c.g4, wc, w1);
+  ln_lds(xs, p_lng, p_lnb, c.g4, a.eps);
+  wave_chain<4 * KB, false>(y, xs, w1, p_b1, nullptr, nullptr, w2, c.g4, ws, w1, w1);
 #pragma unroll
-  for (int i = 0; i < KB; ++i) y[i] = x3[i] + splat4(a.fc) * (y[i] + ldg4(a.ff_b2 + 16 * i + c.g4));
-  ln_apply<KB>(y, a.ln_g, a.ln_b, c.g4, a.eps);                                              // block-final LayerNorm
+  for (int i = 0; i < KB; ++i) y[i] = splat4(a.fc) * y[i];
+  ln_lds(y, p_fg, p_fb, c.g4, a.eps);                                                // block-final LayerNorm
   if (c.live) {
 #pragma unroll
     for (int i = 0; i < KB; ++i) stg4(a.y + c.row + 16 * i + c.g4, y[i]);

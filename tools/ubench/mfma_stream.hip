@@ -100,5 +100,11 @@ int main() {
   run<1, 9, 1, 2>("FFN-like: 18 steps, 1000 blocks", w, out, 1000, 18);
   run<1, 9, 2, 1>("FFN-like RT=2: 18 steps, 500 blk", w, out, 500, 18);
   run<0, 9, 1, 2>("mfma only: 18 steps, 1000 blocks", w, out, 1000, 18);
+  // the fused block kernels: 1000 waves (one per SIMD), ~3600 MFMAs each
+  run<0, 9, 1, 1>("fused-like: mfma only, 250 blk", w, out, 250, 100);
+  run<3, 9, 1, 1>("fused-like: interleaved, 250 blk", w, out, 250, 100);
+  run<1, 9, 1, 1>("fused-like: hard fences, 250 blk", w, out, 250, 100);
+  run<0, 9, 1, 1>("fused-like: mfma only, 256 blk", w, out, 256, 100);
+  run<0, 9, 1, 1>("tiny: 1 step, 250 blk", w, out, 250, 2);
   return 0;
 }
