@@ -605,6 +605,9 @@ static void launch_attention_t(const AttnArgs& a, hipStream_t s) {
 }
 
 int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
+  // short full-attention utterances (offline ConformerCTC): K / V^T staged in LDS (attention_lds.hip)
+  static const bool lds_env = [] { const char* v = getenv("MI355ASR_ATTN_LDS"); return v ? atoi(v) != 0 : true; }();
+  if (lds_env && attention_lds_applicable(HS, a)) return launch_attention_lds(HS, a, s);
   if (HS == 36) launch_attention_t<36>(a, s);
   else if (HS == 64) launch_attention_t<64>(a, s);
   else return -1;

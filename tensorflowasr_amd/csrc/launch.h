@@ -164,6 +164,8 @@ int launch_gather(const GatherArgs& a, hipStream_t s);
 int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s);
 int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s);
 int launch_attention(int HS, const AttnArgs& a, hipStream_t s);
+bool attention_lds_applicable(int HS, const AttnArgs& a);
+int launch_attention_lds(int HS, const AttnArgs& a, hipStream_t s);
 int launch_dwconv(int K, const DwArgs& a, hipStream_t s);
 int launch_stft(const StftArgs& a, hipStream_t s);
 int launch_utt_max(const UttMaxArgs& a, int B, hipStream_t s);
