@@ -3,8 +3,10 @@
 // q k^T with q pre-scaled by 1/sqrt(hs), softmax over keys, no mask, no positional term), called from
 // conformer_blocks.py:164-170.
 //
-// One workgroup = 4 waves = 4 query tiles (64 queries) of one (utterance, head).  K (row-major) and V (transposed)
-// of that head are staged in LDS once per workgroup -- the four waves read every K/V fragment from there instead
+// One workgroup = 8 waves = 8 query tiles (128 queries) of one (utterance, head); two workgroups share a CU
+// (2 x 74 KB of LDS), i.e. 4 waves per SIMD, so that one wave's staging / softmax / LDS latency is covered by
+// the other waves' MFMAs.  K (row-major) and V (transposed)
+// of that head are staged in LDS once per workgroup -- the eight waves read every K/V fragment from there instead
 // of each streaming them from L2 with 15 vector-memory instructions per key tile (attention_kernel in blocks.hip,
 // which stays for band attention, T > 256 and head size 64).  Per wave:
 //   S^T[key][query] = K Q^T        9 MFMAs per 16-key tile (hs = 36 = 9 k-steps of 4), scores of all <=256 keys
@@ -19,9 +21,11 @@ namespace {
 
 constexpr int TP = 256;        // padded key count held in LDS
 constexpr int VS = TP + 4;     // row stride of V^T (floats): 16-byte aligned rows, 2-way bank conflicts at most
+constexpr int AW = 8;          // waves (query tiles) per workgroup
+constexpr int ATH = AW * 64;
 
 template <int HS>
-__global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_lds_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
   constexpr int FB = HS / 16;          // full 16-wide feature blocks
   constexpr int TS = (HS % 16) / 4;    // tail k-steps (feature = 16*FB + 4*ts + g)
   constexpr int OT = (HS + 15) / 16;   // output feature tiles
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_lds_kernel(AttnArg
 
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, g4 = g * 4, c = lane & 15;
-  const int qt = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int qt = blockIdx.x * AW + (threadIdx.x >> 6);
   const int T = a.T;
   const int h = blockIdx.y, b = blockIdx.z;
   const int ld = a.ld, D = a.D;
@@ -51,12 +55,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_lds_kernel(AttnArg
 
   // ---- stage K and V^T of this (utterance, head); rows past T are zero
   // (all loads first, then the LDS writes: a load -> write loop would expose one L2 round trip per iteration)
-  static_assert((TP * C4) % BLOCK_THREADS == 0, "stage loop must tile evenly");
-  constexpr int NIT = TP * C4 / BLOCK_THREADS;
+  constexpr int NIT = (TP * C4 + ATH - 1) / ATH;
   f32x4 kv[NIT], vv[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int idx = threadIdx.x + it * BLOCK_THREADS;
+    const int idx = min((int)threadIdx.x + it * ATH, TP * C4 - 1);
     const int key = idx / C4, ch = idx - key * C4;
     const float* row = base + (size_t)min(key, T - 1) * ld + 4 * ch;
     kv[it] = ldg4(row + D);
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_lds_kernel(AttnArg
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int idx = threadIdx.x + it * BLOCK_THREADS;
+    const int idx = min((int)threadIdx.x + it * ATH, TP * C4 - 1);    // tail threads rewrite the last chunk
     const int key = idx / C4, ch = idx - key * C4;
     const bool ok = key < T;
     const f32x4 k = ok ? kv[it] : splat4(0.f), v = ok ? vv[it] : splat4(0.f);
@@ -180,7 +183,7 @@ bool attention_lds_applicable(int HS, const AttnArgs& a) { return HS == 36 && a.
 int launch_attention_lds(int HS, const AttnArgs& a, hipStream_t s) {
   if (!attention_lds_applicable(HS, a)) return -1;
   const int qtiles = (a.T + 15) / 16;
-  dim3 grid((qtiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.H, a.B);
-  hipLaunchKernelGGL((attention_lds_kernel<36>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  dim3 grid((qtiles + AW - 1) / AW, a.H, a.B);
+  hipLaunchKernelGGL((attention_lds_kernel<36>), grid, dim3(ATH), 0, s, a);
   return 0;
 }
