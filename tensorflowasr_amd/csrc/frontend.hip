@@ -9,6 +9,7 @@
 //   collapse_kernel  CTC greedy merge-repeated / drop-blank / pad -1       (test_asr.py:196-200,
 //                    Inference/CppInference/onnx/src/core/ctc_greedy_decoder.h:22-43)
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "launch.h"
@@ -292,6 +293,8 @@ static void launch_subconv_t(const SubConvArgs& a, hipStream_t s) {
 }
 
 int launch_subconv(int D, const SubConvArgs& a, hipStream_t s) {
+  static const bool v1 = [] { const char* v = getenv("MI355ASR_SUBCONV_V1"); return v && atoi(v) != 0; }();
+  if (D == 144 && !v1) return launch_subconv144(a, s);    // subconv.hip
   if (D == 144) launch_subconv_t<144>(a, s);
   else if (D == 256) launch_subconv_t<256>(a, s);
   else return -1;

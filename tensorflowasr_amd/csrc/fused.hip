@@ -21,10 +21,9 @@
 //     the 512-register budget it parks them in AGPRs and moves them back and forth around every MFMA group.
 // Reference semantics: asr/models/conformer_blocks.py:126-134 (FFModule), :164-170 + multihead_attention.py:151-188
 // (MHSA), :209-219 (ConvModule), :259-265 (block).
-#include <type_traits>
-
 #include "common.h"
 #include "launch.h"
+#include "wstream.h"
 
 namespace {
 
@@ -32,88 +31,12 @@ constexpr int D = 144;
 constexpr int KB = D / 16;   // 9
 constexpr int NB = KB;       // fragments per batch (dmodel 144: every batch on the path is 9 fragments)
 
-// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N)
-template <int I, int N, class F>
-DEV void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>());
-    static_for<I + 1, N>(f);
-  }
-}
-
-// ---- parameter stash --------------------------------------------------------------------------------------
-DEV void stash(float* dst, const float* __restrict__ src, int n) {
-  for (int i = threadIdx.x; i < n; i += BLOCK_THREADS) dst[i] = src[i];
-}
-// this lane's float4 of tile `tile` of a stashed vector (lanes of one 16-lane group read the same address)
-DEV f32x4 lds4(const float* v, int tile, int g4) { return *reinterpret_cast<const f32x4*>(v + 16 * tile + g4); }
-
-// ---- weight stream ----------------------------------------------------------------------------------------
-// The weight stream of a kernel is one sequence of 9-fragment batches (one k-block x 9 column tiles) that runs
-// across GEMM and stage boundaries.  Two register buffers wb[0], wb[1] hold it: while batch t is consumed from
-// wb[CUR] (five fenced groups of 2+2+2+2+1 tiles), the slots a group has just finished with are refilled with the
-// same fragments of batch t+2, and wb[CUR^1] holds batch t+1.  A fragment is therefore requested ~16 fragments
-// = 64 MFMAs = ~2000 cycles before its first use, with no more registers than plain double buffering; fetching
-// only one batch ahead (~1100 cycles) left 17 % of the wave's cycles in s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES,
-// profiles/r01c_pmc_probe.csv) because one wave per SIMD has nothing else to run while it waits on L2.
-// Invariant on entry to batch t with CUR: wb[CUR] = batch t (all 9 issued), wb[CUR^1] = batch t+1 slots 0..7.
-// Addresses are (uniform batch pointer in SGPRs) + (lane * 16 bytes in one VGPR): no per-load vector address math.
-struct WStream {
-  f32x4 wb[2][NB];
-  unsigned lane16;   // lane * 16 bytes
-};
-DEV f32x4 ldw(const f32x4* __restrict__ batch, int frag, unsigned lane16) {
-  // pin the (uniform) fragment address to an SGPR pair so that the load is `global_load v, v_lane16, s[..]`;
-  // left alone, hipcc folds the lane offset into a 64-bit VGPR base and spends two VALU adds per fragment
-  unsigned long long p = reinterpret_cast<unsigned long long>(batch + frag * 64);
-  asm("" : "+s"(p));     // opaque SGPR pair: keeps LLVM from re-associating the lane offset into the base
-  typedef const __attribute__((address_space(1))) char* gptr;
-  gptr sp = (gptr)p;
-  return *(const __attribute__((address_space(1))) f32x4*)(sp + lane16);
-}
-DEV void stream_begin(WStream& s, const f32x4* __restrict__ b0, const f32x4* __restrict__ b1) {
-#pragma unroll
-  for (int i = 0; i < NB; ++i) s.wb[0][i] = ldw(b0, i, s.lane16);
-#pragma unroll
-  for (int i = 0; i < NB - 1; ++i) s.wb[1][i] = ldw(b1, i, s.lane16);
-}
-
-// acc[i] += wb[CUR][i]^T * x  (one k-block, 9 column tiles); p1 / p2 = addresses of batches t+1 / t+2.
-// hook(gi) runs inside fence group gi: a place for VALU / LDS work that should issue under the MFMAs.
-template <int CUR, class HOOK>
-DEV void batch_step(f32x4 (&acc)[NB], const f32x4 x, WStream& s, unsigned l16, const f32x4* __restrict__ p1,
-                    const f32x4* __restrict__ p2, HOOK&& hook) {
-  static_for<0, 5>([&](auto GI) {
-    constexpr int gi = decltype(GI)::value;
-    if constexpr (gi == 0) {
-      s.wb[CUR ^ 1][NB - 1] = ldw(p1, NB - 1, l16);
-    } else {
-      s.wb[CUR][2 * gi - 2] = ldw(p2, 2 * gi - 2, l16);
-      s.wb[CUR][2 * gi - 1] = ldw(p2, 2 * gi - 1, l16);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 2 * gi; i < 2 * gi + 2 && i < NB; ++i) acc[i] = mfma4(s.wb[CUR][i][j], x[j], acc[i]);
-    hook(GI);
-    __builtin_amdgcn_sched_barrier(0);
-  });
-}
-
-struct NoHook {
-  template <class T, class G> DEV void operator()(T, G) const {}
-};
-
 // acc[i] += W[t]^T * x[t] for the 9 batches own(0..8) of one GEMM; next0 / next1 = the two batches that follow it
 // in the kernel's stream.  Enters with CUR, leaves with CUR^1 (9 is odd).  hook(T, GI) as in batch_step.
 template <int CUR, class OWN, class HOOK>
-DEV void wave_gemm(f32x4 (&acc)[NB], const f32x4 (&x)[KB], WStream& s, OWN&& own, const f32x4* __restrict__ next0,
+DEV void wave_gemm(f32x4 (&acc)[NB], const f32x4 (&x)[KB], WStream<NB>& s, OWN&& own, const f32x4* __restrict__ next0,
                    const f32x4* __restrict__ next1, HOOK&& hook) {
-  // the 32-bit lane offset is re-materialised (opaquely) in the block that uses it: the `saddr + zext(voffset)`
-  // addressing mode is only selected when the zero-extension is visible in the same basic block
-  unsigned l16 = s.lane16;
-  asm volatile("" : "+v"(l16));
+  const unsigned l16 = fresh_lane16(s.lane16);
   static_for<0, KB>([&](auto T) {
     constexpr int t = decltype(T)::value;
     const f32x4* p1 = (t + 1 < KB) ? own(t + 1) : next0;
@@ -146,7 +69,7 @@ struct Act {
 // the k-block); next0 / next1 = the two batches after the chain.  Enters and leaves with CUR = 0.
 template <int HT, bool AFF>
 DEV void wave_chain(f32x4 (&y)[KB], const f32x4 (&xin)[KB], const f32x4* __restrict__ w1, const float* b1,
-                    const float* aff_s, const float* aff_t, const f32x4* __restrict__ w2, int g4, WStream& s,
+                    const float* aff_s, const float* aff_t, const f32x4* __restrict__ w2, int g4, WStream<NB>& s,
                     const f32x4* __restrict__ next0, const f32x4* __restrict__ next1) {
   static_assert(HT % NB == 0, "hidden tiles must split evenly");
   Act<AFF> act{b1, aff_s, aff_t, g4, {}, {}, {}};
@@ -210,7 +133,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void ff1_qkv_kernel(Ff1QkvArgs a)
   f32x4 xs[KB], y[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + c.row + 16 * kb + c.g4);
-  WStream ws;
+  WStream<NB> ws;
   ws.lane16 = (unsigned)c.lane * 16u;
   stream_begin(ws, w1, w1 + (size_t)(4 * KB) * 64);    // first two batches ride under the stash + LayerNorm
   stash(p_ln1g, a.ff_ln_g, D); stash(p_ln1b, a.ff_ln_b, D); stash(p_b1, a.ff_b1, 4 * D); stash(p_b2, a.ff_b2, D);
@@ -258,7 +181,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void out_glu_kernel(OutGluArgs a)
   f32x4 xs[KB], acc[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + c.row + 16 * kb + c.g4);
-  WStream ws;
+  WStream<NB> ws;
   ws.lane16 = (unsigned)c.lane * 16u;
   stream_begin(ws, wo, wo + (size_t)KB * 64);
 #pragma unroll
@@ -306,7 +229,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void tail_ff2_kernel(TailFf2Args 
   f32x4 xs[KB], y[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
-  WStream ws;
+  WStream<NB> ws;
   ws.lane16 = (unsigned)c.lane * 16u;
   stream_begin(ws, wpc, wpc + (size_t)(2 * KB) * 64);
 #pragma unroll

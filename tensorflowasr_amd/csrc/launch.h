@@ -171,5 +171,6 @@ int launch_stft(const StftArgs& a, hipStream_t s);
 int launch_utt_max(const UttMaxArgs& a, int B, hipStream_t s);
 int launch_mel(const MelArgs& a, hipStream_t s);
 int launch_subconv(int D, const SubConvArgs& a, hipStream_t s);
+int launch_subconv144(const SubConvArgs& a, hipStream_t s);
 int launch_stream_gemm(int D, const StreamGemmArgs& a, hipStream_t s);
 int launch_collapse(const CollapseArgs& a, hipStream_t s);
