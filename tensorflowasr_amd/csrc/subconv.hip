@@ -27,62 +27,63 @@ struct SubCtx {
   const float *p_w1, *p_b1;   // LDS
 };
 
-// the nine k-blocks (kt, kf) of channel block cb.  Enters with CUR0, leaves with CUR0 ^ 1.
+struct SubState {
+  f32x4 xf;          // conv1 operand of the next k-block to be multiplied
+  f32x4 tw[2][2];    // conv1 taps (LDS -> registers) of the next hook
+};
+
+DEV f32x4 rd_tap(const float* w1c, int tp) {
+  int off = tp * D;
+  asm volatile("" : "+v"(off));          // opaque: otherwise the reads are CSE'd across q and pinned in 36 VGPRs
+  return *reinterpret_cast<const f32x4*>(w1c + off);
+}
+// scalar FMAs on purpose: a float4 * splat is lowered to v_pk_fma_f32 with the window value duplicated into a
+// register pair, and hipcc keeps all 49 duplicated pairs live (98 VGPRs -> scratch spills)
+DEV void tap(f32x4& v, const SubCtx& cx, int q, int tp, const f32x4 w) {
+  const int kt = q / 3, kf = q % 3, i = tp / 3, j = tp % 3;
+  float m = cx.win[2 * kt + i][2 * kf + j];
+  asm volatile("" : "+v"(m));
+  v.x = __builtin_fmaf(m, w.x, v.x); v.y = __builtin_fmaf(m, w.y, v.y);
+  v.z = __builtin_fmaf(m, w.z, v.z); v.w = __builtin_fmaf(m, w.w, v.w);
+}
+DEV f32x4 finish(f32x4 v, const SubCtx& cx, int q) {
+  const bool ok = (cx.valid >> q) & 1u;            // conv2's zero padding of the conv1 activation
+  v.x = ok ? fmaxf(v.x, 0.f) : 0.f; v.y = ok ? fmaxf(v.y, 0.f) : 0.f;
+  v.z = ok ? fmaxf(v.z, 0.f) : 0.f; v.w = ok ? fmaxf(v.w, 0.f) : 0.f;
+  return v;
+}
+
+// The nine k-blocks (kt, kf) of channel block cb.  Enters with buffer parity CUR0 (weights and taps), leaves with
+// CUR0 ^ 1.  The conv1 operand of the k-block after the current one -- (cb, q+1), or (cb+1, 0) during q = 8 -- is
+// evaluated in the hooks of the current one: taps two at a time, read from LDS (broadcast reads, 4 addresses per
+// wave) one fence group before the FMAs that use them.
 template <int CUR0>
-DEV void channel_block(f32x4 (&acc)[NB], WStream<NB>& ws, unsigned l16, const SubCtx& cx, int cb,
+DEV void channel_block(f32x4 (&acc)[NB], WStream<NB>& ws, SubState& st, unsigned l16, const SubCtx& cx, int cb,
                        const f32x4* __restrict__ w2) {
-  // conv1 taps of this channel block are read from LDS (broadcast reads, 4 addresses per wave) one fence group
-  // before the FMAs that use them; holding all nine float4 in registers would push the kernel past 256 VGPRs
+  const int cbn = min(cb + 1, KB - 1);
   const float* w1c = cx.p_w1 + 16 * cb + cx.g4;
-  const f32x4 b1v = lds4(cx.p_b1, cb, cx.g4);
-  auto rd = [&](int tp) -> f32x4 {
-    int off = tp * D;
-    asm volatile("" : "+v"(off));        // opaque: otherwise the reads are CSE'd across q and pinned in 36 VGPRs
-    return *reinterpret_cast<const f32x4*>(w1c + off);
-  };
-  // scalar FMAs on purpose: a float4 * splat is lowered to v_pk_fma_f32 with the window value duplicated into a
-  // register pair, and hipcc keeps all 49 duplicated pairs live (98 VGPRs -> scratch spills)
-  auto tap = [&](f32x4& v, int q, int tp, const f32x4 w) {
-    const int kt = q / 3, kf = q % 3, i = tp / 3, j = tp % 3;
-    float m = cx.win[2 * kt + i][2 * kf + j];
-    asm volatile("" : "+v"(m));
-    v.x = __builtin_fmaf(m, w.x, v.x); v.y = __builtin_fmaf(m, w.y, v.y);
-    v.z = __builtin_fmaf(m, w.z, v.z); v.w = __builtin_fmaf(m, w.w, v.w);
-  };
-  auto finish = [&](f32x4 v, int q) -> f32x4 {
-    const bool ok = (cx.valid >> q) & 1u;          // conv2's zero padding of the conv1 activation
-    v.x = ok ? fmaxf(v.x, 0.f) : 0.f; v.y = ok ? fmaxf(v.y, 0.f) : 0.f;
-    v.z = ok ? fmaxf(v.z, 0.f) : 0.f; v.w = ok ? fmaxf(v.w, 0.f) : 0.f;
-    return v;
-  };
-  // operand of k-block 0: evaluated up front (once per channel block)
-  f32x4 xf = b1v;
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp) tap(xf, 0, tp, rd(tp));
-  xf = finish(xf, 0);
-  f32x4 tw[2][2];
-  tw[0][0] = rd(0); tw[0][1] = rd(1);                              // taps of the first hook
+  const float* w1n = cx.p_w1 + 16 * cbn + cx.g4;
+  const f32x4 b1v = lds4(cx.p_b1, cb, cx.g4), b1n = lds4(cx.p_b1, cbn, cx.g4);
   static_for<0, 9>([&](auto Q) {
     constexpr int q = decltype(Q)::value;
+    constexpr int qn = (q + 1) % 9;                                // k-block whose operand is being prepared
     const int sidx = cb * 9 + q;                                   // batch index in the conv2 weight stream
     const f32x4* p1 = w2 + (size_t)min(sidx + 1, 9 * KB - 1) * (KB * 64);
     const f32x4* p2 = w2 + (size_t)min(sidx + 2, 9 * KB - 1) * (KB * 64);
-    f32x4 xn = b1v;
-    batch_step<(CUR0 + q) & 1>(acc, xf, ws, l16, p1, p2, [&](auto GI) {
+    f32x4 xn = (q < 8) ? b1v : b1n;
+    batch_step<(CUR0 + q) & 1>(acc, st.xf, ws, l16, p1, p2, [&](auto GI) {
       constexpr int gi = decltype(GI)::value;
-      if constexpr (q < 8) {                                       // conv1 of k-block q+1 under the MFMAs of q
-        constexpr int h = q * 5 + gi;                              // hook counter: taps sit in tw[h & 1]
-        tap(xn, q + 1, 2 * gi, tw[h & 1][0]);
-        if constexpr (gi < 4) tap(xn, q + 1, 2 * gi + 1, tw[h & 1][1]);
-        if constexpr (gi == 4) xn = finish(xn, q + 1);
-        if constexpr (h + 1 < 40) {                                // fetch the taps of the next hook
-          constexpr int gn = (gi + 1) % 5;
-          tw[(h + 1) & 1][0] = rd(2 * gn);
-          if constexpr (gn < 4) tw[(h + 1) & 1][1] = rd(2 * gn + 1);
-        }
-      }
+      constexpr int h = CUR0 + q * 5 + gi;                         // hook counter: its taps sit in tw[h & 1]
+      tap(xn, cx, qn, 2 * gi, st.tw[h & 1][0]);
+      if constexpr (gi < 4) tap(xn, cx, qn, 2 * gi + 1, st.tw[h & 1][1]);
+      if constexpr (gi == 4) xn = finish(xn, cx, qn);
+      // fetch the taps of the next hook: same target while gi < 4, else the k-block after it
+      constexpr int gn = (gi + 1) % 5;
+      const float* wsrc = (q < 7 || (q == 7 && gi < 4)) ? w1c : w1n;
+      st.tw[(h + 1) & 1][0] = rd_tap(wsrc, 2 * gn);
+      if constexpr (gn < 4) st.tw[(h + 1) & 1][1] = rd_tap(wsrc, 2 * gn + 1);
     });
-    xf = xn;
+    st.xf = xn;
   });
 }
 
@@ -134,16 +135,27 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv144_kernel(SubConvArg
   f32x4 acc[NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n) acc[n] = lds4(p_b2, n, g4);
+  // operand of the very first k-block (channel block 0, tap position 0) and the taps of the first hook
+  SubState st;
+  {
+    const float* w1c = p_w1 + g4;
+    f32x4 v = lds4(p_b1, 0, g4);
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) tap(v, cx, 0, tp, rd_tap(w1c, tp));
+    st.xf = finish(v, cx, 0);
+    st.tw[0][0] = rd_tap(w1c, 0);
+    st.tw[0][1] = rd_tap(w1c, 1);
+  }
   // nine channel blocks of nine batches each; the buffer parity repeats every two blocks
 #pragma unroll 1
   for (int cb = 0; cb + 1 < KB; cb += 2) {
     const unsigned l16 = fresh_lane16(ws.lane16);
-    channel_block<0>(acc, ws, l16, cx, cb, w2);
-    channel_block<1>(acc, ws, l16, cx, cb + 1, w2);
+    channel_block<0>(acc, ws, st, l16, cx, cb, w2);
+    channel_block<1>(acc, ws, st, l16, cx, cb + 1, w2);
   }
   {
     const unsigned l16 = fresh_lane16(ws.lane16);
-    channel_block<0>(acc, ws, l16, cx, KB - 1, w2);
+    channel_block<0>(acc, ws, st, l16, cx, KB - 1, w2);
   }
   if (pos < P) {
     float* orow = a.out + (size_t)pos * D;

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the per-round rocprofv3 evidence on an MI355X box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh <tag>      e.g. r01c
+# 1 kernel-trace/stats pass + 3 separate PMC passes (never combined with other trace domains), then the summary
+# (profiles/<tag>_summary.md, profiles/<tag>_kernel_stats.csv, profiles/pmc_traffic.json) written into
+# gpurun_out/profiles_<tag>/ for copying into profiles/.
+set -u
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events"
+O=$R/gpurun_out
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -- $BENCH > $O/prof_${TAG}_stats.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_${TAG}_fetch -- $BENCH > $O/prof_${TAG}_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_${TAG}_write -- $BENCH > $O/prof_${TAG}_write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_${TAG}_mfma -- $BENCH > $O/prof_${TAG}_mfma.log 2>&1
+cd $R
+python tools/summarize_rocprof.py $TAG $O/prof_${TAG}_stats $O/prof_${TAG}_fetch $O/prof_${TAG}_write $O/prof_${TAG}_mfma > $O/prof_${TAG}_summary.log 2>&1
+mkdir -p $O/profiles_${TAG}
+cp profiles/${TAG}_summary.md profiles/${TAG}_kernel_stats.csv profiles/pmc_traffic.json $O/profiles_${TAG}/
+python bench.py > $O/profiles_${TAG}/${TAG}_bench_n1.json 2> $O/prof_${TAG}_bench.log
+tail -30 profiles/${TAG}_summary.md
+tail -1 $O/profiles_${TAG}/${TAG}_bench_n1.json
