@@ -193,6 +193,27 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav_dev, int32_t B, i
                            const mi355asr_chunk_outputs* outs, int32_t* n_picked_host, int32_t* t_pick_host,
                            void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ---- Translator: phoneme ids + encoder output -> text logits -------------------------------
+ * replaces: Translator(inp_classes, tar_classes, dmodel, num_blocks, head_size, num_heads, kernel_size, dropout,
+ * fc_factor) (test_asr.py:76-84; conformer_blocks.py:505-548): Embedding(inp_classes -> d) -> num_blocks x RBlock
+ * (FFModule -> cross-attention with q = LN(x + sinusoid PE), k = v = encoder output -> ConvModule -> FFModule -> LN)
+ * -> Dense(d -> tar_classes).  Weight names: inp_embedding/embeddings, decoder_conformer_block_<i>/... (as the
+ * ConformerBlock), fully_connected/{kernel,bias}. */
+typedef struct {
+  int32_t dmodel, num_blocks, head_size, num_heads, kernel_size;
+  float   fc_factor;
+  int32_t inp_classes, tar_classes;
+} mi355asr_translator_config;
+int mi355asr_translator_create(const mi355asr_translator_config* cfg, mi355asr_model** out);
+/* U = token positions per utterance (padded CTC output), T = encoder frames per utterance */
+int mi355asr_translator_workspace_bytes(const mi355asr_model* m, int32_t B, int32_t U, int32_t T, size_t* bytes);
+/* replaces: translator([ctc_decode, enc_outputs], training=False) and tf.argmax(., -1) (test_asr.py:202-203,
+ * streaming :149-150).  ids_dev i32 [B, U] (values clamped to [0, inp_classes)), enc_dev f32 [B, T, d];
+ * logits_dev f32 [B, U, tar_classes] or NULL, argmax_dev i32 [B, U] or NULL (first maximum wins). */
+int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids_dev, const float* enc_dev, int32_t B,
+                                int32_t U, int32_t T, float* logits_dev, int32_t* argmax_dev, void* ws_dev,
+                                size_t ws_bytes, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around each kernel (off by default).
  * profile_read waits for the recorded events, then returns accumulated milliseconds and launch counts per
  * kernel category below (arrays of at least MI355ASR_NUM_KERNELS); reset != 0 clears the accumulators.

@@ -31,6 +31,12 @@ class ChunkConfig(ctypes.Structure):
             "decoder_num_classes", "decoder_num_blocks", "decoder_win_front", "decoder_win_back")]
 
 
+class TranslatorConfig(ctypes.Structure):
+    """mirror of `mi355asr_translator_config`."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("dmodel", "num_blocks", "head_size", "num_heads", "kernel_size")] + \
+        [("fc_factor", ctypes.c_float), ("inp_classes", ctypes.c_int32), ("tar_classes", ctypes.c_int32)]
+
+
 class ChunkOutputs(ctypes.Structure):
     """mirror of `mi355asr_chunk_outputs`."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("front_out", "enc_out", "picker_logits", "picker_hidden", "picked",
@@ -73,6 +79,9 @@ SIGNATURES = {
     "mi355asr_chunk_out_frames": (ctypes.c_int, [_P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "mi355asr_chunk_workspace_bytes": (ctypes.c_int, [_P, _I, _I, ctypes.POINTER(_SZ)]),
     "mi355asr_chunk_predict": (ctypes.c_int, [_P, _P, _I, _I, ctypes.POINTER(ChunkOutputs), _P, _P, _P, _SZ, _P]),
+    "mi355asr_translator_create": (ctypes.c_int, [ctypes.POINTER(TranslatorConfig), ctypes.POINTER(_P)]),
+    "mi355asr_translator_workspace_bytes": (ctypes.c_int, [_P, _I, _I, _I, ctypes.POINTER(_SZ)]),
+    "mi355asr_translator_forward": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "mi355asr_profile_enable": (ctypes.c_int, [_P, _I]),
     "mi355asr_profile_read": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), _I, _I]),
 }

@@ -64,6 +64,8 @@ struct BlockDev {
   const float *ff_ln_g[2], *ff_ln_b[2], *ff_w1p[2], *ff_b1[2], *ff_w2p[2], *ff_b2[2];
   // mhsa_module
   const float *att_ln_g, *att_ln_b, *qkv_wp, *qkv_b, *out_wp, *out_b;
+  // RBlock cross-attention (Translator): query kernel [d,d] and [key | value] kernels [d,2d], packed separately
+  const float *xq_wp = nullptr, *xkv_wp = nullptr;
   // conv_module
   const float *cv_ln_g, *cv_ln_b, *pw1_wp, *pw1_b, *dw_w, *pc_w1p, *pc_b1, *bn_s, *bn_t, *pw2_wp, *pw2_b;
   // block-final LayerNorm
@@ -112,6 +114,11 @@ struct mi355asr_model {
   // ChunkConformer (mi355asr_chunk_create): front + encoder / phone picker / context helper / text decoder stacks
   bool is_chunk = false;
   mi355asr_chunk_config ccfg;
+  // Translator (mi355asr_translator_create): Embedding + RBlock stack + Dense head
+  bool is_translator = false;
+  mi355asr_translator_config tcfg;
+  StackDev t_stack;
+  const float *t_emb = nullptr, *t_pe = nullptr;   // [inp_classes, d], [kMaxTokens, d]
   StackDev c_enc, c_picker, c_helper, c_decoder;
   // optional per-kernel timing with HIP events on the launch stream (mi355asr_profile_*)
   mutable bool prof = false;
@@ -285,6 +292,8 @@ FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vecto
 struct BlockOff {
   size_t ff_ln_g[2], ff_ln_b[2], ff_w1p[2], ff_b1[2], ff_w2p[2], ff_b2[2];
   size_t att_ln_g, att_ln_b, qkv_wp, qkv_b, out_wp, out_b;
+  size_t xq_wp = 0, xkv_wp = 0;
+  bool cross = false;
   size_t cv_ln_g, cv_ln_b, pw1_wp, pw1_b, dw_w, pc_w1p, pc_b1, bn_s, bn_t, pw2_wp, pw2_b;
   size_t ln_g, ln_b;
 };
@@ -375,6 +384,7 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
 
 BlockDev resolve(const BlockOff& o, const float* base) {
   BlockDev b;
+  if (o.cross) { b.xq_wp = base + o.xq_wp; b.xkv_wp = base + o.xkv_wp; }
   for (int i = 0; i < 2; ++i) {
     b.ff_ln_g[i] = base + o.ff_ln_g[i];
     b.ff_ln_b[i] = base + o.ff_ln_b[i];
@@ -464,14 +474,23 @@ struct Scratch {
 // One ConformerBlock (conformer_blocks.py:259-265).  Input in sc.xa, output to `out` (or sc.xa if null).
 // Input in sc.xa; output to `out`, or (out == nullptr) left in sc.xa -- the fused path ping-pongs xa/xb by swapping
 // the two pointers in `sc` instead of copying.
+// RBlock of the Translator (conformer_blocks.py:455-463, 496-503): the attention is a cross-attention with
+// q = LN(x + PE) and k = v = the encoder output (T_enc frames per utterance), everything else is a ConformerBlock.
+struct CrossAttn {
+  const float* enc;   // [B, T_enc, d]
+  int T_enc;
+  float* kv;          // scratch [B * T_enc, 2d]
+  const float* pe;    // [>= T, d]
+};
+
 int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int B, int T,
-              float* out, hipStream_t s) {
+              float* out, hipStream_t s, const CrossAttn* cross = nullptr) {
   const int d = m->cfg.dmodel, H = m->cfg.num_heads, hs = m->cfg.head_size;
   const int ksz = bo.ksz;
   const float fc = bo.fc;
   const int M = B * T;
   static const bool fused_env = [] { const char* v = getenv("MI355ASR_FUSED"); return v ? atoi(v) != 0 : true; }();
-  if (d == 144 && fused_env) {
+  if (d == 144 && fused_env && !cross) {
     // token-local runs of layers in one launch each (fused.hip); attention and the depthwise conv mix tokens
     const float qscale = 1.0f / std::sqrt((float)hs);
     Ff1QkvArgs k1{};
@@ -482,7 +501,8 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M;
     { PROF(MI355ASR_K_FF1_QKV); LAUNCH_TRY(launch_ff1_qkv(k1, s), "ff_module_1 + qkv"); }
     AttnArgs at{};
-    at.qkv = sc.qkv; at.ctx = sc.ctx; at.B = B; at.T = T; at.H = H; at.D = d; at.ld = 3 * d;
+    at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ctx = sc.ctx;
+  at.B = B; at.Tq = T; at.Tk = T; at.H = H; at.D = d; at.ldq = 3 * d; at.ldk = 3 * d;
     at.win_front = bo.win_front; at.win_back = bo.win_back;
     { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
     OutGluArgs k2{};
@@ -511,15 +531,32 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
   f1.w1p = w.ff_w1p[0]; f1.b1 = w.ff_b1[0]; f1.w2p = w.ff_w2p[0]; f1.b2 = w.ff_b2[0];
   f1.scale = fc; f1.eps = kLnEps; f1.M = M;
   { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_chain2(d, 0, f1, s), "ff_module_1"); }
-  // mhsa: qkv = LN(xb) Wqkv (q pre-scaled)
-  GemmArgs q{};
-  q.x = sc.xb; q.y = sc.qkv; q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.wp = w.qkv_wp; q.bias = w.qkv_b;
-  q.M = M; q.NT = 3 * d / 16; q.ldy = 3 * d; q.n_valid = 3 * d; q.eps = kLnEps;
-  q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
-  { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm_rows(d, EPI_QKV, true, q, s), "qkv projection"); }
   AttnArgs at{};
-  at.qkv = sc.qkv; at.ctx = sc.ctx; at.B = B; at.T = T; at.H = H; at.D = d; at.ld = 3 * d;
+  at.ctx = sc.ctx; at.B = B; at.Tq = T; at.H = H; at.D = d;
   at.win_front = bo.win_front; at.win_back = bo.win_back;
+  if (cross) {
+    // q = (LN(xb + PE) Wq) / sqrt(hs)  [M, d] ; [k | v] = enc [Wk | Wv]  [B*T_enc, 2d]
+    AddPeArgs pa{sc.xb, cross->pe, sc.u, B, T, d};
+    { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_add_pe(pa, s), "positional encoding"); }
+    GemmArgs q{};
+    q.x = sc.u; q.y = sc.qkv; q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.wp = w.xq_wp; q.bias = w.qkv_b;
+    q.M = M; q.NT = d / 16; q.ldy = d; q.n_valid = d; q.eps = kLnEps;
+    q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
+    { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm_rows(d, EPI_QKV, true, q, s), "cross-attention query projection"); }
+    GemmArgs kv{};
+    kv.x = cross->enc; kv.y = cross->kv; kv.wp = w.xkv_wp; kv.bias = w.qkv_b;   // qkv_b: 3d zeros (no bias)
+    kv.M = B * cross->T_enc; kv.NT = 2 * d / 16; kv.ldy = 2 * d; kv.n_valid = 2 * d; kv.eps = kLnEps;
+    { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, kv, s), "cross-attention key/value projection"); }
+    at.q = sc.qkv; at.ldq = d; at.k = cross->kv; at.v = cross->kv + d; at.ldk = 2 * d; at.Tk = cross->T_enc;
+  } else {
+    // mhsa: qkv = LN(xb) Wqkv (q pre-scaled)
+    GemmArgs q{};
+    q.x = sc.xb; q.y = sc.qkv; q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.wp = w.qkv_wp; q.bias = w.qkv_b;
+    q.M = M; q.NT = 3 * d / 16; q.ldy = 3 * d; q.n_valid = 3 * d; q.eps = kLnEps;
+    q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
+    { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm_rows(d, EPI_QKV, true, q, s), "qkv projection"); }
+    at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ldq = 3 * d; at.ldk = 3 * d; at.Tk = T;
+  }
   { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
   // xa = xb + ctx Wo + bo
   GemmArgs op{};
@@ -604,11 +641,13 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
 }
 
 int finalize_chunk(mi355asr_model* m, hipStream_t s);
+int finalize_translator(mi355asr_model* m, hipStream_t s);
 
 int check_ready(const mi355asr_model* m, bool need_encoder = false) {
   if (!m) return fail(MI355ASR_EINVAL, "null model handle");
   if (!m->finalized) return fail(MI355ASR_ESTATE, "weights not finalised: call mi355asr_finalize_weights first");
   if (m->is_chunk) return fail(MI355ASR_ESTATE, "ChunkConformer handle: use mi355asr_chunk_predict");
+  if (m->is_translator) return fail(MI355ASR_ESTATE, "Translator handle: use mi355asr_translator_forward");
   if (need_encoder && !m->cfg.has_encoder) return fail(MI355ASR_ESTATE, "model was created without an encoder (has_encoder=0)");
   return 0;
 }
@@ -659,6 +698,7 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "ctc head"); }
   return 0;
 }
+
 
 }  // namespace
 
@@ -806,6 +846,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   for (const auto& e : m->expected)
     if (!m->host.count(e.name) || !m->host[e.name].set) return fail(MI355ASR_EWEIGHT, "missing weight '%s'", e.name.c_str());
   if (m->is_chunk) return finalize_chunk(m, (hipStream_t)stream);
+  if (m->is_translator) return finalize_translator(m, (hipStream_t)stream);
   const auto& c = m->cfg;
   const Dims& dm = m->dm;
   const int d = c.dmodel;
@@ -1218,6 +1259,79 @@ int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int 
   return 0;
 }
 
+// =======================================================================================================
+// Translator (conformer_blocks.py:505-548)
+// =======================================================================================================
+constexpr int kMaxTokens = 2048;   // rows of the positional-encoding table
+
+struct TransPlan {
+  size_t xa, xb, qkv, ctx, u, dw, kv, amax, total;
+};
+TransPlan make_trans_plan(const mi355asr_model* m, int B, int U, int T) {
+  const size_t d = m->cfg.dmodel, M = (size_t)B * U;
+  TransPlan p;
+  size_t o = 0;
+  auto take = [&](size_t floats) { size_t at = o; o = align256(o + floats * 4); return at; };
+  p.xa = take(M * d); p.xb = take(M * d); p.qkv = take(M * 3 * d); p.ctx = take(M * d);
+  p.u = take(M * d); p.dw = take(M * d); p.kv = take((size_t)B * T * 2 * d); p.amax = take(M);
+  p.total = o;
+  return p;
+}
+
+int finalize_translator(mi355asr_model* m, hipStream_t s) {
+  const auto& c = m->cfg;
+  const auto& tc = m->tcfg;
+  const int d = c.dmodel, H = c.num_heads, hs = c.head_size, V = tc.tar_classes;
+  ArenaBuilder ab;
+  const size_t o_emb = ab.put(m->host["inp_embedding/embeddings"].data);
+  // positional_encoding.py:19-36: pe[pos, 2i] = sin(pos / 10000^(2i/d)), pe[pos, 2i+1] = cos(pos / 10000^(2i/d))
+  std::vector<float> pe((size_t)kMaxTokens * d);
+  for (int pos = 0; pos < kMaxTokens; ++pos)
+    for (int i = 0; i < d; ++i) {
+      const double ang = (double)pos / std::pow(10000.0, (double)(2 * (i / 2)) / d);
+      pe[(size_t)pos * d + i] = (float)((i & 1) ? std::cos(ang) : std::sin(ang));
+    }
+  const size_t o_pe = ab.put(pe);
+  StackOff so;
+  for (int i = 0; i < tc.num_blocks; ++i) {
+    const std::string p = "decoder_conformer_block_" + std::to_string(i);
+    BlockOff o = pack_block(m, ab, p, d, H, hs, c.kernel_size);
+    const auto& qk = m->host[p + "/mhsa_module/mha/query_kernel"].data;   // [H, d, hs]
+    const auto& kk = m->host[p + "/mhsa_module/mha/key_kernel"].data;
+    const auto& vk = m->host[p + "/mhsa_module/mha/value_kernel"].data;
+    o.cross = true;
+    o.xq_wp = ab.put(pack_p16([&](int i2, int n) { return qk[((size_t)(n / hs) * d + i2) * hs + n % hs]; }, d, d, d / 16));
+    o.xkv_wp = ab.put(pack_p16(
+        [&](int i2, int n) {
+          const int r = n % d;
+          const std::vector<float>& w = n < d ? kk : vk;
+          return w[((size_t)(r / hs) * d + i2) * hs + r % hs];
+        },
+        d, 2 * d, 2 * d / 16));
+    so.blocks.push_back(o);
+  }
+  const auto& fc = m->host["fully_connected/kernel"].data;
+  const int ct = gemm_ct(d, EPI_HEAD);
+  so.NT_fc = ceil_div(ceil_div(V, 16), ct) * ct;
+  so.fc_w = ab.put(pack_p16([&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, so.NT_fc));
+  so.fc_b = ab.put_padded(m->host["fully_connected/bias"].data.data(), V, (size_t)so.NT_fc * 16);
+  if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }
+  HIP_TRY(hipMalloc((void**)&m->arena, ab.buf.size() * sizeof(float)));
+  m->arena_floats = ab.buf.size();
+  HIP_TRY(hipMemcpyAsync(m->arena, ab.buf.data(), ab.buf.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const float* base = m->arena;
+  m->t_emb = base + o_emb;
+  m->t_pe = base + o_pe;
+  resolve_stack(m->t_stack, so, base, false, V);
+  m->t_stack.opts.ksz = c.kernel_size;
+  m->t_stack.opts.fc = c.fc_factor;
+  for (auto& kv : m->host) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); }
+  m->finalized = true;
+  return 0;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -1380,6 +1494,70 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
   if (outs->helper_out) HIP_TRY(hipMemcpyAsync(outs->helper_out, sc.xa, actp, hipMemcpyDeviceToDevice, s));
   rc = run_stack(m, m->c_decoder, sc.xa, B, Tp, sc, outs->text_logits, outs->text_argmax ? outs->text_argmax : amax, s);
   return rc;
+}
+
+// ---- Translator ----------------------------------------------------------------------------------------
+int mi355asr_translator_create(const mi355asr_translator_config* cfg, mi355asr_model** out) {
+  if (!cfg || !out) return fail(MI355ASR_EINVAL, "null argument");
+  const auto& c = *cfg;
+  if (c.dmodel != 144 && c.dmodel != 256) return fail(MI355ASR_EINVAL, "Translator: dmodel=%d, kernels instantiated for 144 and 256", c.dmodel);
+  if (c.num_heads * c.head_size != c.dmodel || (c.head_size != 36 && c.head_size != 64))
+    return fail(MI355ASR_EINVAL, "Translator: need num_heads*head_size == dmodel and head_size 36 or 64");
+  if (c.kernel_size != 32 && c.kernel_size != 5) return fail(MI355ASR_EINVAL, "kernel_size=%d unsupported", c.kernel_size);
+  if (c.num_blocks < 1 || c.inp_classes < 1 || c.tar_classes < 2) return fail(MI355ASR_EINVAL, "Translator: bad block / class counts");
+  auto* m = new mi355asr_model();
+  m->is_translator = true;
+  m->tcfg = c;
+  std::memset(&m->cfg, 0, sizeof(m->cfg));
+  m->cfg.dmodel = c.dmodel; m->cfg.head_size = c.head_size; m->cfg.num_heads = c.num_heads;
+  m->cfg.kernel_size = c.kernel_size; m->cfg.fc_factor = c.fc_factor;
+  std::memset(&m->dm, 0, sizeof(m->dm));
+  const int d = c.dmodel;
+  auto& ex = m->expected;
+  ex.push_back({"inp_embedding/embeddings", {c.inp_classes, d}});
+  for (int i = 0; i < c.num_blocks; ++i)
+    add_block_expected(ex, "decoder_conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size, c.kernel_size);
+  ex.push_back({"fully_connected/kernel", {d, c.tar_classes}});
+  ex.push_back({"fully_connected/bias", {c.tar_classes}});
+  for (const auto& e : ex) m->host[e.name] = HostTensor{};
+  *out = m;
+  return 0;
+}
+
+int mi355asr_translator_workspace_bytes(const mi355asr_model* m, int32_t B, int32_t U, int32_t T, size_t* bytes) {
+  if (!m || !m->is_translator || !bytes) return fail(MI355ASR_EINVAL, "not a Translator handle / null argument");
+  if (B < 1 || U < 1 || T < 1) return fail(MI355ASR_EINVAL, "B, U, T must be positive (got %d, %d, %d)", B, U, T);
+  *bytes = make_trans_plan(m, B, U, T).total;
+  return 0;
+}
+
+int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids, const float* enc, int32_t B, int32_t U,
+                                int32_t T, float* logits, int32_t* amax, void* ws_, size_t ws_bytes, void* stream) {
+  if (!m || !m->is_translator) return fail(MI355ASR_EINVAL, "not a Translator handle");
+  if (!m->finalized) return fail(MI355ASR_ESTATE, "weights not finalised: call mi355asr_finalize_weights first");
+  if (!ids || !enc || !ws_) return fail(MI355ASR_EINVAL, "null argument");
+  if (B < 1 || U < 1 || T < 1) return fail(MI355ASR_EINVAL, "B, U, T must be positive (got %d, %d, %d)", B, U, T);
+  if (U > kMaxTokens) return fail(MI355ASR_EINVAL, "U=%d exceeds the positional-encoding table (%d rows)", U, kMaxTokens);
+  const TransPlan p = make_trans_plan(m, B, U, T);
+  if (ws_bytes < p.total) return fail(MI355ASR_EINVAL, "workspace too small: %zu < %zu", ws_bytes, p.total);
+  char* ws = (char*)ws_;
+  hipStream_t s = (hipStream_t)stream;
+  const int d = m->cfg.dmodel, M = B * U;
+  Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
+             (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
+  EmbedArgs ea{ids, m->t_emb, sc.xa, M, m->tcfg.inp_classes, d};
+  LAUNCH_TRY(launch_embed(ea, s), "embedding");
+  CrossAttn cr{enc, T, (float*)(ws + p.kv), m->t_pe};
+  for (const auto& blk : m->t_stack.blocks) {
+    int rc = run_block(m, blk, m->t_stack.opts, sc, B, U, nullptr, s, &cr);
+    if (rc) return rc;
+  }
+  GemmArgs hd{};
+  hd.x = sc.xa; hd.y = logits; hd.wp = m->t_stack.fc_wp; hd.bias = m->t_stack.fc_b;
+  hd.M = M; hd.NT = m->t_stack.NT_fc; hd.ldy = m->tcfg.tar_classes; hd.n_valid = m->tcfg.tar_classes; hd.eps = kLnEps;
+  hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
+  { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "translator head"); }
+  return 0;
 }
 
 }  // extern "C"

@@ -37,14 +37,15 @@ __global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, g4 = g * 4, c = lane & 15;
   const int qt = blockIdx.x * AW + (threadIdx.x >> 6);
-  const int T = a.T;
+  const int T = a.Tk, TQ = a.Tq;       // keys / queries per utterance
   const int h = blockIdx.y, b = blockIdx.z;
-  const int ld = a.ld, D = a.D;
-  const float* __restrict__ base = a.qkv + (size_t)b * T * ld + h * HS;
+  const int ld = a.ldk, D = a.D;
+  const float* __restrict__ kbase = a.k + (size_t)b * T * ld + h * HS;
+  const float* __restrict__ vbase = a.v + (size_t)b * T * ld + h * HS;
 
   // ---- this lane's query fragment (log2 e folded in: softmax uses exp2)
   const int tq = qt * 16 + c;
-  const float* qrow = base + (size_t)min(tq, T - 1) * ld;
+  const float* qrow = a.q + ((size_t)b * TQ + min(tq, TQ - 1)) * a.ldq + h * HS;
   constexpr float LOG2E = 1.4426950408889634f;
   f32x4 q4[FB > 0 ? FB : 1];
   float qs[TS > 0 ? TS : 1];
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
   for (int it = 0; it < NIT; ++it) {
     const int idx = min((int)threadIdx.x + it * ATH, TP * C4 - 1);
     const int key = idx / C4, ch = idx - key * C4;
-    const float* row = base + (size_t)min(key, T - 1) * ld + 4 * ch;
-    kv[it] = ldg4(row + D);
-    vv[it] = ldg4(row + 2 * D);
+    const size_t row = (size_t)min(key, T - 1) * ld + 4 * ch;
+    kv[it] = ldg4(kbase + row);
+    vv[it] = ldg4(vbase + row);
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
     Vt[(4 * ch + 3) * VS + key] = v.w;
   }
   __syncthreads();
-  if (qt * 16 >= T) return;
+  if (qt * 16 >= TQ) return;
   const int nkt = (T + 15) / 16;       // key tiles that hold at least one real key (uniform)
 
   // ---- S^T = K Q^T
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
       if (kt < nkt) pv_tile(kt);
   }
   const float inv = 1.0f / group_sum(psum);
-  if (tq < T) {
-    float* orow = a.ctx + ((size_t)b * T + tq) * D + h * HS;
+  if (tq < TQ) {
+    float* orow = a.ctx + ((size_t)b * TQ + tq) * D + h * HS;
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
       if (16 * i + g4 < HS) stg4(orow + 16 * i + g4, o[i] * splat4(inv));
@@ -178,11 +179,13 @@ __global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
 
 }  // namespace
 
-bool attention_lds_applicable(int HS, const AttnArgs& a) { return HS == 36 && a.win_front < 0 && a.T <= TP && a.T > 16; }
+bool attention_lds_applicable(int HS, const AttnArgs& a) {
+  return HS == 36 && a.win_front < 0 && a.Tk <= TP && a.Tk > 16 && a.Tq > 16;
+}
 
 int launch_attention_lds(int HS, const AttnArgs& a, hipStream_t s) {
   if (!attention_lds_applicable(HS, a)) return -1;
-  const int qtiles = (a.T + 15) / 16;
+  const int qtiles = (a.Tq + 15) / 16;
   dim3 grid((qtiles + AW - 1) / AW, a.H, a.B);
   hipLaunchKernelGGL((attention_lds_kernel<36>), grid, dim3(ATH), 0, s, a);
   return 0;

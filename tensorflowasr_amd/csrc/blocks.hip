@@ -429,15 +429,16 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a)
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, g4 = g * 4, c = lane & 15;
   const int qt = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  const int T = a.T;
-  if (qt * 16 >= T) return;
+  const int T = a.Tk, TQ = a.Tq;       // keys / queries per utterance
+  if (qt * 16 >= TQ) return;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int ld = a.ld;  // row stride of the qkv buffer (3*D)
+  const int ld = a.ldk;  // row stride of the k / v buffers
   const int D = a.D;
-  const float* __restrict__ base = a.qkv + (size_t)b * T * ld + h * HS;
+  const float* __restrict__ kbase = a.k + (size_t)b * T * ld + h * HS;
+  const float* __restrict__ vbase = a.v + (size_t)b * T * ld + h * HS;
 
   const int tq = qt * 16 + c;
-  const float* qrow = base + (size_t)min(tq, T - 1) * ld;
+  const float* qrow = a.q + ((size_t)b * TQ + min(tq, TQ - 1)) * a.ldq + h * HS;
   f32x4 q4[FB > 0 ? FB : 1];
   float qs[TS > 0 ? TS : 1];
 #pragma unroll
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a)
 #pragma unroll
     for (int tt = 0; tt < KG; ++tt) {
       const int tk = min(k0 + 16 * (batch * KG + tt) + c, T - 1);
-      const float* krow = base + D + (size_t)tk * ld;
+      const float* krow = kbase + (size_t)tk * ld;
 #pragma unroll
       for (int s = 0; s < FB; ++s) kb4[buf][tt][s] = ldg4(krow + 16 * s + g4);
 #pragma unroll
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a)
       const int kb = k0 + 16 * (batch * VG + tt) + g4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float* vrow = base + 2 * D + (size_t)min(kb + j, T - 1) * ld;
+        const float* vrow = vbase + (size_t)min(kb + j, T - 1) * ld;
 #pragma unroll
         for (int i = 0; i < OT; ++i) {
           const int f = 16 * i + c;
@@ -583,8 +584,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a)
     }
   }
   const float inv = 1.0f / group_sum(l_run);
-  if (tq < T) {
-    float* orow = a.ctx + ((size_t)b * T + tq) * D + h * HS;
+  if (tq < TQ) {
+    float* orow = a.ctx + ((size_t)b * TQ + tq) * D + h * HS;
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
       if (16 * i + g4 < HS) stg4(orow + 16 * i + g4, o[i] * splat4(inv));
@@ -594,11 +595,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a)
 
 template <int HS>
 static void launch_attention_t(const AttnArgs& a, hipStream_t s) {
-  const int qtiles = (a.T + 15) / 16;
+  const int qtiles = (a.Tq + 15) / 16;
   dim3 grid((qtiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.H, a.B);
   // keys are swept in blocks of 16*KT; short sequences (streaming blocks: T = 13) and band attention
   // (win_front + win_back + 16 keys per query tile) use small blocks
-  const int span = a.win_front >= 0 ? min(a.T, a.win_front + a.win_back + 31) : a.T;
+  const int span = a.win_front >= 0 ? min(a.Tk, a.win_front + a.win_back + 31) : a.Tk;
   if (span <= 16) hipLaunchKernelGGL((attention_kernel<HS, 1>), grid, dim3(BLOCK_THREADS), 0, s, a);
   else if (span <= 96) hipLaunchKernelGGL((attention_kernel<HS, 4>), grid, dim3(BLOCK_THREADS), 0, s, a);
   else hipLaunchKernelGGL((attention_kernel<HS, 16>), grid, dim3(BLOCK_THREADS), 0, s, a);

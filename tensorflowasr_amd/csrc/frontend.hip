@@ -416,3 +416,41 @@ int launch_gather(const GatherArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, s, a);
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Translator input side (conformer_blocks.py:537-539, 455-457): Embedding lookup of the phoneme ids, and the
+// sinusoidal positional term added to the *query* input of the cross-attention (positional_encoding.py:19-53;
+// table computed on the host in double precision, [max_len, D]).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
+  const int d4n = a.D / 4;
+  const size_t total = (size_t)a.M * d4n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % d4n) * 4;
+    const size_t row = i / d4n;
+    const int id = min(max(a.ids[row], 0), a.V - 1);
+    stg4(a.dst + row * a.D + c4, ldg4(a.table + (size_t)id * a.D + c4));
+  }
+}
+__global__ __launch_bounds__(256) void add_pe_kernel(AddPeArgs a) {
+  const int d4n = a.D / 4;
+  const size_t total = (size_t)a.B * a.U * d4n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % d4n) * 4;
+    const size_t row = i / d4n;
+    const int u = (int)(row % a.U);
+    stg4(a.dst + row * a.D + c4, ldg4(a.src + row * a.D + c4) + ldg4(a.pe + (size_t)u * a.D + c4));
+  }
+}
+int launch_embed(const EmbedArgs& a, hipStream_t s) {
+  const size_t total = (size_t)a.M * (a.D / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(embed_kernel, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, a);
+  return 0;
+}
+int launch_add_pe(const AddPeArgs& a, hipStream_t s) {
+  const size_t total = (size_t)a.B * a.U * (a.D / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(add_pe_kernel, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, a);
+  return 0;
+}

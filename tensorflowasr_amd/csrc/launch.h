@@ -49,11 +49,15 @@ struct GemmArgs {
 };
 
 struct AttnArgs {
-  const float* qkv;  // [B*T, ld] : q | k | v, each D = H*HS wide, head-major
-  float* ctx;        // [B*T, D]
-  int B, T, H, D, ld;
+  // q [B*Tq, ldq], k / v [B*Tk, ldk]: head h occupies columns [h*HS, (h+1)*HS) of each.  Self-attention passes the
+  // three column blocks of one [B*T, 3D] qkv buffer (Tq == Tk); the Translator's cross-attention passes q from the
+  // token stream and k / v from the encoder output (conformer_blocks.py:459).
+  const float *q, *k, *v;
+  float* ctx;        // [B*Tq, D]
+  int B, Tq, Tk, H, D, ldq, ldk;
   // band attention of the ChunkConformer (chunk_conformer_blocks.py:158-176): query i sees keys
   // [min(max(i-win_front,0), T-win_back), max(min(i+win_back,T), win_back)]; win_front < 0 = full attention
+  // (band attention is self-attention only: Tq == Tk == T)
   int win_front, win_back;
 };
 
@@ -135,6 +139,20 @@ struct GatherArgs {
   float* dst;                // [B, Tp, D] zero padded
   int B, T, Tp, D;
 };
+struct EmbedArgs {
+  const int32_t* ids;        // [M]
+  const float* table;        // [V, D]
+  float* dst;                // [M, D]
+  int M, V, D;
+};
+struct AddPeArgs {
+  const float* src;          // [B, U, D]
+  const float* pe;           // [>= U, D]
+  float* dst;                // [B, U, D]
+  int B, U, D;
+};
+int launch_embed(const EmbedArgs& a, hipStream_t s);
+int launch_add_pe(const AddPeArgs& a, hipStream_t s);
 // block-level fused kernels (fused.hip, dmodel 144)
 struct Ff1QkvArgs {
   const float* x0; float* x1; float* qkv;

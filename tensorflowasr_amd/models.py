@@ -39,6 +39,8 @@ def default_weights(names_and_shapes, rng, sample_rate=16000, n_dft=1024, n_mels
             w[name] = {"real_kernels": frontend_consts.stft_kernels(n_dft)[0],
                        "imag_kernels": frontend_consts.stft_kernels(n_dft)[1],
                        "freq2mel": frontend_consts.freq2mel(sample_rate, n_dft, n_mels)}[leaf]
+        elif leaf == "embeddings":                  # tf.keras.layers.Embedding default: uniform(-0.05, 0.05)
+            w[name] = rng.uniform(-0.05, 0.05, shape).astype(np.float32)
         elif leaf in ("gamma", "moving_variance"):
             w[name] = np.ones(shape, np.float32)
         elif leaf in ("beta", "moving_mean", "bias", "projection_bias"):  # includes the Keras-MHA [H, hs] biases
@@ -61,7 +63,8 @@ class _Handle:
         self.cfg = cfg
         self.device = torch.device(device)
         self.ptr = ctypes.c_void_p()
-        create = self.lib.mi355asr_chunk_create if isinstance(cfg, _lib.ChunkConfig) else self.lib.mi355asr_create
+        create = {_lib.ChunkConfig: self.lib.mi355asr_chunk_create,
+                  _lib.TranslatorConfig: self.lib.mi355asr_translator_create}.get(type(cfg), self.lib.mi355asr_create)
         _lib.check(create(ctypes.byref(cfg), ctypes.byref(self.ptr)))
         self._ws = None
         self.built = False
@@ -401,6 +404,69 @@ class CTCDecoder(_ModelBase):
 
     def conformer_block(self, index, x):
         return ConformerEncoder.conformer_block(self, index, x, stack=1)
+
+
+class Translator(_ModelBase):
+    """asr/models/conformer_blocks.py:505-566: Embedding(inp_classes -> d) + num_blocks RBlocks (FFModule, cross-
+    attention of the token stream over the encoder output with a sinusoidal positional term on the query,
+    ConvModule, FFModule, LayerNorm) + Dense(d -> tar_classes).  Called as the reference calls it:
+    `translator([ctc_decode, enc_outputs], training=False)` (test_asr.py:202) or `.inference(ids, enc)` (:149)."""
+
+    def __init__(self, inp_classes, tar_classes, dmodel=144, num_blocks=16, head_size=36, num_heads=4,
+                 fc_factor=0.5, dropout=0.0, kernel_size=32, device="cuda:0", name="translator", **kwargs):
+        self.name = name
+        self.inp_classes, self.tar_classes, self.dmodel = inp_classes, tar_classes, dmodel
+        self.num_blocks, self.head_size, self.num_heads = num_blocks, head_size, num_heads
+        self.fc_factor, self.kernel_size = fc_factor, kernel_size
+        self.sample_rate, self.n_mels = 16000, 80
+        self._weights = None
+        cfg = _lib.TranslatorConfig(dmodel=dmodel, num_blocks=num_blocks, head_size=head_size, num_heads=num_heads,
+                                    kernel_size=kernel_size, fc_factor=fc_factor, inp_classes=inp_classes,
+                                    tar_classes=tar_classes)
+        self._h = _Handle(cfg, device)
+
+    def _expected_shapes(self):
+        d = self.dmodel
+        s = {"inp_embedding/embeddings": (self.inp_classes, d)}
+        for i in range(self.num_blocks):
+            s.update(_block_shapes("decoder_conformer_block_%d" % i, d, self.num_heads, self.head_size, self.kernel_size))
+        s["fully_connected/kernel"] = (d, self.tar_classes)
+        s["fully_connected/bias"] = (self.tar_classes,)
+        return s
+
+    def __call__(self, x, training=None, mask=None, return_argmax=False):
+        """x = [ids int [B, U], enc float [B, T, dmodel]] -> logits [B, U, tar_classes] (torch, on device)."""
+        if training:
+            raise NotImplementedError("inference path only")
+        ids, enc = x
+        return self._forward(ids, enc, return_argmax)
+
+    def set_inference_func(self):
+        self.inference = lambda inputs, enc: self._forward(inputs, enc, False)
+
+    def _forward(self, ids, enc, return_argmax):
+        h = self._h
+        if not h.built:
+            self._build()
+        idt = h.to_device(ids, dtype=torch.int32)
+        e = h.to_device(enc)
+        if idt.dim() != 2 or e.dim() != 3 or e.shape[0] != idt.shape[0] or e.shape[2] != self.dmodel:
+            raise ValueError("expected ids [B, U] and enc [B, T, %d], got %s and %s"
+                             % (self.dmodel, tuple(idt.shape), tuple(e.shape)))
+        B, U = idt.shape
+        T = e.shape[1]
+        if U == 0:                                   # nothing decoded: Keras returns an empty [B, 0, V] tensor
+            z = torch.empty((B, 0, self.tar_classes), dtype=torch.float32, device=h.device)
+            return (z, torch.empty((B, 0), dtype=torch.int32, device=h.device)) if return_argmax else z
+        logits = torch.empty((B, U, self.tar_classes), dtype=torch.float32, device=h.device)
+        amax = torch.empty((B, U), dtype=torch.int32, device=h.device)
+        n = ctypes.c_size_t()
+        _lib.check(h.lib.mi355asr_translator_workspace_bytes(h.ptr, B, U, T, ctypes.byref(n)))
+        ws = h.workspace(n.value)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_translator_forward(h.ptr, _p(idt), _p(e), B, U, T, _p(logits), _p(amax), _p(ws),
+                                                         n.value, h._stream()))
+        return (logits, amax) if return_argmax else logits
 
 
 def ctc_greedy_decode(frame_argmax, input_length=None, blank=None, device=None):

@@ -450,3 +450,49 @@ def test_chunk_conformer_full_S_config_10s(torch_cuda):
     a = ctc_prefix_beam_decode(got["text_logits"], got["counts"], 8, 0.999, 40, is_logits=True)
     b = ctc_prefix_beam_decode(torch.softmax(got["text_logits"], -1).cpu().numpy(), got["counts"], 8, 0.999, 40)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Translator
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,U,T,blocks", [(2, 7, 30, 1), (3, 40, 250, 2), (1, 1, 13, 1), (2, 23, 300, 2)])
+def test_translator_parity(torch_cuda, B, U, T, blocks):
+    """Embedding + RBlocks (cross-attention over the encoder output, PE on the query) + Dense head against the
+    oracle.  (3, 40, 250): the LDS attention kernel with Tq != Tk; (2, 23, 300): the online-softmax kernel;
+    (1, 1, 13): a single token."""
+    from tensorflowasr_amd.models import Translator
+    cfg = dict(co.CONFORMER_S, translator_num_blocks=blocks, translator_kernel_size=32, translator_fc_factor=0.5)
+    inp, tar = 1332, 517
+    w = co.translator_weights(cfg, inp, tar, seed=11 + blocks)
+    tr = Translator(inp_classes=inp, tar_classes=tar, dmodel=144, num_blocks=blocks, head_size=36, num_heads=4,
+                    kernel_size=32, fc_factor=0.5)
+    tr.load_weights(w, by_name=False)
+    rng = np.random.default_rng(B * 1000 + U)
+    ids = rng.integers(0, inp, (B, U)).astype(np.int32)
+    ids[0, U // 2:] = 0                                   # 0-padding after the decoded tokens (test_asr.py:199)
+    enc = rng.standard_normal((B, T, 144)).astype(np.float32)
+    ref = co.translator(ids, enc.astype(np.float64), w, cfg)
+    got, amax = tr([ids, enc], training=False, return_argmax=True)
+    got = got.cpu().numpy()
+    assert got.shape == ref.shape
+    assert maxdiff(got, ref) < TOL
+    bad = [b for b in argmax_mismatch_report(got, ref) if b[1] > 1e-3]   # ties closer than the tolerance may flip
+    assert not bad, bad
+    assert (amax.cpu().numpy() == got.argmax(-1)).all()
+    tr.set_inference_func()
+    assert maxdiff(tr.inference(ids, enc).cpu().numpy(), got) == 0.0
+
+
+def test_translator_rejects_bad_shapes_and_clamps_ids(torch_cuda):
+    from tensorflowasr_amd.models import Translator
+    cfg = dict(co.CONFORMER_S, translator_num_blocks=1, translator_kernel_size=32, translator_fc_factor=0.5)
+    w = co.translator_weights(cfg, 20, 30, seed=1)
+    tr = Translator(inp_classes=20, tar_classes=30, num_blocks=1)
+    tr.load_weights(w, by_name=False)
+    enc = np.random.default_rng(0).standard_normal((1, 40, 144)).astype(np.float32)
+    with pytest.raises(ValueError):
+        tr([np.zeros((2, 3), np.int32), enc])
+    a = tr([np.array([[25, -3, 4]], np.int32), enc]).cpu().numpy()     # out-of-range ids clamp to [0, 19]
+    b = tr([np.array([[19, 0, 4]], np.int32), enc]).cpu().numpy()
+    assert maxdiff(a, b) == 0.0
+    assert tr([np.zeros((1, 0), np.int32), enc]).shape == (1, 0, 30)

@@ -140,6 +140,31 @@ def test_python_models_mirror_reference_constructor_surface():
     assert full.blank == 1331
 
 
+def test_translator_surface_and_config_struct():
+    """Translator(inp_classes, tar_classes, dmodel, num_blocks, head_size, num_heads, kernel_size, dropout, fc_factor)
+    as test_asr.py:76-84 constructs it; SURVEY 8a: 2.62 M parameters for the S config."""
+    from tensorflowasr_amd.models import Translator
+    hdr = open(os.path.join(ROOT, "include", "mi355asr.h")).read()
+    body = hdr[hdr.index("typedef struct {", hdr.index("Translator:")):hdr.index("} mi355asr_translator_config;")]
+    fields = re.findall(r"(int32_t|float)\s+([\w, ]+);", body)
+    names = [n.strip() for _, group in fields for n in group.split(",")]
+    assert names == [n for n, _ in _lib.TranslatorConfig._fields_]
+    tr = Translator(inp_classes=1332, tar_classes=9160, dmodel=144, num_blocks=2, head_size=36, num_heads=4,
+                    kernel_size=32, dropout=0.1, fc_factor=0.5)
+    assert abs(tr.count_params() - 2.62e6) < 0.02e6
+    names = tr._h.weight_names()
+    assert names[0] == "inp_embedding/embeddings" and names[-1] == "fully_connected/bias"
+    assert "decoder_conformer_block_1/mhsa_module/mha/key_kernel" in names
+    lib = _lib.lib()
+    p = ctypes.c_void_p()
+    bad = _lib.TranslatorConfig(dmodel=144, num_blocks=0, head_size=36, num_heads=4, kernel_size=32, fc_factor=0.5,
+                                inp_classes=10, tar_classes=10)
+    assert lib.mi355asr_translator_create(ctypes.byref(bad), ctypes.byref(p)) == -1
+    n = ctypes.c_size_t()
+    assert lib.mi355asr_translator_workspace_bytes(tr._h.ptr, 1, 30, 250, ctypes.byref(n)) == 0 and n.value > 0
+    assert lib.mi355asr_translator_workspace_bytes(tr._h.ptr, 1, 0, 250, ctypes.byref(n)) == -1
+
+
 def test_product_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

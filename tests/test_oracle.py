@@ -206,3 +206,27 @@ def test_beam_pruning_quirk_cutoff_prob_one_disables_top_n():
     assert len(bo.pruned_log_probs(p, 1.0, 2)) == 5           # decoder_utils.cpp:18-31: top-n ignored at cutoff 1.0
     assert [c for c, _ in bo.pruned_log_probs(p, 0.99, 2)] == [0, 1]
     assert [c for c, _ in bo.pruned_log_probs(p, 0.6, 40)] == [0, 1]
+
+
+def test_positional_encoding_known_values_and_translator_shapes():
+    """positional_encoding.py:19-36: even columns sin, odd columns cos of pos / 10000^(2*(i//2)/size)."""
+    pe = co.positional_encoding(6, 8)
+    assert pe.shape == (6, 8)
+    assert np.allclose(pe[0], [0, 1, 0, 1, 0, 1, 0, 1])
+    assert np.isclose(pe[1, 0], np.sin(1.0)) and np.isclose(pe[1, 1], np.cos(1.0))
+    assert np.isclose(pe[3, 2], np.sin(3.0 / 10.0)) and np.isclose(pe[3, 3], np.cos(3.0 / 10.0))
+    assert np.isclose(pe[5, 6], np.sin(5.0 / 1000.0)) and np.isclose(pe[5, 7], np.cos(5.0 / 1000.0))
+    cfg = dict(co.CONFORMER_S, translator_num_blocks=1, translator_kernel_size=32, translator_fc_factor=0.5)
+    w = co.translator_weights(cfg, 50, 60, seed=5)
+    rng = np.random.default_rng(0)
+    ids = rng.integers(0, 50, (2, 9))
+    enc = rng.standard_normal((2, 20, 144))
+    y = co.translator(ids, enc, w, cfg)
+    assert y.shape == (2, 9, 60) and np.isfinite(y).all()
+    # the positional term matters (same token at two positions gives different outputs) ...
+    same = np.full((1, 4), 7)
+    ys = co.translator(same, enc[:1], w, cfg)
+    assert np.abs(ys[0, 0] - ys[0, 3]).max() > 1e-3
+    # ... and the encoder output is only seen through the cross-attention (permuting its frames changes nothing)
+    yp = co.translator(ids[:1], enc[:1, ::-1], w, cfg)
+    assert np.abs(yp - y[:1]).max() < 1e-9
