@@ -496,3 +496,87 @@ def test_translator_rejects_bad_shapes_and_clamps_ids(torch_cuda):
     b = tr([np.array([[19, 0, 4]], np.int32), enc]).cpu().numpy()
     assert maxdiff(a, b) == 0.0
     assert tr([np.zeros((1, 0), np.int32), enc]).shape == (1, 0, 30)
+
+
+def _write_wav(path, x, sr=16000):
+    import wave
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(sr)
+        f.writeframes((np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
+
+
+def _asr_config(tmp_path, streaming, model_yaml):
+    from tensorflowasr_amd.config import load_yaml
+    (tmp_path / "phones.txt").write_text("\n".join(["<S>", "</S>", "[SPACE]", "[UNK]"] + ["p%d" % i for i in range(56)]) + "\n")
+    (tmp_path / "chars.txt").write_text("\n".join(["<S>", "</S>", "[SPACE]", "[UNK]"] + [chr(0x4e00 + i) for i in range(96)]) + "\n")
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tensorflowasr_amd", "configs")
+    cfg = load_yaml(os.path.join(here, "am_data_streaming.yml" if streaming else "am_data.yml"))
+    cfg.update(load_yaml(os.path.join(here, model_yaml)))
+    cfg["inp_config"]["vocabulary"] = str(tmp_path / "phones.txt")
+    cfg["tar_config"]["vocabulary"] = str(tmp_path / "chars.txt")
+    cfg["running_config"]["outdir"] = str(tmp_path / "logs")
+    return cfg
+
+
+def test_asr_offline_stt_end_to_end(torch_cuda, tmp_path):
+    """test_asr.py:186-219 with checkpoints on disk: wav file -> phones, text; every stage against the oracle."""
+    from tensorflowasr_amd.asr import ASR
+    cfg = _asr_config(tmp_path, False, "conformerS.yml")
+    cfg["model_config"]["num_blocks"] = 2                      # a short encoder keeps the oracle fast
+    mc = dict(co.CONFORMER_S, num_blocks=2, translator_num_blocks=2, translator_kernel_size=32, translator_fc_factor=0.5)
+    V_in, V_out = 61, 101                                      # vocabulary + blank
+    we = co.encoder_weights(mc, seed=21)
+    wc = co.ctc_decoder_weights(mc, V_in, seed=22)
+    wt = co.translator_weights(mc, V_in, V_out, seed=23)
+    x = co.synth_wave(3, length=40000)
+    # a random network's frames are nearly identical (one phone for the whole utterance); centring the CTC head on
+    # this utterance makes the argmax follow the per-frame deviations -> a 54-token phone sequence
+    xq = (np.clip(x, -1, 1) * 32767).astype("<i2").astype(np.float64) / 32768.0
+    enc0 = co.conformer_encoder(xq[None], we, mc)
+    wc["fully_connected/bias"] = np.zeros(V_in, np.float32)
+    wc["fully_connected/bias"] = (-co.ctc_decoder(enc0, wc, mc).mean(axis=(0, 1))).astype(np.float32)
+    for sub, w in (("encoder", we), ("ctc_decoder", wc), ("translator", wt)):
+        d = tmp_path / "logs" / (sub + "-ckpt")
+        d.mkdir(parents=True)
+        np.savez(d / "model_5.npz", **{k: v * 0 for k, v in w.items()})        # an older step: must be ignored
+        np.savez(d / "model_40.npz", **w)
+    _write_wav(tmp_path / "utt.wav", x)
+    asr = ASR(cfg)
+    assert asr.phone_featurizer.num_classes == V_in and asr.text_featurizer.num_classes == V_out
+    phones, text = asr.stt(str(tmp_path / "utt.wav"))
+    # oracle pipeline on the same PCM16-quantised samples
+    wav = asr.speech_featurizer.load_wav(str(tmp_path / "utt.wav")).astype(np.float64)[None]
+    enc = co.conformer_encoder(wav, we, mc)
+    ids, lens = co.ctc_greedy(co.ctc_decoder(enc, wc, mc), np.array([enc.shape[1]]), blank=V_in - 1)
+    row = np.clip(ids[0][:lens[0]], 0, None)
+    tl = co.translator(row[None], enc, wt, mc)
+    exp_ph = [int(n) for n in row if n != 0]
+    exp_tx = []
+    for n in tl[0].argmax(-1):
+        if n != 0:
+            exp_tx.append(int(n))
+        if n == 1:
+            break
+    assert len(exp_ph) > 3
+    assert phones == " ".join(asr.phone_featurizer.iextract(exp_ph))
+    assert text == "".join(asr.text_featurizer.iextract(exp_tx))
+
+
+def test_asr_stream_stt_runs_block_conformer(torch_cuda, tmp_path):
+    """test_asr.py:116-164: 0.5 s blocks through the StreamingConformerEncoder, global CTC + Translator per block."""
+    from tensorflowasr_amd.asr import ASR
+    cfg = _asr_config(tmp_path, True, "Streaming_ConformerS.yml")
+    asr = ASR(cfg, load_checkpoint=False)                      # Keras-default random init (seeded)
+    x = co.synth_wave(4, length=20000)                         # 2.5 blocks: the tail block is zero-padded
+    _write_wav(tmp_path / "s.wav", x)
+    phones, text = asr.stt(str(tmp_path / "s.wav"))
+    assert isinstance(phones, str) and isinstance(text, str)
+    # same ids as running the pieces by hand on the zero-padded signal
+    wav = asr.speech_featurizer.load_wav(str(tmp_path / "s.wav"))
+    wav = np.pad(wav, (0, 24000 - len(wav)))[None, :, None]
+    enc = asr.encoder(wav)
+    assert enc.shape[1] == 3 * 13
+    ids, _ = asr._phone_ids(enc)
+    assert phones == " ".join(asr.phone_featurizer.iextract([int(n) for n in ids[0].cpu().numpy() if n != 0]))
