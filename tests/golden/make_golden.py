@@ -183,7 +183,28 @@ def make_beam_kats():
     print("beam KATs:", len(meta), "cases; best of the last:", out["ids_%d" % (len(cases) - 1)][0][:out["lens_%d" % (len(cases) - 1)][0]][:10])
 
 
+def make_wer_kats():
+    """(S+I+D)/N and the S / D / I split from the reference's own utils/xer.py (numpy-only, importable here)."""
+    from utils import xer
+    rng = np.random.default_rng(7)
+    kats = []
+    for n in range(60):
+        lr, lh = int(rng.integers(1, 14)), int(rng.integers(0, 14))
+        r = rng.integers(0, 6, lr).tolist()
+        h = rng.integers(0, 6, lh).tolist()
+        if n % 5 == 0:
+            h = list(r)
+        if n % 7 == 0 and len(r) > 2:
+            h = r[1:] + [9]
+        score, s, d, i = xer.wer(r, h)
+        kats.append({"r": r, "h": h, "score": score, "s": s, "d": d, "i": i})
+    json.dump(kats, open(os.path.join(HERE, "wer_kat.json"), "w"))
+    print("wer_kat.json:", len(kats), "cases")
+
+
 if __name__ == "__main__":
+    sys.path.insert(0, REF)
+    make_wer_kats()
     make_onnx_fixtures()
     make_greedy_kats()
     make_beam_kats()

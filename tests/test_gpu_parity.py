@@ -580,3 +580,49 @@ def test_asr_stream_stt_runs_block_conformer(torch_cuda, tmp_path):
     assert enc.shape[1] == 3 * 13
     ids, _ = asr._phone_ids(enc)
     assert phones == " ".join(asr.phone_featurizer.iextract([int(n) for n in ids[0].cpu().numpy() if n != 0]))
+
+
+def test_am_tester_metrics_match_oracle_pipeline(torch_cuda, tmp_path):
+    """am_tester.py:34-89 over one batch of the list-file loader: S/I/D counts, SER and CER equal the ones the
+    oracle pipeline gives with the same error-rate arithmetic."""
+    from test_host import _eval_fixture
+    from tensorflowasr_amd.eval import AMTester, EvalList, wer
+    cfg = _eval_fixture(tmp_path, False)
+    cfg["model_config"]["num_blocks"] = 2
+    cfg["running_config"]["outdir"] = str(tmp_path / "logs")
+    t = AMTester(cfg, load_checkpoint=False)
+    ds = EvalList(cfg, t.speech_featurizer, t.phone_featurizer, t.text_featurizer, batch_size=3)
+    batch = ds.eval_data_generator()
+    x, in_len, ph, _, txt = batch
+    mc = dict(co.CONFORMER_S, num_blocks=2, translator_num_blocks=2, translator_kernel_size=32, translator_fc_factor=0.5)
+    we, wc, wt = t.encoder.get_weights_dict(), t.ctc_model.get_weights_dict(), t.translator.get_weights_dict()
+    for k in ("mel_layer/real_kernels", "mel_layer/imag_kernels"):
+        we[k] = we[k].reshape(1024, 513)                       # Keras variable shape [n_dft,1,1,nb] -> oracle's 2-D
+    enc = co.conformer_encoder(x[..., 0].astype(np.float64), we, mc)
+    wc["fully_connected/bias"] = (-co.ctc_decoder(enc, wc, mc).mean(axis=(0, 1))).astype(np.float32)   # varied argmax
+    t.ctc_model.load_weights(wc, by_name=False)
+    ids, lens = co.ctc_greedy(co.ctc_decoder(enc, wc, mc), in_len, blank=t.phone_featurizer.blank)
+    dense = np.clip(ids[:, :max(int(lens.max()), 1)], 0, None)
+    tr = co.translator(dense, enc, wt, mc).argmax(-1)
+    n = [0, 0, 0, 0]
+    ser = []
+    for hyp, ref in zip(dense, ph):
+        i, j = [int(v) for v in hyp if v != 0], [int(v) for v in ref if v != 0]
+        _, s_, d_, i_ = wer(j, i)
+        n[0] += len(j); n[1] += s_; n[2] += i_; n[3] += d_
+        ser.append(0 if i == j else 1)
+    m = [0, 0, 0, 0]
+    for hyp, ref in zip(tr, txt):
+        hyp = [int(v) for v in hyp]
+        if 1 in hyp:
+            hyp = hyp[:hyp.index(1)]
+        i, j = [v for v in hyp if v not in (0, 1)], [int(v) for v in ref if v not in (0, 1)]
+        _, s_, d_, i_ = wer(j, i)
+        m[0] += len(j); m[1] += s_; m[2] += i_; m[3] += d_
+    assert lens.min() >= 5                                     # the hypotheses are real sequences, not a constant
+    t.set_datasets([batch])
+    t.set_all_steps(1)
+    r = t.run()
+    assert r["phone_s_i_d"] == "%d_%d_%d" % tuple(n[1:]) and r["trans_s_i_d"] == "%d_%d_%d" % tuple(m[1:])
+    assert abs(r["phone_cer"] - sum(n[1:]) / (n[0] + 1e-6)) < 1e-12 and abs(r["txt_cer"] - sum(m[1:]) / (m[0] + 1e-6)) < 1e-12
+    assert r["phone_ser"] == np.mean(ser) and r["steps"] == 1

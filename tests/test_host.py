@@ -2,6 +2,7 @@
 argument validation / error reporting, weight-name surface, shape helpers, featurizers, config, constants.
 No kernel is launched here (no GPU in this container)."""
 import ctypes
+import json
 import os
 import re
 import struct
@@ -163,6 +164,65 @@ def test_translator_surface_and_config_struct():
     n = ctypes.c_size_t()
     assert lib.mi355asr_translator_workspace_bytes(tr._h.ptr, 1, 30, 250, ctypes.byref(n)) == 0 and n.value > 0
     assert lib.mi355asr_translator_workspace_bytes(tr._h.ptr, 1, 0, 250, ctypes.byref(n)) == -1
+
+
+def test_wer_matches_reference_xer_kats():
+    """utils/xer.py:211-220 (distance AND the S / D / I split of the reference's tie-breaking); fixtures made by
+    importing the reference module (tests/golden/make_golden.py::make_wer_kats)."""
+    from tensorflowasr_amd.eval import levenshtein, wer
+    kats = json.load(open(os.path.join(ROOT, "tests", "golden", "wer_kat.json")))
+    assert len(kats) == 60
+    for k in kats:
+        score, s, d, i = wer(k["r"], k["h"])
+        assert (s, d, i) == (k["s"], k["d"], k["i"]), k
+        assert score == k["score"]
+    assert levenshtein("kitten", "sitting")[0] == 3
+    assert wer(list("abc"), [])[1:] == (0, 3, 0)
+
+
+def _eval_fixture(tmp_path, streaming):
+    import wave
+    from tensorflowasr_amd.config import load_yaml
+    (tmp_path / "phones.txt").write_text("\n".join(["<S>", "</S>", "[SPACE]", "[UNK]"] + ["p%d" % i for i in range(20)]) + "\n")
+    (tmp_path / "chars.txt").write_text("\n".join(["<S>", "</S>", "[SPACE]", "[UNK]"] + [chr(0x4e00 + i) for i in range(30)]) + "\n")
+    here = os.path.join(ROOT, "tensorflowasr_amd", "configs")
+    cfg = load_yaml(os.path.join(here, "am_data_streaming.yml" if streaming else "am_data.yml"))
+    cfg.update(load_yaml(os.path.join(here, "Streaming_ConformerS.yml" if streaming else "conformerS.yml")))
+    cfg["inp_config"]["vocabulary"] = str(tmp_path / "phones.txt")
+    cfg["tar_config"]["vocabulary"] = str(tmp_path / "chars.txt")
+    lines = []
+    for n, L in enumerate([12000, 300, 20480, 16000 * 8, 9000]):      # 300: too short, 8 s: over wav_max_duration
+        x = (0.3 * np.sin(np.arange(L) * (0.01 + 0.003 * n))).astype(np.float32)
+        with wave.open(str(tmp_path / ("u%d.wav" % n)), "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes((x * 32767).astype("<i2").tobytes())
+        lines.append("%s\t%s\t%s" % (tmp_path / ("u%d.wav" % n), chr(0x4e00 + n) + chr(0x4e01 + n), "p%d p%d p1" % (n, n + 3)))
+    lines.append("%s\t%s\tp1 zz" % (tmp_path / "u0.wav", chr(0x4e00)))     # unknown phone token: skipped
+    (tmp_path / "eval.list").write_text("\n".join(lines) + "\n")
+    cfg["speech_config"]["eval_list"] = str(tmp_path / "eval.list")
+    return cfg
+
+
+@pytest.mark.parametrize("streaming", [False, True])
+def test_eval_list_batches_like_the_reference_loader(tmp_path, streaming):
+    """am_dataloader.py:118-227: skips, peak normalisation, in_len, padding (offline and streaming)."""
+    from tensorflowasr_amd.eval import EvalList
+    from tensorflowasr_amd.featurizers import SpeechFeaturizer, TextFeaturizer
+    cfg = _eval_fixture(tmp_path, streaming)
+    ds = EvalList(cfg, SpeechFeaturizer(cfg["speech_config"]), TextFeaturizer(cfg["inp_config"]),
+                  TextFeaturizer(cfg["tar_config"]), batch_size=3)
+    x, in_len, ph, ph_len, txt = ds.eval_data_generator()
+    assert x.dtype == np.float32 and x.ndim == 3 and x.shape[0] == 3 and x.shape[2] == 1
+    assert ph.tolist() == [[4, 7, 5], [6, 9, 5], [8, 11, 5]] and ph_len.tolist() == [3, 3, 3]   # p0 p3 p1 / p2 p5 p1 / p4 p7 p1
+    assert txt[0].tolist() == [4, 5, 1] and txt[1].tolist() == [6, 7, 1]          # chars + </S>
+    if not streaming:
+        assert x.shape[1] == 20480 and in_len.tolist() == [12000 // 640, 20480 // 640, 9000 // 640]
+        assert abs(np.abs(x[0]).max() - 1.0) < 1e-6 and abs(np.abs(x[2]).max() - 1.0) < 1e-6   # peak-normalised
+        assert np.all(x[0, 12000:] == 0)
+    else:
+        assert x.shape[1] == 24000                                                 # next multiple of the 8000-sample block
+        assert in_len.tolist() == [2 * 13, 3 * 13, 2 * 13]                         # whole blocks x 13 frames
+        assert abs(np.abs(x[0]).max() - 0.3) < 1e-3                                # raw samples, not normalised
 
 
 def test_product_fails_loudly_without_gpu():
