@@ -70,14 +70,14 @@ def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES, stft_mode=0):
     }
 
 
-def build_model(device, rank, world):
+def build_model(device, rank, world, use_dist=False):
     m = ConformerCTC(NUM_CLASSES, device=device, **S_CFG)
     m._build(seed=0)                       # Keras-default random init of the S architecture + DFT/mel constants
     w = m.get_weights_dict()
     golden = os.path.join(ROOT, "tests", "golden", "ctc_decoder_weights.npz")
     if os.path.exists(golden):             # trained CTCDecoder weights exported by the reference
         w.update({k: v for k, v in np.load(golden).items()})
-    if world > 1:
+    if use_dist:
         from tensorflowasr_amd.parallel import broadcast_weights
         w = broadcast_weights(w, src=0, device=device)
     m.load_weights(w, by_name=False)
@@ -133,21 +133,24 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # MI355ASR_BENCH_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1` exercises the RCCL code path
+    # (init, barrier, broadcast, all_gather) on a one-GPU box
+    use_dist = world > 1 or os.environ.get("MI355ASR_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
         from tensorflowasr_amd.parallel import all_gather_ids
 
     B, L = args.batch, int(args.seconds * 16000)
-    model = build_model(device, rank, world)
+    model = build_model(device, rank, world, use_dist)
     wav = torch.from_numpy(synth_batch(rank * B, B, L)).to(device)      # inputs resident in HBM
     T = model.prepare(B, L)
     h = model._h
 
     def step():
         ids, lens = model.recognize(wav)
-        if world > 1:
+        if use_dist:
             return all_gather_ids(ids, lens)
         return ids, lens
 
@@ -157,18 +160,18 @@ def main():
     cnt = (ctypes.c_int64 * nk)()
 
     def timed_region(n_steps):
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -227,7 +230,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

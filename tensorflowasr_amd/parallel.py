@@ -3,7 +3,8 @@ contiguously, results exchanged with torch.distributed (backend "nccl" = RCCL ov
 CPU for tests).  The reference has no multi-device inference path: this is new design.
 
 Collectives on the path: one broadcast of the flattened weights at start-up; per batch one all_gather of
-`int32[B_local, T]` token ids + `int32[B_local]` lengths (~64 KB per rank at B_local=64, T=250)."""
+`int32[B_local, T + 1]` (token ids, -1 padded, plus the length in the last column; ~64 KB per rank at
+B_local=64, T=250)."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -37,8 +38,12 @@ def all_gather_ids(ids, lens, group=None):
     """ids int32 [B_local, T] (-1 padded), lens int32 [B_local] -> ([B_total, T], [B_total]) on every rank,
     in rank order (requires equal B_local on all ranks, which shard_range gives when world | B_total)."""
     world = dist.get_world_size(group)
-    out_ids = torch.empty((world * ids.shape[0], ids.shape[1]), dtype=ids.dtype, device=ids.device)
-    out_lens = torch.empty((world * lens.shape[0],), dtype=lens.dtype, device=lens.device)
-    dist.all_gather_into_tensor(out_ids, ids.contiguous(), group=group)
-    dist.all_gather_into_tensor(out_lens, lens.contiguous(), group=group)
-    return out_ids, out_lens
+    B, T = ids.shape
+    # one collective per batch: the lengths ride in an extra column of the id matrix (xGMI is latency-, not
+    # bandwidth-bound at 64 KB per rank, so the second all_gather would double the exchange time)
+    packed = torch.empty((B, T + 1), dtype=ids.dtype, device=ids.device)
+    packed[:, :T] = ids
+    packed[:, T] = lens.to(ids.dtype)
+    out = torch.empty((world * B, T + 1), dtype=ids.dtype, device=ids.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    return out[:, :T], out[:, T].to(lens.dtype)
