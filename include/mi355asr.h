@@ -133,6 +133,21 @@ int mi355asr_ctc_prefix_beam(const float* x_dev, int32_t is_logits, const int32_
                              int32_t num_threads, int32_t max_len, int32_t* ids_host, int32_t* lens_host,
                              float* scores_host, int32_t* n_hyp_host, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Stateful prefix beam search for streaming recognition.
+ * replaces: class BeamDecoder (zip:ctc_decoders/ctc_beam_search_decoder.h: BeamDecoder(vocabulary, beam_size,
+ * cutoff_prob, cutoff_top_n, ext_scorer = nullptr), .decode(probs_seq), .reset(); .cpp:217-405).  decode() consumes
+ * T more frames, continuing from the prefix trie the previous calls left, and returns the current beam (best
+ * first) -- feeding an utterance in pieces gives the result of feeding it whole.  As in the reference class, the
+ * vocabulary INCLUDES the blank as its last entry: probs rows have V = num_classes entries, blank = V-1 (:238-240).
+ * Host-side (the trie search is branchy integer work); probs_host f32 [T, V]; outputs as in
+ * mi355asr_ctc_prefix_beam_host for one utterance: ids i32 [beam, max_len], lens i32 [beam], scores f32 [beam]. */
+typedef struct mi355asr_beam mi355asr_beam;
+int mi355asr_beam_create(int32_t V, int32_t beam_size, double cutoff_prob, int32_t cutoff_top_n, mi355asr_beam** out);
+int mi355asr_beam_decode(mi355asr_beam* d, const float* probs_host, int32_t T, int32_t max_len, int32_t* ids_host,
+                         int32_t* lens_host, float* scores_host, int32_t* n_hyp_host);
+int mi355asr_beam_reset(mi355asr_beam* d);
+int mi355asr_beam_destroy(mi355asr_beam* d);
+
 /* encoder + CTCDecoder + greedy in one call: wav [B,L] -> ids i32 [B,T_total] (-1 padded), out_len i32 [B].
  * This is the timed region of bench.py (offline_stt steps 3-5, test_asr.py:191-198). */
 int mi355asr_recognize(mi355asr_model* m, const float* wav_dev, int32_t B, int32_t L, const int32_t* in_len_dev,

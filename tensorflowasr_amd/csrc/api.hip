@@ -1560,4 +1560,32 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids, const flo
   return 0;
 }
 
+// ---- stateful BeamDecoder ----------------------------------------------------------------------------------
+struct mi355asr_beam { void* st; int V, beam; };
+int mi355asr_beam_create(int32_t V, int32_t beam_size, double cutoff_prob, int32_t cutoff_top_n, mi355asr_beam** out) {
+  if (!out) return fail(MI355ASR_EINVAL, "null argument");
+  if (V < 2 || beam_size < 1 || cutoff_top_n < 1 || !(cutoff_prob > 0.0) || cutoff_prob > 1.0)
+    return fail(MI355ASR_EINVAL, "beam decoder: need V >= 2, beam_size >= 1, cutoff_top_n >= 1, 0 < cutoff_prob <= 1");
+  auto* d = new mi355asr_beam{mi355asr_beam_state_new(V, beam_size, cutoff_prob, cutoff_top_n), V, beam_size};
+  *out = d;
+  return 0;
+}
+int mi355asr_beam_decode(mi355asr_beam* d, const float* probs, int32_t T, int32_t max_len, int32_t* ids, int32_t* lens,
+                         float* scores, int32_t* n_hyp) {
+  if (!d || !ids || !lens || !scores || !n_hyp || (T > 0 && !probs)) return fail(MI355ASR_EINVAL, "null argument");
+  if (T < 0 || max_len < 1) return fail(MI355ASR_EINVAL, "T must be >= 0 and max_len >= 1 (got %d, %d)", T, max_len);
+  *n_hyp = mi355asr_beam_state_decode(d->st, probs, T, max_len, ids, lens, scores);
+  return 0;
+}
+int mi355asr_beam_reset(mi355asr_beam* d) {
+  if (!d) return fail(MI355ASR_EINVAL, "null argument");
+  mi355asr_beam_state_reset(d->st);
+  return 0;
+}
+int mi355asr_beam_destroy(mi355asr_beam* d) {
+  if (!d) return 0;
+  mi355asr_beam_state_free(d->st);
+  delete d;
+  return 0;
+}
 }  // extern "C"

@@ -10,6 +10,10 @@ int mi355asr_beam_host_impl(const float* probs, const int32_t* in_len, int B, in
 int mi355asr_beam_topn_impl(const int32_t* top_idx, const float* top_p, const int32_t* in_len, int B, int T, int V,
                             int N, int beam_size, double cutoff_prob, int cutoff_top_n, int num_threads, int max_len,
                             int32_t* ids, int32_t* lens, float* scores, int32_t* n_hyp);
+void* mi355asr_beam_state_new(int V, int beam_size, double cutoff_prob, int cutoff_top_n);
+void mi355asr_beam_state_free(void* h);
+void mi355asr_beam_state_reset(void* h);
+int mi355asr_beam_state_decode(void* h, const float* probs, int T, int max_len, int32_t* ids, int32_t* lens, float* scores);
 int mi355asr_launch_topn(const float* x_dev, int frames, int V, int N, int is_logits, int32_t* idx_dev, float* p_dev,
                          hipStream_t s);
 }

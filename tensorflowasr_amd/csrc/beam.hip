@@ -333,4 +333,37 @@ int mi355asr_launch_topn(const float* x_dev, int frames, int V, int N, int is_lo
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+
+// ---- stateful decoder (replaces: class BeamDecoder, ctc_beam_search_decoder.cpp:217-405, ext_scorer == nullptr) ----
+struct BeamState {
+  Search s;
+  int V, beam, cutoff_top_n, frame;
+  double cutoff_prob;
+  std::vector<Cand> cands;
+  std::vector<int> order;
+};
+
+void* mi355asr_beam_state_new(int V, int beam_size, double cutoff_prob, int cutoff_top_n) {
+  auto* st = new BeamState();
+  st->V = V; st->beam = beam_size; st->cutoff_prob = cutoff_prob; st->cutoff_top_n = cutoff_top_n; st->frame = 0;
+  st->s.reset(beam_size, V - 1);       // BeamDecoder: blank_id = vocabulary.size() - 1 (:238-240)
+  return st;
+}
+void mi355asr_beam_state_free(void* h) { delete static_cast<BeamState*>(h); }
+void mi355asr_beam_state_reset(void* h) {
+  auto* st = static_cast<BeamState*>(h);
+  st->s.reset(st->beam, st->V - 1);
+  st->frame = 0;
+}
+int mi355asr_beam_state_decode(void* h, const float* probs, int T, int max_len, int32_t* ids, int32_t* lens,
+                               float* scores) {
+  auto* st = static_cast<BeamState*>(h);
+  for (int t = 0; t < T; ++t) {
+    pruned_from_row(probs + (size_t)t * st->V, st->V, st->cutoff_prob, st->cutoff_top_n, st->cands, st->order);
+    st->s.step(st->frame++, st->cands);          // the stamp must be unique over the decoder's lifetime
+  }
+  // BeamDecoder::decode sorts the beam before returning (:389-392); the order carries over to the next call
+  return st->s.finish(max_len, ids, lens, scores);
+}
+
 }  // extern "C"

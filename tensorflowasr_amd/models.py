@@ -635,6 +635,52 @@ def ctc_prefix_beam_decode(x, input_length=None, beam_width=10, cutoff_prob=0.99
     return ids, lens, scores, n_hyp
 
 
+class BeamDecoder:
+    """Stateful prefix beam search: externals/ctc_decoders `BeamDecoder(vocabulary, beam_size, cutoff_prob,
+    cutoff_top_n)` with `.decode(probs_seq)` / `.reset()` (ctc_beam_search_decoder.cpp:217-405, no external scorer).
+    `vocabulary` includes the blank as its LAST entry, as the reference class expects.  decode() returns the current
+    beam as [(log_prob, text)], best first, after consuming the given frames; `decode_ids` returns token ids."""
+
+    def __init__(self, vocabulary, beam_size, cutoff_prob=1.0, cutoff_top_n=40, ext_scorer=None):
+        if ext_scorer is not None:
+            raise NotImplementedError("external scorer (KenLM / OpenFST) is not part of this build")
+        self.vocabulary = list(vocabulary)
+        self.beam_size = int(beam_size)
+        self.lib = _lib.lib()
+        self.ptr = ctypes.c_void_p()
+        _lib.check(self.lib.mi355asr_beam_create(len(self.vocabulary), self.beam_size, float(cutoff_prob),
+                                                 int(cutoff_top_n), ctypes.byref(self.ptr)))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.mi355asr_beam_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+    def reset(self):
+        _lib.check(self.lib.mi355asr_beam_reset(self.ptr))
+        self._frames = 0
+
+    def decode_ids(self, probs_seq, max_len=None):
+        x = probs_seq.detach().cpu().numpy() if torch.is_tensor(probs_seq) else np.asarray(probs_seq)
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, len(self.vocabulary))
+        self._frames = getattr(self, "_frames", 0) + x.shape[0]
+        max_len = int(max_len or max(self._frames, 1))
+        ids = np.empty((self.beam_size, max_len), np.int32)
+        lens = np.empty((self.beam_size,), np.int32)
+        scores = np.empty((self.beam_size,), np.float32)
+        n = ctypes.c_int32()
+        _lib.check(self.lib.mi355asr_beam_decode(self.ptr, x.ctypes.data_as(ctypes.c_void_p), x.shape[0], max_len,
+                                                 ids.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p),
+                                                 scores.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)))
+        return [(float(scores[i]), ids[i, :lens[i]].tolist()) for i in range(n.value)]
+
+    def decode(self, probs_seq):
+        return [(sc, "".join(self.vocabulary[t] for t in toks)) for sc, toks in self.decode_ids(probs_seq)]
+
+
 def _chunk_block_shapes(p, d, H, hs, k):
     s = _block_shapes(p, d, H, hs, k)
     m = p + "/mhsa_module/mha"

@@ -183,6 +183,54 @@ def make_beam_kats():
     print("beam KATs:", len(meta), "cases; best of the last:", out["ids_%d" % (len(cases) - 1)][0][:out["lens_%d" % (len(cases) - 1)][0]][:10])
 
 
+def make_stateful_beam_kats():
+    """The reference's stateful BeamDecoder (ctc_beam_search_decoder.cpp:217-405) fed in pieces, with a reset in
+    between: the beam after every decode() call."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_ctc_beam.so"))
+    lib.ref_beam_decoder_new.restype = ctypes.c_void_p
+    lib.ref_beam_decoder_new.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    lib.ref_beam_decoder_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ref_beam_decoder_reset.argtypes = [ctypes.c_void_p]
+    lib.ref_beam_decoder_free.argtypes = [ctypes.c_void_p]
+    rng = np.random.default_rng(99)
+    out = {}
+    cases = [(9, 6, 1.0, 40, [5, 1, 7, 4]), (30, 10, 0.99, 8, [13, 12]), (5, 3, 0.9, 3, [1, 1, 1, 1, 9]),
+             (1332, 10, 0.99, 40, [20, 11, 19])]
+    for ci, (V, beam, cp, ctn, pieces) in enumerate(cases):
+        T = sum(pieces)
+        sharp = 4.0 if V > 100 else 1.5
+        x = rng.standard_normal((2, T, V)) * sharp
+        x[..., V - 1] += 2.0                                   # blank-heavy, like a trained CTC model
+        p = np.exp(x - x.max(-1, keepdims=True))
+        p = (p / p.sum(-1, keepdims=True)).astype(np.float32)
+        h = lib.ref_beam_decoder_new(V, beam, cp, ctn)
+        res = []
+        for u in range(2):                                     # second utterance after reset()
+            if u:
+                lib.ref_beam_decoder_reset(h)
+            o = 0
+            for n in pieces:
+                pd = np.ascontiguousarray(p[u, o:o + n], np.float64)
+                o += n
+                sc = np.zeros(beam)
+                ids = -np.ones((beam, T), np.int32)
+                ln = np.zeros(beam, np.int32)
+                k = lib.ref_beam_decoder_decode(h, pd.ctypes.data, n, V, T, sc.ctypes.data, ids.ctypes.data, ln.ctypes.data)
+                res.append((k, sc.astype(np.float32), ids, ln))
+        lib.ref_beam_decoder_free(h)
+        out["c%d_meta" % ci] = np.array([V, beam, ctn, len(pieces)], np.int32)
+        out["c%d_cp" % ci] = np.array([cp])
+        out["c%d_pieces" % ci] = np.array(pieces, np.int32)
+        out["c%d_probs" % ci] = p
+        out["c%d_n" % ci] = np.array([r[0] for r in res], np.int32)
+        out["c%d_scores" % ci] = np.stack([r[1] for r in res])
+        out["c%d_ids" % ci] = np.stack([r[2] for r in res])
+        out["c%d_lens" % ci] = np.stack([r[3] for r in res])
+    np.savez_compressed(os.path.join(OUT, "beam_stateful_kat.npz"), **out)
+    print("beam_stateful_kat.npz:", len(cases), "cases")
+
+
 def make_wer_kats():
     """(S+I+D)/N and the S / D / I split from the reference's own utils/xer.py (numpy-only, importable here)."""
     from utils import xer
@@ -198,13 +246,14 @@ def make_wer_kats():
             h = r[1:] + [9]
         score, s, d, i = xer.wer(r, h)
         kats.append({"r": r, "h": h, "score": score, "s": s, "d": d, "i": i})
-    json.dump(kats, open(os.path.join(HERE, "wer_kat.json"), "w"))
+    json.dump(kats, open(os.path.join(OUT, "wer_kat.json"), "w"))
     print("wer_kat.json:", len(kats), "cases")
 
 
 if __name__ == "__main__":
     sys.path.insert(0, REF)
     make_wer_kats()
+    make_stateful_beam_kats()
     make_onnx_fixtures()
     make_greedy_kats()
     make_beam_kats()

@@ -353,6 +353,45 @@ def test_prefix_beam_batch_threads_ragged_lengths():
         assert ids1[u, 0, :lens1[u, 0]].tolist() == gid[u, :glen[u]].tolist()
 
 
+def test_stateful_beam_decoder_matches_reference_class_bit_exact():
+    """BeamDecoder.decode / reset (ctc_beam_search_decoder.cpp:217-405) fed in pieces: beam contents, order and
+    float32 scores after every call equal the reference class compiled in place (tests/golden/make_golden.py)."""
+    from tensorflowasr_amd.models import BeamDecoder
+    kat = np.load(os.path.join(ROOT, "tests", "golden", "beam_stateful_kat.npz"))
+    ncases = len([k for k in kat.files if k.endswith("_meta")])
+    assert ncases == 4
+    for ci in range(ncases):
+        V, beam, ctn, npieces = [int(v) for v in kat["c%d_meta" % ci]]
+        cp = float(kat["c%d_cp" % ci][0])
+        pieces, probs = kat["c%d_pieces" % ci], kat["c%d_probs" % ci]
+        dec = BeamDecoder(["%04x" % v for v in range(V)], beam, cp, ctn)
+        call = 0
+        for u in range(2):
+            if u:
+                dec.reset()
+            o = 0
+            for n in pieces:
+                got = dec.decode_ids(probs[u, o:o + n], max_len=probs.shape[1])
+                o += int(n)
+                k = int(kat["c%d_n" % ci][call])
+                assert len(got) == k
+                for i in range(k):
+                    ln = int(kat["c%d_lens" % ci][call][i])
+                    assert got[i][1] == kat["c%d_ids" % ci][call][i][:ln].tolist(), (ci, call, i)
+                    assert np.float32(got[i][0]) == kat["c%d_scores" % ci][call][i], (ci, call, i)
+                call += 1
+        # piecewise == whole
+        dec.reset()
+        whole = dec.decode_ids(probs[1], max_len=probs.shape[1])
+        assert [w[1] for w in whole] == [g[1] for g in got]
+        text = BeamDecoder(["%04x" % v for v in range(V)], beam, cp, ctn).decode(probs[1])
+        assert text[0][1] == "".join("%04x" % t for t in whole[0][1])
+    with pytest.raises(_lib.Mi355AsrError):
+        BeamDecoder(["a"], 4)
+    with pytest.raises(NotImplementedError):
+        BeamDecoder(["a", "b"], 4, ext_scorer=object())
+
+
 def test_prefix_beam_argument_errors():
     from tensorflowasr_amd.models import ctc_prefix_beam_decode
     with pytest.raises(_lib.Mi355AsrError):
