@@ -83,6 +83,10 @@ SIGNATURES = {
     "mi355asr_chunk_out_frames": (ctypes.c_int, [_P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "mi355asr_chunk_workspace_bytes": (ctypes.c_int, [_P, _I, _I, ctypes.POINTER(_SZ)]),
     "mi355asr_chunk_predict": (ctypes.c_int, [_P, _P, _I, _I, ctypes.POINTER(ChunkOutputs), _P, _P, _P, _SZ, _P]),
+    "mi355asr_chunk_front_stream_shape": (ctypes.c_int, [_P, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "mi355asr_chunk_stream_workspace_bytes": (ctypes.c_int, [_P, _I, _I, _I, _I, ctypes.POINTER(_SZ)]),
+    "mi355asr_chunk_front_stream": (ctypes.c_int, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _SZ, _P]),
+    "mi355asr_chunk_stack_stream": (ctypes.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "mi355asr_translator_create": (ctypes.c_int, [ctypes.POINTER(TranslatorConfig), ctypes.POINTER(_P)]),
     "mi355asr_translator_workspace_bytes": (ctypes.c_int, [_P, _I, _I, _I, ctypes.POINTER(_SZ)]),
     "mi355asr_translator_forward": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _SZ, _P]),

@@ -1332,6 +1332,109 @@ int finalize_translator(mi355asr_model* m, hipStream_t s) {
 }
 
 
+// =======================================================================================================
+// ChunkConformer streaming (single stream, explicit caches; chunk_conformer_blocks.py:72-91, 206-220, 294-310,
+// 381-388, 447-458, 530-560, 641-672, 750-770).  The caller owns the caches and trims them (valid / window
+// slicing is plain indexing, done in tensorflowasr_amd/models.py as the reference does it in Python).
+// =======================================================================================================
+struct StreamPlan {
+  size_t xa, xb, qkv, ctx, u, dw, amax, logp, pmax, mel, sub, total;
+};
+// N = longest [cache ; new] row count of any module, F = mel frames of the wav buffer, Fs = rows of [sub cache ; mel]
+StreamPlan make_stream_plan(const mi355asr_model* m, int N, int F, int Fs) {
+  const size_t d = m->cfg.dmodel;
+  StreamPlan p;
+  size_t o = 0;
+  auto take = [&](size_t floats) { size_t at = o; o = align256(o + floats * 4); return at; };
+  p.xa = take(N * d); p.xb = take(N * d); p.qkv = take((size_t)N * 3 * d); p.ctx = take(N * d);
+  p.u = take(N * d); p.dw = take(N * d); p.amax = take(N);
+  const int FT = ceil_div(std::max(F, 1), 16);
+  p.logp = take((size_t)std::max(F, 1) * m->dm.LP);
+  p.pmax = take((size_t)std::max(FT * m->dm.NCH_dft, F));
+  p.mel = take((size_t)std::max(F, 1) * m->cfg.n_mels);
+  p.sub = take((size_t)std::max(Fs, 1) * m->dm.F2 * d);
+  p.total = o;
+  return p;
+}
+
+// ChunkConformerBlock.stream_call (:381-388) for one stream: x (T rows) in sc.xa -> result in sc.xa.
+// new_mha [Cm+T, d] / new_cnn [Cc+T, d] receive [cache ; module input] (untrimmed).
+int run_block_stream(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int T,
+                     const float* mha_cache, int Cm, const float* cnn_cache, int Cc, float* new_mha, float* new_cnn,
+                     hipStream_t s) {
+  const int d = m->cfg.dmodel, H = m->cfg.num_heads, hs = m->cfg.head_size;
+  const int N = Cm + T, Nc = Cc + T;
+  const size_t row = (size_t)d * 4;
+  // ff_module_1: xb = xa + fc * FFN(LN(xa))
+  Chain2Args f1{};
+  f1.x = sc.xa; f1.res = sc.xa; f1.y = sc.xb;
+  f1.ln_g = w.ff_ln_g[0]; f1.ln_b = w.ff_ln_b[0];
+  f1.w1p = w.ff_w1p[0]; f1.b1 = w.ff_b1[0]; f1.w2p = w.ff_w2p[0]; f1.b2 = w.ff_b2[0];
+  f1.scale = bo.fc; f1.eps = kLnEps; f1.M = T;
+  { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_chain2(d, 0, f1, s), "ff_module_1"); }
+  // new_mha = [cache ; xb]; q/k/v of every row of it (the queries are its last T rows, :209-214)
+  if (Cm > 0) HIP_TRY(hipMemcpyAsync(new_mha, mha_cache, Cm * row, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(new_mha + (size_t)Cm * d, sc.xb, T * row, hipMemcpyDeviceToDevice, s));
+  GemmArgs q{};
+  q.x = new_mha; q.y = sc.qkv; q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.wp = w.qkv_wp; q.bias = w.qkv_b;
+  q.M = N; q.NT = 3 * d / 16; q.ldy = 3 * d; q.n_valid = 3 * d; q.eps = kLnEps;
+  q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
+  { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm_rows(d, EPI_QKV, true, q, s), "qkv projection"); }
+  AttnArgs at{};
+  at.q = sc.qkv + (size_t)Cm * 3 * d; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ctx = sc.ctx;
+  at.B = 1; at.Tq = T; at.Tk = N; at.H = H; at.D = d; at.ldq = 3 * d; at.ldk = 3 * d;
+  at.win_front = bo.win_front; at.win_back = bo.win_back; at.q_off = Cm;
+  { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
+  GemmArgs op{};
+  op.x = sc.ctx; op.y = sc.xa; op.res = sc.xb; op.wp = w.out_wp; op.bias = w.out_b;
+  op.M = T; op.NT = d / 16; op.ldy = d; op.n_valid = d; op.eps = kLnEps;
+  { PROF(MI355ASR_K_ATTN_OUT); LAUNCH_TRY(launch_gemm_rows(d, EPI_RESIDUAL, false, op, s), "attention out-projection"); }
+  // new_cnn = [cache ; xa]; the conv module runs over all of it, its last T rows are kept (:297-306)
+  if (Cc > 0) HIP_TRY(hipMemcpyAsync(new_cnn, cnn_cache, Cc * row, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(new_cnn + (size_t)Cc * d, sc.xa, T * row, hipMemcpyDeviceToDevice, s));
+  GemmArgs g{};
+  g.x = new_cnn; g.y = sc.u; g.ln_g = w.cv_ln_g; g.ln_b = w.cv_ln_b; g.wp = w.pw1_wp; g.bias = w.pw1_b;
+  g.M = Nc; g.NT = 2 * d / 16; g.ldy = d; g.n_valid = d; g.eps = kLnEps;
+  { PROF(MI355ASR_K_PW1_GLU); LAUNCH_TRY(launch_gemm_rows(d, EPI_GLU, true, g, s), "pw_conv_1 + GLU"); }
+  DwArgs dwa{};
+  dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = 1; dwa.T = Nc; dwa.D = d;
+  dwa.pad_left = bo.causal ? bo.ksz - 1 : (bo.ksz - 1) / 2;
+  { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(bo.ksz, dwa, s), "depthwise conv"); }
+  Chain2Args cv{};
+  cv.x = sc.dw + (size_t)Cc * d; cv.res = sc.xa; cv.y = sc.xb;
+  cv.w1p = w.pc_w1p; cv.b1 = w.pc_b1; cv.aff_s = w.bn_s; cv.aff_t = w.bn_t; cv.w2p = w.pw2_wp; cv.b2 = w.pw2_b;
+  cv.scale = 1.0f; cv.eps = kLnEps; cv.M = T;
+  { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_chain2(d, 1, cv, s), "conv module tail"); }
+  Chain2Args f2{};
+  f2.x = sc.xb; f2.res = sc.xb; f2.y = sc.xa;
+  f2.ln_g = w.ff_ln_g[1]; f2.ln_b = w.ff_ln_b[1];
+  f2.w1p = w.ff_w1p[1]; f2.b1 = w.ff_b1[1]; f2.w2p = w.ff_w2p[1]; f2.b2 = w.ff_b2[1];
+  f2.fln_g = w.ln_g; f2.fln_b = w.ln_b;
+  f2.scale = bo.fc; f2.eps = kLnEps; f2.M = T;
+  { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_chain2(d, 0, f2, s), "ff_module_2 + LayerNorm"); }
+  return 0;
+}
+
+// mel frames of a wav buffer / rows after the two VALID stride-2 convs over [sub cache ; last chunk_num mel frames]
+void front_stream_shape(const mi355asr_model* m, int Lw, int S, int chunk_num, int* F, int* nf, int* T1, int* T2, int* Tout) {
+  *F = (Lw - 1) / m->dm.hop + 1;
+  *nf = std::min(*F, chunk_num);
+  const int rows = S + *nf;
+  *T1 = rows >= 3 ? (rows - 3) / 2 + 1 : 0;
+  *T2 = *T1 >= 3 ? (*T1 - 3) / 2 + 1 : 0;
+  *Tout = std::min(*T2, chunk_num / m->cfg.reduction_factor);
+}
+
+const StackDev* chunk_stack_by_id(const mi355asr_model* m, int id) {
+  switch (id) {
+    case 0: return &m->c_enc;
+    case 1: return &m->c_picker;
+    case 2: return &m->c_helper;
+    case 3: return &m->c_decoder;
+  }
+  return nullptr;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1586,6 +1689,128 @@ int mi355asr_beam_destroy(mi355asr_beam* d) {
   if (!d) return 0;
   mi355asr_beam_state_free(d->st);
   delete d;
+  return 0;
+}
+// ---- ChunkConformer streaming ------------------------------------------------------------------------------
+int mi355asr_chunk_front_stream_shape(const mi355asr_model* m, int32_t Lw, int32_t S, int32_t chunk_num, int32_t* nf,
+                                      int32_t* t_out) {
+  if (!m || !m->is_chunk || !nf || !t_out) return fail(MI355ASR_EINVAL, "not a ChunkConformer handle / null argument");
+  if (Lw < 1 || S < 0 || chunk_num < m->cfg.reduction_factor)
+    return fail(MI355ASR_EINVAL, "need Lw >= 1, S >= 0, chunk_num >= reduction_factor (got %d, %d, %d)", Lw, S, chunk_num);
+  int F, T1, T2;
+  front_stream_shape(m, Lw, S, chunk_num, &F, nf, &T1, &T2, t_out);
+  return 0;
+}
+
+int mi355asr_chunk_stream_workspace_bytes(const mi355asr_model* m, int32_t max_rows, int32_t Lw, int32_t S,
+                                          int32_t chunk_num, size_t* bytes) {
+  if (!m || !m->is_chunk || !bytes) return fail(MI355ASR_EINVAL, "not a ChunkConformer handle / null argument");
+  if (max_rows < 1 || Lw < 1 || S < 0 || chunk_num < 1) return fail(MI355ASR_EINVAL, "bad sizes");
+  *bytes = make_stream_plan(m, max_rows, (Lw - 1) / m->dm.hop + 1, S + chunk_num).total;
+  return 0;
+}
+
+int mi355asr_chunk_front_stream(mi355asr_model* m, const float* wav, int32_t Lw, const float* sub_cache, int32_t S,
+                                int32_t chunk_num, float* front_out, float* new_sub, void* ws_, size_t ws_bytes,
+                                void* stream) {
+  if (!m || !m->is_chunk) return fail(MI355ASR_EINVAL, "not a ChunkConformer handle");
+  if (!m->finalized) return fail(MI355ASR_ESTATE, "weights not finalised: call mi355asr_finalize_weights first");
+  if (!wav || !front_out || !new_sub || !ws_ || (S > 0 && !sub_cache)) return fail(MI355ASR_EINVAL, "null argument");
+  if (Lw < 1 || S < 0 || chunk_num < m->cfg.reduction_factor)
+    return fail(MI355ASR_EINVAL, "need Lw >= 1, S >= 0, chunk_num >= reduction_factor (got %d, %d, %d)", Lw, S, chunk_num);
+  const auto& c = m->cfg;
+  const int d = c.dmodel;
+  int F, nf, T1, T2, Tout;
+  front_stream_shape(m, Lw, S, chunk_num, &F, &nf, &T1, &T2, &Tout);
+  const StreamPlan p = make_stream_plan(m, std::max(Tout, 1), F, S + nf);
+  if (ws_bytes < p.total) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total);
+  char* ws = (char*)ws_;
+  hipStream_t s = (hipStream_t)stream;
+  // valid Melspectrogram of the whole buffer (each call left-pads n_dft-1 zeros, as the layer does), last nf frames
+  const int FT = ceil_div(F, 16);
+  float* logp = (float*)(ws + p.logp);
+  float* mel = (float*)(ws + p.mel);
+  if (m->fft_ok) {
+    FftStftArgs fa{wav, logp, (float*)(ws + p.pmax), m->fft_w1p, m->fft_w2p, m->fft_twc, m->fft_tws, m->fft_win,
+                   1, Lw, F, m->dm.hop, c.n_dft - 1, m->dm.LP, 0};
+    PROF(MI355ASR_K_STFT);
+    LAUNCH_TRY(launch_fft_stft(fa, s), "stft (valid, fft)");
+  } else {
+    StftArgs st{};
+    st.wav = wav; st.logp = logp; st.pmax = (float*)(ws + p.pmax); st.wp = m->dft_wp;
+    st.B = 1; st.L = Lw; st.F = F; st.hop = m->dm.hop; st.pad_left = c.n_dft - 1; st.n_dft = c.n_dft;
+    st.NT = m->dm.NT_dft; st.LP = m->dm.LP; st.nbins = m->dm.nbins; st.FT = FT; st.NCH = m->dm.NCH_dft;
+    st.db10 = 0;
+    PROF(MI355ASR_K_STFT);
+    LAUNCH_TRY(launch_stft(st, s), "stft (valid)");
+  }
+  MelArgs me{};
+  me.logp = logp; me.umax = nullptr; me.mel = mel; me.wp = m->mel_wp;
+  me.B = 1; me.F = F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
+  me.NM = c.n_mels; me.FT = FT; me.floor_db = 0.f;
+  { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel(me, s), "mel (valid)"); }
+  // new_sub = [sub cache ; last nf mel frames]  (ConvSubsampling.stream_call :75)
+  const size_t mrow = (size_t)c.n_mels * 4;
+  if (S > 0) HIP_TRY(hipMemcpyAsync(new_sub, sub_cache, S * mrow, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(new_sub + (size_t)S * c.n_mels, mel + (size_t)(F - nf) * c.n_mels, nf * mrow,
+                         hipMemcpyDeviceToDevice, s));
+  if (Tout < 1) return 0;
+  // pad 2/2 on the mel axis only, two VALID 3x3 stride-2 convs, last Tout frames, Dense (:77-89)
+  SubConvArgs sa{};
+  sa.mel = new_sub; sa.out = (float*)(ws + p.sub); sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
+  sa.B = 1; sa.F = S + nf; sa.NM = c.n_mels; sa.T1 = T1; sa.F1 = m->dm.F1; sa.T2 = T2; sa.F2 = m->dm.F2;
+  sa.st1 = 2; sa.pt1 = 0; sa.pf1 = 2; sa.pt2 = 0; sa.pf2 = 0;
+  { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling (stream)"); }
+  StreamGemmArgs lg{};
+  lg.x = sa.out + (size_t)(T2 - Tout) * m->dm.F2 * d; lg.y = front_out; lg.wp = m->lin_wp; lg.bias = m->lin_b;
+  lg.M = Tout; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.ldy = d; lg.n_valid = d;
+  { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear"); }
+  return 0;
+}
+
+int mi355asr_chunk_stack_stream(mi355asr_model* m, int32_t stack, const float* x, int32_t T, const float* mha_cache,
+                                int32_t Cm, const float* cnn_cache, int32_t Cc, float* hidden, float* logits,
+                                int32_t* amax, float* new_mha, float* new_cnn, void* ws_, size_t ws_bytes,
+                                void* stream) {
+  if (!m || !m->is_chunk) return fail(MI355ASR_EINVAL, "not a ChunkConformer handle");
+  if (!m->finalized) return fail(MI355ASR_ESTATE, "weights not finalised: call mi355asr_finalize_weights first");
+  const StackDev* st = chunk_stack_by_id(m, stack);
+  if (!st) return fail(MI355ASR_EINVAL, "stack=%d: 0 encoder, 1 picker, 2 helper, 3 decoder", stack);
+  if (!x || !hidden || !new_mha || !new_cnn || !ws_ || (Cm > 0 && !mha_cache) || (Cc > 0 && !cnn_cache))
+    return fail(MI355ASR_EINVAL, "null argument");
+  if (T < 1 || Cm < 0 || Cc < 0) return fail(MI355ASR_EINVAL, "need T >= 1, Cm >= 0, Cc >= 0 (got %d, %d, %d)", T, Cm, Cc);
+  if ((logits || amax) && !st->fc_wp) return fail(MI355ASR_EINVAL, "stack %d has no fully_connected head", stack);
+  const int d = m->cfg.dmodel;
+  const int N = std::max(Cm, Cc) + T;
+  const StreamPlan p = make_stream_plan(m, N, 1, 1);
+  if (ws_bytes < p.total) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total);
+  char* ws = (char*)ws_;
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
+             (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
+  if (st->proj_wp) {
+    GemmArgs pr{};
+    pr.x = x; pr.y = sc.xa; pr.wp = st->proj_wp; pr.bias = st->proj_b;
+    pr.M = T; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
+    { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "project"); }
+  } else {
+    HIP_TRY(hipMemcpyAsync(sc.xa, x, (size_t)T * d * 4, hipMemcpyDeviceToDevice, s));
+  }
+  const size_t nb = st->blocks.size();
+  for (size_t i = 0; i < nb; ++i) {
+    int rc = run_block_stream(m, st->blocks[i], st->opts, sc, T, mha_cache ? mha_cache + i * (size_t)Cm * d : nullptr, Cm,
+                              cnn_cache ? cnn_cache + i * (size_t)Cc * d : nullptr, Cc,
+                              new_mha + i * (size_t)(Cm + T) * d, new_cnn + i * (size_t)(Cc + T) * d, s);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(hidden, sc.xa, (size_t)T * d * 4, hipMemcpyDeviceToDevice, s));
+  if (st->fc_wp && (logits || amax)) {
+    GemmArgs hd{};
+    hd.x = sc.xa; hd.y = logits; hd.wp = st->fc_wp; hd.bias = st->fc_b;
+    hd.M = T; hd.NT = st->NT_fc; hd.ldy = st->num_classes; hd.n_valid = st->num_classes; hd.eps = kLnEps;
+    hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
+    { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "fully_connected"); }
+  }
   return 0;
 }
 }  // extern "C"

@@ -490,10 +490,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a)
   const bool band = a.win_front >= 0;
   int klo = 0, khi = T - 1, kbeg = 0, kend = T;
   if (band) {
-    const int iq = min(tq, T - 1);
+    const int iq = a.q_off + min(tq, TQ - 1);
     klo = min(max(iq - a.win_front, 0), T - a.win_back);
     khi = max(min(iq + a.win_back, T), a.win_back);
-    const int i0 = qt * 16, i1 = min(qt * 16 + 15, T - 1);
+    const int i0 = a.q_off + qt * 16, i1 = a.q_off + min(qt * 16 + 15, TQ - 1);
     const int lo0 = min(max(i0 - a.win_front, 0), T - a.win_back);        // lo() and hi() are non-decreasing in i
     const int hi1 = min(max(min(i1 + a.win_back, T), a.win_back), T - 1);
     kbeg = (max(lo0, 0) / 16) * 16;

@@ -55,6 +55,8 @@ struct AttnArgs {
   const float *q, *k, *v;
   float* ctx;        // [B*Tq, D]
   int B, Tq, Tk, H, D, ldq, ldk;
+  int q_off = 0;     // band mask only: query row tq is sequence position q_off + tq of the Tk keys (streaming: the
+                     // queries are the last Tq rows of [cache ; new], chunk_conformer_blocks.py:209-214)
   // band attention of the ChunkConformer (chunk_conformer_blocks.py:158-176): query i sees keys
   // [min(max(i-win_front,0), T-win_back), max(min(i+win_back,T), win_back)]; win_front < 0 = full attention
   // (band attention is self-attention only: Tq == Tk == T)

@@ -714,6 +714,7 @@ class ChunkConformer(_ModelBase):
         self.sample_rate, self.n_mels = fr["sample_rate"], fr["n_mels"]
         self.phone_num_classes, self.txt_num_classes = phone, txt
         self.blocks = {"encoder": en["num_blocks"], "picker": pk["num_blocks"], "helper": hp["num_blocks"], "decoder": dc["num_blocks"]}
+        self._config = config
         self._weights = None
         cfg = _lib.ChunkConfig(
             dmodel=en["dmodel"], head_size=en["head_size"], num_heads=en["num_heads"], kernel_size=en["kernel_size"],
@@ -791,3 +792,150 @@ class ChunkConformer(_ModelBase):
         return r
 
     __call__ = predict
+
+    # ---- streaming with explicit caches (chunk_conformer_blocks.py:799-866; single stream, B = 1) -----------------
+    def _stream_cfg(self):
+        mc = self._config["model_config"]
+        fr = mc["ChunkConformerFront"]
+        chunk_num = int(fr.get("chunk_num", 16))
+        hop = int(fr["stride_ms"] * fr["sample_rate"] // 1000)
+        win = {k: (mc[n]["win_front"], mc[n]["win_back"]) for k, n in (("encoder", "ChunkConformerEncoder"),
+               ("picker", "ChunkCTCPicker"), ("helper", "ContextHelper"), ("decoder", "ChunkCTCDecoder"))}
+        return chunk_num, hop, chunk_num // fr["reduction_factor"], win
+
+    def init_picker_caches(self, B=1):
+        """(front_wav_cache, front_sub_cache, encoder_mha_cache, encoder_cnn_cache, picker_mha_cache,
+        picker_cnn_cache, dec_inp) as ChunkConformer.init_picker_caches (:799-808)."""
+        if B != 1:
+            raise NotImplementedError("the streaming entry points are single-stream, as the reference's (dec_inp is [1, 0, d])")
+        dev, d = self._h.device, self.dmodel
+        _, _, sub_length, _ = self._stream_cfg()
+        z = lambda n: torch.zeros((n, 1, 0, d), dtype=torch.float32, device=dev)
+        return (torch.zeros((1, 0, 1), device=dev), torch.zeros((1, sub_length, self.n_mels, 1), device=dev),
+                z(self.blocks["encoder"]), z(self.blocks["encoder"]), z(self.blocks["picker"]), z(self.blocks["picker"]),
+                torch.zeros((1, 0, d), device=dev))
+
+    def init_decoder_caches(self, B=1):
+        """(helper_mha_cache, helper_cnn_cache, decoder_mha_cache, decoder_cnn_cache, dec_inp) (:810-814)."""
+        if B != 1:
+            raise NotImplementedError("the streaming entry points are single-stream, as the reference's")
+        dev, d = self._h.device, self.dmodel
+        z = lambda n: torch.zeros((n, 1, 0, d), dtype=torch.float32, device=dev)
+        return (z(self.blocks["helper"]), z(self.blocks["helper"]), z(self.blocks["decoder"]), z(self.blocks["decoder"]),
+                torch.zeros((1, 0, d), device=dev))
+
+    def _stream_ws(self, max_rows, Lw, S, chunk_num):
+        h = self._h
+        n = ctypes.c_size_t()
+        _lib.check(h.lib.mi355asr_chunk_stream_workspace_bytes(h.ptr, int(max_rows), int(max(Lw, 1)), int(S), int(chunk_num),
+                                                               ctypes.byref(n)))
+        return h.workspace(n.value), n.value
+
+    def _stack_stream(self, stack, x, mha_caches, cnn_caches, want_logits):
+        """one *.stream_call up to the valid/unvalid slicing: x [1,T,d], caches [nblk,1,C,d] -> hidden [1,T,d],
+        logits [1,T,V] or None, new (untrimmed) caches [nblk,1,C+T,d]."""
+        h = self._h
+        nblk, _, Cm, d = mha_caches.shape
+        Cc = cnn_caches.shape[2]
+        T = x.shape[1]
+        dev = h.device
+        x = x.contiguous()
+        mha_caches, cnn_caches = mha_caches.contiguous(), cnn_caches.contiguous()
+        hidden = torch.empty((1, T, d), dtype=torch.float32, device=dev)
+        V = {1: self.phone_num_classes, 3: self.txt_num_classes}.get(stack)
+        logits = torch.empty((1, T, V), dtype=torch.float32, device=dev) if (want_logits and V) else None
+        new_mha = torch.empty((nblk, 1, Cm + T, d), dtype=torch.float32, device=dev)
+        new_cnn = torch.empty((nblk, 1, Cc + T, d), dtype=torch.float32, device=dev)
+        ws, n = self._stream_ws(max(Cm, Cc) + T, 1, 0, 16)
+        with torch.cuda.device(dev):
+            _lib.check(h.lib.mi355asr_chunk_stack_stream(h.ptr, stack, _p(x), T, _p(mha_caches) if Cm else None, Cm,
+                                                         _p(cnn_caches) if Cc else None, Cc, _p(hidden), _p(logits), None,
+                                                         _p(new_mha), _p(new_cnn), _p(ws), n, h._stream()))
+        return hidden, logits, new_mha, new_cnn
+
+    def _stack_stream_call(self, name, stack, x, mha_caches, cnn_caches, head):
+        """ChunkConformerEncoder / ChunkCTCDecoder / ContextHelper .stream_call including the slicing (:546-558,
+        660-672, 764-770) -> (valid_logits, valid_hidden, new_mha, new_cnn, unvalid_logits)."""
+        _, _, _, win = self._stream_cfg()
+        wf, wb = win[name]
+        k = self.kernel_size
+        hidden, logits, new_mha, new_cnn = self._stack_stream(stack, x, mha_caches, cnn_caches, head)
+        if wb != 0:
+            cut = lambda a, ax: a.narrow(ax, 0, max(a.shape[ax] - wb, 0))
+            valid_hidden = cut(hidden, 1)
+            valid_logits = cut(logits, 1) if head else None
+            unvalid = logits[:, -wb:] if head else None
+            new_mha, new_cnn = cut(new_mha, 2), cut(new_cnn, 2)
+        else:
+            valid_hidden, valid_logits = hidden, logits
+            unvalid = torch.zeros_like(logits) if head else None
+        return valid_logits, valid_hidden, new_mha[:, :, -wf:], new_cnn[:, :, -k:], unvalid
+
+    def picker_stream_predict(self, input_wav, caches):
+        """ChunkConformer.picker_stream_predict (:824-842): input_wav [1, L, 1] (the reference feeds chunk_num * hop
+        = 2560 samples per call) -> (valid_ctc_out, unvalid_ctc_out, valid_hidden_out, caches)."""
+        h = self._h
+        if not h.built:
+            self._build()
+        front_wav_cache, front_sub_cache, enc_mha, enc_cnn, pk_mha, pk_cnn, dec_inp = caches
+        chunk_num, hop, sub_length, _ = self._stream_cfg()
+        dev, d = h.device, self.dmodel
+        wav = _wave2d(h, input_wav)
+        if wav.shape[0] != 1:
+            raise NotImplementedError("single stream only")
+        new_wav = torch.cat([front_wav_cache.reshape(1, -1), wav], 1).contiguous()          # :449
+        Lw = new_wav.shape[1]
+        sub = front_sub_cache.reshape(1, -1, self.n_mels).contiguous()
+        S = sub.shape[1]
+        nf, tout = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(h.lib.mi355asr_chunk_front_stream_shape(h.ptr, Lw, S, chunk_num, ctypes.byref(nf), ctypes.byref(tout)))
+        front = torch.empty((1, tout.value, d), dtype=torch.float32, device=dev)
+        new_sub = torch.empty((1, S + nf.value, self.n_mels), dtype=torch.float32, device=dev)
+        ws, n = self._stream_ws(max(tout.value, 1), Lw, S, chunk_num)
+        with torch.cuda.device(dev):
+            _lib.check(h.lib.mi355asr_chunk_front_stream(h.ptr, _p(new_wav), Lw, _p(sub) if S else None, S, chunk_num,
+                                                         _p(front), _p(new_sub), _p(ws), n, h._stream()))
+        new_wav_cache = new_wav[:, -chunk_num * hop:].reshape(1, -1, 1)                       # :456
+        new_sub_cache = new_sub[:, -sub_length:].reshape(1, -1, self.n_mels, 1)               # :457
+        if tout.value == 0:
+            empty = torch.zeros((1, 0, self.phone_num_classes), device=dev)
+            return empty, empty, torch.zeros((1, 0, d), device=dev), (new_wav_cache, new_sub_cache, enc_mha, enc_cnn,
+                                                                    pk_mha, pk_cnn, dec_inp)
+        _, valid_enc, enc_mha, enc_cnn, _ = self._stack_stream_call("encoder", 0, front, enc_mha, enc_cnn, False)
+        dec_inp = torch.cat([dec_inp, valid_enc], 1)                                          # :830
+        if dec_inp.shape[1] == 0:
+            empty = torch.zeros((1, 0, self.phone_num_classes), device=dev)
+            return empty, empty, dec_inp, (new_wav_cache, new_sub_cache, enc_mha, enc_cnn, pk_mha, pk_cnn, dec_inp)
+        valid_ctc, valid_hidden, pk_mha, pk_cnn, unvalid_ctc = self._stack_stream_call("picker", 1, dec_inp, pk_mha, pk_cnn, True)
+        dec_inp = dec_inp[:, valid_ctc.shape[1]:]                                             # :833-834
+        return valid_ctc, unvalid_ctc, valid_hidden, (new_wav_cache, new_sub_cache, enc_mha, enc_cnn, pk_mha, pk_cnn, dec_inp)
+
+    def decoder_stream_predict(self, valid_enc_out, caches):
+        """ChunkConformer.decoder_stream_predict (:844-857): picked features [1, Tp, d] -> (valid_ctc_out,
+        unvalid_ctc_out, caches)."""
+        h = self._h
+        helper_mha, helper_cnn, dec_mha, dec_cnn, dec_inp = caches
+        x = h.to_device(valid_enc_out)
+        _, helped, helper_mha, helper_cnn, _ = self._stack_stream_call("helper", 2, x, helper_mha, helper_cnn, False)
+        dec_inp = torch.cat([dec_inp, helped], 1)
+        valid_ctc, _, dec_mha, dec_cnn, unvalid_ctc = self._stack_stream_call("decoder", 3, dec_inp, dec_mha, dec_cnn, True)
+        dec_inp = dec_inp[:, valid_ctc.shape[1]:]
+        return valid_ctc, unvalid_ctc, (helper_mha, helper_cnn, dec_mha, dec_cnn, dec_inp)
+
+    def feature_pick(self, encoder_hidden_states, ctc_outs, max_T=None):
+        """ChunkConformer.feature_pick (:913-999): keep the frames whose argmax is not the blank, compacted per
+        utterance, zero padded to the batch maximum -> (feature_outputs [B,Tp,d], ctc_outputs [B,Tp,V])."""
+        hid = self._h.to_device(encoder_hidden_states)
+        ctc = self._h.to_device(ctc_outs)
+        keep = ctc.argmax(-1) != (self.phone_num_classes - 1)
+        counts = keep.sum(-1)
+        Tp = int(counts.max().item()) if counts.numel() else 0
+        if max_T is not None:
+            Tp = max(Tp, int(max_T))
+        f = torch.zeros((hid.shape[0], Tp, hid.shape[-1]), dtype=hid.dtype, device=hid.device)
+        c = torch.zeros((ctc.shape[0], Tp, ctc.shape[-1]), dtype=ctc.dtype, device=ctc.device)
+        for b in range(hid.shape[0]):
+            n = int(counts[b].item())
+            f[b, :n] = hid[b][keep[b]]
+            c[b, :n] = ctc[b][keep[b]]
+        return f, c

@@ -626,3 +626,69 @@ def test_am_tester_metrics_match_oracle_pipeline(torch_cuda, tmp_path):
     assert r["phone_s_i_d"] == "%d_%d_%d" % tuple(n[1:]) and r["trans_s_i_d"] == "%d_%d_%d" % tuple(m[1:])
     assert abs(r["phone_cer"] - sum(n[1:]) / (n[0] + 1e-6)) < 1e-12 and abs(r["txt_cer"] - sum(m[1:]) / (m[0] + 1e-6)) < 1e-12
     assert r["phone_ser"] == np.mean(ser) and r["steps"] == 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ChunkConformer streaming with explicit caches (chunk_conformer_blocks.py:799-866)
+# ---------------------------------------------------------------------------------------------------------
+def _stream_oracle(x, w, cfg, nchunks, samples):
+    pc, dc = co.chunk_init_picker_caches(cfg), co.chunk_init_decoder_caches(cfg)
+    ph, hid, txt, unv, steps = [], [], [], None, []
+    for i in range(nchunks):
+        vp, _, vh, pc = co.chunk_picker_stream_predict(x[:, i * samples:(i + 1) * samples], pc, w, cfg)
+        if vp.shape[1] == 0:
+            continue
+        ph.append(vp); hid.append(vh)
+        f, _ = co.feature_pick(vh, vp, cfg["picker_num_classes"] - 1)
+        if f.shape[1] != 0:
+            vt, unv, dc = co.chunk_decoder_stream_predict(f, dc, w, cfg)
+            txt.append(vt)
+            steps.append((i, vt.shape[1]))
+    return np.concatenate(ph, 1), np.concatenate(hid, 1), np.concatenate(txt, 1), unv, pc, dc, steps
+
+
+@pytest.mark.parametrize("samples,nchunks", [(2560, 30), (5120, 9)])
+def test_chunk_conformer_streaming_matches_oracle_and_offline(torch_cuda, samples, nchunks):
+    """picker_stream_predict / feature_pick / decoder_stream_predict fed chunk by chunk, as test_chunk_asr.py:60-83
+    drives them: every valid output against the oracle's restatement of the stream_call chain, the final caches
+    against the oracle's, and -- the point of the cache design -- against the OFFLINE predict of the whole signal."""
+    cfg = dict(co.CHUNK_S, enc_num_blocks=2, picker_num_classes=30, decoder_num_classes=40)
+    w = co.chunk_weights(cfg, seed=3)
+    x = waves(1, samples * nchunks, 5)
+    w["picker/fully_connected/bias"][-1] = _pick_bias_for_ragged_counts(cfg, w, x)
+    ref_ph, ref_hid, ref_txt, ref_unv, rpc, rdc, rsteps = _stream_oracle(x.astype(np.float64), w, cfg, nchunks, samples)
+    m = _chunk_model(cfg, w)
+    caches, caches2 = m.init_picker_caches(1), m.init_decoder_caches(1)
+    ph, txt, steps, unv = [], [], [], None
+    for i in range(nchunks):
+        vp, _, vh, caches = m.picker_stream_predict(x[:, i * samples:(i + 1) * samples, None], caches)
+        if vp.shape[1] == 0:
+            continue
+        ph.append(vp)
+        f, _ = m.feature_pick(vh, vp)
+        if f.shape[1] != 0:
+            vt, unv, caches2 = m.decoder_stream_predict(f, caches2)
+            txt.append(vt)
+            steps.append((i, vt.shape[1]))
+    ph = torch_cuda.cat(ph, 1).cpu().numpy()
+    txt = torch_cuda.cat(txt, 1).cpu().numpy()
+    assert steps == rsteps                                           # same picks at every step
+    assert ph.shape == ref_ph.shape and maxdiff(ph, ref_ph) < TOL
+    assert txt.shape == ref_txt.shape and maxdiff(txt, ref_txt) < TOL
+    assert maxdiff(unv.cpu().numpy(), ref_unv) < TOL
+    # caches: window lengths and contents
+    assert caches[0].shape == (1, 2560, 1) and caches[1].shape == (1, 4, 80, 1)
+    assert caches[2].shape == (2, 1, 36, 144) and caches[3].shape == (2, 1, 32, 144)
+    assert maxdiff(caches[2][1, 0].cpu().numpy(), rpc["enc_mha"][1][0]) < TOL
+    assert maxdiff(caches[3][0, 0].cpu().numpy(), rpc["enc_cnn"][0][0]) < TOL
+    assert maxdiff(caches[1][0, :, :, 0].cpu().numpy(), rpc["front_sub"][0]) < TOL
+    assert caches2[4].shape[1] == rdc["dec_inp"].shape[1] == 8        # decoder win_back rows wait for right context
+    assert maxdiff(caches2[2][0, 0].cpu().numpy(), rdc["decoder_mha"][0][0]) < TOL
+    if samples != 2560:
+        return      # feeding more than chunk_num * hop samples per call drops mel frames (:452), by the reference's design
+    # streaming == offline on the same signal
+    off = m.predict(x, stages=True)
+    assert maxdiff(ph, off["picker_logits"].cpu().numpy()) < TOL
+    n = txt.shape[1]
+    assert maxdiff(txt, off["text_logits"].cpu().numpy()[:, :n]) < TOL
+    assert n == off["text_logits"].shape[1] - 8

@@ -230,3 +230,36 @@ def test_positional_encoding_known_values_and_translator_shapes():
     # ... and the encoder output is only seen through the cross-attention (permuting its frames changes nothing)
     yp = co.translator(ids[:1], enc[:1, ::-1], w, cfg)
     assert np.abs(yp - y[:1]).max() < 1e-9
+
+
+def test_chunk_streaming_restatement_equals_offline_predict():
+    """The cache design of chunk_conformer_blocks.py:799-866: feeding chunk_num * hop = 2560 samples per call with
+    the caches carried over reproduces the offline predict() -- picker logits on every frame, text logits on every
+    frame that has its win_back = 8 frames of right context."""
+    cfg = dict(co.CHUNK_S, enc_num_blocks=1, picker_num_classes=12, decoder_num_classes=15)
+    w = co.chunk_weights(cfg, seed=4)
+    n = 22
+    x = co.synth_wave(2, length=2560 * n)[None]
+    z = co.chunk_predict(x, w, cfg)["picker_logits"]
+    gap = np.sort(z[..., :-1].max(-1) - z[..., -1], axis=None)
+    w["picker/fully_connected/bias"][-1] = 0.5 * (gap[gap.size // 3] + gap[gap.size // 3 + 1])   # ~2/3 of the frames kept
+    off = co.chunk_predict(x, w, cfg)
+    pc, dc = co.chunk_init_picker_caches(cfg), co.chunk_init_decoder_caches(cfg)
+    ph, txt, unv = [], [], None
+    for i in range(n):
+        vp, _, vh, pc = co.chunk_picker_stream_predict(x[:, i * 2560:(i + 1) * 2560], pc, w, cfg)
+        assert vp.shape[1] == 4                                   # 16 mel frames -> 4 encoder frames per call
+        ph.append(vp)
+        f, _ = co.feature_pick(vh, vp, cfg["picker_num_classes"] - 1)
+        if f.shape[1]:
+            vt, unv, dc = co.chunk_decoder_stream_predict(f, dc, w, cfg)
+            txt.append(vt)
+    assert np.abs(np.concatenate(ph, 1) - off["picker_logits"]).max() < 1e-10
+    txt = np.concatenate(txt, 1)
+    assert 0 < off["counts"][0] < 4 * n                           # the picker drops some frames
+    assert txt.shape[1] == off["text_logits"].shape[1] - 8
+    assert np.abs(txt - off["text_logits"][:, :txt.shape[1]]).max() < 1e-10
+    assert np.abs(unv - off["text_logits"][:, -8:]).max() < 1e-10
+    # caches are cut to the attention window / conv kernel / carry-over lengths
+    assert pc["enc_mha"][0].shape[1] == 36 and pc["enc_cnn"][0].shape[1] == 32 and pc["front_wav"].shape[1] == 2560
+    assert dc["dec_inp"].shape[1] == 8 and pc["dec_inp"].shape[1] == 0
