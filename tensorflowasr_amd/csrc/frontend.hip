@@ -313,28 +313,44 @@ __global__ __launch_bounds__(BLOCK_THREADS) void stream_gemm_kernel(StreamGemmAr
   const int tok = wid * 16 + c;
   const float* __restrict__ xr = a.x + (size_t)min(tok, a.M - 1) * a.K + g4;
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wp) + lane;
+  const int c0 = blockIdx.y * CT;        // first column tile of this wave (grid.y > 1: few rows, columns split)
   f32x4 acc[1][CT];
 #pragma unroll
-  for (int i = 0; i < CT; ++i) acc[0][i] = ldg4(a.bias + 16 * i + g4);
+  for (int i = 0; i < CT; ++i) acc[0][i] = ldg4(a.bias + 16 * (c0 + i) + g4);
   const int KBT = a.K / 16;
   auto xp = [&](int, int kb) -> f32x4 { return ldg4(xr + 16 * kb); };
-  sweep_k<1, CT>(acc, wp, a.NT, 0, KBT, xp, [](int, int, f32x4 x) { return x; });
+  sweep_k<1, CT>(acc, wp, a.NT, c0, KBT, xp, [](int, int, f32x4 x) { return x; });
   if (tok < a.M) {
     float* orow = a.y + (size_t)tok * a.ldy;
 #pragma unroll
     for (int i = 0; i < CT; ++i)
-      if (16 * i + g4 + 3 < a.n_valid) stg4(orow + 16 * i + g4, acc[0][i]);
+      if (16 * (c0 + i) + g4 + 3 < a.n_valid) stg4(orow + 16 * (c0 + i) + g4, acc[0][i]);
   }
 }
 
 int launch_stream_gemm(int D, const StreamGemmArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
-  dim3 grid((tiles + 3) / 4);
   if (a.K % 32 != 0) return -1;   // sweep_k consumes k-blocks in pairs
-  if (D == 144 && a.NT == 9) hipLaunchKernelGGL((stream_gemm_kernel<9>), grid, dim3(BLOCK_THREADS), 0, s, a);
-  else if (D == 256 && a.NT == 16) hipLaunchKernelGGL((stream_gemm_kernel<16>), grid, dim3(BLOCK_THREADS), 0, s, a);
-  else return -1;
-  return 0;
+  // One wave owns 16 rows x CT column tiles over the whole K.  With few rows (streaming: 64 chunks x 13 frames =
+  // 52 row tiles, K = 5120) that leaves most SIMDs idle for the length of one very long wave, so the columns are
+  // split over grid.y until there is about a wave per SIMD; the rows are then re-read NT/CT times (from L2).
+#define SG(CTV) do { dim3 grid((tiles + 3) / 4, a.NT / (CTV)); \
+    hipLaunchKernelGGL((stream_gemm_kernel<CTV>), grid, dim3(BLOCK_THREADS), 0, s, a); return 0; } while (0)
+  const int want = 1024;          // SIMDs
+  if (D == 144 && a.NT == 9) {
+    if (tiles >= want) SG(9);
+    if (tiles * 3 >= want) SG(3);
+    SG(1);
+  }
+  if (D == 256 && a.NT == 16) {
+    if (tiles >= want) SG(16);
+    if (tiles * 2 >= want) SG(8);
+    if (tiles * 4 >= want) SG(4);
+    if (tiles * 8 >= want) SG(2);
+    SG(1);
+  }
+#undef SG
+  return -1;
 }
 
 // ---------------------------------------------------------------------------------------------------
