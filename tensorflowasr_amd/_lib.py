@@ -108,6 +108,9 @@ def lib():
             raise Mi355AsrError(
                 "libmi355asr.so not found at %s -- build it with `python -m tensorflowasr_amd.build` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # torch first: its wheel bundles its own libamdhip64; loading ours before it would bring a second HIP runtime
+        # into the process (the one under /opt/rocm) and device memory from one is invisible to the other
+        import torch  # noqa: F401
         h = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
