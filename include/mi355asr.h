@@ -57,6 +57,9 @@ typedef struct {
   int32_t ctc_num_blocks;    /* model_config.ctcdecoder_num_blocks        1                    */
   int32_t ctc_kernel_size;   /* model_config.ctcdecoder_kernel_size       32                   */
   float   ctc_fc_factor;     /* model_config.ctcdecoder_fc_factor         0.5                  */
+  int32_t gemm_dtype;        /* 0: fp32 MFMA everywhere (the reference's arithmetic; default)
+                              * 1: bf16 MFMA for the dense layers -- bf16 GEMM inputs, fp32 accumulation, fp32
+                              *    LayerNorm / softmax / activations / frontend (BASELINE config 3)               */
 } mi355asr_config;
 
 const char* mi355asr_last_error(void);

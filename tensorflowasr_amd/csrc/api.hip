@@ -103,6 +103,9 @@ struct mi355asr_model {
   bool finalized = false;
   float* arena = nullptr;
   size_t arena_floats = 0;
+  // gemm_dtype 1: the whole arena again in bf16 (same element offsets; packed matrices keep their fragment order)
+  unsigned short* arena16 = nullptr;
+  const void* w16(const float* p) const { return arena16 + (p - arena); }
   const float *dft_wp = nullptr, *mel_wp = nullptr, *c1_w = nullptr, *c1_b = nullptr, *c2_wp = nullptr,
               *c2_b = nullptr, *lin_wp = nullptr, *lin_b = nullptr, *proj_wp = nullptr, *proj_b = nullptr,
               *fc_wp = nullptr, *fc_b = nullptr;
@@ -408,7 +411,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
 
 // ---- workspace plan (byte offsets, 256-byte aligned) --------------------------------------------------
 struct Plan {
-  size_t xa, xb, qkv, ctx, u, dw, enc, amax, logp, pmax, umax, mel, sub, total;
+  size_t xa, xb, qkv, ctx, u, dw, enc, amax, logp, pmax, umax, mel, sub, h4, total;
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -431,6 +434,7 @@ Plan make_plan(const mi355asr_model* m, int Bp, int F, int T) {
   p.ctx = take(M * d);
   p.u = take(M * d);
   p.dw = take(M * d);
+  p.h4 = m->cfg.gemm_dtype == 1 ? take(M * 4 * d) : 0;   // before logp: the block-only entry points size to p.logp
   p.enc = take(M * d);
   p.amax = take(M);
   const int FT = ceil_div(F, 16);
@@ -469,6 +473,7 @@ int geometry(const mi355asr_model* m, int B, int L, Geometry* g) {
 // ---- launch sequences ---------------------------------------------------------------------------------
 struct Scratch {
   float *xa, *xb, *qkv, *ctx, *u, *dw;
+  float* h4 = nullptr;   // [M, 4d] FFN hidden (bf16 GEMM path only: its layers are separate launches)
 };
 
 // One ConformerBlock (conformer_blocks.py:259-265).  Input in sc.xa, output to `out` (or sc.xa if null).
@@ -490,6 +495,51 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
   const float fc = bo.fc;
   const int M = B * T;
   static const bool fused_env = [] { const char* v = getenv("MI355ASR_FUSED"); return v ? atoi(v) != 0 : true; }();
+  if (m->cfg.gemm_dtype == 1 && !cross) {
+    // bf16 MFMA for every dense layer (bf16.hip); LayerNorm / softmax / activations / depthwise conv in fp32
+    auto g16 = [&](const float* x, int ldx, int K, const float* wp, const float* bias, int NT, float* y, int ldy) {
+      Gemm16Args g{};
+      g.x = x; g.ldx = ldx; g.K = K; g.wp = m->w16(wp); g.bias = bias; g.NT = NT; g.y = y; g.ldy = ldy;
+      g.M = M; g.n_valid = 16 * NT; g.eps = kLnEps; g.scale = 1.0f;
+      return g;
+    };
+    auto ffn = [&](int i, const float* x, float* y, const float* fg, const float* fb) -> int {
+      Gemm16Args a1 = g16(x, d, d, w.ff_w1p[i], w.ff_b1[i], 4 * d / 16, sc.h4, 4 * d);
+      a1.ln_g = w.ff_ln_g[i]; a1.ln_b = w.ff_ln_b[i];
+      { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_gemm16_bf16(E16_SWISH, true, a1, s), "ffn1 (bf16)"); }
+      Gemm16Args a2 = g16(sc.h4, 4 * d, 4 * d, w.ff_w2p[i], w.ff_b2[i], d / 16, y, d);
+      a2.res = x; a2.scale = fc; a2.fln_g = fg; a2.fln_b = fb;
+      { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_gemm16_bf16(E16_RES, false, a2, s), "ffn2 (bf16)"); }
+      return 0;
+    };
+    int rc = ffn(0, sc.xa, sc.xb, nullptr, nullptr);
+    if (rc) return rc;
+    Gemm16Args q = g16(sc.xb, d, d, w.qkv_wp, w.qkv_b, 3 * d / 16, sc.qkv, 3 * d);
+    q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
+    { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm16_bf16(E16_QKV, true, q, s), "qkv (bf16)"); }
+    AttnArgs at{};
+    at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ctx = sc.ctx;
+    at.B = B; at.Tq = T; at.Tk = T; at.H = H; at.D = d; at.ldq = 3 * d; at.ldk = 3 * d;
+    at.win_front = bo.win_front; at.win_back = bo.win_back;
+    { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
+    Gemm16Args op = g16(sc.ctx, d, d, w.out_wp, w.out_b, d / 16, sc.xa, d);
+    op.res = sc.xb;
+    { PROF(MI355ASR_K_ATTN_OUT); LAUNCH_TRY(launch_gemm16_bf16(E16_RES, false, op, s), "attention out (bf16)"); }
+    Gemm16Args gl = g16(sc.xa, d, d, w.pw1_wp, w.pw1_b, 2 * d / 16, sc.u, d);
+    gl.ln_g = w.cv_ln_g; gl.ln_b = w.cv_ln_b; gl.n_valid = d;
+    { PROF(MI355ASR_K_PW1_GLU); LAUNCH_TRY(launch_gemm16_bf16(E16_GLU, true, gl, s), "pw_conv_1 + GLU (bf16)"); }
+    DwArgs dwa{};
+    dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
+    dwa.pad_left = bo.causal ? ksz - 1 : (ksz - 1) / 2;
+    { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
+    Gemm16Args pc = g16(sc.dw, d, d, w.pc_w1p, w.pc_b1, 2 * d / 16, sc.h4, 2 * d);
+    pc.aff_s = w.bn_s; pc.aff_t = w.bn_t;
+    { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_gemm16_bf16(E16_AFFSWISH, false, pc, s), "pointwise + BN + swish (bf16)"); }
+    Gemm16Args p2 = g16(sc.h4, 2 * d, 2 * d, w.pw2_wp, w.pw2_b, d / 16, sc.xb, d);
+    p2.res = sc.xa;
+    { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_gemm16_bf16(E16_RES, false, p2, s), "pw_conv_2 (bf16)"); }
+    return ffn(1, sc.xb, out ? out : sc.xa, w.ln_g, w.ln_b);
+  }
   if (d == 144 && fused_env && !cross) {
     // token-local runs of layers in one launch each (fused.hip); attention and the depthwise conv mix tokens
     const float qscale = 1.0f / std::sqrt((float)hs);
@@ -633,6 +683,13 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   sa.B = Bp; sa.F = F; sa.NM = c.n_mels; sa.T1 = T1; sa.F1 = m->dm.F1; sa.T2 = T2; sa.F2 = m->dm.F2;
   sa.st1 = m->dm.st1; sa.pt1 = pt1; sa.pf1 = m->dm.pf1; sa.pt2 = pt2; sa.pf2 = m->dm.pf2;
   { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling"); }
+  if (m->cfg.gemm_dtype == 1) {
+    Gemm16Args lg{};
+    lg.x = sub; lg.ldx = m->dm.F2 * d; lg.wp = m->w16(m->lin_wp); lg.bias = m->lin_b; lg.y = out; lg.ldy = d;
+    lg.M = Bp * T2; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.n_valid = d; lg.eps = kLnEps;
+    { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_gemm16_bf16(E16_BIAS, false, lg, s), "subsampling linear (bf16)"); }
+    return 0;
+  }
   StreamGemmArgs lg{};
   lg.x = sub; lg.y = out; lg.wp = m->lin_wp; lg.bias = m->lin_b;
   lg.M = Bp * T2; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.ldy = d; lg.n_valid = d;
@@ -660,6 +717,7 @@ int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const P
   if (rc) return rc;
   Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
+  sc.h4 = (float*)(ws + p.h4);
   rc = run_subsampling(m, mel, g.Bp, g.F, (float*)(ws + p.sub), sc.xa, s);
   if (rc) return rc;
   const int nb = m->cfg.num_blocks;
@@ -680,16 +738,33 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   const int M = B * T;
   Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
+  sc.h4 = (float*)(ws + p.h4);
+  const bool bf16 = m->cfg.gemm_dtype == 1;
+  if (bf16) {
+    Gemm16Args pr{};
+    pr.x = enc; pr.ldx = d; pr.wp = m->w16(m->proj_wp); pr.bias = m->proj_b; pr.y = sc.xa; pr.ldy = d;
+    pr.M = M; pr.K = d; pr.NT = d / 16; pr.n_valid = d; pr.eps = kLnEps;
+    { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm16_bf16(E16_BIAS, false, pr, s), "ctc project (bf16)"); }
+  } else {
   GemmArgs pr{};
   pr.x = enc; pr.y = sc.xa; pr.wp = m->proj_wp; pr.bias = m->proj_b;
   pr.M = M; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
   { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "ctc project"); }
+  }
   for (int i = 0; i < m->cfg.ctc_num_blocks; ++i) {
     BlockOpts bo;
     bo.ksz = m->cfg.ctc_kernel_size;
     bo.fc = m->cfg.ctc_fc_factor;
     int rc = run_block(m, m->ctc_blocks[i], bo, sc, B, T, nullptr, s);
     if (rc) return rc;
+  }
+  if (bf16) {
+    Gemm16Args hd{};
+    hd.x = sc.xa; hd.ldx = d; hd.wp = m->w16(m->fc_wp); hd.bias = m->fc_b; hd.y = logits; hd.ldy = m->cfg.num_classes;
+    hd.M = M; hd.K = d; hd.NT = m->NT_fc; hd.n_valid = m->cfg.num_classes; hd.eps = kLnEps;
+    hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
+    { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm16_bf16(E16_HEAD, false, hd, s), "ctc head (bf16)"); }
+    return 0;
   }
   GemmArgs hd{};
   hd.x = sc.xa; hd.y = logits; hd.wp = m->fc_wp; hd.bias = m->fc_b;
@@ -724,6 +799,7 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
   if (c.num_classes > 0 && c.ctc_kernel_size != 32 && c.ctc_kernel_size != 5)
     return fail(MI355ASR_EINVAL, "ctc_kernel_size=%d unsupported", c.ctc_kernel_size);
   if (c.reduction_factor != 4) return fail(MI355ASR_EINVAL, "reduction_factor=%d: only 4 is supported", c.reduction_factor);
+  if (c.gemm_dtype != 0 && c.gemm_dtype != 1) return fail(MI355ASR_EINVAL, "gemm_dtype=%d: 0 (fp32 MFMA) or 1 (bf16 MFMA)", c.gemm_dtype);
   if (c.n_dft != 1024) return fail(MI355ASR_EINVAL, "n_dft=%d: the reference hard-codes 1024 (conformer_blocks.py:312)", c.n_dft);
   if (c.n_mels != 80 && c.n_mels != 128) return fail(MI355ASR_EINVAL, "n_mels=%d: mel kernel instantiated for 80 and 128", c.n_mels);
   if (c.num_blocks < 0 || c.ctc_num_blocks < 0 || c.chunk_size < 0 || c.num_classes < 0)
@@ -803,6 +879,7 @@ int mi355asr_destroy(mi355asr_model* m) {
   for (auto& p : m->ev_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
   for (auto e : m->ev_free) (void)hipEventDestroy(e);
   if (m->arena) (void)hipFree(m->arena);
+  if (m->arena16) (void)hipFree(m->arena16);
   delete m;
   return 0;
 }
@@ -911,6 +988,13 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
+  if (m->arena16) { (void)hipFree(m->arena16); m->arena16 = nullptr; }
+  if (c.gemm_dtype == 1) {
+    const size_t n16 = (m->arena_floats + 3) & ~(size_t)3;
+    HIP_TRY(hipMalloc((void**)&m->arena16, n16 * sizeof(unsigned short)));
+    if (launch_to_bf16(m->arena, m->arena16, m->arena_floats & ~(size_t)3, s) != 0) return fail(MI355ASR_EINVAL, "bf16 conversion failed");
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   m->enc_blocks.clear();
   m->ctc_blocks.clear();
   for (auto& o : eo) m->enc_blocks.push_back(resolve(o, base));
@@ -1081,6 +1165,7 @@ int mi355asr_conformer_block(mi355asr_model* m, int32_t stack, int32_t index, co
   hipStream_t s = (hipStream_t)stream;
   Scratch sc{(float*)(w + p.xa), (float*)(w + p.xb), (float*)(w + p.qkv),
              (float*)(w + p.ctx), (float*)(w + p.u), (float*)(w + p.dw)};
+  sc.h4 = (float*)(w + p.h4);
   HIP_TRY(hipMemcpyAsync(sc.xa, x, (size_t)B * T * m->cfg.dmodel * 4, hipMemcpyDeviceToDevice, s));
   BlockOpts bo;
   bo.ksz = stack == 0 ? m->cfg.kernel_size : m->cfg.ctc_kernel_size;

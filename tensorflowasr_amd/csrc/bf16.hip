@@ -1,0 +1,269 @@
+// bf16-MFMA variant of the dense layers (BASELINE config 3: "StreamingConformerCTC ... bf16 MFMA"): bf16 inputs to
+// every GEMM (weights rounded once on the host, activations rounded to nearest-even at the operand), fp32
+// accumulation, fp32 LayerNorm / softmax / swish / GLU / residuals -- the split SURVEY 8d prescribes for that config.
+//
+// One generic kernel: Y[M, N] = epilogue( LN?(X)[M, K] . W[K, N] + b ),  any K that is a multiple of 16.
+// Same transposed-product layout as the fp32 kernels (common.h), with v_mfma_f32_16x16x16_bf16: the lane that held
+// four fp32 k-steps of a token (k = 16 kb + 4 g + j) holds the same four values as one packed bf16x4 operand, so
+// one MFMA (16 cycles) replaces four v_mfma_f32_16x16x4_f32 (128 cycles) per (k-block, column tile), and the
+// weight fragments are half the bytes ("P16" order, 4 bf16 per lane).
+// A wave owns 16 rows x CT column tiles; X is streamed from global/L2 per k-block (not held in registers), so K is
+// free (the 5120-wide subsampling Dense and the 1024-wide FFN hidden use the same code).  The streaming shapes this
+// exists for are tiny (832 rows): columns are split over grid.y so that every launch has several hundred waves,
+// and the layers of a block run as separate launches (the hidden activation goes through HBM: 3.4 MB).
+#include "common.h"
+#include "launch.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+DEV s16x4 to_bf16x4(f32x4 v) {      // 2 x v_cvt_pk_bf16_f32 (round to nearest even)
+  f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+  u32x2 p = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_t)),
+             __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_t))};
+  return __builtin_bit_cast(s16x4, p);
+}
+DEV f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
+// NF weight fragments per k-block: CT column tiles (+ CT gate tiles for GLU).
+// KS = 4: the four waves of a workgroup share one row tile and split K between them (partial sums meet in LDS, wave 0
+// runs the epilogue) -- for the streaming shapes, where 52 row tiles would otherwise be 52 long serial waves.
+// KS = 1: one row tile per wave, as everywhere else.
+// The k-loop fetches U k-blocks (operand + weight fragments) at a time, one group ahead.
+template <int CT, int EPI, bool LN, int KS>
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_bf16_kernel(Gemm16Args a) {
+  constexpr int NF = (EPI == E16_GLU) ? 2 * CT : CT;
+  constexpr int U = NF <= 4 ? 4 : (NF <= 8 ? 2 : 1);
+  __shared__ f32x4 red[KS > 1 ? (KS - 1) * NF * 64 : 1];
+  const int lane = threadIdx.x & 63;
+  const int g4 = (lane >> 4) * 4, c = lane & 15;
+  const int wave = threadIdx.x >> 6;
+  const int wid = KS > 1 ? blockIdx.x : blockIdx.x * WAVES_PER_BLOCK + wave;
+  const int ks = KS > 1 ? wave : 0;
+  if ((size_t)wid * 16 >= (size_t)a.M) return;          // uniform per workgroup when KS > 1
+  const int tok = wid * 16 + c;
+  const bool live = tok < a.M;
+  const float* __restrict__ xr = a.x + (size_t)min(tok, a.M - 1) * a.ldx + g4;
+  const int KB = a.K / 16, NT = a.NT;
+  const int KBs = (KB + KS - 1) / KS;
+  const int kbeg = ks * KBs, kend = min(KB, kbeg + KBs);
+  const int half = NT / 2;
+  const int NTC = (EPI == E16_GLU) ? half : NT;           // tiles swept in chunks of CT
+  const s16x4* __restrict__ wp = reinterpret_cast<const s16x4*>(a.wp) + lane;
+
+  // prologue LayerNorm statistics (two-pass, biased variance, eps inside the sqrt: Keras semantics)
+  float mean = 0.f, rstd = 1.f;
+  if (LN) {
+    float s = 0.f;
+    for (int kb = 0; kb < KB; ++kb) { const f32x4 v = ldg4(xr + 16 * kb); s += (v.x + v.y) + (v.z + v.w); }
+    mean = group_sum(s) / (float)a.K;
+    float q = 0.f;
+    for (int kb = 0; kb < KB; ++kb) {
+      const f32x4 d = ldg4(xr + 16 * kb) - splat4(mean);
+      q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    rstd = 1.0f / sqrtf(group_sum(q) / (float)a.K + a.eps);
+  }
+  auto xfrag = [&](int kb) -> s16x4 {
+    f32x4 v = ldg4(xr + 16 * kb);
+    if (LN) v = (v - splat4(mean)) * splat4(rstd) * ldg4(a.ln_g + 16 * kb + g4) + ldg4(a.ln_b + 16 * kb + g4);
+    return to_bf16x4(v);
+  };
+
+  float best_v = -INFINITY;
+  int best_i = 0;
+  // EPI_HEAD sweeps every column chunk inside the wave (the argmax needs all classes); the others take the chunk
+  // blockIdx.y selects
+  const int c_begin = (EPI == E16_HEAD) ? 0 : blockIdx.y * CT;
+  const int c_end = (EPI == E16_HEAD) ? NTC : c_begin + CT;
+  for (int c0 = c_begin; c0 < c_end; c0 += CT) {
+    f32x4 acc[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[i] = splat4(0.f);
+    s16x4 wb[2][U][NF], xb[2][U];
+    auto load_group = [&](int kb0, s16x4 (&w)[U][NF], s16x4 (&x)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int kb = min(kb0 + u, kend - 1);
+        x[u] = xfrag(kb);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) w[u][i] = wp[(size_t)(kb * NT + c0 + i) * 64];
+        if (EPI == E16_GLU) {
+#pragma unroll
+          for (int i = 0; i < CT; ++i) w[u][CT + i] = wp[(size_t)(kb * NT + half + c0 + i) * 64];
+        }
+      }
+    };
+    auto mma_group = [&](int kb0, const s16x4 (&w)[U][NF], const s16x4 (&x)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (kb0 + u < kend) {
+#pragma unroll
+          for (int i = 0; i < NF; ++i) acc[i] = mfma_bf16(w[u][i], x[u], acc[i]);
+        }
+      }
+    };
+    if (kbeg < kend) {
+      load_group(kbeg, wb[0], xb[0]);
+      for (int kb0 = kbeg; kb0 < kend; kb0 += 2 * U) {
+        load_group(kb0 + U, wb[1], xb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(kb0, wb[0], xb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_group(kb0 + 2 * U, wb[0], xb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(kb0 + U, wb[1], xb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (KS > 1) {
+      // partial sums of waves 1..KS-1 -> LDS -> wave 0
+      if (c0 != c_begin) __syncthreads();                 // the previous chunk's partial sums have been consumed
+      if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) red[((wave - 1) * NF + i) * 64 + lane] = acc[i];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int w2 = 0; w2 < KS - 1; ++w2)
+#pragma unroll
+          for (int i = 0; i < NF; ++i) acc[i] += red[(w2 * NF + i) * 64 + lane];
+      }
+    }
+    if (KS > 1 && wave != 0) continue;                    // only wave 0 holds the full sums
+    // ---- epilogue of this chunk: lane holds Y[token c][feature 16*(c0+i) + g4 + 0..3]
+    float* yrow = a.y ? a.y + (size_t)min(tok, a.M - 1) * a.ldy : nullptr;
+    if (EPI == E16_GLU) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const int f0 = 16 * (c0 + i) + g4;
+        const f32x4 va = acc[i] + ldg4(a.bias + f0), vb = acc[CT + i] + ldg4(a.bias + 16 * half + f0);
+        f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
+        if (live) stg4(yrow + f0, o);
+      }
+    } else if (EPI == E16_RES) {
+      // y = res + scale * (acc + bias), optionally followed by a LayerNorm over the row (needs CT == NT)
+      f32x4 v[CT];
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const int f0 = 16 * (c0 + i) + g4;
+        v[i] = ldg4(a.res + (size_t)min(tok, a.M - 1) * a.ldy + f0) + splat4(a.scale) * (acc[i] + ldg4(a.bias + f0));
+      }
+      if (a.fln_g) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mu = group_sum(s) / (float)(16 * CT);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          const f32x4 d = v[i] - splat4(mu);
+          q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+        const float rs = 1.0f / sqrtf(group_sum(q) / (float)(16 * CT) + a.eps);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          const int f0 = 16 * (c0 + i) + g4;
+          v[i] = (v[i] - splat4(mu)) * splat4(rs) * ldg4(a.fln_g + f0) + ldg4(a.fln_b + f0);
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i) stg4(yrow + 16 * (c0 + i) + g4, v[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const int f0 = 16 * (c0 + i) + g4;
+        f32x4 v = acc[i] + ldg4(a.bias + f0);
+        if (EPI == E16_SWISH) v = swish4(v);
+        if (EPI == E16_AFFSWISH) v = swish4(v * ldg4(a.aff_s + f0) + ldg4(a.aff_t + f0));
+        if (EPI == E16_QKV) { if (c0 + i < a.qtiles) v *= splat4(a.qscale); }
+        if (EPI == E16_HEAD) {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (f0 + j < a.n_valid && vv[j] > best_v) { best_v = vv[j]; best_i = f0 + j; }   // first maximum wins
+          if (yrow && live) {
+            if (f0 + 3 < a.n_valid && (a.ldy & 3) == 0) stg4(yrow + f0, v);
+            else
+#pragma unroll
+              for (int j = 0; j < 4; ++j) if (f0 + j < a.n_valid) yrow[f0 + j] = vv[j];
+          }
+        } else if (live && f0 + 3 < a.n_valid) {
+          stg4(yrow + f0, v);
+        }
+      }
+    }
+  }
+  if (EPI == E16_HEAD && a.argmax_out && (KS == 1 || wave == 0)) {
+    // the 4 lane groups of a token hold disjoint feature sets: max over groups, lowest index on ties
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+      const float ov = __shfl_xor(best_v, off);
+      const int oi = __shfl_xor(best_i, off);
+      if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+    }
+    if (live && lane < 16) a.argmax_out[tok] = best_i;
+  }
+}
+
+template <int CT, int EPI, bool LN>
+void go(const Gemm16Args& a, hipStream_t s) {
+  const int tiles = (a.M + 15) / 16;
+  const int ntc = (EPI == E16_GLU) ? a.NT / 2 : a.NT;
+  const int ny = EPI == E16_HEAD ? 1 : ntc / CT;
+  // fewer than ~2 waves per SIMD with one wave per row tile -> split K over the four waves of a workgroup
+  if ((size_t)tiles * ny < 2048) {
+    hipLaunchKernelGGL((gemm16_bf16_kernel<CT, EPI, LN, 4>), dim3(tiles, ny), dim3(BLOCK_THREADS), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((gemm16_bf16_kernel<CT, EPI, LN, 1>), dim3((tiles + 3) / 4, ny), dim3(BLOCK_THREADS), 0, s, a);
+  }
+}
+
+__global__ void to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
+  for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+    const s16x4 v = to_bf16x4(ldg4(src + i));
+    *reinterpret_cast<s16x4*>(dst + i) = v;
+  }
+}
+
+}  // namespace
+
+// whole-arena conversion: a packed fp32 matrix at float offset o is the same fragment order at element offset o
+int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
+  if (n % 4 != 0) return -1;
+  hipLaunchKernelGGL(to_bf16_kernel, dim3(1024), dim3(256), 0, s, src, (unsigned short*)dst, n);
+  return 0;
+}
+
+// Column tiles per wave: the full row (CT = NT) when the epilogue needs it (residual + LayerNorm, N = dmodel) or when
+// there are enough row tiles to fill the chip; otherwise 3 (dmodel 144) / 4 (dmodel 256) so that small M still gives
+// several hundred waves.
+int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s) {
+  if (a.K % 16 != 0 || a.K < 16) return -1;
+  const int tiles = (a.M + 15) / 16;
+  const int ntc = (epi == E16_GLU) ? a.NT / 2 : a.NT;
+  const bool d144 = (ntc % 9 == 0);
+  if (!d144 && ntc % 4 != 0 && epi != E16_HEAD) return -1;
+#define CASE(E, L) \
+  if (epi == E && ln == L) { \
+    if (E == E16_RES) { if (ntc == 9) go<9, E, L>(a, s); else if (ntc == 16) go<16, E, L>(a, s); else return -1; } \
+    else if (E == E16_HEAD) { if (a.NT % 12 != 0) return -1; go<12, E, L>(a, s); } \
+    else if (d144) { if (tiles >= 1024 && ntc % 9 == 0 && E != E16_GLU) go<9, E, L>(a, s); else go<3, E, L>(a, s); } \
+    else { if (tiles >= 1024 && ntc % 16 == 0) go<(E == E16_GLU ? 8 : 16), E, L>(a, s); else go<4, E, L>(a, s); } \
+    return 0; }
+  CASE(E16_BIAS, false)
+  CASE(E16_SWISH, true)
+  CASE(E16_RES, false)
+  CASE(E16_QKV, true)
+  CASE(E16_GLU, true)
+  CASE(E16_AFFSWISH, false)
+  CASE(E16_HEAD, false)
+#undef CASE
+  return -1;
+}

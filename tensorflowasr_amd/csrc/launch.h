@@ -155,6 +155,26 @@ struct AddPeArgs {
 };
 int launch_embed(const EmbedArgs& a, hipStream_t s);
 int launch_add_pe(const AddPeArgs& a, hipStream_t s);
+// bf16-MFMA GEMM family (bf16.hip)
+enum { E16_BIAS = 0, E16_SWISH = 1, E16_RES = 2, E16_QKV = 3, E16_GLU = 4, E16_AFFSWISH = 5, E16_HEAD = 6 };
+struct Gemm16Args {
+  const float* x;       // [M, ldx] fp32, the first K columns are the operand
+  int ldx;
+  const void* wp;       // bf16 weights in P16 fragment order [K/16][NT][64 lanes][4]
+  const float* bias;    // [NT*16]
+  float* y;             // [M, ldy] (E16_HEAD: may be null)
+  int ldy;
+  const float* res;     // [M, ldy] (E16_RES)
+  const float *ln_g, *ln_b;     // prologue LayerNorm over K
+  const float *fln_g, *fln_b;   // E16_RES: optional LayerNorm over the output row (N = 16*NT)
+  const float *aff_s, *aff_t;   // E16_AFFSWISH
+  int M, K, NT, n_valid;
+  float scale, eps, qscale;
+  int qtiles;
+  int32_t* argmax_out;  // [M] (E16_HEAD)
+};
+int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s);
+int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // block-level fused kernels (fused.hip, dmodel 144)
 struct Ff1QkvArgs {
   const float* x0; float* x1; float* qkv;

@@ -148,6 +148,13 @@ def _wave2d(h, inputs):
     return x.contiguous()
 
 
+def _gemm_dtype(v):
+    try:
+        return {"float32": 0, "fp32": 0, 0: 0, "bfloat16": 1, "bf16": 1, 1: 1}[v]
+    except KeyError:
+        raise ValueError("gemm_dtype must be 'float32' or 'bfloat16', got %r" % (v,))
+
+
 class _ModelBase:
     def _names_and_shapes(self):
         shapes = self._expected_shapes()
@@ -260,7 +267,10 @@ class ConformerEncoder(_ModelBase):
     def __init__(self, dmodel=144, reduction_factor=4, num_blocks=16, head_size=36, num_heads=4, kernel_size=32,
                  fc_factor=0.5, dropout=0.0, add_wav_info=False, sample_rate=16000, n_mels=80,
                  mel_layer_type="leaf", mel_layer_trainable=False, stride_ms=10, name="conformer_encoder",
-                 device="cuda:0", chunk_size=0, **kwargs):
+                 device="cuda:0", chunk_size=0, gemm_dtype="float32", **kwargs):
+        """gemm_dtype (not in the reference): "float32" (default, the reference's arithmetic) or "bfloat16" = bf16 MFMA
+        inputs with fp32 accumulation for the dense layers (BASELINE config 3)."""
+        self.gemm_dtype = _gemm_dtype(gemm_dtype)
         if mel_layer_type != "Melspectrogram":
             raise NotImplementedError("mel_layer_type=%r: only 'Melspectrogram' is on the MI355X hot path" % mel_layer_type)
         if add_wav_info:
@@ -283,7 +293,8 @@ class ConformerEncoder(_ModelBase):
                           num_heads=self.num_heads, kernel_size=self.kernel_size, fc_factor=self.fc_factor,
                           reduction_factor=self.reduction_factor, n_mels=self.n_mels, sample_rate=self.sample_rate,
                           stride_ms=self.stride_ms, n_dft=1024, chunk_size=self.chunk_size, has_encoder=1,
-                          num_classes=0, ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5)
+                          num_classes=0, ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5,
+                          gemm_dtype=self.gemm_dtype)
         self._h = _Handle(cfg, self._device)
 
     def _expected_shapes(self):
@@ -369,7 +380,7 @@ class CTCDecoder(_ModelBase):
     """asr/models/conformer_blocks.py:385-438: Dense(d->d) + num_blocks ConformerBlocks + Dense(d->num_classes)."""
 
     def __init__(self, num_classes, dmodel=144, num_blocks=16, head_size=36, num_heads=4, fc_factor=0.5,
-                 dropout=0.0, kernel_size=32, device="cuda:0", name="ctc_decoder", **kwargs):
+                 dropout=0.0, kernel_size=32, device="cuda:0", name="ctc_decoder", gemm_dtype="float32", **kwargs):
         self.name = name
         self.num_classes, self.dmodel = num_classes, dmodel
         self.num_blocks, self.head_size, self.num_heads = num_blocks, head_size, num_heads
@@ -379,7 +390,7 @@ class CTCDecoder(_ModelBase):
         cfg = _lib.Config(dmodel=dmodel, num_blocks=0, head_size=head_size, num_heads=num_heads, kernel_size=32,
                           fc_factor=0.5, reduction_factor=4, n_mels=80, sample_rate=16000, stride_ms=10, n_dft=1024,
                           chunk_size=0, has_encoder=0, num_classes=num_classes, ctc_num_blocks=num_blocks,
-                          ctc_kernel_size=kernel_size, ctc_fc_factor=fc_factor)
+                          ctc_kernel_size=kernel_size, ctc_fc_factor=fc_factor, gemm_dtype=_gemm_dtype(gemm_dtype))
         self._h = _Handle(cfg, device)
 
     def _expected_shapes(self):
@@ -496,7 +507,7 @@ class ConformerCTC(_ModelBase):
     def __init__(self, num_classes, dmodel=144, reduction_factor=4, num_blocks=13, head_size=36, num_heads=4,
                  kernel_size=32, fc_factor=0.5, sample_rate=16000, n_mels=80, stride_ms=10, chunk_size=0,
                  ctcdecoder_num_blocks=1, ctcdecoder_kernel_size=32, ctcdecoder_fc_factor=0.5,
-                 device="cuda:0", name="conformer_ctc", **kwargs):
+                 device="cuda:0", name="conformer_ctc", gemm_dtype="float32", **kwargs):
         self.name = name
         self.num_classes, self.dmodel = num_classes, dmodel
         self.blank = num_classes - 1               # utils/text_featurizers.py:65-70 (blank_at_zero: False)
@@ -510,7 +521,7 @@ class ConformerCTC(_ModelBase):
                           n_mels=n_mels, sample_rate=sample_rate, stride_ms=stride_ms, n_dft=1024,
                           chunk_size=self.chunk_size, has_encoder=1, num_classes=num_classes,
                           ctc_num_blocks=ctcdecoder_num_blocks, ctc_kernel_size=ctcdecoder_kernel_size,
-                          ctc_fc_factor=ctcdecoder_fc_factor)
+                          ctc_fc_factor=ctcdecoder_fc_factor, gemm_dtype=_gemm_dtype(gemm_dtype))
         self._h = _Handle(cfg, device)
 
     @classmethod

@@ -692,3 +692,81 @@ def test_chunk_conformer_streaming_matches_oracle_and_offline(torch_cuda, sample
     n = txt.shape[1]
     assert maxdiff(txt, off["text_logits"].cpu().numpy()[:, :n]) < TOL
     assert n == off["text_logits"].shape[1] - 8
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bf16 MFMA mode (mi355asr_config.gemm_dtype = 1; BASELINE config 3)
+# ---------------------------------------------------------------------------------------------------------
+def _bf16_case(base, blocks, L, chunk, seed):
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = small_cfg(blocks, base)
+    w = co.encoder_weights(cfg, seed=seed)
+    w.update(co.ctc_decoder_weights(cfg, 300, seed=seed + 1))
+    kw = {k: v for k, v in encoder_kwargs(cfg, chunk).items() if k != "mel_layer_type"}
+    x = waves(3, L, 17)
+    out = {}
+    for dt in ("float32", "bfloat16"):
+        m = ConformerCTC(300, gemm_dtype=dt, **kw)
+        m.load_weights(w, by_name=False)
+        enc = m.encode(x)
+        logits, amax = m.ctc_logits(enc, return_argmax=True)
+        out[dt] = (enc.cpu().numpy(), logits.cpu().numpy(), amax.cpu().numpy())
+    return cfg, w, x, out
+
+
+@pytest.mark.parametrize("base,blocks,L,chunk", [(co.STREAMING_S, 2, 24000, 8000), (co.CONFORMER_S, 2, 32000, 0)])
+def test_bf16_gemm_mode_against_rounding_oracle_and_fp32(torch_cuda, base, blocks, L, chunk):
+    """bf16 inputs / fp32 accumulation for the dense layers (d = 256 streaming blocks and d = 144 offline):
+    (1) within 2e-3 of the oracle run with both GEMM operands rounded to bf16 -- this pins the implementation;
+    (2) against the fp32 path: the deviation the bf16 mode costs ("tolerance relaxed; report max abs diff
+    and ids agreement"), bounded loosely."""
+    cfg, w, x, out = _bf16_case(base, blocks, L, chunk, seed=31)
+    co.GEMM_ROUND_BF16 = True
+    try:
+        if chunk:
+            enc_ref = co.streaming_conformer_encoder(x.astype(np.float64), w, cfg, chunk)
+        else:
+            enc_ref = co.conformer_encoder(x.astype(np.float64), w, cfg)
+        logits_ref = co.ctc_decoder(enc_ref, w, cfg)
+    finally:
+        co.GEMM_ROUND_BF16 = False
+    enc16, logits16, amax16 = out["bfloat16"]
+    enc32, logits32, amax32 = out["float32"]
+    assert enc16.shape == enc_ref.shape
+    # End to end the two are not bit-comparable: the fp32 frontend differs from the fp64 oracle's by ~1e-5 relative,
+    # which moves a fraction of a percent of the GEMM operands across a bf16 rounding boundary (one bf16 ulp = 2^-8
+    # relative each).  Loose bound here; the per-block test below pins the arithmetic.
+    e_enc, e_log = np.abs(enc16 - enc_ref), np.abs(logits16 - logits_ref)
+    print("bf16 vs rounding oracle: encoder max %.3g mean %.3g ; logits max %.3g mean %.3g"
+          % (e_enc.max(), e_enc.mean(), e_log.max(), e_log.mean()))
+    assert e_enc.max() < 2e-2 and e_enc.mean() < 2e-3
+    assert e_log.max() < 4e-2 and e_log.mean() < 3e-3
+    assert (amax16 == logits16.argmax(-1)).all()
+    d_enc, d_log = maxdiff(enc16, enc32), maxdiff(logits16, logits32)
+    agree = float((amax16 == amax32).mean())
+    print("bf16 vs fp32: encoder max|d|=%.3g logits max|d|=%.3g argmax agreement=%.4f" % (d_enc, d_log, agree))
+    assert 1e-4 < d_enc < 0.2 and d_log < 0.3 and agree > 0.95
+
+
+@pytest.mark.parametrize("base", [co.STREAMING_S, co.CONFORMER_S])
+def test_bf16_block_matches_rounding_oracle(torch_cuda, base):
+    """One ConformerBlock in bf16 mode on an exact fp32 input: every dense layer sees the same operands as the oracle
+    with both GEMM operands rounded to bf16, so only the (rare) fp32-vs-fp64 tie flips remain."""
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = small_cfg(1, base)
+    w = co.encoder_weights(cfg, seed=5)
+    w.update(co.ctc_decoder_weights(cfg, 100, seed=6))
+    m = ConformerCTC(100, gemm_dtype="bfloat16", **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+    m.load_weights(w, by_name=False)
+    x = np.random.default_rng(2).standard_normal((3, 45, cfg["dmodel"])).astype(np.float32)
+    got = m.conformer_block(0, x).cpu().numpy()
+    co.GEMM_ROUND_BF16 = True
+    try:
+        ref = co.conformer_block(x.astype(np.float64), w, "conformer_block_0", cfg["head_size"], cfg["fc_factor"])
+    finally:
+        co.GEMM_ROUND_BF16 = False
+    exact = co.conformer_block(x.astype(np.float64), w, "conformer_block_0", cfg["head_size"], cfg["fc_factor"])
+    e = np.abs(got - ref)
+    print("bf16 block vs rounding oracle: max %.3g mean %.3g (vs exact: max %.3g)" % (e.max(), e.mean(), np.abs(got - exact).max()))
+    assert e.max() < 6e-3 and e.mean() < 3e-4      # tie flips: ~1e-4 mean (see the test above)
+    assert np.abs(got - exact).max() > 10 * e.mean()               # it really is the bf16 path

@@ -43,7 +43,7 @@ def test_config_struct_matches_header_layout():
 def _create(**over):
     cfg = dict(dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32, fc_factor=0.5, reduction_factor=4,
                n_mels=80, sample_rate=16000, stride_ms=10, n_dft=1024, chunk_size=0, has_encoder=1, num_classes=0,
-               ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5)
+               ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5, gemm_dtype=0)
     cfg.update(over)
     lib = _lib.lib()
     p = ctypes.c_void_p()
@@ -52,7 +52,7 @@ def _create(**over):
 
 
 @pytest.mark.parametrize("bad", [dict(dmodel=100), dict(head_size=32), dict(kernel_size=7), dict(reduction_factor=2),
-                                 dict(n_dft=512), dict(n_mels=64), dict(num_heads=3)])
+                                 dict(n_dft=512), dict(n_mels=64), dict(num_heads=3), dict(gemm_dtype=2)])
 def test_create_rejects_unsupported_configs_with_message(bad):
     lib, rc, p = _create(**bad)
     assert rc == -1 and not p.value

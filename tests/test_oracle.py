@@ -263,3 +263,25 @@ def test_chunk_streaming_restatement_equals_offline_predict():
     # caches are cut to the attention window / conv kernel / carry-over lengths
     assert pc["enc_mha"][0].shape[1] == 36 and pc["enc_cnn"][0].shape[1] == 32 and pc["front_wav"].shape[1] == 2560
     assert dc["dec_inp"].shape[1] == 8 and pc["dec_inp"].shape[1] == 0
+
+
+def test_bf16_rounding_emulation():
+    """bf16_round = round-to-nearest-even on the top 16 bits (what v_cvt_pk_bf16_f32 does)."""
+    x = np.array([1.0, 1.00390625, 1.01171875, -3.14159274, 65504.0, 1e-30, 0.0], np.float32)
+    r = co.bf16_round(x)
+    assert r.dtype == np.float32 and (r.view(np.uint32) & 0xFFFF == 0).all()
+    assert r[0] == 1.0 and r[1] == 1.0 and r[2] == 1.015625        # tie -> even ; above the tie -> up
+    assert abs(r[3] + 3.140625) < 1e-7
+    assert np.all(np.abs(r[:5] - x[:5]) <= np.abs(x[:5]) * 2.0 ** -8)
+    cfg = dict(co.CONFORMER_S)
+    w = co.block_weights(np.random.default_rng(0), "b", 144, 4, 36, 32)
+    xin = np.random.default_rng(1).standard_normal((1, 20, 144))
+    exact = co.conformer_block(xin, w, "b", 36)
+    co.GEMM_ROUND_BF16 = True
+    try:
+        rounded = co.conformer_block(xin, w, "b", 36)
+    finally:
+        co.GEMM_ROUND_BF16 = False
+    d = np.abs(rounded - exact).max()
+    assert 1e-4 < d < 0.1                                           # visibly bf16, still the same function
+    assert np.abs(co.conformer_block(xin, w, "b", 36) - exact).max() == 0.0
