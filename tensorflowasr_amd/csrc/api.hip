@@ -409,6 +409,15 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   return b;
 }
 
+// Layer-at-a-time GEMM family (bf16.hip) instead of the fused / chained fp32 kernels: in bf16 mode, and in fp32 for
+// dmodel values those kernels are not instantiated for (e.g. 512 = ConformerL).
+bool use_gemm16(const mi355asr_model* m) { return m->cfg.gemm_dtype == 1 || (m->cfg.dmodel != 144 && m->cfg.dmodel != 256); }
+int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s) {
+  if (m->cfg.gemm_dtype == 1) { g.wp = m->w16(wp); return launch_gemm16_bf16(epi, ln, g, s); }
+  g.wp = wp;
+  return launch_gemm16_f32(epi, ln, g, s);
+}
+
 // ---- workspace plan (byte offsets, 256-byte aligned) --------------------------------------------------
 struct Plan {
   size_t xa, xb, qkv, ctx, u, dw, enc, amax, logp, pmax, umax, mel, sub, h4, total;
@@ -434,7 +443,7 @@ Plan make_plan(const mi355asr_model* m, int Bp, int F, int T) {
   p.ctx = take(M * d);
   p.u = take(M * d);
   p.dw = take(M * d);
-  p.h4 = m->cfg.gemm_dtype == 1 ? take(M * 4 * d) : 0;   // before logp: the block-only entry points size to p.logp
+  p.h4 = use_gemm16(m) ? take(M * 4 * d) : 0;   // before logp: the block-only entry points size to p.logp
   p.enc = take(M * d);
   p.amax = take(M);
   const int FT = ceil_div(F, 16);
@@ -495,28 +504,28 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
   const float fc = bo.fc;
   const int M = B * T;
   static const bool fused_env = [] { const char* v = getenv("MI355ASR_FUSED"); return v ? atoi(v) != 0 : true; }();
-  if (m->cfg.gemm_dtype == 1 && !cross) {
-    // bf16 MFMA for every dense layer (bf16.hip); LayerNorm / softmax / activations / depthwise conv in fp32
+  if (use_gemm16(m) && !cross) {
+    // one launch per dense layer (bf16.hip: bf16 or fp32 operands); LayerNorm / softmax / activations / depthwise conv in fp32
     auto g16 = [&](const float* x, int ldx, int K, const float* wp, const float* bias, int NT, float* y, int ldy) {
       Gemm16Args g{};
-      g.x = x; g.ldx = ldx; g.K = K; g.wp = m->w16(wp); g.bias = bias; g.NT = NT; g.y = y; g.ldy = ldy;
+      g.x = x; g.ldx = ldx; g.K = K; g.wp = wp; g.bias = bias; g.NT = NT; g.y = y; g.ldy = ldy;
       g.M = M; g.n_valid = 16 * NT; g.eps = kLnEps; g.scale = 1.0f;
       return g;
     };
     auto ffn = [&](int i, const float* x, float* y, const float* fg, const float* fb) -> int {
       Gemm16Args a1 = g16(x, d, d, w.ff_w1p[i], w.ff_b1[i], 4 * d / 16, sc.h4, 4 * d);
       a1.ln_g = w.ff_ln_g[i]; a1.ln_b = w.ff_ln_b[i];
-      { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_gemm16_bf16(E16_SWISH, true, a1, s), "ffn1 (bf16)"); }
+      { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_gemm16(m, E16_SWISH, true, a1, w.ff_w1p[i], s), "ffn1"); }
       Gemm16Args a2 = g16(sc.h4, 4 * d, 4 * d, w.ff_w2p[i], w.ff_b2[i], d / 16, y, d);
       a2.res = x; a2.scale = fc; a2.fln_g = fg; a2.fln_b = fb;
-      { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_gemm16_bf16(E16_RES, false, a2, s), "ffn2 (bf16)"); }
+      { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_gemm16(m, E16_RES, false, a2, w.ff_w2p[i], s), "ffn2"); }
       return 0;
     };
     int rc = ffn(0, sc.xa, sc.xb, nullptr, nullptr);
     if (rc) return rc;
     Gemm16Args q = g16(sc.xb, d, d, w.qkv_wp, w.qkv_b, 3 * d / 16, sc.qkv, 3 * d);
     q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
-    { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm16_bf16(E16_QKV, true, q, s), "qkv (bf16)"); }
+    { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm16(m, E16_QKV, true, q, w.qkv_wp, s), "qkv"); }
     AttnArgs at{};
     at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ctx = sc.ctx;
     at.B = B; at.Tq = T; at.Tk = T; at.H = H; at.D = d; at.ldq = 3 * d; at.ldk = 3 * d;
@@ -524,20 +533,20 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
     Gemm16Args op = g16(sc.ctx, d, d, w.out_wp, w.out_b, d / 16, sc.xa, d);
     op.res = sc.xb;
-    { PROF(MI355ASR_K_ATTN_OUT); LAUNCH_TRY(launch_gemm16_bf16(E16_RES, false, op, s), "attention out (bf16)"); }
+    { PROF(MI355ASR_K_ATTN_OUT); LAUNCH_TRY(launch_gemm16(m, E16_RES, false, op, w.out_wp, s), "attention out"); }
     Gemm16Args gl = g16(sc.xa, d, d, w.pw1_wp, w.pw1_b, 2 * d / 16, sc.u, d);
     gl.ln_g = w.cv_ln_g; gl.ln_b = w.cv_ln_b; gl.n_valid = d;
-    { PROF(MI355ASR_K_PW1_GLU); LAUNCH_TRY(launch_gemm16_bf16(E16_GLU, true, gl, s), "pw_conv_1 + GLU (bf16)"); }
+    { PROF(MI355ASR_K_PW1_GLU); LAUNCH_TRY(launch_gemm16(m, E16_GLU, true, gl, w.pw1_wp, s), "pw_conv_1 + GLU"); }
     DwArgs dwa{};
     dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
     dwa.pad_left = bo.causal ? ksz - 1 : (ksz - 1) / 2;
     { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
     Gemm16Args pc = g16(sc.dw, d, d, w.pc_w1p, w.pc_b1, 2 * d / 16, sc.h4, 2 * d);
     pc.aff_s = w.bn_s; pc.aff_t = w.bn_t;
-    { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_gemm16_bf16(E16_AFFSWISH, false, pc, s), "pointwise + BN + swish (bf16)"); }
+    { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_gemm16(m, E16_AFFSWISH, false, pc, w.pc_w1p, s), "pointwise + BN + swish"); }
     Gemm16Args p2 = g16(sc.h4, 2 * d, 2 * d, w.pw2_wp, w.pw2_b, d / 16, sc.xb, d);
     p2.res = sc.xa;
-    { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_gemm16_bf16(E16_RES, false, p2, s), "pw_conv_2 (bf16)"); }
+    { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_gemm16(m, E16_RES, false, p2, w.pw2_wp, s), "pw_conv_2"); }
     return ffn(1, sc.xb, out ? out : sc.xa, w.ln_g, w.ln_b);
   }
   if (d == 144 && fused_env && !cross) {
@@ -683,11 +692,11 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   sa.B = Bp; sa.F = F; sa.NM = c.n_mels; sa.T1 = T1; sa.F1 = m->dm.F1; sa.T2 = T2; sa.F2 = m->dm.F2;
   sa.st1 = m->dm.st1; sa.pt1 = pt1; sa.pf1 = m->dm.pf1; sa.pt2 = pt2; sa.pf2 = m->dm.pf2;
   { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling"); }
-  if (m->cfg.gemm_dtype == 1) {
+  if (use_gemm16(m)) {
     Gemm16Args lg{};
-    lg.x = sub; lg.ldx = m->dm.F2 * d; lg.wp = m->w16(m->lin_wp); lg.bias = m->lin_b; lg.y = out; lg.ldy = d;
+    lg.x = sub; lg.ldx = m->dm.F2 * d; lg.bias = m->lin_b; lg.y = out; lg.ldy = d;
     lg.M = Bp * T2; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.n_valid = d; lg.eps = kLnEps;
-    { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_gemm16_bf16(E16_BIAS, false, lg, s), "subsampling linear (bf16)"); }
+    { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_gemm16(m, E16_BIAS, false, lg, m->lin_wp, s), "subsampling linear"); }
     return 0;
   }
   StreamGemmArgs lg{};
@@ -739,12 +748,12 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
   sc.h4 = (float*)(ws + p.h4);
-  const bool bf16 = m->cfg.gemm_dtype == 1;
+  const bool bf16 = use_gemm16(m);
   if (bf16) {
     Gemm16Args pr{};
-    pr.x = enc; pr.ldx = d; pr.wp = m->w16(m->proj_wp); pr.bias = m->proj_b; pr.y = sc.xa; pr.ldy = d;
+    pr.x = enc; pr.ldx = d; pr.bias = m->proj_b; pr.y = sc.xa; pr.ldy = d;
     pr.M = M; pr.K = d; pr.NT = d / 16; pr.n_valid = d; pr.eps = kLnEps;
-    { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm16_bf16(E16_BIAS, false, pr, s), "ctc project (bf16)"); }
+    { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm16(m, E16_BIAS, false, pr, m->proj_wp, s), "ctc project"); }
   } else {
   GemmArgs pr{};
   pr.x = enc; pr.y = sc.xa; pr.wp = m->proj_wp; pr.bias = m->proj_b;
@@ -760,10 +769,10 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   }
   if (bf16) {
     Gemm16Args hd{};
-    hd.x = sc.xa; hd.ldx = d; hd.wp = m->w16(m->fc_wp); hd.bias = m->fc_b; hd.y = logits; hd.ldy = m->cfg.num_classes;
+    hd.x = sc.xa; hd.ldx = d; hd.bias = m->fc_b; hd.y = logits; hd.ldy = m->cfg.num_classes;
     hd.M = M; hd.K = d; hd.NT = m->NT_fc; hd.n_valid = m->cfg.num_classes; hd.eps = kLnEps;
     hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
-    { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm16_bf16(E16_HEAD, false, hd, s), "ctc head (bf16)"); }
+    { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm16(m, E16_HEAD, false, hd, m->fc_wp, s), "ctc head"); }
     return 0;
   }
   GemmArgs hd{};
@@ -788,8 +797,8 @@ const char* mi355asr_version(void) { return "mi355asr 0.1 (gfx950, fp32 MFMA)"; 
 int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
   if (!cfg || !out) return fail(MI355ASR_EINVAL, "null argument");
   const auto& c = *cfg;
-  if (c.dmodel != 144 && c.dmodel != 256)
-    return fail(MI355ASR_EINVAL, "dmodel=%d: kernels are instantiated for 144 (ConformerS) and 256 (ConformerM/StreamingS)", c.dmodel);
+  if (c.dmodel != 144 && (c.dmodel % 128 != 0 || c.dmodel < 128 || c.dmodel > 1024))
+    return fail(MI355ASR_EINVAL, "dmodel=%d: supported are 144 (ConformerS), 256 (ConformerM / StreamingS) and other multiples of 128 up to 1024 (512 = ConformerL)", c.dmodel);
   if (c.num_heads * c.head_size != c.dmodel)
     return fail(MI355ASR_EINVAL, "num_heads*head_size (%d*%d) must equal dmodel (%d)", c.num_heads, c.head_size, c.dmodel);
   if (c.head_size != 36 && c.head_size != 64)

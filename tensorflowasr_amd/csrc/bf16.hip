@@ -28,15 +28,33 @@ DEV s16x4 to_bf16x4(f32x4 v) {      // 2 x v_cvt_pk_bf16_f32 (round to nearest e
 }
 DEV f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
+// operand precision of the kernel: bf16 (one 16x16x16 MFMA per k-block and column tile) or fp32 (four 16x16x4 MFMAs;
+// the layer-at-a-time path for dmodel values the fused / chained fp32 kernels are not instantiated for, e.g. 512)
+struct PBf16 {
+  typedef s16x4 W;
+  typedef s16x4 X;
+  static DEV X cvt(f32x4 v) { return to_bf16x4(v); }
+  static DEV f32x4 mma(W w, X x, f32x4 acc) { return mfma_bf16(w, x, acc); }
+};
+struct PF32 {
+  typedef f32x4 W;
+  typedef f32x4 X;
+  static DEV X cvt(f32x4 v) { return v; }
+  static DEV f32x4 mma(W w, X x, f32x4 acc) { return mma_kblock(w, x, acc); }
+};
+
 // NF weight fragments per k-block: CT column tiles (+ CT gate tiles for GLU).
 // KS = 4: the four waves of a workgroup share one row tile and split K between them (partial sums meet in LDS, wave 0
 // runs the epilogue) -- for the streaming shapes, where 52 row tiles would otherwise be 52 long serial waves.
 // KS = 1: one row tile per wave, as everywhere else.
 // The k-loop fetches U k-blocks (operand + weight fragments) at a time, one group ahead.
-template <int CT, int EPI, bool LN, int KS>
-__global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_bf16_kernel(Gemm16Args a) {
+template <class P, int CT, int EPI, bool LN, int KS>
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_kernel(Gemm16Args a) {
+  typedef typename P::W WF;
+  typedef typename P::X XF;
   constexpr int NF = (EPI == E16_GLU) ? 2 * CT : CT;
-  constexpr int U = NF <= 4 ? 4 : (NF <= 8 ? 2 : 1);
+  constexpr int U0 = NF <= 4 ? 4 : (NF <= 8 ? 2 : 1);
+  constexpr int U = (sizeof(WF) > 8 && U0 > 1) ? U0 / 2 : U0;     // fp32 fragments are twice the registers
   __shared__ f32x4 red[KS > 1 ? (KS - 1) * NF * 64 : 1];
   const int lane = threadIdx.x & 63;
   const int g4 = (lane >> 4) * 4, c = lane & 15;
@@ -52,7 +70,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_bf16_kernel(Gemm16Arg
   const int kbeg = ks * KBs, kend = min(KB, kbeg + KBs);
   const int half = NT / 2;
   const int NTC = (EPI == E16_GLU) ? half : NT;           // tiles swept in chunks of CT
-  const s16x4* __restrict__ wp = reinterpret_cast<const s16x4*>(a.wp) + lane;
+  const WF* __restrict__ wp = reinterpret_cast<const WF*>(a.wp) + lane;
 
   // prologue LayerNorm statistics (two-pass, biased variance, eps inside the sqrt: Keras semantics)
   float mean = 0.f, rstd = 1.f;
@@ -67,10 +85,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_bf16_kernel(Gemm16Arg
     }
     rstd = 1.0f / sqrtf(group_sum(q) / (float)a.K + a.eps);
   }
-  auto xfrag = [&](int kb) -> s16x4 {
+  auto xfrag = [&](int kb) -> XF {
     f32x4 v = ldg4(xr + 16 * kb);
     if (LN) v = (v - splat4(mean)) * splat4(rstd) * ldg4(a.ln_g + 16 * kb + g4) + ldg4(a.ln_b + 16 * kb + g4);
-    return to_bf16x4(v);
+    return P::cvt(v);
   };
 
   float best_v = -INFINITY;
@@ -83,8 +101,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_bf16_kernel(Gemm16Arg
     f32x4 acc[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) acc[i] = splat4(0.f);
-    s16x4 wb[2][U][NF], xb[2][U];
-    auto load_group = [&](int kb0, s16x4 (&w)[U][NF], s16x4 (&x)[U]) {
+    WF wb[2][U][NF];
+    XF xb[2][U];
+    auto load_group = [&](int kb0, WF (&w)[U][NF], XF (&x)[U]) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int kb = min(kb0 + u, kend - 1);
@@ -97,12 +116,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_bf16_kernel(Gemm16Arg
         }
       }
     };
-    auto mma_group = [&](int kb0, const s16x4 (&w)[U][NF], const s16x4 (&x)[U]) {
+    auto mma_group = [&](int kb0, const WF (&w)[U][NF], const XF (&x)[U]) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (kb0 + u < kend) {
 #pragma unroll
-          for (int i = 0; i < NF; ++i) acc[i] = mfma_bf16(w[u][i], x[u], acc[i]);
+          for (int i = 0; i < NF; ++i) acc[i] = P::mma(w[u][i], x[u], acc[i]);
         }
       }
     };
@@ -212,17 +231,81 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_bf16_kernel(Gemm16Arg
   }
 }
 
-template <int CT, int EPI, bool LN>
+void launch_layernorm_rows(float* y, const float* g, const float* b, int M, int N, int ld, float eps, hipStream_t s);
+
+template <class P, int CT, int EPI, bool LN>
 void go(const Gemm16Args& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
   const int ntc = (EPI == E16_GLU) ? a.NT / 2 : a.NT;
   const int ny = EPI == E16_HEAD ? 1 : ntc / CT;
   // fewer than ~2 waves per SIMD with one wave per row tile -> split K over the four waves of a workgroup
   if ((size_t)tiles * ny < 2048) {
-    hipLaunchKernelGGL((gemm16_bf16_kernel<CT, EPI, LN, 4>), dim3(tiles, ny), dim3(BLOCK_THREADS), 0, s, a);
+    hipLaunchKernelGGL((gemm16_kernel<P, CT, EPI, LN, 4>), dim3(tiles, ny), dim3(BLOCK_THREADS), 0, s, a);
   } else {
-    hipLaunchKernelGGL((gemm16_bf16_kernel<CT, EPI, LN, 1>), dim3((tiles + 3) / 4, ny), dim3(BLOCK_THREADS), 0, s, a);
+    hipLaunchKernelGGL((gemm16_kernel<P, CT, EPI, LN, 1>), dim3((tiles + 3) / 4, ny), dim3(BLOCK_THREADS), 0, s, a);
   }
+}
+
+// Column tiles per wave: the full row (CT = NT) when the epilogue needs it (residual + LayerNorm: N = dmodel = 144 /
+// 256 / 512) or when there are enough row tiles to fill the chip; otherwise 3 (dmodel 144) / 4 so that small M still
+// gives several hundred waves.
+template <class P>
+int dispatch(int epi, bool ln, const Gemm16Args& a, hipStream_t s) {
+  if (a.K % 16 != 0 || a.K < 16) return -1;
+  const int tiles = (a.M + 15) / 16;
+  const int ntc = (epi == E16_GLU) ? a.NT / 2 : a.NT;
+  const bool d144 = (ntc % 9 == 0);
+  if (!d144 && ntc % 4 != 0 && epi != E16_HEAD) return -1;
+#define CASE(E, L) \
+  if (epi == E && ln == L) { \
+    if constexpr (E == E16_RES) { \
+      if (ntc == 9) go<P, 9, E, L>(a, s); else if (ntc == 16) go<P, 16, E, L>(a, s); \
+      else if (ntc % 8 == 0) { \
+        /* wide rows (dmodel 512): column chunks of 8 tiles, the row LayerNorm as a second pass over y */ \
+        Gemm16Args b = a; b.fln_g = nullptr; b.fln_b = nullptr; go<P, 8, E, L>(b, s); \
+        if (a.fln_g) launch_layernorm_rows(a.y, a.fln_g, a.fln_b, a.M, 16 * ntc, a.ldy, a.eps, s); \
+      } else return -1; \
+    } else if constexpr (E == E16_HEAD) { if (a.NT % 12 != 0) return -1; go<P, 12, E, L>(a, s); } \
+    else if (d144) { if (tiles >= 1024 && E != E16_GLU) go<P, 9, E, L>(a, s); else go<P, 3, E, L>(a, s); } \
+    else { if (tiles >= 1024 && ntc % 8 == 0) go<P, 8, E, L>(a, s); else go<P, 4, E, L>(a, s); } \
+    return 0; }
+  CASE(E16_BIAS, false)
+  CASE(E16_SWISH, true)
+  CASE(E16_RES, false)
+  CASE(E16_QKV, true)
+  CASE(E16_GLU, true)
+  CASE(E16_AFFSWISH, false)
+  CASE(E16_HEAD, false)
+#undef CASE
+  return -1;
+}
+
+// y[row] = LayerNorm(y[row]) in place, one wave per row (two-pass statistics, Keras semantics)
+__global__ __launch_bounds__(BLOCK_THREADS) void layernorm_rows_kernel(float* y, const float* __restrict__ g,
+                                                                      const float* __restrict__ b, int M, int N, int ld, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float* p = y + (size_t)row * ld;
+  float s = 0.f;
+  for (int i = lane * 4; i < N; i += 256) { const f32x4 v = ldg4(p + i); s += (v.x + v.y) + (v.z + v.w); }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)N;
+  float q = 0.f;
+  for (int i = lane * 4; i < N; i += 256) {
+    const f32x4 d = ldg4(p + i) - splat4(mean);
+    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) q += __shfl_xor(q, off);
+  const float rstd = 1.0f / sqrtf(q / (float)N + eps);
+  for (int i = lane * 4; i < N; i += 256)
+    stg4(p + i, (ldg4(p + i) - splat4(mean)) * splat4(rstd) * ldg4(g + i) + ldg4(b + i));
+}
+void launch_layernorm_rows(float* y, const float* g, const float* b, int M, int N, int ld, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s,
+                     y, g, b, M, N, ld, eps);
 }
 
 __global__ void to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
@@ -241,29 +324,6 @@ int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
   return 0;
 }
 
-// Column tiles per wave: the full row (CT = NT) when the epilogue needs it (residual + LayerNorm, N = dmodel) or when
-// there are enough row tiles to fill the chip; otherwise 3 (dmodel 144) / 4 (dmodel 256) so that small M still gives
-// several hundred waves.
-int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s) {
-  if (a.K % 16 != 0 || a.K < 16) return -1;
-  const int tiles = (a.M + 15) / 16;
-  const int ntc = (epi == E16_GLU) ? a.NT / 2 : a.NT;
-  const bool d144 = (ntc % 9 == 0);
-  if (!d144 && ntc % 4 != 0 && epi != E16_HEAD) return -1;
-#define CASE(E, L) \
-  if (epi == E && ln == L) { \
-    if (E == E16_RES) { if (ntc == 9) go<9, E, L>(a, s); else if (ntc == 16) go<16, E, L>(a, s); else return -1; } \
-    else if (E == E16_HEAD) { if (a.NT % 12 != 0) return -1; go<12, E, L>(a, s); } \
-    else if (d144) { if (tiles >= 1024 && ntc % 9 == 0 && E != E16_GLU) go<9, E, L>(a, s); else go<3, E, L>(a, s); } \
-    else { if (tiles >= 1024 && ntc % 16 == 0) go<(E == E16_GLU ? 8 : 16), E, L>(a, s); else go<4, E, L>(a, s); } \
-    return 0; }
-  CASE(E16_BIAS, false)
-  CASE(E16_SWISH, true)
-  CASE(E16_RES, false)
-  CASE(E16_QKV, true)
-  CASE(E16_GLU, true)
-  CASE(E16_AFFSWISH, false)
-  CASE(E16_HEAD, false)
-#undef CASE
-  return -1;
-}
+int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { return dispatch<PBf16>(epi, ln, a, s); }
+// same kernel with fp32 operands: wp = the fp32 P16 weights
+int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { return dispatch<PF32>(epi, ln, a, s); }

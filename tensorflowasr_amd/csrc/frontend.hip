@@ -283,6 +283,98 @@ __global__ __launch_bounds__(BLOCK_THREADS) void subconv_kernel(SubConvArgs a) {
   }
 }
 
+// Same implicit GEMM for any dmodel that is a multiple of 128 (256: ConformerM / StreamingS, 512: ConformerL), with the
+// output channels split over grid.y in chunks of NBW column tiles: a wave keeps 16 positions x NBW tiles of
+// accumulators (32 VGPRs) instead of the whole row, so the kernel fits 256 registers with two waves per SIMD at any
+// width, and small position counts (streaming: 64 chunks x 13 x 20 positions) still give a few thousand waves.
+// conv1 is recomputed per column chunk (VALU work x D/128); dmodel is a run-time value here.
+template <int NBW>
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv_split_kernel(SubConvArgs a, int D) {
+  const int KB = D / 16, NT = D / 16;
+  const int lane = threadIdx.x & 63;
+  const int g4 = (lane >> 4) * 4, c = lane & 15;
+  const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int c0 = blockIdx.y * NBW;
+  const int P = a.B * a.T2 * a.F2;
+  if ((size_t)wid * 16 >= (size_t)P) return;
+  const int pos = wid * 16 + c;
+  float win[7][7];
+  bool tv[3], fv[3];
+  {
+    const int p = min(pos, P - 1);
+    const int b = p / (a.T2 * a.F2);
+    const int r = p % (a.T2 * a.F2);
+    const int t2 = r / a.F2, f2 = r % a.F2;
+    const int tm0 = 4 * t2 - 2 * a.pt2 - a.pt1;
+    const int fm0 = 4 * f2 - 2 * a.pf2 - a.pf1;
+    const float* __restrict__ mb = a.mel + (size_t)b * a.F * a.NM;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int tm = tm0 + i, fm = fm0 + j;
+        win[i][j] = (tm >= 0 && tm < a.F && fm >= 0 && fm < a.NM) ? mb[(size_t)tm * a.NM + fm] : 0.f;
+      }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int t1 = 2 * t2 + k - a.pt2, f1 = 2 * f2 + k - a.pf2;
+      tv[k] = (t1 >= 0 && t1 < a.T1);
+      fv[k] = (f1 >= 0 && f1 < a.F1);
+    }
+  }
+  f32x4 acc[NBW];
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) acc[n] = ldg4(a.b2 + 16 * (c0 + n) + g4);
+  const f32x4* __restrict__ w2 = reinterpret_cast<const f32x4*>(a.w2p) + lane;
+  f32x4 wb[2][NBW];
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) wb[0][n] = w2[(size_t)(0 * NT + c0 + n) * 64];
+#pragma unroll 1
+  for (int cb = 0; cb < KB; ++cb) {
+    f32x4 w1v[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w1v[i][j] = ldg4(a.w1 + (size_t)(i * 3 + j) * D + 16 * cb + g4);
+    const f32x4 b1v = ldg4(a.b1 + 16 * cb + g4);
+    const int cbn = (cb + 1 < KB) ? cb + 1 : cb;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int kt = q / 3, kf = q % 3;
+      const int kbn = (q + 1 < 9) ? cb * 9 + q + 1 : cbn * 9;
+#pragma unroll
+      for (int n = 0; n < NBW; ++n) wb[(q + 1) & 1][n] = w2[(size_t)(kbn * NT + c0 + n) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 v = b1v;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float m = win[2 * kt + i][2 * kf + j];
+          v.x = __builtin_fmaf(m, w1v[i][j].x, v.x); v.y = __builtin_fmaf(m, w1v[i][j].y, v.y);
+          v.z = __builtin_fmaf(m, w1v[i][j].z, v.z); v.w = __builtin_fmaf(m, w1v[i][j].w, v.w);
+        }
+      const bool ok = tv[kt] & fv[kf];
+      v.x = ok ? fmaxf(v.x, 0.f) : 0.f; v.y = ok ? fmaxf(v.y, 0.f) : 0.f;
+      v.z = ok ? fmaxf(v.z, 0.f) : 0.f; v.w = ok ? fmaxf(v.w, 0.f) : 0.f;
+      mma_batch<NBW>(acc, wb[q & 1], v);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // nine steps per channel block: the batch prefetched last sits in wb[1]; the next block starts from wb[0]
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) wb[0][n] = wb[1][n];
+  }
+  if (pos < P) {
+    float* orow = a.out + (size_t)pos * D;
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+      f32x4 v = acc[n];
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      stg4(orow + 16 * (c0 + n) + g4, v);
+    }
+  }
+}
+
 template <int D>
 static void launch_subconv_t(const SubConvArgs& a, hipStream_t s) {
   const int P = a.B * a.T2 * a.F2;
@@ -295,10 +387,16 @@ static void launch_subconv_t(const SubConvArgs& a, hipStream_t s) {
 int launch_subconv(int D, const SubConvArgs& a, hipStream_t s) {
   static const bool v1 = [] { const char* v = getenv("MI355ASR_SUBCONV_V1"); return v && atoi(v) != 0; }();
   if (D == 144 && !v1) return launch_subconv144(a, s);    // subconv.hip
-  if (D == 144) launch_subconv_t<144>(a, s);
-  else if (D == 256) launch_subconv_t<256>(a, s);
-  else return -1;
-  return 0;
+  if (D == 144) { launch_subconv_t<144>(a, s); return 0; }
+  static const bool v1_256 = [] { const char* v = getenv("MI355ASR_SUBCONV256_V1"); return v && atoi(v) != 0; }();
+  if (D == 256 && v1_256) { launch_subconv_t<256>(a, s); return 0; }
+  if (D % 128 == 0) {
+    const int P = a.B * a.T2 * a.F2;
+    const int tiles = (P + 15) / 16;
+    hipLaunchKernelGGL((subconv_split_kernel<8>), dim3((tiles + 3) / 4, D / 128), dim3(BLOCK_THREADS), 0, s, a, D);
+    return 0;
+  }
+  return -1;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -174,6 +174,7 @@ struct Gemm16Args {
   int32_t* argmax_out;  // [M] (E16_HEAD)
 };
 int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s);
+int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s);   // wp = fp32 P16 weights
 int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // block-level fused kernels (fused.hip, dmodel 144)
 struct Ff1QkvArgs {

@@ -770,3 +770,30 @@ def test_bf16_block_matches_rounding_oracle(torch_cuda, base):
     print("bf16 block vs rounding oracle: max %.3g mean %.3g (vs exact: max %.3g)" % (e.max(), e.mean(), np.abs(got - exact).max()))
     assert e.max() < 6e-3 and e.mean() < 3e-4      # tie flips: ~1e-4 mean (see the test above)
     assert np.abs(got - exact).max() > 10 * e.mean()               # it really is the bf16 path
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ConformerM / ConformerL (asr/configs/conformerM.yml, conformerL.yml)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("base,L", [(co.CONFORMER_L, 24000), (co.CONFORMER_M, 32000), (co.CONFORMER_L, 3000)])
+def test_conformer_m_and_l_parity(torch_cuda, base, L):
+    """dmodel 256 (chained fp32 kernels + column-split subsampling conv) and dmodel 512 = 8 heads x 64 (layer-at-a-time
+    fp32 GEMM kernels): waveform -> encoder -> CTC logits -> greedy ids against the oracle."""
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = small_cfg(2, base)
+    w = co.encoder_weights(cfg, seed=41)
+    w.update(co.ctc_decoder_weights(cfg, 200, seed=42))
+    m = ConformerCTC(200, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+    m.load_weights(w, by_name=False)
+    x = waves(2, L, 23)
+    enc_ref = co.conformer_encoder(x.astype(np.float64), w, cfg)
+    logits_ref = co.ctc_decoder(enc_ref, w, cfg)
+    enc = m.encode(x)
+    logits, amax = m.ctc_logits(enc, return_argmax=True)
+    assert maxdiff(enc.cpu().numpy(), enc_ref) < TOL
+    assert maxdiff(logits.cpu().numpy(), logits_ref) < TOL
+    bad = [b for b in argmax_mismatch_report(logits.cpu().numpy(), logits_ref) if b[1] > 1e-3]
+    assert not bad, bad
+    ids, lens = m.recognize(x)
+    rid, rlen = co.ctc_greedy(logits.cpu().numpy(), [logits.shape[1]] * 2, 199)
+    assert (ids.cpu().numpy() == rid).all() and (lens.cpu().numpy() == rlen).all()

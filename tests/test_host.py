@@ -59,6 +59,16 @@ def test_create_rejects_unsupported_configs_with_message(bad):
     assert len(lib.mi355asr_last_error()) > 10
 
 
+def test_create_accepts_the_three_reference_model_sizes():
+    """conformerS / M / L .yml: dmodel 144 (4 x 36), 256 (4 x 64), 512 (8 x 64)."""
+    for d, h, hs in ((144, 4, 36), (256, 4, 64), (512, 8, 64)):
+        lib, rc, p = _create(dmodel=d, num_heads=h, head_size=hs)
+        assert rc == 0 and p.value, lib.mi355asr_last_error()
+        lib.mi355asr_destroy(p)
+    lib, rc, p = _create(dmodel=320, num_heads=5, head_size=64)
+    assert rc == -1 and b"multiples of 128" in lib.mi355asr_last_error()
+
+
 def test_weight_surface_and_shape_validation():
     lib, rc, p = _create(num_classes=1332, ctc_num_blocks=1)
     assert rc == 0
