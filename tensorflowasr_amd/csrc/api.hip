@@ -504,7 +504,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
   const float fc = bo.fc;
   const int M = B * T;
   static const bool fused_env = [] { const char* v = getenv("MI355ASR_FUSED"); return v ? atoi(v) != 0 : true; }();
-  if (use_gemm16(m) && !cross) {
+  if (use_gemm16(m)) {
     // one launch per dense layer (bf16.hip: bf16 or fp32 operands); LayerNorm / softmax / activations / depthwise conv in fp32
     auto g16 = [&](const float* x, int ldx, int K, const float* wp, const float* bias, int NT, float* y, int ldy) {
       Gemm16Args g{};
@@ -523,13 +523,26 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     };
     int rc = ffn(0, sc.xa, sc.xb, nullptr, nullptr);
     if (rc) return rc;
-    Gemm16Args q = g16(sc.xb, d, d, w.qkv_wp, w.qkv_b, 3 * d / 16, sc.qkv, 3 * d);
-    q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
-    { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm16(m, E16_QKV, true, q, w.qkv_wp, s), "qkv"); }
     AttnArgs at{};
-    at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ctx = sc.ctx;
-    at.B = B; at.Tq = T; at.Tk = T; at.H = H; at.D = d; at.ldq = 3 * d; at.ldk = 3 * d;
+    at.ctx = sc.ctx; at.B = B; at.Tq = T; at.H = H; at.D = d;
     at.win_front = bo.win_front; at.win_back = bo.win_back;
+    if (cross) {
+      // RBlock: q = (LN(xb + PE) Wq) / sqrt(hs) ; [k | v] = enc [Wk | Wv]
+      AddPeArgs pa{sc.xb, cross->pe, sc.u, B, T, d};
+      { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_add_pe(pa, s), "positional encoding"); }
+      Gemm16Args q = g16(sc.u, d, d, w.xq_wp, w.qkv_b, d / 16, sc.qkv, d);
+      q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
+      { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm16(m, E16_QKV, true, q, w.xq_wp, s), "cross-attention query projection"); }
+      Gemm16Args kv = g16(cross->enc, d, d, w.xkv_wp, w.qkv_b, 2 * d / 16, cross->kv, 2 * d);
+      kv.M = B * cross->T_enc;
+      { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm16(m, E16_BIAS, false, kv, w.xkv_wp, s), "cross-attention key/value projection"); }
+      at.q = sc.qkv; at.ldq = d; at.k = cross->kv; at.v = cross->kv + d; at.ldk = 2 * d; at.Tk = cross->T_enc;
+    } else {
+      Gemm16Args q = g16(sc.xb, d, d, w.qkv_wp, w.qkv_b, 3 * d / 16, sc.qkv, 3 * d);
+      q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
+      { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm16(m, E16_QKV, true, q, w.qkv_wp, s), "qkv"); }
+      at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ldq = 3 * d; at.ldk = 3 * d; at.Tk = T;
+    }
     { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
     Gemm16Args op = g16(sc.ctx, d, d, w.out_wp, w.out_b, d / 16, sc.xa, d);
     op.res = sc.xb;
@@ -1359,7 +1372,7 @@ int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int 
 constexpr int kMaxTokens = 2048;   // rows of the positional-encoding table
 
 struct TransPlan {
-  size_t xa, xb, qkv, ctx, u, dw, kv, amax, total;
+  size_t xa, xb, qkv, ctx, u, dw, kv, amax, h4, total;
 };
 TransPlan make_trans_plan(const mi355asr_model* m, int B, int U, int T) {
   const size_t d = m->cfg.dmodel, M = (size_t)B * U;
@@ -1368,6 +1381,7 @@ TransPlan make_trans_plan(const mi355asr_model* m, int B, int U, int T) {
   auto take = [&](size_t floats) { size_t at = o; o = align256(o + floats * 4); return at; };
   p.xa = take(M * d); p.xb = take(M * d); p.qkv = take(M * 3 * d); p.ctx = take(M * d);
   p.u = take(M * d); p.dw = take(M * d); p.kv = take((size_t)B * T * 2 * d); p.amax = take(M);
+  p.h4 = use_gemm16(m) ? take(M * 4 * d) : 0;
   p.total = o;
   return p;
 }
@@ -1697,7 +1711,8 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
 int mi355asr_translator_create(const mi355asr_translator_config* cfg, mi355asr_model** out) {
   if (!cfg || !out) return fail(MI355ASR_EINVAL, "null argument");
   const auto& c = *cfg;
-  if (c.dmodel != 144 && c.dmodel != 256) return fail(MI355ASR_EINVAL, "Translator: dmodel=%d, kernels instantiated for 144 and 256", c.dmodel);
+  if (c.dmodel != 144 && (c.dmodel % 128 != 0 || c.dmodel < 128 || c.dmodel > 1024))
+    return fail(MI355ASR_EINVAL, "Translator: dmodel=%d, supported are 144 and multiples of 128 up to 1024", c.dmodel);
   if (c.num_heads * c.head_size != c.dmodel || (c.head_size != 36 && c.head_size != 64))
     return fail(MI355ASR_EINVAL, "Translator: need num_heads*head_size == dmodel and head_size 36 or 64");
   if (c.kernel_size != 32 && c.kernel_size != 5) return fail(MI355ASR_EINVAL, "kernel_size=%d unsupported", c.kernel_size);
@@ -1742,6 +1757,7 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids, const flo
   const int d = m->cfg.dmodel, M = B * U;
   Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
+  sc.h4 = (float*)(ws + p.h4);
   EmbedArgs ea{ids, m->t_emb, sc.xa, M, m->tcfg.inp_classes, d};
   LAUNCH_TRY(launch_embed(ea, s), "embedding");
   CrossAttn cr{enc, T, (float*)(ws + p.kv), m->t_pe};
@@ -1753,6 +1769,13 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids, const flo
   hd.x = sc.xa; hd.y = logits; hd.wp = m->t_stack.fc_wp; hd.bias = m->t_stack.fc_b;
   hd.M = M; hd.NT = m->t_stack.NT_fc; hd.ldy = m->tcfg.tar_classes; hd.n_valid = m->tcfg.tar_classes; hd.eps = kLnEps;
   hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
+  if (use_gemm16(m)) {
+    Gemm16Args h16{};
+    h16.x = sc.xa; h16.ldx = d; h16.bias = hd.bias; h16.y = logits; h16.ldy = hd.ldy; h16.M = M; h16.K = d; h16.NT = hd.NT;
+    h16.n_valid = hd.n_valid; h16.eps = kLnEps; h16.argmax_out = hd.argmax_out;
+    { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm16(m, E16_HEAD, false, h16, m->t_stack.fc_wp, s), "translator head"); }
+    return 0;
+  }
   { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "translator head"); }
   return 0;
 }
