@@ -411,7 +411,18 @@ BlockDev resolve(const BlockOff& o, const float* base) {
 
 // Layer-at-a-time GEMM family (bf16.hip) instead of the fused / chained fp32 kernels: in bf16 mode, and in fp32 for
 // dmodel values those kernels are not instantiated for (e.g. 512 = ConformerL).
-bool use_gemm16(const mi355asr_model* m) { return m->cfg.gemm_dtype == 1 || (m->cfg.dmodel != 144 && m->cfg.dmodel != 256); }
+bool use_gemm16(const mi355asr_model* m) {
+  static const bool force = [] { const char* v = getenv("MI355ASR_GEMM16"); return v && atoi(v) != 0; }();
+  return force || m->cfg.gemm_dtype == 1 || (m->cfg.dmodel != 144 && m->cfg.dmodel != 256);
+}
+// Few rows (single utterances, small batches, the Translator's token stream): the fused / chained kernels give each
+// 16-row tile to ONE wave that walks a whole run of layers serially (~70 us per fused kernel however small M is); below
+// ~4k rows most SIMDs idle meanwhile, and one launch per layer with K / column splitting is faster (64 x 10 s: 4.5 ms
+// fused vs 8.5 ms; 16 x 10 s: 3.0 vs 2.6 ms; one 10 s utterance: 2.6 vs 1.4 ms).  MI355ASR_SMALL_M overrides.
+bool gemm16_for(const mi355asr_model* m, size_t M) {
+  static const long small_m = [] { const char* v = getenv("MI355ASR_SMALL_M"); return v ? atol(v) : 4096L; }();
+  return use_gemm16(m) || (long)M <= small_m;
+}
 int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s) {
   if (m->cfg.gemm_dtype == 1) { g.wp = m->w16(wp); return launch_gemm16_bf16(epi, ln, g, s); }
   g.wp = wp;
@@ -443,7 +454,7 @@ Plan make_plan(const mi355asr_model* m, int Bp, int F, int T) {
   p.ctx = take(M * d);
   p.u = take(M * d);
   p.dw = take(M * d);
-  p.h4 = use_gemm16(m) ? take(M * 4 * d) : 0;   // before logp: the block-only entry points size to p.logp
+  p.h4 = gemm16_for(m, M) ? take(M * 4 * d) : 0;   // before logp: the block-only entry points size to p.logp
   p.enc = take(M * d);
   p.amax = take(M);
   const int FT = ceil_div(F, 16);
@@ -504,7 +515,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
   const float fc = bo.fc;
   const int M = B * T;
   static const bool fused_env = [] { const char* v = getenv("MI355ASR_FUSED"); return v ? atoi(v) != 0 : true; }();
-  if (use_gemm16(m)) {
+  if (gemm16_for(m, M)) {
     // one launch per dense layer (bf16.hip: bf16 or fp32 operands); LayerNorm / softmax / activations / depthwise conv in fp32
     auto g16 = [&](const float* x, int ldx, int K, const float* wp, const float* bias, int NT, float* y, int ldy) {
       Gemm16Args g{};
@@ -761,7 +772,7 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
   sc.h4 = (float*)(ws + p.h4);
-  const bool bf16 = use_gemm16(m);
+  const bool bf16 = gemm16_for(m, M);
   if (bf16) {
     Gemm16Args pr{};
     pr.x = enc; pr.ldx = d; pr.bias = m->proj_b; pr.y = sc.xa; pr.ldy = d;
@@ -1216,7 +1227,7 @@ int chunk_geometry(const mi355asr_model* m, int B, int L, ChunkGeom* g) {
 }
 
 struct ChunkPlan {
-  size_t xa, xb, qkv, ctx, u, dw, hid, amax, idx, cnt, logp, pmax, mel, sub, total;
+  size_t xa, xb, qkv, ctx, u, dw, hid, amax, idx, cnt, logp, pmax, mel, sub, h4, total;
 };
 
 ChunkPlan make_chunk_plan(const mi355asr_model* m, int B, int F, int T) {
@@ -1233,6 +1244,7 @@ ChunkPlan make_chunk_plan(const mi355asr_model* m, int B, int F, int T) {
   p.pmax = take((size_t)B * std::max(FT * m->dm.NCH_dft, F));
   p.mel = take((size_t)B * F * m->cfg.n_mels);
   p.sub = take(M * m->dm.F2 * d);
+  p.h4 = gemm16_for(m, M) ? take(M * 4 * d) : 0;
   p.total = o;
   return p;
 }
@@ -1381,7 +1393,7 @@ TransPlan make_trans_plan(const mi355asr_model* m, int B, int U, int T) {
   auto take = [&](size_t floats) { size_t at = o; o = align256(o + floats * 4); return at; };
   p.xa = take(M * d); p.xb = take(M * d); p.qkv = take(M * 3 * d); p.ctx = take(M * d);
   p.u = take(M * d); p.dw = take(M * d); p.kv = take((size_t)B * T * 2 * d); p.amax = take(M);
-  p.h4 = use_gemm16(m) ? take(M * 4 * d) : 0;
+  p.h4 = gemm16_for(m, M) ? take(M * 4 * d) : 0;
   p.total = o;
   return p;
 }
@@ -1640,6 +1652,7 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
   const size_t act = (size_t)B * T * d * 4;
   Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
+  sc.h4 = (float*)(ws + p.h4);
   // ---- front: valid Melspectrogram (log10, no max-normalisation) + left-padded VALID ConvSubsampling
   {
     const int FT = ceil_div(g.F, 16);
@@ -1769,7 +1782,7 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids, const flo
   hd.x = sc.xa; hd.y = logits; hd.wp = m->t_stack.fc_wp; hd.bias = m->t_stack.fc_b;
   hd.M = M; hd.NT = m->t_stack.NT_fc; hd.ldy = m->tcfg.tar_classes; hd.n_valid = m->tcfg.tar_classes; hd.eps = kLnEps;
   hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
-  if (use_gemm16(m)) {
+  if (gemm16_for(m, M)) {
     Gemm16Args h16{};
     h16.x = sc.xa; h16.ldx = d; h16.bias = hd.bias; h16.y = logits; h16.ldy = hd.ldy; h16.M = M; h16.K = d; h16.NT = hd.NT;
     h16.n_valid = hd.n_valid; h16.eps = kLnEps; h16.argmax_out = hd.argmax_out;
