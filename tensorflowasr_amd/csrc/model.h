@@ -1,0 +1,225 @@
+// Internal host-side model definitions shared by api.hip, api_chunk.hip and api_translator.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355asr.h"
+#include "beam.h"
+#include "launch.h"
+
+namespace mi355 {
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess) return fail(MI355ASR_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+#define LAUNCH_TRY(expr, what)                                                             \
+  do {                                                                                     \
+    if ((expr) != 0) return fail(MI355ASR_EINVAL, "no kernel instantiation for %s", what); \
+    hipError_t e__ = hipGetLastError();                                                    \
+    if (e__ != hipSuccess) return fail(MI355ASR_EHIP, "launch %s: %s", what, hipGetErrorString(e__)); \
+  } while (0)
+
+constexpr float kLnEps = 1e-3f;  // Keras LayerNormalization default
+constexpr float kBnEps = 1e-3f;  // Keras BatchNormalization default
+
+struct HostTensor {
+  std::vector<float> data;
+  bool set = false;
+};
+struct Expected {
+  std::string name;
+  std::vector<int64_t> dims;  // Keras layout
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto d : dims) n *= d;
+    return n;
+  }
+};
+
+struct BlockDev {
+  // ff_module_1 / ff_module_2
+  const float *ff_ln_g[2], *ff_ln_b[2], *ff_w1p[2], *ff_b1[2], *ff_w2p[2], *ff_b2[2];
+  // mhsa_module
+  const float *att_ln_g, *att_ln_b, *qkv_wp, *qkv_b, *out_wp, *out_b;
+  // RBlock cross-attention (Translator): query kernel [d,d] and [key | value] kernels [d,2d], packed separately
+  const float *xq_wp = nullptr, *xkv_wp = nullptr;
+  // conv_module
+  const float *cv_ln_g, *cv_ln_b, *pw1_wp, *pw1_b, *dw_w, *pc_w1p, *pc_b1, *bn_s, *bn_t, *pw2_wp, *pw2_b;
+  // block-final LayerNorm
+  const float *ln_g, *ln_b;
+};
+
+struct Dims {
+  int hop, nbins, NT_dft, NCH_dft, LP, KBm, NTm, F1, F2, st1, pf1, pf2;
+};
+
+// per-stack block options: ConformerBlock (full attention, 'same' depthwise padding) or ChunkConformerBlock
+// (band attention [win_front, win_back], 'causal' depthwise padding; chunk_conformer_blocks.py:327-398)
+struct BlockOpts {
+  int ksz = 32;
+  float fc = 0.5f;
+  int win_front = -1;   // < 0: full attention
+  int win_back = 0;
+  bool causal = false;
+};
+
+struct StackDev {
+  std::vector<BlockDev> blocks;
+  const float *proj_wp = nullptr, *proj_b = nullptr, *fc_wp = nullptr, *fc_b = nullptr;
+  int NT_fc = 0, num_classes = 0;
+  BlockOpts opts;
+};
+
+}  // namespace mi355
+using namespace mi355;
+
+struct mi355asr_model {
+  mi355asr_config cfg;
+  Dims dm;
+  std::vector<Expected> expected;
+  std::map<std::string, HostTensor> host;
+  bool finalized = false;
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  // gemm_dtype 1: the whole arena again in bf16 (same element offsets; packed matrices keep their fragment order)
+  unsigned short* arena16 = nullptr;
+  const void* w16(const float* p) const { return arena16 + (p - arena); }
+  const float *dft_wp = nullptr, *mel_wp = nullptr, *c1_w = nullptr, *c1_b = nullptr, *c2_wp = nullptr,
+              *c2_b = nullptr, *lin_wp = nullptr, *lin_b = nullptr, *proj_wp = nullptr, *proj_b = nullptr,
+              *fc_wp = nullptr, *fc_b = nullptr;
+  int NT_fc = 0;
+  // FFT-as-GEMM STFT operands; fft_ok only when the loaded DFT kernels are window * exp(-2 pi i k n / N) (pack_fft)
+  bool fft_ok = false;
+  const float *fft_w1p = nullptr, *fft_w2p = nullptr, *fft_twc = nullptr, *fft_tws = nullptr, *fft_win = nullptr;
+  std::vector<BlockDev> enc_blocks, ctc_blocks;
+  // ChunkConformer (mi355asr_chunk_create): front + encoder / phone picker / context helper / text decoder stacks
+  bool is_chunk = false;
+  mi355asr_chunk_config ccfg;
+  // Translator (mi355asr_translator_create): Embedding + RBlock stack + Dense head
+  bool is_translator = false;
+  mi355asr_translator_config tcfg;
+  StackDev t_stack;
+  const float *t_emb = nullptr, *t_pe = nullptr;   // [inp_classes, d], [kMaxTokens, d]
+  StackDev c_enc, c_picker, c_helper, c_decoder;
+  // optional per-kernel timing with HIP events on the launch stream (mi355asr_profile_*)
+  mutable bool prof = false;
+  mutable std::vector<hipEvent_t> ev_free;
+  struct Pending { int cat; hipEvent_t e0, e1; };
+  mutable std::vector<Pending> ev_pending;
+  mutable double prof_ms[MI355ASR_NUM_KERNELS] = {0};
+  mutable int64_t prof_cnt[MI355ASR_NUM_KERNELS] = {0};
+  hipEvent_t get_event() const {
+    if (!ev_free.empty()) { hipEvent_t e = ev_free.back(); ev_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+};
+namespace mi355 {
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// brackets one kernel launch with events on its stream when profiling is on
+struct ProfScope {
+  const mi355asr_model* m;
+  int cat;
+  hipStream_t s;
+  hipEvent_t e0 = nullptr;
+  ProfScope(const mi355asr_model* m_, int cat_, hipStream_t s_) : m(m_), cat(cat_), s(s_) {
+    if (m->prof) { e0 = m->get_event(); (void)hipEventRecord(e0, s); }
+  }
+  ~ProfScope() {
+    if (m->prof && e0) {
+      hipEvent_t e1 = m->get_event();
+      (void)hipEventRecord(e1, s);
+      m->ev_pending.push_back({cat, e0, e1});
+    }
+  }
+};
+#define PROF(cat) ProfScope prof_scope_##cat(m, cat, s)
+
+struct ArenaBuilder {
+  std::vector<float> buf;
+  size_t put(const std::vector<float>& v) {
+    size_t off = (buf.size() + 63) & ~(size_t)63;  // 256-byte alignment
+    buf.resize(off + v.size());
+    std::memcpy(buf.data() + off, v.data(), v.size() * sizeof(float));
+    return off;
+  }
+  size_t put_padded(const float* p, size_t n, size_t padded) {
+    std::vector<float> v(padded, 0.f);
+    std::memcpy(v.data(), p, n * sizeof(float));
+    return put(v);
+  }
+};
+
+struct FftOff { bool ok = false; size_t w1 = 0, w2 = 0, twc = 0, tws = 0, win = 0; };
+
+struct BlockOff {
+  size_t ff_ln_g[2], ff_ln_b[2], ff_w1p[2], ff_b1[2], ff_w2p[2], ff_b2[2];
+  size_t att_ln_g, att_ln_b, qkv_wp, qkv_b, out_wp, out_b;
+  size_t xq_wp = 0, xkv_wp = 0;
+  bool cross = false;
+  size_t cv_ln_g, cv_ln_b, pw1_wp, pw1_b, dw_w, pc_w1p, pc_b1, bn_s, bn_t, pw2_wp, pw2_b;
+  size_t ln_g, ln_b;
+};
+
+struct Plan {
+  size_t xa, xb, qkv, ctx, u, dw, enc, amax, logp, pmax, umax, mel, sub, h4, total;
+};
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Geometry {
+  int Bp, Lb, F, T1, T, nblk;
+};
+
+struct Scratch {
+  float *xa, *xb, *qkv, *ctx, *u, *dw;
+  float* h4 = nullptr;   // [M, 4d] FFN hidden (bf16 GEMM path only: its layers are separate launches)
+};
+
+struct CrossAttn {
+  const float* enc;   // [B, T_enc, d]
+  int T_enc;
+  float* kv;          // scratch [B * T_enc, 2d]
+  const float* pe;    // [>= T, d]
+};
+
+struct StackOff {
+  std::vector<BlockOff> blocks;
+  size_t proj_w = 0, proj_b = 0, fc_w = 0, fc_b = 0;
+  int NT_fc = 0;
+};
+
+// ---- shared host functions (defined in api.hip) -----------------------------------------------------------
+int fail(int code, const char* fmt, ...);
+void same_pad(int n, int k, int s, int* out, int* before);
+void add_block_expected(std::vector<Expected>& ex, const std::string& p, int d, int H, int hs, int k, bool keras_mha = false);
+std::vector<float> pack_p16(const std::function<float(int, int)>& f, int K, int N, int NTpad);
+FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vector<float>& im, int n_dft, int nb);
+BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k, bool keras_mha = false);
+BlockDev resolve(const BlockOff& o, const float* base);
+bool use_gemm16(const mi355asr_model* m);
+bool gemm16_for(const mi355asr_model* m, size_t M);
+int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s);
+int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int B, int T, float* out,
+              hipStream_t s, const CrossAttn* cross = nullptr);
+void resolve_stack(StackDev& sd, const StackOff& so, const float* base, bool project, int V);   // api_chunk.hip
+int finalize_chunk(mi355asr_model* m, hipStream_t s);        // api_chunk.hip
+int finalize_translator(mi355asr_model* m, hipStream_t s);   // api_translator.hip
+
+}  // namespace mi355
