@@ -60,6 +60,9 @@ typedef struct {
   int32_t gemm_dtype;        /* 0: fp32 MFMA everywhere (the reference's arithmetic; default)
                               * 1: bf16 MFMA for the dense layers -- bf16 GEMM inputs, fp32 accumulation, fp32
                               *    LayerNorm / softmax / activations / frontend (BASELINE config 3)               */
+  int32_t mel_layer_type;    /* speech_config.mel_layer_type: 0 = 'Melspectrogram' (default), 1 = 'leaf' (LEAF frontend,
+                              *    leaf_audio/frontend.py: Gabor filters + Gaussian pooling + PCEN + instance norm;
+                              *    needs n_mels 80, stride_ms 10 at 16 kHz)                                       */
 } mi355asr_config;
 
 const char* mi355asr_last_error(void);

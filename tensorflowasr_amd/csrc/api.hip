@@ -489,6 +489,17 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
 int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, float* logp, float* pmax,
             float* umax, float* mel, hipStream_t s) {
   const auto& c = m->cfg;
+  if (c.mel_layer_type == 1) {
+    // LEAF: Gabor conv + squared modulus + Gaussian pooling (partials in the log-power scratch), then PCEN + instance norm
+    int nf, pl;
+    same_pad(Lb, 401, m->dm.hop, &nf, &pl);
+    LeafConvArgs la{wav, m->leaf_wp, m->leaf_gcoef, logp, m->leaf_p0, m->leaf_p1, Bp, Lb, F, F, m->dm.hop, pl};
+    { PROF(MI355ASR_K_STFT); LAUNCH_TRY(launch_leaf_conv_pool(la, s), "leaf gabor conv + pooling"); }
+    LeafPcenArgs lp{logp, m->leaf_alpha, m->leaf_delta, m->leaf_root, m->leaf_smooth, m->leaf_gamma, m->leaf_beta, mel,
+                    Bp, F, F, m->dm.hop, pl};
+    { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_leaf_pcen_norm(lp, s), "leaf PCEN + instance norm"); }
+    return 0;
+  }
   const int FT = ceil_div(F, 16);
   int out, before;
   same_pad(Lb, c.n_dft, m->dm.hop, &out, &before);
@@ -643,6 +654,9 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
   if (c.num_classes > 0 && c.ctc_kernel_size != 32 && c.ctc_kernel_size != 5)
     return fail(MI355ASR_EINVAL, "ctc_kernel_size=%d unsupported", c.ctc_kernel_size);
   if (c.reduction_factor != 4) return fail(MI355ASR_EINVAL, "reduction_factor=%d: only 4 is supported", c.reduction_factor);
+  if (c.mel_layer_type != 0 && c.mel_layer_type != 1) return fail(MI355ASR_EINVAL, "mel_layer_type=%d: 0 (Melspectrogram) or 1 (leaf)", c.mel_layer_type);
+  if (c.mel_layer_type == 1 && (c.n_mels != 80 || c.stride_ms * c.sample_rate / 1000 != 160 || c.sample_rate != 16000))
+    return fail(MI355ASR_EINVAL, "leaf frontend: instantiated for 80 filters, 16 kHz, 10 ms stride (window 401, hop 160)");
   if (c.gemm_dtype != 0 && c.gemm_dtype != 1) return fail(MI355ASR_EINVAL, "gemm_dtype=%d: 0 (fp32 MFMA) or 1 (bf16 MFMA)", c.gemm_dtype);
   if (c.n_dft != 1024) return fail(MI355ASR_EINVAL, "n_dft=%d: the reference hard-codes 1024 (conformer_blocks.py:312)", c.n_dft);
   if (c.n_mels != 80 && c.n_mels != 128) return fail(MI355ASR_EINVAL, "n_mels=%d: mel kernel instantiated for 80 and 128", c.n_mels);
@@ -665,10 +679,22 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
   same_pad(dm.F1, 3, 2, &dm.F2, &dm.pf2);
   const int d = c.dmodel;
   auto& ex = m->expected;
+  if (c.has_encoder && c.mel_layer_type == 1) {
+    // leaf_audio.frontend.Leaf variables (frontend.py:106-160)
+    ex.push_back({"mel_layer/tfbanks_preemp/kernel", {2, 1, 1}});
+    ex.push_back({"mel_layer/tfbanks_complex_conv/kernel", {c.n_mels, 2}});
+    ex.push_back({"mel_layer/learnable_pooling/kernel", {1, 1, c.n_mels, 1}});
+    for (const char* n : {"alpha", "delta", "root"}) ex.push_back({std::string("mel_layer/PCEN/") + n, {c.n_mels}});
+    ex.push_back({"mel_layer/PCEN/EMA/smooth", {c.n_mels}});
+    ex.push_back({"mel_layer/tfbanks_instancenorm/gamma", {c.n_mels}});
+    ex.push_back({"mel_layer/tfbanks_instancenorm/beta", {c.n_mels}});
+  }
   if (c.has_encoder) {
+    if (c.mel_layer_type == 0) {
     ex.push_back({"mel_layer/real_kernels", {c.n_dft, 1, 1, dm.nbins}});
     ex.push_back({"mel_layer/imag_kernels", {c.n_dft, 1, 1, dm.nbins}});
     ex.push_back({"mel_layer/freq2mel", {dm.nbins, c.n_mels}});
+    }
     ex.push_back({"conv_subsampling/conv1/kernel", {3, 3, 1, d}});
     ex.push_back({"conv_subsampling/conv1/bias", {d}});
     ex.push_back({"conv_subsampling/conv2/kernel", {3, 3, d, d}});
@@ -730,6 +756,7 @@ int mi355asr_destroy(mi355asr_model* m) {
 
 int mi355asr_stft_mode(const mi355asr_model* m) {
   if (!m || !m->finalized || (!m->is_chunk && !m->cfg.has_encoder)) return -1;
+  if (!m->is_chunk && m->cfg.mel_layer_type == 1) return -1;     // LEAF frontend: no STFT
   return m->fft_ok ? 1 : 0;
 }
 int mi355asr_num_weights(const mi355asr_model* m) { return m ? (int)m->expected.size() : 0; }
@@ -775,10 +802,47 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0;
   FftOff fo;
   std::vector<BlockOff> eo, co;
+  size_t o_leafw = 0, o_lg = 0, o_la = 0, o_ld = 0, o_lr = 0, o_ls = 0, o_lga = 0, o_lbe = 0;
+  if (c.has_encoder && c.mel_layer_type == 1) {
+    // Gabor filters from (center, sigma) with the layer's constraint (convolution.py:137-153, impulse_responses.py:39-64)
+    const int K = 401, NF = c.n_mels;
+    const auto& gk = m->host["mel_layer/tfbanks_complex_conv/kernel"].data;
+    const double pi = 3.14159265358979323846, s2l2 = std::sqrt(2.0 * std::log(2.0));
+    std::vector<double> re((size_t)NF * K), im((size_t)NF * K);
+    for (int f = 0; f < NF; ++f) {
+      const double mu = std::min(std::max((double)gk[2 * f], 0.0), pi);
+      const double sg = std::min(std::max((double)gk[2 * f + 1], 4.0 * s2l2 / pi), K * s2l2 / pi);
+      const double den = 1.0 / (std::sqrt(2.0 * pi) * sg);
+      for (int t = 0; t < K; ++t) {
+        const double tt = t - K / 2, gs = std::exp(-tt * tt / (2.0 * sg * sg));
+        re[(size_t)f * K + t] = den * std::cos(mu * tt) * gs;
+        im[(size_t)f * K + t] = den * std::sin(mu * tt) * gs;
+      }
+    }
+    o_leafw = ab.put(pack_p16([&](int k, int n) { return k < K ? (float)((n & 1) ? im[(size_t)(n >> 1) * K + k] : re[(size_t)(n >> 1) * K + k]) : 0.f; },
+                           26 * 16, 2 * NF, 2 * NF / 16));
+    const auto& ps = m->host["mel_layer/learnable_pooling/kernel"].data;
+    std::vector<float> gc(NF);
+    for (int f = 0; f < NF; ++f) {           // impulse_responses.gaussian_lowpass (:103-119), as exp2 coefficients
+      const double sg = std::min(std::max((double)ps[f], 2.0 / K), 0.5);
+      const double den = sg * 0.5 * (K - 1);
+      gc[f] = (float)(-0.5 * 1.4426950408889634 / (den * den));
+    }
+    o_lg = ab.put(gc);
+    o_la = ab.put(m->host["mel_layer/PCEN/alpha"].data);
+    o_ld = ab.put(m->host["mel_layer/PCEN/delta"].data);
+    o_lr = ab.put(m->host["mel_layer/PCEN/root"].data);
+    o_ls = ab.put(m->host["mel_layer/PCEN/EMA/smooth"].data);
+    o_lga = ab.put(m->host["mel_layer/tfbanks_instancenorm/gamma"].data);
+    o_lbe = ab.put(m->host["mel_layer/tfbanks_instancenorm/beta"].data);
+    const auto& pk = m->host["mel_layer/tfbanks_preemp/kernel"].data;
+    m->leaf_p0 = pk[0]; m->leaf_p1 = pk[1];
+  }
   if (c.has_encoder) {
+  const int nb = dm.nbins;
+  if (c.mel_layer_type == 0) {
   const auto& re = m->host["mel_layer/real_kernels"].data;
   const auto& im = m->host["mel_layer/imag_kernels"].data;
-  const int nb = dm.nbins;
   // DFT columns interleaved (re, im) per bin so that power = x^2 + y^2 / z^2 + w^2 inside one lane
   o_dft = ab.put(pack_p16(
       [&](int k, int n) { const int bin = n >> 1; return (n & 1) ? im[(size_t)k * nb + bin] : re[(size_t)k * nb + bin]; },
@@ -786,6 +850,8 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   fo = pack_fft(ab, re, im, c.n_dft, nb);
   const auto& f2m = m->host["mel_layer/freq2mel"].data;
   o_mel = ab.put(pack_p16([&](int k, int n) { return k < nb ? f2m[(size_t)k * c.n_mels + n] : 0.f; }, dm.KBm * 16, c.n_mels, dm.NTm));
+  }
+  (void)nb;
   o_c1w = ab.put(m->host["conv_subsampling/conv1/kernel"].data);  // [3][3][1][d] == [(i*3+j)*d + c]
   o_c1b = ab.put(m->host["conv_subsampling/conv1/bias"].data);
   const auto& c2 = m->host["conv_subsampling/conv2/kernel"].data;              // [3][3][d][d]
@@ -832,6 +898,8 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
+  m->leaf_wp = base + o_leafw; m->leaf_gcoef = base + o_lg; m->leaf_alpha = base + o_la; m->leaf_delta = base + o_ld;
+  m->leaf_root = base + o_lr; m->leaf_smooth = base + o_ls; m->leaf_gamma = base + o_lga; m->leaf_beta = base + o_lbe;
   if (m->arena16) { (void)hipFree(m->arena16); m->arena16 = nullptr; }
   if (c.gemm_dtype == 1) {
     const size_t n16 = (m->arena_floats + 3) & ~(size_t)3;

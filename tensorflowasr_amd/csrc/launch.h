@@ -155,6 +155,23 @@ struct AddPeArgs {
 };
 int launch_embed(const EmbedArgs& a, hipStream_t s);
 int launch_add_pe(const AddPeArgs& a, hipStream_t s);
+// LEAF frontend (leaf.hip)
+struct LeafConvArgs {
+  const float* wav;     // [B, L]
+  const float* wp;      // Gabor filters, P16 packed [26][10][64][4]: rows = taps (401, zero padded), cols = (re, im) per filter
+  const float* gcoef;   // [80] -0.5 log2(e) / (sigma_c * 200)^2 of the Gaussian pooling windows
+  float* part;          // [B, NH, 4, 80] partial pooled sums per hop
+  float p0, p1;         // pre-emphasis taps: xp[n] = p0 x[n] + p1 x[n+1]
+  int B, L, F, NH, hop, pl;   // pl = left padding of the SAME pooling
+};
+struct LeafPcenArgs {
+  const float* part;
+  const float *alpha, *delta, *root, *smooth, *gamma, *beta;   // [80] each
+  float* out;           // [B, F, 80]
+  int B, F, NH, hop, pl;
+};
+int launch_leaf_conv_pool(const LeafConvArgs& a, hipStream_t s);
+int launch_leaf_pcen_norm(const LeafPcenArgs& a, hipStream_t s);
 // bf16-MFMA GEMM family (bf16.hip)
 enum { E16_BIAS = 0, E16_SWISH = 1, E16_RES = 2, E16_QKV = 3, E16_GLU = 4, E16_AFFSWISH = 5, E16_HEAD = 6 };
 struct Gemm16Args {

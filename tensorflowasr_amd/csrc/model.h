@@ -104,6 +104,10 @@ struct mi355asr_model {
   // FFT-as-GEMM STFT operands; fft_ok only when the loaded DFT kernels are window * exp(-2 pi i k n / N) (pack_fft)
   bool fft_ok = false;
   const float *fft_w1p = nullptr, *fft_w2p = nullptr, *fft_twc = nullptr, *fft_tws = nullptr, *fft_win = nullptr;
+  // LEAF frontend (mel_layer_type 1): packed Gabor filters, pooling coefficients, PCEN / instance-norm vectors
+  const float *leaf_wp = nullptr, *leaf_gcoef = nullptr, *leaf_alpha = nullptr, *leaf_delta = nullptr, *leaf_root = nullptr,
+              *leaf_smooth = nullptr, *leaf_gamma = nullptr, *leaf_beta = nullptr;
+  float leaf_p0 = 0.f, leaf_p1 = 1.f;
   std::vector<BlockDev> enc_blocks, ctc_blocks;
   // ChunkConformer (mi355asr_chunk_create): front + encoder / phone picker / context helper / text decoder stacks
   bool is_chunk = false;

@@ -54,3 +54,29 @@ def freq2mel(sr=16000, n_dft=1024, n_mels=80, fmin=0.0, fmax=None, norm=1):
     elif norm is not None:
         raise ValueError("norm must be 1, 'slaney' or None")
     return np.ascontiguousarray(fb.T.astype(np.float32))
+
+
+def leaf_default_weights(n_filters=80, sample_rate=16000, prefix="mel_layer"):
+    """Initial values of the LEAF frontend as ConformerEncoder constructs it (conformer_blocks.py:316): PreempInit(0.97),
+    GaborInit(sample_rate, min_freq = 30 * (sr // 8000), max_freq = 3900 * (sr // 8000)) -- centre frequency and width
+    of each Gabor filter read off a 512-point HTK mel bank (leaf_audio/melfilters.py:58-92) -- Gaussian pooling sigma
+    0.4, PCEN alpha 0.96 / smoothing 0.04 / delta 2 / root 2, instance-norm gamma 1 / beta 0 (frontend.py:106-160)."""
+    n_fft = 512
+    lo, hi = 30.0 * (sample_rate // 8000), 3900.0 * (sample_rate // 8000)
+    nbins = n_fft // 2 + 1
+    to_mel = lambda f: 1127.0 * np.log1p(np.asarray(f, np.float64) / 700.0)
+    spec = to_mel(np.linspace(0.0, sample_rate / 2.0, nbins)[1:])[:, None]       # tf.signal skips the DC bin ...
+    edges = np.linspace(to_mel(lo), to_mel(hi), n_filters + 2)
+    lower, center, upper = edges[None, :-2], edges[None, 1:-1], edges[None, 2:]
+    bank = np.maximum(0.0, np.minimum((spec - lower) / (center - lower), (upper - spec) / (upper - center)))
+    bank = np.sqrt(np.pad(bank, ((1, 0), (0, 0))).T)                              # ... and pads it back as zeros
+    centers = bank.argmax(1).astype(np.float64)
+    fwhm = (bank >= bank.max(1, keepdims=True) / 2.0).sum(1).astype(np.float64)
+    kern = np.stack([centers * 2 * np.pi / n_fft, np.sqrt(2.0 * np.log(2.0)) * n_fft / (np.pi * fwhm)], 1)
+    one = np.ones(n_filters, np.float32)
+    return {prefix + "/tfbanks_preemp/kernel": np.array([-0.97, 1.0], np.float32).reshape(2, 1, 1),
+            prefix + "/tfbanks_complex_conv/kernel": kern.astype(np.float32),
+            prefix + "/learnable_pooling/kernel": np.full((1, 1, n_filters, 1), 0.4, np.float32),
+            prefix + "/PCEN/alpha": 0.96 * one, prefix + "/PCEN/delta": 2.0 * one, prefix + "/PCEN/root": 2.0 * one,
+            prefix + "/PCEN/EMA/smooth": 0.04 * one,
+            prefix + "/tfbanks_instancenorm/gamma": one.copy(), prefix + "/tfbanks_instancenorm/beta": 0.0 * one}

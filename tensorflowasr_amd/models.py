@@ -39,6 +39,8 @@ def default_weights(names_and_shapes, rng, sample_rate=16000, n_dft=1024, n_mels
             w[name] = {"real_kernels": frontend_consts.stft_kernels(n_dft)[0],
                        "imag_kernels": frontend_consts.stft_kernels(n_dft)[1],
                        "freq2mel": frontend_consts.freq2mel(sample_rate, n_dft, n_mels)}[leaf]
+        elif name.startswith("mel_layer/") and name in frontend_consts.leaf_default_weights(n_mels, sample_rate):
+            w[name] = frontend_consts.leaf_default_weights(n_mels, sample_rate)[name]
         elif leaf == "embeddings":                  # tf.keras.layers.Embedding default: uniform(-0.05, 0.05)
             w[name] = rng.uniform(-0.05, 0.05, shape).astype(np.float32)
         elif leaf in ("gamma", "moving_variance"):
@@ -238,14 +240,21 @@ def _block_shapes(p, d, H, hs, k):
     return s
 
 
-def _encoder_shapes(d, H, hs, k, num_blocks, n_mels, n_dft=1024):
+def _encoder_shapes(d, H, hs, k, num_blocks, n_mels, n_dft=1024, leaf=False):
     nb = n_dft // 2 + 1
     f2 = -(-(-(-n_mels // 2)) // 2)
-    s = {"mel_layer/real_kernels": (n_dft, 1, 1, nb), "mel_layer/imag_kernels": (n_dft, 1, 1, nb),
-         "mel_layer/freq2mel": (nb, n_mels),
+    if leaf:
+        s = {"mel_layer/tfbanks_preemp/kernel": (2, 1, 1), "mel_layer/tfbanks_complex_conv/kernel": (n_mels, 2),
+             "mel_layer/learnable_pooling/kernel": (1, 1, n_mels, 1), "mel_layer/PCEN/alpha": (n_mels,),
+             "mel_layer/PCEN/delta": (n_mels,), "mel_layer/PCEN/root": (n_mels,), "mel_layer/PCEN/EMA/smooth": (n_mels,),
+             "mel_layer/tfbanks_instancenorm/gamma": (n_mels,), "mel_layer/tfbanks_instancenorm/beta": (n_mels,)}
+    else:
+        s = {"mel_layer/real_kernels": (n_dft, 1, 1, nb), "mel_layer/imag_kernels": (n_dft, 1, 1, nb),
+             "mel_layer/freq2mel": (nb, n_mels)}
+    s.update({
          "conv_subsampling/conv1/kernel": (3, 3, 1, d), "conv_subsampling/conv1/bias": (d,),
          "conv_subsampling/conv2/kernel": (3, 3, d, d), "conv_subsampling/conv2/bias": (d,),
-         "conv_subsampling/linear/kernel": (f2 * d, d), "conv_subsampling/linear/bias": (d,)}
+         "conv_subsampling/linear/kernel": (f2 * d, d), "conv_subsampling/linear/bias": (d,)})
     for i in range(num_blocks):
         s.update(_block_shapes("conformer_block_%d" % i, d, H, hs, k))
     return s
@@ -271,8 +280,10 @@ class ConformerEncoder(_ModelBase):
         """gemm_dtype (not in the reference): "float32" (default, the reference's arithmetic) or "bfloat16" = bf16 MFMA
         inputs with fp32 accumulation for the dense layers (BASELINE config 3)."""
         self.gemm_dtype = _gemm_dtype(gemm_dtype)
-        if mel_layer_type != "Melspectrogram":
-            raise NotImplementedError("mel_layer_type=%r: only 'Melspectrogram' is on the MI355X hot path" % mel_layer_type)
+        if mel_layer_type not in ("Melspectrogram", "leaf"):
+            raise NotImplementedError("mel_layer_type=%r: 'Melspectrogram' and 'leaf' are implemented (the reference's "
+                                      "third choice, the plain Spectrogram layer, is not)" % mel_layer_type)
+        self.mel_layer_type = mel_layer_type
         if add_wav_info:
             raise NotImplementedError("add_wav_info=True (WavePickModel branch) is outside the hot path")
         self.name = name
@@ -294,12 +305,12 @@ class ConformerEncoder(_ModelBase):
                           reduction_factor=self.reduction_factor, n_mels=self.n_mels, sample_rate=self.sample_rate,
                           stride_ms=self.stride_ms, n_dft=1024, chunk_size=self.chunk_size, has_encoder=1,
                           num_classes=0, ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5,
-                          gemm_dtype=self.gemm_dtype)
+                          gemm_dtype=self.gemm_dtype, mel_layer_type=int(self.mel_layer_type == "leaf"))
         self._h = _Handle(cfg, self._device)
 
     def _expected_shapes(self):
         return _encoder_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks,
-                               self.n_mels)
+                               self.n_mels, leaf=self.mel_layer_type == "leaf")
 
     def __call__(self, inputs, training=False, **kwargs):
         """wav [B, L, 1] (or [B, L]) float32 -> torch.Tensor [B, T, dmodel] on the device."""
@@ -507,8 +518,11 @@ class ConformerCTC(_ModelBase):
     def __init__(self, num_classes, dmodel=144, reduction_factor=4, num_blocks=13, head_size=36, num_heads=4,
                  kernel_size=32, fc_factor=0.5, sample_rate=16000, n_mels=80, stride_ms=10, chunk_size=0,
                  ctcdecoder_num_blocks=1, ctcdecoder_kernel_size=32, ctcdecoder_fc_factor=0.5,
-                 device="cuda:0", name="conformer_ctc", gemm_dtype="float32", **kwargs):
+                 device="cuda:0", name="conformer_ctc", gemm_dtype="float32", mel_layer_type="Melspectrogram", **kwargs):
         self.name = name
+        if mel_layer_type not in ("Melspectrogram", "leaf"):
+            raise NotImplementedError("mel_layer_type=%r" % mel_layer_type)
+        self.mel_layer_type = mel_layer_type
         self.num_classes, self.dmodel = num_classes, dmodel
         self.blank = num_classes - 1               # utils/text_featurizers.py:65-70 (blank_at_zero: False)
         self.num_blocks, self.head_size, self.num_heads, self.kernel_size = num_blocks, head_size, num_heads, kernel_size
@@ -521,7 +535,8 @@ class ConformerCTC(_ModelBase):
                           n_mels=n_mels, sample_rate=sample_rate, stride_ms=stride_ms, n_dft=1024,
                           chunk_size=self.chunk_size, has_encoder=1, num_classes=num_classes,
                           ctc_num_blocks=ctcdecoder_num_blocks, ctc_kernel_size=ctcdecoder_kernel_size,
-                          ctc_fc_factor=ctcdecoder_fc_factor, gemm_dtype=_gemm_dtype(gemm_dtype))
+                          ctc_fc_factor=ctcdecoder_fc_factor, gemm_dtype=_gemm_dtype(gemm_dtype),
+                          mel_layer_type=int(mel_layer_type == "leaf"))
         self._h = _Handle(cfg, device)
 
     @classmethod
@@ -538,7 +553,8 @@ class ConformerCTC(_ModelBase):
                    ctcdecoder_fc_factor=mc["ctcdecoder_fc_factor"], device=device)
 
     def _expected_shapes(self):
-        s = _encoder_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks, self.n_mels)
+        s = _encoder_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks, self.n_mels,
+                            leaf=self.mel_layer_type == "leaf")
         s.update(_ctc_shapes(self.dmodel, self.num_heads, self.head_size, self.ctc_kernel, self.ctc_blocks,
                              self.num_classes))
         return s

@@ -824,3 +824,70 @@ def test_translator_dmodel_512(torch_cuda):
     got, amax = tr([ids, enc], return_argmax=True)
     assert maxdiff(got.cpu().numpy(), ref) < TOL
     assert (amax.cpu().numpy() == got.cpu().numpy().argmax(-1)).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LEAF frontend (mel_layer_type 'leaf')
+# ---------------------------------------------------------------------------------------------------------
+def _leaf_weights(cfg, seed, trained=True):
+    w = co.encoder_weights(cfg, seed=seed)
+    for k in [k for k in w if k.startswith("mel_layer/")]:
+        del w[k]
+    lw = co.leaf_default_weights()
+    if trained:                                         # move every learnable off its initial value
+        rng = np.random.default_rng(seed)
+        lw["mel_layer/tfbanks_preemp/kernel"] = np.array([-0.93, 1.02], np.float32).reshape(2, 1, 1)
+        k = lw["mel_layer/tfbanks_complex_conv/kernel"]
+        k[:, 0] *= rng.uniform(0.97, 1.03, 80).astype(np.float32)
+        k[:, 1] *= rng.uniform(0.8, 1.2, 80).astype(np.float32)
+        lw["mel_layer/learnable_pooling/kernel"] = rng.uniform(0.25, 0.6, (1, 1, 80, 1)).astype(np.float32)
+        lw["mel_layer/PCEN/alpha"] = rng.uniform(0.8, 1.05, 80).astype(np.float32)          # > 1 is clipped
+        lw["mel_layer/PCEN/delta"] = rng.uniform(1.0, 3.0, 80).astype(np.float32)
+        lw["mel_layer/PCEN/root"] = rng.uniform(0.9, 3.0, 80).astype(np.float32)            # < 1 is clipped
+        lw["mel_layer/PCEN/EMA/smooth"] = rng.uniform(0.02, 0.08, 80).astype(np.float32)
+        lw["mel_layer/tfbanks_instancenorm/gamma"] = rng.uniform(0.5, 1.5, 80).astype(np.float32)
+        lw["mel_layer/tfbanks_instancenorm/beta"] = (0.2 * rng.standard_normal(80)).astype(np.float32)
+    w.update(lw)
+    return w
+
+
+@pytest.mark.parametrize("L,trained", [(16000, True), (24160, False), (8100, True), (1000, True)])
+def test_leaf_frontend_parity(torch_cuda, L, trained):
+    """Gabor conv + squared modulus + Gaussian pooling + PCEN + instance norm against the oracle; lengths that are
+    and are not multiples of the hop (the SAME padding of the pooling depends on L)."""
+    from tensorflowasr_amd.models import ConformerEncoder
+    cfg = small_cfg(1)
+    w = _leaf_weights(cfg, 7, trained)
+    e = ConformerEncoder(**dict(encoder_kwargs(cfg), mel_layer_type="leaf"))
+    e.load_weights(w, by_name=False)
+    assert e._h.lib.mi355asr_stft_mode(e._h.ptr) == -1
+    x = waves(2, L, 60)
+    ref = co.leaf_frontend(x.astype(np.float64), w)
+    got = e.melspectrogram(x).cpu().numpy()
+    assert got.shape == ref.shape == (2, -(-L // 160), 80)
+    assert maxdiff(got, ref) < TOL
+    enc_ref = co.conformer_block(co.conv_subsampling(ref, w), w, "conformer_block_0", cfg["head_size"], cfg["fc_factor"])
+    assert maxdiff(e(x).cpu().numpy(), enc_ref) < TOL
+
+
+def test_leaf_streaming_blocks_and_full_batch(torch_cuda):
+    """LEAF under the Block Conformer (every 0.5 s block is its own utterance for the frontend) and at B = 8 x 10 s."""
+    from tensorflowasr_amd.models import ConformerEncoder, StreamingConformerEncoder
+    cfg = small_cfg(1, co.STREAMING_S)
+    w = _leaf_weights(cfg, 8)
+    st = StreamingConformerEncoder(**dict(encoder_kwargs(cfg), mel_layer_type="leaf"))
+    st.add_chunk_size(8000, 80, 640)
+    st.load_weights(w, by_name=False)
+    x = waves(2, 16000, 70)
+    mel = st.melspectrogram(x).cpu().numpy()                     # [B * 2 blocks, 50, 80]
+    ref = co.leaf_frontend(x.reshape(4, 8000).astype(np.float64), w)
+    assert maxdiff(mel, ref) < TOL
+    cfg2 = small_cfg(1)
+    w2 = _leaf_weights(cfg2, 9)
+    e = ConformerEncoder(**dict(encoder_kwargs(cfg2), mel_layer_type="leaf"))
+    e.load_weights(w2, by_name=False)
+    xb = waves(8, 160000, 80)
+    got = e.melspectrogram(xb).cpu().numpy()
+    assert np.isfinite(got).all() and got.shape == (8, 1000, 80)
+    assert maxdiff(got[:1], co.leaf_frontend(xb[:1].astype(np.float64), w2)) < TOL
+    assert np.abs(got.mean(axis=1) - w2["mel_layer/tfbanks_instancenorm/beta"]).max() < 1e-3   # instance norm: mean = beta

@@ -43,7 +43,7 @@ def test_config_struct_matches_header_layout():
 def _create(**over):
     cfg = dict(dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32, fc_factor=0.5, reduction_factor=4,
                n_mels=80, sample_rate=16000, stride_ms=10, n_dft=1024, chunk_size=0, has_encoder=1, num_classes=0,
-               ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5, gemm_dtype=0)
+               ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5, gemm_dtype=0, mel_layer_type=0)
     cfg.update(over)
     lib = _lib.lib()
     p = ctypes.c_void_p()
@@ -137,7 +137,10 @@ def test_python_models_mirror_reference_constructor_surface():
     assert enc.hop_size == 640                                           # conformer_blocks.py:302
     assert enc.count_params() == sum(int(np.prod(v.shape)) for v in co.encoder_weights(cfg, 0).values())
     with pytest.raises(NotImplementedError):
-        ConformerEncoder(mel_layer_type="leaf")
+        ConformerEncoder(mel_layer_type="Spectrogram")
+    leaf = ConformerEncoder(mel_layer_type="leaf", num_blocks=1)       # the reference's default frontend
+    assert "mel_layer/tfbanks_complex_conv/kernel" in leaf._h.weight_names()
+    assert "mel_layer/real_kernels" not in leaf._h.weight_names()
     with pytest.raises(NotImplementedError):
         ConformerEncoder(mel_layer_type="Melspectrogram", add_wav_info=True)
     dec = CTCDecoder(num_classes=1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32,
@@ -242,6 +245,15 @@ def test_product_fails_loudly_without_gpu():
     enc = ConformerEncoder(**encoder_kwargs(small_cfg(1)))
     with pytest.raises(Exception):
         enc(np.zeros((1, 16000, 1), np.float32))       # no CPU fallback: must raise, not compute
+
+
+def test_leaf_default_weights_match_oracle_restatement():
+    a, b = frontend_consts.leaf_default_weights(), co.leaf_default_weights()
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    k = a["mel_layer/tfbanks_complex_conv/kernel"]
+    assert k.shape == (80, 2) and np.all(np.diff(k[:, 0]) >= 0) and 0 < k[0, 0] < k[-1, 0] < np.pi   # mel-spaced centres
 
 
 def test_frontend_constants_match_oracle_restatement():
