@@ -493,10 +493,11 @@ int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, fl
     // LEAF: Gabor conv + squared modulus + Gaussian pooling (partials in the log-power scratch), then PCEN + instance norm
     int nf, pl;
     same_pad(Lb, 401, m->dm.hop, &nf, &pl);
-    LeafConvArgs la{wav, m->leaf_wp, m->leaf_gcoef, logp, m->leaf_p0, m->leaf_p1, Bp, Lb, F, F, m->dm.hop, pl};
+    const int NH = ceil_div(Lb, 128);          // position tiles of 128 (leaf.hip)
+    LeafConvArgs la{wav, m->leaf_wp, m->leaf_gcoef, logp, m->leaf_p0, m->leaf_p1, Bp, Lb, F, NH, m->dm.hop, pl};
     { PROF(MI355ASR_K_STFT); LAUNCH_TRY(launch_leaf_conv_pool(la, s), "leaf gabor conv + pooling"); }
     LeafPcenArgs lp{logp, m->leaf_alpha, m->leaf_delta, m->leaf_root, m->leaf_smooth, m->leaf_gamma, m->leaf_beta, mel,
-                    Bp, F, F, m->dm.hop, pl};
+                    Bp, F, NH, m->dm.hop, pl};
     { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_leaf_pcen_norm(lp, s), "leaf PCEN + instance norm"); }
     return 0;
   }

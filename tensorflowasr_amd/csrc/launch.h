@@ -160,7 +160,7 @@ struct LeafConvArgs {
   const float* wav;     // [B, L]
   const float* wp;      // Gabor filters, P16 packed [26][10][64][4]: rows = taps (401, zero padded), cols = (re, im) per filter
   const float* gcoef;   // [80] -0.5 log2(e) / (sigma_c * 200)^2 of the Gaussian pooling windows
-  float* part;          // [B, NH, 4, 80] partial pooled sums per hop
+  float* part;          // [B, NH, 4, 80] partial pooled sums per tile of 128 positions (NH = ceil(L / 128))
   float p0, p1;         // pre-emphasis taps: xp[n] = p0 x[n] + p1 x[n+1]
   int B, L, F, NH, hop, pl;   // pl = left padding of the SAME pooling
 };

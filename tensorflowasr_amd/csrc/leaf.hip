@@ -5,29 +5,30 @@
 //
 // leaf_conv_pool_kernel: the Gabor convolution is a GEMM  [L positions] x [K = 401 taps (26 k-blocks)] x [160 channels],
 // 20.5 GFLOP per 10 s utterance -- more than the rest of the ConformerCTC(S) path together -- and its [L, 160] output
-// (102 MB per utterance) must never reach HBM.  One workgroup = one hop of 160 positions = 5 waves x 2 row tiles:
-//   * the pre-emphasised, zero-padded signal window of the hop (160 + 416 samples) is staged in LDS once;
-//   * the 10 KB weight slab of each k-block goes through a double-buffered LDS stage shared by the five waves
+// (102 MB per utterance) must never reach HBM.  One workgroup = 128 positions = 4 waves x 2 row tiles (one wave per
+// SIMD, two workgroups per CU so that one's barriers fall under the other's MFMAs):
+//   * the pre-emphasised, zero-padded signal window of the tile (128 + 416 samples) is staged in LDS once;
+//   * the 10 KB weight slab of each k-block goes through a double-buffered LDS stage shared by the four waves
 //     (one barrier per k-block), so L2 sees each slab once per workgroup instead of once per wave;
 //   * squared modulus in registers: interleaving (re, im) per filter puts both parts of a filter in one lane;
 //   * every position contributes to at most three pooled frames; the Gaussian weights are evaluated on the fly
 //     (one v_exp per value), reduced over the 16 positions of a tile with shuffles, over the waves through LDS, and
-//     written as four partial sums per hop -- no atomics, the result is deterministic.
-// leaf_pcen_norm_kernel: one thread per (utterance, channel): sum of the (<= 4) hop partials per frame, floor, the
+//     written as four partial sums per position tile -- no atomics, the result is deterministic.
+// leaf_pcen_norm_kernel: one thread per (utterance, channel): sum of the tile partials that fall on a frame, floor, the
 // EMA recurrence over frames, PCEN, then instance-norm statistics and normalisation in a second sweep.
 #include "common.h"
 #include "launch.h"
 
 namespace {
 
-constexpr int LW = 5;                       // waves per workgroup
+constexpr int LW = 4;                       // waves per workgroup
 constexpr int LTH = LW * 64;
 constexpr int KTAPS = 401, KBL = 26;        // taps, k-blocks (416 rows, zero padded)
 constexpr int NTL = 10;                     // 160 channels
-constexpr int HOP_TILE = 160;               // positions per workgroup (= 5 waves x 32)
+constexpr int HOP_TILE = 128;               // positions per workgroup (= 4 waves x 2 row tiles of 16)
 constexpr int XWIN = HOP_TILE + 16 * KBL;   // staged samples per hop
 
-__global__ __launch_bounds__(LTH, 1) void leaf_conv_pool_kernel(LeafConvArgs a) {
+__global__ __launch_bounds__(LTH, 2) void leaf_conv_pool_kernel(LeafConvArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 wlds[2][NTL * 64];
   __shared__ float xlds[XWIN + 8];
   __shared__ float red[LW][4][80];
@@ -58,11 +59,13 @@ __global__ __launch_bounds__(LTH, 1) void leaf_conv_pool_kernel(LeafConvArgs a) 
 #pragma unroll 1
   for (int kb = 0; kb < KBL; ++kb) {
     const int cur = kb & 1;
-    // next slab: global -> registers now, -> LDS after the MFMAs (two f32x4 per thread: 640 fragments / 320 threads)
-    f32x4 nw0 = splat4(0.f), nw1 = splat4(0.f);
+    // next slab: global -> registers now, -> LDS after the MFMAs (640 fragments / 256 threads: 2.5 per thread)
+    f32x4 nw0 = splat4(0.f), nw1 = splat4(0.f), nw2 = splat4(0.f);
     if (kb + 1 < KBL) {
-      nw0 = wg[(size_t)(kb + 1) * NTL * 64 + threadIdx.x];
-      nw1 = wg[(size_t)(kb + 1) * NTL * 64 + LTH + threadIdx.x];
+      const f32x4* src = wg + (size_t)(kb + 1) * NTL * 64;
+      nw0 = src[threadIdx.x];
+      nw1 = src[LTH + threadIdx.x];
+      if (threadIdx.x < NTL * 64 - 2 * LTH) nw2 = src[2 * LTH + threadIdx.x];
     }
     f32x4 xf[2];
 #pragma unroll
@@ -79,13 +82,14 @@ __global__ __launch_bounds__(LTH, 1) void leaf_conv_pool_kernel(LeafConvArgs a) 
     if (kb + 1 < KBL) {
       wlds[cur ^ 1][threadIdx.x] = nw0;
       wlds[cur ^ 1][LTH + threadIdx.x] = nw1;
+      if (threadIdx.x < NTL * 64 - 2 * LTH) wlds[cur ^ 1][2 * LTH + threadIdx.x] = nw2;
     }
     __syncthreads();
   }
 
   // ---- squared modulus: lane holds filters fA = 8 nt + 2 g (regs x, y = re, im) and fA + 1 (regs z, w)
   // ---- pooling: position n contributes g_f[tau] * |.|^2 to frame f, tau = n - (hop f - pl) in [0, 401)
-  const int fb = h + a.pl / a.hop - 2;       // first of the four frames this hop can touch
+  const int fb = (HOP_TILE * h + a.pl) / a.hop - 2;   // first of the four frames this tile can touch
   for (int rel = 0; rel < 4; ++rel) {
     const int f = fb + rel;
     float wsum[2 * NTL];
@@ -124,8 +128,8 @@ __global__ __launch_bounds__(LTH, 1) void leaf_conv_pool_kernel(LeafConvArgs a) 
     }
   }
   __syncthreads();
-  {
-    const int rel = threadIdx.x / 80, ch = threadIdx.x % 80;     // 320 threads = 4 x 80
+  for (int i = threadIdx.x; i < 320; i += LTH) {
+    const int rel = i / 80, ch = i % 80;
     float s = 0.f;
 #pragma unroll
     for (int w2 = 0; w2 < LW; ++w2) s += red[w2][rel][ch];
@@ -143,14 +147,15 @@ __global__ __launch_bounds__(128) void leaf_pcen_norm_kernel(LeafPcenArgs a) {
   const float dr = __powf(delta, inv_root);
   const float* __restrict__ part = a.part + (size_t)b * a.NH * 320;
   float* out = a.out + (size_t)b * a.F * 80 + ch;
-  const int q = a.pl / a.hop;
   float state = 0.f, sum = 0.f;
   for (int f = 0; f < a.F; ++f) {
+    // tiles whose four-frame range [fb, fb + 3], fb = (128 h + pl) / hop - 2, contains f (ascending order: deterministic)
     float p = 0.f;
-#pragma unroll
-    for (int rel = 0; rel < 4; ++rel) {
-      const int h = f - q + 2 - rel;
-      if (h >= 0 && h < a.NH) p += part[((size_t)h * 4 + rel) * 80 + ch];
+    const int h_lo = max((a.hop * (f - 1) - a.pl) / HOP_TILE - 1, 0);
+    const int h_hi = min((a.hop * (f + 3) - a.pl) / HOP_TILE + 1, a.NH - 1);
+    for (int h = h_lo; h <= h_hi; ++h) {
+      const int rel = f - ((HOP_TILE * h + a.pl) / a.hop - 2);
+      if (rel >= 0 && rel < 4) p += part[((size_t)h * 4 + rel) * 80 + ch];
     }
     p = fmaxf(p, 1e-5f);
     state = (f == 0) ? p : sm * p + (1.0f - sm) * state;           // EMA, initial state = frame 0
