@@ -63,6 +63,8 @@ typedef struct {
   int32_t mel_layer_type;    /* speech_config.mel_layer_type: 0 = 'Melspectrogram' (default), 1 = 'leaf' (LEAF frontend,
                               *    leaf_audio/frontend.py: Gabor filters + Gaussian pooling + PCEN + instance norm;
                               *    needs n_mels 80, stride_ms 10 at 16 kHz)                                       */
+  int32_t add_wav_info;      /* speech_config.add_wav_info: 1 adds WavePickModel(waveform) (asr/models/wav_model.py:108-146)
+                              *    to the subsampled features (conformer_blocks.py:344-348); needs L % hop_size == 0   */
 } mi355asr_config;
 
 const char* mi355asr_last_error(void);

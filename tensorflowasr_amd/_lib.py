@@ -16,7 +16,7 @@ class Config(ctypes.Structure):
         ("stride_ms", ctypes.c_int32), ("n_dft", ctypes.c_int32), ("chunk_size", ctypes.c_int32),
         ("has_encoder", ctypes.c_int32), ("num_classes", ctypes.c_int32), ("ctc_num_blocks", ctypes.c_int32),
         ("ctc_kernel_size", ctypes.c_int32), ("ctc_fc_factor", ctypes.c_float), ("gemm_dtype", ctypes.c_int32),
-        ("mel_layer_type", ctypes.c_int32),
+        ("mel_layer_type", ctypes.c_int32), ("add_wav_info", ctypes.c_int32),
     ]
 
 

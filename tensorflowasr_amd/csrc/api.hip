@@ -262,6 +262,8 @@ int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, cons
 // ---- workspace plan (byte offsets, 256-byte aligned) --------------------------------------------------
 
 
+size_t wavpick_floats(const mi355asr_model* m, int Bp, int Lmax);
+
 // Bp = number of independent encoder inputs (utterances, or utterances x blocks when streaming),
 // F mel frames and T encoder frames per input.
 Plan make_plan(const mi355asr_model* m, int Bp, int F, int T) {
@@ -289,6 +291,8 @@ Plan make_plan(const mi355asr_model* m, int Bp, int F, int T) {
   p.umax = take(Bp);
   p.mel = take((size_t)Bp * F * m->cfg.n_mels);
   p.sub = take(M * m->dm.F2 * d);
+  p.wv_floats = wavpick_floats(m, Bp, F * m->dm.hop);      // add_wav_info branch (0 when off); L <= F * hop
+  p.wv = p.wv_floats ? take(p.wv_floats) : 0;
   p.total = o;
   return p;
 }
@@ -565,6 +569,92 @@ int check_ready(const mi355asr_model* m, bool need_encoder = false) {
   return 0;
 }
 
+
+// WavePickModel.get_scales (wav_model.py:132-146): prime factors of hop_size merged down to four strides, descending
+std::vector<int> wave_pick_scales(int num) {
+  std::vector<int> sc;
+  while (num > 1) {
+    int i = 2;
+    while (i < 100 && num % i != 0) ++i;
+    if (i >= 100) return {};
+    num /= i;
+    sc.push_back(i);
+  }
+  while (sc.size() > 4) {
+    std::vector<int> ns(sc.begin() + 2, sc.end());
+    ns.push_back(sc[0] * sc[1]);
+    std::sort(ns.begin(), ns.end());
+    sc = ns;
+  }
+  std::reverse(sc.begin(), sc.end());
+  return sc;
+}
+
+// floats of scratch the add_wav_info branch needs for Bp inputs of at most Lmax samples
+size_t wavpick_floats(const mi355asr_model* m, int Bp, int Lmax) {
+  if (!m->cfg.add_wav_info || m->wp_stride0 == 0) return 0;
+  const size_t T0 = ceil_div(Lmax, m->wp_stride0);
+  size_t s1 = 0, t = T0;
+  for (const auto& st : m->wp_stages) { t = ceil_div((int)t, st.stride); s1 = std::max(s1, (t + 8) * (size_t)st.c); }
+  return (size_t)Bp * ((T0 + 8) * 32 * 2 + 4 * s1) + 1024;
+}
+
+// xa[Bp*T, d] += WavePickModel(wav)  (conformer_blocks.py:344-348); every Conv1D is a GEMM over overlapping rows of a
+// padded channels-last copy of its input (wavpick.hip)
+int run_wavpick(const mi355asr_model* m, const float* wav, int Bp, int Lb, int T, float* xa, float* wv, hipStream_t s) {
+  const int d = m->cfg.dmodel;
+  const float slope = 0.3f;                          // tf.keras.layers.LeakyReLU() default
+  const int T0 = ceil_div(Lb, m->wp_stride0);
+  size_t s1 = 0;
+  { int t = T0; for (const auto& st : m->wp_stages) { t = ceil_div(t, st.stride); s1 = std::max(s1, (size_t)(t + 8) * st.c); } }
+  float* bufA = wv;
+  float* bufP = bufA + (size_t)Bp * (T0 + 8) * 32;
+  float* bufY = bufP + (size_t)Bp * (T0 + 8) * 32;
+  float* bufH = bufY + (size_t)Bp * s1;
+  float* bufG = bufH + (size_t)Bp * s1;
+  float* bufS = bufG + (size_t)Bp * s1;
+  int out0, pl0;
+  same_pad(Lb, 7, m->wp_stride0, &out0, &pl0);
+  WpSepConvArgs sa{wav, m->wp_dw, m->wp_pw, m->wp_b, bufA, Bp, Lb, T0, m->wp_stride0, pl0, slope};
+  LAUNCH_TRY(launch_wp_sepconv(sa, s), "wav_layer separable conv");
+  auto conv = [&](const float* xpad, int Tpad, int cin, int k, int stride, int Tout, const float* wp, const float* bias, int cout,
+                  float* y, const float* res) -> int {
+    Gemm16Args g{};
+    g.x = xpad; g.ldx = stride * cin; g.K = k * cin; g.wp = wp; g.bias = bias; g.NT = cout / 16; g.y = y; g.ldy = cout;
+    g.M = Bp * Tout; g.n_valid = cout; g.eps = kLnEps; g.scale = 1.0f; g.res = res;
+    g.rpb = Tout; g.bstride = (long long)Tpad * cin;
+    LAUNCH_TRY(launch_gemm16_f32(res ? E16_RES : E16_BIAS, false, g, s), "wav_layer conv1d");
+    return 0;
+  };
+  const float *cur = bufA, *cur2 = nullptr;
+  int Tc = T0, cin = 32;
+  for (const auto& st : m->wp_stages) {
+    int Tn, lo;
+    same_pad(Tc, 3, st.stride, &Tn, &lo);
+    const int hi = std::max((Tn - 1) * st.stride + 3 - Tc, 0) - lo;
+    WpPadActArgs pz{cur, cur2, bufP, Bp, Tc, cin, lo, hi, 0, 1.0f};
+    LAUNCH_TRY(launch_wp_pad_act(pz, s), "wav_layer zero pad");
+    int rc = conv(bufP, Tc + lo + hi, cin, 3, st.stride, Tn, st.cw, st.cb, st.c, bufY, nullptr);
+    if (rc) return rc;
+    // TFResidualStack (wav_model.py:57-104)
+    WpPadActArgs pr{bufY, nullptr, bufP, Bp, Tn, st.c, 2, 2, 1, slope};
+    LAUNCH_TRY(launch_wp_pad_act(pr, s), "wav_layer reflect pad + LeakyReLU");
+    rc = conv(bufP, Tn + 4, st.c, 5, 1, Tn, st.w5, st.b5, st.c, bufH, nullptr);
+    if (rc) return rc;
+    WpPadActArgs pg{bufH, nullptr, bufG, Bp, Tn, st.c, 0, 0, 0, slope};
+    LAUNCH_TRY(launch_wp_pad_act(pg, s), "wav_layer LeakyReLU");
+    rc = conv(bufY, Tn, st.c, 1, 1, Tn, st.ws, st.bs, st.c, bufS, nullptr);
+    if (rc) return rc;
+    rc = conv(bufG, Tn, st.c, 1, 1, Tn, st.w1, st.b1, st.c, bufH, nullptr);
+    if (rc) return rc;
+    cur = bufS; cur2 = bufH; Tc = Tn; cin = st.c;    // the sum of the two branches is formed by the next padded copy
+  }
+  if (Tc != T) return fail(MI355ASR_EINVAL, "add_wav_info: the waveform branch yields %d frames, the frontend %d", Tc, T);
+  WpPadActArgs pf{cur, cur2, bufP, Bp, Tc, cin, 3, 3, 0, 1.0f};
+  LAUNCH_TRY(launch_wp_pad_act(pf, s), "wav_layer zero pad");
+  return conv(bufP, Tc + 6, cin, 7, 1, Tc, m->wp_fw, m->wp_fb, d, xa, xa);
+}
+
 int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const Plan& p, char* ws, float* enc_out,
                  hipStream_t s) {
   float* logp = (float*)(ws + p.logp);
@@ -576,6 +666,10 @@ int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const P
   sc.h4 = (float*)(ws + p.h4);
   rc = run_subsampling(m, mel, g.Bp, g.F, (float*)(ws + p.sub), sc.xa, s);
   if (rc) return rc;
+  if (m->cfg.add_wav_info) {
+    rc = run_wavpick(m, wav, g.Bp, g.Lb, g.T, sc.xa, (float*)(ws + p.wv), s);
+    if (rc) return rc;
+  }
   const int nb = m->cfg.num_blocks;
   for (int i = 0; i < nb; ++i) {
     BlockOpts bo;
@@ -704,6 +798,35 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
     ex.push_back({"conv_subsampling/linear/bias", {d}});
     for (int i = 0; i < c.num_blocks; ++i)
       add_block_expected(ex, "conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size, c.kernel_size);
+  }
+  if (c.add_wav_info != 0 && c.add_wav_info != 1) { delete m; return fail(MI355ASR_EINVAL, "add_wav_info=%d: 0 or 1", c.add_wav_info); }
+  if (c.has_encoder && c.add_wav_info) {
+    // WavePickModel(dmodel, hop_size * reduction_factor) (conformer_blocks.py:329-331, wav_model.py:108-131)
+    const std::vector<int> scales = wave_pick_scales(dm.hop * c.reduction_factor);
+    if (scales.size() != 4) { delete m; return fail(MI355ASR_EINVAL, "add_wav_info: hop_size*reduction_factor=%d does not factor into four strides", dm.hop * c.reduction_factor); }
+    m->wp_stride0 = scales[0];
+    ex.push_back({"wav_layer/sep_conv/depthwise_kernel", {7, 1, 1}});
+    ex.push_back({"wav_layer/sep_conv/pointwise_kernel", {1, 1, 32}});
+    ex.push_back({"wav_layer/sep_conv/bias", {32}});
+    int cin = 32;
+    for (int i = 1; i < 4; ++i) {
+      const int ch = std::min(32 * (i + 1), d);
+      mi355asr_model::WavStage st{};
+      st.cin = cin; st.c = ch; st.stride = scales[i];
+      m->wp_stages.push_back(st);
+      const std::string n = std::to_string(i);
+      ex.push_back({"wav_layer/conv_" + n + "/kernel", {3, cin, ch}});
+      ex.push_back({"wav_layer/conv_" + n + "/bias", {ch}});
+      ex.push_back({"wav_layer/res_" + n + "/conv5/kernel", {5, ch, ch}});
+      ex.push_back({"wav_layer/res_" + n + "/conv5/bias", {ch}});
+      ex.push_back({"wav_layer/res_" + n + "/conv1/kernel", {1, ch, ch}});
+      ex.push_back({"wav_layer/res_" + n + "/conv1/bias", {ch}});
+      ex.push_back({"wav_layer/res_" + n + "/shortcut/kernel", {1, ch, ch}});
+      ex.push_back({"wav_layer/res_" + n + "/shortcut/bias", {ch}});
+      cin = ch;
+    }
+    ex.push_back({"wav_layer/final/kernel", {7, cin, d}});
+    ex.push_back({"wav_layer/final/bias", {d}});
   }
   if (c.num_classes > 0) {
     ex.push_back({"project/kernel", {d, d}});
@@ -870,6 +993,35 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   for (int i = 0; i < c.num_blocks; ++i)
     eo.push_back(pack_block(m, ab, "conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size, c.kernel_size));
   }
+  struct WavOff { size_t cw, cb, w5, b5, w1, b1, ws, bs; };
+  std::vector<WavOff> wo;
+  size_t o_wdw = 0, o_wpw = 0, o_wb = 0, o_wfw = 0, o_wfb = 0;
+  if (c.has_encoder && c.add_wav_info) {
+    // a Conv1D kernel [k, cin, cout] is already the [k*cin, cout] matrix of the GEMM over k overlapping channels-last rows
+    auto conv_w = [&](const std::string& name, int K, int N) {
+      const auto& w = m->host[name].data;
+      return ab.put(pack_p16([&](int k, int n) { return w[(size_t)k * N + n]; }, K, N, N / 16));
+    };
+    o_wdw = ab.put(m->host["wav_layer/sep_conv/depthwise_kernel"].data);
+    o_wpw = ab.put(m->host["wav_layer/sep_conv/pointwise_kernel"].data);
+    o_wb = ab.put(m->host["wav_layer/sep_conv/bias"].data);
+    for (size_t i = 0; i < m->wp_stages.size(); ++i) {
+      const auto& st = m->wp_stages[i];
+      const std::string n = std::to_string(i + 1);
+      WavOff w{};
+      w.cw = conv_w("wav_layer/conv_" + n + "/kernel", 3 * st.cin, st.c);
+      w.cb = ab.put(m->host["wav_layer/conv_" + n + "/bias"].data);
+      w.w5 = conv_w("wav_layer/res_" + n + "/conv5/kernel", 5 * st.c, st.c);
+      w.b5 = ab.put(m->host["wav_layer/res_" + n + "/conv5/bias"].data);
+      w.w1 = conv_w("wav_layer/res_" + n + "/conv1/kernel", st.c, st.c);
+      w.b1 = ab.put(m->host["wav_layer/res_" + n + "/conv1/bias"].data);
+      w.ws = conv_w("wav_layer/res_" + n + "/shortcut/kernel", st.c, st.c);
+      w.bs = ab.put(m->host["wav_layer/res_" + n + "/shortcut/bias"].data);
+      wo.push_back(w);
+    }
+    o_wfw = conv_w("wav_layer/final/kernel", 7 * m->wp_stages.back().c, d);
+    o_wfb = ab.put(m->host["wav_layer/final/bias"].data);
+  }
   size_t o_pw = 0, o_pb = 0, o_fw = 0, o_fb = 0;
   if (c.num_classes > 0) {
     const auto& pj = m->host["project/kernel"].data;
@@ -901,6 +1053,12 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
   m->leaf_wp = base + o_leafw; m->leaf_gcoef = base + o_lg; m->leaf_alpha = base + o_la; m->leaf_delta = base + o_ld;
   m->leaf_root = base + o_lr; m->leaf_smooth = base + o_ls; m->leaf_gamma = base + o_lga; m->leaf_beta = base + o_lbe;
+  m->wp_dw = base + o_wdw; m->wp_pw = base + o_wpw; m->wp_b = base + o_wb; m->wp_fw = base + o_wfw; m->wp_fb = base + o_wfb;
+  for (size_t i = 0; i < wo.size(); ++i) {
+    auto& st = m->wp_stages[i];
+    st.cw = base + wo[i].cw; st.cb = base + wo[i].cb; st.w5 = base + wo[i].w5; st.b5 = base + wo[i].b5;
+    st.w1 = base + wo[i].w1; st.b1 = base + wo[i].b1; st.ws = base + wo[i].ws; st.bs = base + wo[i].bs;
+  }
   if (m->arena16) { (void)hipFree(m->arena16); m->arena16 = nullptr; }
   if (c.gemm_dtype == 1) {
     const size_t n16 = (m->arena_floats + 3) & ~(size_t)3;

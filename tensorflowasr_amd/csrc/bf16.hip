@@ -64,7 +64,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_kernel(Gemm16Args a) 
   if ((size_t)wid * 16 >= (size_t)a.M) return;          // uniform per workgroup when KS > 1
   const int tok = wid * 16 + c;
   const bool live = tok < a.M;
-  const float* __restrict__ xr = a.x + (size_t)min(tok, a.M - 1) * a.ldx + g4;
+  const int rowi = min(tok, a.M - 1);
+  const float* __restrict__ xr = (a.rpb > 0 ? a.x + (size_t)(rowi / a.rpb) * a.bstride + (size_t)(rowi % a.rpb) * a.ldx
+                                            : a.x + (size_t)rowi * a.ldx) + g4;
   const int KB = a.K / 16, NT = a.NT;
   const int KBs = (KB + KS - 1) / KS;
   const int kbeg = ks * KBs, kend = min(KB, kbeg + KBs);
@@ -254,8 +256,8 @@ int dispatch(int epi, bool ln, const Gemm16Args& a, hipStream_t s) {
   if (a.K % 16 != 0 || a.K < 16) return -1;
   const int tiles = (a.M + 15) / 16;
   const int ntc = (epi == E16_GLU) ? a.NT / 2 : a.NT;
-  const bool d144 = (ntc % 9 == 0);
-  if (!d144 && ntc % 4 != 0 && epi != E16_HEAD) return -1;
+  const bool d144 = (ntc % 9 == 0) || (ntc % 4 != 0 && ntc % 3 == 0);     // column tiles in chunks of 3 / 9
+  if (ntc % 4 != 0 && ntc % 3 != 0 && epi != E16_HEAD) return -1;
 #define CASE(E, L) \
   if (epi == E && ln == L) { \
     if constexpr (E == E16_RES) { \
@@ -266,7 +268,7 @@ int dispatch(int epi, bool ln, const Gemm16Args& a, hipStream_t s) {
         if (a.fln_g) launch_layernorm_rows(a.y, a.fln_g, a.fln_b, a.M, 16 * ntc, a.ldy, a.eps, s); \
       } else return -1; \
     } else if constexpr (E == E16_HEAD) { if (a.NT % 12 != 0) return -1; go<P, 12, E, L>(a, s); } \
-    else if (d144) { if (tiles >= 1024 && E != E16_GLU) go<P, 9, E, L>(a, s); else go<P, 3, E, L>(a, s); } \
+    else if (d144) { if (tiles >= 1024 && ntc % 9 == 0 && E != E16_GLU) go<P, 9, E, L>(a, s); else go<P, 3, E, L>(a, s); } \
     else { if (tiles >= 1024 && ntc % 8 == 0) go<P, 8, E, L>(a, s); else go<P, 4, E, L>(a, s); } \
     return 0; }
   CASE(E16_BIAS, false)

@@ -172,6 +172,24 @@ struct LeafPcenArgs {
 };
 int launch_leaf_conv_pool(const LeafConvArgs& a, hipStream_t s);
 int launch_leaf_pcen_norm(const LeafPcenArgs& a, hipStream_t s);
+// add_wav_info branch (wavpick.hip)
+struct WpSepConvArgs {
+  const float* wav;     // [B, L]
+  const float *dw, *pw, *bias;   // depthwise [7], pointwise [32], bias [32]
+  float* out;           // [B, T0, 32] = LeakyReLU(SeparableConv1D(32, 7, stride))
+  int B, L, T0, stride, pad_left;
+  float slope;
+};
+struct WpPadActArgs {
+  const float* src;     // [B, T, C]
+  const float* src2;    // optional second addend [B, T, C]
+  float* dst;           // [B, T + lo + hi, C]
+  int B, T, C, lo, hi;
+  int reflect;          // 1: tf.pad REFLECT, 0: zeros
+  float slope;          // LeakyReLU slope applied to (src + src2); 1 = identity
+};
+int launch_wp_sepconv(const WpSepConvArgs& a, hipStream_t s);
+int launch_wp_pad_act(const WpPadActArgs& a, hipStream_t s);
 // bf16-MFMA GEMM family (bf16.hip)
 enum { E16_BIAS = 0, E16_SWISH = 1, E16_RES = 2, E16_QKV = 3, E16_GLU = 4, E16_AFFSWISH = 5, E16_HEAD = 6 };
 struct Gemm16Args {
@@ -189,6 +207,10 @@ struct Gemm16Args {
   float scale, eps, qscale;
   int qtiles;
   int32_t* argmax_out;  // [M] (E16_HEAD)
+  // optional batched / overlapping rows (conv1d as a GEMM on channels-last activations): row r reads from
+  // x + (r / rpb) * bstride + (r % rpb) * ldx when rpb > 0
+  int rpb = 0;
+  long long bstride = 0;
 };
 int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s);
 int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s);   // wp = fp32 P16 weights

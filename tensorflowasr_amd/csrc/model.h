@@ -108,6 +108,11 @@ struct mi355asr_model {
   const float *leaf_wp = nullptr, *leaf_gcoef = nullptr, *leaf_alpha = nullptr, *leaf_delta = nullptr, *leaf_root = nullptr,
               *leaf_smooth = nullptr, *leaf_gamma = nullptr, *leaf_beta = nullptr;
   float leaf_p0 = 0.f, leaf_p1 = 1.f;
+  // add_wav_info: WavePickModel weights (conv kernels P16-packed with K = k * Cin)
+  struct WavStage { const float *cw, *cb, *w5, *b5, *w1, *b1, *ws, *bs; int cin, c, stride; };
+  const float *wp_dw = nullptr, *wp_pw = nullptr, *wp_b = nullptr, *wp_fw = nullptr, *wp_fb = nullptr;
+  int wp_stride0 = 0;
+  std::vector<WavStage> wp_stages;
   std::vector<BlockDev> enc_blocks, ctc_blocks;
   // ChunkConformer (mi355asr_chunk_create): front + encoder / phone picker / context helper / text decoder stacks
   bool is_chunk = false;
@@ -182,7 +187,7 @@ struct BlockOff {
 };
 
 struct Plan {
-  size_t xa, xb, qkv, ctx, u, dw, enc, amax, logp, pmax, umax, mel, sub, h4, total;
+  size_t xa, xb, qkv, ctx, u, dw, enc, amax, logp, pmax, umax, mel, sub, h4, wv, wv_floats, total;
 };
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }

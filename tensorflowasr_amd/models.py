@@ -240,7 +240,22 @@ def _block_shapes(p, d, H, hs, k):
     return s
 
 
-def _encoder_shapes(d, H, hs, k, num_blocks, n_mels, n_dft=1024, leaf=False):
+def _wav_layer_shapes(d):
+    """WavePickModel variables (asr/models/wav_model.py:108-131) under the handle's `wav_layer/` names."""
+    s = {"wav_layer/sep_conv/depthwise_kernel": (7, 1, 1), "wav_layer/sep_conv/pointwise_kernel": (1, 1, 32),
+         "wav_layer/sep_conv/bias": (32,)}
+    cin = 32
+    for i in range(1, 4):
+        c = min(32 * (i + 1), d)
+        s["wav_layer/conv_%d/kernel" % i], s["wav_layer/conv_%d/bias" % i] = (3, cin, c), (c,)
+        for sub, k in (("conv5", 5), ("conv1", 1), ("shortcut", 1)):
+            s["wav_layer/res_%d/%s/kernel" % (i, sub)], s["wav_layer/res_%d/%s/bias" % (i, sub)] = (k, c, c), (c,)
+        cin = c
+    s["wav_layer/final/kernel"], s["wav_layer/final/bias"] = (7, cin, d), (d,)
+    return s
+
+
+def _encoder_shapes(d, H, hs, k, num_blocks, n_mels, n_dft=1024, leaf=False, add_wav_info=False):
     nb = n_dft // 2 + 1
     f2 = -(-(-(-n_mels // 2)) // 2)
     if leaf:
@@ -255,6 +270,8 @@ def _encoder_shapes(d, H, hs, k, num_blocks, n_mels, n_dft=1024, leaf=False):
          "conv_subsampling/conv1/kernel": (3, 3, 1, d), "conv_subsampling/conv1/bias": (d,),
          "conv_subsampling/conv2/kernel": (3, 3, d, d), "conv_subsampling/conv2/bias": (d,),
          "conv_subsampling/linear/kernel": (f2 * d, d), "conv_subsampling/linear/bias": (d,)})
+    if add_wav_info:
+        s.update(_wav_layer_shapes(d))
     for i in range(num_blocks):
         s.update(_block_shapes("conformer_block_%d" % i, d, H, hs, k))
     return s
@@ -270,8 +287,9 @@ def _ctc_shapes(d, H, hs, k, num_blocks, num_classes):
 
 
 class ConformerEncoder(_ModelBase):
-    """asr/models/conformer_blocks.py:277-384.  `mel_layer_type` must be 'Melspectrogram' (the default of
-    asr/configs/am_data.yml:3); 'leaf' and `add_wav_info=True` are outside this path."""
+    """asr/models/conformer_blocks.py:277-384.  `mel_layer_type`: 'Melspectrogram' (the default of
+    asr/configs/am_data.yml:3) or 'leaf'; `add_wav_info=True` adds the WavePickModel branch (wav_model.py:108-146) to
+    the subsampled features."""
 
     def __init__(self, dmodel=144, reduction_factor=4, num_blocks=16, head_size=36, num_heads=4, kernel_size=32,
                  fc_factor=0.5, dropout=0.0, add_wav_info=False, sample_rate=16000, n_mels=80,
@@ -284,8 +302,6 @@ class ConformerEncoder(_ModelBase):
             raise NotImplementedError("mel_layer_type=%r: 'Melspectrogram' and 'leaf' are implemented (the reference's "
                                       "third choice, the plain Spectrogram layer, is not)" % mel_layer_type)
         self.mel_layer_type = mel_layer_type
-        if add_wav_info:
-            raise NotImplementedError("add_wav_info=True (WavePickModel branch) is outside the hot path")
         self.name = name
         self.dmodel, self.num_heads, self.head_size = dmodel, num_heads, head_size
         self.fc_factor, self.dropout = fc_factor, dropout      # dropout is identity at inference
@@ -293,7 +309,7 @@ class ConformerEncoder(_ModelBase):
         self.num_blocks, self.kernel_size = num_blocks, kernel_size
         self.sample_rate, self.n_mels, self.stride_ms = sample_rate, n_mels, stride_ms
         self.hop_size = int(stride_ms * sample_rate // 1000) * reduction_factor   # conformer_blocks.py:302
-        self.add_wav_info = add_wav_info
+        self.add_wav_info = bool(add_wav_info)
         self.chunk_size = int(chunk_size)
         self._device = device
         self._weights = None
@@ -305,12 +321,13 @@ class ConformerEncoder(_ModelBase):
                           reduction_factor=self.reduction_factor, n_mels=self.n_mels, sample_rate=self.sample_rate,
                           stride_ms=self.stride_ms, n_dft=1024, chunk_size=self.chunk_size, has_encoder=1,
                           num_classes=0, ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5,
-                          gemm_dtype=self.gemm_dtype, mel_layer_type=int(self.mel_layer_type == "leaf"))
+                          gemm_dtype=self.gemm_dtype, mel_layer_type=int(self.mel_layer_type == "leaf"),
+                          add_wav_info=int(self.add_wav_info))
         self._h = _Handle(cfg, self._device)
 
     def _expected_shapes(self):
         return _encoder_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks,
-                               self.n_mels, leaf=self.mel_layer_type == "leaf")
+                               self.n_mels, leaf=self.mel_layer_type == "leaf", add_wav_info=self.add_wav_info)
 
     def __call__(self, inputs, training=False, **kwargs):
         """wav [B, L, 1] (or [B, L]) float32 -> torch.Tensor [B, T, dmodel] on the device."""
@@ -518,8 +535,10 @@ class ConformerCTC(_ModelBase):
     def __init__(self, num_classes, dmodel=144, reduction_factor=4, num_blocks=13, head_size=36, num_heads=4,
                  kernel_size=32, fc_factor=0.5, sample_rate=16000, n_mels=80, stride_ms=10, chunk_size=0,
                  ctcdecoder_num_blocks=1, ctcdecoder_kernel_size=32, ctcdecoder_fc_factor=0.5,
-                 device="cuda:0", name="conformer_ctc", gemm_dtype="float32", mel_layer_type="Melspectrogram", **kwargs):
+                 device="cuda:0", name="conformer_ctc", gemm_dtype="float32", mel_layer_type="Melspectrogram",
+                 add_wav_info=False, **kwargs):
         self.name = name
+        self.add_wav_info = bool(add_wav_info)
         if mel_layer_type not in ("Melspectrogram", "leaf"):
             raise NotImplementedError("mel_layer_type=%r" % mel_layer_type)
         self.mel_layer_type = mel_layer_type
@@ -536,7 +555,7 @@ class ConformerCTC(_ModelBase):
                           chunk_size=self.chunk_size, has_encoder=1, num_classes=num_classes,
                           ctc_num_blocks=ctcdecoder_num_blocks, ctc_kernel_size=ctcdecoder_kernel_size,
                           ctc_fc_factor=ctcdecoder_fc_factor, gemm_dtype=_gemm_dtype(gemm_dtype),
-                          mel_layer_type=int(mel_layer_type == "leaf"))
+                          mel_layer_type=int(mel_layer_type == "leaf"), add_wav_info=int(self.add_wav_info))
         self._h = _Handle(cfg, device)
 
     @classmethod
@@ -554,7 +573,7 @@ class ConformerCTC(_ModelBase):
 
     def _expected_shapes(self):
         s = _encoder_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks, self.n_mels,
-                            leaf=self.mel_layer_type == "leaf")
+                            leaf=self.mel_layer_type == "leaf", add_wav_info=self.add_wav_info)
         s.update(_ctc_shapes(self.dmodel, self.num_heads, self.head_size, self.ctc_kernel, self.ctc_blocks,
                              self.num_classes))
         return s

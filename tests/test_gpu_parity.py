@@ -891,3 +891,68 @@ def test_leaf_streaming_blocks_and_full_batch(torch_cuda):
     assert np.isfinite(got).all() and got.shape == (8, 1000, 80)
     assert maxdiff(got[:1], co.leaf_frontend(xb[:1].astype(np.float64), w2)) < TOL
     assert np.abs(got.mean(axis=1) - w2["mel_layer/tfbanks_instancenorm/beta"]).max() < 1e-3   # instance norm: mean = beta
+
+
+# ---------------------------------------------------------------------------------------------------------
+# add_wav_info: WavePickModel branch added to the subsampled features (wav_model.py:108-146)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("base,L,B", [(None, 16000, 3), (None, 640 * 7, 1), ("M", 32000, 2), ("STREAMING_S", 8000, 4),
+                                      ("20ms", 1280 * 9, 2)])
+def test_add_wav_info_encoder_parity(torch_cuda, base, L, B):
+    """Encoder with the waveform branch against the oracle, and the branch alone as the difference of two encoders
+    without conformer blocks (dmodel 144 -> stage channels 64/96/128; 256 -> the same, final conv 7*128 -> 256)."""
+    from tensorflowasr_amd.models import ConformerEncoder
+    cfg = small_cfg(1, {"M": co.CONFORMER_M, "STREAMING_S": co.STREAMING_S, "20ms": dict(co.CONFORMER_S, stride_ms=20)}.get(base))
+    w = co.encoder_weights(cfg, seed=21)
+    hop = cfg["stride_ms"] * 16 * cfg.get("reduction_factor", 4)        # 640 -> strides [8,5,4,4]; 1280 -> [16,5,4,4]
+    w.update(co.wave_pick_weights(cfg["dmodel"], hop, seed=22))
+    x = waves(B, L, 90)
+    e = ConformerEncoder(**dict(encoder_kwargs(cfg), mel_layer_type="Melspectrogram", add_wav_info=True))
+    e.load_weights(w, by_name=False)
+    ref = co.conformer_encoder(x.astype(np.float64), w, dict(cfg, add_wav_info=True))
+    got = e(x).cpu().numpy()
+    assert got.shape == ref.shape
+    assert maxdiff(got, ref) < TOL
+    # the branch itself: no blocks, with minus without
+    cfg0 = dict(cfg, num_blocks=0)
+    w0 = {k: v for k, v in w.items() if not k.startswith("conformer_block_")}
+    ea = ConformerEncoder(**dict(encoder_kwargs(cfg0), mel_layer_type="Melspectrogram", add_wav_info=True))
+    ea.load_weights(w0, by_name=False)
+    eb = ConformerEncoder(**dict(encoder_kwargs(cfg0), mel_layer_type="Melspectrogram"))
+    eb.load_weights({k: v for k, v in w0.items() if not k.startswith("wav_layer/")}, by_name=False)
+    branch = ea(x).cpu().numpy().astype(np.float64) - eb(x).cpu().numpy()
+    ref_b = co.wave_pick_model(x.astype(np.float64), w, cfg["dmodel"], hop)
+    assert np.abs(ref_b).max() > 0.05                    # the branch is not negligible in the sum
+    assert maxdiff(branch, ref_b) < TOL
+
+
+def test_add_wav_info_with_leaf_ctc_and_errors(torch_cuda):
+    """The reference's newest configuration: leaf frontend + waveform branch, through ConformerCTC."""
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = small_cfg(1)
+    V = 40
+    w = _leaf_weights(cfg, 31)
+    w.update(co.wave_pick_weights(cfg["dmodel"], 640, seed=32))
+    w.update(co.ctc_decoder_weights(cfg, V, seed=33))
+    kw = dict(encoder_kwargs(cfg))
+    kw.pop("mel_layer_type")
+    m = ConformerCTC(V, ctcdecoder_num_blocks=cfg["ctcdecoder_num_blocks"], mel_layer_type="leaf", add_wav_info=True, **kw)
+    m.load_weights(w, by_name=False)
+    x = waves(2, 16000, 95)
+    enc_ref = co.conformer_encoder(x.astype(np.float64), w, dict(cfg, mel_layer_type="leaf", add_wav_info=True))
+    enc = m.encode(x)
+    assert maxdiff(enc.cpu().numpy(), enc_ref) < TOL
+    logits_ref = co.ctc_decoder(enc_ref, w, cfg)
+    assert maxdiff(m.ctc_logits(enc).cpu().numpy(), logits_ref) < 2e-3
+    ids, lens = m.recognize(x)
+    T = logits_ref.shape[1]
+    ref_ids, ref_lens = co.ctc_greedy(logits_ref, np.full(2, T), V - 1)
+    if not argmax_mismatch_report(m.ctc_logits(enc).cpu().numpy(), logits_ref):
+        assert (lens.cpu().numpy() == ref_lens).all()
+        for b in range(2):
+            assert (ids[b, :ref_lens[b]].cpu().numpy() == ref_ids[b, :ref_lens[b]]).all()
+    # a length that is not a multiple of hop_size: both branches yield ceil(L / hop_size) frames (nested SAME strides)
+    xr = waves(1, 16000 + 160, 96)
+    ref_r = co.conformer_encoder(xr.astype(np.float64), w, dict(cfg, mel_layer_type="leaf", add_wav_info=True))
+    assert ref_r.shape[1] == 26
+    assert maxdiff(m.encode(xr).cpu().numpy(), ref_r) < TOL

@@ -141,8 +141,13 @@ def test_python_models_mirror_reference_constructor_surface():
     leaf = ConformerEncoder(mel_layer_type="leaf", num_blocks=1)       # the reference's default frontend
     assert "mel_layer/tfbanks_complex_conv/kernel" in leaf._h.weight_names()
     assert "mel_layer/real_kernels" not in leaf._h.weight_names()
-    with pytest.raises(NotImplementedError):
-        ConformerEncoder(mel_layer_type="Melspectrogram", add_wav_info=True)
+    wv = ConformerEncoder(mel_layer_type="Melspectrogram", add_wav_info=True, num_blocks=1)    # WavePickModel branch
+    names = {n: tuple(s) for n, s in wv._names_and_shapes()}
+    ref_w = co.wave_pick_weights(144, 640)
+    assert {k: v for k, v in names.items() if k.startswith("wav_layer/")} == {k: v.shape for k, v in ref_w.items()}
+    assert set(names) == set(wv._h.weight_names())                       # the handle expects exactly these tensors
+    with pytest.raises(Exception, match="four strides"):
+        ConformerEncoder(mel_layer_type="Melspectrogram", add_wav_info=True, stride_ms=1, sample_rate=1000, num_blocks=1)
     dec = CTCDecoder(num_classes=1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32,
                      dropout=0.1, fc_factor=0.5)
     assert dec.count_params() == 759_348 + 0 or dec.count_params() > 700_000     # ~0.76 M

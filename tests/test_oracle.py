@@ -285,3 +285,43 @@ def test_bf16_rounding_emulation():
     d = np.abs(rounded - exact).max()
     assert 1e-4 < d < 0.1                                           # visibly bf16, still the same function
     assert np.abs(co.conformer_block(xin, w, "b", 36) - exact).max() == 0.0
+
+
+def test_wave_pick_model_against_torch_convs():
+    """add_wav_info branch (wav_model.py:108-146): strides from hop_size, and the oracle's conv stack against an
+    independent torch.nn.functional restatement with Keras SAME padding."""
+    import torch
+    import torch.nn.functional as F
+    assert co.wave_pick_scales(640) == [8, 5, 4, 4]
+    assert co.wave_pick_scales(160 * 4 * 2) == [16, 5, 4, 4]      # 2^8 * 5: pairs of the smallest factors merge first
+    assert int(np.prod(co.wave_pick_scales(480))) == 480
+    d, hop = 144, 640
+    w = co.wave_pick_weights(d, hop, seed=5)
+    x = np.stack([co.synth_wave(i, 640 * 6) for i in range(2)])
+    got = co.wave_pick_model(x, w, d, hop)
+    assert got.shape == (2, 6, d)
+
+    def same(t, k, s):                                  # Keras/TF SAME: total = max((ceil(n/s)-1)*s + k - n, 0), left = total // 2
+        n = t.shape[-1]
+        tot = max((-(-n // s) - 1) * s + k - n, 0)
+        return F.pad(t, (tot // 2, tot - tot // 2))
+
+    def conv(t, name, s=1, pad=True):
+        k = torch.from_numpy(w[name + "/kernel"].astype(np.float64)).permute(2, 1, 0)      # [k, cin, cout] -> [cout, cin, k]
+        b = torch.from_numpy(w[name + "/bias"].astype(np.float64))
+        return F.conv1d(same(t, k.shape[-1], s) if pad else t, k, b, stride=s)
+
+    t = torch.from_numpy(x.astype(np.float64))[:, None, :]
+    dw = torch.from_numpy(w["wav_layer/sep_conv/depthwise_kernel"].astype(np.float64)).reshape(1, 1, 7)
+    t = F.conv1d(same(t, 7, 8), dw, stride=8)
+    t = t * torch.from_numpy(w["wav_layer/sep_conv/pointwise_kernel"].astype(np.float64)).reshape(1, 32, 1) \
+        + torch.from_numpy(w["wav_layer/sep_conv/bias"].astype(np.float64)).reshape(1, 32, 1)
+    t = F.leaky_relu(t, 0.3)
+    for i, s in zip((1, 2, 3), (5, 4, 4)):
+        t = conv(t, "wav_layer/conv_%d" % i, s)
+        a = F.pad(F.leaky_relu(t, 0.3), (2, 2), mode="reflect")
+        a = conv(a, "wav_layer/res_%d/conv5" % i, pad=False)
+        a = conv(F.leaky_relu(a, 0.3), "wav_layer/res_%d/conv1" % i, pad=False)
+        t = conv(t, "wav_layer/res_%d/shortcut" % i, pad=False) + a
+    t = conv(t, "wav_layer/final")
+    assert np.abs(t.permute(0, 2, 1).numpy() - got).max() < 1e-10
