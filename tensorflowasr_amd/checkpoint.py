@@ -1,0 +1,287 @@
+"""Checkpoint readers that funnel into the C-ABI weight names.
+
+* `.npz` of Keras-layout tensors: `Model.load_weights(path)` reads it directly (models.py).
+* tf2onnx exports of the reference's models (`test_asr.py:232-242` writes them; the repository ships
+  `Inference/PythonInference/asr/models/offline/ctc_model.onnx`): `ctc_decoder_weights_from_onnx` below recovers the
+  CTCDecoder's Keras tensors from the graph.  tf2onnx keeps the TF scope names on most nodes but const-folds some
+  weights into anonymous initializers and lowers the attention einsums to Gemm/MatMul, so the tensors are located
+  *structurally* (node-name suffixes inside each block scope, and for the attention projections by following the data
+  flow from the `truediv` / `Softmax` nodes), not by the export's initializer numbering.
+* Keras `.h5`: needs an HDF5 reader (h5py is not part of this image); convert with
+  `np.savez(path, **{w.name: w.numpy() for w in model.weights})` under the names of DESIGN.md section 6.
+
+No onnx / protobuf package is used: the ONNX file is a protobuf whose few fields of interest are decoded here
+(onnx.proto3: ModelProto.graph = 7; GraphProto.node = 1, initializer = 5; NodeProto.input = 1, output = 2, name = 3,
+op_type = 4, attribute = 5; AttributeProto.name = 1, i = 3, ints = 8; TensorProto.dims = 1, data_type = 2,
+float_data = 4, int32_data = 5, int64_data = 7, name = 8, raw_data = 9)."""
+import re
+import struct
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------------------
+# protobuf wire format
+# ---------------------------------------------------------------------------------------------------------
+def _varint(b, p):
+    v = s = 0
+    while True:
+        c = b[p]
+        p += 1
+        v |= (c & 0x7F) << s
+        if c < 0x80:
+            return v, p
+        s += 7
+
+
+def _msg(b):
+    """(field, wire type, value) triples of one message; length-delimited values are memoryview slices."""
+    p, n = 0, len(b)
+    while p < n:
+        key, p = _varint(b, p)
+        f, t = key >> 3, key & 7
+        if t == 0:
+            v, p = _varint(b, p)
+        elif t == 1:
+            v, p = bytes(b[p:p + 8]), p + 8
+        elif t == 2:
+            ln, p = _varint(b, p)
+            v, p = b[p:p + ln], p + ln
+        elif t == 5:
+            v, p = bytes(b[p:p + 4]), p + 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % t)
+        yield f, t, v
+
+
+def _packed_varints(v):
+    out, p = [], 0
+    while p < len(v):
+        x, p = _varint(v, p)
+        out.append(x)
+    return out
+
+
+_DTYPES = {1: np.float32, 6: np.int32, 7: np.int64, 11: np.float64, 9: np.bool_, 10: np.float16}
+
+
+def _tensor(b):
+    dims, dtype, name, raw = [], 1, "", None
+    fdata, idata = [], []
+    for f, t, v in _msg(b):
+        if f == 1:
+            dims += _packed_varints(v) if t == 2 else [v]
+        elif f == 2:
+            dtype = v
+        elif f == 8:
+            name = bytes(v).decode()
+        elif f == 9:
+            raw = bytes(v)
+        elif f == 4:
+            fdata += list(struct.unpack("<%df" % (len(v) // 4), bytes(v))) if t == 2 else [struct.unpack("<f", v)[0]]
+        elif f in (5, 7):
+            idata += _packed_varints(v) if t == 2 else [v]
+    if dtype not in _DTYPES:
+        return name, None
+    dt = _DTYPES[dtype]
+    if raw is not None:
+        arr = np.frombuffer(raw, dtype=dt).copy()
+    elif fdata:
+        arr = np.asarray(fdata, dt)
+    else:
+        arr = np.asarray([x - (1 << 64) if x >= (1 << 63) else x for x in idata], dt)
+    return name, arr.reshape(dims)
+
+
+class OnnxNode:
+    __slots__ = ("op", "name", "inputs", "outputs", "ints")
+
+    def __init__(self):
+        self.op, self.name, self.inputs, self.outputs, self.ints = "", "", [], [], {}
+
+
+def read_onnx(path):
+    """-> (nodes in file order, {initializer name: ndarray})."""
+    with open(path, "rb") as fh:
+        buf = memoryview(fh.read())
+    graph = None
+    for f, t, v in _msg(buf):
+        if f == 7:
+            graph = v
+    if graph is None:
+        raise ValueError("%s: no GraphProto" % path)
+    nodes, inits = [], {}
+    for f, t, v in _msg(graph):
+        if f == 1:
+            n = OnnxNode()
+            for g, u, w in _msg(v):
+                if g == 1:
+                    n.inputs.append(bytes(w).decode())
+                elif g == 2:
+                    n.outputs.append(bytes(w).decode())
+                elif g == 3:
+                    n.name = bytes(w).decode()
+                elif g == 4:
+                    n.op = bytes(w).decode()
+                elif g == 5:
+                    an, ai, ais = "", None, []
+                    for h, x, y in _msg(w):
+                        if h == 1:
+                            an = bytes(y).decode()
+                        elif h == 3:
+                            ai = y
+                        elif h == 8:
+                            ais += _packed_varints(y) if x == 2 else [y]
+                    n.ints[an] = ais if ais else ai
+            nodes.append(n)
+        elif f == 5:
+            name, arr = _tensor(v)
+            if arr is not None:
+                inits[name] = arr
+    return nodes, inits
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CTCDecoder (conformer_blocks.py:385-438) from a tf2onnx graph
+# ---------------------------------------------------------------------------------------------------------
+_PASS = ("Reshape", "Squeeze", "Unsqueeze", "Transpose", "Identity", "Cast")
+
+
+class _Graph:
+    def __init__(self, nodes, inits):
+        self.nodes, self.inits = nodes, inits
+        self.producer = {o: n for n in nodes for o in n.outputs}
+        self.consumers = {}
+        for n in nodes:
+            for i in n.inputs:
+                self.consumers.setdefault(i, []).append(n)
+
+    def node(self, suffix, op=None):
+        hits = [n for n in self.nodes if n.name.endswith(suffix) and (op is None or n.op == op)]
+        if len(hits) != 1:
+            raise ValueError("expected exactly one %s node named *%s, found %d" % (op or "", suffix, len(hits)))
+        return hits[0]
+
+    def back_to(self, tensor, ops):
+        """follow the first input through shape-only ops until a node of one of `ops` produced the tensor"""
+        while True:
+            n = self.producer.get(tensor)
+            if n is None:
+                raise ValueError("tensor %s has no producer of type %s" % (tensor, ops))
+            if n.op in ops:
+                return n
+            if n.op not in _PASS:
+                raise ValueError("unexpected %s node %s while tracing back to %s" % (n.op, n.name, ops))
+            tensor = n.inputs[0]
+
+    def forward_to(self, tensor, op):
+        """follow the data consumers (ignoring Shape side branches) through shape-only ops to the first `op` node"""
+        while True:
+            cs = [c for c in self.consumers.get(tensor, []) if c.op != "Shape"]
+            hit = [c for c in cs if c.op == op]
+            if hit:
+                return hit[0], tensor
+            cs = [c for c in cs if c.op in _PASS and c.inputs[0] == tensor]
+            if len(cs) != 1:
+                raise ValueError("cannot follow %s forward to a %s node" % (tensor, op))
+            tensor = cs[0].outputs[0]
+
+    def const_of(self, tensor):
+        """the initializer behind `tensor` (possibly through shape-only ops) and the shape it is used with"""
+        chain = []
+        while tensor not in self.inits:
+            n = self.producer.get(tensor)
+            if n is None or n.op not in _PASS:
+                raise ValueError("%s is not a constant" % tensor)
+            chain.append(n)
+            tensor = n.inputs[0]
+        return np.asarray(self.inits[tensor], np.float32)
+
+
+def ctc_decoder_weights_from_onnx(path, num_heads=4):
+    """Keras-layout CTCDecoder tensors (names of DESIGN.md section 6) from the reference's `ctc_model.onnx` export.
+    The exported BatchNormalization arrives folded to (scale, shift); it is returned as gamma = scale, beta = shift,
+    moving_mean = 0, moving_variance = 1 - eps (eps = 1e-3), which reproduces scale * x + shift exactly."""
+    nodes, inits = read_onnx(path)
+    g = _Graph(nodes, inits)
+    f32 = lambda name: np.asarray(inits[name], np.float32)  # noqa: E731
+    w = {}
+
+    def dense(pattern):
+        """(kernel, bias) initializers of Dense layers matching `pattern` with one group = the layer index, ascending"""
+        idx = sorted({int(m.group(1)) for n in inits for m in [re.fullmatch(pattern + r"/Tensordot/ReadVariableOp:0", n)] if m})
+        return [(f32(pattern.replace(r"(\d+)", str(i)) + "/Tensordot/ReadVariableOp:0"),
+                 f32(pattern.replace(r"(\d+)", str(i)) + "/BiasAdd/ReadVariableOp:0")) for i in idx]
+
+    (w["project/kernel"], w["project/bias"]), = dense(r"dense_(\d+)")
+    w["fully_connected/kernel"] = f32("fully_connected/Tensordot/ReadVariableOp:0")
+    w["fully_connected/bias"] = f32("fully_connected/BiasAdd/ReadVariableOp:0")
+    d = w["project/kernel"].shape[0]
+    hs = d // num_heads
+    blocks = sorted({int(m.group(1)) for n in nodes for m in [re.match(r"decoder_conformer_block_(\d+)/", n.name)] if m})
+    for bi in blocks:
+        blk = "decoder_conformer_block_%d" % bi
+
+        def ln(dst, scope):
+            idx = {int(m.group(1)) for n in nodes
+                   for m in [re.fullmatch(re.escape(blk + "/" + scope) + r"layer_normalization_(\d+)/mul_3", n.name)] if m}
+            if len(idx) != 1:
+                raise ValueError("LayerNormalization under %s/%s not found" % (blk, scope))
+            base = "%s/%slayer_normalization_%d" % (blk, scope, idx.pop())
+            w[dst + "/gamma"] = f32(g.node(base + "/mul_3", "Mul").inputs[1])
+            w[dst + "/beta"] = f32(g.node(base + "/add", "Add").inputs[1])
+
+        ln(blk + "/ff_module_1/ln", "ff_module_1/")
+        ln(blk + "/mhsa_module/ln", "mhsa_module/")
+        ln(blk + "/conv_module/ln", "conv_module/")
+        ln(blk + "/ff_module_2/ln", "ff_module_2/")
+        ln(blk + "/ln", "")
+        for ff in ("ff_module_1", "ff_module_2"):
+            (k1, b1), (k2, b2) = dense(re.escape("%s/%s/" % (blk, ff)) + r"dense_(\d+)")
+            p = "%s/%s" % (blk, ff)
+            w[p + "/ffn1/kernel"], w[p + "/ffn1/bias"], w[p + "/ffn2/kernel"], w[p + "/ffn2/bias"] = k1, b1, k2, b2
+        # attention: query = the Gemm feeding `truediv`; key = the other operand of the MatMul the scaled query enters;
+        # value = the other operand of the MatMul the Softmax output enters.  tf2onnx turned einsum "BNI,HIO->BNHO"
+        # into Gemm(transB = 1) with W[h * hs + o, i] = kernel[h, i, o].
+        m = blk + "/mhsa_module/mha"
+        mha = [n for n in nodes if re.fullmatch(re.escape(blk) + r"/mhsa_module/multi_head_attention_(\d+)/truediv", n.name)]
+        if len(mha) != 1:
+            raise ValueError("%s: attention scaling node not found" % blk)
+        scope = mha[0].name[:-len("/truediv")]
+        q_gemm = g.back_to(mha[0].inputs[0], ("Gemm",))
+        qk, q_in = g.forward_to(mha[0].outputs[0], "MatMul")
+        k_gemm = g.back_to([i for i in qk.inputs if i != q_in][0], ("Gemm",))
+        sm = g.node(scope + "/Softmax", "Softmax")
+        pv, p_in = g.forward_to(sm.outputs[0], "MatMul")
+        v_gemm = g.back_to([i for i in pv.inputs if i != p_in][0], ("Gemm",))
+        for nm, gm in (("query_kernel", q_gemm), ("key_kernel", k_gemm), ("value_kernel", v_gemm)):
+            if gm.ints.get("transB") != 1:
+                raise ValueError("%s: expected Gemm(transB=1) for %s" % (blk, nm))
+            w[m + "/" + nm] = np.ascontiguousarray(g.const_of(gm.inputs[1]).reshape(num_heads, hs, d).transpose(0, 2, 1))
+        badd = g.node(scope + "/add", "Add")
+        o_gemm = g.back_to(badd.inputs[0], ("Gemm",))
+        proj = g.const_of(o_gemm.inputs[1])                       # [.., O, H, I] -> projection_kernel[h, i, o]
+        w[m + "/projection_kernel"] = np.ascontiguousarray(proj.reshape(d, num_heads, hs).transpose(1, 2, 0))
+        w[m + "/projection_bias"] = f32(badd.inputs[1])
+        c = blk + "/conv_module"
+        conv = lambda suffix: g.node(c + suffix, "Conv")  # noqa: E731
+        pw1 = conv("/pw_conv_1/conv1d")
+        w[c + "/pw_conv_1/kernel"] = np.ascontiguousarray(g.const_of(pw1.inputs[1])[:, :, 0, 0].T[None])
+        w[c + "/pw_conv_1/bias"] = f32(g.node(c + "/pw_conv_1/BiasAdd", "Add").inputs[1]).reshape(-1)
+        dw = conv("/dw_conv/separable_conv2d/depthwise")
+        w[c + "/dw_conv/depthwise_kernel"] = np.ascontiguousarray(g.const_of(dw.inputs[1])[:, 0, 0, :].T[:, :, None])
+        pw = conv("/dw_conv/BiasAdd")
+        w[c + "/dw_conv/pointwise_kernel"] = np.ascontiguousarray(g.const_of(pw.inputs[1])[:, :, 0, 0].T[None])
+        w[c + "/dw_conv/bias"] = f32(pw.inputs[2]).reshape(-1)
+        bn = [n for n in nodes if re.fullmatch(re.escape(c) + r"/batch_normalization_(\d+)/batchnorm/mul_1", n.name)]
+        if len(bn) != 1:
+            raise ValueError("%s: folded BatchNormalization not found" % blk)
+        scale = f32(bn[0].inputs[1]).reshape(-1)
+        shift = f32(g.node(bn[0].name[:-len("mul_1")] + "add_1", "Add").inputs[1]).reshape(-1)
+        w[c + "/bn/gamma"], w[c + "/bn/beta"] = scale, shift
+        w[c + "/bn/moving_mean"] = np.zeros_like(scale)
+        w[c + "/bn/moving_variance"] = np.full_like(scale, 1.0 - 1e-3)
+        pw2 = conv("/pw_conv_2/conv1d")
+        w[c + "/pw_conv_2/kernel"] = np.ascontiguousarray(g.const_of(pw2.inputs[1])[:, :, 0, 0].T[None])
+        w[c + "/pw_conv_2/bias"] = f32(g.node(c + "/pw_conv_2/BiasAdd", "Add").inputs[1]).reshape(-1)
+    return w

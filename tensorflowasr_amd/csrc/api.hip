@@ -497,11 +497,20 @@ int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, fl
     // LEAF: Gabor conv + squared modulus + Gaussian pooling (partials in the log-power scratch), then PCEN + instance norm
     int nf, pl;
     same_pad(Lb, 401, m->dm.hop, &nf, &pl);
-    const int NH = ceil_div(Lb, 128);          // position tiles of 128 (leaf.hip)
-    LeafConvArgs la{wav, m->leaf_wp, m->leaf_gcoef, logp, m->leaf_p0, m->leaf_p1, Bp, Lb, F, NH, m->dm.hop, pl};
-    { PROF(MI355ASR_K_STFT); LAUNCH_TRY(launch_leaf_conv_pool(la, s), "leaf gabor conv + pooling"); }
+    // leaf_terms = 0: fp32 MFMA kernel, tiles of 128 positions; 2 / 3: split-bf16 kernel, tiles of 512 (leaf.hip)
+    const int tile = m->leaf_terms ? kLeafSplitTile : 128, nrel = m->leaf_terms ? kLeafSplitSlots : 4;
+    const int NH = ceil_div(Lb, tile);
+    if (m->leaf_terms) {
+      LeafConvArgs la{wav, m->leaf_wsplit, m->leaf_gcoef, logp, m->leaf_p0, m->leaf_p1, Bp, Lb, F, NH, m->dm.hop, pl};
+      PROF(MI355ASR_K_STFT);
+      LAUNCH_TRY(launch_leaf_conv_pool_split(m->leaf_terms, la, s), "leaf gabor conv (split bf16) + pooling");
+    } else {
+      LeafConvArgs la{wav, m->leaf_wp, m->leaf_gcoef, logp, m->leaf_p0, m->leaf_p1, Bp, Lb, F, NH, m->dm.hop, pl};
+      PROF(MI355ASR_K_STFT);
+      LAUNCH_TRY(launch_leaf_conv_pool(la, s), "leaf gabor conv + pooling");
+    }
     LeafPcenArgs lp{logp, m->leaf_alpha, m->leaf_delta, m->leaf_root, m->leaf_smooth, m->leaf_gamma, m->leaf_beta, mel,
-                    Bp, F, NH, m->dm.hop, pl};
+                    Bp, F, NH, m->dm.hop, pl, tile, nrel};
     { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_leaf_pcen_norm(lp, s), "leaf PCEN + instance norm"); }
     return 0;
   }
@@ -759,6 +768,10 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
     return fail(MI355ASR_EINVAL, "negative count in config");
   auto* m = new mi355asr_model();
   m->cfg = c;
+  if (const char* e = std::getenv("MI355ASR_LEAF_TERMS")) {   // 0 = fp32 MFMA Gabor conv; 2 / 3 = bf16 terms per operand
+    const int t = std::atoi(e);
+    if (t == 0 || t == 2 || t == 3) m->leaf_terms = t;
+  }
   Dims& dm = m->dm;
   dm.hop = c.stride_ms * c.sample_rate / 1000;
   if (dm.hop <= 0) { delete m; return fail(MI355ASR_EINVAL, "stride_ms*sample_rate/1000 must be positive"); }
@@ -926,7 +939,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0;
   FftOff fo;
   std::vector<BlockOff> eo, co;
-  size_t o_leafw = 0, o_lg = 0, o_la = 0, o_ld = 0, o_lr = 0, o_ls = 0, o_lga = 0, o_lbe = 0;
+  size_t o_leafw = 0, o_leafs = 0, o_lg = 0, o_la = 0, o_ld = 0, o_lr = 0, o_ls = 0, o_lga = 0, o_lbe = 0;
   if (c.has_encoder && c.mel_layer_type == 1) {
     // Gabor filters from (center, sigma) with the layer's constraint (convolution.py:137-153, impulse_responses.py:39-64)
     const int K = 401, NF = c.n_mels;
@@ -945,6 +958,30 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
     }
     o_leafw = ab.put(pack_p16([&](int k, int n) { return k < K ? (float)((n & 1) ? im[(size_t)(n >> 1) * K + k] : re[(size_t)(n >> 1) * K + k]) : 0.f; },
                            26 * 16, 2 * NF, 2 * NF / 16));
+    {
+      // split-bf16 fragments [13 k-blocks of 32 taps][10 column tiles][terms][64 lanes][8]: lane (r = lane & 15, g = lane >> 4)
+      // holds taps 32 kb + 8 g + 0..7 of channel 16 nt + r; term t = round-to-nearest-even bf16 of what terms < t left
+      const int NS = m->leaf_terms ? m->leaf_terms : 3;
+      std::vector<uint16_t> frag((size_t)13 * 10 * NS * 64 * 8);
+      auto rne = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); };
+      for (int kb = 0; kb < 13; ++kb)
+        for (int nt = 0; nt < 10; ++nt)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int tap = 32 * kb + 8 * (lane >> 4) + j, ch = 16 * nt + (lane & 15);
+              float r = tap < K ? (float)((ch & 1) ? im[(size_t)(ch >> 1) * K + tap] : re[(size_t)(ch >> 1) * K + tap]) : 0.f;
+              for (int t = 0; t < NS; ++t) {
+                const uint16_t hb = rne(r);
+                const uint32_t back = (uint32_t)hb << 16;
+                float hf; std::memcpy(&hf, &back, 4);
+                r -= hf;
+                frag[((((size_t)kb * 10 + nt) * NS + t) * 64 + lane) * 8 + j] = hb;
+              }
+            }
+      std::vector<float> as_f(frag.size() / 2);
+      std::memcpy(as_f.data(), frag.data(), frag.size() * 2);
+      o_leafs = ab.put(as_f);
+    }
     const auto& ps = m->host["mel_layer/learnable_pooling/kernel"].data;
     std::vector<float> gc(NF);
     for (int f = 0; f < NF; ++f) {           // impulse_responses.gaussian_lowpass (:103-119), as exp2 coefficients
@@ -1051,7 +1088,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
-  m->leaf_wp = base + o_leafw; m->leaf_gcoef = base + o_lg; m->leaf_alpha = base + o_la; m->leaf_delta = base + o_ld;
+  m->leaf_wp = base + o_leafw; m->leaf_wsplit = base + o_leafs; m->leaf_gcoef = base + o_lg; m->leaf_alpha = base + o_la; m->leaf_delta = base + o_ld;
   m->leaf_root = base + o_lr; m->leaf_smooth = base + o_ls; m->leaf_gamma = base + o_lga; m->leaf_beta = base + o_lbe;
   m->wp_dw = base + o_wdw; m->wp_pw = base + o_wpw; m->wp_b = base + o_wb; m->wp_fw = base + o_wfw; m->wp_fb = base + o_wfb;
   for (size_t i = 0; i < wo.size(); ++i) {

@@ -169,8 +169,12 @@ struct LeafPcenArgs {
   const float *alpha, *delta, *root, *smooth, *gamma, *beta;   // [80] each
   float* out;           // [B, F, 80]
   int B, F, NH, hop, pl;
+  int tile, nrel;       // positions per partial tile and frame slots per tile: 128 / 4 (fp32 kernel), 512 / 7 (split kernel)
 };
 int launch_leaf_conv_pool(const LeafConvArgs& a, hipStream_t s);
+// split-bf16 variant (ns = 2 or 3 bf16 terms per fp32 operand): wp = bf16 fragments [13][10][ns][64][8]
+constexpr int kLeafSplitTile = 512, kLeafSplitSlots = 7;   // positions per workgroup, frames a tile can touch
+int launch_leaf_conv_pool_split(int ns, const LeafConvArgs& a, hipStream_t s);
 int launch_leaf_pcen_norm(const LeafPcenArgs& a, hipStream_t s);
 // add_wav_info branch (wavpick.hip)
 struct WpSepConvArgs {

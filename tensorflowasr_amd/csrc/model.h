@@ -108,6 +108,8 @@ struct mi355asr_model {
   const float *leaf_wp = nullptr, *leaf_gcoef = nullptr, *leaf_alpha = nullptr, *leaf_delta = nullptr, *leaf_root = nullptr,
               *leaf_smooth = nullptr, *leaf_gamma = nullptr, *leaf_beta = nullptr;
   float leaf_p0 = 0.f, leaf_p1 = 1.f;
+  const float* leaf_wsplit = nullptr;   // Gabor filters as split-bf16 MFMA fragments (leaf.hip)
+  int leaf_terms = 3;                   // bf16 terms per fp32 operand in the Gabor conv (0: fp32 MFMA kernel)
   // add_wav_info: WavePickModel weights (conv kernels P16-packed with K = k * Cin)
   struct WavStage { const float *cw, *cb, *w5, *b5, *w1, *b1, *ws, *bs; int cin, c, stride; };
   const float *wp_dw = nullptr, *wp_pw = nullptr, *wp_b = nullptr, *wp_fw = nullptr, *wp_fb = nullptr;

@@ -172,13 +172,18 @@ class _ModelBase:
         return self
 
     def load_weights(self, weights, by_name=True, strict=None):
-        """`weights`: path to an .npz of Keras-layout tensors, or a dict name -> array.  (The reference's
-        Keras .h5 checkpoints need h5py, which is not part of this image; see INTEGRATION.md.)"""
+        """`weights`: a dict name -> array, the path of an .npz of Keras-layout tensors, or the path of the reference's
+        tf2onnx export of the CTCDecoder (`ctc_model.onnx`; checkpoint.py).  (The reference's Keras .h5 checkpoints need
+        h5py, which is not part of this image; see INTEGRATION.md.)"""
         if isinstance(weights, (str, os.PathLike)):
             path = str(weights)
             if path.endswith(".h5"):
                 raise NotImplementedError("Keras .h5 checkpoints: convert to .npz first (INTEGRATION.md)")
-            weights = dict(np.load(path))
+            if path.endswith(".onnx"):
+                from . import checkpoint
+                weights = checkpoint.ctc_decoder_weights_from_onnx(path, num_heads=self.num_heads)
+            else:
+                weights = dict(np.load(path))
         if strict is None:
             strict = not by_name
         if not getattr(self, "_weights", None):

@@ -11,7 +11,7 @@ import wave
 import numpy as np
 import pytest
 
-from helpers import ROOT, co, encoder_kwargs, small_cfg
+from helpers import ROOT, co, encoder_kwargs, golden_ctc_weights, small_cfg
 from tensorflowasr_amd import _lib, frontend_consts
 from tensorflowasr_amd.config import UserConfig
 from tensorflowasr_amd.featurizers import SpeechFeaturizer, TextFeaturizer, read_raw_audio
@@ -425,3 +425,23 @@ def test_prefix_beam_argument_errors():
         ctc_prefix_beam_decode(np.zeros((1, 3, 1), np.float32), None, 4)        # V < 2
     with pytest.raises(ValueError):
         ctc_prefix_beam_decode(np.zeros((1, 3, 4), np.float32), None, 4, is_logits=True)
+
+
+REF_ONNX = "/root/reference/Inference/PythonInference/asr/models/offline/ctc_model.onnx"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_ONNX), reason="the reference tree is only present in the build container")
+def test_ctc_decoder_weights_from_the_reference_onnx_export():
+    """checkpoint.py (product code, structural tracing of the tf2onnx graph) recovers exactly the tensors that the
+    oracle-side extraction pinned by executing the graph (tests/golden/ctc_decoder_weights.npz), and CTCDecoder accepts
+    the .onnx path."""
+    from tensorflowasr_amd import checkpoint
+    w = checkpoint.ctc_decoder_weights_from_onnx(REF_ONNX, num_heads=4)
+    gold = golden_ctc_weights()
+    assert set(w) == set(gold)
+    for k in gold:
+        assert w[k].dtype == np.float32 and np.array_equal(w[k], gold[k]), k
+    dec = CTCDecoder(num_classes=1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32)
+    assert {n: tuple(s) for n, s in dec._names_and_shapes()} == {k: v.shape for k, v in w.items()}
+    nodes, inits = checkpoint.read_onnx(REF_ONNX)
+    assert len(nodes) == 307 and len(inits) == 62
