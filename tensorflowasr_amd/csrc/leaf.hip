@@ -31,6 +31,19 @@ constexpr int NTL = 10;                     // 160 channels
 constexpr int HOP_TILE = 128;               // positions per workgroup (= 4 waves x 2 row tiles of 16)
 constexpr int XWIN = HOP_TILE + 16 * KBL;   // staged samples per hop
 
+// sum over the 16 lanes of a row (the 16 positions of a row tile) with DPP adds; every lane ends with the total
+template <int CTRL>
+DEV float dpp_add(float v) {
+  const int s = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+  return v + __builtin_bit_cast(float, s);
+}
+DEV float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  return dpp_add<0x140>(v); // row_mirror
+}
+
 __global__ __launch_bounds__(LTH, 2) void leaf_conv_pool_kernel(LeafConvArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 wlds[2][NTL * 64];
   __shared__ float xlds[XWIN + 8];
@@ -117,11 +130,7 @@ __global__ __launch_bounds__(LTH, 2) void leaf_conv_pool_kernel(LeafConvArgs a) 
     }
     // sum over the 16 positions of the tile (lanes c)
 #pragma unroll
-    for (int i = 0; i < 2 * NTL; ++i) {
-      float v = wsum[i];
-      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-      wsum[i] = v;
-    }
+    for (int i = 0; i < 2 * NTL; ++i) wsum[i] = row16_sum(wsum[i]);
     if (c == 0) {
 #pragma unroll
       for (int i = 0; i < NTL; ++i) {
@@ -260,9 +269,23 @@ __global__ __launch_bounds__(STH, 2) void leaf_conv_pool_split_kernel(LeafConvAr
     __syncthreads();
   }
 
-  // ---- squared modulus + Gaussian pooling: the wave's 64 positions touch frames fbw .. fbw + 3
+  // ---- squared modulus + Gaussian pooling: the wave's 64 positions touch frames fbw .. fbw + 3.
+  // lane holds filters 8 nt + 2 g (x, y = re, im) and 8 nt + 2 g + 1 (z, w); |.|^2 once, then one mul + v_exp + fma per
+  // (value, frame): positions outside [0, L) or outside the frame's window get t^2 = 3e38, i.e. weight exp2(-huge) = 0
   const int n_w = SPOS * h + 64 * wave;
   const int fbw = (n_w + a.pl) / a.hop - 2;
+  float sq[4][2 * NTL], gc[2 * NTL];
+#pragma unroll
+  for (int i = 0; i < NTL; ++i) {
+    gc[2 * i] = a.gcoef[8 * i + 2 * g];        // -0.5 log2(e) / (sigma 200)^2  (< 0)
+    gc[2 * i + 1] = a.gcoef[8 * i + 2 * g + 1];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const f32x4 v = acc[rt][i];
+      sq[rt][2 * i] = v.x * v.x + v.y * v.y;
+      sq[rt][2 * i + 1] = v.z * v.z + v.w * v.w;
+    }
+  }
   for (int rel = 0; rel < 4; ++rel) {
     const int f = fbw + rel;
     float wsum[2 * NTL];
@@ -275,23 +298,14 @@ __global__ __launch_bounds__(STH, 2) void leaf_conv_pool_split_kernel(LeafConvAr
         if (tau0 + 15 < 0 || tau0 >= KTAPS) continue;
         const int n = n_w + 16 * rt + c, tau = tau0 + c;
         const bool ok = (n < L) && tau >= 0 && tau < KTAPS;
-        const float t2 = (float)(tau - (KTAPS - 1) / 2) * (float)(tau - (KTAPS - 1) / 2);
+        const float t = (float)(tau - (KTAPS - 1) / 2);
+        const float t2 = ok ? t * t : 3.0e38f;
 #pragma unroll
-        for (int i = 0; i < NTL; ++i) {
-          const f32x4 v = acc[rt][i];
-          const float sa = v.x * v.x + v.y * v.y, sb = v.z * v.z + v.w * v.w;
-          const float ca = a.gcoef[8 * i + 2 * g], cb = a.gcoef[8 * i + 2 * g + 1];
-          wsum[2 * i] += ok ? sa * __builtin_amdgcn_exp2f(ca * t2) : 0.f;
-          wsum[2 * i + 1] += ok ? sb * __builtin_amdgcn_exp2f(cb * t2) : 0.f;
-        }
+        for (int i = 0; i < 2 * NTL; ++i) wsum[i] = __builtin_fmaf(sq[rt][i], __builtin_amdgcn_exp2f(gc[i] * t2), wsum[i]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2 * NTL; ++i) {
-      float v = wsum[i];
-      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-      wsum[i] = v;
-    }
+    for (int i = 0; i < 2 * NTL; ++i) wsum[i] = row16_sum(wsum[i]);
     if (c == 0) {
 #pragma unroll
       for (int i = 0; i < NTL; ++i) {

@@ -94,6 +94,28 @@ def config5(steps):
     return res
 
 
+def frontend_variants(steps):
+    """the headline shape (ConformerCTC(S), 64 x 10 s, fp32) with the reference's other frontend options, and the
+    larger model sizes"""
+    from tensorflowasr_amd.models import ConformerCTC
+    B, L = 64, 160000
+    wav = torch.from_numpy(synth_batch(0, B, L)).cuda()
+    res = {"config": "ConformerCTC 64 x 10 s, recognize() ms/step by frontend option / model size", "dtype": "f32"}
+    variants = [("S_mel", {}), ("S_mel_wavinfo", dict(add_wav_info=True)), ("S_leaf", dict(mel_layer_type="leaf")),
+                ("S_leaf_wavinfo", dict(mel_layer_type="leaf", add_wav_info=True)),
+                ("M_mel", dict(dmodel=256, num_blocks=13, head_size=64, num_heads=4)),
+                ("L_mel", dict(dmodel=512, num_blocks=13, head_size=64, num_heads=8))]
+    for name, kw in variants:
+        m = ConformerCTC(1332, **kw)
+        m._build()
+        m.prepare(B, L)
+        t = timed(lambda: m.recognize(wav), steps)
+        res[name] = {"ms_step": round(t * 1e3, 3), "audio_frames_per_s": round(B * 1000 / t, 1)}
+        del m
+        torch.cuda.empty_cache()
+    return res
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
@@ -104,3 +126,5 @@ if __name__ == "__main__":
         print(json.dumps(config3(a.steps, "float32")), flush=True)
     if a.only in (0, 5):
         print(json.dumps(config5(a.steps)), flush=True)
+    if a.only in (0, 2):
+        print(json.dumps(frontend_variants(a.steps)), flush=True)
