@@ -550,7 +550,7 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   same_pad(F, 3, m->dm.st1, &T1, &pt1);
   same_pad(T1, 3, 2, &T2, &pt2);
   SubConvArgs sa{};
-  sa.mel = mel; sa.out = sub; sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
+  sa.mel = mel; sa.out = sub; sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b; sa.w2s = m->c2_wsplit;
   sa.B = Bp; sa.F = F; sa.NM = c.n_mels; sa.T1 = T1; sa.F1 = m->dm.F1; sa.T2 = T2; sa.F2 = m->dm.F2;
   sa.st1 = m->dm.st1; sa.pt1 = pt1; sa.pf1 = m->dm.pf1; sa.pt2 = pt2; sa.pf2 = m->dm.pf2;
   { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling"); }
@@ -936,7 +936,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   const Dims& dm = m->dm;
   const int d = c.dmodel;
   ArenaBuilder ab;
-  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0;
+  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0;
   FftOff fo;
   std::vector<BlockOff> eo, co;
   size_t o_leafw = 0, o_leafs = 0, o_lg = 0, o_la = 0, o_ld = 0, o_lr = 0, o_ls = 0, o_lga = 0, o_lbe = 0;
@@ -1024,6 +1024,32 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
       },
       9 * d, d, d / 16));
   o_c2b = ab.put(m->host["conv_subsampling/conv2/bias"].data);
+  if (d == 144) {
+    // split-bf16 fragments for subconv144_split_kernel: step s = 5 cb + pair; lane (r = lane & 15, g = lane >> 4) of
+    // column tile nt holds, for out channel 16 nt + r, in-channels 16 cb + 4 g + (j & 3) at tap 2 pair + (j >> 2)
+    // (the tenth tap is zero); term t = round-to-nearest-even bf16 of what the terms before it left
+    const int steps = (d / 16) * 5, NTc = d / 16;
+    std::vector<uint16_t> frag((size_t)steps * NTc * 3 * 64 * 8);
+    auto rne = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); };
+    for (int st = 0; st < steps; ++st)
+      for (int nt = 0; nt < NTc; ++nt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int cb = st / 5, pair = st % 5, q = 2 * pair + (j >> 2);
+            const int cin = 16 * cb + 4 * (lane >> 4) + (j & 3), cout = 16 * nt + (lane & 15);
+            float r = q < 9 ? c2[((size_t)q * d + cin) * d + cout] : 0.f;
+            for (int t = 0; t < 3; ++t) {
+              const uint16_t hb = rne(r);
+              const uint32_t back = (uint32_t)hb << 16;
+              float hf; std::memcpy(&hf, &back, 4);
+              r -= hf;
+              frag[((((size_t)st * NTc + nt) * 3 + t) * 64 + lane) * 8 + j] = hb;
+            }
+          }
+    std::vector<float> as_f(frag.size() / 2);
+    std::memcpy(as_f.data(), frag.data(), frag.size() * 2);
+    o_c2s = ab.put(as_f);
+  }
   const auto& lin = m->host["conv_subsampling/linear/kernel"].data;
   o_lw = ab.put(pack_p16([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d, d / 16));
   o_lb = ab.put(m->host["conv_subsampling/linear/bias"].data);
@@ -1085,7 +1111,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->fft_ok = fo.ok;
   m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;
   m->fft_win = base + fo.win;
-  m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
+  m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = (d == 144 && c.has_encoder) ? base + o_c2s : nullptr;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
   m->leaf_wp = base + o_leafw; m->leaf_wsplit = base + o_leafs; m->leaf_gcoef = base + o_lg; m->leaf_alpha = base + o_la; m->leaf_delta = base + o_ld;

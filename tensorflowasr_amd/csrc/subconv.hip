@@ -168,11 +168,266 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv144_kernel(SubConvArg
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-bf16 variant (default): the same implicit GEMM on v_mfma_f32_16x16x32_bf16 with every fp32 operand written as
+// the exact sum of three bf16 terms (see leaf.hip: the six term pairs with i + j <= 2, smallest first, are as accurate
+// as an fp32 FMA chain, at 6 x 16 cycles per 32 k-slots instead of 8 x 32), and -- because the matrix pipe is then
+// 2.7x faster than any per-wave weight stream can feed -- the conv2 weights shared by the eight waves of a workgroup
+// through a double-buffered LDS slab instead of one register stream per wave.
+//   * workgroup = 256 consecutive positions (t2, f2) of one utterance = 8 waves x 2 row tiles; grid (ceil(T2 F2 / 256), B)
+//     (B = 64, T2 F2 = 5000: 1280 workgroups = exactly five per CU);
+//   * the mel patch of the tile (59 frames x 83 bins) is staged in LDS once; conv1 is evaluated from it per lane;
+//   * k-slots: one 32-wide MFMA step = (channel block of 16, tap pair (2 p, 2 p + 1)): lane group g holds conv1
+//     channels 4 g .. 4 g + 3 at tap 2 p (slots 0..3) and at tap 2 p + 1 (slots 4..7); the ninth tap is paired with
+//     zeros (45 steps for 40.5 steps' worth of K: 10 % idle slots);
+//   * per step a 27 KB weight slab (9 column tiles x 3 terms) goes global -> registers -> LDS behind the MFMAs of the
+//     previous step; waves 0..3 compute the conv1 values + split of step s before its MFMAs, waves 4..7 (their SIMD
+//     partners) those of step s + 1 after the MFMAs of step s: one wave's VALU phase always faces the other's MFMAs;
+//   * the split is by truncation (x & 0xffff0000, remainder exact), packed with v_perm_b32: 11 VALU per value pair.
+constexpr int SCW = 8, SCT = SCW * 64, SRT = 2, SPOSG = SCW * 16 * SRT;   // 256 positions per workgroup
+constexpr int NPAIR = 5, NK32 = KB * NPAIR;        // MFMA steps
+constexpr int SLABF = NB * 3 * 64;                 // 16-byte fragments per step (27 KB)
+constexpr int MELP = 8192;                         // floats of LDS for the mel patch
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct SplitFrag { u32x4 t[3]; };                  // 8 k-slots x 3 terms
+
+// exact three-term bf16 split of eight fp32 values (slots 0..3 = lo, 4..7 = hi), two values per dword
+DEV SplitFrag split8(f32x4 lo, f32x4 hi) {
+  float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  SplitFrag f;
+#pragma unroll
+  for (int term = 0; term < 3; ++term) {
+    unsigned d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * k]), a1 = __builtin_bit_cast(unsigned, v[2 * k + 1]);
+      d[k] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);           // (a0 >> 16) | (a1 & 0xffff0000)
+      if (term < 2) {
+        v[2 * k] -= __builtin_bit_cast(float, a0 & 0xffff0000u);
+        v[2 * k + 1] -= __builtin_bit_cast(float, a1 & 0xffff0000u);
+      }
+    }
+    f.t[term] = u32x4{d[0], d[1], d[2], d[3]};
+  }
+  return f;
+}
+
+struct SplitLane {
+  int mb[SRT];                // float offset of the lane's 7x7 mel window in the LDS patch, per row tile
+  unsigned valid[SRT];        // bit kt*3+kf: conv1 position inside [0,T1) x [0,F1)
+};
+
+// conv1 + ReLU (+ conv2's zero padding) at tap q for channels 16 cb + 4 g .. + 3 of row tile rt
+template <int Q>
+DEV f32x4 conv1_at(const float* melp, int RS, const SplitLane& sl, int rt, const f32x4 (&w1r)[9], f32x4 b1v) {
+  constexpr int kt = Q / 3, kf = Q % 3;
+  f32x4 v = b1v;
+  int off = sl.mb[rt];
+  asm volatile("" : "+v"(off));            // opaque: otherwise the window reads are hoisted out of the channel-block loop
+  const float* mp = melp + off + (2 * kt) * RS + 2 * kf;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float m = mp[i * RS + j];
+      const f32x4 w = w1r[i * 3 + j];
+      v.x = __builtin_fmaf(m, w.x, v.x); v.y = __builtin_fmaf(m, w.y, v.y);
+      v.z = __builtin_fmaf(m, w.z, v.z); v.w = __builtin_fmaf(m, w.w, v.w);
+    }
+  const bool ok = (sl.valid[rt] >> Q) & 1u;
+  v.x = ok ? fmaxf(v.x, 0.f) : 0.f; v.y = ok ? fmaxf(v.y, 0.f) : 0.f;
+  v.z = ok ? fmaxf(v.z, 0.f) : 0.f; v.w = ok ? fmaxf(v.w, 0.f) : 0.f;
+  return v;
+}
+
+template <int PAIR>
+DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitLane& sl, const f32x4 (&w1r)[9], f32x4 b1v) {
+#pragma unroll
+  for (int rt = 0; rt < SRT; ++rt) {
+    const f32x4 lo = conv1_at<2 * PAIR>(melp, RS, sl, rt, w1r, b1v);
+    f32x4 hi = splat4(0.f);
+    if constexpr (2 * PAIR + 1 < 9) hi = conv1_at<2 * PAIR + 1>(melp, RS, sl, rt, w1r, b1v);
+    xf[rt] = split8(lo, hi);
+  }
+}
+
+__global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a, int RS, int rows) {
+  __shared__ __attribute__((aligned(16))) u32x4 wl[2][SLABF];
+  __shared__ __attribute__((aligned(16))) float melp[MELP];
+  __shared__ __attribute__((aligned(16))) float p_w1[9 * D], p_b1[D], p_b2[D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g4 = (lane >> 4) * 4, c = lane & 15;
+  const int b = blockIdx.y, r0 = blockIdx.x * SPOSG, PU = a.T2 * a.F2;
+  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(a.w2s);
+  constexpr int NQ = (SLABF + SCT - 1) / SCT;
+  u32x4 nw[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int idx = threadIdx.x + SCT * q;
+    nw[q] = u32x4{0u, 0u, 0u, 0u};
+    if (idx < SLABF) nw[q] = wg[idx];
+  }
+  // mel patch: rows tm_base .. + rows, bins fm_base .. + RS (zero outside the utterance / the mel range)
+  const int t2a = r0 / a.F2;
+  const int tm_base = 4 * t2a - 2 * a.pt2 - a.pt1, fm_base = -2 * a.pf2 - a.pf1;
+  const float* __restrict__ mbp = a.mel + (size_t)b * a.F * a.NM;
+  for (int i = threadIdx.x; i < rows * RS; i += SCT) {
+    const int rr = i / RS, jj = i - rr * RS;
+    const int tm = tm_base + rr, fm = fm_base + jj;
+    melp[i] = (tm >= 0 && tm < a.F && fm >= 0 && fm < a.NM) ? mbp[(size_t)tm * a.NM + fm] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 9 * D; i += SCT) p_w1[i] = a.w1[i];
+  for (int i = threadIdx.x; i < D; i += SCT) { p_b1[i] = a.b1[i]; p_b2[i] = a.b2[i]; }
+  SplitLane sl;
+#pragma unroll
+  for (int rt = 0; rt < SRT; ++rt) {
+    const int r = min(r0 + 32 * wave + 16 * rt + c, PU - 1);
+    const int t2 = r / a.F2, f2 = r - t2 * a.F2;
+    sl.mb[rt] = 4 * (t2 - t2a) * RS + 4 * f2;
+    unsigned vm = 0;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int kf = 0; kf < 3; ++kf) {
+        const int t1 = 2 * t2 + kt - a.pt2, f1 = 2 * f2 + kf - a.pf2;
+        vm |= (unsigned)((t1 >= 0) & (t1 < a.T1) & (f1 >= 0) & (f1 < a.F1)) << (kt * 3 + kf);
+      }
+    sl.valid[rt] = vm;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int idx = threadIdx.x + SCT * q;
+    if (idx < SLABF) wl[0][idx] = nw[q];
+  }
+  __syncthreads();
+
+  f32x4 acc[SRT][NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const f32x4 bv = lds4(p_b2, n, g4);
+#pragma unroll
+    for (int rt = 0; rt < SRT; ++rt) acc[rt][n] = bv;
+  }
+  f32x4 w1r[9];
+  auto load_taps = [&](int cb) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) w1r[tp] = *reinterpret_cast<const f32x4*>(p_w1 + tp * D + 16 * cb + g4);
+  };
+  SplitFrag xa[SRT];
+  const bool late = __builtin_amdgcn_readfirstlane(wave) >= SCW / 2;
+  // the whole step loop once per order (compile-time LATE): with a run-time order inside one loop hipcc keeps both
+  // paths' temporaries alive and spills (256 VGPRs + 232 bytes of scratch instead of 194)
+  auto run = [&](auto LATE_T) {
+  constexpr bool LATE = decltype(LATE_T)::value;
+  if constexpr (LATE) {
+    load_taps(0);
+    frags_for<0>(xa, melp, RS, sl, w1r, lds4(p_b1, 0, g4));
+  }
+#pragma unroll 1
+  for (int cb = 0; cb < KB; ++cb) {
+    static_for<0, NPAIR>([&](auto PI) {
+      constexpr int pair = decltype(PI)::value;
+      const int s = cb * NPAIR + pair, cur = s & 1;
+      const bool more = s + 1 < NK32;
+      if (more) {
+        const u32x4* src = wg + (size_t)(s + 1) * SLABF;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int idx = threadIdx.x + SCT * q;
+          if (idx < SLABF) nw[q] = src[idx];
+        }
+      }
+      // operand of the next step (VALU + LDS reads) and the MFMAs of this one are independent.  hipcc puts the ~270
+      // VALU instructions in front of the 108 MFMAs, and an in-order wave cannot fill the matrix pipe's shadow that
+      // way; since all waves meet at the barrier of every step the two waves of a SIMD would also be in the same phase.
+      // So the waves of the upper half of the workgroup (the SIMD partners of the lower half) run the two parts in
+      // the opposite order: one wave's conv1 / split VALU work always faces its partner's MFMAs.
+      auto frags_this = [&]() {              // early waves: the operand of this step, just before its MFMAs
+        if constexpr (pair == 0) load_taps(cb);
+        frags_for<pair>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+      };
+      auto frags_next = [&]() {              // late waves: the operand of the next step, after this step's MFMAs
+        if constexpr (pair + 1 < NPAIR) {
+          frags_for<pair + 1>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+        } else {
+          const int cbn = min(cb + 1, KB - 1);
+          load_taps(cbn);
+          frags_for<0>(xa, melp, RS, sl, w1r, lds4(p_b1, cbn, g4));
+        }
+      };
+      auto mfma_cur = [&]() {
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          bf16x8 wf[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) wf[t] = __builtin_bit_cast(bf16x8, wl[cur][(n * 3 + t) * 64 + lane]);
+#pragma unroll
+          for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+            for (int p = 0; p <= ord; ++p)
+#pragma unroll
+              for (int rt = 0; rt < SRT; ++rt)
+                acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ord - p], __builtin_bit_cast(bf16x8, xa[rt].t[p]),
+                                                                     acc[rt][n], 0, 0, 0);
+        }
+      };
+      if constexpr (LATE) {
+        mfma_cur();
+        __builtin_amdgcn_sched_barrier(0);
+        frags_next();
+      } else {
+        frags_this();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_cur();
+      }
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int idx = threadIdx.x + SCT * q;
+          if (idx < SLABF) wl[cur ^ 1][idx] = nw[q];
+        }
+      }
+      __syncthreads();
+    });
+  }
+  };
+  if (late) run(std::integral_constant<bool, true>{});
+  else run(std::integral_constant<bool, false>{});
+#pragma unroll
+  for (int rt = 0; rt < SRT; ++rt) {
+    const int r = r0 + 32 * wave + 16 * rt + c;
+    if (r < PU) {
+      float* orow = a.out + ((size_t)b * PU + r) * D;
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        f32x4 v = acc[rt][n];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        stg4(orow + 16 * n + g4, v);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int launch_subconv144(const SubConvArgs& a, hipStream_t s) {
   const int P = a.B * a.T2 * a.F2;
   const int tiles = (P + 15) / 16;
   hipLaunchKernelGGL(subconv144_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
+  return 0;
+}
+
+// split-bf16 kernel; returns -1 when the shape does not fit its LDS mel patch (the caller falls back)
+int launch_subconv144_split(const SubConvArgs& a, hipStream_t s) {
+  const int PU = a.T2 * a.F2;
+  const int RS = 4 * a.F2 + 4;                               // bins fm_base .. fm_base + 4 (F2 - 1) + 6
+  const int span = (SPOSG - 1 + a.F2 - 1) / a.F2;            // t2 steps a tile can touch beyond its first
+  const int rows = 4 * span + 7;
+  if (!a.w2s || a.st1 != 2 || rows * RS > MELP || PU <= 0) return -1;
+  hipLaunchKernelGGL(subconv144_split_kernel, dim3((PU + SPOSG - 1) / SPOSG, a.B), dim3(SCT), 0, s, a, RS, rows);
   return 0;
 }
