@@ -10,6 +10,9 @@
 //     k-block q, so its VALU work issues in the matrix pipe's shadow instead of between two MFMA batches;
 //   * 256-register budget (two waves per SIMD, accumulators stay in VGPRs).
 // K is ordered (channel block cb, kt, kf): one set of conv1 taps serves nine k-blocks.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "launch.h"
 #include "wstream.h"
@@ -255,7 +258,10 @@ DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitL
   }
 }
 
-__global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a, int RS, int rows) {
+// DIAG != 0: timing experiments only (results are wrong): 1 = no conv1 / split work, 2 = one weight-fragment read per
+// step instead of nine, 3 = no slab traffic (global -> LDS), 4 = no barrier in the step loop
+template <int DIAG>
+__global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a, int RS, int rows, int late_mode) {
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][SLABF];
   __shared__ __attribute__((aligned(16))) float melp[MELP];
   __shared__ __attribute__((aligned(16))) float p_w1[9 * D], p_b1[D], p_b2[D];
@@ -318,7 +324,18 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
     for (int tp = 0; tp < 9; ++tp) w1r[tp] = *reinterpret_cast<const f32x4*>(p_w1 + tp * D + 16 * cb + g4);
   };
   SplitFrag xa[SRT];
-  const bool late = __builtin_amdgcn_readfirstlane(wave) >= SCW / 2;
+  if constexpr (DIAG == 1) {
+#pragma unroll
+    for (int rt = 0; rt < SRT; ++rt)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) xa[rt].t[t] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  }
+  // which waves run MFMAs first: the SIMD partner of a wave must take the other order (see the step loop)
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const bool late = late_mode == 0 ? wv >= SCW / 2
+                  : late_mode == 1 ? (wv & 1) != 0
+                  : late_mode == 2 ? ((wv >> 1) & 1) != 0
+                                   : (__builtin_amdgcn_s_getreg(0x1804) & 1) != 0;   // HW_ID.wave_id: slot on the SIMD
   // the whole step loop once per order (compile-time LATE): with a run-time order inside one loop hipcc keeps both
   // paths' temporaries alive and spills (256 VGPRs + 232 bytes of scratch instead of 194)
   auto run = [&](auto LATE_T) {
@@ -333,7 +350,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
       constexpr int pair = decltype(PI)::value;
       const int s = cb * NPAIR + pair, cur = s & 1;
       const bool more = s + 1 < NK32;
-      if (more) {
+      if (more && DIAG != 3) {
         const u32x4* src = wg + (size_t)(s + 1) * SLABF;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -360,11 +377,13 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
         }
       };
       auto mfma_cur = [&]() {
+        bf16x8 wf[3];
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
-          bf16x8 wf[3];
+          if (DIAG != 2 || n == 0) {
 #pragma unroll
-          for (int t = 0; t < 3; ++t) wf[t] = __builtin_bit_cast(bf16x8, wl[cur][(n * 3 + t) * 64 + lane]);
+            for (int t = 0; t < 3; ++t) wf[t] = __builtin_bit_cast(bf16x8, wl[cur][(n * 3 + t) * 64 + lane]);
+          }
 #pragma unroll
           for (int ord = 2; ord >= 0; --ord)
 #pragma unroll
@@ -375,7 +394,9 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
                                                                      acc[rt][n], 0, 0, 0);
         }
       };
-      if constexpr (LATE) {
+      if constexpr (DIAG == 1) {
+        mfma_cur();
+      } else if constexpr (LATE) {
         mfma_cur();
         __builtin_amdgcn_sched_barrier(0);
         frags_next();
@@ -384,14 +405,14 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
         __builtin_amdgcn_sched_barrier(0);
         mfma_cur();
       }
-      if (more) {
+      if (more && DIAG != 3) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int idx = threadIdx.x + SCT * q;
           if (idx < SLABF) wl[cur ^ 1][idx] = nw[q];
         }
       }
-      __syncthreads();
+      if constexpr (DIAG != 4) __syncthreads();
     });
   }
   };
@@ -428,6 +449,20 @@ int launch_subconv144_split(const SubConvArgs& a, hipStream_t s) {
   const int span = (SPOSG - 1 + a.F2 - 1) / a.F2;            // t2 steps a tile can touch beyond its first
   const int rows = 4 * span + 7;
   if (!a.w2s || a.st1 != 2 || rows * RS > MELP || PU <= 0) return -1;
-  hipLaunchKernelGGL(subconv144_split_kernel, dim3((PU + SPOSG - 1) / SPOSG, a.B), dim3(SCT), 0, s, a, RS, rows);
+  static const int late_mode = [] { const char* v = getenv("MI355ASR_SUBCONV_LATE"); return v ? atoi(v) : 0; }();
+  static const int diag = [] {
+    const char* v = getenv("MI355ASR_SUBCONV_DIAG");
+    const int d = v ? atoi(v) : 0;
+    if (d) fprintf(stderr, "libmi355asr: MI355ASR_SUBCONV_DIAG=%d -- timing experiment, the subsampling output is WRONG\n", d);
+    return d;
+  }();
+  const dim3 grid((PU + SPOSG - 1) / SPOSG, a.B);
+  switch (diag) {
+    case 1: hipLaunchKernelGGL(subconv144_split_kernel<1>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
+    case 2: hipLaunchKernelGGL(subconv144_split_kernel<2>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
+    case 3: hipLaunchKernelGGL(subconv144_split_kernel<3>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
+    case 4: hipLaunchKernelGGL(subconv144_split_kernel<4>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
+    default: hipLaunchKernelGGL(subconv144_split_kernel<0>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode);
+  }
   return 0;
 }
