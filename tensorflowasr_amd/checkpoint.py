@@ -285,3 +285,79 @@ def ctc_decoder_weights_from_onnx(path, num_heads=4):
         w[c + "/pw_conv_2/kernel"] = np.ascontiguousarray(g.const_of(pw2.inputs[1])[:, :, 0, 0].T[None])
         w[c + "/pw_conv_2/bias"] = f32(g.node(c + "/pw_conv_2/BiasAdd", "Add").inputs[1]).reshape(-1)
     return w
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Keras variable names -> C-ABI names
+# ---------------------------------------------------------------------------------------------------------
+_AUTO = re.compile(r"^(layer_normalization|dense|conv2d|multi_head_attention|batch_normalization)(?:_(\d+))?$")
+
+
+def keras_names_to_abi(names):
+    """Map the Keras variable names of one of the reference's sub-models (ConformerEncoder, CTCDecoder; e.g.
+    `conformer_encoder/conformer_block_3/ff_module_1/dense_12/kernel:0`, as `model.weights` / the `.h5` `weight_names`
+    attributes list them) to the C-ABI names of DESIGN.md section 6.  Keras numbers auto-named layers (`dense_12`,
+    `layer_normalization_7`, ...) globally in construction order, so only the ORDER of the numbers inside one scope
+    is meaningful: the first Dense of an FFModule is ffn1, the second ffn2; the first Conv2D of conv_subsampling is
+    conv1, the second conv2 (conformer_blocks.py:76-86, 116-123).  Returns {keras name: abi name}; names that are
+    not part of the inference path (e.g. optimizer slots) are left out.
+
+    Typical use on a machine that has TensorFlow:
+        m = keras_names_to_abi([v.name for v in model.weights])
+        np.savez("encoder.npz", **{m[v.name]: v.numpy() for v in model.weights if v.name in m})"""
+    anchors = ("mel_layer", "conv_subsampling", "wav_layer", "conformer_block_", "decoder_conformer_block_",
+               "fully_connected", "dense")
+    parsed = []
+    for full in names:
+        parts = full.split(":")[0].split("/")
+        start = next((i for i, p in enumerate(parts) if p.startswith(anchors)), None)
+        if start is None:
+            continue
+        parsed.append((full, parts[start:]))
+
+    def auto_index(p):
+        m = _AUTO.match(p)
+        return (m.group(1), int(m.group(2) or 0)) if m else None
+
+    # rank of every auto-numbered layer among its siblings of the same kind inside the same scope
+    groups = {}
+    for _, parts in parsed:
+        for depth, p in enumerate(parts[:-1]):
+            ai = auto_index(p)
+            if ai:
+                groups.setdefault((tuple(parts[:depth]), ai[0]), set()).add(ai[1])
+    rank = {k: {n: i for i, n in enumerate(sorted(v))} for k, v in groups.items()}
+
+    out = {}
+    for full, parts in parsed:
+        var = parts[-1]
+        scope = []
+        ok = True
+        for depth, p in enumerate(parts[:-1]):
+            ai = auto_index(p)
+            if not ai:
+                scope.append(p)
+                continue
+            kind, r = ai[0], rank[(tuple(parts[:depth]), ai[0])][ai[1]]
+            parent = parts[depth - 1] if depth else ""
+            if kind == "layer_normalization":
+                scope.append("ln")
+            elif kind == "batch_normalization":
+                scope.append("bn")
+            elif kind == "multi_head_attention":
+                scope.append("mha")
+            elif kind == "conv2d" and parent == "conv_subsampling":
+                scope.append(("conv1", "conv2")[r] if r < 2 else None)
+            elif kind == "dense" and parent == "conv_subsampling":
+                scope.append("linear")
+            elif kind == "dense" and parent.startswith("ff_module"):
+                scope.append(("ffn1", "ffn2")[r] if r < 2 else None)
+            elif kind == "dense" and depth == 0:
+                scope.append("project")                 # CTCDecoder.project (conformer_blocks.py:400)
+            else:
+                ok = False
+            if scope and scope[-1] is None:
+                ok = False
+        if ok:
+            out[full] = "/".join(scope + [var])
+    return out

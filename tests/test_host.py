@@ -445,3 +445,44 @@ def test_ctc_decoder_weights_from_the_reference_onnx_export():
     assert {n: tuple(s) for n, s in dec._names_and_shapes()} == {k: v.shape for k, v in w.items()}
     nodes, inits = checkpoint.read_onnx(REF_ONNX)
     assert len(nodes) == 307 and len(inits) == 62
+
+
+def test_keras_variable_names_map_to_abi_names():
+    """checkpoint.keras_names_to_abi on names shaped like the reference's Keras variables: auto-numbered layers are
+    resolved by their order inside a scope (the numbering seen in the exported graph: dense_53.., layer_normalization_65..)."""
+    from tensorflowasr_amd import checkpoint
+    blk = "ctc_decoder/decoder_conformer_block_0"
+    names = ["ctc_decoder/dense_53/kernel:0", "ctc_decoder/dense_53/bias:0",
+             blk + "/ff_module_1/layer_normalization_65/gamma:0", blk + "/ff_module_1/layer_normalization_65/beta:0",
+             blk + "/ff_module_1/dense_54/kernel:0", blk + "/ff_module_1/dense_54/bias:0",
+             blk + "/ff_module_1/dense_55/kernel:0", blk + "/ff_module_1/dense_55/bias:0",
+             blk + "/mhsa_module/layer_normalization_66/gamma:0",
+             blk + "/mhsa_module/multi_head_attention_13/query_kernel:0",
+             blk + "/mhsa_module/multi_head_attention_13/projection_bias:0",
+             blk + "/conv_module/layer_normalization_67/beta:0", blk + "/conv_module/pw_conv_1/kernel:0",
+             blk + "/conv_module/dw_conv/depthwise_kernel:0", blk + "/conv_module/dw_conv/pointwise_kernel:0",
+             blk + "/conv_module/batch_normalization_13/moving_variance:0", blk + "/conv_module/pw_conv_2/bias:0",
+             blk + "/ff_module_2/dense_57/kernel:0", blk + "/ff_module_2/dense_56/kernel:0",
+             blk + "/layer_normalization_69/gamma:0", "ctc_decoder/fully_connected/kernel:0", "Adam/iter:0"]
+    m = checkpoint.keras_names_to_abi(names)
+    b = "decoder_conformer_block_0"
+    assert m["ctc_decoder/dense_53/kernel:0"] == "project/kernel"
+    assert m[blk + "/ff_module_1/dense_54/kernel:0"] == b + "/ff_module_1/ffn1/kernel"
+    assert m[blk + "/ff_module_1/dense_55/bias:0"] == b + "/ff_module_1/ffn2/bias"
+    assert m[blk + "/ff_module_2/dense_56/kernel:0"] == b + "/ff_module_2/ffn1/kernel"
+    assert m[blk + "/ff_module_2/dense_57/kernel:0"] == b + "/ff_module_2/ffn2/kernel"
+    assert m[blk + "/mhsa_module/multi_head_attention_13/query_kernel:0"] == b + "/mhsa_module/mha/query_kernel"
+    assert m[blk + "/conv_module/batch_normalization_13/moving_variance:0"] == b + "/conv_module/bn/moving_variance"
+    assert m[blk + "/layer_normalization_69/gamma:0"] == b + "/ln/gamma"
+    assert m["ctc_decoder/fully_connected/kernel:0"] == "fully_connected/kernel"
+    assert "Adam/iter:0" not in m
+    dec = CTCDecoder(num_classes=1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32)
+    assert set(m.values()) <= {n for n, _ in dec._names_and_shapes()}
+    enc = ["conformer_encoder/conv_subsampling/conv2d_4/kernel:0", "conformer_encoder/conv_subsampling/conv2d_5/bias:0",
+           "conformer_encoder/conv_subsampling/dense_9/kernel:0",
+           "conformer_encoder/conformer_block_11/ff_module_2/dense_99/bias:0",
+           "conformer_encoder/conformer_block_11/ff_module_2/dense_98/bias:0"]
+    e = checkpoint.keras_names_to_abi(enc)
+    assert e[enc[0]] == "conv_subsampling/conv1/kernel" and e[enc[1]] == "conv_subsampling/conv2/bias"
+    assert e[enc[2]] == "conv_subsampling/linear/kernel"
+    assert e[enc[3]] == "conformer_block_11/ff_module_2/ffn2/bias" and e[enc[4]] == "conformer_block_11/ff_module_2/ffn1/bias"
