@@ -84,6 +84,34 @@ std::vector<float> pack_p16(const std::function<float(int, int)>& f, int K, int 
 }
 
 
+// W[k][n] -> split-bf16 fragments for v_mfma_f32_16x16x32_bf16: [ceil(K/32) steps][N/16 tiles][3 terms][64 lanes][8],
+// lane (r = lane & 15, g = lane >> 4) of tile nt holds, for column 16 nt + r, rows k = 32 step + 16 (j >> 2) + 4 g + (j & 3)
+// (the two 16-blocks of a step side by side, as a lane's accumulator-layout float4 pair provides them); zero past K.
+// Term t = round-to-nearest-even bf16 of what the terms before it left (three terms hold all 24 significand bits).
+std::vector<float> pack_split32(const std::function<float(int, int)>& f, int K, int N) {
+  const int steps = ceil_div(K, 32), NT = N / 16;
+  std::vector<uint16_t> frag((size_t)steps * NT * 3 * 64 * 8, 0);
+  auto rne = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); };
+  for (int st = 0; st < steps; ++st)
+    for (int nt = 0; nt < NT; ++nt)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * st + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3), n = 16 * nt + (lane & 15);
+          float r = k < K ? f(k, n) : 0.f;
+          for (int t = 0; t < 3; ++t) {
+            const uint16_t hb = rne(r);
+            const uint32_t back = (uint32_t)hb << 16;
+            float hf; std::memcpy(&hf, &back, 4);
+            r -= hf;
+            frag[((((size_t)st * NT + nt) * 3 + t) * 64 + lane) * 8 + j] = hb;
+          }
+        }
+  std::vector<float> as_f(frag.size() / 2);
+  std::memcpy(as_f.data(), frag.data(), frag.size() * 2);
+  return as_f;
+}
+
+
 // The DFT kernels are model variables (time_frequency.py:62-75 creates them from backend.py:27-69 and a checkpoint
 // may overwrite them).  When they are exactly window[n] * (cos, -+sin)(2 pi k n / 1024) the STFT runs as a
 // 32 x 32 Cooley-Tukey factorisation (fft_stft.hip); otherwise the dense DFT GEMM stays.  MI355ASR_FFT=0 forces dense.
@@ -183,12 +211,14 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   const auto& pk = T(a + "/mha/projection_kernel");  // [H, hs, d]: row k = h*hs + i
   o.out_wp = ab.put(pack_p16([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d, d / 16));
   o.out_b = ab.put(T(a + "/mha/projection_bias"));
+  if (d == 144) { o.out_ws = ab.put(pack_split32([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d)); o.split = true; }
   }
   const std::string c = p + "/conv_module";
   o.cv_ln_g = ab.put(T(c + "/ln/gamma"));
   o.cv_ln_b = ab.put(T(c + "/ln/beta"));
   const auto& pw1 = T(c + "/pw_conv_1/kernel");
   o.pw1_wp = ab.put(pack_p16([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d, 2 * d / 16));
+  if (o.split) o.pw1_ws = ab.put(pack_split32([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d));
   o.pw1_b = ab.put(T(c + "/pw_conv_1/bias"));
   o.dw_w = ab.put(T(c + "/dw_conv/depthwise_kernel"));  // [k, d, 1] == [k][d]
   const auto& pc = T(c + "/dw_conv/pointwise_kernel");
@@ -231,6 +261,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
+  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; }
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
   b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
@@ -409,6 +440,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k2.ctx = sc.ctx; k2.x1 = sc.xb; k2.x2 = sc.xa; k2.u = sc.u;
     k2.out_wp = w.out_wp; k2.out_b = w.out_b; k2.cv_ln_g = w.cv_ln_g; k2.cv_ln_b = w.cv_ln_b;
     k2.pw1_wp = w.pw1_wp; k2.pw1_b = w.pw1_b; k2.eps = kLnEps; k2.M = M;
+    k2.out_ws = w.out_ws; k2.pw1_ws = w.pw1_ws;
     { PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU"); }
     DwArgs dwa{};
     dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;

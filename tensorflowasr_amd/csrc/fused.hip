@@ -21,6 +21,8 @@
 //     the 512-register budget it parks them in AGPRs and moves them back and forth around every MFMA group.
 // Reference semantics: asr/models/conformer_blocks.py:126-134 (FFModule), :164-170 + multihead_attention.py:151-188
 // (MHSA), :209-219 (ConvModule), :259-265 (block).
+#include <cstdlib>
+
 #include "common.h"
 #include "launch.h"
 #include "wstream.h"
@@ -217,6 +219,147 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void out_glu_kernel(OutGluArgs a)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// out_glu on the bf16 matrix pipe (fp32 operands as three bf16 terms, see subconv.hip / leaf.hip) with the weights
+// shared through LDS.  At 16 000 tokens there is one 16-token row tile per wave and one wave per SIMD, so the fp32
+// kernel above is bound by each wave's own MFMA chain (4 x 32 cycles per fragment); six bf16 MFMAs per 32 k-slots are
+// 2.7x faster, which a per-wave weight stream from L2 cannot feed -- the four waves of a workgroup read the fragments
+// from a double-buffered LDS slab instead, filled by global_load_lds_dwordx4 (no register round trip) one step ahead.
+//   step 0..4: out-projection, k-slots = (feature block 2 t | block 2 t + 1) of ctx, 9 column tiles   (27 KB slab)
+//   step 5..9: pw_conv_1 on LN(x2), same k-slots, 18 column tiles (value | gate)                    (54 KB slab)
+// A lane's B operand for step t is the split of its two accumulator-layout float4 (blocks 2 t, 2 t + 1): the transposed
+// chain property of the fp32 kernels carries over.  Column tiles are processed in groups of three (fragments of the
+// next group are read from LDS during the 18 MFMAs of the current one; MFMAs on one accumulator are three apart).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct Split8 { u32x4_t t[3]; };
+
+DEV Split8 split8(f32x4 lo, f32x4 hi) {      // exact: x = t0 + t1 + t2 (truncation, remainders are exact)
+  float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  Split8 f;
+#pragma unroll
+  for (int term = 0; term < 3; ++term) {
+    unsigned d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * k]), a1 = __builtin_bit_cast(unsigned, v[2 * k + 1]);
+      d[k] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+      if (term < 2) {
+        v[2 * k] -= __builtin_bit_cast(float, a0 & 0xffff0000u);
+        v[2 * k + 1] -= __builtin_bit_cast(float, a1 & 0xffff0000u);
+      }
+    }
+    f.t[term] = u32x4_t{d[0], d[1], d[2], d[3]};
+  }
+  return f;
+}
+DEV void dma16(const u32x4_t* gsrc, u32x4_t* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+constexpr int KS32 = 5;                       // 32-wide steps over K = 144 (the last half step is zero)
+constexpr int OG_SLAB = 2 * KB * 3 * 64;      // fragments of the larger slab (18 tiles)
+
+// acc[0..NT) += W(step)^T x  for one 32-wide step: slab = [NT tiles][3 terms][64 lanes] in LDS
+template <int NT>
+DEV void split_step(f32x4* acc, const Split8& xf, const u32x4_t* slab, int lane) {
+  static_assert(NT % 3 == 0, "tiles in groups of three");
+  bf16x8_t wf[2][3][3];
+  auto fetch = [&](int grp, int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) wf[buf][i][t] = __builtin_bit_cast(bf16x8_t, slab[((3 * grp + i) * 3 + t) * 64 + lane]);
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int grp = 0; grp < NT / 3; ++grp) {
+    if (grp + 1 < NT / 3) fetch(grp + 1, (grp + 1) & 1);
+#pragma unroll
+    for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+      for (int p = 0; p <= ord; ++p)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          acc[3 * grp + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[grp & 1][i][ord - p], __builtin_bit_cast(bf16x8_t, xf.t[p]),
+                                                                     acc[3 * grp + i], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_split_kernel(OutGluArgs a) {
+  __shared__ __attribute__((aligned(16))) u32x4_t wl[2][OG_SLAB];
+  __shared__ __attribute__((aligned(16))) float p_ob[D], p_lng[D], p_lnb[D], p_pb[2 * D];
+  const WaveCtx c = wave_ctx(a.M);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const u32x4_t* wo = reinterpret_cast<const u32x4_t*>(a.out_ws);
+  const u32x4_t* wg = reinterpret_cast<const u32x4_t*>(a.pw1_ws);
+  constexpr int SO = KB * 3 * 64, SG = 2 * KB * 3 * 64;      // slab sizes (fragments)
+  // slab of step s -> buffer s & 1
+  auto fill = [&](int s) {
+    const u32x4_t* src = s < KS32 ? wo + (size_t)s * SO : wg + (size_t)(s - KS32) * SG;
+    const int n = s < KS32 ? SO : SG;
+    for (int w0 = 64 * wv; w0 < n; w0 += BLOCK_THREADS) dma16(src + w0 + c.lane, &wl[s & 1][w0]);
+  };
+  fill(0);
+  f32x4 xs[KB + 1], acc[2 * KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + c.row + 16 * kb + c.g4);
+  xs[KB] = splat4(0.f);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) acc[kb] = ldg4(a.x1 + c.row + 16 * kb + c.g4);    // residual rides in the accumulator
+  stash(p_ob, a.out_b, D); stash(p_lng, a.cv_ln_g, D); stash(p_lnb, a.cv_ln_b, D); stash(p_pb, a.pw1_b, 2 * D);
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < KB; ++i) acc[i] += lds4(p_ob, i, c.g4);
+#pragma unroll 1
+  for (int s = 0; s < KS32; ++s) {
+    fill(s + 1);
+    Split8 xf;
+    // xs[2 s], xs[2 s + 1] with a run-time s: select through a small switch so that xs stays in registers
+    f32x4 lo = xs[0], hi = xs[1];
+    if (s == 1) { lo = xs[2]; hi = xs[3]; } else if (s == 2) { lo = xs[4]; hi = xs[5]; }
+    else if (s == 3) { lo = xs[6]; hi = xs[7]; } else if (s == 4) { lo = xs[8]; hi = xs[9]; }
+    xf = split8(lo, hi);
+    split_step<KB>(acc, xf, wl[s & 1], c.lane);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < KB; ++i) xs[i] = acc[i];                                      // x2 = x1 + attention
+  if (c.live) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(a.x2 + c.row + 16 * i + c.g4, xs[i]);
+  }
+  {
+    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
+    ln_lds(xr, p_lng, p_lnb, c.g4, a.eps);
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * KB; ++i) acc[i] = lds4(p_pb, i, c.g4);                   // value tiles 0..8, gate tiles 9..17
+#pragma unroll 1
+  for (int s = 0; s < KS32; ++s) {
+    if (s + 1 < KS32) fill(KS32 + s + 1);
+    f32x4 lo = xs[0], hi = xs[1];
+    if (s == 1) { lo = xs[2]; hi = xs[3]; } else if (s == 2) { lo = xs[4]; hi = xs[5]; }
+    else if (s == 3) { lo = xs[6]; hi = xs[7]; } else if (s == 4) { lo = xs[8]; hi = xs[9]; }
+    const Split8 xf = split8(lo, hi);
+    split_step<2 * KB>(acc, xf, wl[(KS32 + s) & 1], c.lane);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+  }
+  if (c.live) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const f32x4 va = acc[i], vb = acc[KB + i];
+      f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
+      stg4(a.u + c.row + 16 * i + c.g4, o);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void tail_ff2_kernel(TailFf2Args a) {
   __shared__ __attribute__((aligned(16))) float p_pcb[2 * D], p_bns[2 * D], p_bnt[2 * D], p_pw2b[D], p_lng[D], p_lnb[D], p_b1[4 * D],
@@ -267,7 +410,15 @@ int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
 }
 int launch_out_glu(const OutGluArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
-  hipLaunchKernelGGL(out_glu_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
+  // MI355ASR_OUTGLU_SPLIT=1: the split-bf16 / LDS-slab kernel instead of the fp32-MFMA register-stream one.  Off by
+  // default: with one row tile per wave (16 000 tokens) a slab's MFMAs last 0.4-0.8 us, less than the latency of the
+  // DMA that fetches the next one, and LDS cannot hold the ~140 KB in flight that would cover it -- measured 28.1 us
+  // against 26.4 us.  It pays once a wave owns several row tiles (B >= 256).
+  static const bool split = [] { const char* v = getenv("MI355ASR_OUTGLU_SPLIT"); return v && atoi(v) != 0; }();
+  if (a.out_ws && a.pw1_ws && split)
+    hipLaunchKernelGGL(out_glu_split_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL(out_glu_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
 }
 int launch_tail_ff2(const TailFf2Args& a, hipStream_t s) {

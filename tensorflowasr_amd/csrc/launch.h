@@ -233,6 +233,7 @@ struct OutGluArgs {
   const float *out_wp, *out_b, *cv_ln_g, *cv_ln_b, *pw1_wp, *pw1_b;
   float eps;
   int M;
+  const float *out_ws = nullptr, *pw1_ws = nullptr;   // the same kernels as split-bf16 fragments [5][NT][3][64][8] (fused.hip)
 };
 struct TailFf2Args {
   const float* dw; const float* x2; float* y;

@@ -196,6 +196,13 @@ constexpr int MELP = 8192;                         // floats of LDS for the mel 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// 16 bytes per lane, global -> LDS without a register round trip; `lds` is the wave's (uniform) base, lane i writes
+// lds + 16 i.  Completion is counted by vmcnt.
+DEV void dma16(const u32x4* gsrc, u32x4* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
 struct SplitFrag { u32x4 t[3]; };                  // 8 k-slots x 3 terms
 
 // exact three-term bf16 split of eight fp32 values (slots 0..3 = lo, 4..7 = hi), two values per dword
@@ -351,11 +358,13 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
       const int s = cb * NPAIR + pair, cur = s & 1;
       const bool more = s + 1 < NK32;
       if (more && DIAG != 3) {
+        // next slab: global -> LDS directly (global_load_lds_dwordx4: lane i of a wave lands at base + 16 i); buffer
+        // cur ^ 1 was last read in step s - 1, whose barrier every wave has passed
         const u32x4* src = wg + (size_t)(s + 1) * SLABF;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const int idx = threadIdx.x + SCT * q;
-          if (idx < SLABF) nw[q] = src[idx];
+          const int w0 = SCT * q + 64 * wv;                    // wave-uniform
+          if (w0 < SLABF) dma16(src + w0 + lane, &wl[cur ^ 1][w0]);
         }
       }
       // operand of the next step (VALU + LDS reads) and the MFMAs of this one are independent.  hipcc puts the ~270
@@ -405,13 +414,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
         __builtin_amdgcn_sched_barrier(0);
         mfma_cur();
       }
-      if (more && DIAG != 3) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int idx = threadIdx.x + SCT * q;
-          if (idx < SLABF) wl[cur ^ 1][idx] = nw[q];
-        }
-      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's part of the slab has landed
       if constexpr (DIAG != 4) __syncthreads();
     });
   }

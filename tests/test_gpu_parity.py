@@ -960,3 +960,34 @@ def test_add_wav_info_with_leaf_ctc_and_errors(torch_cuda):
     ref_r = co.conformer_encoder(xr.astype(np.float64), w, dict(cfg, mel_layer_type="leaf", add_wav_info=True))
     assert ref_r.shape[1] == 26
     assert maxdiff(m.encode(xr).cpu().numpy(), ref_r) < TOL
+
+
+def test_opt_in_kernel_variants_in_a_subprocess(torch_cuda):
+    """Kernel choices that are read from the environment once per process: the split-bf16 / LDS-slab out_glu kernel
+    (MI355ASR_OUTGLU_SPLIT=1, off by default) and the fp32-MFMA subsampling kernel (MI355ASR_SUBCONV_F32=1), with the
+    fused block path forced for a small batch (MI355ASR_SMALL_M=0).  Each must agree with the oracle like the defaults."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, maxdiff, small_cfg, waves
+from tensorflowasr_amd.models import ConformerEncoder
+cfg = small_cfg(2)
+w = co.encoder_weights(cfg, seed=3)
+e = ConformerEncoder(**encoder_kwargs(cfg)); e.load_weights(w, by_name=False)
+rng = np.random.default_rng(5)
+x = rng.standard_normal((3, 250, 144)).astype(np.float32)
+blk = maxdiff(e.conformer_block(1, x).cpu().numpy(), co.conformer_block(x.astype(np.float64), w, "conformer_block_1", 36))
+wav = waves(2, 16000, 11)
+enc = maxdiff(e(wav).cpu().numpy(), co.conformer_encoder(wav.astype(np.float64), w, cfg))
+print("RESULT %.3e %.3e" % (blk, enc))
+'''
+    for extra in ({"MI355ASR_OUTGLU_SPLIT": "1"}, {"MI355ASR_SUBCONV_F32": "1"}, {}):
+        env = dict(os.environ, MI355ASR_SMALL_M="0", **extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+        assert line, out.stderr[-2000:]
+        blk, enc = (float(v) for v in line[0].split()[1:])
+        assert blk < TOL and enc < TOL, (extra, blk, enc)
