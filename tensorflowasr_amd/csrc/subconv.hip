@@ -232,7 +232,7 @@ struct SplitLane {
 };
 
 // conv1 + ReLU (+ conv2's zero padding) at tap q for channels 16 cb + 4 g .. + 3 of row tile rt
-template <int Q>
+template <int Q, int DIAG = 0>
 DEV f32x4 conv1_at(const float* melp, int RS, const SplitLane& sl, int rt, const f32x4 (&w1r)[9], f32x4 b1v) {
   constexpr int kt = Q / 3, kf = Q % 3;
   f32x4 v = b1v;
@@ -243,7 +243,7 @@ DEV f32x4 conv1_at(const float* melp, int RS, const SplitLane& sl, int rt, const
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const float m = mp[i * RS + j];
+      const float m = DIAG == 5 ? __builtin_bit_cast(float, off + i * RS + j) : mp[i * RS + j];
       const f32x4 w = w1r[i * 3 + j];
       v.x = __builtin_fmaf(m, w.x, v.x); v.y = __builtin_fmaf(m, w.y, v.y);
       v.z = __builtin_fmaf(m, w.z, v.z); v.w = __builtin_fmaf(m, w.w, v.w);
@@ -254,19 +254,25 @@ DEV f32x4 conv1_at(const float* melp, int RS, const SplitLane& sl, int rt, const
   return v;
 }
 
-template <int PAIR>
+template <int PAIR, int DIAG = 0>
 DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitLane& sl, const f32x4 (&w1r)[9], f32x4 b1v) {
 #pragma unroll
   for (int rt = 0; rt < SRT; ++rt) {
-    const f32x4 lo = conv1_at<2 * PAIR>(melp, RS, sl, rt, w1r, b1v);
+    const f32x4 lo = conv1_at<2 * PAIR, DIAG>(melp, RS, sl, rt, w1r, b1v);
     f32x4 hi = splat4(0.f);
-    if constexpr (2 * PAIR + 1 < 9) hi = conv1_at<2 * PAIR + 1>(melp, RS, sl, rt, w1r, b1v);
-    xf[rt] = split8(lo, hi);
+    if constexpr (2 * PAIR + 1 < 9) hi = conv1_at<2 * PAIR + 1, DIAG>(melp, RS, sl, rt, w1r, b1v);
+    if constexpr (DIAG == 6) {               // no split: the raw bits as three "terms"
+      const u32x4 l = __builtin_bit_cast(u32x4, lo), h = __builtin_bit_cast(u32x4, hi);
+      xf[rt].t[0] = l; xf[rt].t[1] = h; xf[rt].t[2] = l ^ h;
+    } else {
+      xf[rt] = split8(lo, hi);
+    }
   }
 }
 
 // DIAG != 0: timing experiments only (results are wrong): 1 = no conv1 / split work, 2 = one weight-fragment read per
-// step instead of nine, 3 = no slab traffic (global -> LDS), 4 = no barrier in the step loop
+// step instead of nine, 3 = no slab traffic (global -> LDS), 4 = no barrier in the step loop, 5 = conv1 without its mel
+// reads from LDS, 6 = no operand split
 template <int DIAG>
 __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a, int RS, int rows, int late_mode) {
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][SLABF];
@@ -342,6 +348,8 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
   const bool late = late_mode == 0 ? wv >= SCW / 2
                   : late_mode == 1 ? (wv & 1) != 0
                   : late_mode == 2 ? ((wv >> 1) & 1) != 0
+                  : late_mode == 4 ? false
+                  : late_mode == 5 ? true
                                    : (__builtin_amdgcn_s_getreg(0x1804) & 1) != 0;   // HW_ID.wave_id: slot on the SIMD
   // the whole step loop once per order (compile-time LATE): with a run-time order inside one loop hipcc keeps both
   // paths' temporaries alive and spills (256 VGPRs + 232 bytes of scratch instead of 194)
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
   constexpr bool LATE = decltype(LATE_T)::value;
   if constexpr (LATE) {
     load_taps(0);
-    frags_for<0>(xa, melp, RS, sl, w1r, lds4(p_b1, 0, g4));
+    frags_for<0, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, 0, g4));
   }
 #pragma unroll 1
   for (int cb = 0; cb < KB; ++cb) {
@@ -374,15 +382,15 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
       // the opposite order: one wave's conv1 / split VALU work always faces its partner's MFMAs.
       auto frags_this = [&]() {              // early waves: the operand of this step, just before its MFMAs
         if constexpr (pair == 0) load_taps(cb);
-        frags_for<pair>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+        frags_for<pair, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
       };
       auto frags_next = [&]() {              // late waves: the operand of the next step, after this step's MFMAs
         if constexpr (pair + 1 < NPAIR) {
-          frags_for<pair + 1>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+          frags_for<pair + 1, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
         } else {
           const int cbn = min(cb + 1, KB - 1);
           load_taps(cbn);
-          frags_for<0>(xa, melp, RS, sl, w1r, lds4(p_b1, cbn, g4));
+          frags_for<0, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cbn, g4));
         }
       };
       auto mfma_cur = [&]() {
@@ -465,6 +473,8 @@ int launch_subconv144_split(const SubConvArgs& a, hipStream_t s) {
     case 2: hipLaunchKernelGGL(subconv144_split_kernel<2>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
     case 3: hipLaunchKernelGGL(subconv144_split_kernel<3>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
     case 4: hipLaunchKernelGGL(subconv144_split_kernel<4>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
+    case 5: hipLaunchKernelGGL(subconv144_split_kernel<5>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
+    case 6: hipLaunchKernelGGL(subconv144_split_kernel<6>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
     default: hipLaunchKernelGGL(subconv144_split_kernel<0>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode);
   }
   return 0;

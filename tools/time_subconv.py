@@ -26,7 +26,7 @@ if len(sys.argv) > 1:
     h.lib.mi355asr_profile_read(h.ptr, t, c, 32, 1)
     print(json.dumps({"mode": sys.argv[1], "subconv_ms": round(t[3] / max(c[3], 1), 4), "tail_ff2_ms": round(t[17] / max(c[17], 1), 4)}))
 else:
-    for mode in ("0", "diag1", "diag2", "diag3", "diag4", "f32"):
+    for mode in ("0", "4", "5", "diag1", "diag5", "diag6"):
         env = dict(os.environ)
         if mode == "f32":
             env["MI355ASR_SUBCONV_F32"] = "1"
