@@ -7,8 +7,8 @@
   weights into anonymous initializers and lowers the attention einsums to Gemm/MatMul, so the tensors are located
   *structurally* (node-name suffixes inside each block scope, and for the attention projections by following the data
   flow from the `truediv` / `Softmax` nodes), not by the export's initializer numbering.
-* Keras `.h5`: needs an HDF5 reader (h5py is not part of this image); convert with
-  `np.savez(path, **{w.name: w.numpy() for w in model.weights})` under the names of DESIGN.md section 6.
+* Keras `.h5` weight files: read with the pure-Python HDF5 reader `h5lite.py` (h5py is not available next to the system
+  interpreter of this image), variable names mapped by `keras_names_to_abi`; `keras_h5_to_abi(path)`.
 
 No onnx / protobuf package is used: the ONNX file is a protobuf whose few fields of interest are decoded here
 (onnx.proto3: ModelProto.graph = 7; GraphProto.node = 1, initializer = 5; NodeProto.input = 1, output = 2, name = 3,
@@ -360,4 +360,22 @@ def keras_names_to_abi(names):
                 ok = False
         if ok:
             out[full] = "/".join(scope + [var])
+    return out
+
+
+def keras_h5_to_abi(path):
+    """{C-ABI name: array} from a Keras `.h5` weight file of one of the reference's sub-models (`model.save_weights`,
+    `ctc_runners.py:272-325`): variables read with h5lite.keras_weights, names mapped with keras_names_to_abi.  The mel
+    layer's DFT kernels / filterbank (non-trainable variables `real_kernels`, `imag_kernels` and an unnamed `Variable`)
+    are mapped when present; everything that is not part of the inference path is dropped."""
+    from . import h5lite
+    raw = h5lite.keras_weights(path)
+    m = keras_names_to_abi(list(raw))
+    out = {m[k]: np.asarray(v, np.float32) for k, v in raw.items() if k in m}
+    for k, v in raw.items():                                  # Melspectrogram layer (time_frequency.py:62-75, 152-189)
+        leaf = k.split(":")[0].rsplit("/", 1)[-1]
+        if "mel_layer" in k and leaf in ("real_kernels", "imag_kernels"):
+            out["mel_layer/" + leaf] = np.asarray(v, np.float32)
+        elif "mel_layer" in k and leaf.startswith("Variable"):
+            out["mel_layer/freq2mel"] = np.asarray(v, np.float32)
     return out

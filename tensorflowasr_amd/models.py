@@ -172,14 +172,16 @@ class _ModelBase:
         return self
 
     def load_weights(self, weights, by_name=True, strict=None):
-        """`weights`: a dict name -> array, the path of an .npz of Keras-layout tensors, or the path of the reference's
-        tf2onnx export of the CTCDecoder (`ctc_model.onnx`; checkpoint.py).  (The reference's Keras .h5 checkpoints need
-        h5py, which is not part of this image; see INTEGRATION.md.)"""
+        """`weights`: a dict name -> array, the path of an .npz of Keras-layout tensors, the path of a Keras `.h5`
+        weight file as the reference's trainers write them (`ctc_runners.py:272-325`; read by the pure-Python HDF5 reader
+        h5lite.py, variable names mapped by checkpoint.keras_names_to_abi), or the path of the reference's tf2onnx export
+        of the CTCDecoder (`ctc_model.onnx`; checkpoint.py)."""
         if isinstance(weights, (str, os.PathLike)):
             path = str(weights)
-            if path.endswith(".h5"):
-                raise NotImplementedError("Keras .h5 checkpoints: convert to .npz first (INTEGRATION.md)")
-            if path.endswith(".onnx"):
+            if path.endswith((".h5", ".hdf5")):
+                from . import checkpoint
+                weights = checkpoint.keras_h5_to_abi(path)
+            elif path.endswith(".onnx"):
                 from . import checkpoint
                 weights = checkpoint.ctc_decoder_weights_from_onnx(path, num_heads=self.num_heads)
             else:
