@@ -37,6 +37,8 @@ def kernel_peak(name):
     if name == "subconv" and not int(os.environ.get("MI355ASR_SUBCONV_F32", "0") or 0) \
             and not int(os.environ.get("MI355ASR_SUBCONV_V1", "0") or 0):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
+    if name == "sublinear" and int(os.environ.get("MI355ASR_SUBLINEAR_SPLIT", "1") or 0):
+        return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA"
 PEAK_HBM_GBS = 8000.0
 

@@ -596,6 +596,13 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   StreamGemmArgs lg{};
   lg.x = sub; lg.y = out; lg.wp = m->lin_wp; lg.bias = m->lin_b;
   lg.M = Bp * T2; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.ldy = d; lg.n_valid = d;
+  // MI355ASR_SUBLINEAR_SPLIT: 1 (default) = split-bf16 ring-DMA kernel (fused.hip) from 4096 rows, 2 = for any row
+  // count, 0 = the fp32-MFMA stream_gemm_kernel
+  static const int lin_split = [] { const char* v = std::getenv("MI355ASR_SUBLINEAR_SPLIT"); return v ? std::atoi(v) : 1; }();
+  if (lin_split && m->lin_wsplit && (lg.M >= 4096 || lin_split == 2)) {
+    PROF(MI355ASR_K_SUBLINEAR);
+    if (launch_sublinear_split(lg, m->lin_wsplit, s) == 0) return 0;
+  }
   { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear"); }
   return 0;
 }
@@ -968,7 +975,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   const Dims& dm = m->dm;
   const int d = c.dmodel;
   ArenaBuilder ab;
-  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0;
+  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0;
   FftOff fo;
   std::vector<BlockOff> eo, co;
   size_t o_leafw = 0, o_leafs = 0, o_lg = 0, o_la = 0, o_ld = 0, o_lr = 0, o_ls = 0, o_lga = 0, o_lbe = 0;
@@ -1085,6 +1092,14 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   const auto& lin = m->host["conv_subsampling/linear/kernel"].data;
   o_lw = ab.put(pack_p16([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d, d / 16));
   o_lb = ab.put(m->host["conv_subsampling/linear/bias"].data);
+  if (d == 144) {
+    // the same kernel for sublinear_split_kernel: 1728 fragments per 32-wide step, padded to 7 x 256 (4 floats each)
+    const std::vector<float> sp = pack_split32([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d);
+    const size_t steps = (size_t)ceil_div(dm.F2 * d, 32), used = 1728 * 4, stride = 1792 * 4;
+    std::vector<float> padded(steps * stride, 0.f);
+    for (size_t st = 0; st < steps; ++st) std::memcpy(padded.data() + st * stride, sp.data() + st * used, used * sizeof(float));
+    o_lws = ab.put(padded);
+  }
   for (int i = 0; i < c.num_blocks; ++i)
     eo.push_back(pack_block(m, ab, "conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size, c.kernel_size));
   }
@@ -1144,6 +1159,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;
   m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = (d == 144 && c.has_encoder) ? base + o_c2s : nullptr;
+  m->lin_wsplit = (d == 144 && c.has_encoder) ? base + o_lws : nullptr;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
   m->leaf_wp = base + o_leafw; m->leaf_wsplit = base + o_leafs; m->leaf_gcoef = base + o_lg; m->leaf_alpha = base + o_la; m->leaf_delta = base + o_ld;

@@ -361,6 +361,88 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_split_kernel(OutGluA
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Dense(F2 d -> d) of the subsampling (K = 2880, N = 144) on the bf16 pipe with split operands: the long-K layer is where
+// a deep DMA ring works -- per 32-wide step a workgroup (4 waves x 16 rows) needs a 27 KB weight slab and its own
+// 64 x 32 tile of x; both are fetched by global_load_lds_dwordx4 into a ring of RING buffers, RING - 1 steps ahead, so
+// that the ~1-2 us of DMA latency is covered by several steps of MFMAs (one step = 54 MFMAs = 0.4 us; the out_glu
+// experiment above had a single step of cover).  Every thread issues exactly SL_DMA DMAs per step (the slab is padded to
+// 7 x 256 fragments), so "slab s + 1 has landed" is the counted wait vmcnt((RING - 2) * SL_DMA).
+//   x tile in LDS: 16-byte slot (chunk, row) at chunk * 64 + row -- the 16 lanes of a row tile read consecutive slots.
+constexpr int SL_RING = 4;
+constexpr int SL_WFR = 7 * BLOCK_THREADS;            // weight fragments per slab (1728 used)
+constexpr int SL_XFR = 2 * BLOCK_THREADS;            // x slots per slab: 64 rows x 8 chunks of 16 bytes
+constexpr int SL_DMA = 9;                            // DMA instructions per thread and step
+constexpr int SL_SLOT = SL_WFR + SL_XFR;             // fragments per ring slot (36 KB)
+
+__global__ __launch_bounds__(BLOCK_THREADS, 1) void sublinear_split_kernel(StreamGemmArgs a, const u32x4_t* __restrict__ ws) {
+  // four separate LDS objects and a step loop unrolled by four (static slot per step): with one ring[4][..] array the
+  // compiler cannot tell a ds_read of slot s from the pending DMA writes to the other slots and waits vmcnt(0) before it
+  __shared__ __attribute__((aligned(16))) u32x4_t ring0[SL_SLOT], ring1[SL_SLOT], ring2[SL_SLOT], ring3[SL_SLOT];
+  __shared__ __attribute__((aligned(16))) float p_b[D];
+  static_assert(SL_RING == 4, "four ring slots");
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int row0 = blockIdx.x * 64;
+  const int steps = a.K / 32;
+  // this thread's two x chunks per step: slot p = tid + 256 q -> (chunk = p / 64, row = p % 64)
+  const float* xsrc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int p = threadIdx.x + BLOCK_THREADS * q;
+    const int row = min(row0 + (p & 63), a.M - 1);
+    xsrc[q] = a.x + (size_t)row * a.K + 4 * (p >> 6);
+  }
+  auto fill = [&](int s, u32x4_t* slot) {             // slab of step s -> ring slot
+    const u32x4_t* wsrc = ws + (size_t)s * SL_WFR;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) dma16(wsrc + BLOCK_THREADS * q + 64 * wv + lane, slot + BLOCK_THREADS * q + 64 * wv);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      dma16(reinterpret_cast<const u32x4_t*>(xsrc[q] + 32 * s), slot + SL_WFR + BLOCK_THREADS * q + 64 * wv);
+  };
+  fill(0, ring0);
+  fill(min(1, steps - 1), ring1);
+  fill(min(2, steps - 1), ring2);
+  for (int i = threadIdx.x; i < D; i += BLOCK_THREADS) p_b[i] = a.bias[i];
+  f32x4 acc[KB];
+  constexpr int kWait = 0x0f70 | (((SL_RING - 2) * SL_DMA) & 15) | ((((SL_RING - 2) * SL_DMA) >> 4) << 14);
+  __builtin_amdgcn_s_waitcnt(kWait);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < KB; ++i) acc[i] = lds4(p_b, i, 4 * g);
+  // one step: refill the slot read in the previous step with the slab RING - 1 steps ahead (past the end the last slab
+  // again, so that every step issues SL_DMA DMAs and the counted wait stays valid), then the MFMAs of this slot
+  auto step = [&](int s, const u32x4_t* cur, u32x4_t* refill) {
+    fill(min(s + SL_RING - 1, steps - 1), refill);
+    const f32x4 lo = __builtin_bit_cast(f32x4, cur[SL_WFR + g * 64 + 16 * wv + c]);
+    const f32x4 hi = __builtin_bit_cast(f32x4, cur[SL_WFR + (4 + g) * 64 + 16 * wv + c]);
+    const Split8 xf = split8(lo, hi);
+    split_step<KB>(acc, xf, cur, lane);
+    // slab s + 1 has landed (counted: the two slabs issued after it may still be in flight); a bare s_barrier -- the
+    // fence of __syncthreads() would wait for every outstanding DMA
+    __builtin_amdgcn_s_waitcnt(kWait & ~0x0f00);          // + lgkmcnt(0): this wave's LDS reads of the slot are done
+    __builtin_amdgcn_s_barrier();
+  };
+  int s = 0;
+#pragma unroll 1
+  for (; s + 4 <= steps; s += 4) {
+    step(s, ring0, ring3);
+    step(s + 1, ring1, ring0);
+    step(s + 2, ring2, ring1);
+    step(s + 3, ring3, ring2);
+  }
+  if (s < steps) step(s++, ring0, ring3);
+  if (s < steps) step(s++, ring1, ring0);
+  if (s < steps) step(s++, ring2, ring1);
+  const int tok = row0 + 16 * wv + c;
+  if (tok < a.M) {
+    float* yrow = a.y + (size_t)tok * a.ldy;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(yrow + 16 * i + 4 * g, acc[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void tail_ff2_kernel(TailFf2Args a) {
   __shared__ __attribute__((aligned(16))) float p_pcb[2 * D], p_bns[2 * D], p_bnt[2 * D], p_pw2b[D], p_lng[D], p_lnb[D], p_b1[4 * D],
       p_b2[D], p_fg[D], p_fb[D];
@@ -419,6 +501,13 @@ int launch_out_glu(const OutGluArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(out_glu_split_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   else
     hipLaunchKernelGGL(out_glu_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
+  return 0;
+}
+// split-bf16 ring-DMA kernel for the subsampling Dense; ws = pack_split32 fragments padded to 1792 per step
+int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s) {
+  if (a.NT != KB || a.K % 32 != 0 || a.M <= 0 || !ws) return -1;
+  hipLaunchKernelGGL(sublinear_split_kernel, dim3((a.M + 63) / 64), dim3(BLOCK_THREADS), 0, s, a,
+                     reinterpret_cast<const u32x4_t*>(ws));
   return 0;
 }
 int launch_tail_ff2(const TailFf2Args& a, hipStream_t s) {
