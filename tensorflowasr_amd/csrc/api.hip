@@ -112,6 +112,23 @@ std::vector<float> pack_split32(const std::function<float(int, int)>& f, int K, 
 }
 
 
+// Appends the slabs of W (pack_split32 order) to a slab stream: one slab = 9 column tiles of one 32-wide step = 1728
+// fragments of 16 bytes, padded to 1792 (SlabStream in fused.hip).  group_major: all steps of tile group 0, then of
+// group 1, ... (the order a GEMM swept in column chunks consumes them); else step by step, its groups side by side.
+void append_slabs(std::vector<float>& stream, const std::function<float(int, int)>& f, int K, int N, bool group_major) {
+  const std::vector<float> sp = pack_split32(f, K, N);
+  const int steps = ceil_div(K, 32), NT = N / 16, groups = NT / 9;
+  const size_t used = 1728 * 4, stride = 1792 * 4;
+  auto put = [&](int st, int gr) {
+    const size_t at = stream.size();
+    stream.resize(at + stride, 0.f);
+    std::memcpy(stream.data() + at, sp.data() + ((size_t)st * NT + 9 * gr) * 192 * 4, used * sizeof(float));
+  };
+  if (group_major) { for (int gr = 0; gr < groups; ++gr) for (int st = 0; st < steps; ++st) put(st, gr); }
+  else { for (int st = 0; st < steps; ++st) for (int gr = 0; gr < groups; ++gr) put(st, gr); }
+}
+
+
 // The DFT kernels are model variables (time_frequency.py:62-75 creates them from backend.py:27-69 and a checkpoint
 // may overwrite them).  When they are exactly window[n] * (cos, -+sin)(2 pi k n / 1024) the STFT runs as a
 // 32 x 32 Cooley-Tukey factorisation (fft_stft.hip); otherwise the dense DFT GEMM stays.  MI355ASR_FFT=0 forces dense.
@@ -218,7 +235,15 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   o.cv_ln_b = ab.put(T(c + "/ln/beta"));
   const auto& pw1 = T(c + "/pw_conv_1/kernel");
   o.pw1_wp = ab.put(pack_p16([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d, 2 * d / 16));
-  if (o.split) o.pw1_ws = ab.put(pack_split32([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d));
+  if (o.split) {
+    o.pw1_ws = ab.put(pack_split32([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d));
+    // slab stream of out_glu_ring_kernel: out-projection (5 slabs), then pw_conv_1 step by step (value | gate)
+    const auto& pk2 = keras_mha ? T(a + "/mha/attention_output/kernel") : T(a + "/mha/projection_kernel");
+    std::vector<float> st;
+    append_slabs(st, [&](int kk, int n) { return pk2[(size_t)kk * d + n]; }, d, d, false);
+    append_slabs(st, [&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d, false);
+    o.og_slabs = ab.put(st);
+  }
   o.pw1_b = ab.put(T(c + "/pw_conv_1/bias"));
   o.dw_w = ab.put(T(c + "/dw_conv/depthwise_kernel"));  // [k, d, 1] == [k][d]
   const auto& pc = T(c + "/dw_conv/pointwise_kernel");
@@ -261,7 +286,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
-  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; }
+  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; }
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
   b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
@@ -440,7 +465,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k2.ctx = sc.ctx; k2.x1 = sc.xb; k2.x2 = sc.xa; k2.u = sc.u;
     k2.out_wp = w.out_wp; k2.out_b = w.out_b; k2.cv_ln_g = w.cv_ln_g; k2.cv_ln_b = w.cv_ln_b;
     k2.pw1_wp = w.pw1_wp; k2.pw1_b = w.pw1_b; k2.eps = kLnEps; k2.M = M;
-    k2.out_ws = w.out_ws; k2.pw1_ws = w.pw1_ws;
+    k2.out_ws = w.out_ws; k2.pw1_ws = w.pw1_ws; k2.og_slabs = w.og_slabs;
     { PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU"); }
     DwArgs dwa{};
     dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;

@@ -259,6 +259,133 @@ DEV void dma16(const u32x4_t* gsrc, u32x4_t* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+constexpr int KS32X = 5;                      // 32-wide steps over K = 144
+
+// ---- slab ring: weights as a linear stream of 28 KB slabs (9 column tiles x 3 terms x 64 lanes, padded to 7 x 256
+// fragments so that every thread issues exactly 7 DMAs per slab), fetched three slabs ahead into a ring of four LDS
+// slots by global_load_lds_dwordx4.  "Slab s + 1 has landed" is the counted wait vmcnt(14) -- valid as long as the
+// slab DMAs are the only vector-memory operations in flight (inputs are loaded before the stream starts, outputs are
+// stored after it ends).  The fragment reads are inline asm: the compiler would otherwise put vmcnt(0) in front of
+// every LDS read that may alias a pending DMA (it tracks LDS-DMA per LDS object; a ring indexed at run time is one
+// object), and the fence of __syncthreads() waits for all DMAs too -- hence also the bare s_barrier.
+constexpr int SLB = 7 * BLOCK_THREADS;
+struct SlabStream {
+  u32x4_t* ring;              // LDS, 4 x SLB fragments
+  const u32x4_t* src;         // global slab stream
+  int total, s, wv, lane;
+  DEV void issue(int slab) const {
+    const u32x4_t* g = src + (size_t)min(slab, total - 1) * SLB + 64 * wv + lane;
+    u32x4_t* l = ring + (slab & 3) * SLB + 64 * wv;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) dma16(g + BLOCK_THREADS * q, l + BLOCK_THREADS * q);
+  }
+  DEV void begin() { s = 0; issue(0); issue(1); issue(2); }
+  DEV void prefetch() const { issue(s + 3); }            // into the slot read in step s - 1
+  DEV unsigned cur_addr() const {                        // LDS byte address of this lane's first fragment of slab s
+    return (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ring + (s & 3) * SLB + lane);
+  }
+  DEV void advance() {
+    __builtin_amdgcn_s_waitcnt(0x007e);                  // vmcnt(14) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    ++s;
+  }
+};
+
+template <int OFF>
+DEV u32x4_t lds_read16(unsigned addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+// acc[0..9) += W(slab)^T x: column tiles in groups of three, the fragments of the next group are requested before the
+// 18 MFMAs of the current one (LDS returns in order: lgkmcnt(9) = "everything but the nine newest reads")
+DEV void slab_step(f32x4* acc, const Split8& xf, unsigned addr) {
+  u32x4_t w0[3][3], w1[3][3], w2[3][3];
+#define SLAB_FETCH(W, GRP) \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) { \
+    W[i][0] = lds_read16<((3 * GRP + 0) * 3 + 0) * 1024>(addr + i * 3 * 1024); \
+    W[i][1] = lds_read16<((3 * GRP + 0) * 3 + 1) * 1024>(addr + i * 3 * 1024); \
+    W[i][2] = lds_read16<((3 * GRP + 0) * 3 + 2) * 1024>(addr + i * 3 * 1024); }
+#define SLAB_WAIT(W, N) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(W[0][0]), "+v"(W[0][1]), "+v"(W[0][2]), "+v"(W[1][0]), "+v"(W[1][1]), \
+               "+v"(W[1][2]), "+v"(W[2][0]), "+v"(W[2][1]), "+v"(W[2][2]))
+#define SLAB_MMA(W, GRP) \
+  _Pragma("unroll") for (int ord = 2; ord >= 0; --ord) \
+    _Pragma("unroll") for (int p = 0; p <= ord; ++p) \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) \
+        acc[3 * GRP + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, W[i][ord - p]), \
+                                                                   __builtin_bit_cast(bf16x8_t, xf.t[p]), acc[3 * GRP + i], 0, 0, 0);
+  SLAB_FETCH(w0, 0)
+  SLAB_FETCH(w1, 1)
+  SLAB_WAIT(w0, 9);
+  SLAB_MMA(w0, 0)
+  SLAB_FETCH(w2, 2)
+  SLAB_WAIT(w1, 9);
+  SLAB_MMA(w1, 1)
+  SLAB_WAIT(w2, 0);
+  SLAB_MMA(w2, 2)
+#undef SLAB_FETCH
+#undef SLAB_WAIT
+#undef SLAB_MMA
+}
+
+// out_glu on the slab ring: 5 slabs of the out-projection, then per 32-wide step of pw_conv_1 one slab of value tiles
+// and one of gate tiles (15 slabs).  Inputs are loaded before the stream starts; x2 and u are stored after it ends.
+__global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_ring_kernel(OutGluArgs a) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[4 * SLB];
+  __shared__ __attribute__((aligned(16))) float p_ob[D], p_lng[D], p_lnb[D], p_pb[2 * D];
+  const WaveCtx c = wave_ctx(a.M);
+  SlabStream st{ring, reinterpret_cast<const u32x4_t*>(a.og_slabs), 15, 0,
+                __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
+  st.begin();
+  f32x4 xs[KB + 1], acc[2 * KB], x2[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + c.row + 16 * kb + c.g4);
+  xs[KB] = splat4(0.f);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) acc[kb] = ldg4(a.x1 + c.row + 16 * kb + c.g4);    // residual rides in the accumulator
+  stash(p_ob, a.out_b, D); stash(p_lng, a.cv_ln_g, D); stash(p_lnb, a.cv_ln_b, D); stash(p_pb, a.pw1_b, 2 * D);
+  __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): inputs, parameters and the first three slabs
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < KB; ++i) acc[i] += lds4(p_ob, i, c.g4);
+  static_for<0, KS32X>([&](auto T) {
+    constexpr int t = decltype(T)::value;
+    st.prefetch();
+    const Split8 xf = split8(xs[2 * t], xs[2 * t + 1]);
+    slab_step(acc, xf, st.cur_addr());
+    st.advance();
+  });
+#pragma unroll
+  for (int i = 0; i < KB; ++i) { x2[i] = acc[i]; xs[i] = acc[i]; }                  // x2 = x1 + attention
+  {
+    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
+    ln_lds(xr, p_lng, p_lnb, c.g4, a.eps);
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * KB; ++i) acc[i] = lds4(p_pb, i, c.g4);                   // value tiles 0..8, gate tiles 9..17
+  static_for<0, KS32X>([&](auto T) {
+    constexpr int t = decltype(T)::value;
+    const Split8 xf = split8(xs[2 * t], xs[2 * t + 1]);
+    st.prefetch();
+    slab_step(acc, xf, st.cur_addr());
+    st.advance();
+    st.prefetch();
+    slab_step(acc + KB, xf, st.cur_addr());
+    st.advance();
+  });
+  if (c.live) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      stg4(a.x2 + c.row + 16 * i + c.g4, x2[i]);
+      const f32x4 va = acc[i], vb = acc[KB + i];
+      f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
+      stg4(a.u + c.row + 16 * i + c.g4, o);
+    }
+  }
+}
+
 constexpr int KS32 = 5;                       // 32-wide steps over K = 144 (the last half step is zero)
 constexpr int OG_SLAB = 2 * KB * 3 * 64;      // fragments of the larger slab (18 tiles)
 
@@ -492,12 +619,13 @@ int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
 }
 int launch_out_glu(const OutGluArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
-  // MI355ASR_OUTGLU_SPLIT=1: the split-bf16 / LDS-slab kernel instead of the fp32-MFMA register-stream one.  Off by
-  // default: with one row tile per wave (16 000 tokens) a slab's MFMAs last 0.4-0.8 us, less than the latency of the
-  // DMA that fetches the next one, and LDS cannot hold the ~140 KB in flight that would cover it -- measured 28.1 us
-  // against 26.4 us.  It pays once a wave owns several row tiles (B >= 256).
-  static const bool split = [] { const char* v = getenv("MI355ASR_OUTGLU_SPLIT"); return v && atoi(v) != 0; }();
-  if (a.out_ws && a.pw1_ws && split)
+  // MI355ASR_OUTGLU_SPLIT: 0 = the fp32-MFMA register-stream kernel (26.6 us at 16 000 tokens); 1 = split-bf16 with
+  // double-buffered LDS slabs (28.4 us: a slab's MFMAs last 0.4-0.8 us, less than the latency of the one DMA in flight);
+  // 2 (default) = the same on the four-slot slab ring, three slabs of DMA in flight (23.3 us)
+  static const int split = [] { const char* v = getenv("MI355ASR_OUTGLU_SPLIT"); return v ? atoi(v) : 2; }();
+  if (a.og_slabs && split == 2)
+    hipLaunchKernelGGL(out_glu_ring_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
+  else if (a.out_ws && a.pw1_ws && split == 1)
     hipLaunchKernelGGL(out_glu_split_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   else
     hipLaunchKernelGGL(out_glu_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);

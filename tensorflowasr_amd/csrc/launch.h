@@ -234,6 +234,7 @@ struct OutGluArgs {
   float eps;
   int M;
   const float *out_ws = nullptr, *pw1_ws = nullptr;   // the same kernels as split-bf16 fragments [5][NT][3][64][8] (fused.hip)
+  const float* og_slabs = nullptr;                     // ... and as the slab stream of out_glu_ring_kernel (15 slabs of 1792 fragments)
 };
 struct TailFf2Args {
   const float* dw; const float* x2; float* y;

@@ -61,7 +61,7 @@ struct BlockDev {
   // block-final LayerNorm
   const float *ln_g, *ln_b;
   // out-projection / pw_conv_1 kernels as split-bf16 fragments (dmodel 144, Keras-layout MHA; fused.hip), or null
-  const float *out_ws = nullptr, *pw1_ws = nullptr;
+  const float *out_ws = nullptr, *pw1_ws = nullptr, *og_slabs = nullptr;
 };
 
 struct Dims {
@@ -190,7 +190,7 @@ struct BlockOff {
   bool cross = false;
   size_t cv_ln_g, cv_ln_b, pw1_wp, pw1_b, dw_w, pc_w1p, pc_b1, bn_s, bn_t, pw2_wp, pw2_b;
   size_t ln_g, ln_b;
-  size_t out_ws = 0, pw1_ws = 0;
+  size_t out_ws = 0, pw1_ws = 0, og_slabs = 0;
   bool split = false;
 };
 
@@ -228,6 +228,7 @@ void same_pad(int n, int k, int s, int* out, int* before);
 void add_block_expected(std::vector<Expected>& ex, const std::string& p, int d, int H, int hs, int k, bool keras_mha = false);
 std::vector<float> pack_p16(const std::function<float(int, int)>& f, int K, int N, int NTpad);
 std::vector<float> pack_split32(const std::function<float(int, int)>& f, int K, int N);
+void append_slabs(std::vector<float>& stream, const std::function<float(int, int)>& f, int K, int N, bool group_major);
 FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vector<float>& im, int n_dft, int nb);
 BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k, bool keras_mha = false);
 BlockDev resolve(const BlockOff& o, const float* base);

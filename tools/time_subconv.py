@@ -24,15 +24,15 @@ if len(sys.argv) > 1:
     t = (ctypes.c_double * 32)()
     c = (ctypes.c_int64 * 32)()
     h.lib.mi355asr_profile_read(h.ptr, t, c, 32, 1)
-    print(json.dumps({"mode": sys.argv[1], "subconv_ms": round(t[3] / max(c[3], 1), 4), "sublinear_ms": round(t[4] / max(c[4], 1), 4),
+    print(json.dumps({"mode": sys.argv[1], "subconv_ms": round(t[3] / max(c[3], 1), 4), "sublinear_ms": round(t[4] / max(c[4], 1), 4), "out_glu_ms": round(t[16] / max(c[16], 1), 4), "ff1_qkv_ms": round(t[15] / max(c[15], 1), 4),
                       "tail_ff2_ms": round(t[17] / max(c[17], 1), 4)}))
 else:
-    for mode in ("0", "linsplit"):
+    for mode in ("0", "og1", "og2"):
         env = dict(os.environ)
         if mode == "f32":
             env["MI355ASR_SUBCONV_F32"] = "1"
-        elif mode == "linsplit":
-            env["MI355ASR_SUBLINEAR_SPLIT"] = "1"
+        elif mode.startswith("og"):
+            env["MI355ASR_OUTGLU_SPLIT"] = mode[2:]
         elif mode.startswith("diag"):
             env["MI355ASR_SUBCONV_DIAG"] = mode[4:]
         else:
