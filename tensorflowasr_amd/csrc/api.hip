@@ -228,7 +228,24 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   const auto& pk = T(a + "/mha/projection_kernel");  // [H, hs, d]: row k = h*hs + i
   o.out_wp = ab.put(pack_p16([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d, d / 16));
   o.out_b = ab.put(T(a + "/mha/projection_bias"));
-  if (d == 144) { o.out_ws = ab.put(pack_split32([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d)); o.split = true; }
+  if (d == 144) {
+    o.out_ws = ab.put(pack_split32([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d)); o.split = true;
+    // slab stream of ff1_qkv_ring_kernel: per hidden chunk of 144 the five steps of W1[:, chunk] and of W2[chunk, :],
+    // then q, k, v (five steps each)
+    const auto& f1 = T(p + "/ff_module_1/ffn1/kernel");
+    const auto& f2 = T(p + "/ff_module_1/ffn2/kernel");
+    std::vector<float> st;
+    for (int ch = 0; ch < 4; ++ch) {
+      append_slabs(st, [&](int kk, int n) { return f1[(size_t)kk * 4 * d + d * ch + n]; }, d, d, false);
+      append_slabs(st, [&](int kk, int n) { return f2[(size_t)(d * ch + kk) * d + n]; }, d, d, false);
+    }
+    append_slabs(st, [&](int i, int n) {
+      const int which = n / d, r = n % d, h = r / hs, oo = r % hs;
+      const std::vector<float>& w = which == 0 ? qk : (which == 1 ? kk_ : vk);
+      return w[((size_t)h * d + i) * hs + oo];
+    }, d, 3 * d, true);
+    o.ff1_slabs = ab.put(st);
+  }
   }
   const std::string c = p + "/conv_module";
   o.cv_ln_g = ab.put(T(c + "/ln/gamma"));
@@ -262,6 +279,22 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   }
   const auto& pw2 = T(c + "/pw_conv_2/kernel");
   o.pw2_wp = ab.put(pack_p16([&](int kk, int n) { return pw2[(size_t)kk * d + n]; }, 2 * d, d, d / 16));
+  if (o.split) {
+    // slab stream of tail_ff2_ring_kernel: per hidden chunk of 144 the five steps of W1[:, chunk] and of W2[chunk, :]
+    // for the conv tail (pointwise 144 -> 288, pw_conv_2 288 -> 144), then for FFModule 2 (144 -> 576 -> 144)
+    const auto& f1 = T(p + "/ff_module_2/ffn1/kernel");
+    const auto& f2 = T(p + "/ff_module_2/ffn2/kernel");
+    std::vector<float> st;
+    for (int ch = 0; ch < 2; ++ch) {
+      append_slabs(st, [&](int kk, int n) { return pc[(size_t)kk * 2 * d + d * ch + n]; }, d, d, false);
+      append_slabs(st, [&](int kk, int n) { return pw2[(size_t)(d * ch + kk) * d + n]; }, d, d, false);
+    }
+    for (int ch = 0; ch < 4; ++ch) {
+      append_slabs(st, [&](int kk, int n) { return f1[(size_t)kk * 4 * d + d * ch + n]; }, d, d, false);
+      append_slabs(st, [&](int kk, int n) { return f2[(size_t)(d * ch + kk) * d + n]; }, d, d, false);
+    }
+    o.tail_slabs = ab.put(st);
+  }
   o.pw2_b = ab.put(T(c + "/pw_conv_2/bias"));
   o.ln_g = ab.put(T(p + "/ln/gamma"));
   o.ln_b = ab.put(T(p + "/ln/beta"));
@@ -286,7 +319,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
-  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; }
+  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; }
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
   b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
@@ -454,7 +487,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k1.ff_ln_g = w.ff_ln_g[0]; k1.ff_ln_b = w.ff_ln_b[0]; k1.ff_w1p = w.ff_w1p[0]; k1.ff_b1 = w.ff_b1[0];
     k1.ff_w2p = w.ff_w2p[0]; k1.ff_b2 = w.ff_b2[0];
     k1.att_ln_g = w.att_ln_g; k1.att_ln_b = w.att_ln_b; k1.qkv_wp = w.qkv_wp; k1.qkv_b = w.qkv_b;
-    k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M;
+    k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M; k1.slabs = w.ff1_slabs;
     { PROF(MI355ASR_K_FF1_QKV); LAUNCH_TRY(launch_ff1_qkv(k1, s), "ff_module_1 + qkv"); }
     AttnArgs at{};
     at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ctx = sc.ctx;
@@ -476,7 +509,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k4.pc_w1p = w.pc_w1p; k4.pc_b1 = w.pc_b1; k4.bn_s = w.bn_s; k4.bn_t = w.bn_t; k4.pw2_wp = w.pw2_wp; k4.pw2_b = w.pw2_b;
     k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];
     k4.ff_w2p = w.ff_w2p[1]; k4.ff_b2 = w.ff_b2[1]; k4.ln_g = w.ln_g; k4.ln_b = w.ln_b;
-    k4.fc = fc; k4.eps = kLnEps; k4.M = M;
+    k4.fc = fc; k4.eps = kLnEps; k4.M = M; k4.slabs = w.tail_slabs;
     { PROF(MI355ASR_K_TAIL_FF2); LAUNCH_TRY(launch_tail_ff2(k4, s), "conv tail + ff_module_2"); }
     if (!out) std::swap(sc.xa, sc.xb);
     return 0;

@@ -269,25 +269,33 @@ constexpr int KS32X = 5;                      // 32-wide steps over K = 144
 // every LDS read that may alias a pending DMA (it tracks LDS-DMA per LDS object; a ring indexed at run time is one
 // object), and the fence of __syncthreads() waits for all DMAs too -- hence also the bare s_barrier.
 constexpr int SLB = 7 * BLOCK_THREADS;
+template <int RING>
 struct SlabStream {
-  u32x4_t* ring;              // LDS, 4 x SLB fragments
+  u32x4_t* ring;              // LDS, RING x SLB fragments
   const u32x4_t* src;         // global slab stream
-  int total, s, wv, lane;
-  DEV void issue(int slab) const {
+  int total, wv, lane;
+  int s = 0, rd = 0;          // slabs consumed; ring slot of slab s (the slot before it is the one to refill)
+  DEV void issue(int slab, int slot) const {
     const u32x4_t* g = src + (size_t)min(slab, total - 1) * SLB + 64 * wv + lane;
-    u32x4_t* l = ring + (slab & 3) * SLB + 64 * wv;
+    u32x4_t* l = ring + slot * SLB + 64 * wv;
 #pragma unroll
     for (int q = 0; q < 7; ++q) dma16(g + BLOCK_THREADS * q, l + BLOCK_THREADS * q);
   }
-  DEV void begin() { s = 0; issue(0); issue(1); issue(2); }
-  DEV void prefetch() const { issue(s + 3); }            // into the slot read in step s - 1
+  DEV void begin() {
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) issue(i, i);
+  }
+  DEV void prefetch() const { issue(s + RING - 1, rd == 0 ? RING - 1 : rd - 1); }   // into the slot read in step s - 1
   DEV unsigned cur_addr() const {                        // LDS byte address of this lane's first fragment of slab s
-    return (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ring + (s & 3) * SLB + lane);
+    return (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ring + rd * SLB + lane);
   }
   DEV void advance() {
-    __builtin_amdgcn_s_waitcnt(0x007e);                  // vmcnt(14) lgkmcnt(0)
+    // slab s + 1 has landed: the RING - 2 slabs issued after it (7 DMAs each) may still be in flight; lgkmcnt(0)
+    constexpr int n = 7 * (RING - 2);
+    __builtin_amdgcn_s_waitcnt(0x0070 | (n & 15) | ((n >> 4) << 14));
     __builtin_amdgcn_s_barrier();
     ++s;
+    rd = rd + 1 == RING ? 0 : rd + 1;
   }
 };
 
@@ -301,7 +309,7 @@ DEV u32x4_t lds_read16(unsigned addr) {
 // acc[0..9) += W(slab)^T x: column tiles in groups of three, the fragments of the next group are requested before the
 // 18 MFMAs of the current one (LDS returns in order: lgkmcnt(9) = "everything but the nine newest reads")
 DEV void slab_step(f32x4* acc, const Split8& xf, unsigned addr) {
-  u32x4_t w0[3][3], w1[3][3], w2[3][3];
+  u32x4_t w0[3][3], w1[3][3];
 #define SLAB_FETCH(W, GRP) \
   _Pragma("unroll") for (int i = 0; i < 3; ++i) { \
     W[i][0] = lds_read16<((3 * GRP + 0) * 3 + 0) * 1024>(addr + i * 3 * 1024); \
@@ -320,14 +328,174 @@ DEV void slab_step(f32x4* acc, const Split8& xf, unsigned addr) {
   SLAB_FETCH(w1, 1)
   SLAB_WAIT(w0, 9);
   SLAB_MMA(w0, 0)
-  SLAB_FETCH(w2, 2)
+  SLAB_FETCH(w0, 2)
   SLAB_WAIT(w1, 9);
   SLAB_MMA(w1, 1)
-  SLAB_WAIT(w2, 0);
-  SLAB_MMA(w2, 2)
+  SLAB_WAIT(w0, 0);
+  SLAB_MMA(w0, 2)
 #undef SLAB_FETCH
 #undef SLAB_WAIT
 #undef SLAB_MMA
+}
+
+// ff1_qkv on the slab ring (five slots: 150 KB of LDS with the parameter stash).  Slab order: for each of the four
+// hidden chunks (9 tiles) the 5 steps of W1 for that chunk, then the 5 steps of W2 over the chunk's 144 hidden features;
+// then q, k, v (5 steps each): 55 slabs.  LN(x0) is split once and reused by the four chunks.
+__global__ __launch_bounds__(BLOCK_THREADS, 1) void ff1_qkv_ring_kernel(Ff1QkvArgs a) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
+  __shared__ __attribute__((aligned(16))) float p_ln1g[D], p_ln1b[D], p_b1[4 * D], p_b2[D], p_ln2g[D], p_ln2b[D], p_qb[3 * D];
+  const WaveCtx c = wave_ctx(a.M);
+  SlabStream<5> st{ring, reinterpret_cast<const u32x4_t*>(a.slabs), 55,
+                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
+  st.begin();
+  f32x4 xs[KB + 1], y[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + c.row + 16 * kb + c.g4);
+  xs[KB] = splat4(0.f);
+  stash(p_ln1g, a.ff_ln_g, D); stash(p_ln1b, a.ff_ln_b, D); stash(p_b1, a.ff_b1, 4 * D); stash(p_b2, a.ff_b2, D);
+  stash(p_ln2g, a.att_ln_g, D); stash(p_ln2b, a.att_ln_b, D); stash(p_qb, a.qkv_b, 3 * D);
+  __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): inputs, parameters and the first four slabs
+  __syncthreads();
+  const float inv_fc = 1.0f / a.fc;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) y[kb] = lds4(p_b2, kb, c.g4) + splat4(inv_fc) * xs[kb];
+  {
+    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
+    ln_lds(xr, p_ln1g, p_ln1b, c.g4, a.eps);
+  }
+  Split8 xf[KS32X];
+#pragma unroll
+  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
+#pragma unroll 1
+  for (int ch = 0; ch < 4; ++ch) {
+    f32x4 h[KB + 1];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) h[i] = lds4(p_b1, ch * KB + i, c.g4);
+    h[KB] = splat4(0.f);
+    static_for<0, KS32X>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      st.prefetch();
+      slab_step(h, xf[t], st.cur_addr());
+      st.advance();
+    });
+#pragma unroll
+    for (int i = 0; i < KB; ++i) h[i] = swish4(h[i]);
+    static_for<0, KS32X>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      st.prefetch();
+      const Split8 hf = split8(h[2 * t], h[2 * t + 1]);
+      slab_step(y, hf, st.cur_addr());
+      st.advance();
+    });
+  }
+  f32x4 x1[KB];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) { x1[i] = splat4(a.fc) * y[i]; xs[i] = x1[i]; }     // x1 = x0 + fc * (ffn + b2)
+  {
+    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
+    ln_lds(xr, p_ln2g, p_ln2b, c.g4, a.eps);
+  }
+#pragma unroll
+  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
+  f32x4 acc[3 * KB];
+#pragma unroll
+  for (int i = 0; i < 3 * KB; ++i) acc[i] = lds4(p_qb, i, c.g4);
+  static_for<0, 3>([&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    static_for<0, KS32X>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      st.prefetch();
+      slab_step(acc + q * KB, xf[t], st.cur_addr());
+      st.advance();
+    });
+  });
+  if (c.live) {
+    float* qrow = a.qkv + (size_t)c.tok * (3 * D);
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      stg4(a.x1 + c.row + 16 * i + c.g4, x1[i]);
+      stg4(qrow + 16 * i + c.g4, acc[i] * splat4(a.qscale));
+      stg4(qrow + 16 * (KB + i) + c.g4, acc[KB + i]);
+      stg4(qrow + 16 * (2 * KB + i) + c.g4, acc[2 * KB + i]);
+    }
+  }
+}
+
+// tail_ff2 on the slab ring: conv-module tail (two hidden chunks of pointwise + BN + swish + pw_conv_2), FFModule 2
+// (four hidden chunks) -- 60 slabs -- and the block-final LayerNorm.
+__global__ __launch_bounds__(BLOCK_THREADS, 1) void tail_ff2_ring_kernel(TailFf2Args a) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
+  __shared__ __attribute__((aligned(16))) float p_pcb[2 * D], p_bns[2 * D], p_bnt[2 * D], p_pw2b[D], p_lng[D], p_lnb[D], p_b1[4 * D],
+      p_b2[D], p_fg[D], p_fb[D];
+  const WaveCtx c = wave_ctx(a.M);
+  SlabStream<5> st{ring, reinterpret_cast<const u32x4_t*>(a.slabs), 60,
+                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
+  st.begin();
+  f32x4 xs[KB + 1], y[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
+  xs[KB] = splat4(0.f);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + c.row + 16 * kb + c.g4);     // residuals ride in the accumulators
+  stash(p_pcb, a.pc_b1, 2 * D); stash(p_bns, a.bn_s, 2 * D); stash(p_bnt, a.bn_t, 2 * D); stash(p_pw2b, a.pw2_b, D);
+  stash(p_lng, a.ff_ln_g, D); stash(p_lnb, a.ff_ln_b, D); stash(p_b1, a.ff_b1, 4 * D); stash(p_b2, a.ff_b2, D);
+  stash(p_fg, a.ln_g, D); stash(p_fb, a.ln_b, D);
+  __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): inputs, parameters and the first four slabs
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < KB; ++i) y[i] += lds4(p_pw2b, i, c.g4);
+  Split8 xf[KS32X];
+#pragma unroll
+  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
+  // y += W2 act(W1 x + b1) over NCH hidden chunks of 9 tiles; AFF: act = swish(s (.) + t) (folded BatchNorm)
+  auto chain = [&](int nch, const float* b1, const float* as, const float* at, bool aff) {
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+      f32x4 h[KB + 1];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) h[i] = lds4(b1, ch * KB + i, c.g4);
+      h[KB] = splat4(0.f);
+      static_for<0, KS32X>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        st.prefetch();
+        slab_step(h, xf[t], st.cur_addr());
+        st.advance();
+      });
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        if (aff) h[i] = h[i] * lds4(as, ch * KB + i, c.g4) + lds4(at, ch * KB + i, c.g4);
+        h[i] = swish4(h[i]);
+      }
+      static_for<0, KS32X>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        st.prefetch();
+        const Split8 hf = split8(h[2 * t], h[2 * t + 1]);
+        slab_step(y, hf, st.cur_addr());
+        st.advance();
+      });
+    }
+  };
+  chain(2, p_pcb, p_bns, p_bnt, true);
+  const float inv_fc = 1.0f / a.fc;
+#pragma unroll
+  for (int i = 0; i < KB; ++i) {
+    xs[i] = y[i];                                                                    // x3 = x2 + conv module
+    y[i] = lds4(p_b2, i, c.g4) + splat4(inv_fc) * y[i];                              // x3/fc + b2 (+ W2 h)
+  }
+  {
+    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
+    ln_lds(xr, p_lng, p_lnb, c.g4, a.eps);
+  }
+#pragma unroll
+  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
+  chain(4, p_b1, nullptr, nullptr, false);
+#pragma unroll
+  for (int i = 0; i < KB; ++i) y[i] = splat4(a.fc) * y[i];
+  ln_lds(y, p_fg, p_fb, c.g4, a.eps);                                                // block-final LayerNorm
+  if (c.live) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(a.y + c.row + 16 * i + c.g4, y[i]);
+  }
 }
 
 // out_glu on the slab ring: 5 slabs of the out-projection, then per 32-wide step of pw_conv_1 one slab of value tiles
@@ -336,8 +504,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_ring_kernel(OutGluAr
   __shared__ __attribute__((aligned(16))) u32x4_t ring[4 * SLB];
   __shared__ __attribute__((aligned(16))) float p_ob[D], p_lng[D], p_lnb[D], p_pb[2 * D];
   const WaveCtx c = wave_ctx(a.M);
-  SlabStream st{ring, reinterpret_cast<const u32x4_t*>(a.og_slabs), 15, 0,
-                __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
+  SlabStream<4> st{ring, reinterpret_cast<const u32x4_t*>(a.og_slabs), 15,
+                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
   st.begin();
   f32x4 xs[KB + 1], acc[2 * KB], x2[KB];
 #pragma unroll
@@ -612,7 +780,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void tail_ff2_kernel(TailFf2Args 
 
 }  // namespace
 
+int launch_ff1_qkv_impl(const Ff1QkvArgs& a, hipStream_t s);
 int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
+  // MI355ASR_FF1QKV_RING: 1 (default) = split-bf16 MFMAs on the five-slot slab ring (54 us at 16 000 tokens),
+  // 0 = the fp32-MFMA register-stream kernel (69 us)
+  static const int ringk = [] { const char* v = getenv("MI355ASR_FF1QKV_RING"); return v ? atoi(v) : 1; }();
+  if (ringk && a.slabs) {
+    const int tiles = (a.M + 15) / 16;
+    hipLaunchKernelGGL(ff1_qkv_ring_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
+    return 0;
+  }
+  return launch_ff1_qkv_impl(a, s);
+}
+int launch_ff1_qkv_impl(const Ff1QkvArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
   hipLaunchKernelGGL(ff1_qkv_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
@@ -640,6 +820,13 @@ int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t
 }
 int launch_tail_ff2(const TailFf2Args& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
+  // MI355ASR_TAILFF2_RING: 1 (default) = split-bf16 MFMAs on the five-slot slab ring (60 us at 16 000 tokens),
+  // 0 = the fp32-MFMA register-stream kernel (74 us)
+  static const int ringk = [] { const char* v = getenv("MI355ASR_TAILFF2_RING"); return v ? atoi(v) : 1; }();
+  if (ringk && a.slabs) {
+    hipLaunchKernelGGL(tail_ff2_ring_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
+    return 0;
+  }
   hipLaunchKernelGGL(tail_ff2_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
 }

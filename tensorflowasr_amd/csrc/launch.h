@@ -227,6 +227,7 @@ struct Ff1QkvArgs {
   const float *att_ln_g, *att_ln_b, *qkv_wp, *qkv_b;
   float fc, qscale, eps;
   int M;
+  const float* slabs = nullptr;   // slab stream of ff1_qkv_ring_kernel (55 slabs of 1792 fragments), or null
 };
 struct OutGluArgs {
   const float* ctx; const float* x1; float* x2; float* u;
@@ -242,6 +243,7 @@ struct TailFf2Args {
   const float *ff_ln_g, *ff_ln_b, *ff_w1p, *ff_b1, *ff_w2p, *ff_b2, *ln_g, *ln_b;
   float fc, eps;
   int M;
+  const float* slabs = nullptr;   // slab stream of tail_ff2_ring_kernel (60 slabs of 1792 fragments), or null
 };
 int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s);
 int launch_out_glu(const OutGluArgs& a, hipStream_t s);

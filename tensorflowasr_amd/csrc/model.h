@@ -61,7 +61,7 @@ struct BlockDev {
   // block-final LayerNorm
   const float *ln_g, *ln_b;
   // out-projection / pw_conv_1 kernels as split-bf16 fragments (dmodel 144, Keras-layout MHA; fused.hip), or null
-  const float *out_ws = nullptr, *pw1_ws = nullptr, *og_slabs = nullptr;
+  const float *out_ws = nullptr, *pw1_ws = nullptr, *og_slabs = nullptr, *ff1_slabs = nullptr, *tail_slabs = nullptr;
 };
 
 struct Dims {
@@ -190,7 +190,7 @@ struct BlockOff {
   bool cross = false;
   size_t cv_ln_g, cv_ln_b, pw1_wp, pw1_b, dw_w, pc_w1p, pc_b1, bn_s, bn_t, pw2_wp, pw2_b;
   size_t ln_g, ln_b;
-  size_t out_ws = 0, pw1_ws = 0, og_slabs = 0;
+  size_t out_ws = 0, pw1_ws = 0, og_slabs = 0, ff1_slabs = 0, tail_slabs = 0;
   bool split = false;
 };
 

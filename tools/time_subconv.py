@@ -27,12 +27,16 @@ if len(sys.argv) > 1:
     print(json.dumps({"mode": sys.argv[1], "subconv_ms": round(t[3] / max(c[3], 1), 4), "sublinear_ms": round(t[4] / max(c[4], 1), 4), "out_glu_ms": round(t[16] / max(c[16], 1), 4), "ff1_qkv_ms": round(t[15] / max(c[15], 1), 4),
                       "tail_ff2_ms": round(t[17] / max(c[17], 1), 4)}))
 else:
-    for mode in ("0", "og1", "og2"):
+    for mode in ("0", "tailring"):
         env = dict(os.environ)
         if mode == "f32":
             env["MI355ASR_SUBCONV_F32"] = "1"
         elif mode.startswith("og"):
             env["MI355ASR_OUTGLU_SPLIT"] = mode[2:]
+        elif mode == "ffring":
+            env["MI355ASR_FF1QKV_RING"] = "1"
+        elif mode == "tailring":
+            env["MI355ASR_TAILFF2_RING"] = "1"
         elif mode.startswith("diag"):
             env["MI355ASR_SUBCONV_DIAG"] = mode[4:]
         else:
