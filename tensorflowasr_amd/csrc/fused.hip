@@ -299,6 +299,29 @@ struct SlabStream {
   }
 };
 
+// parameter stash in two phases: all global loads of a kernel first, then the LDS writes (stash() per array makes one
+// L2 round trip per array: load, wait, write)
+template <int N>
+struct StashRegs { float r[(N + BLOCK_THREADS - 1) / BLOCK_THREADS]; };
+template <int N>
+DEV StashRegs<N> stash_load(const float* __restrict__ src) {
+  StashRegs<N> s;
+#pragma unroll
+  for (int k = 0; k < (N + BLOCK_THREADS - 1) / BLOCK_THREADS; ++k) {
+    const int idx = threadIdx.x + BLOCK_THREADS * k;
+    s.r[k] = idx < N ? src[idx] : 0.f;
+  }
+  return s;
+}
+template <int N>
+DEV void stash_store(float* dst, const StashRegs<N>& s) {
+#pragma unroll
+  for (int k = 0; k < (N + BLOCK_THREADS - 1) / BLOCK_THREADS; ++k) {
+    const int idx = threadIdx.x + BLOCK_THREADS * k;
+    if (idx < N) dst[idx] = s.r[k];
+  }
+}
+
 template <int OFF>
 DEV u32x4_t lds_read16(unsigned addr) {
   u32x4_t v;
@@ -352,8 +375,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void ff1_qkv_ring_kernel(Ff1QkvAr
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + c.row + 16 * kb + c.g4);
   xs[KB] = splat4(0.f);
-  stash(p_ln1g, a.ff_ln_g, D); stash(p_ln1b, a.ff_ln_b, D); stash(p_b1, a.ff_b1, 4 * D); stash(p_b2, a.ff_b2, D);
-  stash(p_ln2g, a.att_ln_g, D); stash(p_ln2b, a.att_ln_b, D); stash(p_qb, a.qkv_b, 3 * D);
+  {
+    const auto r0 = stash_load<D>(a.ff_ln_g), r1 = stash_load<D>(a.ff_ln_b), r3 = stash_load<D>(a.ff_b2),
+               r4 = stash_load<D>(a.att_ln_g), r5 = stash_load<D>(a.att_ln_b);
+    const auto r2 = stash_load<4 * D>(a.ff_b1);
+    const auto r6 = stash_load<3 * D>(a.qkv_b);
+    stash_store<D>(p_ln1g, r0); stash_store<D>(p_ln1b, r1); stash_store<4 * D>(p_b1, r2); stash_store<D>(p_b2, r3);
+    stash_store<D>(p_ln2g, r4); stash_store<D>(p_ln2b, r5); stash_store<3 * D>(p_qb, r6);
+  }
   __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): inputs, parameters and the first four slabs
   __syncthreads();
   const float inv_fc = 1.0f / a.fc;
@@ -437,9 +466,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void tail_ff2_ring_kernel(TailFf2
   xs[KB] = splat4(0.f);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + c.row + 16 * kb + c.g4);     // residuals ride in the accumulators
-  stash(p_pcb, a.pc_b1, 2 * D); stash(p_bns, a.bn_s, 2 * D); stash(p_bnt, a.bn_t, 2 * D); stash(p_pw2b, a.pw2_b, D);
-  stash(p_lng, a.ff_ln_g, D); stash(p_lnb, a.ff_ln_b, D); stash(p_b1, a.ff_b1, 4 * D); stash(p_b2, a.ff_b2, D);
-  stash(p_fg, a.ln_g, D); stash(p_fb, a.ln_b, D);
+  {
+    const auto r0 = stash_load<2 * D>(a.pc_b1), r1 = stash_load<2 * D>(a.bn_s), r2 = stash_load<2 * D>(a.bn_t);
+    const auto r3 = stash_load<D>(a.pw2_b), r4 = stash_load<D>(a.ff_ln_g), r5 = stash_load<D>(a.ff_ln_b),
+               r7 = stash_load<D>(a.ff_b2), r8 = stash_load<D>(a.ln_g), r9 = stash_load<D>(a.ln_b);
+    const auto r6 = stash_load<4 * D>(a.ff_b1);
+    stash_store<2 * D>(p_pcb, r0); stash_store<2 * D>(p_bns, r1); stash_store<2 * D>(p_bnt, r2); stash_store<D>(p_pw2b, r3);
+    stash_store<D>(p_lng, r4); stash_store<D>(p_lnb, r5); stash_store<4 * D>(p_b1, r6); stash_store<D>(p_b2, r7);
+    stash_store<D>(p_fg, r8); stash_store<D>(p_fb, r9);
+  }
   __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): inputs, parameters and the first four slabs
   __syncthreads();
 #pragma unroll
@@ -513,7 +548,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_ring_kernel(OutGluAr
   xs[KB] = splat4(0.f);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) acc[kb] = ldg4(a.x1 + c.row + 16 * kb + c.g4);    // residual rides in the accumulator
-  stash(p_ob, a.out_b, D); stash(p_lng, a.cv_ln_g, D); stash(p_lnb, a.cv_ln_b, D); stash(p_pb, a.pw1_b, 2 * D);
+  {
+    const auto r0 = stash_load<D>(a.out_b), r1 = stash_load<D>(a.cv_ln_g), r2 = stash_load<D>(a.cv_ln_b);
+    const auto r3 = stash_load<2 * D>(a.pw1_b);
+    stash_store<D>(p_ob, r0); stash_store<D>(p_lng, r1); stash_store<D>(p_lnb, r2); stash_store<2 * D>(p_pb, r3);
+  }
   __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): inputs, parameters and the first three slabs
   __syncthreads();
 #pragma unroll
