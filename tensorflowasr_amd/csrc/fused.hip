@@ -289,11 +289,15 @@ struct SlabStream {
   DEV unsigned cur_addr() const {                        // LDS byte address of this lane's first fragment of slab s
     return (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ring + rd * SLB + lane);
   }
-  DEV void advance() {
-    // slab s + 1 has landed: the RING - 2 slabs issued after it (7 DMAs each) may still be in flight; lgkmcnt(0)
+  // "everything but the RING - 2 newest slabs has landed" + this wave's LDS operations are done, then the barrier.
+  // After begin(): slab 0 and every vector-memory operation issued before begin() are complete.
+  DEV void sync() const {
     constexpr int n = 7 * (RING - 2);
     __builtin_amdgcn_s_waitcnt(0x0070 | (n & 15) | ((n >> 4) << 14));
     __builtin_amdgcn_s_barrier();
+  }
+  DEV void advance() {                                   // slab s + 1 has landed
+    sync();
     ++s;
     rd = rd + 1 == RING ? 0 : rd + 1;
   }
@@ -370,7 +374,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void ff1_qkv_ring_kernel(Ff1QkvAr
   const WaveCtx c = wave_ctx(a.M);
   SlabStream<5> st{ring, reinterpret_cast<const u32x4_t*>(a.slabs), 55,
                    __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
-  st.begin();
   f32x4 xs[KB + 1], y[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + c.row + 16 * kb + c.g4);
@@ -380,11 +383,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void ff1_qkv_ring_kernel(Ff1QkvAr
                r4 = stash_load<D>(a.att_ln_g), r5 = stash_load<D>(a.att_ln_b);
     const auto r2 = stash_load<4 * D>(a.ff_b1);
     const auto r6 = stash_load<3 * D>(a.qkv_b);
+    st.begin();                                            // after the input / parameter loads: see sync()
     stash_store<D>(p_ln1g, r0); stash_store<D>(p_ln1b, r1); stash_store<4 * D>(p_b1, r2); stash_store<D>(p_b2, r3);
     stash_store<D>(p_ln2g, r4); stash_store<D>(p_ln2b, r5); stash_store<3 * D>(p_qb, r6);
   }
-  __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): inputs, parameters and the first four slabs
-  __syncthreads();
+  st.sync();                                               // inputs, parameters and slab 0; three slabs still in flight
   const float inv_fc = 1.0f / a.fc;
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) y[kb] = lds4(p_b2, kb, c.g4) + splat4(inv_fc) * xs[kb];
@@ -459,7 +462,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void tail_ff2_ring_kernel(TailFf2
   const WaveCtx c = wave_ctx(a.M);
   SlabStream<5> st{ring, reinterpret_cast<const u32x4_t*>(a.slabs), 60,
                    __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
-  st.begin();
   f32x4 xs[KB + 1], y[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
@@ -471,12 +473,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void tail_ff2_ring_kernel(TailFf2
     const auto r3 = stash_load<D>(a.pw2_b), r4 = stash_load<D>(a.ff_ln_g), r5 = stash_load<D>(a.ff_ln_b),
                r7 = stash_load<D>(a.ff_b2), r8 = stash_load<D>(a.ln_g), r9 = stash_load<D>(a.ln_b);
     const auto r6 = stash_load<4 * D>(a.ff_b1);
+    st.begin();
     stash_store<2 * D>(p_pcb, r0); stash_store<2 * D>(p_bns, r1); stash_store<2 * D>(p_bnt, r2); stash_store<D>(p_pw2b, r3);
     stash_store<D>(p_lng, r4); stash_store<D>(p_lnb, r5); stash_store<4 * D>(p_b1, r6); stash_store<D>(p_b2, r7);
     stash_store<D>(p_fg, r8); stash_store<D>(p_fb, r9);
   }
-  __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): inputs, parameters and the first four slabs
-  __syncthreads();
+  st.sync();
 #pragma unroll
   for (int i = 0; i < KB; ++i) y[i] += lds4(p_pw2b, i, c.g4);
   Split8 xf[KS32X];
@@ -541,7 +543,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_ring_kernel(OutGluAr
   const WaveCtx c = wave_ctx(a.M);
   SlabStream<4> st{ring, reinterpret_cast<const u32x4_t*>(a.og_slabs), 15,
                    __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
-  st.begin();
   f32x4 xs[KB + 1], acc[2 * KB], x2[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + c.row + 16 * kb + c.g4);
@@ -551,10 +552,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_ring_kernel(OutGluAr
   {
     const auto r0 = stash_load<D>(a.out_b), r1 = stash_load<D>(a.cv_ln_g), r2 = stash_load<D>(a.cv_ln_b);
     const auto r3 = stash_load<2 * D>(a.pw1_b);
+    st.begin();
     stash_store<D>(p_ob, r0); stash_store<D>(p_lng, r1); stash_store<D>(p_lnb, r2); stash_store<2 * D>(p_pb, r3);
   }
-  __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): inputs, parameters and the first three slabs
-  __syncthreads();
+  st.sync();
 #pragma unroll
   for (int i = 0; i < KB; ++i) acc[i] += lds4(p_ob, i, c.g4);
   static_for<0, KS32X>([&](auto T) {
