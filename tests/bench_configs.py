@@ -5,7 +5,7 @@
   config 5  ChunkConformer + CTC prefix beam (externals/ctc_decoders), 16 x 30 s utterances per GPU
             (= 128 over 8 GPUs), beam 10 and 100, cutoff_prob 0.99, cutoff_top_n 40.
 
-    python tools/bench_configs.py [--steps K]      -> one JSON line per configuration (synthetic data, random init)
+    python tests/bench_configs.py [--steps K]      -> one JSON line per configuration (synthetic data, random init)
 
 Kept out of bench.py so that the driver's contract line stays the headline metric on the headline config."""
 import argparse
