@@ -52,7 +52,26 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_example(force, verbose)
     return LIB
+
+
+EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "asr_session.cpp")
+EXAMPLE_BIN = os.path.abspath(os.path.join(HERE, "..", "examples", "asr_session"))   # git-ignored, travels with gpurun
+
+
+def build_example(force=False, verbose=True):
+    """examples/asr_session.cpp: the reference's C++ `Session` on the C ABI, linked against libmi355asr.so."""
+    src = os.path.abspath(EXAMPLE_SRC)
+    if not os.path.exists(src):
+        return None
+    inc = os.path.abspath(os.path.join(HERE, "..", "include"))
+    if force or _stale(EXAMPLE_BIN, [src, LIB, os.path.join(inc, "mi355asr.h")]):
+        cmd = [_hipcc(), "-std=c++17", "-O2", "-I" + inc, src, "-L" + HERE, "-lmi355asr", "-Wl,-rpath,$ORIGIN/../tensorflowasr_amd", "-Wl,-rpath," + HERE, "-o", EXAMPLE_BIN]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return EXAMPLE_BIN
 
 
 if __name__ == "__main__":

@@ -999,6 +999,15 @@ const char* mi355asr_weight_name(const mi355asr_model* m, int32_t i) {
   return m->expected[i].name.c_str();
 }
 
+int mi355asr_weight_shape(const mi355asr_model* m, int32_t i, int32_t* rank, int64_t* dims, int32_t max_rank) {
+  if (!m || !rank || i < 0 || i >= (int)m->expected.size()) return fail(MI355ASR_EINVAL, "weight index %d out of range", i);
+  const auto& d = m->expected[i].dims;
+  *rank = (int32_t)d.size();
+  if ((int)d.size() > max_rank || (!dims && !d.empty())) return fail(MI355ASR_EINVAL, "dims array too small for rank %d", (int)d.size());
+  for (size_t k = 0; k < d.size(); ++k) dims[k] = d[k];
+  return 0;
+}
+
 int mi355asr_load_weight(mi355asr_model* m, const char* name, const float* data, int32_t rank, const int64_t* dims) {
   if (!m || !name || !data || rank < 0 || (rank > 0 && !dims)) return fail(MI355ASR_EINVAL, "null argument");
   const Expected* e = nullptr;

@@ -993,3 +993,14 @@ print("RESULT %.3e %.3e" % (blk, enc))
         assert line, out.stderr[-2000:]
         blk, enc = (float(v) for v in line[0].split()[1:])
         assert blk < TOL and enc < TOL, (extra, blk, enc)
+
+
+def test_cpp_session_example_runs(torch_cuda):
+    """examples/asr_session.cpp -- the reference's C++ Session on the C ABI, no Python in the process: enumerates the
+    tensors with mi355asr_weight_shape, fills them, recognises a synthetic utterance twice with identical ids."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "asr_session")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    assert "repeatable: yes" in out.stdout and "75 encoder frames" in out.stdout

@@ -486,3 +486,35 @@ def test_keras_variable_names_map_to_abi_names():
     assert e[enc[0]] == "conv_subsampling/conv1/kernel" and e[enc[1]] == "conv_subsampling/conv2/bias"
     assert e[enc[2]] == "conv_subsampling/linear/kernel"
     assert e[enc[3]] == "conformer_block_11/ff_module_2/ffn2/bias" and e[enc[4]] == "conformer_block_11/ff_module_2/ffn1/bias"
+
+
+def test_weight_shape_query_matches_the_python_mirror():
+    """mi355asr_weight_shape: what a non-Python caller uses to enumerate the tensors (examples/asr_session.cpp)"""
+    lib, rc, p = _create(num_classes=1332, ctc_num_blocks=1)
+    assert rc == 0
+    from tensorflowasr_amd.models import ConformerCTC
+    expect = {n: tuple(s) for n, s in ConformerCTC(1332, num_blocks=1)._names_and_shapes()}
+    rank = ctypes.c_int32()
+    dims = (ctypes.c_int64 * 8)()
+    seen = {}
+    for i in range(lib.mi355asr_num_weights(p)):
+        assert lib.mi355asr_weight_shape(p, i, ctypes.byref(rank), dims, 8) == 0
+        seen[lib.mi355asr_weight_name(p, i).decode()] = tuple(dims[k] for k in range(rank.value))
+    assert seen == expect
+    assert lib.mi355asr_weight_shape(p, 10 ** 6, ctypes.byref(rank), dims, 8) == -1
+    assert lib.mi355asr_weight_shape(p, 0, ctypes.byref(rank), dims, 1) == -1      # conv / DFT kernels have rank 4
+    lib.mi355asr_destroy(p)
+
+
+def test_cpp_session_example_builds_and_fails_loudly_without_a_gpu():
+    """examples/asr_session.cpp (the reference's C++ Session on the C ABI) compiles against include/mi355asr.h and links
+    to libmi355asr.so; without a device it must exit non-zero with the HIP error, not fall back to anything."""
+    import subprocess
+    from tensorflowasr_amd import build as b
+    exe = b.build_example(verbose=False)
+    assert exe and os.path.exists(exe)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and "error:" in out.stderr
