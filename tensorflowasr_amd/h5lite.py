@@ -7,7 +7,7 @@ blocks (and version-2 "OHDR" headers without creation indices); old-style groups
 heap + SNOD nodes) and compact link messages; datasets with compact, contiguous or chunked (v1 B-tree) layout, the
 deflate and shuffle filters; little/big-endian integer and IEEE float types; fixed-length and variable-length (global
 heap) strings; attributes (message versions 1-3) of those types.  Not supported: dense link / attribute storage
-(fractal heaps), version-4 layouts, virtual / external storage, compound types -- a clear error is raised.
+(fractal heaps), version-4 chunk indices, virtual / external storage, compound types -- a clear error is raised.
 
     f = H5File(path); f.attrs["layer_names"]; f["layer/sub/kernel:0"].read() -> numpy array; f.visit() -> dataset paths
 
@@ -187,11 +187,6 @@ class H5File:
             return _Type("vlen", size, vlen_string=is_str)
         raise H5Error("unsupported datatype class %d (version %d)" % (cls, ver))
 
-    def _datatype_len(self, d):
-        """bytes of the datatype message starting at d[0] (needed inside version-1 attribute messages only via the
-        stored sizes, so this is not used there)"""
-        raise NotImplementedError
-
     def _vlen_string(self, raw, i):
         e = 4 + self.O + 4
         ln = int.from_bytes(raw[i * e:i * e + 4], "little")
@@ -230,8 +225,11 @@ class H5File:
     def _attributes(self, obj):
         out = {}
         for t, d in obj.msgs:
-            if t == 0x15:
-                raise H5Error("dense attribute storage (fractal heap) is not supported")
+            if t == 0x15:                                       # attribute info: dense storage if it names a fractal heap
+                q = 2 + (2 if d[1] & 1 else 0)
+                if self._addr_of(d, q) != _UNDEF:
+                    raise H5Error("dense attribute storage (fractal heap) is not supported")
+                continue
             if t != 0x0C:
                 continue
             ver = d[0]
@@ -395,8 +393,8 @@ class Dataset:
         f = self.f
         lay = self.obj.first(0x08)
         ver, cls = lay[0], lay[1]
-        if ver != 3:
-            raise H5Error("data layout message version %d is not supported" % ver)
+        if ver not in (3, 4) or (ver == 4 and cls == 2):
+            raise H5Error("data layout message version %d (class %d) is not supported" % (ver, cls))
         shape = self.shape
         if shape is None:
             return None

@@ -104,3 +104,26 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def latest_format_fixture():
+    """keras_weights_latest.h5: the same layout written with libver='latest' (superblock 3, version-2 object headers,
+    link messages instead of symbol tables, version-4 contiguous layouts, a big-endian float64 dataset)."""
+    r = np.random.default_rng(1)
+    path = os.path.join(OUT, "keras_weights_latest.h5")
+    vals = {}
+    with h5py.File(path, "w", libver="latest") as f:
+        f.attrs["layer_names"] = np.asarray([b"a", b"b"])
+        f.attrs["backend"] = "tensorflow"
+        for layer in ("a", "b"):
+            g = f.create_group(layer)
+            g.attrs["weight_names"] = np.asarray([("%s/kernel:0" % layer).encode(), ("%s/bias:0" % layer).encode()])
+            vals["%s/kernel:0" % layer] = r.standard_normal((4, 5)).astype(np.float32)
+            vals["%s/bias:0" % layer] = r.standard_normal((5,)).astype(">f8")
+            g.create_dataset("%s/kernel:0" % layer, data=vals["%s/kernel:0" % layer])
+            g.create_dataset("%s/bias:0" % layer, data=vals["%s/bias:0" % layer])
+    np.savez(os.path.join(OUT, "keras_weights_latest.npz"), **vals)
+
+
+if __name__ == "__main__":
+    latest_format_fixture()

@@ -60,3 +60,13 @@ def test_keras_h5_to_abi_names(ref):
     from tensorflowasr_amd.models import CTCDecoder
     dec = CTCDecoder(num_classes=1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32)
     assert set(w) == {n for n, _ in dec._names_and_shapes()}          # exactly the tensors a CTCDecoder handle expects
+
+
+def test_latest_format_bounds_file():
+    """written with libver='latest': superblock 3, version-2 object headers (OHDR), link messages, compact attributes
+    announced by an attribute-info message, version-4 contiguous layouts, a big-endian float64 dataset"""
+    ref = dict(np.load(os.path.join(GOLDEN, "keras_weights_latest.npz")))
+    w = h5lite.keras_weights(os.path.join(GOLDEN, "keras_weights_latest.h5"))
+    assert set(w) == set(ref) == {"a/kernel:0", "a/bias:0", "b/kernel:0", "b/bias:0"}
+    for k in ref:
+        assert np.array_equal(w[k], ref[k]) and w[k].dtype.itemsize == ref[k].dtype.itemsize, k
