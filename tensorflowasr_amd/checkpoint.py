@@ -7,6 +7,9 @@
   weights into anonymous initializers and lowers the attention einsums to Gemm/MatMul, so the tensors are located
   *structurally* (node-name suffixes inside each block scope, and for the attention projections by following the data
   flow from the `truediv` / `Softmax` nodes), not by the export's initializer numbering.
+* TensorFlow checkpoints (tensor bundle: `.index` + `.data-*`; what `save_weights(prefix)` writes and the ChunkConformer
+  trainer uses): `tfbundle.py` (sorted-string-table index, CRC32C-checked tensors, object graph -> variable names);
+  `tf_checkpoint_to_abi(path)`.
 * Keras `.h5` weight files: read with the pure-Python HDF5 reader `h5lite.py` (h5py is not available next to the system
   interpreter of this image), variable names mapped by `keras_names_to_abi`; `keras_h5_to_abi(path)`.
 
@@ -379,3 +382,15 @@ def keras_h5_to_abi(path):
         elif "mel_layer" in k and leaf.startswith("Variable"):
             out["mel_layer/freq2mel"] = np.asarray(v, np.float32)
     return out
+
+
+def tf_checkpoint_to_abi(path):
+    """{C-ABI name: array} from a TensorFlow checkpoint in the tensor-bundle format (`model.save_weights(prefix)`,
+    `tf.train.Checkpoint`, a SavedModel's `variables/`): tensors and their Keras variable names are read by
+    tfbundle.Bundle (object graph -> full_name), then mapped with keras_names_to_abi.  For the ChunkConformer
+    sub-models, whose Keras scopes differ from the C-ABI prefixes (front / encoder / picker / helper / decoder), use
+    `tfbundle.Bundle(prefix).variables_by_name()` and a rename of your own."""
+    from . import tfbundle
+    raw = tfbundle.Bundle(tfbundle.checkpoint_prefix(path)).variables_by_name()
+    m = keras_names_to_abi(list(raw))
+    return {m[k]: np.asarray(v, np.float32) for k, v in raw.items() if k in m}
