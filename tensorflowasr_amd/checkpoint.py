@@ -394,3 +394,72 @@ def tf_checkpoint_to_abi(path):
     raw = tfbundle.Bundle(tfbundle.checkpoint_prefix(path)).variables_by_name()
     m = keras_names_to_abi(list(raw))
     return {m[k]: np.asarray(v, np.float32) for k, v in raw.items() if k in m}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ChunkConformer: object-graph paths of a TensorFlow checkpoint -> C-ABI names
+# ---------------------------------------------------------------------------------------------------------
+_CHUNK_ROOT = {"front": "front", "encoder": "encoder", "phone_picker": "picker", "decoder": "decoder", "helper": "helper"}
+_CHUNK_BLOCK = {"ffm1": "ff_module_1", "ffm2": "ff_module_2", "mhsam": "mhsa_module", "convm": "conv_module", "ln": "ln"}
+_CHUNK_MHA = {"_query_dense": "query", "_key_dense": "key", "_value_dense": "value", "_output_dense": "attention_output"}
+_CHUNK_MEL = {"dft_real_kernels": "real_kernels", "dft_imag_kernels": "imag_kernels", "freq2mel": "freq2mel"}
+
+
+def chunk_checkpoint_keys_to_abi(keys):
+    """Map the keys of a ChunkConformer checkpoint written by `model.save_weights(prefix)` / `tf.train.Checkpoint` to
+    the C-ABI names of the chunk handle.  Checkpoint keys are *attribute paths* in the Python object graph
+    (`encoder/conformer_blocks/3/ffm1/ffn1/kernel/.ATTRIBUTES/VARIABLE_VALUE`), which the reference's source fixes
+    (chunk_conformer_blocks.py: ChunkConformer.{front, encoder, phone_picker, decoder, helper} :782-786; ChunkConformerBlock.
+    {ffm1, mhsam, convm, ffm2, ln} :343-365; FFModule.{ln, ffn1, ffn2} :108-114; ChunkMHSAModule.{ln, mha} :146-147 with the
+    Keras MultiHeadAttention sub-layers `_query_dense`, ...; ChunkConvModule.{ln, pw_conv_1, dw_conv, bn, pw_conv_2}
+    :244-265; ChunkConformerEncoder.conformer_blocks :488; ChunkCTCDecoder.{project, decode_layers, fc} :588-609;
+    ChunkConformerFront.{conv_subsampling, mel_layer} :414-421) -- unlike Keras variable *names*, they do not depend on
+    layer auto-numbering.  Returns {checkpoint key: abi name}; optimizer slots and unknown paths are left out.
+    Not verified against a real ChunkConformer checkpoint (none is available); the inverse construction from the C-ABI
+    names is tested."""
+    out = {}
+    for key in keys:
+        path = key.split("/.ATTRIBUTES/")[0].split("/")
+        if len(path) < 3 or path[0] not in _CHUNK_ROOT or ".OPTIMIZER_SLOT" in key:
+            continue
+        root = _CHUNK_ROOT[path[0]]
+        rest = path[1:]
+        abi = None
+        if root == "front":
+            if rest[0] == "conv_subsampling" and len(rest) == 3 and rest[1] in ("conv1", "conv2", "linear"):
+                abi = "front/conv_subsampling/%s/%s" % (rest[1], rest[2])
+            elif rest[0] == "mel_layer" and len(rest) == 2 and rest[1] in _CHUNK_MEL:
+                abi = "front/mel_layer/" + _CHUNK_MEL[rest[1]]
+        else:
+            lst = "conformer_blocks" if root == "encoder" else "decode_layers"
+            if rest[0] == lst and len(rest) >= 4 and rest[1].isdigit() and rest[2] in _CHUNK_BLOCK:
+                blk = ("encoder/chunk_conformer_block_%s" if root == "encoder" else root + "/block_%s") % rest[1]
+                mod, tail = _CHUNK_BLOCK[rest[2]], rest[3:]
+                if mod == "ln" and len(tail) == 1:
+                    abi = "%s/ln/%s" % (blk, tail[0])
+                elif mod == "mhsa_module" and tail[0] == "mha" and len(tail) == 3 and tail[1] in _CHUNK_MHA:
+                    abi = "%s/mhsa_module/mha/%s/%s" % (blk, _CHUNK_MHA[tail[1]], tail[2])
+                elif mod != "ln" and len(tail) == 2:
+                    abi = "%s/%s/%s/%s" % (blk, mod, tail[0], tail[1])
+            elif root != "encoder" and rest[0] == "project" and len(rest) == 2:
+                abi = "%s/project/%s" % (root, rest[1])
+            elif root != "encoder" and rest[0] == "fc" and len(rest) == 2:
+                abi = "%s/fully_connected/%s" % (root, rest[1])
+        if abi:
+            out[key] = abi
+    return out
+
+
+def chunk_checkpoint_to_abi(path):
+    """{C-ABI name: array} for a ChunkConformer handle from a TensorFlow tensor-bundle checkpoint of the reference's
+    `ChunkConformer` model (see chunk_checkpoint_keys_to_abi); the DFT kernels are reshaped to the handle's 2-D layout."""
+    from . import tfbundle
+    b = tfbundle.Bundle(tfbundle.checkpoint_prefix(path))
+    m = chunk_checkpoint_keys_to_abi(b.keys())
+    out = {}
+    for key, abi in m.items():
+        v = np.asarray(b.tensor(key), np.float32)
+        if abi.endswith(("real_kernels", "imag_kernels")) and v.ndim == 4:
+            v = v.reshape(v.shape[0], v.shape[-1])
+        out[abi] = v
+    return out

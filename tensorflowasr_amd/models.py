@@ -182,8 +182,9 @@ class _ModelBase:
                 from . import checkpoint
                 weights = checkpoint.keras_h5_to_abi(path)
             elif path.endswith(".index") or os.path.isdir(path) or os.path.exists(path + ".index"):
-                from . import checkpoint
-                weights = checkpoint.tf_checkpoint_to_abi(path)      # TensorFlow tensor-bundle checkpoint
+                from . import checkpoint                             # TensorFlow tensor-bundle checkpoint
+                weights = (checkpoint.chunk_checkpoint_to_abi(path) if type(self).__name__ == "ChunkConformer"
+                           else checkpoint.tf_checkpoint_to_abi(path))
             elif path.endswith(".onnx"):
                 from . import checkpoint
                 weights = checkpoint.ctc_decoder_weights_from_onnx(path, num_heads=self.num_heads)

@@ -518,3 +518,38 @@ def test_cpp_session_example_builds_and_fails_loudly_without_a_gpu():
         pytest.skip("GPU present: covered by the gpu test")
     out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 1 and "error:" in out.stderr
+
+
+def test_chunk_checkpoint_keys_map_onto_every_chunk_tensor():
+    """checkpoint.chunk_checkpoint_keys_to_abi: object-graph attribute paths of the reference's ChunkConformer (fixed by
+    its source) -> the names the chunk handle expects.  The keys are constructed here from the attribute names in
+    chunk_conformer_blocks.py; every tensor of the handle must be reached exactly once."""
+    from tensorflowasr_amd import checkpoint
+    inv_root = {"front": "front", "encoder": "encoder", "picker": "phone_picker", "decoder": "decoder", "helper": "helper"}
+    inv_blk = {"ff_module_1": "ffm1", "ff_module_2": "ffm2", "mhsa_module": "mhsam", "conv_module": "convm"}
+    inv_mha = {"query": "_query_dense", "key": "_key_dense", "value": "_value_dense", "attention_output": "_output_dense"}
+    inv_mel = {"real_kernels": "dft_real_kernels", "imag_kernels": "dft_imag_kernels", "freq2mel": "freq2mel"}
+    abi_names = sorted(co.chunk_weights(dict(co.CHUNK_S), seed=0))
+    keys = {}
+    for n in abi_names:
+        p = n.split("/")
+        root = inv_root[p[0]]
+        if p[0] == "front":
+            k = "front/mel_layer/" + inv_mel[p[2]] if p[1] == "mel_layer" else "/".join(["front"] + p[1:])
+        elif p[1] in ("project", "fully_connected"):
+            k = "%s/%s/%s" % (root, "project" if p[1] == "project" else "fc", p[2])
+        else:
+            idx = p[1].rsplit("_", 1)[1]
+            lst = "conformer_blocks" if p[0] == "encoder" else "decode_layers"
+            if p[2] == "ln":
+                tail = ["ln", p[3]]
+            elif p[2] == "mhsa_module" and p[3] == "mha":
+                tail = ["mhsam", "mha", inv_mha[p[4]], p[5]]
+            else:
+                tail = [inv_blk[p[2]]] + p[3:]
+            k = "/".join([root, lst, idx] + tail)
+        keys[k + "/.ATTRIBUTES/VARIABLE_VALUE"] = n
+    extra = ["optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE", "encoder/conformer_blocks/0/ffm1/ffn1/kernel/.OPTIMIZER_SLOT/optimizer/m/.ATTRIBUTES/VARIABLE_VALUE",
+             "helper/sample_helper/embeddings/.ATTRIBUTES/VARIABLE_VALUE", "_CHECKPOINTABLE_OBJECT_GRAPH"]
+    m = checkpoint.chunk_checkpoint_keys_to_abi(list(keys) + extra)
+    assert m == keys
