@@ -461,21 +461,25 @@ int launch_subconv144_split(const SubConvArgs& a, hipStream_t s) {
   const int rows = 4 * span + 7;
   if (!a.w2s || a.st1 != 2 || rows * RS > MELP || PU <= 0) return -1;
   static const int late_mode = [] { const char* v = getenv("MI355ASR_SUBCONV_LATE"); return v ? atoi(v) : 0; }();
+  const dim3 grid((PU + SPOSG - 1) / SPOSG, a.B);
+#ifdef MI355ASR_DIAG_KERNELS
+  // timing-only variants (wrong results), compiled in with -DMI355ASR_DIAG_KERNELS: see the DIAG comment above
   static const int diag = [] {
     const char* v = getenv("MI355ASR_SUBCONV_DIAG");
     const int d = v ? atoi(v) : 0;
     if (d) fprintf(stderr, "libmi355asr: MI355ASR_SUBCONV_DIAG=%d -- timing experiment, the subsampling output is WRONG\n", d);
     return d;
   }();
-  const dim3 grid((PU + SPOSG - 1) / SPOSG, a.B);
   switch (diag) {
-    case 1: hipLaunchKernelGGL(subconv144_split_kernel<1>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
-    case 2: hipLaunchKernelGGL(subconv144_split_kernel<2>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
-    case 3: hipLaunchKernelGGL(subconv144_split_kernel<3>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
-    case 4: hipLaunchKernelGGL(subconv144_split_kernel<4>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
-    case 5: hipLaunchKernelGGL(subconv144_split_kernel<5>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
-    case 6: hipLaunchKernelGGL(subconv144_split_kernel<6>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); break;
-    default: hipLaunchKernelGGL(subconv144_split_kernel<0>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode);
+    case 1: hipLaunchKernelGGL(subconv144_split_kernel<1>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    case 2: hipLaunchKernelGGL(subconv144_split_kernel<2>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    case 3: hipLaunchKernelGGL(subconv144_split_kernel<3>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    case 4: hipLaunchKernelGGL(subconv144_split_kernel<4>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    case 5: hipLaunchKernelGGL(subconv144_split_kernel<5>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    case 6: hipLaunchKernelGGL(subconv144_split_kernel<6>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    default: break;
   }
+#endif
+  hipLaunchKernelGGL(subconv144_split_kernel<0>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode);
   return 0;
 }

@@ -1,4 +1,6 @@
-"""subconv kernel time (HIP events via mi355asr_profile_*) for the MI355ASR_SUBCONV_LATE modes; one process per mode."""
+"""Kernel times (HIP events via mi355asr_profile_*) under environment-selected kernel variants, one process per mode.
+The `diagN` modes need a library built with MI355ASR_EXTRA_HIPCC_FLAGS=-DMI355ASR_DIAG_KERNELS (`python -m
+tensorflowasr_amd.build --force`); they time wrong-result variants of the split subsampling kernel."""
 import json
 import os
 import subprocess
