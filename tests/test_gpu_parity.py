@@ -999,8 +999,9 @@ def test_cpp_session_example_runs(torch_cuda):
     """examples/asr_session.cpp -- the reference's C++ Session on the C ABI, no Python in the process: enumerates the
     tensors with mi355asr_weight_shape, fills them, recognises a synthetic utterance twice with identical ids."""
     import subprocess
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "asr_session")
-    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    from tensorflowasr_amd import build as b
+    exe = b.build_example(verbose=False)                 # no-op when examples/asr_session is up to date
+    assert exe and os.path.exists(exe)
     out = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-1000:]
     assert "repeatable: yes" in out.stdout and "75 encoder frames" in out.stdout
