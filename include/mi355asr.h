@@ -82,7 +82,8 @@ int mi355asr_load_weight(mi355asr_model* m, const char* name, const float* data_
 /* number of tensors the configuration expects / name of the i-th one (so loaders can iterate) */
 int mi355asr_num_weights(const mi355asr_model* m);
 const char* mi355asr_weight_name(const mi355asr_model* m, int32_t i);
-/* Keras-layout shape of the i-th tensor (what model.weights[i].shape is in the reference): *rank and dims[0..*rank) */
+/* replaces: iterating model.weights / model.summary() after _build() (test_asr.py:85-93): Keras-layout shape of the
+ * i-th tensor, *rank and dims[0..*rank); a non-Python caller sizes its buffers with it (examples/asr_session.cpp). */
 int mi355asr_weight_shape(const mi355asr_model* m, int32_t i, int32_t* rank, int64_t* dims, int32_t max_rank);
 /* replaces: model._build() (test_asr.py:85-87): checks every tensor is present, packs the matrices into
  * MFMA fragment order, folds BatchNorm into (scale, shift), uploads to HBM. */
