@@ -268,6 +268,15 @@ constexpr int KS32X = 5;                      // 32-wide steps over K = 144
 // stored after it ends).  The fragment reads are inline asm: the compiler would otherwise put vmcnt(0) in front of
 // every LDS read that may alias a pending DMA (it tracks LDS-DMA per LDS object; a ring indexed at run time is one
 // object), and the fence of __syncthreads() waits for all DMAs too -- hence also the bare s_barrier.
+// s_waitcnt vmcnt(PER * ahead) lgkmcnt(0) for a wave-uniform run-time `ahead` in [0, MAXA] (the count is an immediate)
+template <int PER, int MAXA>
+DEV void wait_dma_ahead(int ahead) {
+  static_for<0, MAXA + 1>([&](auto K) {
+    constexpr int k = decltype(K)::value, n = PER * k;
+    if (ahead == k) __builtin_amdgcn_s_waitcnt(0x0070 | (n & 15) | ((n >> 4) << 14));
+  });
+}
+
 constexpr int SLB = 7 * BLOCK_THREADS;
 template <int RING>
 struct SlabStream {
@@ -285,19 +294,25 @@ struct SlabStream {
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) issue(i, i);
   }
-  DEV void prefetch() const { issue(s + RING - 1, rd == 0 ? RING - 1 : rd - 1); }   // into the slot read in step s - 1
+  // slab s + RING - 1 into the slot read in step s - 1; nothing past the end of the stream (a DMA still in flight when
+  // the workgroup ends could land in the LDS of the next workgroup on the CU)
+  DEV void prefetch() const {
+    if (s + RING - 1 < total) issue(s + RING - 1, rd == 0 ? RING - 1 : rd - 1);
+  }
   DEV unsigned cur_addr() const {                        // LDS byte address of this lane's first fragment of slab s
     return (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ring + rd * SLB + lane);
   }
-  // "everything but the RING - 2 newest slabs has landed" + this wave's LDS operations are done, then the barrier.
-  // After begin(): slab 0 and every vector-memory operation issued before begin() are complete.
+  // After begin() (s = 0): slab 0 and every vector-memory operation issued before begin() are complete; the RING - 2
+  // slabs issued after slab 0 may still be in flight.  This wave's LDS operations are done; then the barrier.
   DEV void sync() const {
-    constexpr int n = 7 * (RING - 2);
-    __builtin_amdgcn_s_waitcnt(0x0070 | (n & 15) | ((n >> 4) << 14));
+    wait_dma_ahead<7, RING - 2>(min(RING - 2, max(total - 1, 0)));
     __builtin_amdgcn_s_barrier();
   }
-  DEV void advance() {                                   // slab s + 1 has landed
-    sync();
+  // end of step s: slab s + 1 has landed.  In flight may be only the slabs issued after it: s + 2 .. min(s + RING - 1,
+  // total - 1); in the last steps that is fewer than RING - 2, down to none -- the stream ends with no DMA outstanding.
+  DEV void advance() {
+    wait_dma_ahead<7, RING - 2>(max(min(RING - 2, total - 2 - s), 0));
+    __builtin_amdgcn_s_barrier();
     ++s;
     rd = rd + 1 == RING ? 0 : rd + 1;
   }
@@ -745,17 +760,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void sublinear_split_kernel(Strea
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < KB; ++i) acc[i] = lds4(p_b, i, 4 * g);
-  // one step: refill the slot read in the previous step with the slab RING - 1 steps ahead (past the end the last slab
-  // again, so that every step issues SL_DMA DMAs and the counted wait stays valid), then the MFMAs of this slot
+  // one step: refill the slot read in the previous step with the slab RING - 1 steps ahead, then the MFMAs of this slot
   auto step = [&](int s, const u32x4_t* cur, u32x4_t* refill) {
-    fill(min(s + SL_RING - 1, steps - 1), refill);
+    if (s + SL_RING - 1 < steps) fill(s + SL_RING - 1, refill);     // nothing past the end: see SlabStream::prefetch
     const f32x4 lo = __builtin_bit_cast(f32x4, cur[SL_WFR + g * 64 + 16 * wv + c]);
     const f32x4 hi = __builtin_bit_cast(f32x4, cur[SL_WFR + (4 + g) * 64 + 16 * wv + c]);
     const Split8 xf = split8(lo, hi);
     split_step<KB>(acc, xf, cur, lane);
-    // slab s + 1 has landed (counted: the two slabs issued after it may still be in flight); a bare s_barrier -- the
-    // fence of __syncthreads() would wait for every outstanding DMA
-    __builtin_amdgcn_s_waitcnt(kWait & ~0x0f00);          // + lgkmcnt(0): this wave's LDS reads of the slot are done
+    // slab s + 1 has landed (counted: the slabs issued after it -- two, fewer in the last steps -- may still be in
+    // flight) and this wave's LDS reads of the slot are done; a bare s_barrier -- the fence of __syncthreads() would
+    // wait for every outstanding DMA
+    wait_dma_ahead<SL_DMA, SL_RING - 2>(max(min(SL_RING - 2, steps - 2 - s), 0));
     __builtin_amdgcn_s_barrier();
   };
   int s = 0;
