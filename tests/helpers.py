@@ -55,6 +55,33 @@ def argmax_mismatch_report(gpu_logits, ref_logits):
     return out
 
 
+def assert_frames_and_ids(gpu_logits, gpu_argmax, gpu_ids, gpu_lens, ref_logits, in_len, blank, max_undecided=0.005, tol=1e-3):
+    """Token ids against the oracle, unconditionally.  Every frame's argmax must be the oracle's unless the oracle's own
+    margin between the two candidates is inside ten times the measured logit error (an fp32 forward cannot resolve such
+    a frame against an fp64 one); those frames are listed and bounded in number, and the ids must equal the collapse of
+    the oracle's argmax with exactly those frames patched.  Never skips.  gpu_* are NumPy arrays for the same
+    utterances as ref_logits."""
+    err = maxdiff(gpu_logits, ref_logits)
+    assert err < tol, err
+    ra = co.frame_argmax(ref_logits)
+    assert np.array_equal(gpu_argmax, co.frame_argmax(gpu_logits)), "in-kernel argmax != argmax of the kernel's own logits"
+    diff = np.argwhere(gpu_argmax != ra)
+    report = []
+    for b, t in diff:
+        margin = float(ref_logits[b, t, ra[b, t]] - ref_logits[b, t, gpu_argmax[b, t]])
+        report.append((int(b), int(t), int(ra[b, t]), int(gpu_argmax[b, t]), margin))
+    decisive = [r for r in report if r[4] > 10 * err]
+    assert not decisive, "argmax differs on frames the oracle decides clearly (err %.3g): %s" % (err, decisive[:10])
+    assert len(report) <= max_undecided * ra.size, "too many undecided frames: %d of %d" % (len(report), ra.size)
+    patched = ra.copy()
+    for b, t, _, g, _ in report:
+        patched[b, t] = g
+    rid, rlen = co.ctc_collapse(patched, in_len, blank)
+    assert np.array_equal(gpu_lens, rlen), (gpu_lens, rlen)
+    assert np.array_equal(gpu_ids, rid)
+    return err, report
+
+
 def chunk_config_dict(cfg):
     """oracle-style flat chunk config -> the reference's nested model YAML (asr/configs/chunk_conformerS.yml)."""
     common = dict(dmodel=cfg["dmodel"], head_size=cfg["head_size"], num_heads=cfg["num_heads"],

@@ -1,0 +1,240 @@
+"""GPU parity tests on the BASELINE.json configurations THEMSELVES: the shapes that are
+benchmarked are the shapes that are checked against the oracle.
+
+  config 2  ConformerCTC(S), 13 + 1 blocks, 64 x 10 s, fp32, built exactly as bench.py builds it (Keras-default random
+            encoder, the reference's exported CTCDecoder weights)
+  config 3  StreamingConformerCTC (d = 256, 4 blocks, k = 5), batch = 64 streaming chunks, bf16 MFMA inputs
+  config 5  ChunkConformer at chunk_conformerS.yml dimensions (15 + 1 + 2 + 1 blocks, 277 / 9171 classes), 30 s
+            utterances (T = 750, band attention), prefix beam search
+
+Token ids are compared with the oracle UNCONDITIONALLY (`assert_frames_and_ids`): every frame's argmax must be the
+oracle's unless the oracle's own margin between the two candidates is inside ten times the measured logit error (an
+fp32 forward cannot resolve such a frame against an fp64 one -- the reference's TF fp32 forward could not either);
+those frames are listed, bounded in number, and the ids must then equal the collapse of the oracle argmax with exactly
+those frames patched.  Nothing is skipped."""
+import numpy as np
+import pytest
+
+from helpers import (assert_frames_and_ids, chunk_config_dict, co, golden_ctc_io, golden_ctc_weights, maxdiff, waves)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def oracle_weights(w):
+    """model.get_weights_dict() (Keras variable shapes) -> what the oracle takes (2-D DFT kernels)."""
+    w = dict(w)
+    for k in list(w):
+        if k.endswith(("mel_layer/real_kernels", "mel_layer/imag_kernels")):
+            w[k] = np.asarray(w[k]).reshape(1024, 513)
+    return w
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 2
+# ---------------------------------------------------------------------------------------------------------------
+SAMPLED = [0, 21, 42, 63]
+
+
+@pytest.fixture(scope="module")
+def bench_model(torch_cuda):
+    """exactly bench.build_model(): _build(seed=0) + tests/golden/ctc_decoder_weights.npz"""
+    import bench
+    m = bench.build_model(torch_cuda.device("cuda", 0), 0, 1, False)
+    return m, oracle_weights(m.get_weights_dict())
+
+
+def test_config2_batch64_10s_as_benched_ids_and_logits_vs_oracle(bench_model, torch_cuda):
+    from tensorflowasr_amd.synthetic import synth_batch
+    m, w = bench_model
+    cfg = dict(co.CONFORMER_S)
+    x = synth_batch(0, 64, 160000)                        # the bench's own inputs (rank 0)
+    xd = torch_cuda.from_numpy(x).cuda()
+    ids, lens = m.recognize(xd)
+    ids, lens = ids.cpu().numpy().copy(), lens.cpu().numpy().copy()
+    assert ids.shape == (64, 250)
+    enc = m.encode(xd)
+    logits, amax = m.ctc_logits(enc, return_argmax=True)
+    enc, logits, amax = enc.cpu().numpy(), logits.cpu().numpy(), amax.cpu().numpy()
+    enc_ref = co.conformer_encoder(x[SAMPLED].astype(np.float64), w, cfg)
+    lg_ref = co.ctc_decoder(enc_ref, w, cfg)
+    e_enc = maxdiff(enc[SAMPLED], enc_ref)
+    assert e_enc < TOL
+    err, report = assert_frames_and_ids(logits[SAMPLED], amax[SAMPLED], ids[SAMPLED], lens[SAMPLED], lg_ref,
+                                        [250] * len(SAMPLED), 1331)
+    print("config 2 as benched: encoder max|d| %.3g, logits max|d| %.3g, undecided frames %d / %d"
+          % (e_enc, err, len(report), 250 * len(SAMPLED)))
+    # every one of the 64: the integer path is exact given the kernel's own logits
+    gid, glen = co.ctc_collapse(amax, [250] * 64, 1331)
+    assert np.array_equal(ids, gid) and np.array_equal(lens, glen)
+
+
+def test_config2_batch64_10s_nonblank_head_ids_vs_oracle(torch_cuda):
+    """the same shape with a CTC head that emits tokens (the trained CTCDecoder answers `blank` to a random encoder):
+    13 + 1 blocks, synthetic head centred on the batch so that the argmax follows the per-frame deviations."""
+    from tensorflowasr_amd.models import ConformerCTC
+    from tensorflowasr_amd.synthetic import synth_batch
+    import bench
+    cfg = dict(co.CONFORMER_S)
+    w = co.encoder_weights(cfg, seed=0)
+    w.update(co.ctc_decoder_weights(cfg, 1332, seed=1))
+    x = synth_batch(0, 64, 160000)
+    enc_ref = co.conformer_encoder(x[SAMPLED].astype(np.float64), w, cfg)
+    w["fully_connected/bias"] = np.zeros(1332, np.float32)
+    w["fully_connected/bias"] = (-co.ctc_decoder(enc_ref, w, cfg).mean(axis=(0, 1))).astype(np.float32)
+    lg_ref = co.ctc_decoder(enc_ref, w, cfg)
+    m = ConformerCTC(1332, **bench.S_CFG)
+    m.load_weights(w, by_name=False)
+    xd = torch_cuda.from_numpy(x).cuda()
+    ids, lens = m.recognize(xd)
+    ids, lens = ids.cpu().numpy().copy(), lens.cpu().numpy().copy()
+    logits, amax = m.ctc_logits(m.encode(xd), return_argmax=True)
+    logits, amax = logits.cpu().numpy(), amax.cpu().numpy()
+    err, report = assert_frames_and_ids(logits[SAMPLED], amax[SAMPLED], ids[SAMPLED], lens[SAMPLED], lg_ref,
+                                        [250] * len(SAMPLED), 1331, max_undecided=0.02)
+    assert lens[SAMPLED].min() > 100                      # real token sequences
+    print("config 2, token-emitting head: logits max|d| %.3g, undecided frames %d / 1000 %s" % (err, len(report), report[:4]))
+
+
+def test_config2_trained_ctc_decoder_at_batch64(torch_cuda):
+    """the reference's exported CTCDecoder on 64 x 250 frames (the fused block kernels' row count) with inputs that make
+    it emit tokens: argmax identical to the reference graph's own output (tests/golden/ctc_decoder_io.npz, 26 % of
+    the frames non-blank), every copy bit-identical."""
+    from tensorflowasr_amd.models import CTCDecoder, ctc_greedy_decode
+    io = golden_ctc_io()
+    dec = CTCDecoder(1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32)
+    dec.load_weights(golden_ctc_weights(), by_name=False)
+    xb = np.tile(io["x_b"], (64, 1, 1))
+    assert xb.shape == (64, 250, 144)
+    lg, am = dec(xb, return_argmax=True)
+    lg, am = lg.cpu().numpy(), am.cpu().numpy()
+    assert np.array_equal(am[0], io["argmax_b"][0])
+    assert maxdiff(lg[0, ::8], io["logits_b_every8"][0]) < TOL
+    assert all(np.array_equal(am[0], am[b]) for b in range(64))
+    ids, lens = ctc_greedy_decode(am, None, 1331)
+    rid, rlen = co.ctc_collapse(np.tile(io["argmax_b"], (64, 1)), [250] * 64, 1331)
+    assert np.array_equal(ids.cpu().numpy(), rid) and np.array_equal(lens.cpu().numpy(), rlen) and rlen[0] > 10
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 3: StreamingConformerCTC, batch = 64 streaming chunks, bf16 MFMA inputs
+# ---------------------------------------------------------------------------------------------------------------
+def test_config3_64_streaming_chunks_bf16_vs_rounding_oracle(torch_cuda):
+    """Streaming_ConformerS.yml at full depth (4 blocks, d = 256, k = 5; CTCDecoder 1 block k = 32) on 64 chunks of
+    8000 samples = 4 streams x 16 chunks, the global CTC over each stream's 208 frames.  Against the oracle that
+    rounds both GEMM operands to bf16 (pins the arithmetic), and against the exact fp32 oracle (what the mode costs)."""
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = dict(co.STREAMING_S)
+    V = 1332
+    w = co.encoder_weights(cfg, seed=51)
+    w.update(co.ctc_decoder_weights(cfg, V, seed=52))
+    kw = dict(dmodel=256, reduction_factor=4, num_blocks=4, head_size=64, num_heads=4, kernel_size=5, fc_factor=0.5,
+              sample_rate=16000, n_mels=80, stride_ms=10, chunk_size=8000, ctcdecoder_num_blocks=1,
+              ctcdecoder_kernel_size=32, ctcdecoder_fc_factor=0.5)
+    assert all(cfg[k] == kw[k] for k in ("dmodel", "num_blocks", "head_size", "num_heads", "kernel_size"))
+    x = waves(4, 16 * 8000, 300)                                        # 4 streams x 16 chunks = 64 chunks
+    out = {}
+    for dt in ("bfloat16", "float32"):
+        m = ConformerCTC(V, gemm_dtype=dt, **kw)
+        m.load_weights(w, by_name=False)
+        as_chunks = m.encode(x.reshape(64, 8000))                       # batch = 64 chunks, one per "stream"
+        enc = m.encode(x)                                               # the same 64 chunks as 4 streams
+        assert enc.shape == (4, 16 * 13, 256)
+        assert np.array_equal(as_chunks.cpu().numpy().reshape(4, 208, 256), enc.cpu().numpy())
+        logits, amax = m.ctc_logits(enc, return_argmax=True)
+        ids, lens = m.recognize(x)
+        out[dt] = (enc.cpu().numpy(), logits.cpu().numpy(), amax.cpu().numpy(), ids.cpu().numpy().copy(), lens.cpu().numpy().copy())
+    exact_enc = co.streaming_conformer_encoder(x.astype(np.float64), w, cfg, 8000)
+    exact_lg = co.ctc_decoder(exact_enc, w, cfg)
+    co.GEMM_ROUND_BF16 = True
+    try:
+        r_enc = co.streaming_conformer_encoder(x.astype(np.float64), w, cfg, 8000)
+        r_lg = co.ctc_decoder(r_enc, w, cfg)
+    finally:
+        co.GEMM_ROUND_BF16 = False
+    enc16, lg16, am16, ids16, lens16 = out["bfloat16"]
+    enc32, lg32, am32, ids32, lens32 = out["float32"]
+    # fp32 mode: the usual contract, ids unconditionally
+    assert maxdiff(enc32, exact_enc) < TOL
+    assert_frames_and_ids(lg32, am32, ids32, lens32, exact_lg, [208] * 4, V - 1, max_undecided=0.02)
+    # bf16 mode vs the rounding oracle: operands within 1e-7 of a rounding boundary flip, each flip is one bf16 ulp
+    e_enc, e_lg = np.abs(enc16 - r_enc), np.abs(lg16 - r_lg)
+    print("config 3 bf16 vs rounding oracle: encoder max %.3g mean %.3g; logits max %.3g mean %.3g"
+          % (e_enc.max(), e_enc.mean(), e_lg.max(), e_lg.mean()))
+    assert e_enc.max() < 2e-2 and e_enc.mean() < 2e-3
+    assert e_lg.max() < 4e-2 and e_lg.mean() < 3e-3
+    # integer path exact given the kernel's own logits
+    assert np.array_equal(am16, co.frame_argmax(lg16))
+    gid, glen = co.ctc_collapse(am16, [208] * 4, V - 1)
+    assert np.array_equal(ids16, gid) and np.array_equal(lens16, glen)
+    # and what bf16 costs against exact arithmetic (report max abs diff and ids agreement)
+    agree = float((am16 == co.frame_argmax(exact_lg)).mean())
+    print("config 3 bf16 vs exact fp64: encoder max|d| %.3g, logits max|d| %.3g, argmax agreement %.4f"
+          % (maxdiff(enc16, exact_enc), maxdiff(lg16, exact_lg), agree))
+    assert maxdiff(enc16, exact_enc) < 0.2 and maxdiff(lg16, exact_lg) < 0.3 and agree > 0.95
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 5: ChunkConformer (full chunk_conformerS dims) on 30 s utterances + prefix beam search
+# ---------------------------------------------------------------------------------------------------------------
+def test_config5_chunk_conformer_2x30s_stages_and_beam_vs_oracle(torch_cuda):
+    from tensorflowasr_amd.models import ChunkConformer, ctc_prefix_beam_decode
+    from test_gpu_parity import _pick_bias_for_ragged_counts
+    torch = torch_cuda
+    cfg = dict(co.CHUNK_S)
+    assert (cfg["enc_num_blocks"], cfg["picker_num_classes"], cfg["decoder_num_classes"]) == (15, 277, 9171)
+    w = co.chunk_weights(cfg, seed=5)
+    x = waves(2, 480000, 200)
+    w["picker/fully_connected/bias"][-1] = _pick_bias_for_ragged_counts(cfg, w, x)
+    ref = co.chunk_predict(x.astype(np.float64), w, cfg)
+    assert ref["front"].shape == (2, 750, 144)
+    m = ChunkConformer(chunk_config_dict(cfg), cfg["picker_num_classes"], cfg["decoder_num_classes"])
+    m.load_weights(w, by_name=False)
+    got = m.predict(x, stages=True)
+    for k in ("front", "enc", "picker_logits", "picker_hidden"):
+        e = maxdiff(got[k].cpu().numpy(), ref[k])
+        print("config 5 stage %-14s max|d| %.3g" % (k, e))
+        assert e < TOL, k
+    # the picker's decisions drive feature_pick: they must be the oracle's on every frame
+    pa_g, pa_r = got["picker_logits"].cpu().numpy().argmax(-1), ref["picker_logits"].argmax(-1)
+    blank = cfg["picker_num_classes"] - 1
+    assert np.array_equal(pa_g == blank, pa_r == blank)
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert 100 < ref["counts"].min() and ref["counts"].max() < 750
+    for k in ("picked", "helper", "text_logits"):
+        assert got[k].shape == ref[k].shape, k
+        e = maxdiff(got[k].cpu().numpy(), ref[k])
+        print("config 5 stage %-14s max|d| %.3g" % (k, e))
+        assert e < TOL, k
+    # prefix beam search: device path (fused softmax + top-n on the GPU logits, host search) against the HOST path
+    # (`mi355asr_ctc_prefix_beam_host`, bit-exact vs the reference decoder's KATs) on the ORACLE's probabilities
+    counts = ref["counts"]
+    p_ref = co.softmax(ref["text_logits"]).astype(np.float32)
+    for beam in (10, 100):
+        a = ctc_prefix_beam_decode(got["text_logits"], counts, beam, 0.99, 40, is_logits=True)
+        b = ctc_prefix_beam_decode(p_ref, counts, beam, 0.99, 40)
+        for u in range(2):
+            na, nb = a[1][u, 0], b[1][u, 0]
+            # best hypothesis: same token sequence, score within the logit error accumulated over the frames
+            assert na == nb and np.array_equal(a[0][u, 0, :na], b[0][u, 0, :nb]), (beam, u)
+            assert abs(a[2][u, 0] - b[2][u, 0]) < 1e-4 * counts[u] + 1e-3
+            assert na > 20
+        # the whole beam: near-ties may swap neighbouring ranks (scores are ~1e-3 apart at -4400); the hypothesis SETS
+        # must overlap almost completely
+        same, common, tot = 0, 0, 0
+        for u in range(2):
+            n = int(min(a[3][u], b[3][u]))
+            ha = [tuple(a[0][u, i, :a[1][u, i]]) for i in range(n)]
+            hb = [tuple(b[0][u, i, :b[1][u, i]]) for i in range(n)]
+            same += sum(int(p == q) for p, q in zip(ha, hb))
+            common += len(set(ha) & set(hb))
+            tot += n
+        print("config 5 beam %d: %d / %d hypotheses identical in rank, %d in common" % (beam, same, tot, common))
+        assert same >= 0.5 * tot and common >= 0.85 * tot
