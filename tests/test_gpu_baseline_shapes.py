@@ -226,8 +226,8 @@ def test_config5_chunk_conformer_2x30s_stages_and_beam_vs_oracle(torch_cuda):
             assert na == nb and np.array_equal(a[0][u, 0, :na], b[0][u, 0, :nb]), (beam, u)
             assert abs(a[2][u, 0] - b[2][u, 0]) < 1e-4 * counts[u] + 1e-3
             assert na > 20
-        # the whole beam: near-ties may swap neighbouring ranks (scores are ~1e-3 apart at -4400); the hypothesis SETS
-        # must overlap almost completely
+        # the whole beam: neighbouring hypotheses are ~1e-3 apart at scores of -4400 (fp32 resolution 5e-4), so ranks
+        # below the first may swap under a 1e-6 perturbation of the logits; the hypothesis SETS must agree
         same, common, tot = 0, 0, 0
         for u in range(2):
             n = int(min(a[3][u], b[3][u]))
@@ -236,5 +236,6 @@ def test_config5_chunk_conformer_2x30s_stages_and_beam_vs_oracle(torch_cuda):
             same += sum(int(p == q) for p, q in zip(ha, hb))
             common += len(set(ha) & set(hb))
             tot += n
+            assert np.abs(np.sort(a[2][u, :n]) - np.sort(b[2][u, :n])).max() < 1e-4 * counts[u] + 1e-3
         print("config 5 beam %d: %d / %d hypotheses identical in rank, %d in common" % (beam, same, tot, common))
-        assert same >= 0.5 * tot and common >= 0.85 * tot
+        assert common >= 0.9 * tot
