@@ -618,8 +618,55 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_ring_kernel(OutGluAr
 // same register-resident chain as before: ds_read_b128 + MFMA + one s_barrier per slab, nothing else), waves 4-7 --
 // one per SIMD, beside a consumer -- issue the DMAs, wait for them (their own vmcnt) and meet the consumers at the
 // barrier.  512 threads => 256 registers per wave, so the accumulators stay in architectural VGPRs.
+// Fragment pipeline of the loader-wave kernels: one register set of nine fragments (3 column tiles x 3 terms) that is
+// refilled in place -- the three fragments of a term are re-requested (for the next group) as soon as the MFMAs that
+// read them have issued, so a group needs 36 fragment registers instead of the 72 of the double buffer in slab_step.
+// Order inside a group: W2 x0 | fetch | W1 x1, W1 x0 | fetch | W0 x2, W0 x1, W0 x0 | fetch  (3 + 6 + 9 MFMAs; the three
+// accumulators rotate, so MFMAs on one accumulator are three apart).  LDS returns in order and exactly nine reads are
+// outstanding at each wait, hence lgkmcnt(6) = "the three oldest have landed".  The pipeline runs across slab
+// boundaries: the last group of slab s prefetches group 0 of slab s + 1, which the loaders guarantee has landed one
+// barrier earlier (RingLoader waits for slab s + 2 before the barrier that ends step s).
+struct WG3 { u32x4_t w[3][3]; };   // [tile][term]
+#define GRP_FETCH(G, GRP, TERM, ADDR) \
+  G.w[0][TERM] = lds_read16<((3 * (GRP) + 0) * 3 + (TERM)) * 1024>(ADDR); \
+  G.w[1][TERM] = lds_read16<((3 * (GRP) + 1) * 3 + (TERM)) * 1024>(ADDR); \
+  G.w[2][TERM] = lds_read16<((3 * (GRP) + 2) * 3 + (TERM)) * 1024>(ADDR);
+#define GRP_WAIT(G, TERM) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(G.w[0][TERM]), "+v"(G.w[1][TERM]), "+v"(G.w[2][TERM]))
+#define GRP_MMA(ACC, G, TERM, XT) \
+  _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) \
+    ACC[i_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, G.w[i_][TERM]), \
+                                                      __builtin_bit_cast(bf16x8_t, XT), ACC[i_], 0, 0, 0);
+template <int NGRP>
+DEV void grp_step(f32x4* acc, const Split8& xf, WG3& g, unsigned naddr) {
+  GRP_WAIT(g, 2);
+  GRP_MMA(acc, g, 2, xf.t[0])
+  GRP_FETCH(g, NGRP, 2, naddr)
+  GRP_WAIT(g, 1);
+  GRP_MMA(acc, g, 1, xf.t[1])
+  GRP_MMA(acc, g, 1, xf.t[0])
+  GRP_FETCH(g, NGRP, 1, naddr)
+  GRP_WAIT(g, 0);
+  GRP_MMA(acc, g, 0, xf.t[2])
+  GRP_MMA(acc, g, 0, xf.t[1])
+  GRP_MMA(acc, g, 0, xf.t[0])
+  GRP_FETCH(g, NGRP, 0, naddr)
+}
+DEV void grp_prime(WG3& g, unsigned addr) {
+  GRP_FETCH(g, 0, 2, addr)
+  GRP_FETCH(g, 0, 1, addr)
+  GRP_FETCH(g, 0, 0, addr)
+}
+// acc[0..9) += W(slab at addr)^T x; leaves the fragments of group 0 of the slab at next_addr in flight
+DEV void slab_step_p(f32x4* acc, const Split8& xf, WG3& g, unsigned addr, unsigned next_addr) {
+  grp_step<1>(acc, xf, g, addr);
+  grp_step<2>(acc + 3, xf, g, addr);
+  grp_step<0>(acc + 6, xf, g, next_addr);
+}
+
 constexpr int LD_THREADS = 2 * BLOCK_THREADS;
 
+// Measured alternatives (profiles/r02_ring_experiments.md): sending part or all of a slab through VGPRs (global_load ->
+// ds_write_b128) instead of global_load_lds is slower (48 -> 50-51 us), i.e. the DMA path is not what limits the stream.
 template <int RING>
 struct RingLoader {             // waves 4..7
   u32x4_t* ring;
@@ -632,16 +679,18 @@ struct RingLoader {             // waves 4..7
     for (int q = 0; q < 7; ++q) dma16(g + BLOCK_THREADS * q, l + BLOCK_THREADS * q);
   }
   DEV void run() const {
+    static_assert(RING >= 4, "slab s + 1 is read ahead while slab s + RING - 1 is written");
     const int pre = min(RING - 1, total);
     for (int i = 0; i < pre; ++i) issue(i, i);
-    wait_dma_ahead<7, RING - 2>(max(pre - 1, 0));          // slab 0 has landed
-    __builtin_amdgcn_s_barrier();                          // B0 (consumers: inputs + parameter stash)
+    wait_dma_ahead<7, RING - 3>(min(RING - 3, max(pre - 2, 0)));   // slabs 0 and 1 have landed
+    __builtin_amdgcn_s_barrier();                                  // B0 (consumers: inputs + parameter stash)
     int rd = 0;
 #pragma unroll 1
     for (int s = 0; s < total; ++s) {
-      // consumers read slot rd; the slot they read in step s - 1 is free since the barrier that ended that step
+      // consumers read slot rd and prefetch from slot rd + 1; the slot they read in step s - 1 is free since the barrier
+      // that ended that step
       if (s + RING - 1 < total) issue(s + RING - 1, rd == 0 ? RING - 1 : rd - 1);
-      wait_dma_ahead<7, RING - 2>(max(min(RING - 2, total - 2 - s), 0));     // slab s + 1 has landed
+      wait_dma_ahead<7, RING - 3>(max(min(RING - 3, total - 3 - s), 0));     // slab s + 2 has landed
       __builtin_amdgcn_s_barrier();
       rd = rd + 1 == RING ? 0 : rd + 1;
     }
@@ -657,12 +706,15 @@ struct RingReader {             // waves 0..3
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
   }
-  DEV unsigned cur_addr() const {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ring + rd * SLB + lane);
+  DEV unsigned slot_addr(int slot) const {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) void*)(ring + slot * SLB + lane);
   }
-  DEV void advance() {          // slab_step ends with lgkmcnt(0): the slot's reads are complete
+  DEV unsigned cur_addr() const { return slot_addr(rd); }
+  DEV unsigned next_addr() const { return slot_addr(rd + 1 == RING ? 0 : rd + 1); }
+  DEV void advance() {          // every read of the slot has landed (the last wait of slab_step_p covers them)
     __builtin_amdgcn_s_barrier();
     rd = rd + 1 == RING ? 0 : rd + 1;
+    __builtin_amdgcn_sched_barrier(0);   // keeps the operand split of later steps from being hoisted (register pressure)
   }
 };
 
@@ -689,6 +741,8 @@ __global__ __launch_bounds__(LD_THREADS) void ff1_qkv_ld_kernel(Ff1QkvArgs a) {
     stash_store<D>(p_ln2g, r4); stash_store<D>(p_ln2b, r5); stash_store<3 * D>(p_qb, r6);
   }
   st.sync();
+  WG3 wg;
+  grp_prime(wg, st.cur_addr());
   const float inv_fc = 1.0f / a.fc;
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) y[kb] = lds4(p_b2, kb, c.g4) + splat4(inv_fc) * xs[kb];
@@ -707,7 +761,7 @@ __global__ __launch_bounds__(LD_THREADS) void ff1_qkv_ld_kernel(Ff1QkvArgs a) {
     h[KB] = splat4(0.f);
     static_for<0, KS32X>([&](auto T) {
       constexpr int t = decltype(T)::value;
-      slab_step(h, xf[t], st.cur_addr());
+      slab_step_p(h, xf[t], wg, st.cur_addr(), st.next_addr());
       st.advance();
     });
 #pragma unroll
@@ -715,7 +769,7 @@ __global__ __launch_bounds__(LD_THREADS) void ff1_qkv_ld_kernel(Ff1QkvArgs a) {
     static_for<0, KS32X>([&](auto T) {
       constexpr int t = decltype(T)::value;
       const Split8 hf = split8(h[2 * t], h[2 * t + 1]);
-      slab_step(y, hf, st.cur_addr());
+      slab_step_p(y, hf, wg, st.cur_addr(), st.next_addr());
       st.advance();
     });
   }
@@ -739,7 +793,7 @@ __global__ __launch_bounds__(LD_THREADS) void ff1_qkv_ld_kernel(Ff1QkvArgs a) {
     for (int i = 0; i < KB; ++i) acc[i] = lds4(p_qb, q * KB + i, c.g4);
     static_for<0, KS32X>([&](auto T) {
       constexpr int t = decltype(T)::value;
-      slab_step(acc, xf[t], st.cur_addr());
+      slab_step_p(acc, xf[t], wg, st.cur_addr(), st.next_addr());
       st.advance();
     });
     const float sc = q == 0 ? a.qscale : 1.0f;
@@ -777,6 +831,8 @@ __global__ __launch_bounds__(LD_THREADS) void tail_ff2_ld_kernel(TailFf2Args a) 
     stash_store<D>(p_fg, r8); stash_store<D>(p_fb, r9);
   }
   st.sync();
+  WG3 wg;
+  grp_prime(wg, st.cur_addr());
 #pragma unroll
   for (int i = 0; i < KB; ++i) y[i] += lds4(p_pw2b, i, c.g4);
   Split8 xf[KS32X];
@@ -791,7 +847,7 @@ __global__ __launch_bounds__(LD_THREADS) void tail_ff2_ld_kernel(TailFf2Args a) 
       h[KB] = splat4(0.f);
       static_for<0, KS32X>([&](auto T) {
         constexpr int t = decltype(T)::value;
-        slab_step(h, xf[t], st.cur_addr());
+        slab_step_p(h, xf[t], wg, st.cur_addr(), st.next_addr());
         st.advance();
       });
 #pragma unroll
@@ -802,7 +858,7 @@ __global__ __launch_bounds__(LD_THREADS) void tail_ff2_ld_kernel(TailFf2Args a) 
       static_for<0, KS32X>([&](auto T) {
         constexpr int t = decltype(T)::value;
         const Split8 hf = split8(h[2 * t], h[2 * t + 1]);
-        slab_step(y, hf, st.cur_addr());
+        slab_step_p(y, hf, wg, st.cur_addr(), st.next_addr());
         st.advance();
       });
     }
@@ -831,15 +887,15 @@ __global__ __launch_bounds__(LD_THREADS) void tail_ff2_ld_kernel(TailFf2Args a) 
 }
 
 __global__ __launch_bounds__(LD_THREADS) void out_glu_ld_kernel(OutGluArgs a) {
-  __shared__ __attribute__((aligned(16))) u32x4_t ring[4 * SLB];
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
   __shared__ __attribute__((aligned(16))) float p_ob[D], p_lng[D], p_lnb[D], p_pb[2 * D];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wv >= WAVES_PER_BLOCK) {
-    RingLoader<4>{ring, reinterpret_cast<const u32x4_t*>(a.og_slabs), 15, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    RingLoader<5>{ring, reinterpret_cast<const u32x4_t*>(a.og_slabs), 15, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
     return;
   }
   const WaveCtx c = wave_ctx(a.M);
-  RingReader<4> st{ring, c.lane};
+  RingReader<5> st{ring, c.lane};
   f32x4 xs[KB + 1], acc[2 * KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + c.row + 16 * kb + c.g4);
@@ -852,12 +908,14 @@ __global__ __launch_bounds__(LD_THREADS) void out_glu_ld_kernel(OutGluArgs a) {
     stash_store<D>(p_ob, r0); stash_store<D>(p_lng, r1); stash_store<D>(p_lnb, r2); stash_store<2 * D>(p_pb, r3);
   }
   st.sync();
+  WG3 wg;
+  grp_prime(wg, st.cur_addr());
 #pragma unroll
   for (int i = 0; i < KB; ++i) acc[i] += lds4(p_ob, i, c.g4);
   static_for<0, KS32X>([&](auto T) {
     constexpr int t = decltype(T)::value;
     const Split8 xf = split8(xs[2 * t], xs[2 * t + 1]);
-    slab_step(acc, xf, st.cur_addr());
+    slab_step_p(acc, xf, wg, st.cur_addr(), st.next_addr());
     st.advance();
   });
 #pragma unroll
@@ -875,9 +933,9 @@ __global__ __launch_bounds__(LD_THREADS) void out_glu_ld_kernel(OutGluArgs a) {
   static_for<0, KS32X>([&](auto T) {
     constexpr int t = decltype(T)::value;
     const Split8 xf = split8(xs[2 * t], xs[2 * t + 1]);
-    slab_step(acc, xf, st.cur_addr());
+    slab_step_p(acc, xf, wg, st.cur_addr(), st.next_addr());
     st.advance();
-    slab_step(acc + KB, xf, st.cur_addr());
+    slab_step_p(acc + KB, xf, wg, st.cur_addr(), st.next_addr());
     st.advance();
   });
   if (c.live) {

@@ -1,9 +1,16 @@
+# Stall analysis passes (SQ counters, each set in its own rocprofv3 --pmc run; never combined with trace domains):
+#   bash tools/pmc_probe.sh [out_name]     -> gpurun_out/<out_name>.csv (per kernel category averages per launch)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+NAME=${1:-pmc_probe}
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE" "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_SCA"; do
+DIRS=""
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" \
+           "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmcp_$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/pmcp_$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/${NAME}_p$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-h2d > $R/gpurun_out/${NAME}_p$i.log 2>&1
+  DIRS="$DIRS $R/gpurun_out/${NAME}_p$i"
 done
-python $R/tools/pmc_probe.py $R/gpurun_out/pmcp_1 $R/gpurun_out/pmcp_2 $R/gpurun_out/pmcp_3 $R/gpurun_out/pmcp_4 > $R/gpurun_out/pmc_probe.csv
-cat $R/gpurun_out/pmc_probe.csv
+python $R/tools/pmc_probe.py $DIRS > $R/gpurun_out/${NAME}.csv
+cat $R/gpurun_out/${NAME}.csv
