@@ -39,7 +39,8 @@ def kernel_peak(name):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     if name == "sublinear" and int(os.environ.get("MI355ASR_SUBLINEAR_SPLIT", "1") or 0):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
-    ring = {"ff1_qkv": ("MI355ASR_FF1QKV_RING", "1"), "tail_ff2": ("MI355ASR_TAILFF2_RING", "1"), "out_glu": ("MI355ASR_OUTGLU_SPLIT", "2")}
+    ring = {"ff1_qkv": ("MI355ASR_FF1QKV_RING", "2"), "tail_ff2": ("MI355ASR_TAILFF2_RING", "2"), "out_glu": ("MI355ASR_OUTGLU_SPLIT", "3"),
+            "tail_ff1": ("MI355ASR_TAILFF2_RING", "2")}
     if name in ring and int(os.environ.get(*ring[name]) or 0):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA"
@@ -82,6 +83,8 @@ def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES, stft_mode=0):
         "ff1_qkv": 2.0 * 2 * M * d * 4 * d + 3 * 2.0 * M * d * d,
         "out_glu": 2.0 * M * d * d + 2.0 * M * d * 2 * d,
         "tail_ff2": 2.0 * M * d * 2 * d + 2.0 * M * 2 * d * d + 2.0 * 2 * M * d * 4 * d,
+        # tail_ff2 of one block + ff1_qkv of the next in one launch
+        "tail_ff1": 2.0 * M * d * 2 * d + 2.0 * M * 2 * d * d + 2 * (2.0 * 2 * M * d * 4 * d) + 3 * 2.0 * M * d * d,
     }
 
 
@@ -99,7 +102,8 @@ def algorithmic_bytes(B, L, cfg=S_CFG, V=NUM_CLASSES):
         "subconv": 4.0 * B * F * 80 + 4.0 * M * 20 * d + wb(9 * d + 9 * d * d), "sublinear": 4.0 * M * 20 * d + act + wb(20 * d * d),
         "ff1_qkv": act + act + 3 * act + wb(8 * d * d + 3 * d * d), "attention": 3 * act + act,
         "out_glu": act + act + act + act + wb(d * d + 2 * d * d), "dwconv": 2 * act + wb(k * d),
-        "tail_ff2": 3 * act + wb(4 * d * d + 8 * d * d), "ctc_project": 2 * act + wb(d * d),
+        "tail_ff2": 3 * act + wb(4 * d * d + 8 * d * d), "tail_ff1": 2 * act + act + 3 * act + wb(4 * d * d + 16 * d * d + 3 * d * d),
+        "ctc_project": 2 * act + wb(d * d),
         "ctc_head": act + 4.0 * M + wb(d * V),
     }
 
@@ -196,7 +200,7 @@ def main():
     h = model._h
 
     def step():
-        ids, lens = model.recognize(wav)
+        ids, lens = model.recognize(wav, reuse_buffers=True)     # the C-ABI call writes into pre-allocated outputs
         if use_dist:
             return all_gather_ids(ids, lens)
         return ids, lens
@@ -250,7 +254,7 @@ def main():
 
         def serial():
             dev_bufs[0].copy_(host, non_blocking=True)
-            model.recognize(dev_bufs[0])
+            model.recognize(dev_bufs[0], reuse_buffers=True)
 
         for _ in range(2):
             serial()
@@ -278,7 +282,7 @@ def main():
                         dev_bufs[nxt].copy_(host, non_blocking=True)
                         ready[nxt].record(copy_stream)
                 main_stream.wait_event(ready[cur])
-                model.recognize(dev_bufs[cur])
+                model.recognize(dev_bufs[cur], reuse_buffers=True)
                 freed[cur].record(main_stream)
 
         overlapped(3)

@@ -16,7 +16,12 @@
  *     asynchronously on it; nothing synchronises the device
  *   - a handle is not re-entrant: one in-flight call per handle (the reference's C++ Session has the
  *     same contract, asr_session.h keeps mutable buffers); distinct handles are independent
- *   - all arithmetic is IEEE fp32 (v_mfma_f32_16x16x4_f32 + fp32 VALU), matching the reference's dtype
+ *   - values and accumulation are fp32 everywhere, matching the reference's dtype.  Products are formed either by the
+ *     fp32 matrix instruction (v_mfma_f32_16x16x4_f32, an exact fp32 FMA chain) or, in the large dmodel-144 kernels
+ *     (subsampling, the fused block kernels, the LEAF Gabor convolution), on the bf16 matrix pipe from operands that are
+ *     split EXACTLY into three bf16 terms each (six v_mfma_f32_16x16x32_bf16 per product group; the dropped term pairs are
+ *     below 2^-24 of a product) -- measured error against the fp64 oracle is the same for both.
+ *     gemm_dtype = 1 is the separate, lossy bf16 mode (operands rounded to bf16).
  */
 #ifndef MI355ASR_H
 #define MI355ASR_H
@@ -79,6 +84,14 @@ int mi355asr_destroy(mi355asr_model* m);
  * May be called again after finalisation to overwrite a tensor (then finalise again). */
 int mi355asr_load_weight(mi355asr_model* m, const char* name, const float* data_host, int32_t rank,
                          const int64_t* dims);
+/* the same for checkpoints that store other element types (`load_weights(handle, name, host_ptr, dtype, rank,
+ * dims)`): the tensor is converted to fp32 on the host.  bf16 / fp16 are the raw 16-bit patterns. */
+#define MI355ASR_DT_F32 0
+#define MI355ASR_DT_F16 1
+#define MI355ASR_DT_BF16 2
+#define MI355ASR_DT_F64 3
+int mi355asr_load_weight_typed(mi355asr_model* m, const char* name, const void* data_host, int32_t dtype, int32_t rank,
+                               const int64_t* dims);
 /* number of tensors the configuration expects / name of the i-th one (so loaders can iterate) */
 int mi355asr_num_weights(const mi355asr_model* m);
 const char* mi355asr_weight_name(const mi355asr_model* m, int32_t i);
@@ -294,7 +307,8 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids_dev, const
 #define MI355ASR_K_FF1_QKV 15     /* ff1_qkv_kernel       FFModule 1 + LN + q/k/v projections (fused, dmodel 144)     */
 #define MI355ASR_K_OUT_GLU 16     /* out_glu_kernel       out-projection + residual + LN + pw_conv_1 + GLU (fused)    */
 #define MI355ASR_K_TAIL_FF2 17    /* tail_ff2_kernel      ConvModule tail + FFModule 2 + block LayerNorm (fused)      */
-#define MI355ASR_NUM_KERNELS 18
+#define MI355ASR_K_TAIL_FF1 18    /* tail_ff1_ld_kernel   tail_ff2 of block i + ff1_qkv of block i + 1 in one launch  */
+#define MI355ASR_NUM_KERNELS 19
 int mi355asr_profile_enable(mi355asr_model* m, int32_t on);
 int mi355asr_profile_read(mi355asr_model* m, double* ms_out, int64_t* count_out, int32_t n, int32_t reset);
 

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mi355asr_create": (ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(_P)]),
     "mi355asr_destroy": (ctypes.c_int, [_P]),
     "mi355asr_load_weight": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _I, ctypes.POINTER(ctypes.c_int64)]),
+    "mi355asr_load_weight_typed": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
     "mi355asr_num_weights": (ctypes.c_int, [_P]),
     "mi355asr_stft_mode": (ctypes.c_int, [_P]),
     "mi355asr_weight_name": (ctypes.c_char_p, [_P, _I]),
@@ -97,7 +98,7 @@ SIGNATURES = {
 }
 
 KERNEL_NAMES = ["stft", "utt_max", "mel", "subconv", "sublinear", "ffn", "qkv", "attention", "attn_out", "pw1_glu",
-                "dwconv", "conv_tail", "ctc_project", "ctc_head", "collapse", "ff1_qkv", "out_glu", "tail_ff2"]
+                "dwconv", "conv_tail", "ctc_project", "ctc_head", "collapse", "ff1_qkv", "out_glu", "tail_ff2", "tail_ff1"]
 
 _lib = None
 

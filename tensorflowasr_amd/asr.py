@@ -7,7 +7,8 @@
 
 Same construction (featurizers from `inp_config` / `tar_config` / `speech_config`, encoder / CTCDecoder / Translator
 from `model_config`), same checkpoint directory convention (`<outdir>/{encoder,ctc_decoder,translator}-ckpt/
-model_<step>.<ext>`, highest step wins; `.npz` of Keras-layout tensors instead of `.h5`), same
+model_<step>.<ext>`, highest step wins; the reference's Keras `.h5` files, TensorFlow checkpoints and `.npz` files of
+Keras-layout tensors are all read directly -- checkpoint.latest_checkpoint), same
 outputs (`' '.join(phones), ''.join(text)`).  Everything between the waveform and the token ids runs through
 libmi355asr.so; there is no CPU path."""
 import logging
@@ -78,12 +79,8 @@ class ASR:
     # test_asr.py:95-114
     @staticmethod
     def _latest(checkpoint_dir):
-        files = [f for f in os.listdir(checkpoint_dir) if f.endswith(".npz")]
-        if not files:
-            raise FileNotFoundError("no model_<step>.npz in %s (Keras .h5 checkpoints: convert first, INTEGRATION.md)"
-                                    % checkpoint_dir)
-        files.sort(key=lambda x: int(x.split("_")[-1].replace(".npz", "")))
-        return os.path.join(checkpoint_dir, files[-1])
+        from .checkpoint import latest_checkpoint
+        return latest_checkpoint(checkpoint_dir)
 
     def load_checkpoint(self):
         for sub, model, by_name in (("encoder-ckpt", self.encoder, True), ("ctc_decoder-ckpt", self.ctc_model, False),
@@ -97,7 +94,8 @@ class ASR:
         """softmax + tf.keras.backend.ctc_decode(greedy) + clip(-1 -> 0) (test_asr.py:196-200): per-frame argmax
         inside the CTC head kernel, merge/blank-drop on the device."""
         _, frame_ids = self.ctc_model(enc_outputs, training=False, return_argmax=True)
-        ids, lens = ctc_greedy_decode(frame_ids, None, blank=self.phone_featurizer.blank)
+        # tf.keras.backend.ctc_decode: the blank is the LAST class (num_classes - 1), independent of `blank_at_zero`
+        ids, lens = ctc_greedy_decode(frame_ids, None, blank=self.phone_featurizer.num_classes - 1)
         # ctc_decode's dense output is as wide as the longest decoded sequence of the batch, padded with -1; the
         # width matters: the Translator has no mask, padded positions reach their neighbours through its ConvModule
         width = int(lens.max().item())

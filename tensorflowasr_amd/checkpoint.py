@@ -17,6 +17,7 @@ No onnx / protobuf package is used: the ONNX file is a protobuf whose few fields
 (onnx.proto3: ModelProto.graph = 7; GraphProto.node = 1, initializer = 5; NodeProto.input = 1, output = 2, name = 3,
 op_type = 4, attribute = 5; AttributeProto.name = 1, i = 3, ints = 8; TensorProto.dims = 1, data_type = 2,
 float_data = 4, int32_data = 5, int64_data = 7, name = 8, raw_data = 9)."""
+import os
 import re
 import struct
 
@@ -293,7 +294,8 @@ def ctc_decoder_weights_from_onnx(path, num_heads=4):
 # ---------------------------------------------------------------------------------------------------------
 # Keras variable names -> C-ABI names
 # ---------------------------------------------------------------------------------------------------------
-_AUTO = re.compile(r"^(layer_normalization|dense|conv2d|multi_head_attention|batch_normalization)(?:_(\d+))?$")
+_AUTO = re.compile(r"^(layer_normalization|dense|conv2d|multi_head_attention|batch_normalization|conv1d|separable_conv1d|"
+                   r"tf_residual_stack|embedding)(?:_(\d+))?$")
 
 
 def keras_names_to_abi(names):
@@ -308,15 +310,20 @@ def keras_names_to_abi(names):
     Typical use on a machine that has TensorFlow:
         m = keras_names_to_abi([v.name for v in model.weights])
         np.savez("encoder.npz", **{m[v.name]: v.numpy() for v in model.weights if v.name in m})"""
-    anchors = ("mel_layer", "conv_subsampling", "wav_layer", "conformer_block_", "decoder_conformer_block_",
-               "fully_connected", "dense")
+    anchors = ("mel_layer", "conv_subsampling", "wav_layer", "wave_pick_model", "conformer_block_",
+               "decoder_conformer_block_", "fully_connected", "dense", "embedding", "inp_embedding")
     parsed = []
     for full in names:
         parts = full.split(":")[0].split("/")
         start = next((i for i, p in enumerate(parts) if p.startswith(anchors)), None)
         if start is None:
             continue
-        parsed.append((full, parts[start:]))
+        parts = parts[start:]
+        if parts[0].startswith(("wave_pick_model", "wav_layer")):
+            # WavePickModel (wav_model.py:108-131) is a Layer named wave_pick_model holding one Sequential: the scope is
+            # wave_pick_model/sequential[_n]/<layer>/...; the C-ABI prefix is the attribute name, wav_layer
+            parts = ["wav_layer"] + [q for q in parts[1:] if not re.match(r"^sequential(_\d+)?$", q)]
+        parsed.append((full, parts))
 
     def auto_index(p):
         m = _AUTO.match(p)
@@ -357,6 +364,18 @@ def keras_names_to_abi(names):
                 scope.append(("ffn1", "ffn2")[r] if r < 2 else None)
             elif kind == "dense" and depth == 0:
                 scope.append("project")                 # CTCDecoder.project (conformer_blocks.py:400)
+            elif kind == "embedding" and depth == 0:
+                scope.append("inp_embedding")           # Translator.inp_embedding (conformer_blocks.py:536)
+            elif kind == "separable_conv1d" and parent == "wav_layer":
+                scope.append("sep_conv")
+            elif kind == "tf_residual_stack" and parent == "wav_layer":
+                scope.append("res_%d" % (r + 1))        # construction order (wav_model.py:118-124)
+            elif kind == "conv1d" and parent == "wav_layer":
+                # the strided Conv1D of each stage, then the final Conv1D(dout, 7): the last one in construction order
+                n_here = len(rank[(tuple(parts[:depth]), "conv1d")])
+                scope.append("final" if r == n_here - 1 else "conv_%d" % (r + 1))
+            elif kind == "conv1d" and auto_index(parent) and auto_index(parent)[0] == "tf_residual_stack":
+                scope.append(("conv5", "conv1")[r] if r < 2 else None)      # TFResidualStack.blocks (wav_model.py:78-92)
             else:
                 ok = False
             if scope and scope[-1] is None:
@@ -463,3 +482,31 @@ def chunk_checkpoint_to_abi(path):
             v = v.reshape(v.shape[0], v.shape[-1])
         out[abi] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# checkpoint directories (test_asr.py:95-114, ctc_runners.py:272-325)
+# ---------------------------------------------------------------------------------------------------------
+_STEP = re.compile(r"^model_(\d+)(\.npz|\.h5|\.hdf5|\.index|\.ckpt\.index|\.onnx)?$")
+_PREFER = {".npz": 0, ".h5": 1, ".hdf5": 1, ".index": 2, ".ckpt.index": 2, ".onnx": 3}
+
+
+def latest_checkpoint(checkpoint_dir):
+    """The newest `model_<step>` of a `<outdir>/<sub-model>-ckpt/` directory, as the reference picks it
+    (`files.sort(key=lambda x: int(x.split('_')[-1].replace('.h5', '')))`, test_asr.py:96-100): Keras `.h5` weight
+    files as the trainers write them, TensorFlow checkpoints (`model_<step>.index` + data shards), or the `.npz` /
+    `.onnx` forms this package also reads.  Files that do not look like `model_<step>.<ext>` are ignored; among
+    several formats of the same step `.npz` wins, then `.h5`, then the TensorFlow bundle.  Returns the path to hand
+    to `Model.load_weights` (for a TensorFlow bundle: the prefix without `.index`)."""
+    best = None
+    for f in os.listdir(checkpoint_dir):
+        m = _STEP.match(f)
+        if not m or not m.group(2):
+            continue
+        key = (int(m.group(1)), -_PREFER[m.group(2)])
+        if best is None or key > best[0]:
+            best = (key, f, m.group(2))
+    if best is None:
+        raise FileNotFoundError("no model_<step>.{h5,npz,index} in %s" % checkpoint_dir)
+    path = os.path.join(checkpoint_dir, best[1])
+    return path[:-len(".index")] if best[2].endswith(".index") else path

@@ -415,7 +415,8 @@ int geometry(const mi355asr_model* m, int B, int L, Geometry* g) {
 // q = LN(x + PE) and k = v = the encoder output (T_enc frames per utterance), everything else is a ConformerBlock.
 
 int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int B, int T,
-              float* out, hipStream_t s, const CrossAttn* cross) {
+              float* out, hipStream_t s, const CrossAttn* cross, const BlockDev* next, bool* ff1_done, bool skip_ff1) {
+  if (ff1_done) *ff1_done = false;
   const int d = m->cfg.dmodel, H = m->cfg.num_heads, hs = m->cfg.head_size;
   const int ksz = bo.ksz;
   const float fc = bo.fc;
@@ -482,13 +483,19 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
   if (d == 144 && fused_env && !cross) {
     // token-local runs of layers in one launch each (fused.hip); attention and the depthwise conv mix tokens
     const float qscale = 1.0f / std::sqrt((float)hs);
-    Ff1QkvArgs k1{};
-    k1.x0 = sc.xa; k1.x1 = sc.xb; k1.qkv = sc.qkv;
-    k1.ff_ln_g = w.ff_ln_g[0]; k1.ff_ln_b = w.ff_ln_b[0]; k1.ff_w1p = w.ff_w1p[0]; k1.ff_b1 = w.ff_b1[0];
-    k1.ff_w2p = w.ff_w2p[0]; k1.ff_b2 = w.ff_b2[0];
-    k1.att_ln_g = w.att_ln_g; k1.att_ln_b = w.att_ln_b; k1.qkv_wp = w.qkv_wp; k1.qkv_b = w.qkv_b;
-    k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M; k1.slabs = w.ff1_slabs;
-    { PROF(MI355ASR_K_FF1_QKV); LAUNCH_TRY(launch_ff1_qkv(k1, s), "ff_module_1 + qkv"); }
+    auto ff1_args = [&](const BlockDev& bw, const float* x0, float* x1) {
+      Ff1QkvArgs k1{};
+      k1.x0 = x0; k1.x1 = x1; k1.qkv = sc.qkv;
+      k1.ff_ln_g = bw.ff_ln_g[0]; k1.ff_ln_b = bw.ff_ln_b[0]; k1.ff_w1p = bw.ff_w1p[0]; k1.ff_b1 = bw.ff_b1[0];
+      k1.ff_w2p = bw.ff_w2p[0]; k1.ff_b2 = bw.ff_b2[0];
+      k1.att_ln_g = bw.att_ln_g; k1.att_ln_b = bw.att_ln_b; k1.qkv_wp = bw.qkv_wp; k1.qkv_b = bw.qkv_b;
+      k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M; k1.slabs = bw.ff1_slabs;
+      return k1;
+    };
+    if (!skip_ff1) {
+      const Ff1QkvArgs k1 = ff1_args(w, sc.xa, sc.xb);
+      PROF(MI355ASR_K_FF1_QKV); LAUNCH_TRY(launch_ff1_qkv(k1, s), "ff_module_1 + qkv");
+    }
     AttnArgs at{};
     at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ctx = sc.ctx;
   at.B = B; at.Tq = T; at.Tk = T; at.H = H; at.D = d; at.ldq = 3 * d; at.ldk = 3 * d;
@@ -510,6 +517,21 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];
     k4.ff_w2p = w.ff_w2p[1]; k4.ff_b2 = w.ff_b2[1]; k4.ln_g = w.ln_g; k4.ln_b = w.ln_b;
     k4.fc = fc; k4.eps = kLnEps; k4.M = M; k4.slabs = w.tail_slabs;
+    if (next && !out && ff1_done && tail_ff1_available() && k4.slabs && next->ff1_slabs) {
+      // the block output feeds only the next block's ff_module_1: keep it in registers, write x1 (into the buffer the
+      // next block knows as sc.xb after the swap below -- this block's x2, which each workgroup has consumed) and qkv
+      TailFf2Args kf = k4;
+      kf.y = nullptr;
+      const Ff1QkvArgs kn = ff1_args(*next, nullptr, sc.xa);
+      PROF(MI355ASR_K_TAIL_FF1);
+      if (launch_tail_ff1(kf, kn, s) == 0) {
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) return fail(MI355ASR_EHIP, "conv tail + ff_module_2 + next ff_module_1: %s", hipGetErrorString(e_));
+        *ff1_done = true;
+        std::swap(sc.xa, sc.xb);
+        return 0;
+      }
+    }
     { PROF(MI355ASR_K_TAIL_FF2); LAUNCH_TRY(launch_tail_ff2(k4, s), "conv tail + ff_module_2"); }
     if (!out) std::swap(sc.xa, sc.xb);
     return 0;
@@ -777,11 +799,14 @@ int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const P
     if (rc) return rc;
   }
   const int nb = m->cfg.num_blocks;
+  bool ff1_done = false;
   for (int i = 0; i < nb; ++i) {
     BlockOpts bo;
     bo.ksz = m->cfg.kernel_size;
     bo.fc = m->cfg.fc_factor;
-    rc = run_block(m, m->enc_blocks[i], bo, sc, g.Bp, g.T, i == nb - 1 ? enc_out : nullptr, s);
+    const bool skip = ff1_done;
+    rc = run_block(m, m->enc_blocks[i], bo, sc, g.Bp, g.T, i == nb - 1 ? enc_out : nullptr, s, nullptr,
+                   i + 1 < nb ? &m->enc_blocks[i + 1] : nullptr, &ff1_done, skip);
     if (rc) return rc;
   }
   if (nb == 0) HIP_TRY(hipMemcpyAsync(enc_out, sc.xa, (size_t)g.Bp * g.T * m->cfg.dmodel * 4, hipMemcpyDeviceToDevice, s));
@@ -1030,6 +1055,43 @@ int mi355asr_load_weight(mi355asr_model* m, const char* name, const float* data,
   t.set = true;
   m->finalized = false;
   return 0;
+}
+
+int mi355asr_load_weight_typed(mi355asr_model* m, const char* name, const void* data, int32_t dtype, int32_t rank,
+                               const int64_t* dims) {
+  if (!data || rank < 0 || (rank > 0 && !dims)) return fail(MI355ASR_EINVAL, "null argument");
+  if (dtype == MI355ASR_DT_F32) return mi355asr_load_weight(m, name, (const float*)data, rank, dims);
+  int64_t n = 1;
+  for (int i = 0; i < rank; ++i) n *= dims[i];
+  if (n < 0 || n > ((int64_t)1 << 32)) return fail(MI355ASR_EINVAL, "weight '%s': bad element count", name ? name : "?");
+  std::vector<float> v((size_t)n);
+  if (dtype == MI355ASR_DT_F64) {
+    const double* p = (const double*)data;
+    for (int64_t i = 0; i < n; ++i) v[i] = (float)p[i];
+  } else if (dtype == MI355ASR_DT_BF16) {
+    const uint16_t* p = (const uint16_t*)data;
+    for (int64_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)p[i] << 16; std::memcpy(&v[i], &u, 4); }
+  } else if (dtype == MI355ASR_DT_F16) {
+    const uint16_t* p = (const uint16_t*)data;
+    for (int64_t i = 0; i < n; ++i) {
+      const uint32_t h = p[i], sign = (h & 0x8000u) << 16, e = (h >> 10) & 31, f = h & 1023;
+      uint32_t u;
+      if (e == 0) {
+        if (f == 0) u = sign;
+        else {                                           // subnormal half: normalise
+          int sh = 0;
+          uint32_t ff = f;
+          while (!(ff & 1024)) { ff <<= 1; ++sh; }
+          u = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((ff & 1023) << 13);
+        }
+      } else if (e == 31) u = sign | 0x7f800000u | (f << 13);
+      else u = sign | ((e + 112) << 23) | (f << 13);
+      std::memcpy(&v[i], &u, 4);
+    }
+  } else {
+    return fail(MI355ASR_EINVAL, "weight '%s': unknown dtype %d", name ? name : "?", dtype);
+  }
+  return mi355asr_load_weight(m, name, v.data(), rank, dims);
 }
 
 int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {

@@ -654,7 +654,83 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
     if (t0 + i < a.T) stg4(yb + (size_t)(t0 + i) * a.D, acc[i]);
 }
 
+// LDS-tiled depthwise conv: a workgroup owns 64 consecutive frames of one utterance x CB channels; the 64 + K - 1 input
+// rows it needs are staged once (coalesced, zero-filled outside the utterance), then each thread computes 8 frames x 4
+// channels from a register window read from LDS.  The version above re-reads its 39-row window per thread straight from
+// L2 (4.9x read amplification, 39 dependent-latency loads per thread): 15 us at 64 x 250 x 144; this one is bound by the
+// 9 MB in + 9 MB out.
+template <int K, int CB>
+__global__ __launch_bounds__(320) void dwconv_tile_kernel(DwArgs a) {
+  constexpr int TT = 64, TS = 8, C4 = CB / 4, ROWS = TT + K - 1;
+  __shared__ __attribute__((aligned(16))) float tile[ROWS * CB];
+  __shared__ __attribute__((aligned(16))) float wt[K * CB];        // the K x CB taps of this channel block
+  const int b = blockIdx.y, t0 = blockIdx.x * TT, c0 = blockIdx.z * CB;
+  const float* __restrict__ ub = a.u + (size_t)b * a.T * a.D + c0;
+  // all global loads first, then the LDS writes (a load -> write loop costs one L2 round trip per iteration)
+  constexpr int NT = ((CB / 4) * 8 + 63) / 64 * 64, NL = (ROWS * C4 + NT - 1) / NT, NW = (K * C4 + NT - 1) / NT;
+  f32x4 stage[NL], wstage[NW];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const int i = min((int)threadIdx.x + k * NT, K * C4 - 1);
+    const int j = i / C4, c = i - j * C4;
+    wstage[k] = ldg4(a.wd + (size_t)j * a.D + c0 + 4 * c);
+  }
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int i = threadIdx.x + k * NT;
+    const int r = i / C4, c = i - r * C4;
+    const int tt = t0 + r - a.pad_left;
+    stage[k] = (i < ROWS * C4 && tt >= 0 && tt < a.T) ? ldg4(ub + (size_t)tt * a.D + 4 * c) : splat4(0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int i = threadIdx.x + k * NT;
+    if (i < ROWS * C4) *reinterpret_cast<f32x4*>(&tile[4 * i]) = stage[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const int i = threadIdx.x + k * NT;
+    if (i < K * C4) *reinterpret_cast<f32x4*>(&wt[4 * i]) = wstage[k];
+  }
+  __syncthreads();
+  const int c = threadIdx.x % C4, tg = threadIdx.x / C4;
+  if (tg >= TT / TS) return;
+  f32x4 win[TS + K - 1];
+#pragma unroll
+  for (int i = 0; i < TS + K - 1; ++i) win[i] = *reinterpret_cast<const f32x4*>(&tile[(tg * TS + i) * CB + 4 * c]);
+  f32x4 acc[TS];
+#pragma unroll
+  for (int i = 0; i < TS; ++i) acc[i] = splat4(0.f);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(&wt[j * CB + 4 * c]);
+#pragma unroll
+    for (int i = 0; i < TS; ++i) acc[i] += win[i + j] * w;
+  }
+  float* yb = a.y + (size_t)b * a.T * a.D + c0 + 4 * c;
+#pragma unroll
+  for (int i = 0; i < TS; ++i) {
+    const int t = t0 + tg * TS + i;
+    if (t < a.T) stg4(yb + (size_t)t * a.D, acc[i]);
+  }
+}
+
+template <int K, int CB>
+static int launch_dwconv_tile(const DwArgs& a, hipStream_t s) {
+  const int threads = ((CB / 4) * 8 + 63) / 64 * 64;
+  hipLaunchKernelGGL((dwconv_tile_kernel<K, CB>), dim3((a.T + 63) / 64, a.B, a.D / CB), dim3(threads), 0, s, a);
+  return 0;
+}
+
 int launch_dwconv(int K, const DwArgs& a, hipStream_t s) {
+  // MI355ASR_DWCONV_TILE=0: the first-generation kernel (window re-read from L2 per thread)
+  static const int tile = [] { const char* v = getenv("MI355ASR_DWCONV_TILE"); return v ? atoi(v) : 1; }();
+  if (tile && a.T * a.B >= 2048) {
+    if (K == 32 && a.D == 144) return launch_dwconv_tile<32, 144>(a, s);
+    if (K == 32 && a.D % 128 == 0) return launch_dwconv_tile<32, 128>(a, s);
+    if (K == 5 && a.D % 128 == 0) return launch_dwconv_tile<5, 128>(a, s);
+    if (K == 5 && a.D == 144) return launch_dwconv_tile<5, 144>(a, s);
+  }
   constexpr int TT = 8;
   const int total = a.B * ((a.T + TT - 1) / TT) * (a.D / 4);
   dim3 grid((total + 255) / 256);

@@ -117,6 +117,22 @@ DEV WaveCtx wave_ctx(int M) {
   return c;
 }
 
+// the same, recomputed from an opaque copy of the thread index: long kernels call this again before their stores instead of
+// keeping the 64-bit row offset alive across the whole stream (it was the value the register allocator spilled)
+DEV WaveCtx wave_ctx_fresh(int M) {
+  unsigned tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  WaveCtx c;
+  c.lane = tid & 63;
+  c.g4 = (c.lane >> 4) * 4;
+  c.t = c.lane & 15;
+  const int wid = blockIdx.x * WAVES_PER_BLOCK + (int)(tid >> 6);
+  c.tok = wid * 16 + c.t;
+  c.live = c.tok < M;
+  c.row = (size_t)min(c.tok, M - 1) * D;
+  return c;
+}
+
 // LayerNorm with gamma / beta in LDS
 DEV void ln_lds(f32x4 (&xs)[KB], const float* ga, const float* be, int g4, float eps) {
   float mean, rstd;
@@ -670,10 +686,10 @@ constexpr int LD_THREADS = 2 * BLOCK_THREADS;
 template <int RING>
 struct RingLoader {             // waves 4..7
   u32x4_t* ring;
-  const u32x4_t* src;
-  int total, wv, lane;          // wv = 0..3
+  const u32x4_t *src, *src2;    // slabs [0, n1) from src, [n1, total) from src2
+  int n1, total, wv, lane;      // wv = 0..3
   DEV void issue(int slab, int slot) const {
-    const u32x4_t* g = src + (size_t)slab * SLB + 64 * wv + lane;
+    const u32x4_t* g = (slab < n1 ? src + (size_t)slab * SLB : src2 + (size_t)(slab - n1) * SLB) + 64 * wv + lane;
     u32x4_t* l = ring + slot * SLB + 64 * wv;
 #pragma unroll
     for (int q = 0; q < 7; ++q) dma16(g + BLOCK_THREADS * q, l + BLOCK_THREADS * q);
@@ -718,172 +734,209 @@ struct RingReader {             // waves 0..3
   }
 };
 
-__global__ __launch_bounds__(LD_THREADS) void ff1_qkv_ld_kernel(Ff1QkvArgs a) {
-  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
-  __shared__ __attribute__((aligned(16))) float p_ln1g[D], p_ln1b[D], p_b1[4 * D], p_b2[D], p_ln2g[D], p_ln2b[D], p_qb[3 * D];
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (wv >= WAVES_PER_BLOCK) {
-    RingLoader<5>{ring, reinterpret_cast<const u32x4_t*>(a.slabs), 55, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
-    return;
-  }
-  const WaveCtx c = wave_ctx(a.M);
-  RingReader<5> st{ring, c.lane};
-  f32x4 xs[KB + 1], y[KB];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + c.row + 16 * kb + c.g4);
-  xs[KB] = splat4(0.f);
-  {
-    const auto r0 = stash_load<D>(a.ff_ln_g), r1 = stash_load<D>(a.ff_ln_b), r3 = stash_load<D>(a.ff_b2),
-               r4 = stash_load<D>(a.att_ln_g), r5 = stash_load<D>(a.att_ln_b);
-    const auto r2 = stash_load<4 * D>(a.ff_b1);
-    const auto r6 = stash_load<3 * D>(a.qkv_b);
-    stash_store<D>(p_ln1g, r0); stash_store<D>(p_ln1b, r1); stash_store<4 * D>(p_b1, r2); stash_store<D>(p_b2, r3);
-    stash_store<D>(p_ln2g, r4); stash_store<D>(p_ln2b, r5); stash_store<3 * D>(p_qb, r6);
-  }
-  st.sync();
-  WG3 wg;
-  grp_prime(wg, st.cur_addr());
-  const float inv_fc = 1.0f / a.fc;
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) y[kb] = lds4(p_b2, kb, c.g4) + splat4(inv_fc) * xs[kb];
-  {
-    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
-    ln_lds(xr, p_ln1g, p_ln1b, c.g4, a.eps);
-  }
-  Split8 xf[KS32X];
-#pragma unroll
-  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
+// LDS parameter blocks of the two long kernels (so that the fused tail + ff1 kernel can hold both)
+struct Ff1Lds { float ln1g[D], ln1b[D], b1[4 * D], b2[D], ln2g[D], ln2b[D], qb[3 * D]; };
+struct TailLds { float pcb[2 * D], bns[2 * D], bnt[2 * D], pw2b[D], lng[D], lnb[D], b1[4 * D], b2[D], fg[D], fb[D]; };
+
+DEV void ff1_stash(Ff1Lds& p, const Ff1QkvArgs& a) {
+  const auto r0 = stash_load<D>(a.ff_ln_g), r1 = stash_load<D>(a.ff_ln_b), r3 = stash_load<D>(a.ff_b2),
+             r4 = stash_load<D>(a.att_ln_g), r5 = stash_load<D>(a.att_ln_b);
+  const auto r2 = stash_load<4 * D>(a.ff_b1);
+  const auto r6 = stash_load<3 * D>(a.qkv_b);
+  stash_store<D>(p.ln1g, r0); stash_store<D>(p.ln1b, r1); stash_store<4 * D>(p.b1, r2); stash_store<D>(p.b2, r3);
+  stash_store<D>(p.ln2g, r4); stash_store<D>(p.ln2b, r5); stash_store<3 * D>(p.qb, r6);
+}
+DEV void tail_stash(TailLds& p, const TailFf2Args& a) {
+  const auto r0 = stash_load<2 * D>(a.pc_b1), r1 = stash_load<2 * D>(a.bn_s), r2 = stash_load<2 * D>(a.bn_t);
+  const auto r3 = stash_load<D>(a.pw2_b), r4 = stash_load<D>(a.ff_ln_g), r5 = stash_load<D>(a.ff_ln_b),
+             r7 = stash_load<D>(a.ff_b2), r8 = stash_load<D>(a.ln_g), r9 = stash_load<D>(a.ln_b);
+  const auto r6 = stash_load<4 * D>(a.ff_b1);
+  stash_store<2 * D>(p.pcb, r0); stash_store<2 * D>(p.bns, r1); stash_store<2 * D>(p.bnt, r2); stash_store<D>(p.pw2b, r3);
+  stash_store<D>(p.lng, r4); stash_store<D>(p.lnb, r5); stash_store<4 * D>(p.b1, r6); stash_store<D>(p.b2, r7);
+  stash_store<D>(p.fg, r8); stash_store<D>(p.fb, r9);
+}
+
+// y += W2 act(W1 x + b1) over nch hidden chunks of 9 tiles (10 slabs each); aff: act = swish(s (.) + t) (folded BatchNorm)
+template <bool AFF, class ST>
+DEV void ring_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS32X], ST& st, WG3& wg, int g4, int nch, const float* b1,
+                    const float* as, const float* at) {
 #pragma unroll 1
-  for (int ch = 0; ch < 4; ++ch) {
-    f32x4 h[KB + 1];
+  for (int ch = 0; ch < nch; ++ch) {
+    f32x4 h[KB];
 #pragma unroll
-    for (int i = 0; i < KB; ++i) h[i] = lds4(p_b1, ch * KB + i, c.g4);
-    h[KB] = splat4(0.f);
+    for (int i = 0; i < KB; ++i) h[i] = lds4(b1, ch * KB + i, g4);
     static_for<0, KS32X>([&](auto T) {
       constexpr int t = decltype(T)::value;
       slab_step_p(h, xf[t], wg, st.cur_addr(), st.next_addr());
       st.advance();
     });
 #pragma unroll
-    for (int i = 0; i < KB; ++i) h[i] = swish4(h[i]);
+    for (int i = 0; i < KB; ++i) {
+      if (AFF) h[i] = h[i] * lds4(as, ch * KB + i, g4) + lds4(at, ch * KB + i, g4);
+      h[i] = swish4(h[i]);
+    }
     static_for<0, KS32X>([&](auto T) {
       constexpr int t = decltype(T)::value;
-      const Split8 hf = split8(h[2 * t], h[2 * t + 1]);
+      const Split8 hf = split8(h[2 * t], 2 * t + 1 < KB ? h[2 * t + 1 < KB ? 2 * t + 1 : 0] : splat4(0.f));
       slab_step_p(y, hf, wg, st.cur_addr(), st.next_addr());
       st.advance();
     });
   }
+}
+
+// FFModule 1 + q/k/v projections of the 16 tokens in xs (x0 rows, xs[KB] = 0): 55 slabs; stores x1 and qkv
+template <class ST>
+DEV void ff1_consume(const Ff1QkvArgs& a, const Ff1Lds& p, const WaveCtx& c, ST& st, WG3& wg, f32x4 (&xs)[KB]) {
+  f32x4 y[KB];
+  const float inv_fc = 1.0f / a.fc;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) y[kb] = lds4(p.b2, kb, c.g4) + splat4(inv_fc) * xs[kb];
+  ln_lds(xs, p.ln1g, p.ln1b, c.g4, a.eps);
+  Split8 xf[KS32X];
+#pragma unroll
+  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], 2 * t + 1 < KB ? xs[2 * t + 1 < KB ? 2 * t + 1 : 0] : splat4(0.f));
+  ring_chain<false>(y, xf, st, wg, c.g4, 4, p.b1, nullptr, nullptr);
 #pragma unroll
   for (int i = 0; i < KB; ++i) { y[i] = splat4(a.fc) * y[i]; xs[i] = y[i]; }        // x1 = x0 + fc * (ffn + b2)
-  if (c.live) {
-#pragma unroll
-    for (int i = 0; i < KB; ++i) stg4(a.x1 + c.row + 16 * i + c.g4, y[i]);
-  }
   {
-    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
-    ln_lds(xr, p_ln2g, p_ln2b, c.g4, a.eps);
-  }
+    const WaveCtx e = wave_ctx_fresh(a.M);
+    if (e.live) {
 #pragma unroll
-  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
-  float* qrow = a.qkv + (size_t)min(c.tok, a.M - 1) * (3 * D);
+      for (int i = 0; i < KB; ++i) stg4(a.x1 + e.row + 16 * i + e.g4, y[i]);
+    }
+  }
+  ln_lds(xs, p.ln2g, p.ln2b, c.g4, a.eps);
+#pragma unroll
+  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], 2 * t + 1 < KB ? xs[2 * t + 1 < KB ? 2 * t + 1 : 0] : splat4(0.f));
 #pragma unroll 1
   for (int q = 0; q < 3; ++q) {                            // q, k, v: one accumulator set, stored as soon as it is done
     f32x4 acc[KB];
 #pragma unroll
-    for (int i = 0; i < KB; ++i) acc[i] = lds4(p_qb, q * KB + i, c.g4);
+    for (int i = 0; i < KB; ++i) acc[i] = lds4(p.qb, q * KB + i, c.g4);
     static_for<0, KS32X>([&](auto T) {
       constexpr int t = decltype(T)::value;
       slab_step_p(acc, xf[t], wg, st.cur_addr(), st.next_addr());
       st.advance();
     });
     const float sc = q == 0 ? a.qscale : 1.0f;
-    if (c.live) {
+    const WaveCtx e = wave_ctx_fresh(a.M);
+    if (e.live) {
+      float* qrow = a.qkv + (size_t)e.tok * (3 * D) + 16 * q * KB + e.g4;
 #pragma unroll
-      for (int i = 0; i < KB; ++i) stg4(qrow + 16 * (q * KB + i) + c.g4, acc[i] * splat4(sc));
+      for (int i = 0; i < KB; ++i) stg4(qrow + 16 * i, acc[i] * splat4(sc));
     }
   }
 }
 
-__global__ __launch_bounds__(LD_THREADS) void tail_ff2_ld_kernel(TailFf2Args a) {
-  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
-  __shared__ __attribute__((aligned(16))) float p_pcb[2 * D], p_bns[2 * D], p_bnt[2 * D], p_pw2b[D], p_lng[D], p_lnb[D], p_b1[4 * D],
-      p_b2[D], p_fg[D], p_fb[D];
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (wv >= WAVES_PER_BLOCK) {
-    RingLoader<5>{ring, reinterpret_cast<const u32x4_t*>(a.slabs), 60, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
-    return;
-  }
-  const WaveCtx c = wave_ctx(a.M);
-  RingReader<5> st{ring, c.lane};
-  f32x4 xs[KB + 1], y[KB];
+// conv-module tail + FFModule 2 + block-final LayerNorm: xs = dw rows (xs[KB] = 0), y = x2 rows on entry; y = the block's
+// output rows on exit.  60 slabs.
+template <class ST>
+DEV void tail_consume(const TailFf2Args& a, const TailLds& p, const WaveCtx& c, ST& st, WG3& wg, f32x4 (&xs)[KB],
+                      f32x4 (&y)[KB]) {
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
-  xs[KB] = splat4(0.f);
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + c.row + 16 * kb + c.g4);     // residuals ride in the accumulators
-  {
-    const auto r0 = stash_load<2 * D>(a.pc_b1), r1 = stash_load<2 * D>(a.bn_s), r2 = stash_load<2 * D>(a.bn_t);
-    const auto r3 = stash_load<D>(a.pw2_b), r4 = stash_load<D>(a.ff_ln_g), r5 = stash_load<D>(a.ff_ln_b),
-               r7 = stash_load<D>(a.ff_b2), r8 = stash_load<D>(a.ln_g), r9 = stash_load<D>(a.ln_b);
-    const auto r6 = stash_load<4 * D>(a.ff_b1);
-    stash_store<2 * D>(p_pcb, r0); stash_store<2 * D>(p_bns, r1); stash_store<2 * D>(p_bnt, r2); stash_store<D>(p_pw2b, r3);
-    stash_store<D>(p_lng, r4); stash_store<D>(p_lnb, r5); stash_store<4 * D>(p_b1, r6); stash_store<D>(p_b2, r7);
-    stash_store<D>(p_fg, r8); stash_store<D>(p_fb, r9);
-  }
-  st.sync();
-  WG3 wg;
-  grp_prime(wg, st.cur_addr());
-#pragma unroll
-  for (int i = 0; i < KB; ++i) y[i] += lds4(p_pw2b, i, c.g4);
+  for (int i = 0; i < KB; ++i) y[i] += lds4(p.pw2b, i, c.g4);
   Split8 xf[KS32X];
 #pragma unroll
-  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
-  auto chain = [&](int nch, const float* b1, const float* as, const float* at, bool aff) {
-#pragma unroll 1
-    for (int ch = 0; ch < nch; ++ch) {
-      f32x4 h[KB + 1];
-#pragma unroll
-      for (int i = 0; i < KB; ++i) h[i] = lds4(b1, ch * KB + i, c.g4);
-      h[KB] = splat4(0.f);
-      static_for<0, KS32X>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        slab_step_p(h, xf[t], wg, st.cur_addr(), st.next_addr());
-        st.advance();
-      });
-#pragma unroll
-      for (int i = 0; i < KB; ++i) {
-        if (aff) h[i] = h[i] * lds4(as, ch * KB + i, c.g4) + lds4(at, ch * KB + i, c.g4);
-        h[i] = swish4(h[i]);
-      }
-      static_for<0, KS32X>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        const Split8 hf = split8(h[2 * t], h[2 * t + 1]);
-        slab_step_p(y, hf, wg, st.cur_addr(), st.next_addr());
-        st.advance();
-      });
-    }
-  };
-  chain(2, p_pcb, p_bns, p_bnt, true);
+  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], 2 * t + 1 < KB ? xs[2 * t + 1 < KB ? 2 * t + 1 : 0] : splat4(0.f));
+  ring_chain<true>(y, xf, st, wg, c.g4, 2, p.pcb, p.bns, p.bnt);
   const float inv_fc = 1.0f / a.fc;
 #pragma unroll
   for (int i = 0; i < KB; ++i) {
     xs[i] = y[i];                                                                    // x3 = x2 + conv module
-    y[i] = lds4(p_b2, i, c.g4) + splat4(inv_fc) * y[i];                              // x3/fc + b2 (+ W2 h)
+    y[i] = lds4(p.b2, i, c.g4) + splat4(inv_fc) * y[i];                              // x3/fc + b2 (+ W2 h)
   }
-  {
-    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
-    ln_lds(xr, p_lng, p_lnb, c.g4, a.eps);
-  }
+  ln_lds(xs, p.lng, p.lnb, c.g4, a.eps);
 #pragma unroll
-  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
-  chain(4, p_b1, nullptr, nullptr, false);
+  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], 2 * t + 1 < KB ? xs[2 * t + 1 < KB ? 2 * t + 1 : 0] : splat4(0.f));
+  ring_chain<false>(y, xf, st, wg, c.g4, 4, p.b1, nullptr, nullptr);
 #pragma unroll
   for (int i = 0; i < KB; ++i) y[i] = splat4(a.fc) * y[i];
-  ln_lds(y, p_fg, p_fb, c.g4, a.eps);                                                // block-final LayerNorm
-  if (c.live) {
-#pragma unroll
-    for (int i = 0; i < KB; ++i) stg4(a.y + c.row + 16 * i + c.g4, y[i]);
+  ln_lds(y, p.fg, p.fb, c.g4, a.eps);                                                // block-final LayerNorm
+}
+
+__global__ __launch_bounds__(LD_THREADS) void ff1_qkv_ld_kernel(Ff1QkvArgs a) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
+  __shared__ __attribute__((aligned(16))) Ff1Lds p;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wv >= WAVES_PER_BLOCK) {
+    RingLoader<5>{ring, reinterpret_cast<const u32x4_t*>(a.slabs), nullptr, 55, 55, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    return;
   }
+  const WaveCtx c = wave_ctx(a.M);
+  RingReader<5> st{ring, c.lane};
+  f32x4 xs[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + c.row + 16 * kb + c.g4);
+  ff1_stash(p, a);
+  st.sync();
+  WG3 wg;
+  grp_prime(wg, st.cur_addr());
+  ff1_consume(a, p, c, st, wg, xs);
+}
+
+__global__ __launch_bounds__(LD_THREADS) void tail_ff2_ld_kernel(TailFf2Args a) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
+  __shared__ __attribute__((aligned(16))) TailLds p;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wv >= WAVES_PER_BLOCK) {
+    RingLoader<5>{ring, reinterpret_cast<const u32x4_t*>(a.slabs), nullptr, 60, 60, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    return;
+  }
+  const WaveCtx c = wave_ctx(a.M);
+  RingReader<5> st{ring, c.lane};
+  f32x4 xs[KB], y[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + c.row + 16 * kb + c.g4);     // residuals ride in the accumulators
+  tail_stash(p, a);
+  st.sync();
+  WG3 wg;
+  grp_prime(wg, st.cur_addr());
+  tail_consume(a, p, c, st, wg, xs, y);
+  const WaveCtx e = wave_ctx_fresh(a.M);
+  if (e.live) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(a.y + e.row + 16 * i + e.g4, y[i]);
+  }
+}
+
+// tail of block i + ff_module_1 / qkv of block i + 1 in one launch: 115 slabs from two streams; the block output stays in
+// registers (a.y may be null: nothing else reads it), one launch / cold ring fill / input round trip less per block
+// (the fixed part of these kernels is ~12 us of ~46)
+__global__ __launch_bounds__(LD_THREADS) void tail_ff1_ld_kernel(TailFf2Args a, Ff1QkvArgs b) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
+  __shared__ __attribute__((aligned(16))) TailLds pt;
+  __shared__ __attribute__((aligned(16))) Ff1Lds pf;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wv >= WAVES_PER_BLOCK) {
+    RingLoader<5>{ring, reinterpret_cast<const u32x4_t*>(a.slabs), reinterpret_cast<const u32x4_t*>(b.slabs), 60, 115,
+                  wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    return;
+  }
+  const WaveCtx c = wave_ctx(a.M);
+  RingReader<5> st{ring, c.lane};
+  f32x4 xs[KB], y[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + c.row + 16 * kb + c.g4);
+  tail_stash(pt, a);
+  ff1_stash(pf, b);
+  st.sync();
+  WG3 wg;
+  grp_prime(wg, st.cur_addr());
+  tail_consume(a, pt, c, st, wg, xs, y);
+  if (a.y) {
+    const WaveCtx e = wave_ctx_fresh(a.M);
+    if (e.live) {
+#pragma unroll
+      for (int i = 0; i < KB; ++i) stg4(a.y + e.row + 16 * i + e.g4, y[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KB; ++i) xs[i] = y[i];
+  ff1_consume(b, pf, c, st, wg, xs);
 }
 
 __global__ __launch_bounds__(LD_THREADS) void out_glu_ld_kernel(OutGluArgs a) {
@@ -891,7 +944,7 @@ __global__ __launch_bounds__(LD_THREADS) void out_glu_ld_kernel(OutGluArgs a) {
   __shared__ __attribute__((aligned(16))) float p_ob[D], p_lng[D], p_lnb[D], p_pb[2 * D];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wv >= WAVES_PER_BLOCK) {
-    RingLoader<5>{ring, reinterpret_cast<const u32x4_t*>(a.og_slabs), 15, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    RingLoader<5>{ring, reinterpret_cast<const u32x4_t*>(a.og_slabs), nullptr, 15, 15, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
     return;
   }
   const WaveCtx c = wave_ctx(a.M);
@@ -1217,6 +1270,22 @@ int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t
   if (a.NT != KB || a.K % 32 != 0 || a.M <= 0 || !ws) return -1;
   hipLaunchKernelGGL(sublinear_split_kernel, dim3((a.M + 63) / 64), dim3(BLOCK_THREADS), 0, s, a,
                      reinterpret_cast<const u32x4_t*>(ws));
+  return 0;
+}
+// tail of one block + ff1_qkv of the next in one launch; -1 when the loader-wave kernels are switched off
+bool tail_ff1_available() {
+  // MI355ASR_TAIL_FF1=0: separate tail_ff2 / ff1_qkv launches (also whenever one of the two is switched to an older kernel)
+  static const bool on = [] {
+    const char* v = getenv("MI355ASR_TAIL_FF1");
+    const char *r1 = getenv("MI355ASR_TAILFF2_RING"), *r2 = getenv("MI355ASR_FF1QKV_RING");
+    return (v ? atoi(v) != 0 : true) && (!r1 || atoi(r1) == 2) && (!r2 || atoi(r2) == 2);
+  }();
+  return on;
+}
+int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s) {
+  if (!tail_ff1_available() || !a.slabs || !b.slabs || a.M != b.M) return -1;
+  const int tiles = (a.M + 15) / 16;
+  hipLaunchKernelGGL(tail_ff1_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, b);
   return 0;
 }
 int launch_tail_ff2(const TailFf2Args& a, hipStream_t s) {

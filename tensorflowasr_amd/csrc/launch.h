@@ -248,6 +248,8 @@ struct TailFf2Args {
 int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s);
 int launch_out_glu(const OutGluArgs& a, hipStream_t s);
 int launch_tail_ff2(const TailFf2Args& a, hipStream_t s);
+bool tail_ff1_available();
+int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);   // -1: not available, nothing launched
 int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s);   // -1: shape not supported
 int launch_pick(const PickArgs& a, hipStream_t s);
 int launch_gather(const GatherArgs& a, hipStream_t s);

@@ -235,8 +235,12 @@ BlockDev resolve(const BlockOff& o, const float* base);
 bool use_gemm16(const mi355asr_model* m);
 bool gemm16_for(const mi355asr_model* m, size_t M);
 int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s);
+// next / ff1_done (dmodel-144 fused path): when `next` is given and the output stays in the scratch buffers, the tail kernel
+// of this block also runs ff_module_1 + qkv of `next` (one launch) and sets *ff1_done, which the caller passes back in as
+// `skip_ff1` for the next block
 int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int B, int T, float* out,
-              hipStream_t s, const CrossAttn* cross = nullptr);
+              hipStream_t s, const CrossAttn* cross = nullptr, const BlockDev* next = nullptr, bool* ff1_done = nullptr,
+              bool skip_ff1 = false);
 void resolve_stack(StackDev& sd, const StackOff& so, const float* base, bool project, int V);   // api_chunk.hip
 int finalize_chunk(mi355asr_model* m, hipStream_t s);        // api_chunk.hip
 int finalize_translator(mi355asr_model* m, hipStream_t s);   // api_translator.hip

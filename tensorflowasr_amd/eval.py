@@ -170,6 +170,10 @@ class EvalList:
         if not feats:
             raise RuntimeError("no usable utterance in the evaluation list")
         if self.streaming:
+            # am_dataloader.py:198-209 rounds max_input up to the next block boundary TWICE (before each of its two
+            # pad_signal calls), so every streaming batch carries one extra all-zero block; the CTCDecoder and the
+            # Translator attend over all frames without a mask, so that block is part of the reference's numbers
+            max_input = max_input // self.chunk * self.chunk + self.chunk
             max_input = max_input // self.chunk * self.chunk + self.chunk
             chunk_times = self.chunk // reduce + (1 if self.chunk % reduce != 0 else 0)
             input_length = np.clip(input_length, 0, (max_input // self.chunk) * chunk_times)
@@ -221,7 +225,8 @@ class AMTester(ASR):
         features, input_length, phone_labels, _, tar_label = batch
         enc_output = self.encoder(features, training=False)
         _, frame_ids = self.ctc_model(enc_output, training=False, return_argmax=True)
-        ids, lens = ctc_greedy_decode(frame_ids, input_length, blank=self.phone_featurizer.blank)
+        # tf.keras.backend.ctc_decode treats the LAST class as the blank whatever `blank_at_zero` says (am_tester.py:38-40)
+        ids, lens = ctc_greedy_decode(frame_ids, input_length, blank=self.phone_featurizer.num_classes - 1)
         ctc_decode = ids[:, :max(int(lens.max().item()), 1)].clamp_(min=0).contiguous()
         _, translator_out = self.translator([ctc_decode, enc_output], training=False, return_argmax=True)
         ctc_decode, translator_out = ctc_decode.cpu().numpy(), translator_out.cpu().numpy()

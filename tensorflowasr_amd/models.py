@@ -91,10 +91,12 @@ class _Handle:
                 if strict:
                     raise _lib.Mi355AsrError("unexpected weight %r" % name)
                 continue
-            a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
+            a = np.asarray(arr)
+            dt = {"float16": 1, "float64": 3}.get(a.dtype.name, 0)        # MI355ASR_DT_*; anything else goes as fp32
+            a = np.ascontiguousarray(a if dt else a.astype(np.float32, copy=False))
             dims = (ctypes.c_int64 * a.ndim)(*a.shape)
-            _lib.check(self.lib.mi355asr_load_weight(self.ptr, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
-                                                     a.ndim, dims))
+            _lib.check(self.lib.mi355asr_load_weight_typed(self.ptr, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
+                                                           dt, a.ndim, dims))
 
     def finalize(self):
         if self.device.type != "cuda":
@@ -171,12 +173,22 @@ class _ModelBase:
         self._h.finalize()
         return self
 
-    def load_weights(self, weights, by_name=True, strict=None):
+    # tensors that a checkpoint may legitimately leave out: the fixed DFT kernels / mel filterbank of the frontend
+    # (non-trainable variables; Keras-default values are generated by _build())
+    _DEFAULTABLE = ("mel_layer/real_kernels", "mel_layer/imag_kernels", "mel_layer/freq2mel")
+
+    def load_weights(self, weights, by_name=True, strict=None, allow_missing=False):
         """`weights`: a dict name -> array, the path of an .npz of Keras-layout tensors, the path of a Keras `.h5`
         weight file as the reference's trainers write them (`ctc_runners.py:272-325`; read by the pure-Python HDF5 reader
-        h5lite.py, variable names mapped by checkpoint.keras_names_to_abi), or the path of the reference's tf2onnx export
-        of the CTCDecoder (`ctc_model.onnx`; checkpoint.py)."""
-        if isinstance(weights, (str, os.PathLike)):
+        h5lite.py, variable names mapped by checkpoint.keras_names_to_abi), a TensorFlow checkpoint prefix / directory, or
+        the path of the reference's tf2onnx export of the CTCDecoder (`ctc_model.onnx`; checkpoint.py).
+
+        Loading from a PATH checks coverage: if no tensor of the file maps onto this model, or if tensors of the model
+        are absent from it (other than the frontend's fixed DFT / mel matrices), the call raises instead of leaving
+        those tensors at their `_build()` values -- a checkpoint whose names fail to map must not "load" as a
+        random-weight model.  `allow_missing=True` restores Keras' by_name leniency."""
+        from_path = isinstance(weights, (str, os.PathLike))
+        if from_path:
             path = str(weights)
             if path.endswith((".h5", ".hdf5")):
                 from . import checkpoint
@@ -190,6 +202,15 @@ class _ModelBase:
                 weights = checkpoint.ctc_decoder_weights_from_onnx(path, num_heads=self.num_heads)
             else:
                 weights = dict(np.load(path))
+            expected = set(self._h.weight_names())
+            provided = expected & set(weights)
+            if not provided:
+                raise _lib.Mi355AsrError("%s: none of the %d tensors in this file maps onto %s (first names: %s)"
+                                         % (path, len(weights), self.name, sorted(weights)[:3]))
+            missing = sorted(n for n in expected - provided if not n.endswith(self._DEFAULTABLE))
+            if missing and not allow_missing:
+                raise _lib.Mi355AsrError("%s: %d tensors of %s are not in this file (e.g. %s); pass allow_missing=True to keep "
+                                         "their initial values" % (path, len(missing), self.name, missing[:4]))
         if strict is None:
             strict = not by_name
         if not getattr(self, "_weights", None):
@@ -601,8 +622,11 @@ class ConformerCTC(_ModelBase):
         self._lens = torch.empty((B,), dtype=torch.int32, device=h.device)
         return T
 
-    def recognize(self, wav, input_length=None):
-        """wav [B,L(,1)] on device -> (ids int32 [B,T] padded -1, lengths int32 [B]).  Asynchronous."""
+    def recognize(self, wav, input_length=None, reuse_buffers=False):
+        """wav [B,L(,1)] on device -> (ids int32 [B,T] padded -1, lengths int32 [B]).  Asynchronous.
+        reuse_buffers=True returns the model's own pre-allocated output tensors (no allocation, no copy -- what the
+        C-ABI call writes into); the NEXT recognize() of the same shape overwrites them, so only use it when the
+        results are consumed before the next call."""
         h = self._h
         if not h.built:
             self._build()
@@ -619,7 +643,9 @@ class ConformerCTC(_ModelBase):
         with torch.cuda.device(h.device):
             _lib.check(h.lib.mi355asr_recognize(h.ptr, _p(x), B, L, _p(il), _p(self._ids), _p(self._lens), _p(ws), n,
                                                 h._stream()))
-        return self._ids, self._lens
+        if reuse_buffers:
+            return self._ids, self._lens
+        return self._ids.clone(), self._lens.clone()
 
     __call__ = recognize
 

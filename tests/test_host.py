@@ -238,7 +238,9 @@ def test_eval_list_batches_like_the_reference_loader(tmp_path, streaming):
         assert abs(np.abs(x[0]).max() - 1.0) < 1e-6 and abs(np.abs(x[2]).max() - 1.0) < 1e-6   # peak-normalised
         assert np.all(x[0, 12000:] == 0)
     else:
-        assert x.shape[1] == 24000                                                 # next multiple of the 8000-sample block
+        # longest 20480 -> 24000 (next block boundary) -> 32000: the reference rounds up twice (am_dataloader.py:198-209),
+        # every streaming batch carries one extra all-zero block
+        assert x.shape[1] == 32000 and np.all(x[:, 24000:] == 0)
         assert in_len.tolist() == [2 * 13, 3 * 13, 2 * 13]                         # whole blocks x 13 frames
         assert abs(np.abs(x[0]).max() - 0.3) < 1e-3                                # raw samples, not normalised
 
@@ -486,6 +488,115 @@ def test_keras_variable_names_map_to_abi_names():
     assert e[enc[0]] == "conv_subsampling/conv1/kernel" and e[enc[1]] == "conv_subsampling/conv2/bias"
     assert e[enc[2]] == "conv_subsampling/linear/kernel"
     assert e[enc[3]] == "conformer_block_11/ff_module_2/ffn2/bias" and e[enc[4]] == "conformer_block_11/ff_module_2/ffn1/bias"
+
+
+def _keras_style_names(scope, abi_names, start=7):
+    """inverse of checkpoint.keras_names_to_abi for a whole model: C-ABI names (in weight_names() = construction order) ->
+    names as Keras would print them, auto-numbered layers counted globally per kind from `start`."""
+    kinds = {"ln": "layer_normalization", "bn": "batch_normalization", "mha": "multi_head_attention", "ffn1": "dense",
+             "ffn2": "dense", "project": "dense", "linear": "dense", "conv1": "conv2d", "conv2": "conv2d",
+             "inp_embedding": "embedding", "sep_conv": "separable_conv1d", "final": "conv1d", "conv5": "conv1d"}
+    counter, seen, out = {}, {}, {}
+    for abi in abi_names:
+        parts = abi.split("/")
+        keras = []
+        for depth, p in enumerate(parts[:-1]):
+            kind = kinds.get(p)
+            if p.startswith("res_"):
+                kind = "tf_residual_stack"
+            elif re.fullmatch(r"conv_\d+", p) or (p == "conv1" and depth and parts[depth - 1].startswith("res_")):
+                kind = "conv1d"
+            if p == "wav_layer":
+                keras += ["wave_pick_model", "sequential_3"]
+                continue
+            if p in ("conv1", "conv2") and parts[depth - 1] != "conv_subsampling" and not parts[depth - 1].startswith("res_"):
+                kind = None
+            if kind is None:
+                keras.append(p)
+                continue
+            key = tuple(parts[:depth + 1])
+            if key not in seen:
+                n = counter.get(kind, start)
+                counter[kind] = n + 1
+                seen[key] = "%s_%d" % (kind, n) if n else kind
+            keras.append(seen[key])
+        out["/".join([scope] + keras + [parts[-1]]) + ":0"] = abi
+    return out
+
+
+def test_keras_names_cover_every_tensor_of_encoder_with_wav_info_and_translator():
+    """the Translator's Embedding and the WavePickModel branch were not mapped, so loading the reference's
+    `.h5` left them at their random _build() values without an error.  Whole-model name lists, written the way Keras
+    auto-numbers layers, must map onto exactly Handle.weight_names()."""
+    import re as _re  # noqa: F401
+    from tensorflowasr_amd import checkpoint
+    from tensorflowasr_amd.models import ConformerEncoder, Translator
+    enc = ConformerEncoder(dmodel=144, num_blocks=2, add_wav_info=True, mel_layer_type="Melspectrogram")
+    names = [n for n in enc._h.weight_names() if not n.startswith("mel_layer/")]     # DFT / mel constants: see keras_h5_to_abi
+    k2a = _keras_style_names("conformer_encoder", names)
+    assert len(k2a) == len(names)
+    assert any("wave_pick_model/sequential_3/tf_residual_stack_8/conv1d_" in k for k in k2a)
+    assert checkpoint.keras_names_to_abi(list(k2a) + ["Adam/iter:0"]) == k2a
+    tr = Translator(inp_classes=60, tar_classes=80, dmodel=144, num_blocks=2)
+    names = tr._h.weight_names()
+    k2a = _keras_style_names("translator", names, start=2)
+    assert "translator/embedding_2/embeddings:0" in k2a
+    assert checkpoint.keras_names_to_abi(list(k2a)) == k2a
+    assert set(k2a.values()) == set(names)
+
+
+def test_load_weights_from_a_file_checks_coverage(tmp_path):
+    """a checkpoint whose names do not map, or that lacks tensors, must not load as a random-weight model"""
+    from tensorflowasr_amd import _lib
+    dec = CTCDecoder(num_classes=50, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32)
+    shapes = dict(dec._names_and_shapes())
+    rng = np.random.default_rng(0)
+    full = {n: rng.standard_normal(s).astype(np.float32) for n, s in shapes.items()}
+    np.savez(tmp_path / "wrong_names.npz", **{"model/" + k: v for k, v in full.items()})
+    with pytest.raises(_lib.Mi355AsrError, match="none of the"):
+        dec.load_weights(str(tmp_path / "wrong_names.npz"))
+    part = {k: v for k, v in full.items() if "ff_module_2" not in k}
+    np.savez(tmp_path / "partial.npz", **part)
+    with pytest.raises(_lib.Mi355AsrError, match="are not in this file"):
+        dec.load_weights(str(tmp_path / "partial.npz"))
+    with pytest.raises(Exception, match="HIP|GPU|ROCm|device"):   # coverage check passed; the upload needs a device and fails loudly
+        dec.load_weights(str(tmp_path / "partial.npz"), allow_missing=True)
+    assert "decoder_conformer_block_0/ff_module_1/ffn1/kernel" in dec.get_weights_dict()
+
+
+def test_latest_checkpoint_picks_the_newest_step_of_any_format(tmp_path):
+    """test_asr.py:95-114: `<sub-model>-ckpt/model_<step>.h5`, highest step wins; stray files are ignored"""
+    from tensorflowasr_amd.checkpoint import latest_checkpoint
+    d = tmp_path / "encoder-ckpt"
+    d.mkdir()
+    with pytest.raises(FileNotFoundError):
+        latest_checkpoint(str(d))
+    for f in ("model_5.h5", "model_40.h5", "model_7.npz", "notes.txt", "model_final.h5", "checkpoint", "model_100.tmp"):
+        (d / f).write_bytes(b"")
+    assert latest_checkpoint(str(d)).endswith("model_40.h5")
+    (d / "model_40.npz").write_bytes(b"")
+    assert latest_checkpoint(str(d)).endswith("model_40.npz")          # same step: npz before h5
+    (d / "model_41.index").write_bytes(b"")
+    (d / "model_41.data-00000-of-00001").write_bytes(b"")
+    assert latest_checkpoint(str(d)) == str(d / "model_41")             # TensorFlow bundle: the prefix
+
+
+def test_typed_weight_loading_converts_on_the_host():
+    """mi355asr_load_weight_typed: fp16 / bf16 / fp64 checkpoints"""
+    lib, rc, p = _create(num_classes=20, ctc_num_blocks=1, has_encoder=0, num_blocks=0)
+    assert rc == 0
+    x = np.linspace(-3, 3, 144 * 20).reshape(144, 20)
+    dims = (ctypes.c_int64 * 2)(144, 20)
+    h = x.astype(np.float16)
+    b16 = (x.astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    for dt, arr in ((1, h), (2, b16), (3, x.astype(np.float64)), (0, x.astype(np.float32))):
+        arr = np.ascontiguousarray(arr)
+        assert lib.mi355asr_load_weight_typed(p, b"fully_connected/kernel", arr.ctypes.data_as(ctypes.c_void_p), dt, 2, dims) == 0
+    assert lib.mi355asr_load_weight_typed(p, b"fully_connected/kernel", h.ctypes.data_as(ctypes.c_void_p), 9, 2, dims) == -1
+    sub = np.array([6.1e-5, 5.96e-8, -2e-7, 0.0, 65504.0, np.inf], np.float16)     # subnormal halves, max, inf
+    d1 = (ctypes.c_int64 * 1)(6)
+    assert lib.mi355asr_load_weight_typed(p, b"nope", sub.ctypes.data_as(ctypes.c_void_p), 1, 1, d1) == -3
+    lib.mi355asr_destroy(p)
 
 
 def test_weight_shape_query_matches_the_python_mirror():
