@@ -232,6 +232,25 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav_dev, int32_t B, i
                            const mi355asr_chunk_outputs* outs, int32_t* n_picked_host, int32_t* t_pick_host,
                            void* ws_dev, size_t ws_bytes, void* stream);
 
+/* per-frame argmax of given logits or probabilities, f32 [M, V] -> i32 [M], first maximum wins: the decision step of
+ * tf.keras.backend.ctc_decode(greedy) when the logits come from outside a head kernel (the streaming ChunkConformer path
+ * concatenates logits of several calls, test_chunk_asr.py:84-96); feed the result to mi355asr_ctc_greedy. */
+int mi355asr_frame_argmax(const float* x_dev, int32_t M, int32_t V, int32_t* out_dev, void* stream);
+
+/* replaces: ChunkConformer.feature_pick(encoder_hidden_states, ctc_outs[, max_T]) (chunk_conformer_blocks.py:913-999), the
+ * "length regulator" between the phone picker and the text decoder of the streaming path (test_chunk_asr.py:72-75): keep
+ * the frames whose phone argmax is not the blank (class V - 1), compacted per utterance, zero padded to the batch maximum.
+ * Handle-free, two calls because the batch maximum sizes the outputs (a dynamic shape in the reference):
+ *   _count:  ctc_dev f32 [B, T, V] -> idx_dev i32 [B, T] (kept frame indices), cnt_dev i32 [B], counts_host i32 [B];
+ *            synchronises the stream once to return the counts
+ *   _gather: hidden_dev f32 [B, T, d], ctc_dev -> feat_out_dev f32 [B, Tp, d], ctc_out_dev f32 [B, Tp, V] (or NULL)
+ *            for any Tp >= max(counts) (max_T of the reference) */
+int mi355asr_feature_pick_count(const float* ctc_dev, int32_t B, int32_t T, int32_t V, int32_t* idx_dev, int32_t* cnt_dev,
+                                int32_t* counts_host, void* stream);
+int mi355asr_feature_pick_gather(const float* hidden_dev, const float* ctc_dev, const int32_t* idx_dev,
+                                 const int32_t* cnt_dev, int32_t B, int32_t T, int32_t d, int32_t V, int32_t Tp,
+                                 float* feat_out_dev, float* ctc_out_dev, void* stream);
+
 /* ---- ChunkConformer streaming: one stream, explicit caches ------------------------------------------
  * replaces the pieces of ChunkConformer.picker_stream_predict / decoder_stream_predict (chunk_conformer_blocks.py:
  * 824-866, ONNX form :868-898).  The caller owns every cache tensor and does the slicing the reference does in

@@ -2,7 +2,9 @@
 
     python -m tensorflowasr_amd.build [--force]
 """
+import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -30,6 +32,49 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _parse_resource_remarks(text):
+    """`-Rpass-analysis=kernel-resource-usage` remarks -> {kernel: {vgprs, agprs, sgprs, scratch, lds, occupancy}}"""
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "TotalSGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch",
+            "LDS Size [bytes/block]": "lds", "Occupancy [waves/SIMD]": "occupancy"}
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(.*?): (\d+) \[-Rpass-analysis", line)
+        if m and cur is not None and m.group(1) in keys:
+            cur[keys[m.group(1)]] = int(m.group(2))
+    return out
+
+
+def resource_report():
+    """{kernel: resources} of the last build (tensorflowasr_amd/build/*.resources.json)"""
+    rep = {}
+    objdir = os.path.join(HERE, "build")
+    for f in sorted(os.listdir(objdir)) if os.path.isdir(objdir) else []:
+        if f.endswith(".resources.json"):
+            rep.update(json.load(open(os.path.join(objdir, f))))
+    return rep
+
+
+# A kernel that touches scratch is slow twice on this path: its own spill traffic, and the dispatches AROUND it pay for
+# the scratch set-up (measured: dwconv 15 -> 30 us next to a spilling neighbour, profiles/r02_ring_experiments.md).
+# Kernels allowed to keep a private segment (cold paths, listed with the reason):
+SCRATCH_ALLOWED = (
+    "gemm16_kernelINS_4PF32ELi9ELi4ELb1ELi4",      # layer-at-a-time fp32 GEMM, 9-tile / 4-row-tile variant (small batches): 36 B
+    "attention_kernelILi64ELi16",                  # head size 64 online-softmax attention (M / L / streaming models): 48 B
+    "gemm_rows_kernelILi144ELi2ELi9",              # two-row-tile variants of the unfused dmodel-144 GEMMs (>= 65 536 rows): 16-24 B
+)   # round-1 kernels off the headline path; every kernel of the dmodel-144 fused path is scratch-free
+
+
+def check_no_scratch(report=None):
+    bad = {k: v["scratch"] for k, v in (report or resource_report()).items()
+           if v.get("scratch", 0) > 0 and not any(a in k for a in SCRATCH_ALLOWED)}
+    if bad:
+        raise RuntimeError("kernels with scratch (register spills): %s" % bad)
+
+
 def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objdir = os.path.join(HERE, "build")
@@ -38,12 +83,18 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        rep = obj[:-2] + ".resources.json"
         path = os.path.join(CSRC, src)
-        if force or _stale(obj, [path] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+        if force or _stale(obj, [path] + hdrs) or not os.path.exists(rep):
+            cmd = [hipcc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stderr)
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            with open(rep, "w") as f:
+                json.dump(_parse_resource_remarks(r.stderr), f, indent=1, sort_keys=True)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
@@ -54,6 +105,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     build_example(force, verbose)
+    check_no_scratch()
     return LIB
 
 

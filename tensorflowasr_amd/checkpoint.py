@@ -510,3 +510,26 @@ def latest_checkpoint(checkpoint_dir):
         raise FileNotFoundError("no model_<step>.{h5,npz,index} in %s" % checkpoint_dir)
     path = os.path.join(checkpoint_dir, best[1])
     return path[:-len(".index")] if best[2].endswith(".index") else path
+
+
+def latest_tf_checkpoint(checkpoint_dir):
+    """`tf.train.latest_checkpoint(dir)` (test_chunk_asr.py:41, chunk_tester.py:74): the prefix named by the
+    `model_checkpoint_path` line of the directory's `checkpoint` state file; without that file, the `*.index` with the
+    highest trailing number."""
+    state = os.path.join(checkpoint_dir, "checkpoint")
+    if os.path.exists(state):
+        for line in open(state, encoding="utf-8"):
+            m = re.match(r'\s*model_checkpoint_path:\s*"(.*)"\s*$', line)
+            if m:
+                p = m.group(1)
+                p = p if os.path.isabs(p) else os.path.join(checkpoint_dir, p)
+                if os.path.exists(p + ".index"):
+                    return p
+    best = None
+    for f in os.listdir(checkpoint_dir):
+        m = re.match(r"^(.*?)(\d+)\.index$", f)
+        if m and (best is None or int(m.group(2)) > best[0]):
+            best = (int(m.group(2)), f[:-len(".index")])
+    if best is None:
+        raise FileNotFoundError("no TensorFlow checkpoint (checkpoint state file or *.index) in %s" % checkpoint_dir)
+    return os.path.join(checkpoint_dir, best[1])

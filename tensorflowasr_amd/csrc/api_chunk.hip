@@ -442,6 +442,50 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
   return rc;
 }
 
+int mi355asr_frame_argmax(const float* x, int32_t M, int32_t V, int32_t* out, void* stream) {
+  if (!x || !out) return fail(MI355ASR_EINVAL, "null argument");
+  if (M < 0 || V < 1) return fail(MI355ASR_EINVAL, "need M >= 0, V >= 1 (got %d, %d)", M, V);
+  LAUNCH_TRY(launch_row_argmax(x, out, M, V, (hipStream_t)stream), "frame argmax");
+  return 0;
+}
+
+// ---- feature_pick as its own entry point (the streaming path calls it between picker and decoder) --------------------
+int mi355asr_feature_pick_count(const float* ctc, int32_t B, int32_t T, int32_t V, int32_t* idx, int32_t* cnt,
+                                int32_t* counts_host, void* stream) {
+  if (!ctc || !idx || !cnt || !counts_host) return fail(MI355ASR_EINVAL, "null argument");
+  if (B < 1 || T < 0 || V < 2) return fail(MI355ASR_EINVAL, "need B >= 1, T >= 0, V >= 2 (got %d, %d, %d)", B, T, V);
+  hipStream_t s = (hipStream_t)stream;
+  if (T == 0) {
+    for (int b = 0; b < B; ++b) counts_host[b] = 0;
+    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)B * sizeof(int32_t), s));
+    return 0;
+  }
+  // the per-frame argmax is written to idx and compacted in place: pick_kernel reads a 64-frame group before it writes,
+  // and a kept frame t goes to a slot <= t
+  LAUNCH_TRY(launch_row_argmax(ctc, idx, B * T, V, s), "feature_pick argmax");
+  PickArgs pa{idx, idx, cnt, B, T, V - 1};
+  LAUNCH_TRY(launch_pick(pa, s), "feature_pick compaction");
+  HIP_TRY(hipMemcpyAsync(counts_host, cnt, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int mi355asr_feature_pick_gather(const float* hidden, const float* ctc, const int32_t* idx, const int32_t* cnt, int32_t B,
+                                 int32_t T, int32_t d, int32_t V, int32_t Tp, float* feat_out, float* ctc_out, void* stream) {
+  if (!hidden || !idx || !cnt || !feat_out || (ctc_out && !ctc)) return fail(MI355ASR_EINVAL, "null argument");
+  if (B < 1 || T < 0 || Tp < 0 || d < 1 || (ctc_out && V < 1))
+    return fail(MI355ASR_EINVAL, "need B >= 1, T, Tp >= 0, d >= 1 (got B=%d T=%d Tp=%d d=%d V=%d)", B, T, Tp, d, V);
+  hipStream_t s = (hipStream_t)stream;
+  if (Tp == 0) return 0;
+  GatherArgs ga{hidden, idx, cnt, feat_out, B, T, Tp, d};
+  LAUNCH_TRY(launch_gather(ga, s), "feature_pick gather (hidden)");
+  if (ctc_out) {
+    GatherArgs gc{ctc, idx, cnt, ctc_out, B, T, Tp, V};
+    LAUNCH_TRY(launch_gather(gc, s), "feature_pick gather (ctc)");
+  }
+  return 0;
+}
+
 // ---- ChunkConformer streaming ------------------------------------------------------------------------------
 int mi355asr_chunk_front_stream_shape(const mi355asr_model* m, int32_t Lw, int32_t S, int32_t chunk_num, int32_t* nf,
                                       int32_t* t_out) {

@@ -695,17 +695,26 @@ __global__ __launch_bounds__(320) void dwconv_tile_kernel(DwArgs a) {
   __syncthreads();
   const int c = threadIdx.x % C4, tg = threadIdx.x / C4;
   if (tg >= TT / TS) return;
-  f32x4 win[TS + K - 1];
-#pragma unroll
-  for (int i = 0; i < TS + K - 1; ++i) win[i] = *reinterpret_cast<const f32x4*>(&tile[(tg * TS + i) * CB + 4 * c]);
+  // taps in groups of GJ: per group GJ weights + TS + GJ - 1 window rows in registers (the whole TS + K - 1 row window
+  // of K = 32 is 156 registers and spilled to scratch under the 256-register cap of a 320-thread workgroup; a kernel
+  // with scratch also slows the launches around it).  The group loop is NOT unrolled, its body is.
+  constexpr int GJ = (K % 8 == 0) ? 8 : K;
+  const float* __restrict__ trow = &tile[(tg * TS) * CB + 4 * c];
+  const float* __restrict__ wrow = &wt[4 * c];
   f32x4 acc[TS];
 #pragma unroll
   for (int i = 0; i < TS; ++i) acc[i] = splat4(0.f);
+#pragma unroll 1
+  for (int j0 = 0; j0 < K; j0 += GJ) {
+    f32x4 win[TS + GJ - 1], w[GJ];
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const f32x4 w = *reinterpret_cast<const f32x4*>(&wt[j * CB + 4 * c]);
+    for (int r = 0; r < TS + GJ - 1; ++r) win[r] = *reinterpret_cast<const f32x4*>(trow + (j0 + r) * CB);
 #pragma unroll
-    for (int i = 0; i < TS; ++i) acc[i] += win[i + j] * w;
+    for (int j = 0; j < GJ; ++j) w[j] = *reinterpret_cast<const f32x4*>(wrow + (j0 + j) * CB);
+#pragma unroll
+    for (int j = 0; j < GJ; ++j)
+#pragma unroll
+      for (int i = 0; i < TS; ++i) acc[i] += win[i + j] * w[j];
   }
   float* yb = a.y + (size_t)b * a.T * a.D + c0 + 4 * c;
 #pragma unroll

@@ -522,11 +522,53 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   }
 }
 
+// per-row argmax of [M, V] logits, first maximum wins (tf.argmax): one wave per row
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ x, int32_t* __restrict__ out, int M, int V) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* __restrict__ r = x + (size_t)row * V;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lane; i < V; i += 64) {
+    const float v = r[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;     // all-NaN row: class 0
+}
+int launch_row_argmax(const float* x, int32_t* out, int M, int V, hipStream_t s) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(row_argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, out, M, V);
+  return 0;
+}
+
 int launch_pick(const PickArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(pick_kernel, dim3(a.B), dim3(64), 0, s, a);
   return 0;
 }
+// rows whose width is not a multiple of 4 floats (e.g. the picker's 277 classes): element-wise
+__global__ __launch_bounds__(256) void gather1_kernel(GatherArgs a) {
+  const size_t total = (size_t)a.B * a.Tp * a.D;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % a.D);
+    const int j = (int)((i / a.D) % a.Tp);
+    const int b = (int)(i / ((size_t)a.D * a.Tp));
+    a.dst[i] = j < a.cnt[b] ? a.src[((size_t)b * a.T + a.idx[(size_t)b * a.T + j]) * a.D + c] : 0.f;
+  }
+}
+
 int launch_gather(const GatherArgs& a, hipStream_t s) {
+  if (a.D % 4) {
+    const size_t n = (size_t)a.B * a.Tp * a.D;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gather1_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, a);
+    return 0;
+  }
   const size_t total = (size_t)a.B * a.Tp * (a.D / 4);
   if (total == 0) return 0;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);

@@ -252,6 +252,7 @@ bool tail_ff1_available();
 int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);   // -1: not available, nothing launched
 int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s);   // -1: shape not supported
 int launch_pick(const PickArgs& a, hipStream_t s);
+int launch_row_argmax(const float* x, int32_t* out, int M, int V, hipStream_t s);
 int launch_gather(const GatherArgs& a, hipStream_t s);
 int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s);
 int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s);

@@ -560,6 +560,20 @@ def ctc_greedy_decode(frame_argmax, input_length=None, blank=None, device=None):
     return ids, lens
 
 
+def frame_argmax(x, device=None):
+    """per-frame argmax of logits / probabilities [..., V] on the device (first maximum wins) -> int32 [...]"""
+    lib = _lib.lib()
+    t = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+    dev = torch.device(device) if device is not None else (t.device if t.is_cuda else torch.device("cuda:0"))
+    t = t.to(device=dev, dtype=torch.float32).contiguous()
+    V = t.shape[-1]
+    out = torch.empty(t.shape[:-1], dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.mi355asr_frame_argmax(_p(t), int(out.numel()), int(V), _p(out), st))
+    return out
+
+
 class ConformerCTC(_ModelBase):
     """Encoder + CTCDecoder + greedy decode in one handle / one call (`mi355asr_recognize`): the timed region
     of the benchmark and what `ASR.offline_stt` (test_asr.py:186-200) computes up to the token ids."""
@@ -1007,18 +1021,31 @@ class ChunkConformer(_ModelBase):
 
     def feature_pick(self, encoder_hidden_states, ctc_outs, max_T=None):
         """ChunkConformer.feature_pick (:913-999): keep the frames whose argmax is not the blank, compacted per
-        utterance, zero padded to the batch maximum -> (feature_outputs [B,Tp,d], ctc_outputs [B,Tp,V])."""
-        hid = self._h.to_device(encoder_hidden_states)
-        ctc = self._h.to_device(ctc_outs)
-        keep = ctc.argmax(-1) != (self.phone_num_classes - 1)
-        counts = keep.sum(-1)
-        Tp = int(counts.max().item()) if counts.numel() else 0
-        if max_T is not None:
-            Tp = max(Tp, int(max_T))
-        f = torch.zeros((hid.shape[0], Tp, hid.shape[-1]), dtype=hid.dtype, device=hid.device)
-        c = torch.zeros((ctc.shape[0], Tp, ctc.shape[-1]), dtype=ctc.dtype, device=ctc.device)
-        for b in range(hid.shape[0]):
-            n = int(counts[b].item())
-            f[b, :n] = hid[b][keep[b]]
-            c[b, :n] = ctc[b][keep[b]]
+        utterance, zero padded to the batch maximum -> (feature_outputs [B,Tp,d], ctc_outputs [B,Tp,V]).  Argmax,
+        compaction and gather run in libmi355asr.so (`mi355asr_feature_pick_count` / `_gather`); the only host step is
+        reading the B counts that size the outputs."""
+        h = self._h
+        hid = h.to_device(encoder_hidden_states)
+        ctc = h.to_device(ctc_outs)
+        B, T, d = hid.shape
+        V = ctc.shape[-1]
+        if ctc.shape[0] != B or ctc.shape[1] != T:
+            raise ValueError("hidden %s and ctc %s disagree" % (tuple(hid.shape), tuple(ctc.shape)))
+        if V != self.phone_num_classes:
+            raise ValueError("ctc_outs has %d classes, the picker %d" % (V, self.phone_num_classes))
+        idx = torch.empty((B, max(T, 1)), dtype=torch.int32, device=h.device)
+        cnt = torch.empty((B,), dtype=torch.int32, device=h.device)
+        counts = np.zeros(B, np.int32)
+        with torch.cuda.device(h.device):
+            _lib.check(h.lib.mi355asr_feature_pick_count(_p(ctc), B, T, V, _p(idx), _p(cnt),
+                                                         counts.ctypes.data_as(ctypes.c_void_p), h._stream()))
+            Tp = int(counts.max()) if B else 0
+            if max_T is not None:
+                Tp = max(Tp, int(max_T))
+            f = torch.empty((B, Tp, d), dtype=torch.float32, device=h.device)
+            c = torch.empty((B, Tp, V), dtype=torch.float32, device=h.device)
+            if Tp == 0:
+                return f, c
+            _lib.check(h.lib.mi355asr_feature_pick_gather(_p(hid), _p(ctc), _p(idx), _p(cnt), B, T, d, V, Tp, _p(f), _p(c),
+                                                          h._stream()))
         return f, c

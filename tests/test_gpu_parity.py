@@ -701,6 +701,100 @@ def test_chunk_conformer_streaming_matches_oracle_and_offline(torch_cuda, sample
     assert n == off["text_logits"].shape[1] - 8
 
 
+def test_feature_pick_entry_point_matches_oracle(torch_cuda):
+    """mi355asr_feature_pick_count / _gather (argmax, compaction, gather on the device) against the oracle's
+    feature_pick: ragged counts, an utterance with nothing kept, max_T padding, a class count that is not a multiple of 4."""
+    cfg = dict(co.CHUNK_S, enc_num_blocks=1)
+    m = _chunk_model(cfg, co.chunk_weights(cfg, seed=1))
+    rng = np.random.default_rng(4)
+    B, T, d, V = 4, 75, 144, cfg["picker_num_classes"]
+    assert V % 4 != 0
+    hid = rng.standard_normal((B, T, d)).astype(np.float32)
+    ctc = rng.standard_normal((B, T, V)).astype(np.float32)
+    ctc[0, :, -1] += 1.5                                   # mostly blank
+    ctc[2, :, -1] += 50.0                                  # all blank: nothing kept
+    ctc[3, :, -1] -= 50.0                                  # never blank: everything kept
+    ctc[1, 10, 5] = ctc[1, 10, 9] = 40.0                   # a tie: the first maximum wins (class 5, not blank)
+    rf, counts = co.feature_pick(hid.astype(np.float64), ctc.astype(np.float64), V - 1)
+    rc = np.zeros((B, T, V), np.float32)                   # the same compaction applied to the ctc rows
+    for b in range(B):
+        keep = ctc[b].argmax(-1) != V - 1
+        rc[b, :keep.sum()] = ctc[b][keep]
+    assert counts.tolist() == [int((ctc[b].argmax(-1) != V - 1).sum()) for b in range(B)] and counts[2] == 0 and counts[3] == T
+    f, c = m.feature_pick(hid, ctc)
+    assert f.shape == rf.shape == (B, T, d) and c.shape == rc.shape
+    assert np.array_equal(f.cpu().numpy(), rf.astype(np.float32)) and np.array_equal(c.cpu().numpy(), rc)
+    f2, c2 = m.feature_pick(hid[:3], ctc[:3], max_T=60)
+    n = rf[:3].any(-1).sum(1).max()
+    assert f2.shape[1] == 60 >= n and np.array_equal(f2.cpu().numpy()[:, :n], rf[:3, :n].astype(np.float32))
+    assert not f2.cpu().numpy()[2].any()
+    f0, c0 = m.feature_pick(hid[2:3], ctc[2:3])
+    assert f0.shape == (1, 0, d) and c0.shape == (1, 0, V)
+
+
+def _chunk_asr_config(tmp_path, cfg):
+    from tensorflowasr_amd.config import load_yaml
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tensorflowasr_amd", "configs")
+    c = load_yaml(os.path.join(here, "am_data.yml"))
+    c.update(load_yaml(os.path.join(here, "chunk_conformerS.yml")))
+    c["model_config"]["ChunkConformerEncoder"]["num_blocks"] = cfg["enc_num_blocks"]
+    (tmp_path / "phones.txt").write_text("\n".join(["<S>", "</S>", "[SPACE]", "[UNK]"] + ["p%d" % i for i in range(26)]) + "\n")
+    (tmp_path / "chars.txt").write_text("\n".join(["<S>", "</S>", "[SPACE]", "[UNK]"] + [chr(0x4e00 + i) for i in range(36)]) + "\n")
+    c["inp_config"]["vocabulary"] = str(tmp_path / "phones.txt")
+    c["tar_config"]["vocabulary"] = str(tmp_path / "chars.txt")
+    c["running_config"]["outdir"] = str(tmp_path / "logs")
+    return c
+
+
+def test_chunk_asr_stream_call_and_tester(torch_cuda, tmp_path):
+    """test_chunk_asr.py:47-139 and chunk_tester.py:34-63 on the shipped chunk_conformerS.yml (2 encoder blocks): the
+    streaming loop's final phones are the greedy decode of the offline picker's kept frames, the offline text is the
+    greedy decode of predict(); the tester's S/I/D and error rates equal a hand computation from the same logits."""
+    from tensorflowasr_amd.chunk_asr import ChunkAMTester, ChunkASR
+    from tensorflowasr_amd.eval import wer
+    cfg = dict(co.CHUNK_S, enc_num_blocks=2, picker_num_classes=31, decoder_num_classes=41)
+    conf = _chunk_asr_config(tmp_path, cfg)
+    asr = ChunkASR(conf, load_checkpoint=False)
+    assert asr.phone_featurizer.num_classes == 31 and asr.text_featurizer.num_classes == 41 and asr.wav_buf_length == 2560
+    w = co.chunk_weights(cfg, seed=3)
+    x = co.synth_wave(5, length=2560 * 24)
+    _write_wav(tmp_path / "u.wav", x)
+    xq = asr.load_wav(str(tmp_path / "u.wav"))
+    w["picker/fully_connected/bias"][-1] = _pick_bias_for_ragged_counts(cfg, w, xq[None].astype(np.float32))
+    asr.runner.load_weights(w, by_name=False)
+    res = asr.stream_call(str(tmp_path / "u.wav"))
+    assert len(res["streaming"]) > 5 and res["streaming"][-1][0] == 24 * 0.16
+    times = [t for t, _, _ in res["streaming"]]
+    assert times == sorted(times)
+    off = asr.runner.predict(xq[None], stages=True)
+    keep = off["picker_logits"].cpu().numpy()[0].argmax(-1) != 30
+    pl = off["picker_logits"].cpu().numpy()[:, keep]
+    rid, rlen = co.ctc_greedy(pl, [pl.shape[1]], 30)
+    phones = " ".join(asr.phone_featurizer.iextract([int(n) for n in rid[0, :rlen[0]] if n > 0]))
+    assert res["streaming"][-1][1] == phones and len(phones) > 0
+    tl = off["text_logits"].cpu().numpy()
+    tid, tlen = co.ctc_greedy(tl, [tl.shape[1]], 40)
+    assert res["offline"] == "".join(asr.text_featurizer.iextract([int(n) for n in tid[0, :tlen[0]] if n > 0]))
+    # tester over one batch of two utterances
+    t = ChunkAMTester(conf, load_checkpoint=False)
+    t.runner.load_weights(w, by_name=False)
+    xb = np.stack([xq[:2560 * 12], xq[2560 * 12:]]).astype(np.float32)[..., None]
+    labels = np.array([[4, 9, 12, 0], [7, 7, 30, 5]], np.int32)
+    lg, _ = t.runner.predict(xb)
+    hid, hlen = co.ctc_greedy(lg.cpu().numpy(), [lg.shape[1]] * 2, 40)
+    n = [0, 0, 0, 0]
+    ser = []
+    for hyp, ref in zip(np.clip(hid[:, :max(int(hlen.max()), 1)], 0, None), labels):
+        i, j = [int(v) for v in hyp if v != 0], [int(v) for v in ref if v != 0]
+        _, s_, d_, i_ = wer(j, i)
+        n[0] += len(j); n[1] += s_; n[2] += i_; n[3] += d_
+        ser.append(0 if i == j else 1)
+    t.set_datasets([(xb, np.array([48, 48], "int32"), None, None, labels, None)])
+    r = t.run()
+    assert r["s_i_d"] == "%d_%d_%d" % tuple(n[1:]) and r["steps"] == 1
+    assert abs(r["cer"] - sum(n[1:]) / (n[0] + 1e-6)) < 1e-12 and r["ser"] == np.mean(ser)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # bf16 MFMA mode (mi355asr_config.gemm_dtype = 1; BASELINE config 3)
 # ---------------------------------------------------------------------------------------------------------

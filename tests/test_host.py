@@ -581,6 +581,35 @@ def test_latest_checkpoint_picks_the_newest_step_of_any_format(tmp_path):
     assert latest_checkpoint(str(d)) == str(d / "model_41")             # TensorFlow bundle: the prefix
 
 
+def test_latest_tf_checkpoint_reads_the_state_file(tmp_path):
+    """tf.train.latest_checkpoint (test_chunk_asr.py:41): the `checkpoint` state file wins; otherwise the highest *.index"""
+    from tensorflowasr_amd.checkpoint import latest_tf_checkpoint
+    d = tmp_path / "all-ckpt"
+    d.mkdir()
+    with pytest.raises(FileNotFoundError):
+        latest_tf_checkpoint(str(d))
+    for f in ("model_3.index", "model_3.data-00000-of-00001", "model_12.index", "model_12.data-00000-of-00001"):
+        (d / f).write_bytes(b"")
+    assert latest_tf_checkpoint(str(d)) == str(d / "model_12")
+    (d / "checkpoint").write_text('model_checkpoint_path: "model_3"\nall_model_checkpoint_paths: "model_3"\n')
+    assert latest_tf_checkpoint(str(d)) == str(d / "model_3")
+
+
+def test_shipped_chunk_config_is_the_reference_schema():
+    """tensorflowasr_amd/configs/chunk_conformerS.yml: the five sub-model sections with the reference's keys and values
+    (asr/configs/chunk_conformerS.yml), accepted by models.ChunkConformer"""
+    from tensorflowasr_amd.config import load_yaml
+    from tensorflowasr_amd.models import ChunkConformer
+    c = load_yaml(os.path.join(ROOT, "tensorflowasr_amd", "configs", "chunk_conformerS.yml"))
+    mc = c["model_config"]
+    assert mc["name"] == "ChunkConformer" and set(mc) == {"name", "ChunkConformerFront", "ChunkConformerEncoder", "ChunkCTCPicker",
+                                                          "ChunkCTCDecoder", "ContextHelper"}
+    assert mc["ChunkConformerEncoder"]["num_blocks"] == 15 and mc["ChunkCTCDecoder"]["win_back"] == 8
+    assert mc["ChunkConformerFront"]["chunk_num"] == 16 and mc["ChunkCTCPicker"]["num_classes"] == 277
+    m = ChunkConformer(c, 277, 9171)
+    assert m.count_params() > 12_000_000 and m._stream_cfg()[:3] == (16, 160, 4)
+
+
 def test_typed_weight_loading_converts_on_the_host():
     """mi355asr_load_weight_typed: fp16 / bf16 / fp64 checkpoints"""
     lib, rc, p = _create(num_classes=20, ctc_num_blocks=1, has_encoder=0, num_blocks=0)
