@@ -1,0 +1,235 @@
+"""Golden vectors from the REFERENCE ITSELF for the rows of SURVEY section 8 that nothing in this container can pin
+(no TensorFlow / librosa here): mel frontend (a2-a4), ConvSubsampling (a5), the encoders (a10, a11), CTCDecoder + greedy
+ctc_decode (a12, a13), Translator (8f-1), LEAF and WavePickModel (8f-4), ChunkConformer.predict (a15).
+
+Run on any machine that has the reference checkout, TensorFlow 2.8+ and librosa:
+
+    REFERENCE_ROOT=/path/to/TensorflowASR python tests/golden/make_tf_goldens.py          # writes tests/golden/tf_*.npz
+
+What it does, per component: builds the reference's OWN Keras object, overwrites every variable with this repository's
+seeded weights (oracle.conformer_oracle.*_weights -- the same tensors the parity tests load into libmi355asr.so),
+mapping Keras variable names with tensorflowasr_amd.checkpoint.keras_names_to_abi (ChunkConformer: object-graph
+attribute paths with chunk_checkpoint_keys_to_abi) and FAILING if any variable of the model stays unassigned, runs it on
+this repository's seeded inputs with training=False, and stores inputs' seeds and the outputs.  The fixed frontend
+matrices the reference generates with librosa (DFT kernels, `freq2mel`) are stored as they come out of the reference:
+they are weight inputs on our side (librosa's `norm=1` changed meaning across versions).
+
+tests/test_tf_goldens.py picks the fixtures up when they exist: the NumPy oracle and (on the GPU box) libmi355asr.so are
+both compared with them -- that is what turns those rows from "parity unpinned" into pinned.  Nothing here is imported
+by the product; the fixtures are test data.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("REFERENCE_ROOT", "/root/reference")
+for p in (ROOT, os.path.join(ROOT, "tests"), REF):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from helpers import chunk_config_dict, co, waves  # noqa: E402
+from tensorflowasr_amd import checkpoint  # noqa: E402
+
+
+def _abi_of_keras_names(model, extra=None):
+    names = [v.name for v in model.weights]
+    m = checkpoint.keras_names_to_abi(names)
+    for n in names:                                    # the Melspectrogram layer's non-trainable variables
+        leaf = n.split(":")[0].rsplit("/", 1)[-1]
+        if "mel_layer" in n and leaf in ("real_kernels", "imag_kernels"):
+            m[n] = "mel_layer/" + leaf
+        elif "mel_layer" in n and leaf.startswith("Variable"):
+            m[n] = "mel_layer/freq2mel"
+    if extra:
+        m.update(extra(names))
+    return m
+
+
+def assign_by_name(model, weights, keep=("mel_layer/real_kernels", "mel_layer/imag_kernels", "mel_layer/freq2mel")):
+    """every variable of `model` <- weights[abi name]; the frontend constants in `keep` stay as the reference built them and
+    are returned so that the fixture can carry them"""
+    m = _abi_of_keras_names(model)
+    kept, missing = {}, []
+    for v in model.weights:
+        abi = m.get(v.name)
+        if abi in keep:
+            kept[abi] = v.numpy()
+            continue
+        if abi is None or abi not in weights:
+            missing.append((v.name, abi))
+            continue
+        v.assign(np.asarray(weights[abi], np.float32).reshape(v.shape))
+    if missing:
+        raise RuntimeError("variables without a seeded tensor (name mapping incomplete): %s" % missing[:8])
+    return kept
+
+
+def assign_by_object_path(model, weights, tf):
+    """ChunkConformer: checkpoint keys are attribute paths from the model root; walk them to reach each variable"""
+    with tempfile.TemporaryDirectory() as d:
+        prefix = os.path.join(d, "w")
+        model.save_weights(prefix)
+        keys = [k for k, _ in tf.train.list_variables(prefix)]
+    m = checkpoint.chunk_checkpoint_keys_to_abi(keys)
+    kept, done = {}, 0
+    for key, abi in m.items():
+        obj = model
+        for part in key.split("/.ATTRIBUTES/")[0].split("/"):
+            obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+        if abi.startswith("front/mel_layer/"):
+            kept[abi] = obj.numpy()
+            continue
+        obj.assign(np.asarray(weights[abi], np.float32).reshape(obj.shape))
+        done += 1
+    expected = {k for k in weights if not k.startswith("front/mel_layer/")}
+    if done != len(expected):
+        raise RuntimeError("assigned %d of %d ChunkConformer tensors: unmapped %s"
+                           % (done, len(expected), sorted(expected - set(m.values()))[:8]))
+    return kept
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
+
+
+def main():
+    import tensorflow as tf
+    from asr.models import conformer_blocks as cb
+    from asr.models.layers.time_frequency import Melspectrogram
+    meta = dict(tf_version=tf.__version__)
+    try:
+        import librosa
+        meta["librosa_version"] = librosa.__version__
+    except Exception:
+        pass
+    done = []
+
+    # ---- a2-a4: Melspectrogram layer (time_frequency.py:100-189) -------------------------------------------------
+    for L in (32000, 67263):
+        mel = Melspectrogram(sr=16000, n_mels=80, n_hop=160, n_dft=1024, trainable_fb=False)
+        x = waves(2, L, 5)
+        y = mel(tf.constant(x[..., None])).numpy()                      # [B, F, 80, 1]
+        consts = {v.name: v.numpy() for v in mel.weights}
+        fm = [v for k, v in consts.items() if k.split(":")[0].rsplit("/", 1)[-1].startswith("Variable")][0]
+        rk = [v for k, v in consts.items() if "real_kernels" in k][0]
+        ik = [v for k, v in consts.items() if "imag_kernels" in k][0]
+        save("tf_mel_L%d.npz" % L, wave_seed=5, L=L, mel=y[..., 0], freq2mel=fm,
+             real_kernels_bins=rk.reshape(1024, -1)[:, [0, 1, 37, 256, 512]], imag_kernels_bins=ik.reshape(1024, -1)[:, [0, 1, 37, 256, 512]],
+             **{"meta_" + k: v for k, v in meta.items()})
+    done.append("mel")
+
+    # ---- a5: ConvSubsampling (conformer_blocks.py:67-96) -----------------------------------------------------------
+    cfg = dict(co.CONFORMER_S, num_blocks=2)
+    w = co.encoder_weights(cfg, seed=0)
+    sub = cb.ConvSubsampling(odim=144, reduction_factor=4, dropout=0.0)
+    rng = np.random.default_rng(200)
+    melin = (-80.0 * rng.random((3, 200, 80, 1))).astype(np.float32)
+    sub(tf.constant(melin), training=False)
+    full = lambda n: n if "conv_subsampling" in n else "conv_subsampling/" + n      # noqa: E731 (scope of a stand-alone layer)
+    names = {full(v.name): v for v in sub.weights}
+    m = checkpoint.keras_names_to_abi(list(names))
+    if len(m) != len(names):
+        raise RuntimeError("ConvSubsampling variables not mapped: %s" % [n for n in names if n not in m])
+    for n, v in names.items():
+        v.assign(w[m[n]].reshape(v.shape))
+    save("tf_conv_subsampling.npz", mel_seed=200, out=sub(tf.constant(melin), training=False).numpy(), weights_seed=0)
+    done.append("conv_subsampling")
+
+    # ---- a10, a12, a13: ConformerEncoder (2 blocks) + CTCDecoder + ctc_decode --------------------------------------
+    enc = cb.ConformerEncoder(dmodel=144, reduction_factor=4, num_blocks=2, head_size=36, num_heads=4, kernel_size=32,
+                              fc_factor=0.5, dropout=0.0, add_wav_info=False, sample_rate=16000, n_mels=80,
+                              mel_layer_type="Melspectrogram", mel_layer_trainable=False, stride_ms=10)
+    enc._build()
+    kept = assign_by_name(enc, w)
+    V = 50
+    wc = co.ctc_decoder_weights(cfg, V, seed=1)
+    ctc = cb.CTCDecoder(num_classes=V, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32,
+                        dropout=0.0, fc_factor=0.5)
+    ctc._build()
+    assign_by_name(ctc, wc)
+    x = waves(2, 32000)
+    e = enc(tf.constant(x[..., None]), training=False)
+    lg = ctc(e, training=False)
+    dec = tf.keras.backend.ctc_decode(tf.nn.softmax(lg, -1), np.array([e.shape[1]] * 2, "int32"))[0][0].numpy()
+    save("tf_encoder_ctc.npz", wave_seed=0, L=32000, enc=e.numpy(), logits=lg.numpy(), ctc_decode=dec, num_classes=V,
+         enc_weights_seed=0, ctc_weights_seed=1, freq2mel=kept.get("mel_layer/freq2mel"))
+    done.append("encoder_ctc")
+
+    # ---- a11: StreamingConformerEncoder (Streaming_ConformerS.yml dims, 2 blocks) ---------------------------------
+    scfg = dict(co.STREAMING_S, num_blocks=2)
+    ws = co.encoder_weights(scfg, seed=2)
+    senc = cb.StreamingConformerEncoder(dmodel=256, reduction_factor=4, num_blocks=2, head_size=64, num_heads=4,
+                                        kernel_size=5, fc_factor=0.5, dropout=0.0, add_wav_info=False, sample_rate=16000,
+                                        n_mels=80, mel_layer_type="Melspectrogram", mel_layer_trainable=False, stride_ms=10)
+    senc.add_chunk_size(8000, 80, 640)
+    senc._build()
+    assign_by_name(senc, ws)
+    xs = waves(2, 24000, 9)
+    save("tf_streaming_encoder.npz", wave_seed=9, L=24000, enc=senc(tf.constant(xs[..., None]), training=False).numpy(),
+         weights_seed=2)
+    done.append("streaming_encoder")
+
+    # ---- 8f-1: Translator ------------------------------------------------------------------------------------------
+    tcfg = dict(co.CONFORMER_S, translator_num_blocks=2, translator_kernel_size=32, translator_fc_factor=0.5)
+    wt = co.translator_weights(tcfg, 60, 80, seed=13)
+    tr = cb.Translator(inp_classes=60, tar_classes=80, dmodel=144, num_blocks=2, head_size=36, num_heads=4,
+                       fc_factor=0.5, dropout=0.0, kernel_size=32)
+    tr._build()
+    assign_by_name(tr, wt)
+    rng = np.random.default_rng(3040)
+    ids = rng.integers(0, 60, (3, 40)).astype(np.int32)
+    encin = rng.standard_normal((3, 250, 144)).astype(np.float32)
+    save("tf_translator.npz", seed=3040, logits=tr([tf.constant(ids), tf.constant(encin)], training=False).numpy(),
+         weights_seed=13)
+    done.append("translator")
+
+    # ---- 8f-4: LEAF frontend and the WavePickModel branch ----------------------------------------------------------
+    try:
+        from leaf_audio import frontend
+        leaf = frontend.Leaf(n_filters=80, sample_rate=16000, window_stride=10,
+                             complex_conv_init=frontend.initializers.GaborInit(sample_rate=16000, min_freq=60, max_freq=7800))
+        xl = waves(2, 16000, 60)
+        yl = leaf(tf.constant(xl[..., None]), training=False).numpy()
+        save("tf_leaf.npz", wave_seed=60, L=16000, out=yl, **{v.name.replace("/", "|"): v.numpy() for v in leaf.weights})
+        done.append("leaf")
+    except Exception as e:      # tensorflow_addons / leaf dependencies may be missing
+        print("LEAF skipped:", repr(e))
+    from asr.models.wav_model import WavePickModel
+    wp = WavePickModel(144, 640)
+    xw = waves(2, 16000, 90)
+    wp(tf.constant(xw[..., None]), training=False)
+    ww = co.wave_pick_weights(144, 640, seed=22)
+    names = {(v.name if "wave_pick_model" in v.name else "wave_pick_model/" + v.name): v for v in wp.weights}
+    m = checkpoint.keras_names_to_abi(list(names))
+    if len(m) != len(names):
+        raise RuntimeError("WavePickModel variables not mapped: %s" % [n for n in names if n not in m][:8])
+    for n, v in names.items():
+        v.assign(ww[m[n]].reshape(v.shape))
+    save("tf_wave_pick.npz", wave_seed=90, L=16000, out=wp(tf.constant(xw[..., None]), training=False).numpy(), weights_seed=22)
+    done.append("wave_pick")
+
+    # ---- a15: ChunkConformer.predict (chunk_conformerS.yml dims, 2 encoder blocks, small vocabularies) -------------
+    from asr.models.chunk_conformer_blocks import ChunkConformer
+    ccfg = dict(co.CHUNK_S, enc_num_blocks=2, picker_num_classes=30, decoder_num_classes=40)
+    wch = co.chunk_weights(ccfg, seed=3)
+    xc = waves(2, 24000, 40)
+    model = ChunkConformer(chunk_config_dict(ccfg), 30, 40)
+    kept = assign_by_object_path(model, wch, tf)
+    front = model.front(tf.constant(xc[..., None]), training=False)
+    encc = model.encoder(front, training=False)
+    phone, hidden = model.phone_picker(encc, training=False)
+    save("tf_chunk_predict.npz", wave_seed=40, L=24000, front=front.numpy(), enc=encc.numpy(), picker_logits=phone.numpy(),
+         picker_hidden=hidden.numpy(), text_logits=model.predict(tf.constant(xc[..., None])).numpy(), weights_seed=3,
+         freq2mel=kept.get("front/mel_layer/freq2mel"))
+    done.append("chunk_predict")
+    print("done:", done)
+
+
+if __name__ == "__main__":
+    main()
