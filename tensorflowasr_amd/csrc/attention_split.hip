@@ -1,0 +1,220 @@
+// Full (unmasked) multi-head attention for utterances of up to 256 frames, head size 36, on the bf16 matrix pipe with
+// exactly split operands (round 2; replaces attention_lds_kernel on the offline dmodel-144 path).
+// Reference: asr/models/layers/multihead_attention.py:151-188, called from conformer_blocks.py:164-170.
+//
+// Why: attention_lds_kernel runs 336 v_mfma_f32_16x16x4_f32 per wave (32 cycles each) and stages K / V^T twice per
+// (utterance, head) -- once per 128-query workgroup: 35 us per launch, 2.5x the algorithmic HBM traffic.  Here
+//   * one workgroup of 16 waves = all (<= 256) queries of one (utterance, head): K and V are staged ONCE, as MFMA
+//     fragments: every fp32 value is written as three bf16 terms (exact: 3 x 8 significand bits), a fragment read is one
+//     conflict-free ds_read_b128;
+//   * S^T = K Q^T: dims 0..31 as one 16x16x32 bf16 step = six MFMAs over the term pairs (i + j <= 2, smallest first;
+//     the dropped pairs are below 2^-24 of a product), dims 32..35 as one fp32 16x16x4 MFMA: 128 cycles per 16-key tile
+//     instead of 288;
+//   * softmax in registers as before (all <= 256 scores of a query live in its four lanes, exp2 with log2 e folded into q);
+//   * O^T = V^T P^T: the S^T accumulator of two key tiles IS the B operand of a 32-key step once split (the k-slot order
+//     of a step is chosen to match: slot 8g + j <-> key 32s + 4g + j, slot 8g + 4 + j <-> key 32s + 16 + 4g + j, and V is
+//     staged in that order): 18 MFMAs of 16 cycles per 32 keys instead of 24 of 32.
+// 4352 matrix-pipe cycles per wave instead of 10 752.  Grid (ceil(Tq / 256), H, B): at 64 x 10 s exactly one workgroup
+// per CU, four waves per SIMD.
+#include "common.h"
+#include "launch.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct Split8 { u32x4_t t[3]; };
+
+DEV Split8 split8(f32x4 lo, f32x4 hi) {      // exact: x = t0 + t1 + t2 (truncation; the remainders are exact)
+  float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  Split8 f;
+#pragma unroll
+  for (int term = 0; term < 3; ++term) {
+    unsigned d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * k]), a1 = __builtin_bit_cast(unsigned, v[2 * k + 1]);
+      d[k] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+      if (term < 2) {
+        v[2 * k] -= __builtin_bit_cast(float, a0 & 0xffff0000u);
+        v[2 * k + 1] -= __builtin_bit_cast(float, a1 & 0xffff0000u);
+      }
+    }
+    f.t[term] = u32x4_t{d[0], d[1], d[2], d[3]};
+  }
+  return f;
+}
+DEV f32x4 mma32(u32x4_t a, u32x4_t b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// c += A B with both operands split: the six term pairs with i + j <= 2, smallest first
+DEV f32x4 mma_split(const u32x4_t (&a)[3], const Split8& b, f32x4 c) {
+  c = mma32(a[2], b.t[0], c);
+  c = mma32(a[1], b.t[1], c);
+  c = mma32(a[0], b.t[2], c);
+  c = mma32(a[1], b.t[0], c);
+  c = mma32(a[0], b.t[1], c);
+  c = mma32(a[0], b.t[0], c);
+  return c;
+}
+
+constexpr int HS = 36;
+constexpr int TPK = 256;        // keys held in LDS
+constexpr int NKT = TPK / 16;   // key tiles
+constexpr int NST = TPK / 32;   // 32-key steps of P V
+constexpr int OT = 3;           // output feature tiles (48 >= 36)
+constexpr int AW = 16;          // waves = query tiles per workgroup
+constexpr int ATH = AW * 64;
+
+__global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) u32x4_t Kf[3][NKT][64];        // 48 KB  K fragments (dims 0..31), three terms
+  __shared__ __attribute__((aligned(16))) float Kt[NKT][64];              //  4 KB  K[key][32 + g] for the fp32 tail step
+  __shared__ __attribute__((aligned(16))) u32x4_t Vf[3][NST][OT][64];     // 72 KB  V^T fragments in step order, three terms
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = lane >> 4, g4 = g * 4, c = lane & 15;
+  const int T = a.Tk, TQ = a.Tq;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int ld = a.ldk, D = a.D;
+  const float* __restrict__ kbase = a.k + (size_t)b * T * ld + h * HS;
+  const float* __restrict__ vbase = a.v + (size_t)b * T * ld + h * HS;
+
+  // ---- this lane's query fragment: query c of tile qt, dims 8g..8g+7 and 32 + g (log2 e folded in: softmax uses exp2)
+  const int qt = blockIdx.x * AW + wv;
+  const int tq = qt * 16 + c;
+  const float* qrow = a.q + ((size_t)b * TQ + min(tq, TQ - 1)) * a.ldq + h * HS;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const f32x4 qlo = ldg4(qrow + 8 * g), qhi = ldg4(qrow + 8 * g + 4);
+  const float qtl = qrow[32 + g] * LOG2E;
+
+  // ---- stage K: thread (tile wv, lane) owns exactly one fragment triple; all global loads first, then the LDS writes
+  const int skey = 16 * wv + c;
+  const float* krow = kbase + (size_t)min(skey, T - 1) * ld;
+  f32x4 klo = ldg4(krow + 8 * g), khi = ldg4(krow + 8 * g + 4);
+  float ktl = krow[32 + g];
+  // ---- stage V: 256 keys x 9 chunks of 4 features, three per thread
+  constexpr int NV = (TPK * (HS / 4) + ATH - 1) / ATH;
+  f32x4 vv[NV];
+#pragma unroll
+  for (int it = 0; it < NV; ++it) {
+    const int idx = min(tid + it * ATH, TPK * (HS / 4) - 1);
+    const int key = idx / (HS / 4), ch = idx - key * (HS / 4);
+    vv[it] = ldg4(vbase + (size_t)min(key, T - 1) * ld + 4 * ch);
+  }
+  if (skey >= T) { klo = splat4(0.f); khi = splat4(0.f); ktl = 0.f; }
+  {
+    const Split8 kf = split8(klo, khi);
+    Kf[0][wv][lane] = kf.t[0];
+    Kf[1][wv][lane] = kf.t[1];
+    Kf[2][wv][lane] = kf.t[2];
+    Kt[wv][lane] = ktl;
+  }
+  unsigned short* vh = reinterpret_cast<unsigned short*>(&Vf[0][0][0][0]);
+#pragma unroll
+  for (int it = 0; it < NV; ++it) {
+    const int idx = tid + it * ATH;
+    if (idx < TPK * (HS / 4)) {
+      const int key = idx / (HS / 4), ch = idx - key * (HS / 4);
+      const f32x4 v = key < T ? vv[it] : splat4(0.f);            // padded keys must be exact zeros (0 x garbage = NaN)
+      // k-slot of `key` inside its 32-key step (see the header): lane group kg = (key & 15) >> 2, slot 4 * tile + (key & 3)
+      const int s = key >> 5, r = key & 31, kg = (r & 15) >> 2, slot = 4 * (r >> 4) + (r & 3);
+      float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = 4 * ch + q, ot = f >> 4, fc = f & 15;
+        float x = e[q];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const unsigned bits = __builtin_bit_cast(unsigned, x);
+          vh[((((t * NST + s) * OT + ot) * 64 + 16 * kg + fc) << 3) + slot] = (unsigned short)(bits >> 16);
+          x -= __builtin_bit_cast(float, bits & 0xffff0000u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (qt * 16 >= TQ) return;
+  const int nkt = (T + 15) / 16;       // key tiles that hold at least one real key (uniform)
+  const Split8 qf = split8(qlo * splat4(LOG2E), qhi * splat4(LOG2E));
+
+  // ---- S^T = K Q^T: lane holds S^T[key = 16 kt + 4 g + j][query c] in log2 units
+  f32x4 sc[NKT];
+  auto qk_tile = [&](int kt) {
+    const u32x4_t kf[3] = {Kf[0][kt][lane], Kf[1][kt][lane], Kf[2][kt][lane]};
+    const float kl = Kt[kt][lane];
+    f32x4 acc = mma_split(kf, qf, splat4(0.f));
+    sc[kt] = mfma4(kl, qtl, acc);
+  };
+  const bool full = (nkt == NKT);
+  if (full) {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) qk_tile(kt);
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) qk_tile(kt); else sc[kt] = splat4(-INFINITY);
+    }
+  }
+
+  // ---- softmax over keys: keys >= T are masked, which only the last real tile can contain
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    if (kt < nkt && 16 * kt + 16 > T) {
+      const int kb = 16 * kt + g4;
+      sc[kt].x = (kb + 0 < T) ? sc[kt].x : -INFINITY;
+      sc[kt].y = (kb + 1 < T) ? sc[kt].y : -INFINITY;
+      sc[kt].z = (kb + 2 < T) ? sc[kt].z : -INFINITY;
+      sc[kt].w = (kb + 3 < T) ? sc[kt].w : -INFINITY;
+    }
+    mx = fmaxf(mx, fmaxf(fmaxf(sc[kt].x, sc[kt].y), fmaxf(sc[kt].z, sc[kt].w)));
+  }
+  mx = group_max(mx);                  // every query sees key 0, so mx is finite
+  float psum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    sc[kt].x = __builtin_amdgcn_exp2f(sc[kt].x - mx);      // exp2(-inf) = 0 for masked keys
+    sc[kt].y = __builtin_amdgcn_exp2f(sc[kt].y - mx);
+    sc[kt].z = __builtin_amdgcn_exp2f(sc[kt].z - mx);
+    sc[kt].w = __builtin_amdgcn_exp2f(sc[kt].w - mx);
+    psum += (sc[kt].x + sc[kt].y) + (sc[kt].z + sc[kt].w);
+  }
+
+  // ---- O^T[feat][query] += V^T[feat][key] P^T[key][query], 32 keys per step
+  f32x4 o[OT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i) o[i] = splat4(0.f);
+  const int nst = (nkt + 1) / 2;
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+    if (s < nst) {
+      const Split8 pf = split8(sc[2 * s], sc[2 * s + 1]);
+#pragma unroll
+      for (int i = 0; i < OT; ++i) {
+        const u32x4_t vf[3] = {Vf[0][s][i][lane], Vf[1][s][i][lane], Vf[2][s][i][lane]};
+        o[i] = mma_split(vf, pf, o[i]);
+      }
+    }
+  }
+  const float inv = 1.0f / group_sum(psum);
+  if (tq < TQ) {
+    float* orow = a.ctx + ((size_t)b * TQ + tq) * D + h * HS;
+#pragma unroll
+    for (int i = 0; i < OT; ++i) {
+      if (16 * i + g4 < HS) stg4(orow + 16 * i + g4, o[i] * splat4(inv));
+    }
+  }
+}
+
+}  // namespace
+
+bool attention_split_applicable(int hs, const AttnArgs& a) {
+  return hs == HS && a.win_front < 0 && a.Tk <= TPK && a.Tk > 16 && a.Tq > 16 && a.ldk % 4 == 0 && a.ldq % 4 == 0;
+}
+
+int launch_attention_split(int hs, const AttnArgs& a, hipStream_t s) {
+  if (!attention_split_applicable(hs, a)) return -1;
+  const int qtiles = (a.Tq + 15) / 16;
+  hipLaunchKernelGGL(attention_split_kernel, dim3((qtiles + AW - 1) / AW, a.H, a.B), dim3(ATH), 0, s, a);
+  return 0;
+}

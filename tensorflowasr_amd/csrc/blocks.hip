@@ -607,7 +607,12 @@ static void launch_attention_t(const AttnArgs& a, hipStream_t s) {
 
 int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
   // short full-attention utterances (offline ConformerCTC): K / V^T staged in LDS (attention_lds.hip)
+  // MI355ASR_ATTN_SPLIT=0: the fp32-MFMA LDS kernel of round 1 instead of the split-bf16 one (attention_split.hip);
+  // MI355ASR_ATTN_LDS=0: neither (online-softmax kernel with K / V from L2)
   static const bool lds_env = [] { const char* v = getenv("MI355ASR_ATTN_LDS"); return v ? atoi(v) != 0 : true; }();
+  static const bool split_env = [] { const char* v = getenv("MI355ASR_ATTN_SPLIT"); return v ? atoi(v) != 0 : true; }();
+  if (lds_env && split_env && attention_split_applicable(HS, a))
+    return launch_attention_split(HS, a, s);
   if (lds_env && attention_lds_applicable(HS, a)) return launch_attention_lds(HS, a, s);
   if (HS == 36) launch_attention_t<36>(a, s);
   else if (HS == 64) launch_attention_t<64>(a, s);

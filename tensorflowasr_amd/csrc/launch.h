@@ -259,6 +259,8 @@ int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s);
 int launch_attention(int HS, const AttnArgs& a, hipStream_t s);
 bool attention_lds_applicable(int HS, const AttnArgs& a);
 int launch_attention_lds(int HS, const AttnArgs& a, hipStream_t s);
+bool attention_split_applicable(int HS, const AttnArgs& a);
+int launch_attention_split(int HS, const AttnArgs& a, hipStream_t s);
 int launch_dwconv(int K, const DwArgs& a, hipStream_t s);
 int launch_stft(const StftArgs& a, hipStream_t s);
 int launch_utt_max(const UttMaxArgs& a, int B, hipStream_t s);

@@ -724,10 +724,12 @@ def test_feature_pick_entry_point_matches_oracle(torch_cuda):
     f, c = m.feature_pick(hid, ctc)
     assert f.shape == rf.shape == (B, T, d) and c.shape == rc.shape
     assert np.array_equal(f.cpu().numpy(), rf.astype(np.float32)) and np.array_equal(c.cpu().numpy(), rc)
-    f2, c2 = m.feature_pick(hid[:3], ctc[:3], max_T=60)
-    n = rf[:3].any(-1).sum(1).max()
-    assert f2.shape[1] == 60 >= n and np.array_equal(f2.cpu().numpy()[:, :n], rf[:3, :n].astype(np.float32))
-    assert not f2.cpu().numpy()[2].any()
+    f2, c2 = m.feature_pick(hid[:3], ctc[:3], max_T=90)             # max_T above the batch maximum: zero padded to it
+    n = int(counts[:3].max())
+    assert f2.shape[1] == c2.shape[1] == 90 > n and np.array_equal(f2.cpu().numpy()[:, :n], rf[:3, :n].astype(np.float32))
+    assert not f2.cpu().numpy()[2].any() and not f2.cpu().numpy()[:, n:].any()
+    f3, _ = m.feature_pick(hid[:3], ctc[:3], max_T=5)                # below it: the batch maximum wins
+    assert f3.shape[1] == n
     f0, c0 = m.feature_pick(hid[2:3], ctc[2:3])
     assert f0.shape == (1, 0, d) and c0.shape == (1, 0, V)
 
