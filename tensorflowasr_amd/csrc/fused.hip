@@ -22,6 +22,7 @@
 // Reference semantics: asr/models/conformer_blocks.py:126-134 (FFModule), :164-170 + multihead_attention.py:151-188
 // (MHSA), :209-219 (ConvModule), :259-265 (block).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "launch.h"
@@ -648,21 +649,21 @@ struct WG3 { u32x4_t w[3][3]; };   // [tile][term]
   G.w[1][TERM] = lds_read16<((3 * (GRP) + 1) * 3 + (TERM)) * 1024>(ADDR); \
   G.w[2][TERM] = lds_read16<((3 * (GRP) + 2) * 3 + (TERM)) * 1024>(ADDR);
 #define GRP_WAIT(G, TERM) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(G.w[0][TERM]), "+v"(G.w[1][TERM]), "+v"(G.w[2][TERM]))
+#define MMA_ASM(ACC, W, X) \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, W), __builtin_bit_cast(bf16x8_t, X), ACC, 0, 0, 0)
 #define GRP_MMA(ACC, G, TERM, XT) \
-  _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) \
-    ACC[i_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, G.w[i_][TERM]), \
-                                                      __builtin_bit_cast(bf16x8_t, XT), ACC[i_], 0, 0, 0);
+  MMA_ASM(ACC[0], G.w[0][TERM], XT); MMA_ASM(ACC[1], G.w[1][TERM], XT); MMA_ASM(ACC[2], G.w[2][TERM], XT);
+#define WAIT_MMA_ASM(ACC, G, TERM, XT) GRP_WAIT(G, TERM); MMA_ASM(ACC, G.w[0][TERM], XT)
+#define GRP_WAIT_MMA(ACC, G, TERM, XT) \
+  WAIT_MMA_ASM(ACC[0], G, TERM, XT); MMA_ASM(ACC[1], G.w[1][TERM], XT); MMA_ASM(ACC[2], G.w[2][TERM], XT);
 template <int NGRP>
 DEV void grp_step(f32x4* acc, const Split8& xf, WG3& g, unsigned naddr) {
-  GRP_WAIT(g, 2);
-  GRP_MMA(acc, g, 2, xf.t[0])
+  GRP_WAIT_MMA(acc, g, 2, xf.t[0])
   GRP_FETCH(g, NGRP, 2, naddr)
-  GRP_WAIT(g, 1);
-  GRP_MMA(acc, g, 1, xf.t[1])
+  GRP_WAIT_MMA(acc, g, 1, xf.t[1])
   GRP_MMA(acc, g, 1, xf.t[0])
   GRP_FETCH(g, NGRP, 1, naddr)
-  GRP_WAIT(g, 0);
-  GRP_MMA(acc, g, 0, xf.t[2])
+  GRP_WAIT_MMA(acc, g, 0, xf.t[2])
   GRP_MMA(acc, g, 0, xf.t[1])
   GRP_MMA(acc, g, 0, xf.t[0])
   GRP_FETCH(g, NGRP, 0, naddr)
@@ -677,6 +678,92 @@ DEV void slab_step_p(f32x4* acc, const Split8& xf, WG3& g, unsigned addr, unsign
   grp_step<1>(acc, xf, g, addr);
   grp_step<2>(acc + 3, xf, g, addr);
   grp_step<0>(acc + 6, xf, g, next_addr);
+}
+
+// ---- VALU under the MFMAs -------------------------------------------------------------------------------------------
+// Measured (profiles/r02_ring_experiments.md): with swish and the operand splits removed, tail_ff1 drops from 85 to 68 us --
+// hipcc emits that VALU work as clusters between the slabs, where the matrix pipe idles (one consumer wave per SIMD).
+// tools/ubench/mfma_fill.hip: behind one v_mfma_f32_16x16x32_bf16 (16.5 cycles) one or two VALU instructions are free
+// (16.9 / 17.6 cycles per MFMA), the third costs 4.5 cycles, a second v_exp 8, a ds_read_b128 3.3.  So the work is cut into
+// slots of at most two instructions and one transcendental (prep_sched.inc, generated by tools/gen_prep_sched.py) and slot
+// k is issued right behind MFMA k of the slab, fenced there with sched_barrier.
+// What was tried on the way (profiles/r02_ring_experiments.md): fences per MFMA triple with 5-10 instructions per slot (no
+// gain: only ~1-2 hide behind an MFMA); empty asm pins on the slot's registers and the accumulator (hipcc pads each pin
+// with s_nop, which costs what the placement saves); the MFMAs themselves as volatile asm statements (clean ISA, but
+// 4-6 % slower than the builtin: hipcc then also pads around every asm MFMA).  tools/ubench/slab_stream.hip bounds what
+// is left: this stream without DMA / barrier runs 1031 cycles per slab, 1071 with one filler per MFMA, 1332 with two.
+struct PrepCtx {
+  f32x4 &lo, &hi;                       // the two hidden tiles being prepared (residuals of the split end up here)
+  const f32x4 &slo, &tlo, &shi, &thi;   // folded-BatchNorm scale / shift (AFF)
+  Split8& out;
+  float ta, tb, m0, m1;
+};
+template <bool AFF, bool FULL> struct PrepSlots;
+#include "prep_sched.inc"
+#define PREP_PIN(C) __builtin_amdgcn_sched_barrier(0)
+
+// MFMA k of the slab (k = SLOT0 + i), wrapped by the caller's pre(k, acc) / post(k, acc)
+template <int TERM, int SLOT0, int I, bool WAIT, class FILL>
+DEV void mma_f(f32x4* acc, WG3& g, const u32x4_t& xt, const FILL& f) {
+  f.template pre<SLOT0 + I>();
+  if constexpr (WAIT) { WAIT_MMA_ASM(acc[I], g, TERM, xt); } else { MMA_ASM(acc[I], g.w[I][TERM], xt); }
+  f.template post<SLOT0 + I>();
+}
+// WAIT: the batch is the first use of its term's fragments (wait folded into its first MFMA)
+template <int TERM, int SLOT0, bool WAIT, class FILL>
+DEV void grp_mma_f(f32x4* acc, WG3& g, const u32x4_t& xt, const FILL& f) {
+  mma_f<TERM, SLOT0, 0, WAIT>(acc, g, xt, f);
+  mma_f<TERM, SLOT0, 1, false>(acc, g, xt, f);
+  mma_f<TERM, SLOT0, 2, false>(acc, g, xt, f);
+}
+template <int NGRP, int SLOT0, class FILL>
+DEV void grp_step_f(f32x4* acc, const Split8& xf, WG3& g, unsigned naddr, const FILL& pre) {
+
+  grp_mma_f<2, SLOT0 + 0, true>(acc, g, xf.t[0], pre);
+  GRP_FETCH(g, NGRP, 2, naddr)
+  grp_mma_f<1, SLOT0 + 3, true>(acc, g, xf.t[1], pre);
+  grp_mma_f<1, SLOT0 + 6, false>(acc, g, xf.t[0], pre);
+  GRP_FETCH(g, NGRP, 1, naddr)
+  grp_mma_f<0, SLOT0 + 9, true>(acc, g, xf.t[2], pre);
+  grp_mma_f<0, SLOT0 + 12, false>(acc, g, xf.t[1], pre);
+  grp_mma_f<0, SLOT0 + 15, false>(acc, g, xf.t[0], pre);
+  GRP_FETCH(g, NGRP, 0, naddr)
+}
+// W(slab)^T x with prep work for (c.lo, c.hi) behind the MFMAs FIRST .. 53: the N slots of the schedule are spread over the
+// 54 - FIRST MFMAs, the leading ones doubled when there are more slots than MFMAs
+template <bool AFF, bool FULL, int FIRST>
+struct PrepFill {
+  static constexpr int N = PrepSlots<AFF, FULL>::N, ROOM = 54 - FIRST, DBL = N > ROOM ? N - ROOM : 0;
+  static_assert(N <= 2 * ROOM, "prep schedule does not fit");
+  PrepCtx& c;
+  static constexpr int first_slot(int j) { return j < DBL ? 2 * j : j + DBL; }   // work slot(s) of MFMA FIRST + j
+  template <int K>
+  DEV void pre() const {                               // MFMA K - 1 had work: its results before this MFMA
+    constexpr int j = K - FIRST;
+    if constexpr (j >= 1) {
+      if constexpr (first_slot(j - 1) < N) PREP_PIN(c);
+    }
+  }
+  template <int K>
+  DEV void post() const {
+    constexpr int j = K - FIRST;
+    if constexpr (j >= 0) {
+      constexpr int w0 = first_slot(j);
+      if constexpr (w0 < N) {
+        PREP_PIN(c);
+        prep_slot<w0, AFF, FULL>(c);
+        if constexpr (j < DBL && w0 + 1 < N) prep_slot<w0 + 1, AFF, FULL>(c);
+      }
+    }
+  }
+};
+template <bool AFF, bool FULL, int FIRST>
+DEV void slab_step_f(f32x4* acc, const Split8& xf, WG3& g, unsigned addr, unsigned next_addr, PrepCtx& c) {
+  const PrepFill<AFF, FULL, FIRST> f{c};
+  grp_step_f<1, 0>(acc, xf, g, addr, f);
+  grp_step_f<2, 18>(acc + 3, xf, g, addr, f);
+  grp_step_f<0, 36>(acc + 6, xf, g, next_addr, f);
+  PREP_PIN(c);                                          // the last slot before what follows
 }
 
 constexpr int LD_THREADS = 2 * BLOCK_THREADS;
@@ -756,7 +843,10 @@ DEV void tail_stash(TailLds& p, const TailFf2Args& a) {
   stash_store<D>(p.fg, r8); stash_store<D>(p.fb, r9);
 }
 
-// y += W2 act(W1 x + b1) over nch hidden chunks of 9 tiles (10 slabs each); aff: act = swish(s (.) + t) (folded BatchNorm)
+// y += W2 act(W1 x + b1) over nch hidden chunks of 9 tiles (10 slabs each); AFF: act = swish(s (.) + t) (folded BatchNorm).
+// Activation and operand split run behind the MFMAs (slab_step_f), one pair of hidden tiles per slab:
+//   W1 slab 4, MFMAs 18..53 (tiles 0..2 are complete since MFMA 17): prepare (h0, h1) -> operand of W2 slab 0
+//   W2 slab t = 0..3: prepare (h[2t+2], h[2t+3]) -> operand of slab t + 1 (the last pair is (h8, zero padding))
 template <bool AFF, class ST>
 DEV void ring_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS32X], ST& st, WG3& wg, int g4, int nch, const float* b1,
                     const float* as, const float* at) {
@@ -765,20 +855,41 @@ DEV void ring_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS32X], ST& st, WG3& wg, 
     f32x4 h[KB];
 #pragma unroll
     for (int i = 0; i < KB; ++i) h[i] = lds4(b1, ch * KB + i, g4);
-    static_for<0, KS32X>([&](auto T) {
+    static_for<0, KS32X - 1>([&](auto T) {
       constexpr int t = decltype(T)::value;
       slab_step_p(h, xf[t], wg, st.cur_addr(), st.next_addr());
       st.advance();
     });
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      if (AFF) h[i] = h[i] * lds4(as, ch * KB + i, g4) + lds4(at, ch * KB + i, g4);
-      h[i] = swish4(h[i]);
+    Split8 hf[KS32X];
+    f32x4 zero = splat4(0.f);
+    // folded-BatchNorm scale / shift of the pair being prepared (fetched right before its slab)
+    f32x4 slo = splat4(1.f), tlo = splat4(0.f), shi = splat4(1.f), thi = splat4(0.f);
+    auto aff_fetch = [&](int i) {
+      if (AFF) {
+        slo = lds4(as, ch * KB + i, g4); tlo = lds4(at, ch * KB + i, g4);
+        if (i + 1 < KB) { shi = lds4(as, ch * KB + i + 1, g4); thi = lds4(at, ch * KB + i + 1, g4); }
+      }
+    };
+    aff_fetch(0);
+    {
+      PrepCtx c{h[0], h[1], slo, tlo, shi, thi, hf[0], 0.f, 0.f, 0.f, 0.f};
+      slab_step_f<AFF, true, 18>(h, xf[KS32X - 1], wg, st.cur_addr(), st.next_addr(), c);
     }
+    st.advance();
     static_for<0, KS32X>([&](auto T) {
       constexpr int t = decltype(T)::value;
-      const Split8 hf = split8(h[2 * t], 2 * t + 1 < KB ? h[2 * t + 1 < KB ? 2 * t + 1 : 0] : splat4(0.f));
-      slab_step_p(y, hf, wg, st.cur_addr(), st.next_addr());
+      if constexpr (t == KS32X - 1) {
+        slab_step_p(y, hf[t], wg, st.cur_addr(), st.next_addr());
+      } else {
+        aff_fetch(2 * t + 2);
+        if constexpr (2 * t + 3 < KB) {
+          PrepCtx c{h[2 * t + 2], h[2 * t + 3], slo, tlo, shi, thi, hf[t + 1], 0.f, 0.f, 0.f, 0.f};
+          slab_step_f<AFF, true, 0>(y, hf[t], wg, st.cur_addr(), st.next_addr(), c);
+        } else {
+          PrepCtx c{h[2 * t + 2], zero, slo, tlo, shi, thi, hf[t + 1], 0.f, 0.f, 0.f, 0.f};
+          slab_step_f<AFF, false, 0>(y, hf[t], wg, st.cur_addr(), st.next_addr(), c);
+        }
+      }
       st.advance();
     });
   }
