@@ -236,6 +236,8 @@ def test_config5_chunk_conformer_2x30s_stages_and_beam_vs_oracle(torch_cuda):
             same += sum(int(p == q) for p, q in zip(ha, hb))
             common += len(set(ha) & set(hb))
             tot += n
-            assert np.abs(np.sort(a[2][u, :n]) - np.sort(b[2][u, :n])).max() < 1e-4 * counts[u] + 1e-3
+            sa, sb = dict(zip(ha, a[2][u, :n])), dict(zip(hb, b[2][u, :n]))
+            for hyp in set(ha) & set(hb):                      # the same hypothesis scores the same on both paths
+                assert abs(sa[hyp] - sb[hyp]) < 1e-4 * counts[u] + 1e-3
         print("config 5 beam %d: %d / %d hypotheses identical in rank, %d in common" % (beam, same, tot, common))
         assert common >= 0.9 * tot

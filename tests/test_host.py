@@ -695,23 +695,30 @@ def test_chunk_checkpoint_keys_map_onto_every_chunk_tensor():
     assert m == keys
 
 
-def test_profile_artifacts_and_kernel_categories():
-    """the committed rocprofv3 summary of the final build names every kernel of the step, and tools/summarize_rocprof.py
-    files each of them under a category that bench.py's kernel table knows"""
+@pytest.mark.parametrize("tag,dom,dom_kernel", [("r01h", "tail_ff2", "tail_ff2_ring_kernel"), ("r02a", "tail_ff1", "tail_ff1_ld_kernel")])
+def test_profile_artifacts_and_kernel_categories(tag, dom, dom_kernel):
+    """the committed rocprofv3 summary of a round's final build names every kernel of the step, tools/summarize_rocprof.py
+    files each of them under a category that bench.py's kernel table knows, and the rocprof duration of the dominant
+    kernel agrees with the HIP-event duration in the bench line"""
     import csv
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from summarize_rocprof import category
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r01h_kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))))
     names = [r["Name"] for r in rows]
     cats = {category(n) for n in names}
     assert {"stft", "mel", "subconv", "sublinear", "ff1_qkv", "attention", "out_glu", "dwconv", "tail_ff2", "ctc_head",
-            "collapse"} <= cats
+            "collapse", dom} <= cats
     assert all("(" not in c for c in cats), sorted(c for c in cats if "(" in c)      # no kernel left uncategorised
-    bench = json.loads(open(os.path.join(ROOT, "profiles", "r01h_bench_n1.json")).read().strip().splitlines()[-1])
+    assert cats <= set(_lib.KERNEL_NAMES), cats - set(_lib.KERNEL_NAMES)
+    bench = json.loads(open(os.path.join(ROOT, "profiles", tag + "_bench_n1.json")).read().strip().splitlines()[-1])
     assert bench["unit"] == "audio-frames/s" and bench["n_gpus"] == 1 and bench["dtype"] == "f32"
     assert set(bench["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(bench["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert bench["roofline"]["kernel"] == dom
+    if tag != "r01h":
+        assert set(bench["cpu_baseline"]) >= {"threads1", "all_cores", "published_tf2_1core"}
+        assert set(bench["roofline"]) >= {"traffic_source", "hbm_frac", "algorithmic_bytes"} and bench["h2d_inclusive"]
     by = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in rows}
-    tail = next(v for k, v in by.items() if "tail_ff2_ring_kernel" in k)
-    assert abs(tail - bench["kernels"]["tail_ff2"]["avg_ms"] * 1e3) / tail < 0.15      # rocprof and HIP events agree
+    t = next(v for k, v in by.items() if dom_kernel in k)
+    assert abs(t - bench["kernels"][dom]["avg_ms"] * 1e3) / t < 0.15      # rocprof and HIP events agree
