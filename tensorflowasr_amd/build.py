@@ -61,11 +61,7 @@ def resource_report():
 # A kernel that touches scratch is slow twice on this path: its own spill traffic, and the dispatches AROUND it pay for
 # the scratch set-up (measured: dwconv 15 -> 30 us next to a spilling neighbour, profiles/r02_ring_experiments.md).
 # Kernels allowed to keep a private segment (cold paths, listed with the reason):
-SCRATCH_ALLOWED = (
-    "gemm16_kernelINS_4PF32ELi9ELi4ELb1ELi4",      # layer-at-a-time fp32 GEMM, 9-tile / 4-row-tile variant (small batches): 36 B
-    "attention_kernelILi64ELi16",                  # head size 64 online-softmax attention (M / L / streaming models): 48 B
-    "gemm_rows_kernelILi144ELi2ELi9",              # two-row-tile variants of the unfused dmodel-144 GEMMs (>= 65 536 rows): 16-24 B
-)   # round-1 kernels off the headline path; every kernel of the dmodel-144 fused path is scratch-free
+SCRATCH_ALLOWED = ()   # none: every kernel of the library is scratch-free
 
 
 def check_no_scratch(report=None):

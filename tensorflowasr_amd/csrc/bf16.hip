@@ -49,7 +49,7 @@ struct PF32 {
 // KS = 1: one row tile per wave, as everywhere else.
 // The k-loop fetches U k-blocks (operand + weight fragments) at a time, one group ahead.
 template <class P, int CT, int EPI, bool LN, int KS>
-__global__ __launch_bounds__(BLOCK_THREADS, 2) void gemm16_kernel(Gemm16Args a) {
+__global__ __launch_bounds__(BLOCK_THREADS, ((sizeof(typename P::W) > 8 && CT == 9 && LN && KS == 4) ? 1 : 2)) void gemm16_kernel(Gemm16Args a) {   // that one instantiation spilled at 256 registers
   typedef typename P::W WF;
   typedef typename P::X XF;
   constexpr int NF = (EPI == E16_GLU) ? 2 * CT : CT;

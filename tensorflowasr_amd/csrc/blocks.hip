@@ -216,7 +216,9 @@ int launch_chain2(int D, int mode, const Chain2Args& a_in, hipStream_t s) {
 //   EPI_HEAD      optional logits store + per-token argmax, first max wins (fully_connected + greedy)
 // =====================================================================================================
 template <int D, int RT, int CT, int EPI, bool LN>
-__global__ __launch_bounds__(BLOCK_THREADS, ((RT == 1 || D <= 144) ? 2 : 1)) void gemm_rows_kernel(GemmArgs a) {
+// (two row tiles per wave do not fit 256 registers: with a two-waves bound hipcc spilled 16-24 B per lane to scratch,
+// which also slows the dispatches around the kernel -- profiles/r02_ring_experiments.md)
+__global__ __launch_bounds__(BLOCK_THREADS, (RT == 1 ? 2 : 1)) void gemm_rows_kernel(GemmArgs a) {
   constexpr int KB = D / 16;
   constexpr int NF = (EPI == EPI_GLU) ? 2 * CT : CT;   // weight fragments per k-block batch
   const int lane = threadIdx.x & 63;
@@ -417,7 +419,7 @@ int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s) 
 // online softmax, so any T works.
 // =====================================================================================================
 template <int HS, int KT>
-__global__ __launch_bounds__(BLOCK_THREADS, 2) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(BLOCK_THREADS, ((HS > 36 && KT >= 16) ? 1 : 2)) void attention_kernel(AttnArgs a) {   // <64, 16> spilled at 256 registers
   constexpr int FB = HS / 16;          // full 16-wide feature blocks
   constexpr int TS = (HS % 16) / 4;    // tail k-steps (feature = 16*FB + 4*ts + g)
   constexpr int OT = (HS + 15) / 16;   // output feature tiles
