@@ -145,9 +145,12 @@ int mi355asr_ctc_greedy(const int32_t* frame_argmax_dev, const int32_t* in_len_d
  *           also what the unit tests pin against the reference's own decoder).
  *   device: x_dev f32 [B, T, V] logits (is_logits != 0: softmax is fused into the selection kernel) or
  *           probabilities; the per-frame top-cutoff_top_n selection runs on the GPU, the prefix search on
+ *           prefix search on the device as well (beam_device.hip: one workgroup per utterance, the beam in LDS; beam_size
+ *           <= 128, cutoff_top_n <= 40, ws_dev of mi355asr_ctc_prefix_beam_workspace_bytes) or, failing those, on
  *           `num_threads` host threads.  Needs cutoff_prob < 1 and cutoff_top_n <= 128 (otherwise use _host).
- *           Synchronises `stream` (the search consumes the selection on the host).
- *           ws_dev: at least B*T*cutoff_top_n*8 bytes. */
+ *           Synchronises `stream` (the results are host arrays).
+ *           ws_dev: at least B*T*cutoff_top_n*8 bytes (host search); mi355asr_ctc_prefix_beam_workspace_bytes for the
+ *           device search. */
 int mi355asr_ctc_prefix_beam_host(const float* probs_host, const int32_t* in_len_host, int32_t B, int32_t T, int32_t V,
                                   int32_t beam_size, double cutoff_prob, int32_t cutoff_top_n, int32_t num_threads,
                                   int32_t max_len, int32_t* ids_host, int32_t* lens_host, float* scores_host,
@@ -165,6 +168,9 @@ int mi355asr_ctc_prefix_beam(const float* x_dev, int32_t is_logits, const int32_
  * vocabulary INCLUDES the blank as its last entry: probs rows have V = num_classes entries, blank = V-1 (:238-240).
  * Host-side (the trie search is branchy integer work); probs_host f32 [T, V]; outputs as in
  * mi355asr_ctc_prefix_beam_host for one utterance: ids i32 [beam, max_len], lens i32 [beam], scores f32 [beam]. */
+int mi355asr_ctc_prefix_beam_workspace_bytes(int32_t B, int32_t T, int32_t cutoff_top_n, int32_t beam_size, int32_t max_len,
+                                             size_t* bytes);
+
 typedef struct mi355asr_beam mi355asr_beam;
 int mi355asr_beam_create(int32_t V, int32_t beam_size, double cutoff_prob, int32_t cutoff_top_n, mi355asr_beam** out);
 int mi355asr_beam_decode(mi355asr_beam* d, const float* probs_host, int32_t T, int32_t max_len, int32_t* ids_host,

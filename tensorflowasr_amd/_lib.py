@@ -60,6 +60,7 @@ SIGNATURES = {
     "mi355asr_destroy": (ctypes.c_int, [_P]),
     "mi355asr_load_weight": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _I, ctypes.POINTER(ctypes.c_int64)]),
     "mi355asr_load_weight_typed": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
+    "mi355asr_ctc_prefix_beam_workspace_bytes": (ctypes.c_int, [_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_size_t)]),
     "mi355asr_frame_argmax": (ctypes.c_int, [_P, _I, _I, _P, _P]),
     "mi355asr_feature_pick_count": (ctypes.c_int, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "mi355asr_feature_pick_gather": (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

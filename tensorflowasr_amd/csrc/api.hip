@@ -1402,6 +1402,32 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
   float* d_p = (float*)((char*)ws + frames * N * sizeof(int32_t));
   if (mi355asr_launch_topn(x, (int)frames, V, N, is_logits, d_idx, d_p, s) != 0)
     return fail(MI355ASR_EHIP, "top-n kernel launch failed (V=%d needs %zu bytes of LDS)", V, (size_t)V * 4);
+  // MI355ASR_BEAM_DEVICE=0: the prefix search on host threads (beam.hip) instead of the device kernel (beam_device.hip)
+  static const bool dev_env = [] { const char* v = getenv("MI355ASR_BEAM_DEVICE"); return v ? atoi(v) != 0 : true; }();
+  const size_t need_dev = ((need + 255) & ~(size_t)255) + mi355asr_beam_device_ws_bytes(B, T, beam_size, max_len);
+  if (dev_env && mi355asr_beam_device_applicable(V, N, beam_size) && ws_bytes >= need_dev) {
+    char* w = (char*)ws + ((need + 255) & ~(size_t)255);
+    BeamDeviceArgs a{};
+    a.top_idx = d_idx; a.top_p = d_p; a.B = B; a.T = T; a.V = V; a.N = N; a.beam = beam_size;
+    a.cutoff_top_n = cutoff_top_n; a.max_len = max_len; a.cutoff_prob = cutoff_prob;
+    a.arena = (int2*)w;                  w += (size_t)B * ((size_t)T * beam_size + 1) * sizeof(int2);
+    a.ids = (int32_t*)w;                 w += (size_t)B * beam_size * max_len * sizeof(int32_t);
+    a.lens = (int32_t*)w;                w += (size_t)B * beam_size * sizeof(int32_t);
+    a.scores = (float*)w;                w += (size_t)B * beam_size * sizeof(float);
+    a.n_hyp = (int32_t*)w;               w += (size_t)B * sizeof(int32_t);
+    int32_t* d_len = (int32_t*)w;
+    if (in_len) {
+      HIP_TRY(hipMemcpyAsync(d_len, in_len, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      a.in_len = d_len;
+    }
+    if (mi355asr_launch_beam_device(&a, s) != 0) return fail(MI355ASR_EHIP, "device beam search launch failed");
+    HIP_TRY(hipMemcpyAsync(ids, a.ids, (size_t)B * beam_size * max_len * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(lens, a.lens, (size_t)B * beam_size * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(scores, a.scores, (size_t)B * beam_size * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(n_hyp, a.n_hyp, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+  }
   std::vector<int32_t> h_idx(frames * N);
   std::vector<float> h_p(frames * N);
   HIP_TRY(hipMemcpyAsync(h_idx.data(), d_idx, h_idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1409,6 +1435,14 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
   HIP_TRY(hipStreamSynchronize(s));
   return mi355asr_beam_topn_impl(h_idx.data(), h_p.data(), in_len, B, T, V, N, beam_size, cutoff_prob, cutoff_top_n,
                                  num_threads, max_len, ids, lens, scores, n_hyp);
+}
+
+int mi355asr_ctc_prefix_beam_workspace_bytes(int32_t B, int32_t T, int32_t cutoff_top_n, int32_t beam_size, int32_t max_len,
+                                             size_t* bytes) {
+  if (!bytes || B <= 0 || T <= 0 || cutoff_top_n <= 0 || beam_size <= 0 || max_len <= 0) return fail(MI355ASR_EINVAL, "bad argument");
+  const size_t need = (size_t)B * T * std::min(cutoff_top_n, 128) * 8;
+  *bytes = ((need + 255) & ~(size_t)255) + mi355asr_beam_device_ws_bytes(B, T, beam_size, max_len) + (size_t)B * 4 + 256;
+  return 0;
 }
 
 int mi355asr_recognize(mi355asr_model* m, const float* wav, int32_t B, int32_t L, const int32_t* in_len, int32_t* ids,

@@ -14,6 +14,22 @@ void* mi355asr_beam_state_new(int V, int beam_size, double cutoff_prob, int cuto
 void mi355asr_beam_state_free(void* h);
 void mi355asr_beam_state_reset(void* h);
 int mi355asr_beam_state_decode(void* h, const float* probs, int T, int max_len, int32_t* ids, int32_t* lens, float* scores);
+// device prefix search (beam_device.hip): every pointer is a DEVICE pointer
+struct BeamDeviceArgs {
+  const int32_t* top_idx;   // [B, T, N] classes in descending probability (topn_kernel)
+  const float* top_p;       // [B, T, N]
+  const int32_t* in_len;    // [B] or null
+  int B, T, V, N, beam, cutoff_top_n, max_len;
+  double cutoff_prob;
+  int32_t* ids;             // [B, beam, max_len] padded with -1
+  int32_t* lens;            // [B, beam]
+  float* scores;            // [B, beam]
+  int32_t* n_hyp;           // [B]
+  int2* arena;              // [B, T * beam + 1] back-pointers (parent link, character)
+};
+bool mi355asr_beam_device_applicable(int V, int N, int beam);
+size_t mi355asr_beam_device_ws_bytes(int B, int T, int beam, int max_len);
+int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s);
 int mi355asr_launch_topn(const float* x_dev, int frames, int V, int N, int is_logits, int32_t* idx_dev, float* p_dev,
                          hipStream_t s);
 }

@@ -716,8 +716,9 @@ def ctc_prefix_beam_decode(x, input_length=None, beam_width=10, cutoff_prob=0.99
     outs = [a.ctypes.data_as(ctypes.c_void_p) for a in (ids, lens, scores, n_hyp)]
     if on_gpu:
         xd = x.to(torch.float32).contiguous()
-        N = min(cutoff_top_n, V)
-        ws = torch.empty(B * T * N * 8, dtype=torch.uint8, device=xd.device)
+        nbytes = ctypes.c_size_t()
+        _lib.check(lib.mi355asr_ctc_prefix_beam_workspace_bytes(B, T, int(cutoff_top_n), int(beam_width), max_len, ctypes.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=xd.device)
         with torch.cuda.device(xd.device):
             st = ctypes.c_void_p(torch.cuda.current_stream(xd.device).cuda_stream)
             _lib.check(lib.mi355asr_ctc_prefix_beam(_p(xd), int(bool(is_logits)), ilp, B, T, V, beam_width,
