@@ -1415,7 +1415,13 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
     a.lens = (int32_t*)w;                w += (size_t)B * beam_size * sizeof(int32_t);
     a.scores = (float*)w;                w += (size_t)B * beam_size * sizeof(float);
     a.n_hyp = (int32_t*)w;               w += (size_t)B * sizeof(int32_t);
-    int32_t* d_len = (int32_t*)w;
+    int32_t* d_len = (int32_t*)w;        w += (((size_t)B * sizeof(int32_t)) + 7) & ~(size_t)7;
+    // MI355ASR_BEAM_PROF=1: clock counters of utterance 0's search, printed per call (where a frame's time goes)
+    static const bool prof_env = [] { const char* v = getenv("MI355ASR_BEAM_PROF"); return v && atoi(v) != 0; }();
+    if (prof_env) {
+      a.prof = (long long*)w;
+      HIP_TRY(hipMemsetAsync(a.prof, 0, 6 * sizeof(long long), s));
+    }
     if (in_len) {
       HIP_TRY(hipMemcpyAsync(d_len, in_len, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
       a.in_len = d_len;
@@ -1425,7 +1431,14 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
     HIP_TRY(hipMemcpyAsync(lens, a.lens, (size_t)B * beam_size * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(scores, a.scores, (size_t)B * beam_size * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(n_hyp, a.n_hyp, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    long long prof[6] = {0, 0, 0, 0, 0, 0};
+    if (a.prof) HIP_TRY(hipMemcpyAsync(prof, a.prof, sizeof(prof), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (a.prof)
+      fprintf(stderr, "[mi355asr] beam %d, utterance 0: %lld frames (%lld by the radix path); clocks per frame: entries %.0f, "
+              "keys+ranks %.0f, keep %.0f, radix path %.0f\n", beam_size, prof[5], prof[4],
+              (double)prof[0] / std::max(1ll, prof[5]), (double)prof[1] / std::max(1ll, prof[5]),
+              (double)prof[2] / std::max(1ll, prof[5]), (double)prof[3] / std::max(1ll, prof[5]));
     return 0;
   }
   std::vector<int32_t> h_idx(frames * N);
@@ -1441,7 +1454,7 @@ int mi355asr_ctc_prefix_beam_workspace_bytes(int32_t B, int32_t T, int32_t cutof
                                              size_t* bytes) {
   if (!bytes || B <= 0 || T <= 0 || cutoff_top_n <= 0 || beam_size <= 0 || max_len <= 0) return fail(MI355ASR_EINVAL, "bad argument");
   const size_t need = (size_t)B * T * std::min(cutoff_top_n, 128) * 8;
-  *bytes = ((need + 255) & ~(size_t)255) + mi355asr_beam_device_ws_bytes(B, T, beam_size, max_len) + (size_t)B * 4 + 256;
+  *bytes = ((need + 255) & ~(size_t)255) + mi355asr_beam_device_ws_bytes(B, T, beam_size, max_len);
   return 0;
 }
 

@@ -5,12 +5,16 @@
 // path_trie.cpp:37-147 (trie), ctc_beam_search_decoder.cpp:426-459 (batch = thread pool over utterances).
 //
 // MI355X split of the work:
-//   GPU  topn_kernel: per frame softmax (when fed logits) + selection of the cutoff_top_n most probable classes in
-//        descending order -- the only part of the algorithm that touches all V classes (9160 for the text decoder).
-//        HBM-bound: one read of the [frames, V] matrix.
-//   CPU  the prefix search itself: pointer-chasing, data-dependent, a few hundred float ops per frame -- it stays on
-//        the host cores, one utterance per task, like the reference's ThreadPool.  Same arithmetic as the reference:
-//        float32 trie scores, log(p + FLT_MIN) taken in double, log_sum_exp<float>.
+//   GPU  topn_kernel (this file): per frame softmax (when fed logits) + selection of the cutoff_top_n most probable
+//        classes in descending order -- the only part of the algorithm that touches all V classes (9160 for the text
+//        decoder).  HBM-bound: one read of the [frames, V] matrix.
+//   GPU  beam_search_kernel (beam_device.hip): the prefix search, one workgroup per utterance, for beam <= 128 and
+//        cutoff_top_n <= 40.
+//   CPU  the same search on host threads (this file), one utterance per task like the reference's ThreadPool: the
+//        specification of the device search (pinned to the reference decoder's known-answer vectors), the path for
+//        host-resident probabilities, un-pruned mode and the stateful streaming decoder, and the fallback for wider
+//        beams.  Same arithmetic as the reference: float32 trie scores, log(p + FLT_MIN) taken in double,
+//        log_sum_exp<float>.
 // The trie is an index-based arena (no per-node new/delete); the beam is advanced from the touched set instead of a
 // whole-trie DFS per frame (same resulting set: every existing node is either in the beam or was touched this frame).
 #include <hip/hip_runtime.h>
@@ -233,31 +237,21 @@ void run_batch(int B, int num_threads, RowFn&& per_utt) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// GPU: per-frame top-n.  One wave per frame, the frame's V values staged in LDS; n rounds of
-// (per-lane scan, wave arg-max with lowest-index tie break, knock-out).
+// GPU: per-frame top-n.  One wave per frame, the frame's V values staged in LDS.  Output order = the host's
+// stable_sort: value descending, class ascending among equal values.
+//
+// Fast path (N <= 64): lane l owns the classes l, l + 64, ...  Exactly N lanes own a value >= T0 := the N-th largest of
+// the 64 lane maxima, so at least N classes are >= T0, and for independent values only ~1.5 N are.  One pass collects the
+// classes > T0 (all of them) and the first N classes == T0 in class order (ballot compaction keeps class order); the
+// final order comes from counting, for every collected class, the collected classes that precede it.  ~3 passes over the
+// row instead of N.
+// Slow path (N > 64, or more than GT_CAP classes above T0 -- only adversarial rows): N rounds of (per-lane scan, wave
+// arg-max with lowest-class tie break, knock-out).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void topn_kernel(const float* __restrict__ x, int V, int N, int is_logits,
-                                                  int32_t* __restrict__ out_idx, float* __restrict__ out_p) {
-  extern __shared__ float sh[];
-  const int lane = threadIdx.x;
-  const size_t frame = blockIdx.x;
-  const float* row = x + frame * V;
-  float mx = -INFINITY;
-  for (int i = lane; i < V; i += 64) {
-    const float v = row[i];
-    sh[i] = v;
-    mx = fmaxf(mx, v);
-  }
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  float denom = 1.f;
-  if (is_logits) {
-    float s = 0.f;
-    for (int i = lane; i < V; i += 64) s += __expf(sh[i] - mx);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
-    denom = s;
-  }
+constexpr int GT_CAP = 256, EQ_CAP = 64;
+
+__device__ __forceinline__ void topn_rounds(float* sh, int V, int N, int lane, bool is_logits, float mx, float denom,
+                                            int32_t* out_idx, float* out_p) {
   for (int n = 0; n < N; ++n) {
     float best = -INFINITY;
     int bi = 0x7fffffff;
@@ -272,10 +266,97 @@ __global__ __launch_bounds__(64) void topn_kernel(const float* __restrict__ x, i
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
     if (lane == 0) {
-      out_idx[frame * N + n] = bi;
-      out_p[frame * N + n] = is_logits ? __expf(best - mx) / denom : best;
+      out_idx[n] = bi;
+      out_p[n] = is_logits ? __expf(best - mx) / denom : best;
     }
     if (bi != 0x7fffffff && (bi & 63) == lane) sh[bi] = -INFINITY;
+  }
+}
+
+__global__ __launch_bounds__(64) void topn_kernel(const float* __restrict__ x, int V, int N, int is_logits,
+                                                  int32_t* __restrict__ out_idx, float* __restrict__ out_p) {
+  extern __shared__ float sh[];
+  __shared__ float cv[GT_CAP + EQ_CAP];
+  __shared__ int ci[GT_CAP + EQ_CAP];
+  const int lane = threadIdx.x;
+  const size_t frame = blockIdx.x;
+  const float* row = x + frame * V;
+  out_idx += frame * N;
+  out_p += frame * N;
+  float mx = -INFINITY;                     // = this lane's maximum until the reduction below
+  for (int i = lane; i < V; i += 64) {
+    const float v = row[i];
+    sh[i] = v;
+    mx = fmaxf(mx, v);
+  }
+  const float lane_max = mx;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float denom = 1.f;
+  if (is_logits) {
+    float s = 0.f;
+    for (int i = lane; i < V; i += 64) s += __expf(sh[i] - mx);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
+    denom = s;
+  }
+  if (N > 64) {
+    topn_rounds(sh, V, N, lane, is_logits, mx, denom, out_idx, out_p);
+    return;
+  }
+  // T0: the lane maximum of rank N - 1 (ranks made distinct by the lane number)
+  int rank = 0;
+#pragma unroll
+  for (int l = 0; l < 64; ++l) {
+    const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_max), l));
+    rank += (o > lane_max) || (o == lane_max && l < lane);
+  }
+  const unsigned long long pick = __ballot(rank == N - 1);
+  const float T0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_max), (int)__builtin_ctzll(pick)));
+  // collect: classes > T0 into [0, G), the first EQ_CAP classes == T0 into [GT_CAP, GT_CAP + E)
+  const unsigned long long lt = (1ull << lane) - 1;
+  int G = 0, E = 0;
+  for (int i0 = 0; i0 < V; i0 += 64) {
+    const int i = i0 + lane;
+    const float v = i < V ? sh[i] : -INFINITY;
+    const bool gt = i < V && v > T0, eq = i < V && v == T0;
+    const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+    if ((bg | be) == 0) continue;
+    const int pg = G + __popcll(bg & lt), pe = E + __popcll(be & lt);
+    if (gt && pg < GT_CAP) { cv[pg] = v; ci[pg] = i; }
+    if (eq && pe < EQ_CAP) { cv[GT_CAP + pe] = v; ci[GT_CAP + pe] = i; }
+    G += __popcll(bg);
+    E = min(E + __popcll(be), EQ_CAP);
+  }
+  if (G > GT_CAP) {
+    topn_rounds(sh, V, N, lane, is_logits, mx, denom, out_idx, out_p);
+    return;
+  }
+  // candidates: [0, G) and [GT_CAP, GT_CAP + Eu); position of each in (value descending, class ascending) order
+  const int Eu = min(E, N);
+  const int M = G + Eu;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    const int m = m0 + lane;
+    const int slot = m < G ? m : GT_CAP + (m - G);
+    const float v = m < M ? cv[slot] : 0.f;
+    const int id = m < M ? ci[slot] : 0;
+    int before = 0;
+#pragma unroll 8
+    for (int q = 0; q < G; ++q) {
+      const float ov = cv[q];
+      const int oi = ci[q];
+      before += (ov > v) || (ov == v && oi < id);
+    }
+#pragma unroll 8
+    for (int q = 0; q < Eu; ++q) {
+      const float ov = cv[GT_CAP + q];
+      const int oi = ci[GT_CAP + q];
+      before += (ov > v) || (ov == v && oi < id);
+    }
+    if (m < M && before < N) {
+      out_idx[before] = id;
+      out_p[before] = is_logits ? __expf(v - mx) / denom : v;
+    }
   }
 }
 

@@ -25,6 +25,7 @@
 // to std::nth_element -- are broken by slot (existing entries first, then children in (entry, candidate) order).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 
@@ -63,12 +64,14 @@ __device__ __forceinline__ u64 make_key(float score, int ch, int slot) {
 }
 
 struct Beam {
-  u64 id[BMAX], par[BMAX];
+  __align__(16) u64 id[BMAX];
+  u64 par[BMAX];
   int ch[BMAX], arena[BMAX];
   float score[BMAX], b[BMAX], nb[BMAX];
 };
 
-// block-wide exclusive scan of one int per thread (NT = 256 = 4 waves); returns the exclusive prefix, *total = sum
+// block-wide exclusive scan of one int per thread (NT = 256 = 4 waves); returns the exclusive prefix, *total = sum.
+// One barrier: callers alternate `wave_tot` buffers (or have another barrier before the same one is written again).
 __device__ __forceinline__ int block_scan(int v, int* wave_tot, int* total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int inc = v;
@@ -86,23 +89,157 @@ __device__ __forceinline__ int block_scan(int v, int* wave_tot, int* total) {
     if (w < wv) base += t;
     tot += t;
   }
-  __syncthreads();
   *total = tot;
   return base + inc - v;
 }
 
-__global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
-  __shared__ Beam beams[2];
-  __shared__ u64 keys[SMAX];
-  __shared__ u64 exist_mask[BMAX];
-  __shared__ float cb[BMAX], cnb[BMAX], cscore[BMAX];
-  __shared__ int ccand[NMAX];
-  __shared__ float clp[NMAX];
-  __shared__ int hist[256];
-  __shared__ int wave_tot[NT / 64];
-  __shared__ int sh_ncand, sh_blank, sh_digit, sh_need, sh_done;
-  __shared__ u64 sh_prefix;
+// Frame candidates (decoder_utils.cpp:7-38 on the descending top-n list), prepared by the last wave one frame ahead of the
+// search: they do not depend on the beam.
+struct Cands {
+  __align__(16) int c[NMAX];
+  float lp[NMAX];
+  int n, blank;        // number of candidates kept, position of the blank among them (-1: pruned)
+};
 
+struct Shared {
+  Beam beams[2];
+  __align__(16) u64 keys[NT];   // SMALL path: one key per thread
+  u64 exist_mask[2][BMAX];      // [frame parity][entry]: bit k = the child by candidate k is a beam entry itself
+  float cb[BMAX], cnb[BMAX], cscore[BMAX];
+  Cands cands[2];
+  int hist[2][256];
+  int wave_tot[4][NT / 64];
+  int digit, need, done, thr_ok;
+  u64 diff;
+};
+
+// extension of entry j by candidate k (ctc_beam_search_decoder.cpp:99-113)
+__device__ __forceinline__ float child_lp(const Beam& C, const Cands& K, int j, int k) {
+  const int c = K.c[k];
+  if (c == C.ch[j]) return C.b[j] > kNegInf ? K.lp[k] + C.b[j] : kNegInf;
+  return K.lp[k] + C.score[j];
+}
+__device__ __forceinline__ void keep_entry(Shared& sh, const Beam& C, Beam& Nx, int s, int pos) {
+  Nx.id[pos] = C.id[s]; Nx.par[pos] = C.par[s]; Nx.ch[pos] = C.ch[s]; Nx.arena[pos] = C.arena[s];
+  Nx.score[pos] = sh.cscore[s]; Nx.b[pos] = sh.cb[s]; Nx.nb[pos] = sh.cnb[s];
+}
+__device__ __forceinline__ void keep_child(const Beam& C, Beam& Nx, int2* arena, int ai, int j, int c, float lp, int pos) {
+  arena[ai] = make_int2(C.arena[j], c);
+  Nx.id[pos] = mix(C.id[j], c); Nx.par[pos] = C.id[j]; Nx.ch[pos] = c; Nx.arena[pos] = ai;
+  Nx.score[pos] = lp; Nx.b[pos] = kNegInf; Nx.nb[pos] = lp;
+}
+
+__device__ __forceinline__ float key_score(u64 key) {             // inverse of make_key's first word
+  const unsigned u = ~(unsigned)(key >> 32);
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// Steps 3-5 for any beam width.  Keys live in registers: thread (wave w, lane k) owns the children by candidate k of the
+// entries w, w + 4, w + 8, ... (what depends on k is loaded once, what depends on the entry is a broadcast read), and
+// thread i < nbm also owns entry i's own key.  Threshold key by radix select over the bytes of the key (most significant
+// differing byte first, early exit as soon as the selected bin is wanted whole), then compaction in thread order.  Ends
+// with a barrier; returns the size of the next beam.
+constexpr int JPT = BMAX / (NT / 64);      // entries per wave
+__device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx, const Cands& K, const u64* exist, int nbm,
+                                            int beam, int t, int2* arena) {
+  const int tid = threadIdx.x, k = tid & 63, w = tid >> 6;
+  const int nc = K.n, kb = K.blank;
+  const bool cand = k < nc && k != kb;
+  const int c = cand ? K.c[k] : 0;
+  const float clp = cand ? K.lp[k] : 0.f;
+  const u64 key0 = make_key(sh.cscore[0], C.ch[0], 0);
+  u64 ekey = ~0ull, ck[JPT];
+  int valid = 0;
+  u64 diff = 0;
+  if (tid < nbm) {
+    ekey = make_key(sh.cscore[tid], C.ch[tid], tid);
+    ++valid;
+    diff |= ekey ^ key0;
+  }
+#pragma unroll
+  for (int i = 0; i < JPT; ++i) {
+    const int j = w + 4 * i;
+    u64 key = ~0ull;
+    if (j < nbm) {                          // wave-uniform
+      const u64 ex = exist[j];
+      const int chj = C.ch[j];
+      const float bj = C.b[j], sj = C.score[j];
+      if (cand && !((ex >> k) & 1ull)) {
+        const float lp = c == chj ? (bj > kNegInf ? clp + bj : kNegInf) : clp + sj;
+        key = make_key(lp, c, nbm + j * nc + k);
+        ++valid;
+        diff |= key ^ key0;
+      }
+    }
+    ck[i] = key;
+  }
+  if (tid == 0) sh.diff = 0;
+  int M;
+  block_scan(valid, sh.wave_tot[3], &M);    // its barrier also publishes the zeroed diff
+  u64 thr = ~0ull - 1;                      // M <= beam: every valid key (invalid ones are ~0)
+  int shift_keep = 0;
+  if (M > beam) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) diff |= __shfl_xor(diff, off);
+    if (k == 0) atomicOr(&sh.diff, diff);
+    __syncthreads();
+    const int top = (63 - __builtin_clzll(sh.diff | 1ull)) >> 3;       // the keys agree above byte `top`
+    u64 pre = top == 7 ? 0 : (key0 >> (8 * top + 8)) << (8 * top + 8);
+    int need = beam;
+    int pass = top;
+    for (; pass >= 0; --pass) {
+      const int shift = 8 * pass, hb = pass & 1;
+      const u64 hi_mask = pass == 7 ? 0 : ~0ull << (shift + 8);
+      if (ekey != ~0ull && ((ekey ^ pre) & hi_mask) == 0) atomicAdd(&sh.hist[hb][(int)((ekey >> shift) & 255)], 1);
+#pragma unroll
+      for (int i = 0; i < JPT; ++i)
+        if (ck[i] != ~0ull && ((ck[i] ^ pre) & hi_mask) == 0) atomicAdd(&sh.hist[hb][(int)((ck[i] >> shift) & 255)], 1);
+      __syncthreads();
+      const int h = sh.hist[hb][tid];
+      sh.hist[hb][tid] = 0;                 // clean for pass - 2 (and for the next frame)
+      int tot;
+      const int ex = block_scan(h, sh.wave_tot[hb], &tot);
+      if (ex < need && need <= ex + h) {    // the bin that holds the need-th smallest active key
+        sh.digit = tid;
+        sh.need = need - ex;
+        sh.done = (need - ex == h);         // the whole bin is wanted: no need to resolve lower bytes
+      }
+      __syncthreads();
+      pre |= (u64)sh.digit << shift;
+      need = sh.need;
+      if (sh.done) break;
+    }
+    if (pass < 0) pass = 0;
+    shift_keep = 8 * pass;
+    thr = pre;
+  }
+  const u64 thr_s = thr >> shift_keep;
+  int keep_cnt = (ekey != ~0ull && (ekey >> shift_keep) <= thr_s);
+#pragma unroll
+  for (int i = 0; i < JPT; ++i) keep_cnt += (ck[i] != ~0ull && (ck[i] >> shift_keep) <= thr_s);
+  int newn;
+  int pos = block_scan(keep_cnt, sh.wave_tot[2], &newn);
+  if (ekey != ~0ull && (ekey >> shift_keep) <= thr_s) keep_entry(sh, C, Nx, tid, pos++);
+#pragma unroll
+  for (int i = 0; i < JPT; ++i)
+    if (ck[i] != ~0ull && (ck[i] >> shift_keep) <= thr_s) {
+      keep_child(C, Nx, arena, 1 + t * beam + pos, w + 4 * i, c, key_score(ck[i]), pos);
+      ++pos;
+    }
+  __syncthreads();
+  return newn;
+}
+
+// SMALL: beam * (min(N, beam + 2) + 1) <= NT -- one key per thread over the first ncap = min(nc, beam + 2) candidates,
+// ranks by counting, the next beam written in rank order.  A child by the candidate at position k has k - 2 or more
+// siblings that score at least as much (those by the candidates before it, minus the blank and the entry's own
+// character; a sibling that is a beam entry itself scores at least its extension term), so children beyond position
+// beam + 1 are almost never kept.  "Almost" is made exact: the frame is accepted only when the beam is full and its worst
+// kept score is strictly above the best score any skipped child could have (lp[ncap] + the best entry score); otherwise
+// (ties at the beam boundary, under-full beams) the frame is redone by select_radix over all candidates.
+template <bool SMALL>
+__global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
+  __shared__ Shared sh;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int T = a.T, N = a.N, V = a.V, beam = a.beam;
@@ -110,185 +247,186 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   int2* arena = a.arena + (size_t)b * ((size_t)T * beam + 1);
   int cur = 0, nbm = 1;                     // current beam buffer, number of entries
   if (tid == 0) {
-    Beam& B0 = beams[0];
+    Beam& B0 = sh.beams[0];
     B0.id[0] = 1; B0.par[0] = 0; B0.ch[0] = -1; B0.arena[0] = 0;
     B0.score[0] = 0.f; B0.b[0] = 0.f; B0.nb[0] = kNegInf;
     arena[0] = make_int2(-1, -1);
   }
-  __syncthreads();
+  long long prof[5] = {0, 0, 0, 0, 0};
+  const bool profiling = a.prof != nullptr && b == 0 && tid == 0;
 
-  // the top-n list of frame t + 1 is requested while frame t is processed (a dependent global load per frame would cost
-  // more than the rest of the frame)
-  __shared__ float praw[NMAX];
+  // wave 3 holds the top-n list of the frame it prepares next in registers (lane k = position k); the list of the frame
+  // after that is requested as soon as this one is consumed, so no global load sits on the per-frame path
+  const int pl = tid - (NT - 64);
   float p_nx = 0.f;
   int c_nx = 0;
-  if (tid < N && frames > 0) {
-    p_nx = a.top_p[(size_t)b * T * N + tid];
-    c_nx = a.top_idx[(size_t)b * T * N + tid];
+  if (pl >= 0 && pl < N && frames > 0) {
+    p_nx = a.top_p[(size_t)b * T * N + pl];
+    c_nx = a.top_idx[(size_t)b * T * N + pl];
   }
-  for (int t = 0; t < frames; ++t) {
-    const Beam& C = beams[cur];
-    Beam& Nx = beams[cur ^ 1];
-    // ---- 1. pruned candidates (decoder_utils.cpp:7-38 on the descending top-n list)
-    if (tid < N) {
-      praw[tid] = p_nx;
-      ccand[tid] = c_nx;
-      if (t + 1 < frames) {
-        const size_t fn = ((size_t)b * T + t + 1) * N + tid;
-        p_nx = a.top_p[fn];
-        c_nx = a.top_idx[fn];
-      }
-    }
-    if (tid < BMAX) exist_mask[tid] = 0;
-    __syncthreads();
-    if (tid == 0) {
-      double cum = 0.0;
-      int n = 0;
-      for (int i = 0; i < N; ++i) {
-        cum += (double)praw[i];
+  auto prepare = [&](int tt) {              // wave 3 only: candidates of frame tt into cands[tt & 1]
+    Cands& K = sh.cands[tt & 1];
+    double cum = 0.0;
+    int n = 0;
+    bool open = true;
+    for (int i = 0; i < N; ++i) {
+      const float pi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_nx), i));
+      if (open) {
+        cum += (double)pi;
         ++n;
-        if (cum >= a.cutoff_prob || n >= a.cutoff_top_n) break;
+        if (cum >= a.cutoff_prob || n >= a.cutoff_top_n) open = false;
       }
-      sh_ncand = n;
     }
-    if (tid == 64) sh_blank = -1;
-    __syncthreads();
-    const int nc = sh_ncand;
-    if (tid < nc) {
-      clp[tid] = (float)log((double)praw[tid] + (double)FLT_MIN);
-      if (ccand[tid] == V - 1) sh_blank = tid;
+    const bool mine = pl < n;
+    if (mine) {
+      K.c[pl] = c_nx;
+      K.lp[pl] = (float)log((double)p_nx + (double)FLT_MIN);
     }
-    __syncthreads();
-    const int kb = sh_blank;
-    // ---- 2. existing entries
+    const u64 bm = __ballot(mine && c_nx == V - 1);
+    if (pl == 0) {
+      K.n = n;
+      K.blank = bm ? (int)__builtin_ctzll(bm) : -1;
+    }
+    if (pl < N && tt + 1 < frames) {
+      const size_t fn = ((size_t)b * T + tt + 1) * N + pl;
+      p_nx = a.top_p[fn];
+      c_nx = a.top_idx[fn];
+    }
+  };
+  if (pl >= 0 && frames > 0) prepare(0);
+  sh.hist[0][tid] = 0;
+  sh.hist[1][tid] = 0;
+  if (tid < BMAX) sh.exist_mask[0][tid] = 0;
+  __syncthreads();
+
+  for (int t = 0; t < frames; ++t) {
+    const Beam& C = sh.beams[cur];
+    Beam& Nx = sh.beams[cur ^ 1];
+    const Cands& K = sh.cands[t & 1];
+    u64* exist = sh.exist_mask[t & 1];
+    const int nc = K.n, kb = K.blank;
+    long long t0 = 0;
+    if (profiling) t0 = clock64();
+    // ---- 1. (wave 3) the next frame's candidates
+    if (pl >= 0 && t + 1 < frames) prepare(t + 1);
+    if (tid < BMAX) sh.exist_mask[(t + 1) & 1][tid] = 0;
+    // ---- 2. existing entries: blank update, repetition, extension by the parent if that is in the beam
     if (tid < nbm) {
       const int i = tid;
       const int ci = C.ch[i];
-      float bc = kNegInf, nbc = kNegInf;
-      if (kb >= 0) bc = lse(bc, clp[kb] + C.score[i]);
+      const float bc = kb >= 0 ? K.lp[kb] + C.score[i] : kNegInf;  // log_sum_exp(-inf, x) = x
+      float nbc = kNegInf;
+      // position of the entry's own character among the candidates: all NMAX classes are fetched at once (a loop of
+      // dependent LDS reads would cost a latency each)
       int kc = -1;
-      for (int k = 0; k < nc; ++k)
-        if (ccand[k] == ci) kc = k;
+      {
+        int4 cc[NMAX / 4];
+#pragma unroll
+        for (int q = 0; q < NMAX / 4; ++q) cc[q] = reinterpret_cast<const int4*>(K.c)[q];
+#pragma unroll
+        for (int q = 0; q < NMAX / 4; ++q) {
+          if (cc[q].x == ci && 4 * q + 0 < nc) kc = 4 * q + 0;
+          if (cc[q].y == ci && 4 * q + 1 < nc) kc = 4 * q + 1;
+          if (cc[q].z == ci && 4 * q + 2 < nc) kc = 4 * q + 2;
+          if (cc[q].w == ci && 4 * q + 3 < nc) kc = 4 * q + 3;
+        }
+      }
       if (kc >= 0) {
-        nbc = lse(nbc, clp[kc] + C.nb[i]);
+        nbc = K.lp[kc] + C.nb[i];
         const u64 pid = C.par[i];
         int j = -1;
-        for (int jj = 0; jj < nbm; ++jj)
-          if (C.id[jj] == pid) j = jj;
+        for (int j0 = 0; j0 < nbm; j0 += 16) {
+          ulonglong2 ii[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) ii[q] = reinterpret_cast<const ulonglong2*>(C.id + j0)[q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (ii[q].x == pid && j0 + 2 * q < nbm) j = j0 + 2 * q;
+            if (ii[q].y == pid && j0 + 2 * q + 1 < nbm) j = j0 + 2 * q + 1;
+          }
+        }
         if (j >= 0) {
-          float lp = kNegInf;
-          if (ci == C.ch[j] && C.b[j] > kNegInf) lp = clp[kc] + C.b[j];
-          else if (ci != C.ch[j]) lp = clp[kc] + C.score[j];
-          nbc = lse(nbc, lp);
-          atomicOr(&exist_mask[j], 1ull << kc);
+          nbc = lse(nbc, child_lp(C, K, j, kc));
+          atomicOr(&exist[j], 1ull << kc);
         }
       }
-      cb[i] = bc;
-      cnb[i] = nbc;
-      cscore[i] = lse(bc, nbc);
+      sh.cb[i] = bc;
+      sh.cnb[i] = nbc;
+      sh.cscore[i] = lse(bc, nbc);
     }
     __syncthreads();
-    // ---- 3. keys: slots [0, nbm) = existing entries, nbm + j * nc + k = child of entry j by candidate k
-    const int S = nbm + nbm * nc;
-    int valid = 0;
-    for (int s = tid; s < S; s += NT) {
-      u64 key = ~0ull;
-      if (s < nbm) {
-        key = make_key(cscore[s], C.ch[s], s);
-        ++valid;
-      } else {
-        const int j = (s - nbm) / nc, k = (s - nbm) - j * nc;
-        const int c = ccand[k];
-        if (k != kb && !((exist_mask[j] >> k) & 1ull)) {
-          float lp = kNegInf;
-          if (c == C.ch[j] && C.b[j] > kNegInf) lp = clp[k] + C.b[j];
-          else if (c != C.ch[j]) lp = clp[k] + C.score[j];
-          key = make_key(lp, c, s);
-          ++valid;
-        }
-      }
-      keys[s] = key;
-    }
-    int M;
-    block_scan(valid, wave_tot, &M);
-    // ---- 4. the `beam` best: threshold key by radix select (most significant byte first)
-    u64 thr = ~0ull - 1;                      // M <= beam: every valid key (invalid ones are ~0)
-    int shift_keep = 0;
-    if (M > beam) {
-      if (tid == 0) { sh_prefix = 0; sh_need = beam; sh_done = 0; }
-      __syncthreads();
-      int pass = 7;
-      for (; pass >= 0; --pass) {
-        const int shift = 8 * pass;
-        hist[tid] = 0;
-        __syncthreads();
-        const u64 pre = sh_prefix;
-        for (int s = tid; s < S; s += NT) {
-          const u64 key = keys[s];
-          if (key != ~0ull && (pass == 7 || (key >> (shift + 8)) == (pre >> (shift + 8))))
-            atomicAdd(&hist[(int)((key >> shift) & 255)], 1);
-        }
-        __syncthreads();
-        const int h = hist[tid];
-        const int need = sh_need;             // read before the scan's barriers: one thread rewrites it below
-        int tot;
-        const int ex = block_scan(h, wave_tot, &tot);
-        if (ex < need && need <= ex + h) {    // the bin that holds the need-th smallest active key
-          sh_digit = tid;
-          sh_need = need - ex;
-          sh_done = (need - ex == h);         // the whole bin is wanted: no need to resolve lower bytes
-        }
-        __syncthreads();
-        if (tid == 0) sh_prefix = pre | ((u64)sh_digit << shift);
-        __syncthreads();
-        if (sh_done) break;
-      }
-      if (pass < 0) pass = 0;
-      shift_keep = 8 * pass;
-      thr = sh_prefix;
-    }
-    // ---- 5. compaction into the next beam (slot order: existing entries first)
-    int keep_cnt = 0;
-    const int per = (S + NT - 1) / NT;
-    const int s0 = tid * per, s1 = min(S, s0 + per);
-    for (int s = s0; s < s1; ++s) {
-      const u64 key = keys[s];
-      if (key != ~0ull && (key >> shift_keep) <= (thr >> shift_keep)) ++keep_cnt;
-    }
+    long long t1 = 0;
+    if (profiling) { t1 = clock64(); prof[0] += t1 - t0; }
+
     int newn;
-    int pos = block_scan(keep_cnt, wave_tot, &newn);
-    for (int s = s0; s < s1; ++s) {
-      const u64 key = keys[s];
-      if (key == ~0ull || (key >> shift_keep) > (thr >> shift_keep)) continue;
-      if (s < nbm) {
-        Nx.id[pos] = C.id[s]; Nx.par[pos] = C.par[s]; Nx.ch[pos] = C.ch[s]; Nx.arena[pos] = C.arena[s];
-        Nx.score[pos] = cscore[s]; Nx.b[pos] = cb[s]; Nx.nb[pos] = cnb[s];
-      } else {
-        const int j = (s - nbm) / nc, k = (s - nbm) - j * nc;
-        const int c = ccand[k];
-        float lp = kNegInf;
-        if (c == C.ch[j] && C.b[j] > kNegInf) lp = clp[k] + C.b[j];
-        else if (c != C.ch[j]) lp = clp[k] + C.score[j];
-        const int ai = 1 + t * beam + pos;
-        arena[ai] = make_int2(C.arena[j], c);
-        Nx.id[pos] = mix(C.id[j], c); Nx.par[pos] = C.id[j]; Nx.ch[pos] = c; Nx.arena[pos] = ai;
-        Nx.score[pos] = lp; Nx.b[pos] = kNegInf; Nx.nb[pos] = lp;
+    bool redo = !SMALL;
+    if (SMALL) {
+      // ---- 3s. one key per thread: slots [0, nbm) = existing entries, nbm + j * ncap + k = child of entry j by candidate k
+      const int ncap = min(nc, beam + 2);
+      const int S = nbm + nbm * ncap;
+      u64 key = ~0ull;
+      int j = 0, k = 0;
+      float lp = kNegInf;
+      if (tid < nbm) {
+        lp = sh.cscore[tid];
+        key = make_key(lp, C.ch[tid], tid);
+      } else if (tid < S) {
+        j = (tid - nbm) / ncap;
+        k = (tid - nbm) - j * ncap;
+        if (k != kb && !((exist[j] >> k) & 1ull)) {
+          lp = child_lp(C, K, j, k);
+          key = make_key(lp, K.c[k], tid);
+        }
       }
-      ++pos;
+      sh.keys[tid] = key;
+      if (tid == 0) sh.thr_ok = 0;            // every wave has read the previous frame's flag: it is past this frame's first barrier
+      __syncthreads();
+      // ---- 4s. rank = number of better keys (slots make keys distinct)
+      int rank = 0;
+      for (int s0 = 0; s0 < S; s0 += 16) {   // slots [S, NT) hold ~0 and count for nothing
+        ulonglong2 kk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) kk[q] = reinterpret_cast<const ulonglong2*>(sh.keys + s0)[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rank += (kk[q].x < key) + (kk[q].y < key);
+      }
+      const bool keep = key != ~0ull && rank < beam;
+      long long t2 = 0;
+      if (profiling) { t2 = clock64(); prof[1] += t2 - t1; }
+      if (keep) {
+        if (tid < nbm) keep_entry(sh, C, Nx, tid, rank);
+        else keep_child(C, Nx, arena, 1 + t * beam + rank, j, K.c[k], lp, rank);
+        if (rank == beam - 1 && ncap < nc) {
+          float best = kNegInf;
+          for (int i = 0; i < nbm; ++i) best = fmaxf(best, C.score[i]);
+          if (lp > K.lp[ncap] + best) sh.thr_ok = 1;
+        }
+      }
+      newn = __syncthreads_count(keep);
+      redo = ncap < nc && !sh.thr_ok;       // uniform
+      if (profiling) prof[2] += clock64() - t2;
     }
-    __syncthreads();
+    if (redo) {
+      long long t3 = 0;
+      if (profiling) { t3 = clock64(); if (SMALL) ++prof[4]; }
+      newn = select_radix(sh, C, Nx, K, exist, nbm, beam, t, arena);
+      if (profiling) prof[3] += clock64() - t3;
+    }
     cur ^= 1;
     nbm = newn;
   }
+  if (profiling) {
+    for (int i = 0; i < 5; ++i) a.prof[i] = prof[i];
+    a.prof[5] = frames;
+  }
 
   // ---- finish: rank by prefix_compare (+ slot), read the paths back
-  const Beam& C = beams[cur];
+  const Beam& C = sh.beams[cur];
   const int n = min(nbm, beam);
   int32_t* ids = a.ids + (size_t)b * beam * a.max_len;
   int32_t* lens = a.lens + (size_t)b * beam;
   float* scores = a.scores + (size_t)b * beam;
   if (tid == 0) a.n_hyp[b] = n;
-  __threadfence_block();
   for (int i = tid; i < beam; i += NT) {
     if (i >= nbm) continue;
     const u64 ki = make_key(C.score[i], C.ch[i], i);
@@ -321,11 +459,13 @@ bool mi355asr_beam_device_applicable(int V, int N, int beam) { return beam >= 1 
 size_t mi355asr_beam_device_ws_bytes(int B, int T, int beam, int max_len) {
   const size_t arena = (size_t)B * ((size_t)T * beam + 1) * sizeof(int2);
   const size_t out = (size_t)B * beam * ((size_t)max_len * 4 + 8) + (size_t)B * 4;
-  return arena + out + 256;
+  return arena + out + (size_t)B * 4 /* in_len */ + 64 /* profile counters */ + 256;
 }
 
 int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s) {
-  hipLaunchKernelGGL(beam_search_kernel, dim3(a->B), dim3(NT), 0, s, *a);
+  const bool small = a->beam * (std::min(a->N, a->beam + 2) + 1) <= NT;
+  if (small) hipLaunchKernelGGL(beam_search_kernel<true>, dim3(a->B), dim3(NT), 0, s, *a);
+  else hipLaunchKernelGGL(beam_search_kernel<false>, dim3(a->B), dim3(NT), 0, s, *a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -380,6 +380,73 @@ def test_prefix_beam_from_logits_batch(torch_cuda):
         ctc_prefix_beam_decode(zt, in_len, beam, 1.0, 40, is_logits=True)     # un-pruned mode is host-only
 
 
+def test_prefix_beam_topn_ties_and_zero_rows(torch_cuda):
+    """The selection kernel on rows full of ties: the host orders equal probabilities by class (stable_sort), so must the
+    kernel -- rows of quantised probabilities, rows with fewer non-zero classes than cutoff_top_n, a row of equal values,
+    V below one wave.  Beam 1: the search itself is then free of unspecified tie-breaks."""
+    torch = torch_cuda
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    rng = np.random.default_rng(77)
+    for V in (37, 200, 4233):
+        B, T = 3, 40
+        p = rng.random((B, T, V)).astype(np.float32) ** 8
+        p[0] = np.round(p[0] * 16) / 16                      # many ties, many exact zeros
+        p[1, :, 5:] *= (rng.random((T, V - 5)) < 0.02)       # fewer than 40 non-zero classes
+        p[2, ::2] = 1.0                                      # all equal
+        p /= np.maximum(p.sum(-1, keepdims=True), 1e-30)
+        for top_n in (40, 7):
+            d = ctc_prefix_beam_decode(torch.from_numpy(p).cuda(), None, 1, 0.9999, top_n)
+            h = ctc_prefix_beam_decode(p, None, 1, 0.9999, top_n)
+            assert np.array_equal(d[3], h[3]) and np.array_equal(d[1], h[1])
+            assert np.array_equal(d[0], h[0]) and np.array_equal(d[2], h[2])
+
+
+@pytest.mark.parametrize("beam", [1, 4, 10, 14, 15, 40, 100])
+def test_prefix_beam_device_search_equals_host_search(torch_cuda, beam):
+    """The device search (beam_device.hip: one-key-per-thread path up to beam 14, radix path above, and the radix
+    fallback of the former on near-ties) against the host search (beam.hip, pinned to the reference decoder's KATs) on the
+    same probabilities: peaked rows (the cumulative cut keeps a handful of classes), flat rows (all 40 candidates,
+    closely spaced scores), blank-dominated rows; ragged lengths including 0 and 1."""
+    torch = torch_cuda
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    rng = np.random.default_rng(100 + beam)
+    B, T, V = 6, 90, 300
+    z = rng.standard_normal((B, T, V)).astype(np.float32)
+    z[0] *= 6.0
+    z[1] *= 0.2
+    z[2] *= 3.0
+    z[2, :, -1] += 8.0
+    z[3] *= rng.uniform(0.1, 6.0, (T, 1)).astype(np.float32)
+    z[4] *= 2.0
+    z[5] *= 4.0
+    z[5, ::3, -1] += 6.0
+    z[5, 1::3] = z[5, ::3][: z[5, 1::3].shape[0]] + 0.01 * z[5, 1::3]          # repeated characters
+    p = torch.softmax(torch.from_numpy(z), -1).numpy()
+    in_len = np.array([T, T, 61, T, 1, 0], np.int32)
+    for cutoff_prob, top_n in ((0.99, 40), (0.9999, 25)):
+        d = ctc_prefix_beam_decode(torch.from_numpy(p).cuda(), in_len, beam, cutoff_prob, top_n)
+        h = ctc_prefix_beam_decode(p, in_len, beam, cutoff_prob, top_n)
+        assert np.array_equal(d[3], h[3])
+        assert np.array_equal(d[2], h[2])                  # the ranked scores, bit for bit
+        for b in range(B):
+            # Hypotheses with the same float score and last character are ordered by std::sort / std::nth_element in the
+            # reference (unspecified), by node id on the host and by slot on the device: compare groups of equal score as
+            # sets; a group cut by the beam boundary (the last one) may keep different members.
+            n = int(h[3][b])
+            hyp = lambda r, i: tuple(r[0][b, i, :r[1][b, i]])
+            i = 0
+            while i < n:
+                e = i
+                while e + 1 < n and h[2][b, e + 1] == h[2][b, i]:
+                    e += 1
+                gd = {hyp(d, q) for q in range(i, e + 1)}
+                gh = {hyp(h, q) for q in range(i, e + 1)}
+                if e < n - 1:                      # a tie group cut by the beam boundary may keep different members
+                    assert gd == gh, (b, i, e)
+                i = e + 1
+            assert hyp(d, 0) == hyp(h, 0) or (n > 1 and h[2][b, 0] == h[2][b, 1])
+
+
 # ---- row a15: ChunkConformer offline predict (parity unpinned in the reference; oracle = restatement) ----------------
 def _chunk_model(cfg, w):
     from tensorflowasr_amd.models import ChunkConformer
