@@ -193,6 +193,7 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
     o.ff_b2[i] = ab.put(T(q + "/ffn2/bias"));
   }
   const std::string a = p + "/mhsa_module";
+  std::function<float(int, int)> qkv_at;
   o.att_ln_g = ab.put(T(a + "/ln/gamma"));
   o.att_ln_b = ab.put(T(a + "/ln/beta"));
   if (keras_mha) {
@@ -212,6 +213,11 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
     const auto& pk = T(a + "/mha/attention_output/kernel");  // [H, hs, d]: row k = h*hs + i
     o.out_wp = ab.put(pack_p16([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d, d / 16));
     o.out_b = ab.put(T(a + "/mha/attention_output/bias"));
+    qkv_at = [&qk, &kk_, &vk, d](int i, int n) {
+      const int which = n / d, r = n % d;
+      const std::vector<float>& w = which == 0 ? qk : (which == 1 ? kk_ : vk);
+      return w[(size_t)i * d + r];
+    };
   } else {
   const auto& qk = T(a + "/mha/query_kernel");
   const auto& kk_ = T(a + "/mha/key_kernel");
@@ -228,8 +234,16 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   const auto& pk = T(a + "/mha/projection_kernel");  // [H, hs, d]: row k = h*hs + i
   o.out_wp = ab.put(pack_p16([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d, d / 16));
   o.out_b = ab.put(T(a + "/mha/projection_bias"));
+  qkv_at = [&qk, &kk_, &vk, d, hs](int i, int n) {
+    const int which = n / d, r = n % d, h = r / hs, oo = r % hs;
+    const std::vector<float>& w = which == 0 ? qk : (which == 1 ? kk_ : vk);
+    return w[((size_t)h * d + i) * hs + oo];
+  };
+  }
   if (d == 144) {
-    o.out_ws = ab.put(pack_split32([&](int kk, int n) { return pk[(size_t)kk * d + n]; }, d, d)); o.split = true;
+    // the split-bf16 packs of the ring kernels (fused.hip), for either attention layout
+    const auto& pk_out = keras_mha ? T(a + "/mha/attention_output/kernel") : T(a + "/mha/projection_kernel");
+    o.out_ws = ab.put(pack_split32([&](int kk, int n) { return pk_out[(size_t)kk * d + n]; }, d, d)); o.split = true;
     // slab stream of ff1_qkv_ring_kernel: per hidden chunk of 144 the five steps of W1[:, chunk] and of W2[chunk, :],
     // then q, k, v (five steps each)
     const auto& f1 = T(p + "/ff_module_1/ffn1/kernel");
@@ -239,13 +253,8 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
       append_slabs(st, [&](int kk, int n) { return f1[(size_t)kk * 4 * d + d * ch + n]; }, d, d, false);
       append_slabs(st, [&](int kk, int n) { return f2[(size_t)(d * ch + kk) * d + n]; }, d, d, false);
     }
-    append_slabs(st, [&](int i, int n) {
-      const int which = n / d, r = n % d, h = r / hs, oo = r % hs;
-      const std::vector<float>& w = which == 0 ? qk : (which == 1 ? kk_ : vk);
-      return w[((size_t)h * d + i) * hs + oo];
-    }, d, 3 * d, true);
+    append_slabs(st, qkv_at, d, 3 * d, true);
     o.ff1_slabs = ab.put(st);
-  }
   }
   const std::string c = p + "/conv_module";
   o.cv_ln_g = ab.put(T(c + "/ln/gamma"));

@@ -94,8 +94,11 @@ int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int 
   } else if (in != sc.xa) {
     HIP_TRY(hipMemcpyAsync(sc.xa, in, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
   }
-  for (const auto& blk : st.blocks) {
-    int rc = run_block(m, blk, st.opts, sc, B, T, nullptr, s);
+  bool ff1_done = false;                    // the tail of block i also runs ff_module_1 + qkv of block i + 1 (model.h)
+  for (size_t i = 0; i < st.blocks.size(); ++i) {
+    const bool skip = ff1_done;
+    int rc = run_block(m, st.blocks[i], st.opts, sc, B, T, nullptr, s, nullptr,
+                       i + 1 < st.blocks.size() ? &st.blocks[i + 1] : nullptr, &ff1_done, skip);
     if (rc) return rc;
   }
   if (st.fc_wp && (logits || amax)) {

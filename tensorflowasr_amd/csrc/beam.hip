@@ -240,7 +240,7 @@ void run_batch(int B, int num_threads, RowFn&& per_utt) {
 // GPU: per-frame top-n.  One wave per frame, the frame's V values staged in LDS.  Output order = the host's
 // stable_sort: value descending, class ascending among equal values.
 //
-// Fast path (N <= 64): lane l owns the classes l, l + 64, ...  Exactly N lanes own a value >= T0 := the N-th largest of
+// Fast path (N <= 64): the classes are partitioned over the 64 lanes.  Exactly N lanes own a value >= T0 := the N-th largest of
 // the 64 lane maxima, so at least N classes are >= T0, and for independent values only ~1.5 N are.  One pass collects the
 // classes > T0 (all of them) and the first N classes == T0 in class order (ballot compaction keeps class order); the
 // final order comes from counting, for every collected class, the collected classes that precede it.  ~3 passes over the
@@ -275,7 +275,7 @@ __device__ __forceinline__ void topn_rounds(float* sh, int V, int N, int lane, b
 
 __global__ __launch_bounds__(64) void topn_kernel(const float* __restrict__ x, int V, int N, int is_logits,
                                                   int32_t* __restrict__ out_idx, float* __restrict__ out_p) {
-  extern __shared__ float sh[];
+  extern __shared__ __align__(16) float sh[];
   __shared__ float cv[GT_CAP + EQ_CAP];
   __shared__ int ci[GT_CAP + EQ_CAP];
   const int lane = threadIdx.x;
@@ -283,11 +283,42 @@ __global__ __launch_bounds__(64) void topn_kernel(const float* __restrict__ x, i
   const float* row = x + frame * V;
   out_idx += frame * N;
   out_p += frame * N;
-  float mx = -INFINITY;                     // = this lane's maximum until the reduction below
-  for (int i = lane; i < V; i += 64) {
-    const float v = row[i];
-    sh[i] = v;
-    mx = fmaxf(mx, v);
+  // stage the row; mx = the maximum of what this lane staged (any partition of the classes over the lanes serves the
+  // threshold below).  Several loads in flight per lane: with one wave per frame the pass is latency-bound otherwise.
+  float mx = -INFINITY;
+  if ((V & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const float4* row4 = reinterpret_cast<const float4*>(row);
+    float4* sh4 = reinterpret_cast<float4*>(sh);
+    const int V4 = V >> 2;
+    for (int i0 = 0; i0 < V4; i0 += 64 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u + lane;
+        v[u] = i < V4 ? row4[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u + lane;
+        if (i < V4) sh4[i] = v[u];
+        mx = fmaxf(fmaxf(mx, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
+      }
+    }
+  } else {
+    for (int i0 = 0; i0 < V; i0 += 64 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u + lane;
+        v[u] = i < V ? row[i] : -INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u + lane;
+        if (i < V) sh[i] = v[u];
+        mx = fmaxf(mx, v[u]);
+      }
+    }
   }
   const float lane_max = mx;
 #pragma unroll
@@ -295,6 +326,7 @@ __global__ __launch_bounds__(64) void topn_kernel(const float* __restrict__ x, i
   float denom = 1.f;
   if (is_logits) {
     float s = 0.f;
+#pragma unroll 8
     for (int i = lane; i < V; i += 64) s += __expf(sh[i] - mx);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
@@ -316,6 +348,7 @@ __global__ __launch_bounds__(64) void topn_kernel(const float* __restrict__ x, i
   // collect: classes > T0 into [0, G), the first EQ_CAP classes == T0 into [GT_CAP, GT_CAP + E)
   const unsigned long long lt = (1ull << lane) - 1;
   int G = 0, E = 0;
+#pragma unroll 4
   for (int i0 = 0; i0 < V; i0 += 64) {
     const int i = i0 + lane;
     const float v = i < V ? sh[i] : -INFINITY;

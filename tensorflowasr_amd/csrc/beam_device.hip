@@ -46,8 +46,11 @@ __device__ __forceinline__ float logf_cr(float x) { return (float)log((double)x)
 __device__ __forceinline__ float lse(float x, float y) {        // decoder_utils.h:41-49 with T = float
   if (x <= kNegInf) return y;
   if (y <= kNegInf) return x;
-  const float m = fmaxf(x, y);
-  return logf_cr(expf_cr(x - m) + expf_cr(y - m)) + m;
+  // logf(expf(x - m) + expf(y - m)) + m: the larger argument contributes expf(0) = 1 exactly; below 2^-25 the other one
+  // is absorbed by the float addition and logf(1) = 0
+  const float m = fmaxf(x, y), d = fminf(x, y) - m;
+  if (d < -17.5f) return 0.f + m;
+  return logf_cr(1.0f + expf_cr(d)) + m;
 }
 __device__ __forceinline__ u64 mix(u64 parent, int c) {        // prefix identity
   u64 z = parent * 0x9E3779B97F4A7C15ull + (u64)(unsigned)(c + 2) * 0xBF58476D1CE4E5B9ull;
@@ -110,6 +113,7 @@ struct Shared {
   int hist[2][256];
   int wave_tot[4][NT / 64];
   int digit, need, done, thr_ok;
+  float max_score;
   u64 diff;
 };
 
@@ -310,6 +314,13 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     // ---- 1. (wave 3) the next frame's candidates
     if (pl >= 0 && t + 1 < frames) prepare(t + 1);
     if (tid < BMAX) sh.exist_mask[(t + 1) & 1][tid] = 0;
+    if (SMALL && (tid >> 6) == 2) {         // wave 2: the best entry score, for the acceptance test of the small path
+      float best = kNegInf;
+      for (int i = tid & 63; i < nbm; i += 64) best = fmaxf(best, C.score[i]);
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) best = fmaxf(best, __shfl_xor(best, off));
+      if ((tid & 63) == 0) sh.max_score = best;
+    }
     // ---- 2. existing entries: blank update, repetition, extension by the parent if that is in the beam
     if (tid < nbm) {
       const int i = tid;
@@ -361,46 +372,50 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     int newn;
     bool redo = !SMALL;
     if (SMALL) {
-      // ---- 3s. one key per thread: slots [0, nbm) = existing entries, nbm + j * ncap + k = child of entry j by candidate k
-      const int ncap = min(nc, beam + 2);
+      // ---- 3s. slots [0, nbm) = existing entries, nbm + j * ncap + k = child of entry j by candidate k; one thread
+      //          per slot, or a pair of threads when the slots fill at most half of the workgroup (ncap gives one
+      //          candidate away for that: the acceptance test below does not care how ncap was chosen)
+      int ncap = min(nc, beam + 2);
+      if (nbm + nbm * ncap > NT / 2 && ncap > 1 && nbm + nbm * (ncap - 1) <= NT / 2) --ncap;
       const int S = nbm + nbm * ncap;
+      const bool pairs = S <= NT / 2;
+      const int slot = pairs ? tid >> 1 : tid, half = pairs ? tid & 1 : 0;
       u64 key = ~0ull;
       int j = 0, k = 0;
       float lp = kNegInf;
-      if (tid < nbm) {
-        lp = sh.cscore[tid];
-        key = make_key(lp, C.ch[tid], tid);
-      } else if (tid < S) {
-        j = (tid - nbm) / ncap;
-        k = (tid - nbm) - j * ncap;
+      if (slot < nbm) {
+        lp = sh.cscore[slot];
+        key = make_key(lp, C.ch[slot], slot);
+      } else if (slot < S) {
+        j = (slot - nbm) / ncap;
+        k = (slot - nbm) - j * ncap;
         if (k != kb && !((exist[j] >> k) & 1ull)) {
           lp = child_lp(C, K, j, k);
-          key = make_key(lp, K.c[k], tid);
+          key = make_key(lp, K.c[k], slot);
         }
       }
-      sh.keys[tid] = key;
+      if (half == 0) sh.keys[slot] = key;
+      if (pairs && half == 1 && slot + NT / 2 < NT) sh.keys[slot + NT / 2] = ~0ull;
       if (tid == 0) sh.thr_ok = 0;            // every wave has read the previous frame's flag: it is past this frame's first barrier
       __syncthreads();
-      // ---- 4s. rank = number of better keys (slots make keys distinct)
+      // ---- 4s. rank = number of better keys (slots make keys distinct); a pair splits the count
       int rank = 0;
-      for (int s0 = 0; s0 < S; s0 += 16) {   // slots [S, NT) hold ~0 and count for nothing
+      const int sbeg = pairs ? half * (NT / 4) : 0, send = pairs ? min(S, sbeg + NT / 4) : S;
+      for (int s0 = sbeg; s0 < send; s0 += 16) {   // slots [S, NT) hold ~0 and count for nothing
         ulonglong2 kk[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) kk[q] = reinterpret_cast<const ulonglong2*>(sh.keys + s0)[q];
 #pragma unroll
         for (int q = 0; q < 8; ++q) rank += (kk[q].x < key) + (kk[q].y < key);
       }
-      const bool keep = key != ~0ull && rank < beam;
+      if (pairs) rank += __shfl_xor(rank, 1);
+      const bool keep = half == 0 && key != ~0ull && rank < beam;
       long long t2 = 0;
       if (profiling) { t2 = clock64(); prof[1] += t2 - t1; }
       if (keep) {
-        if (tid < nbm) keep_entry(sh, C, Nx, tid, rank);
+        if (slot < nbm) keep_entry(sh, C, Nx, slot, rank);
         else keep_child(C, Nx, arena, 1 + t * beam + rank, j, K.c[k], lp, rank);
-        if (rank == beam - 1 && ncap < nc) {
-          float best = kNegInf;
-          for (int i = 0; i < nbm; ++i) best = fmaxf(best, C.score[i]);
-          if (lp > K.lp[ncap] + best) sh.thr_ok = 1;
-        }
+        if (rank == beam - 1 && ncap < nc && lp > K.lp[ncap] + sh.max_score) sh.thr_ok = 1;
       }
       newn = __syncthreads_count(keep);
       redo = ncap < nc && !sh.thr_ok;       // uniform
