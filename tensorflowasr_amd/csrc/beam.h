@@ -26,7 +26,7 @@ struct BeamDeviceArgs {
   float* scores;            // [B, beam]
   int32_t* n_hyp;           // [B]
   int2* arena;              // [B, T * beam + 1] back-pointers (parent link, character)
-  long long* prof;          // null, or 6 counters of utterance 0: clocks in (entries, keys + ranks, keep, radix path), radix frames, frames
+  long long* prof;          // null, or 9 counters of utterance 0 (MI355ASR_BEAM_PROF)
 };
 bool mi355asr_beam_device_applicable(int V, int N, int beam);
 size_t mi355asr_beam_device_ws_bytes(int B, int T, int beam, int max_len);

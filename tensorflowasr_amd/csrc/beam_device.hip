@@ -36,7 +36,7 @@ namespace {
 constexpr int NT = 256;          // threads per utterance
 constexpr int BMAX = 128;        // beam entries
 constexpr int NMAX = 40;         // candidates per frame (cutoff_top_n)
-constexpr int SMAX = BMAX * (NMAX + 1);
+constexpr int SMALL_BEAM = 16;   // widest beam of the one-key-per-thread kernel
 constexpr float kNegInf = -FLT_MAX;
 
 typedef unsigned long long u64;
@@ -114,7 +114,8 @@ struct Shared {
   int wave_tot[4][NT / 64];
   int digit, need, done, thr_ok;
   float max_score;
-  u64 diff;
+  u64 diff, kmin[2];
+  int kept_j[BMAX];
 };
 
 // extension of entry j by candidate k (ctc_beam_search_decoder.cpp:99-113)
@@ -140,101 +141,141 @@ __device__ __forceinline__ float key_score(u64 key) {             // inverse of 
 
 // Steps 3-5 for any beam width.  Keys live in registers: thread (wave w, lane k) owns the children by candidate k of the
 // entries w, w + 4, w + 8, ... (what depends on k is loaded once, what depends on the entry is a broadcast read), and
-// thread i < nbm also owns entry i's own key.  Threshold key by radix select over the bytes of the key (most significant
-// differing byte first, early exit as soon as the selected bin is wanted whole), then compaction in thread order.  Ends
-// with a barrier; returns the size of the next beam.
-constexpr int JPT = BMAX / (NT / 64);      // entries per wave
+// thread i < nbm also owns entry i's own key.  The threshold key comes from a radix select with digits of up to 8 bits,
+// the first digit starting at the most significant bit in which the finite keys differ (children that cannot be
+// extended score -FLT_MAX: they only matter while the beam is not full, and would otherwise cost whole passes on the
+// exponent bits), early exit as soon as the selected bin is wanted whole.  The kept keys are listed in LDS and installed
+// by one thread each.  Ends with a barrier; returns the size of the next beam.
+constexpr unsigned kNegHi = 0xFF7FFFFFu;   // first key word of a score of -FLT_MAX: ~(~bits(-FLT_MAX))
+struct RadixProf { long long keys, select, install; };
+template <int JPT>                         // entries per wave: nbm <= 4 * JPT
 __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx, const Cands& K, const u64* exist, int nbm,
-                                            int beam, int t, int2* arena) {
+                                            int beam, int t, int2* arena, bool profiling, RadixProf& rp) {
   const int tid = threadIdx.x, k = tid & 63, w = tid >> 6;
+  long long c0 = 0;
+  if (profiling) c0 = clock64();
   const int nc = K.n, kb = K.blank;
   const bool cand = k < nc && k != kb;
   const int c = cand ? K.c[k] : 0;
   const float clp = cand ? K.lp[k] : 0.f;
-  const u64 key0 = make_key(sh.cscore[0], C.ch[0], 0);
   u64 ekey = ~0ull, ck[JPT];
-  int valid = 0;
-  u64 diff = 0;
+  int counts = 0;                           // valid keys + (finite keys << 16)
+  u64 kmin = ~0ull;
   if (tid < nbm) {
     ekey = make_key(sh.cscore[tid], C.ch[tid], tid);
-    ++valid;
-    diff |= ekey ^ key0;
+    counts += 1 + (((unsigned)(ekey >> 32) != kNegHi) << 16);
+    kmin = ekey;
   }
 #pragma unroll
-  for (int i = 0; i < JPT; ++i) {
-    const int j = w + 4 * i;
-    u64 key = ~0ull;
-    if (j < nbm) {                          // wave-uniform
-      const u64 ex = exist[j];
-      const int chj = C.ch[j];
-      const float bj = C.b[j], sj = C.score[j];
-      if (cand && !((ex >> k) & 1ull)) {
-        const float lp = c == chj ? (bj > kNegInf ? clp + bj : kNegInf) : clp + sj;
-        key = make_key(lp, c, nbm + j * nc + k);
-        ++valid;
-        diff |= key ^ key0;
-      }
+  for (int g = 0; g < JPT; g += 4) {
+    if (w + 4 * g >= nbm) {                 // wave-uniform
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ck[g + u] = ~0ull;
+      continue;
     }
-    ck[i] = key;
+    u64 ex[4];
+    int chj[4];
+    float bj[4], sj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {           // four entries' broadcast reads in flight together
+      const int j = min(w + 4 * (g + u), nbm - 1);
+      ex[u] = exist[j]; chj[u] = C.ch[j]; bj[u] = C.b[j]; sj[u] = C.score[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = w + 4 * (g + u);
+      u64 key = ~0ull;
+      if (j < nbm && cand && !((ex[u] >> k) & 1ull)) {
+        const float lp = c == chj[u] ? (bj[u] > kNegInf ? clp + bj[u] : kNegInf) : clp + sj[u];
+        key = make_key(lp, c, nbm + j * nc + k);
+        counts += 1 + (((unsigned)(key >> 32) != kNegHi) << 16);
+        kmin = key < kmin ? key : kmin;
+      }
+      ck[g + u] = key;
+    }
   }
-  if (tid == 0) sh.diff = 0;
-  int M;
-  block_scan(valid, sh.wave_tot[3], &M);    // its barrier also publishes the zeroed diff
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const u64 o = __shfl_xor(kmin, off);
+    kmin = o < kmin ? o : kmin;
+  }
+  if (tid == 0) { sh.diff = 0; }
+  if (k == 0) atomicMin(&sh.kmin[t & 1], kmin);
+  int Mc;
+  block_scan(counts, sh.wave_tot[3], &Mc);  // its barrier also publishes diff = 0 and the best key
+  const int M = Mc & 0xffff, Mfin = Mc >> 16;
+  if (profiling) { const long long cc = clock64(); rp.keys += cc - c0; c0 = cc; }
   u64 thr = ~0ull - 1;                      // M <= beam: every valid key (invalid ones are ~0)
   int shift_keep = 0;
   if (M > beam) {
+    const u64 key0 = sh.kmin[t & 1];
+    const bool fin_only = Mfin > beam;
+    u64 diff = 0;
+    if (ekey != ~0ull && !(fin_only && (unsigned)(ekey >> 32) == kNegHi)) diff |= ekey ^ key0;
+#pragma unroll
+    for (int i = 0; i < JPT; ++i)
+      if (ck[i] != ~0ull && !(fin_only && (unsigned)(ck[i] >> 32) == kNegHi)) diff |= ck[i] ^ key0;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) diff |= __shfl_xor(diff, off);
     if (k == 0) atomicOr(&sh.diff, diff);
     __syncthreads();
-    const int top = (63 - __builtin_clzll(sh.diff | 1ull)) >> 3;       // the keys agree above byte `top`
-    u64 pre = top == 7 ? 0 : (key0 >> (8 * top + 8)) << (8 * top + 8);
+    int low = 64 - __builtin_clzll(sh.diff | 1ull);                     // the keys in play agree in bits [low, 64)
+    u64 pre = low == 64 ? 0 : (key0 >> low) << low;
     int need = beam;
-    int pass = top;
-    for (; pass >= 0; --pass) {
-      const int shift = 8 * pass, hb = pass & 1;
-      const u64 hi_mask = pass == 7 ? 0 : ~0ull << (shift + 8);
-      if (ekey != ~0ull && ((ekey ^ pre) & hi_mask) == 0) atomicAdd(&sh.hist[hb][(int)((ekey >> shift) & 255)], 1);
+    for (int pass = 0; low > 0; ++pass) {
+      const int width = min(8, low), shift = low - width, hb = pass & 1;
+      const u64 hi_mask = low == 64 ? 0 : ~0ull << low;
+      const unsigned dmask = (1u << width) - 1;
+      if (ekey != ~0ull && ((ekey ^ pre) & hi_mask) == 0) atomicAdd(&sh.hist[hb][(int)((unsigned)(ekey >> shift) & dmask)], 1);
 #pragma unroll
       for (int i = 0; i < JPT; ++i)
-        if (ck[i] != ~0ull && ((ck[i] ^ pre) & hi_mask) == 0) atomicAdd(&sh.hist[hb][(int)((ck[i] >> shift) & 255)], 1);
+        if (ck[i] != ~0ull && ((ck[i] ^ pre) & hi_mask) == 0) atomicAdd(&sh.hist[hb][(int)((unsigned)(ck[i] >> shift) & dmask)], 1);
       __syncthreads();
       const int h = sh.hist[hb][tid];
-      sh.hist[hb][tid] = 0;                 // clean for pass - 2 (and for the next frame)
+      sh.hist[hb][tid] = 0;                 // clean for the pass after the next (and for the next frame)
       int tot;
       const int ex = block_scan(h, sh.wave_tot[hb], &tot);
-      if (ex < need && need <= ex + h) {    // the bin that holds the need-th smallest active key
+      if (ex < need && need <= ex + h) {    // the bin that holds the need-th smallest key in play
         sh.digit = tid;
         sh.need = need - ex;
-        sh.done = (need - ex == h);         // the whole bin is wanted: no need to resolve lower bytes
+        sh.done = (need - ex == h);         // the whole bin is wanted: no need to resolve lower bits
       }
       __syncthreads();
       pre |= (u64)sh.digit << shift;
       need = sh.need;
+      low = shift;
       if (sh.done) break;
     }
-    if (pass < 0) pass = 0;
-    shift_keep = 8 * pass;
+    shift_keep = low;
     thr = pre;
   }
+  if (profiling) { const long long cc = clock64(); rp.select += cc - c0; c0 = cc; }
+  // the kept keys into a list (thread order), then one thread per kept key installs it in the next beam
   const u64 thr_s = thr >> shift_keep;
   int keep_cnt = (ekey != ~0ull && (ekey >> shift_keep) <= thr_s);
 #pragma unroll
   for (int i = 0; i < JPT; ++i) keep_cnt += (ck[i] != ~0ull && (ck[i] >> shift_keep) <= thr_s);
   int newn;
   int pos = block_scan(keep_cnt, sh.wave_tot[2], &newn);
-  if (ekey != ~0ull && (ekey >> shift_keep) <= thr_s) keep_entry(sh, C, Nx, tid, pos++);
+  if (keep_cnt) {
+    if (ekey != ~0ull && (ekey >> shift_keep) <= thr_s) { sh.keys[pos] = ekey; sh.kept_j[pos] = -1 - tid; ++pos; }
 #pragma unroll
-  for (int i = 0; i < JPT; ++i)
-    if (ck[i] != ~0ull && (ck[i] >> shift_keep) <= thr_s) {
-      keep_child(C, Nx, arena, 1 + t * beam + pos, w + 4 * i, c, key_score(ck[i]), pos);
-      ++pos;
-    }
+    for (int i = 0; i < JPT; ++i)
+      if (ck[i] != ~0ull && (ck[i] >> shift_keep) <= thr_s) { sh.keys[pos] = ck[i]; sh.kept_j[pos] = w + 4 * i; ++pos; }
+  }
   __syncthreads();
+  if (tid < newn) {
+    const u64 key = sh.keys[tid];
+    const int j = sh.kept_j[tid];
+    if (j < 0) keep_entry(sh, C, Nx, -1 - j, tid);
+    else keep_child(C, Nx, arena, 1 + t * beam + tid, j, (int)((key >> 16) & 0xffff) - 1, key_score(key), tid);
+  }
+  __syncthreads();
+  if (profiling) rp.install += clock64() - c0;
   return newn;
 }
 
-// SMALL: beam * (min(N, beam + 2) + 1) <= NT -- one key per thread over the first ncap = min(nc, beam + 2) candidates,
+// SMALL: beam <= SMALL_BEAM and beam * (min(N, beam + 2) + 1) <= NT -- one key per thread over the first ncap = min(nc, beam + 2) candidates,
 // ranks by counting, the next beam written in rank order.  A child by the candidate at position k has k - 2 or more
 // siblings that score at least as much (those by the candidates before it, minus the blank and the entry's own
 // character; a sibling that is a beam entry itself scores at least its extension term), so children beyond position
@@ -256,7 +297,8 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     B0.score[0] = 0.f; B0.b[0] = 0.f; B0.nb[0] = kNegInf;
     arena[0] = make_int2(-1, -1);
   }
-  long long prof[5] = {0, 0, 0, 0, 0};
+  long long p_entries = 0, p_keys = 0, p_keep = 0, p_radix = 0, p_redone = 0;
+  RadixProf rprof = {0, 0, 0};
   const bool profiling = a.prof != nullptr && b == 0 && tid == 0;
 
   // wave 3 holds the top-n list of the frame it prepares next in registers (lane k = position k); the list of the frame
@@ -301,6 +343,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   sh.hist[0][tid] = 0;
   sh.hist[1][tid] = 0;
   if (tid < BMAX) sh.exist_mask[0][tid] = 0;
+  if (tid < 2) sh.kmin[tid] = ~0ull;
   __syncthreads();
 
   for (int t = 0; t < frames; ++t) {
@@ -314,6 +357,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     // ---- 1. (wave 3) the next frame's candidates
     if (pl >= 0 && t + 1 < frames) prepare(t + 1);
     if (tid < BMAX) sh.exist_mask[(t + 1) & 1][tid] = 0;
+    if (!SMALL && tid == 0) sh.kmin[(t + 1) & 1] = ~0ull;   // select_radix's best key, per frame parity
     if (SMALL && (tid >> 6) == 2) {         // wave 2: the best entry score, for the acceptance test of the small path
       float best = kNegInf;
       for (int i = tid & 63; i < nbm; i += 64) best = fmaxf(best, C.score[i]);
@@ -367,7 +411,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     }
     __syncthreads();
     long long t1 = 0;
-    if (profiling) { t1 = clock64(); prof[0] += t1 - t0; }
+    if (profiling) { t1 = clock64(); p_entries += t1 - t0; }
 
     int newn;
     bool redo = !SMALL;
@@ -411,7 +455,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
       if (pairs) rank += __shfl_xor(rank, 1);
       const bool keep = half == 0 && key != ~0ull && rank < beam;
       long long t2 = 0;
-      if (profiling) { t2 = clock64(); prof[1] += t2 - t1; }
+      if (profiling) { t2 = clock64(); p_keys += t2 - t1; }
       if (keep) {
         if (slot < nbm) keep_entry(sh, C, Nx, slot, rank);
         else keep_child(C, Nx, arena, 1 + t * beam + rank, j, K.c[k], lp, rank);
@@ -419,20 +463,24 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
       }
       newn = __syncthreads_count(keep);
       redo = ncap < nc && !sh.thr_ok;       // uniform
-      if (profiling) prof[2] += clock64() - t2;
+      if (profiling) p_keep += clock64() - t2;
     }
     if (redo) {
       long long t3 = 0;
-      if (profiling) { t3 = clock64(); if (SMALL) ++prof[4]; }
-      newn = select_radix(sh, C, Nx, K, exist, nbm, beam, t, arena);
-      if (profiling) prof[3] += clock64() - t3;
+      if (profiling) { t3 = clock64(); if (SMALL) ++p_redone; }
+      if (SMALL) {                          // a rare frame: reset the best-key cell here rather than in every frame
+        if (tid == 0) sh.kmin[t & 1] = ~0ull;
+        __syncthreads();
+      }
+      newn = select_radix<SMALL ? SMALL_BEAM / 4 : BMAX / 4>(sh, C, Nx, K, exist, nbm, beam, t, arena, profiling, rprof);
+      if (profiling) p_radix += clock64() - t3;
     }
     cur ^= 1;
     nbm = newn;
   }
   if (profiling) {
-    for (int i = 0; i < 5; ++i) a.prof[i] = prof[i];
-    a.prof[5] = frames;
+    a.prof[0] = p_entries; a.prof[1] = p_keys; a.prof[2] = p_keep; a.prof[3] = p_radix; a.prof[4] = p_redone;
+    a.prof[5] = rprof.keys; a.prof[6] = rprof.select; a.prof[7] = rprof.install; a.prof[8] = frames;
   }
 
   // ---- finish: rank by prefix_compare (+ slot), read the paths back
@@ -474,11 +522,11 @@ bool mi355asr_beam_device_applicable(int V, int N, int beam) { return beam >= 1 
 size_t mi355asr_beam_device_ws_bytes(int B, int T, int beam, int max_len) {
   const size_t arena = (size_t)B * ((size_t)T * beam + 1) * sizeof(int2);
   const size_t out = (size_t)B * beam * ((size_t)max_len * 4 + 8) + (size_t)B * 4;
-  return arena + out + (size_t)B * 4 /* in_len */ + 64 /* profile counters */ + 256;
+  return arena + out + (size_t)B * 4 /* in_len */ + 128 /* profile counters */ + 256;
 }
 
 int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s) {
-  const bool small = a->beam * (std::min(a->N, a->beam + 2) + 1) <= NT;
+  const bool small = a->beam <= SMALL_BEAM && a->beam * (std::min(a->N, a->beam + 2) + 1) <= NT;
   if (small) hipLaunchKernelGGL(beam_search_kernel<true>, dim3(a->B), dim3(NT), 0, s, *a);
   else hipLaunchKernelGGL(beam_search_kernel<false>, dim3(a->B), dim3(NT), 0, s, *a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
