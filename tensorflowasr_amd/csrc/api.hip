@@ -1201,26 +1201,29 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
       },
       9 * d, d, d / 16));
   o_c2b = ab.put(m->host["conv_subsampling/conv2/bias"].data);
-  if (d == 144) {
-    // split-bf16 fragments for subconv144_split_kernel: step s = 5 cb + pair; lane (r = lane & 15, g = lane >> 4) of
-    // column tile nt holds, for out channel 16 nt + r, in-channels 16 cb + 4 g + (j & 3) at tap 2 pair + (j >> 2)
-    // (the tenth tap is zero); term t = round-to-nearest-even bf16 of what the terms before it left
-    const int steps = (d / 16) * 5, NTc = d / 16;
-    std::vector<uint16_t> frag((size_t)steps * NTc * 3 * 64 * 8);
+  const bool c2_split = d == 144 || d == 256 || d == 512;
+  if (c2_split) {
+    // split-bf16 fragments for subconv_split_ring_kernel: column chunks of NTc tiles (all nine at dmodel 144, eight
+    // otherwise); step s = 5 cb + pair; lane (r = lane & 15, g = lane >> 4) of column tile nt holds, for out channel
+    // 16 nt + r, in-channels 16 cb + 4 g + (j & 3) at tap 2 pair + (j >> 2) (the tenth tap is zero); term t =
+    // round-to-nearest-even bf16 of what the terms before it left
+    const int steps = (d / 16) * 5, NTc = d == 144 ? 9 : 8, chunks = (d / 16) / NTc;
+    std::vector<uint16_t> frag((size_t)chunks * steps * NTc * 3 * 64 * 8);
     auto rne = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); };
+    for (int ch = 0; ch < chunks; ++ch)
     for (int st = 0; st < steps; ++st)
       for (int nt = 0; nt < NTc; ++nt)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 8; ++j) {
             const int cb = st / 5, pair = st % 5, q = 2 * pair + (j >> 2);
-            const int cin = 16 * cb + 4 * (lane >> 4) + (j & 3), cout = 16 * nt + (lane & 15);
+            const int cin = 16 * cb + 4 * (lane >> 4) + (j & 3), cout = 16 * (ch * NTc + nt) + (lane & 15);
             float r = q < 9 ? c2[((size_t)q * d + cin) * d + cout] : 0.f;
             for (int t = 0; t < 3; ++t) {
               const uint16_t hb = rne(r);
               const uint32_t back = (uint32_t)hb << 16;
               float hf; std::memcpy(&hf, &back, 4);
               r -= hf;
-              frag[((((size_t)st * NTc + nt) * 3 + t) * 64 + lane) * 8 + j] = hb;
+              frag[(((((size_t)ch * steps + st) * NTc + nt) * 3 + t) * 64 + lane) * 8 + j] = hb;
             }
           }
     std::vector<float> as_f(frag.size() / 2);
@@ -1296,7 +1299,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->fft_ok = fo.ok;
   m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;
   m->fft_win = base + fo.win;
-  m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = (d == 144 && c.has_encoder) ? base + o_c2s : nullptr;
+  m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = ((d == 144 || d == 256 || d == 512) && c.has_encoder) ? base + o_c2s : nullptr;
   m->lin_wsplit = (d == 144 && c.has_encoder) ? base + o_lws : nullptr;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;

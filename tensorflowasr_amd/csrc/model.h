@@ -111,7 +111,7 @@ struct mi355asr_model {
               *leaf_smooth = nullptr, *leaf_gamma = nullptr, *leaf_beta = nullptr;
   float leaf_p0 = 0.f, leaf_p1 = 1.f;
   const float* lin_wsplit = nullptr;    // subsampling Dense kernel as split-bf16 fragments, 1792 per 32-wide step (fused.hip)
-  const float* c2_wsplit = nullptr;     // conv2 kernel as split-bf16 fragments (subconv.hip; dmodel 144 only)
+  const float* c2_wsplit = nullptr;     // conv2 kernel as split-bf16 fragments (subconv.hip; dmodel 144 / 256 / 512)
   const float* leaf_wsplit = nullptr;   // Gabor filters as split-bf16 MFMA fragments (leaf.hip)
   int leaf_terms = 3;                   // bf16 terms per fp32 operand in the Gabor conv (0: fp32 MFMA kernel)
   // add_wav_info: WavePickModel weights (conv kernels P16-packed with K = k * Cin)

@@ -189,8 +189,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv144_kernel(SubConvArg
 //     partners) those of step s + 1 after the MFMAs of step s: one wave's VALU phase always faces the other's MFMAs;
 //   * the split is by truncation (x & 0xffff0000, remainder exact), packed with v_perm_b32: 11 VALU per value pair.
 constexpr int SCW = 8, SCT = SCW * 64, SRT = 2, SPOSG = SCW * 16 * SRT;   // 256 positions per workgroup
-constexpr int NPAIR = 5, NK32 = KB * NPAIR;        // MFMA steps
-constexpr int SLABF = NB * 3 * 64;                 // 16-byte fragments per step (27 KB)
+constexpr int NPAIR = 5;                           // MFMA steps per channel block of 16 (nine taps in pairs)
 constexpr int MELP = 8192;                         // floats of LDS for the mel patch
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -273,15 +272,20 @@ DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitL
 // DIAG != 0: timing experiments only (results are wrong): 1 = no conv1 / split work, 2 = one weight-fragment read per
 // step instead of nine, 3 = no slab traffic (global -> LDS), 4 = no barrier in the step loop, 5 = conv1 without its mel
 // reads from LDS, 6 = no operand split
-template <int DIAG>
-__global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a, int RS, int rows, int late_mode) {
+// DM = dmodel (conv1 channels = conv2 in / out channels), NBW = output column tiles of a workgroup: all nine for dmodel
+// 144; eight (128 channels) for 256 / 512, the chunks on grid.z -- conv1 is then recomputed per chunk, the same VALU to
+// MFMA ratio per step as at 144.  Weight fragments: [chunk][step][NBW tiles][3 terms][64 lanes][8].
+template <int DIAG, int DM, int NBW>
+__global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, int RS, int rows, int late_mode) {
+  constexpr int KB = DM / 16, NB = NBW, NK32 = KB * NPAIR, SLABF = NBW * 3 * 64, D = DM;
+  const int c0 = blockIdx.z * NBW;               // first output column tile of this workgroup
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][SLABF];
   __shared__ __attribute__((aligned(16))) float melp[MELP];
   __shared__ __attribute__((aligned(16))) float p_w1[9 * D], p_b1[D], p_b2[D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g4 = (lane >> 4) * 4, c = lane & 15;
   const int b = blockIdx.y, r0 = blockIdx.x * SPOSG, PU = a.T2 * a.F2;
-  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(a.w2s);
+  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(a.w2s) + (size_t)blockIdx.z * NK32 * SLABF;
   constexpr int NQ = (SLABF + SCT - 1) / SCT;
   u32x4 nw[NQ];
 #pragma unroll
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
   f32x4 acc[SRT][NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n) {
-    const f32x4 bv = lds4(p_b2, n, g4);
+    const f32x4 bv = lds4(p_b2, c0 + n, g4);
 #pragma unroll
     for (int rt = 0; rt < SRT; ++rt) acc[rt][n] = bv;
   }
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv144_split_kernel(SubConvArgs a,
       for (int n = 0; n < NB; ++n) {
         f32x4 v = acc[rt][n];
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        stg4(orow + 16 * n + g4, v);
+        stg4(orow + 16 * (c0 + n) + g4, v);
       }
     }
   }
@@ -453,8 +457,20 @@ int launch_subconv144(const SubConvArgs& a, hipStream_t s) {
   return 0;
 }
 
-// split-bf16 kernel; returns -1 when the shape does not fit its LDS mel patch (the caller falls back)
-int launch_subconv144_split(const SubConvArgs& a, hipStream_t s) {
+// split-bf16 kernel for dmodel 144 / 256 / 512; returns -1 when the shape does not fit its LDS mel patch or the dmodel has
+// no instantiation (the caller falls back)
+template <int DIAG>
+static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, int RS, int rows, int late_mode, hipStream_t s) {
+  const dim3 g128(g144.x, g144.y, d / 128);
+  switch (d) {
+    case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 144, 9>), g144, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 256, 8>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    case 512: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 512, 8>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    default: return -1;
+  }
+}
+
+int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
   const int PU = a.T2 * a.F2;
   const int RS = 4 * a.F2 + 4;                               // bins fm_base .. fm_base + 4 (F2 - 1) + 6
   const int span = (SPOSG - 1 + a.F2 - 1) / a.F2;            // t2 steps a tile can touch beyond its first
@@ -471,15 +487,14 @@ int launch_subconv144_split(const SubConvArgs& a, hipStream_t s) {
     return d;
   }();
   switch (diag) {
-    case 1: hipLaunchKernelGGL(subconv144_split_kernel<1>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
-    case 2: hipLaunchKernelGGL(subconv144_split_kernel<2>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
-    case 3: hipLaunchKernelGGL(subconv144_split_kernel<3>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
-    case 4: hipLaunchKernelGGL(subconv144_split_kernel<4>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
-    case 5: hipLaunchKernelGGL(subconv144_split_kernel<5>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
-    case 6: hipLaunchKernelGGL(subconv144_split_kernel<6>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    case 1: return launch_split_d<1>(d, grid, a, RS, rows, late_mode, s);
+    case 2: return launch_split_d<2>(d, grid, a, RS, rows, late_mode, s);
+    case 3: return launch_split_d<3>(d, grid, a, RS, rows, late_mode, s);
+    case 4: return launch_split_d<4>(d, grid, a, RS, rows, late_mode, s);
+    case 5: return launch_split_d<5>(d, grid, a, RS, rows, late_mode, s);
+    case 6: return launch_split_d<6>(d, grid, a, RS, rows, late_mode, s);
     default: break;
   }
 #endif
-  hipLaunchKernelGGL(subconv144_split_kernel<0>, grid, dim3(SCT), 0, s, a, RS, rows, late_mode);
-  return 0;
+  return launch_split_d<0>(d, grid, a, RS, rows, late_mode, s);
 }

@@ -94,7 +94,7 @@ def config5(steps):
     return res
 
 
-def frontend_variants(steps):
+def frontend_variants(steps, names=None):
     """the headline shape (ConformerCTC(S), 64 x 10 s, fp32) with the reference's other frontend options, and the
     larger model sizes"""
     from tensorflowasr_amd.models import ConformerCTC
@@ -106,6 +106,8 @@ def frontend_variants(steps):
                 ("M_mel", dict(dmodel=256, num_blocks=13, head_size=64, num_heads=4)),
                 ("L_mel", dict(dmodel=512, num_blocks=13, head_size=64, num_heads=8))]
     for name, kw in variants:
+        if names and name not in names:
+            continue
         m = ConformerCTC(1332, **kw)
         m._build()
         m.prepare(B, L)
@@ -120,6 +122,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--only", type=int, default=0)
+    ap.add_argument("--variants", default="", help="comma-separated subset of the --only 2 variants (S_mel, M_mel, L_mel, ...)")
     a = ap.parse_args()
     if a.only in (0, 3):
         print(json.dumps(config3(a.steps, "bfloat16")), flush=True)
@@ -127,4 +130,4 @@ if __name__ == "__main__":
     if a.only in (0, 5):
         print(json.dumps(config5(a.steps)), flush=True)
     if a.only in (0, 2):
-        print(json.dumps(frontend_variants(a.steps)), flush=True)
+        print(json.dumps(frontend_variants(a.steps, [v for v in a.variants.split(',') if v])), flush=True)
