@@ -176,10 +176,37 @@ FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vecto
 }
 
 
+// Slab ring of gemm_ring.hip: [N / 128 chunks][K / 32 steps][8 column tiles][3 terms][64 lanes][8 bf16]; a GLU layer's
+// chunk holds four value tiles and the four gate tiles that go with them.
+void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int N, bool glu) {
+  if (K % 64 != 0 || N % (glu ? 128 * 2 : 128) != 0) return;
+  const std::vector<float> sp = pack_split32(f, K, N);       // [step][NT][3 terms][64 lanes][8 bf16]
+  constexpr size_t TILE = 3 * 64 * 8 / 2;                     // floats per (step, column tile)
+  const int steps = K / 32, NT = N / 16, chunks = NT / 8, half = NT / 2;
+  std::vector<float> ring((size_t)chunks * steps * 8 * TILE);
+  for (int ch = 0; ch < chunks; ++ch)
+    for (int st = 0; st < steps; ++st)
+      for (int i = 0; i < 8; ++i) {
+        const int tile = glu ? (i < 4 ? 4 * ch + i : half + 4 * ch + (i - 4)) : 8 * ch + i;
+        std::memcpy(ring.data() + (((size_t)ch * steps + st) * 8 + i) * TILE, sp.data() + ((size_t)st * NT + tile) * TILE,
+                    TILE * sizeof(float));
+      }
+  ab.ring_pairs.emplace_back(p16_off, ab.put(ring));
+}
+// MI355ASR_GEMM_RING=0: the dense layers of dmodel 256 / 512 stay on the fp32-MFMA kernels (chain2 / gemm16<PF32>)
+bool ring_packs_wanted(const mi355asr_model* m) {
+  static const bool on = [] { const char* v = getenv("MI355ASR_GEMM_RING"); return v ? atoi(v) != 0 : true; }();
+  return on && m->cfg.gemm_dtype == 0 && m->cfg.dmodel % 128 == 0;
+}
+void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base) {
+  for (const auto& pr : ab.ring_pairs) m->ring_of[base + pr.first] = base + pr.second;
+}
+
 BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k,
                     bool keras_mha) {
   auto T = [&](const std::string& n) -> const std::vector<float>& { return m->host[n].data; };
   BlockOff o;
+  const bool rings = ring_packs_wanted(m);
   const char* ffn[2] = {"ff_module_1", "ff_module_2"};
   for (int i = 0; i < 2; ++i) {
     const std::string q = p + "/" + ffn[i];
@@ -188,8 +215,10 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
     const auto& w1 = T(q + "/ffn1/kernel");
     const auto& w2 = T(q + "/ffn2/kernel");
     o.ff_w1p[i] = ab.put(pack_p16([&](int kk, int n) { return w1[(size_t)kk * 4 * d + n]; }, d, 4 * d, 4 * d / 16));
+    if (rings) put_ring(ab, o.ff_w1p[i], [&](int kk, int n) { return w1[(size_t)kk * 4 * d + n]; }, d, 4 * d, false);
     o.ff_b1[i] = ab.put(T(q + "/ffn1/bias"));
     o.ff_w2p[i] = ab.put(pack_p16([&](int kk, int n) { return w2[(size_t)kk * d + n]; }, 4 * d, d, d / 16));
+    if (rings) put_ring(ab, o.ff_w2p[i], [&](int kk, int n) { return w2[(size_t)kk * d + n]; }, 4 * d, d, false);
     o.ff_b2[i] = ab.put(T(q + "/ffn2/bias"));
   }
   const std::string a = p + "/mhsa_module";
@@ -240,6 +269,11 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
     return w[((size_t)h * d + i) * hs + oo];
   };
   }
+  if (rings) {
+    const auto& pk_r = keras_mha ? T(a + "/mha/attention_output/kernel") : T(a + "/mha/projection_kernel");
+    put_ring(ab, o.qkv_wp, qkv_at, d, 3 * d, false);
+    put_ring(ab, o.out_wp, [&](int kk, int n) { return pk_r[(size_t)kk * d + n]; }, d, d, false);
+  }
   if (d == 144) {
     // the split-bf16 packs of the ring kernels (fused.hip), for either attention layout
     const auto& pk_out = keras_mha ? T(a + "/mha/attention_output/kernel") : T(a + "/mha/projection_kernel");
@@ -261,6 +295,7 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   o.cv_ln_b = ab.put(T(c + "/ln/beta"));
   const auto& pw1 = T(c + "/pw_conv_1/kernel");
   o.pw1_wp = ab.put(pack_p16([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d, 2 * d / 16));
+  if (rings) put_ring(ab, o.pw1_wp, [&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d, true);
   if (o.split) {
     o.pw1_ws = ab.put(pack_split32([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d));
     // slab stream of out_glu_ring_kernel: out-projection (5 slabs), then pw_conv_1 step by step (value | gate)
@@ -274,6 +309,7 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   o.dw_w = ab.put(T(c + "/dw_conv/depthwise_kernel"));  // [k, d, 1] == [k][d]
   const auto& pc = T(c + "/dw_conv/pointwise_kernel");
   o.pc_w1p = ab.put(pack_p16([&](int kk, int n) { return pc[(size_t)kk * 2 * d + n]; }, d, 2 * d, 2 * d / 16));
+  if (rings) put_ring(ab, o.pc_w1p, [&](int kk, int n) { return pc[(size_t)kk * 2 * d + n]; }, d, 2 * d, false);
   o.pc_b1 = ab.put(T(c + "/dw_conv/bias"));
   {
     const auto &g = T(c + "/bn/gamma"), &b = T(c + "/bn/beta"), &mu = T(c + "/bn/moving_mean"),
@@ -288,6 +324,7 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   }
   const auto& pw2 = T(c + "/pw_conv_2/kernel");
   o.pw2_wp = ab.put(pack_p16([&](int kk, int n) { return pw2[(size_t)kk * d + n]; }, 2 * d, d, d / 16));
+  if (rings) put_ring(ab, o.pw2_wp, [&](int kk, int n) { return pw2[(size_t)kk * d + n]; }, 2 * d, d, false);
   if (o.split) {
     // slab stream of tail_ff2_ring_kernel: per hidden chunk of 144 the five steps of W1[:, chunk] and of W2[chunk, :]
     // for the conv tail (pointwise 144 -> 288, pw_conv_2 288 -> 144), then for FFModule 2 (144 -> 576 -> 144)
@@ -341,7 +378,9 @@ BlockDev resolve(const BlockOff& o, const float* base) {
 // dmodel values those kernels are not instantiated for (e.g. 512 = ConformerL).
 bool use_gemm16(const mi355asr_model* m) {
   static const bool force = [] { const char* v = getenv("MI355ASR_GEMM16"); return v && atoi(v) != 0; }();
-  return force || m->cfg.gemm_dtype == 1 || (m->cfg.dmodel != 144 && m->cfg.dmodel != 256);
+  // dmodel 256 with slab rings (gemm_ring.hip): one launch per dense layer on the split-bf16 pipe beats the fp32 chains
+  return force || m->cfg.gemm_dtype == 1 || (m->cfg.dmodel != 144 && m->cfg.dmodel != 256) ||
+         (m->cfg.dmodel == 256 && !m->ring_of.empty());
 }
 // Few rows (single utterances, small batches, the Translator's token stream): the fused / chained kernels give each
 // 16-row tile to ONE wave that walks a whole run of layers serially (~70 us per fused kernel however small M is); below
@@ -354,6 +393,12 @@ bool gemm16_for(const mi355asr_model* m, size_t M) {
 int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s) {
   if (m->cfg.gemm_dtype == 1) { g.wp = m->w16(wp); return launch_gemm16_bf16(epi, ln, g, s); }
   g.wp = wp;
+  // long batches of dmodel 256 / 512: the same layer on the bf16 pipe with exactly split operands (gemm_ring.hip)
+  static const long ring_min_m = [] { const char* v = getenv("MI355ASR_RING_MIN_M"); return v ? atol(v) : 4096L; }();
+  if ((long)g.M >= ring_min_m && !m->ring_of.empty()) {
+    const auto it = m->ring_of.find(wp);
+    if (it != m->ring_of.end() && launch_gemm_ring(epi, ln, g, it->second, s) == 0) return 0;
+  }
   return launch_gemm16_f32(epi, ln, g, s);
 }
 
@@ -1232,6 +1277,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   }
   const auto& lin = m->host["conv_subsampling/linear/kernel"].data;
   o_lw = ab.put(pack_p16([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d, d / 16));
+  if (ring_packs_wanted(m)) put_ring(ab, o_lw, [&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d, false);
   o_lb = ab.put(m->host["conv_subsampling/linear/bias"].data);
   if (d == 144) {
     // the same kernel for sublinear_split_kernel: 1728 fragments per 32-wide step, padded to 7 x 256 (4 floats each)
@@ -1295,6 +1341,8 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   HIP_TRY(hipMemcpyAsync(m->arena, ab.buf.data(), ab.buf.size() * sizeof(float), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));  // ab.buf is freed on return
   const float* base = m->arena;
+  m->ring_of.clear();
+  register_rings(m, ab, base);
   m->dft_wp = base + o_dft; m->mel_wp = base + o_mel;
   m->fft_ok = fo.ok;
   m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;

@@ -160,6 +160,8 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   HIP_TRY(hipMemcpyAsync(m->arena, ab.buf.data(), ab.buf.size() * sizeof(float), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
   const float* base = m->arena;
+  m->ring_of.clear();
+  register_rings(m, ab, base);
   m->dft_wp = base + o_dft; m->mel_wp = base + o_mel;
   m->fft_ok = fo.ok;
   m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;

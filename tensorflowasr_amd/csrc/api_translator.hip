@@ -70,6 +70,8 @@ int finalize_translator(mi355asr_model* m, hipStream_t s) {
   HIP_TRY(hipMemcpyAsync(m->arena, ab.buf.data(), ab.buf.size() * sizeof(float), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
   const float* base = m->arena;
+  m->ring_of.clear();
+  register_rings(m, ab, base);
   m->t_emb = base + o_emb;
   m->t_pe = base + o_pe;
   resolve_stack(m->t_stack, so, base, false, V);

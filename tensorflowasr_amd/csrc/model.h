@@ -11,6 +11,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mi355asr.h"
@@ -99,6 +100,8 @@ struct mi355asr_model {
   // gemm_dtype 1: the whole arena again in bf16 (same element offsets; packed matrices keep their fragment order)
   unsigned short* arena16 = nullptr;
   const void* w16(const float* p) const { return arena16 + (p - arena); }
+  // fp32 P16 pack -> split-bf16 slab ring of the same matrix (gemm_ring.hip; dmodel 256 / 512 dense layers)
+  std::unordered_map<const float*, const float*> ring_of;
   const float *dft_wp = nullptr, *mel_wp = nullptr, *c1_w = nullptr, *c1_b = nullptr, *c2_wp = nullptr,
               *c2_b = nullptr, *lin_wp = nullptr, *lin_b = nullptr, *proj_wp = nullptr, *proj_b = nullptr,
               *fc_wp = nullptr, *fc_b = nullptr;
@@ -168,6 +171,9 @@ struct ProfScope {
 
 struct ArenaBuilder {
   std::vector<float> buf;
+  // (offset of a P16 weight pack, offset of the same matrix as a gemm_ring.hip slab ring): resolved into
+  // mi355asr_model::ring_of once the arena is on the device
+  std::vector<std::pair<size_t, size_t>> ring_pairs;
   size_t put(const std::vector<float>& v) {
     size_t off = (buf.size() + 63) & ~(size_t)63;  // 256-byte alignment
     buf.resize(off + v.size());
@@ -229,6 +235,10 @@ void add_block_expected(std::vector<Expected>& ex, const std::string& p, int d, 
 std::vector<float> pack_p16(const std::function<float(int, int)>& f, int K, int N, int NTpad);
 std::vector<float> pack_split32(const std::function<float(int, int)>& f, int K, int N);
 void append_slabs(std::vector<float>& stream, const std::function<float(int, int)>& f, int K, int N, bool group_major);
+// W[K, N] as the slab ring of gemm_ring.hip, registered in ab.ring_pairs against the P16 pack at p16_off
+void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int N, bool glu);
+bool ring_packs_wanted(const mi355asr_model* m);
+void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base);
 FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vector<float>& im, int n_dft, int nb);
 BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k, bool keras_mha = false);
 BlockDev resolve(const BlockOff& o, const float* base);

@@ -969,6 +969,44 @@ def test_conformer_m_and_l_parity(torch_cuda, base, L):
     assert (ids.cpu().numpy() == rid).all() and (lens.cpu().numpy() == rlen).all()
 
 
+def test_ring_gemm_path_of_m_and_l_in_a_subprocess(torch_cuda):
+    """gemm_ring.hip (dense layers of dmodel 256 / 512 on the split-bf16 pipe, taken from 4096 rows on) forced for a small
+    batch (MI355ASR_RING_MIN_M=1): encoder and CTC logits against the oracle for ConformerM and ConformerL, with one and
+    with two row tiles per wave (partial tiles in both), and the fp32 kernels it replaces (MI355ASR_GEMM_RING=0)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, maxdiff, small_cfg, waves
+from tensorflowasr_amd.models import ConformerCTC
+res = []
+for base, L in ((co.CONFORMER_M, 32000), (co.CONFORMER_L, 24000)):
+    cfg = small_cfg(2, base)
+    w = co.encoder_weights(cfg, seed=41)
+    w.update(co.ctc_decoder_weights(cfg, 200, seed=42))
+    m = ConformerCTC(200, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+    m.load_weights(w, by_name=False)
+    x = waves(3, L, 23)
+    enc_ref = co.conformer_encoder(x.astype(np.float64), w, cfg)
+    logits_ref = co.ctc_decoder(enc_ref, w, cfg)
+    enc = m.encode(x)
+    logits = m.ctc_logits(enc)
+    res += [maxdiff(enc.cpu().numpy(), enc_ref), maxdiff(logits.cpu().numpy(), logits_ref)]
+print("RESULT " + " ".join("%.3e" % v for v in res))
+'''
+    for extra in ({"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_RT": "1"}, {"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_RT": "2"},
+                  {"MI355ASR_GEMM_RING": "0"}):
+        env = dict(os.environ, **extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+        assert line, out.stderr[-2000:]
+        errs = [float(v) for v in line[0].split()[1:]]
+        print(extra, errs)
+        assert max(errs) < TOL, (extra, errs)
+
+
 def test_translator_dmodel_512(torch_cuda):
     """conformerL.yml Translator (dmodel 512, 8 heads x 64): cross-attention through the layer-at-a-time GEMM path."""
     from tensorflowasr_amd.models import Translator
