@@ -179,7 +179,7 @@ FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vecto
 // Slab ring of gemm_ring.hip: [N / 128 chunks][K / 32 steps][8 column tiles][3 terms][64 lanes][8 bf16]; a GLU layer's
 // chunk holds four value tiles and the four gate tiles that go with them.
 void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int N, bool glu) {
-  if (K % 64 != 0 || N % (glu ? 128 * 2 : 128) != 0) return;
+  if (K % 128 != 0 || N % (glu ? 128 * 2 : 128) != 0) return;
   const std::vector<float> sp = pack_split32(f, K, N);       // [step][NT][3 terms][64 lanes][8 bf16]
   constexpr size_t TILE = 3 * 64 * 8 / 2;                     // floats per (step, column tile)
   const int steps = K / 32, NT = N / 16, chunks = NT / 8, half = NT / 2;

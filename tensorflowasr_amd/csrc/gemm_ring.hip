@@ -1,6 +1,6 @@
 // One dense layer on the bf16 matrix pipe with exactly split operands, for dmodel 256 / 512 and long batches
 // (ConformerM / ConformerL, conformerM.yml / conformerL.yml):
-//     Y[M, N] = epilogue( LN?(X)[M, K] . W[K, N] + b ),   K a multiple of 64, N a multiple of 128,
+//     Y[M, N] = epilogue( LN?(X)[M, K] . W[K, N] + b ),   K a multiple of 128, N a multiple of 128,
 // the Gemm16Args contract of bf16.hip (same epilogues, same call sites in run_block) with fp32 results: every fp32
 // operand is the exact sum of three bf16 terms and the six term pairs with i + j <= 2 go through
 // v_mfma_f32_16x16x32_bf16, smallest first (subconv.hip / leaf.hip: as accurate as an fp32 FMA chain, 6 x 16 cycles
@@ -10,13 +10,15 @@
 //   * workgroup = 8 waves x RT row tiles of 16 tokens (256 or 128 tokens) x one chunk of 8 column tiles (128 columns;
 //     for GLU: 4 value + 4 gate tiles); grid (ceil(M / tokens), N / 128);
 //   * per 32-wide k-step a 24 KB weight slab [8 tiles][3 terms][64 lanes][8 bf16] goes global -> LDS directly
-//     (global_load_lds_dwordx4) into the other half of a double buffer while the MFMAs of the step run; the eight waves
-//     share it (48 or 96 MFMAs per wave and slab);
-//   * the X operand: lane (token c, group g) loads x[token][32 s + 4 g .. + 3] and [32 s + 16 + 4 g .. + 3] two steps
-//     ahead, applies the prologue LayerNorm (statistics from a two-pass prologue, gamma / beta in LDS) and splits into
-//     three bf16x8 terms -- by the lower waves before the MFMAs of the step, by the upper waves (their SIMD partners)
-//     for the next step after them, so one wave's VALU phase faces the other's MFMAs;
-//   * the slab wait is a counted vmcnt: the X loads issued after the slab DMA may stay in flight across the barrier.
+//     (global_load_lds_dwordx4) into a four-slot ring, three steps ahead of its use; the eight waves share it (48 or 96
+//     MFMAs per wave and slab);
+//   * the X operand: lane (token c, group g) loads x[token][32 s + 4 g .. + 3] and [32 s + 16 + 4 g .. + 3] four steps
+//     ahead (two with two row tiles per wave: registers; a first version with one slab and two operand steps in flight ran at the memory latency: 2 us per step),
+//     applies the prologue LayerNorm (two-pass statistics, gamma / beta in LDS) and splits into three bf16x8 terms --
+//     by the lower waves before the MFMAs of the step, by the upper waves (their SIMD partners) for the next step after
+//     them, so one wave's VALU phase faces the other's MFMAs;
+//   * the wait before a step's barrier is a counted vmcnt: everything issued after the slab of the NEXT step -- two
+//     more slabs and the operand loads of three iterations -- stays in flight across the barrier.
 // X is re-read and re-split per column chunk (N / 128 times); at 48-96 MFMAs per ~60 VALU instructions of split that
 // is hidden, and the re-reads come from L2.
 #include <cstdlib>
@@ -31,6 +33,7 @@ constexpr int GW = 8, GT = GW * 64;               // waves / threads per workgro
 constexpr int GNB = 8;                            // column tiles per workgroup
 constexpr int GSLAB = GNB * 3 * 64;               // 16-byte fragments per k-step (24 KB)
 constexpr int GLN_MAX = 512;                      // widest prologue LayerNorm (dmodel)
+constexpr int GUNR = 4;                           // unroll of the step loop (slab slots and operand stages divide it)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -38,6 +41,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 DEV void dma16(const u32x4* gsrc, u32x4* lds) {   // 16 bytes per lane, global -> LDS; lane i lands at lds + 16 i
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int OFF>
+DEV u32x4 lds_read16(unsigned addr) {             // not visible to the compiler as an LDS access: see mfma_step
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
 }
 
 struct Frag { u32x4 t[3]; };                      // 8 k-slots x 3 terms
@@ -65,10 +75,12 @@ DEV Frag split8(f32x4 lo, f32x4 hi) {
 
 struct XRegs { f32x4 lo, hi; };                   // one lane's eight operand values of one k-step, before LN / split
 
-template <int EPI, bool LN, int RT>
+template <int EPI, bool LN, int RT, int RING>
 __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u32x4* __restrict__ wring) {
-  __shared__ __attribute__((aligned(16))) u32x4 wl[2][GSLAB];
-  __shared__ __attribute__((aligned(16))) float p_g[LN ? GLN_MAX : 4], p_b[LN ? GLN_MAX : 4];
+  __shared__ __attribute__((aligned(16))) u32x4 wl[RING][GSLAB];
+  __shared__ __attribute__((aligned(16))) float p_gb[2 * (LN ? GLN_MAX : 4)];   // LayerNorm gamma, then beta
+  float* const p_g = p_gb;
+  float* const p_b = p_gb + (LN ? GLN_MAX : 4);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g4 = (lane >> 4) * 4, c = lane & 15;
   const int r0 = blockIdx.x * (GW * 16 * RT);
@@ -78,9 +90,12 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   constexpr int NQ = GSLAB / GT;                  // 3 DMA instructions per wave and slab
   const int wv = __builtin_amdgcn_readfirstlane(wave);
 
-  // slab 0
+  // the first RING - 1 slabs
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) dma16(wg + GT * q + 64 * wv + lane, &wl[0][GT * q + 64 * wv]);
+  for (int st = 0; st < RING - 1; ++st)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      dma16(wg + (size_t)min(st, steps - 1) * GSLAB + GT * q + 64 * wv + lane, &wl[st][GT * q + 64 * wv]);
   if (LN) {
     for (int i = threadIdx.x; i < a.K; i += GT) { p_g[i] = a.ln_g[i]; p_b[i] = a.ln_b[i]; }
   }
@@ -97,35 +112,96 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
                         : a.x + (size_t)rowi * a.ldx) + g4;
     mean[rt] = 0.f;
     rstd[rt] = 1.f;
-    if (LN) {                                     // two-pass statistics, biased variance, eps inside the sqrt (Keras)
-      float s = 0.f;
-      for (int st = 0; st < steps; ++st) {
-        const f32x4 u = ldg4(xr[rt] + 32 * st), v = ldg4(xr[rt] + 32 * st + 16);
-        s += ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
+  }
+  if (LN) {
+    // two-pass statistics (biased variance, eps inside the sqrt: Keras).  dmodel 256: the whole row of every row tile
+    // is requested at once and both passes run from registers (one memory round trip before the first step instead
+    // of one per pass and row tile); wider rows: eight steps in flight at a time, the second pass reloads (L2).
+    if (steps == 8) {
+      f32x4 u[RT][8], v[RT][8];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { u[rt][i] = ldg4(xr[rt] + 32 * i); v[rt][i] = ldg4(xr[rt] + 32 * i + 16); }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sm += ((u[rt][i].x + u[rt][i].y) + (u[rt][i].z + u[rt][i].w)) + ((v[rt][i].x + v[rt][i].y) + (v[rt][i].z + v[rt][i].w));
+        mean[rt] = group_sum(sm) / (float)a.K;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 du = u[rt][i] - splat4(mean[rt]), dv = v[rt][i] - splat4(mean[rt]);
+          q += ((du.x * du.x + du.y * du.y) + (du.z * du.z + du.w * du.w)) + ((dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w));
+        }
+        rstd[rt] = 1.0f / sqrtf(group_sum(q) / (float)a.K + a.eps);
       }
-      mean[rt] = group_sum(s) / (float)a.K;
-      float q = 0.f;
-      for (int st = 0; st < steps; ++st) {
-        const f32x4 u = ldg4(xr[rt] + 32 * st) - splat4(mean[rt]), v = ldg4(xr[rt] + 32 * st + 16) - splat4(mean[rt]);
-        q += ((u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w)) + ((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float sm = 0.f;
+        for (int st0 = 0; st0 < steps; st0 += 8) {
+          f32x4 u[8], v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { u[i] = ldg4(xr[rt] + 32 * (st0 + i)); v[i] = ldg4(xr[rt] + 32 * (st0 + i) + 16); }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sm += ((u[i].x + u[i].y) + (u[i].z + u[i].w)) + ((v[i].x + v[i].y) + (v[i].z + v[i].w));
+        }
+        mean[rt] = group_sum(sm) / (float)a.K;
+        float q = 0.f;
+        for (int st0 = 0; st0 < steps; st0 += 8) {
+          f32x4 u[8], v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { u[i] = ldg4(xr[rt] + 32 * (st0 + i)); v[i] = ldg4(xr[rt] + 32 * (st0 + i) + 16); }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const f32x4 du = u[i] - splat4(mean[rt]), dv = v[i] - splat4(mean[rt]);
+            q += ((du.x * du.x + du.y * du.y) + (du.z * du.z + du.w * du.w)) + ((dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w));
+          }
+        }
+        rstd[rt] = 1.0f / sqrtf(group_sum(q) / (float)a.K + a.eps);
       }
-      rstd[rt] = 1.0f / sqrtf(group_sum(q) / (float)a.K + a.eps);
     }
   }
+  // The operand loads of the step loop are inline asm as well, with a counted vmcnt before their use: hipcc's own wait
+  // there was vmcnt(0) (everything in flight, the slab just requested included).
   auto xload = [&](int st, XRegs (&x)[RT]) {
     const int sc = min(st, steps - 1);
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { x[rt].lo = ldg4(xr[rt] + 32 * sc); x[rt].hi = ldg4(xr[rt] + 32 * sc + 16); }
+    for (int rt = 0; rt < RT; ++rt) {
+      const float* p = xr[rt] + 32 * sc;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[rt].lo) : "v"(p));
+      asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(x[rt].hi) : "v"(p));
+    }
   };
+  // waits until the loads of stage `x` have landed: N = VMEM operations issued after them
+  auto xwait = [&](XRegs (&x)[RT], auto N_T) {
+    constexpr int N = decltype(N_T)::value;
+    if constexpr (RT == 2)
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x[0].lo), "+v"(x[0].hi), "+v"(x[1].lo), "+v"(x[1].hi) : "n"(N));
+    else
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0].lo), "+v"(x[0].hi) : "n"(N));
+  };
+  // gamma / beta of the prologue LayerNorm come from LDS through the same inline-asm reads as the weight fragments (a
+  // compiler-visible LDS read would again cost a vmcnt(0) while slabs are in flight)
+  const unsigned ln_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(p_g + g4);
+  constexpr unsigned LN_B = sizeof(float) * (LN ? GLN_MAX : 4);      // p_b follows p_g
   auto xsplit = [&](int st, const XRegs (&x)[RT], Frag (&f)[RT]) {
     const int sc = min(st, steps - 1);
+    u32x4 gl = {}, gh = {}, bl = {}, bh = {};
+    if (LN) {
+      const unsigned at = ln_base + 128u * (unsigned)sc;
+      gl = lds_read16<0>(at); gh = lds_read16<64>(at); bl = lds_read16<LN_B>(at); bh = lds_read16<LN_B + 64>(at);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gl), "+v"(gh), "+v"(bl), "+v"(bh));
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       f32x4 lo = x[rt].lo, hi = x[rt].hi;
       if (LN) {
         const f32x4 m = splat4(mean[rt]), r = splat4(rstd[rt]);
-        lo = (lo - m) * r * *reinterpret_cast<const f32x4*>(p_g + 32 * sc + g4) + *reinterpret_cast<const f32x4*>(p_b + 32 * sc + g4);
-        hi = (hi - m) * r * *reinterpret_cast<const f32x4*>(p_g + 32 * sc + 16 + g4) + *reinterpret_cast<const f32x4*>(p_b + 32 * sc + 16 + g4);
+        lo = (lo - m) * r * __builtin_bit_cast(f32x4, gl) + __builtin_bit_cast(f32x4, bl);
+        hi = (hi - m) * r * __builtin_bit_cast(f32x4, gh) + __builtin_bit_cast(f32x4, bh);
       }
       f[rt] = split8(lo, hi);
     }
@@ -137,70 +213,110 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
 #pragma unroll
     for (int n = 0; n < GNB; ++n) acc[rt][n] = splat4(0.f);
 
-  XRegs xq[2][RT];
+  // operand register stages: four steps ahead with one row tile, two with two (256 registers)
+  constexpr int XST = (RT == 1 && RING == 4) ? GUNR : 2;
+  XRegs xq[XST][RT];
   Frag xa[RT];
-  xload(0, xq[0]);
-  xload(1, xq[1]);
-  __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0): slab 0 (and the first operands)
+#pragma unroll
+  for (int st = 0; st < XST; ++st) xload(st, xq[st]);
+  __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0): the first slabs and operands
   __syncthreads();
 
-  auto mfma_step = [&](int cur) {
-    bf16x8 wf[3];
-#pragma unroll
-    for (int n = 0; n < GNB; ++n) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) wf[t] = __builtin_bit_cast(bf16x8, wl[cur][(n * 3 + t) * 64 + lane]);
-#pragma unroll
-      for (int ord = 2; ord >= 0; --ord)
-#pragma unroll
-        for (int p = 0; p <= ord; ++p)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ord - p], __builtin_bit_cast(bf16x8, xa[rt].t[p]),
-                                                                 acc[rt][n], 0, 0, 0);
-    }
+  // The weight fragments are read with inline-asm ds_read_b128 and counted lgkmcnt waits: a compiler-visible LDS read of
+  // the ring makes hipcc wait for vmcnt(0) first -- it cannot tell the slot being read from the slots the LDS-DMA in
+  // flight is writing -- which put the whole DMA latency into every step (the first version of this kernel: 23 % MFMA
+  // busy).  Two column tiles at a time (six MFMAs in a row on one accumulator would each wait for the one before), the
+  // next pair requested before the MFMAs of the current one; LDS returns in order, so lgkmcnt(6) = "all but the six
+  // newest reads".
+  auto mfma_step = [&](int slot) {
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&wl[slot][lane]);
+    u32x4 wa[2][3], wb[2][3];
+#define RING_FETCH(W, PAIR) \
+    W[0][0] = lds_read16<((2 * (PAIR) + 0) * 3 + 0) * 1024>(base); W[0][1] = lds_read16<((2 * (PAIR) + 0) * 3 + 1) * 1024>(base); \
+    W[0][2] = lds_read16<((2 * (PAIR) + 0) * 3 + 2) * 1024>(base); W[1][0] = lds_read16<((2 * (PAIR) + 1) * 3 + 0) * 1024>(base); \
+    W[1][1] = lds_read16<((2 * (PAIR) + 1) * 3 + 1) * 1024>(base); W[1][2] = lds_read16<((2 * (PAIR) + 1) * 3 + 2) * 1024>(base);
+#define RING_WAIT(W, N) \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(W[0][0]), "+v"(W[0][1]), "+v"(W[0][2]), "+v"(W[1][0]), "+v"(W[1][1]), "+v"(W[1][2]))
+#define RING_MMA(W, PAIR) \
+    _Pragma("unroll") for (int ord = 2; ord >= 0; --ord) \
+      _Pragma("unroll") for (int p = 0; p <= ord; ++p) \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) \
+          _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) \
+            acc[rt][2 * (PAIR) + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[h][ord - p]), \
+                __builtin_bit_cast(bf16x8, xa[rt].t[p]), acc[rt][2 * (PAIR) + h], 0, 0, 0);
+    RING_FETCH(wa, 0)
+    RING_FETCH(wb, 1)
+    RING_WAIT(wa, 6);
+    RING_MMA(wa, 0)
+    RING_FETCH(wa, 2)
+    RING_WAIT(wb, 6);
+    RING_MMA(wb, 1)
+    RING_FETCH(wb, 3)
+    RING_WAIT(wa, 6);
+    RING_MMA(wa, 2)
+    RING_WAIT(wb, 0);
+    RING_MMA(wb, 3)
+#undef RING_FETCH
+#undef RING_WAIT
+#undef RING_MMA
   };
-  auto slab_dma = [&](int st, int buf) {          // slab `st` into wl[buf] (read last in step st - 2, two barriers ago)
+  auto slab_dma = [&](int st, int slot) {         // slab `st` into a slot last read in step st - RING
     const u32x4* src = wg + (size_t)min(st, steps - 1) * GSLAB;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) dma16(src + GT * q + 64 * wv + lane, &wl[buf][GT * q + 64 * wv]);
+    for (int q = 0; q < NQ; ++q) dma16(src + GT * q + 64 * wv + lane, &wl[slot][GT * q + 64 * wv]);
   };
-  // one k-step; PAR = its parity (slab buffer, operand register stage), LATE = this wave splits after its MFMAs
-  auto step = [&](int s, auto PAR_T, auto LATE_T) {
-    constexpr int PAR = decltype(PAR_T)::value;
+  // one k-step; SL = s mod GUNR (slab slot SL % RING, operand stage SL % XST), LATE = this wave splits after its MFMAs
+  auto step = [&](int s, auto SL_T, auto LATE_T) {
+    constexpr int SL = decltype(SL_T)::value, NX = (SL + 1) % GUNR, PV = (SL + GUNR - 1) % GUNR;
     constexpr bool LATE = decltype(LATE_T)::value;
-    slab_dma(s + 1, PAR ^ 1);
+    slab_dma(s + RING - 1, PV % RING);            // the slot of step s - 1: every wave is past that step's barrier
     __builtin_amdgcn_sched_barrier(0);
+    // operand loads of a stage are followed by XST - 1 whole iterations (3 slab pieces + 2 RT loads) and this one's slab
+    constexpr int XAFTER = (XST - 1) * (3 + 2 * RT) + 3;
     if constexpr (!LATE) {
-      xsplit(s, xq[PAR], xa);
-      xload(s + 2, xq[PAR]);
+      xwait(xq[SL % XST], std::integral_constant<int, XAFTER>{});
+      xsplit(s, xq[SL % XST], xa);
+      xload(s + XST, xq[SL % XST]);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_step(PAR);
+      mfma_step(SL % RING);
     } else {
-      mfma_step(PAR);
+      mfma_step(SL % RING);
       __builtin_amdgcn_sched_barrier(0);
-      xsplit(s + 1, xq[PAR ^ 1], xa);
-      xload(s + 3, xq[PAR ^ 1]);
+      xwait(xq[NX % XST], std::integral_constant<int, XAFTER>{});
+      xsplit(s + 1, xq[NX % XST], xa);
+      xload(s + 1 + XST, xq[NX % XST]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // the 2 RT operand loads issued after the slab DMA may still be in flight: vmcnt(2 RT)
-    if constexpr (RT == 2) __builtin_amdgcn_s_waitcnt(0x0f74); else __builtin_amdgcn_s_waitcnt(0x0f72);
-    __syncthreads();
+    // slab s + 1 was issued RING - 2 iterations ago; what was issued after it -- the operand loads of that iteration and
+    // everything of the iterations since (3 slab pieces + 2 RT operand loads each) -- may stay in flight
+    constexpr int INFLIGHT = 2 * RT + (RING - 2) * (3 + 2 * RT);
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (INFLIGHT & 15) | ((INFLIGHT >> 4) << 14));
+    // a bare s_barrier: __syncthreads() carries a workgroup fence, for which hipcc waits for vmcnt(0) -- every slab and
+    // operand load in flight.  What must be visible after this barrier is the slab of step s + 1 (waited for above by
+    // each wave for its own pieces); the fragment reads of this step's slot are complete (lgkmcnt(0) before the last MFMAs)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto run = [&](auto LATE_T) {
     constexpr bool LATE = decltype(LATE_T)::value;
     if constexpr (LATE) {
       xsplit(0, xq[0], xa);
-      xload(2, xq[0]);
+      xload(XST, xq[0]);
     }
 #pragma unroll 1
-    for (int s = 0; s < steps; s += 2) {
+    for (int s = 0; s < steps; s += GUNR) {
       step(s, std::integral_constant<int, 0>{}, LATE_T);
       step(s + 1, std::integral_constant<int, 1>{}, LATE_T);
+      step(s + 2, std::integral_constant<int, 2>{}, LATE_T);
+      step(s + 3, std::integral_constant<int, 3>{}, LATE_T);
     }
   };
   if (wv >= GW / 2) run(std::integral_constant<bool, true>{});
   else run(std::integral_constant<bool, false>{});
+  // the last iterations requested operands nobody uses (clamped to the last step); hipcc does not know that those
+  // registers are still being written: keep them until the loads have landed
+#pragma unroll
+  for (int st = 0; st < XST; ++st) xwait(xq[st], std::integral_constant<int, 0>{});
 
   // ---- epilogue: lane holds Y[token c of row tile rt][feature 16 * tile + g4 + 0..3]
   const int half = a.NT / 2;
@@ -259,12 +375,18 @@ __global__ __launch_bounds__(256) void ring_layernorm_rows_kernel(float* y, cons
 template <int EPI, bool LN>
 int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   const int chunks = (EPI == E16_GLU ? a.NT / 2 : a.NT) / (EPI == E16_GLU ? GNB / 2 : GNB);
-  // two row tiles per wave when that still gives every CU a workgroup (MI355ASR_RING_RT=1 / 2 forces one shape: tests)
+  // two row tiles per wave when that still gives every CU a workgroup (MI355ASR_RING_RT=1 / 2 forces one shape: tests).
+  // One row tile: a two-slot ring (49 KB: up to three workgroups per CU) when there are workgroups to share a CU, else
+  // four slots (three slabs in flight).
   static const int force_rt = [] { const char* v = getenv("MI355ASR_RING_RT"); return v ? atoi(v) : 0; }();
-  if (force_rt == 2 || (force_rt != 1 && (size_t)((a.M + 255) / 256) * chunks >= 256))
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2>), dim3((a.M + 255) / 256, chunks), dim3(GT), 0, s, a, (const u32x4*)ring);
+  static const int force_slots = [] { const char* v = getenv("MI355ASR_RING_SLOTS"); return v ? atoi(v) : 0; }();
+  const size_t wg2 = (size_t)((a.M + 255) / 256) * chunks, wg1 = (size_t)((a.M + 127) / 128) * chunks;
+  if (force_rt == 2 || (force_rt != 1 && force_slots != 2 && wg2 >= 256))
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4>), dim3((a.M + 255) / 256, chunks), dim3(GT), 0, s, a, (const u32x4*)ring);
+  else if (force_slots == 2 || (force_slots != 4 && wg1 > 320))
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 2>), dim3((a.M + 127) / 128, chunks), dim3(GT), 0, s, a, (const u32x4*)ring);
   else
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1>), dim3((a.M + 127) / 128, chunks), dim3(GT), 0, s, a, (const u32x4*)ring);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 4>), dim3((a.M + 127) / 128, chunks), dim3(GT), 0, s, a, (const u32x4*)ring);
   return 0;
 }
 
@@ -273,7 +395,7 @@ int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
 // Shapes the ring kernel takes; the pack (api.hip: pack_ring) exists for the dense layers of dmodel 256 / 512 blocks.
 bool gemm_ring_applicable(int epi, bool ln, const Gemm16Args& a) {
   const int ntc = epi == E16_GLU ? a.NT / 2 : a.NT;
-  if (a.K % 64 != 0 || a.K < 64 || ntc % (epi == E16_GLU ? 4 : 8) != 0 || a.n_valid != (epi == E16_GLU ? 16 * ntc : 16 * a.NT)) return false;
+  if (a.K % 128 != 0 || a.K < 128 || ntc % (epi == E16_GLU ? 4 : 8) != 0 || a.n_valid != (epi == E16_GLU ? 16 * ntc : 16 * a.NT)) return false;
   if (ln && a.K > GLN_MAX) return false;
   if ((a.ldx & 3) != 0 || (a.ldy & 3) != 0 || !a.y) return false;
   switch (epi) {

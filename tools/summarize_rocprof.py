@@ -38,6 +38,10 @@ def category(name):
     args = [a.strip() for a in name[name.index("<") + 1:name.index(">")].split(",")]
     if "chain2_kernel" in name:
         return "ffn" if args[-1] == "0" else "conv_tail"
+    if "gemm_ring_kernel" in name:      # <epilogue, LN, row tiles, ring slots>
+        return "gemm_ring<" + ",".join(args[:4]) + ">"
+    if "subconv_split_ring_kernel" in name:
+        return "subconv" if args[1] == "144" else "subconv" + args[1]
     if "gemm_rows_kernel" in name:
         return {"0": "ctc_project", "1": "attn_out", "2": "qkv", "3": "pw1_glu", "4": "ctc_head"}[args[3]]
     return name
