@@ -21,6 +21,7 @@
 //     more slabs and the operand loads of three iterations -- stays in flight across the barrier.
 // X is re-read and re-split per column chunk (N / 128 times); at 48-96 MFMAs per ~60 VALU instructions of split that
 // is hidden, and the re-reads come from L2.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -76,7 +77,7 @@ DEV Frag split8(f32x4 lo, f32x4 hi) {
 struct XRegs { f32x4 lo, hi; };                   // one lane's eight operand values of one k-step, before LN / split
 
 template <int EPI, bool LN, int RT, int RING>
-__global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u32x4* __restrict__ wring) {
+__global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u32x4* __restrict__ wring, int cpw) {
   __shared__ __attribute__((aligned(16))) u32x4 wl[RING][GSLAB];
   __shared__ __attribute__((aligned(16))) float p_gb[2 * (LN ? GLN_MAX : 4)];   // LayerNorm gamma, then beta
   float* const p_g = p_gb;
@@ -84,9 +85,11 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g4 = (lane >> 4) * 4, c = lane & 15;
   const int r0 = blockIdx.x * (GW * 16 * RT);
-  const int chunk = blockIdx.y;
-  const int steps = a.K / 32;
-  const u32x4* __restrict__ wg = wring + (size_t)chunk * steps * GSLAB;
+  // this workgroup's column chunks chunk0 .. chunk0 + cpw - 1, one after the other on the same rows: their slabs are
+  // one contiguous stream (the ring keeps running across the chunk boundary) and the prologue is paid once
+  const int chunk0 = blockIdx.y * cpw;
+  const int steps = a.K / 32, total = cpw * steps;
+  const u32x4* __restrict__ wg = wring + (size_t)chunk0 * steps * GSLAB;
   constexpr int NQ = GSLAB / GT;                  // 3 DMA instructions per wave and slab
   const int wv = __builtin_amdgcn_readfirstlane(wave);
 
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   for (int st = 0; st < RING - 1; ++st)
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-      dma16(wg + (size_t)min(st, steps - 1) * GSLAB + GT * q + 64 * wv + lane, &wl[st][GT * q + 64 * wv]);
+      dma16(wg + (size_t)min(st, total - 1) * GSLAB + GT * q + 64 * wv + lane, &wl[st][GT * q + 64 * wv]);
   if (LN) {
     for (int i = threadIdx.x; i < a.K; i += GT) { p_g[i] = a.ln_g[i]; p_b[i] = a.ln_b[i]; }
   }
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   }
   // The operand loads of the step loop are inline asm as well, with a counted vmcnt before their use: hipcc's own wait
   // there was vmcnt(0) (everything in flight, the slab just requested included).
-  auto xload = [&](int st, XRegs (&x)[RT]) {
-    const int sc = min(st, steps - 1);
+  auto xload = [&](int st, XRegs (&x)[RT]) {   // st < 2 steps: the operand steps wrap into the next column chunk
+    const int sc = st >= steps ? st - steps : st;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const float* p = xr[rt] + 32 * sc;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   const unsigned ln_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(p_g + g4);
   constexpr unsigned LN_B = sizeof(float) * (LN ? GLN_MAX : 4);      // p_b follows p_g
   auto xsplit = [&](int st, const XRegs (&x)[RT], Frag (&f)[RT]) {
-    const int sc = min(st, steps - 1);
+    const int sc = st >= steps ? st - steps : st;
     u32x4 gl = {}, gh = {}, bl = {}, bh = {};
     if (LN) {
       const unsigned at = ln_base + 128u * (unsigned)sc;
@@ -261,15 +264,15 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
 #undef RING_MMA
   };
   auto slab_dma = [&](int st, int slot) {         // slab `st` into a slot last read in step st - RING
-    const u32x4* src = wg + (size_t)min(st, steps - 1) * GSLAB;
+    const u32x4* src = wg + (size_t)min(st, total - 1) * GSLAB;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) dma16(src + GT * q + 64 * wv + lane, &wl[slot][GT * q + 64 * wv]);
   };
   // one k-step; SL = s mod GUNR (slab slot SL % RING, operand stage SL % XST), LATE = this wave splits after its MFMAs
-  auto step = [&](int s, auto SL_T, auto LATE_T) {
+  auto step = [&](int s, int gs, auto SL_T, auto LATE_T) {     // s: step within the chunk, gs: within the slab stream
     constexpr int SL = decltype(SL_T)::value, NX = (SL + 1) % GUNR, PV = (SL + GUNR - 1) % GUNR;
     constexpr bool LATE = decltype(LATE_T)::value;
-    slab_dma(s + RING - 1, PV % RING);            // the slot of step s - 1: every wave is past that step's barrier
+    slab_dma(gs + RING - 1, PV % RING);           // the slot of step gs - 1: every wave is past that step's barrier
     __builtin_amdgcn_sched_barrier(0);
     // operand loads of a stage are followed by XST - 1 whole iterations (3 slab pieces + 2 RT loads) and this one's slab
     constexpr int XAFTER = (XST - 1) * (3 + 2 * RT) + 3;
@@ -297,6 +300,49 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+  // ---- epilogue of one column chunk: lane holds Y[token c of row tile rt][feature 16 * tile + g4 + 0..3]
+  const int half = a.NT / 2;
+  auto epilogue = [&](int chunk) {
+    float* yrow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) yrow[rt] = a.y + (size_t)tok[rt] * a.ldy;
+    if constexpr (EPI == E16_GLU) {
+#pragma unroll
+      for (int i = 0; i < GNB / 2; ++i) {
+        const int f0 = 16 * (chunk * (GNB / 2) + i) + g4;
+        const f32x4 ba = ldg4(a.bias + f0), bb = ldg4(a.bias + 16 * half + f0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const f32x4 va = acc[rt][i] + ba, vb = acc[rt][GNB / 2 + i] + bb;
+          const f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
+          if (live[rt]) stg4(yrow[rt] + f0, o);
+        }
+        if (i & 1) __builtin_amdgcn_sched_barrier(0);     // two tiles' parameters in registers at a time, not all eight
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < GNB; ++i) {
+        const int tile = chunk * GNB + i, f0 = 16 * tile + g4;
+        const f32x4 bv = ldg4(a.bias + f0);
+        f32x4 as = splat4(1.f), at = splat4(0.f);
+        if constexpr (EPI == E16_AFFSWISH) { as = ldg4(a.aff_s + f0); at = ldg4(a.aff_t + f0); }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          f32x4 v = acc[rt][i] + bv;
+          if constexpr (EPI == E16_SWISH) v = swish4(v);
+          if constexpr (EPI == E16_AFFSWISH) v = swish4(v * as + at);
+          if constexpr (EPI == E16_QKV) { if (tile < a.qtiles) v *= splat4(a.qscale); }
+          if constexpr (EPI == E16_RES) v = ldg4(a.res + (size_t)min(tok[rt], a.M - 1) * a.ldy + f0) + splat4(a.scale) * v;
+          if (live[rt]) stg4(yrow[rt] + f0, v);
+        }
+        if (i & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int n = 0; n < GNB; ++n) acc[rt][n] = splat4(0.f);
+  };
   auto run = [&](auto LATE_T) {
     constexpr bool LATE = decltype(LATE_T)::value;
     if constexpr (LATE) {
@@ -304,47 +350,30 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
       xload(XST, xq[0]);
     }
 #pragma unroll 1
-    for (int s = 0; s < steps; s += GUNR) {
-      step(s, std::integral_constant<int, 0>{}, LATE_T);
-      step(s + 1, std::integral_constant<int, 1>{}, LATE_T);
-      step(s + 2, std::integral_constant<int, 2>{}, LATE_T);
-      step(s + 3, std::integral_constant<int, 3>{}, LATE_T);
+    for (int cc = 0; cc < cpw; ++cc) {
+      const int g0 = cc * steps;
+#pragma unroll 1
+      for (int s = 0; s < steps; s += GUNR) {
+        step(s, g0 + s, std::integral_constant<int, 0>{}, LATE_T);
+        step(s + 1, g0 + s + 1, std::integral_constant<int, 1>{}, LATE_T);
+        step(s + 2, g0 + s + 2, std::integral_constant<int, 2>{}, LATE_T);
+        step(s + 3, g0 + s + 3, std::integral_constant<int, 3>{}, LATE_T);
+      }
+      // The epilogue's loads and stores are VMEM operations the counted waits of the step loop do not know about: they
+      // sit between the operand loads already in flight and the next slab pieces, so every count stays an upper bound
+      // of what may be outstanding only if they are complete before the next step starts.
+      epilogue(chunk0 + cc);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   if (wv >= GW / 2) run(std::integral_constant<bool, true>{});
   else run(std::integral_constant<bool, false>{});
-  // the last iterations requested operands nobody uses (clamped to the last step); hipcc does not know that those
-  // registers are still being written: keep them until the loads have landed
+  // the last iterations requested operands nobody uses; hipcc does not know that those registers are still being
+  // written: keep them until the loads have landed
 #pragma unroll
   for (int st = 0; st < XST; ++st) xwait(xq[st], std::integral_constant<int, 0>{});
-
-  // ---- epilogue: lane holds Y[token c of row tile rt][feature 16 * tile + g4 + 0..3]
-  const int half = a.NT / 2;
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    if (!live[rt]) continue;
-    float* yrow = a.y + (size_t)tok[rt] * a.ldy;
-    if constexpr (EPI == E16_GLU) {
-#pragma unroll
-      for (int i = 0; i < GNB / 2; ++i) {
-        const int f0 = 16 * (chunk * (GNB / 2) + i) + g4;
-        const f32x4 va = acc[rt][i] + ldg4(a.bias + f0), vb = acc[rt][GNB / 2 + i] + ldg4(a.bias + 16 * half + f0);
-        const f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
-        stg4(yrow + f0, o);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < GNB; ++i) {
-        const int tile = chunk * GNB + i, f0 = 16 * tile + g4;
-        f32x4 v = acc[rt][i] + ldg4(a.bias + f0);
-        if constexpr (EPI == E16_SWISH) v = swish4(v);
-        if constexpr (EPI == E16_AFFSWISH) v = swish4(v * ldg4(a.aff_s + f0) + ldg4(a.aff_t + f0));
-        if constexpr (EPI == E16_QKV) { if (tile < a.qtiles) v *= splat4(a.qscale); }
-        if constexpr (EPI == E16_RES) v = ldg4(a.res + (size_t)tok[rt] * a.ldy + f0) + splat4(a.scale) * v;
-        stg4(yrow + f0, v);
-      }
-    }
-  }
 }
 
 // y[row] = LayerNorm(y[row]) in place, one wave per row (two-pass statistics, Keras semantics): the block's final
@@ -375,18 +404,38 @@ __global__ __launch_bounds__(256) void ring_layernorm_rows_kernel(float* y, cons
 template <int EPI, bool LN>
 int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   const int chunks = (EPI == E16_GLU ? a.NT / 2 : a.NT) / (EPI == E16_GLU ? GNB / 2 : GNB);
-  // two row tiles per wave when that still gives every CU a workgroup (MI355ASR_RING_RT=1 / 2 forces one shape: tests).
-  // One row tile: a two-slot ring (49 KB: up to three workgroups per CU) when there are workgroups to share a CU, else
-  // four slots (three slabs in flight).
+  // Shape of the launch: RT row tiles per wave (256 or 128 rows per workgroup) and cpw column chunks per workgroup, so
+  // that the workgroups come as close as possible to a whole number of rounds over the 256 CUs (short K: every
+  // workgroup pays a prologue -- first slabs, LayerNorm statistics -- worth several k-steps, and a second, half-empty
+  // round costs as much as a full one); among equals the larger tile.  MI355ASR_RING_RT / _SLOTS / _CPW force one shape
+  // (tests).
   static const int force_rt = [] { const char* v = getenv("MI355ASR_RING_RT"); return v ? atoi(v) : 0; }();
   static const int force_slots = [] { const char* v = getenv("MI355ASR_RING_SLOTS"); return v ? atoi(v) : 0; }();
-  const size_t wg2 = (size_t)((a.M + 255) / 256) * chunks, wg1 = (size_t)((a.M + 127) / 128) * chunks;
-  if (force_rt == 2 || (force_rt != 1 && force_slots != 2 && wg2 >= 256))
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4>), dim3((a.M + 255) / 256, chunks), dim3(GT), 0, s, a, (const u32x4*)ring);
-  else if (force_slots == 2 || (force_slots != 4 && wg1 > 320))
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 2>), dim3((a.M + 127) / 128, chunks), dim3(GT), 0, s, a, (const u32x4*)ring);
+  static const int force_cpw = [] { const char* v = getenv("MI355ASR_RING_CPW"); return v ? atoi(v) : 0; }();
+  int best_rt = 1, best_cpw = 1;
+  double best = 1e30;
+  for (int rt = 2; rt >= 1; --rt) {
+    if (force_rt && rt != force_rt) continue;
+    const int rows = (a.M + 128 * rt - 1) / (128 * rt);
+    for (int cpw = chunks; cpw >= 1; --cpw) {
+      if (chunks % cpw != 0 || (force_cpw && cpw != std::min(force_cpw, chunks) && chunks % std::min(force_cpw, chunks) == 0)) continue;
+      const long wgs = (long)rows * (chunks / cpw);
+      const long rounds = (wgs + 255) / 256;
+      // time ~ rounds x (prologue worth ~6 steps + cpw x steps x rt), in units of one row-tile step
+      const double cost = (double)rounds * (6.0 + (double)cpw * (a.K / 32) * rt + 1.5 * cpw);
+      if (cost < best * 0.999) { best = cost; best_rt = rt; best_cpw = cpw; }
+    }
+  }
+  const int cpw = best_cpw;
+  const dim3 grid((a.M + 128 * best_rt - 1) / (128 * best_rt), chunks / cpw);
+  if (best_rt == 2 && force_slots != 2)
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
+  else if (best_rt == 2)
+    return -1;
+  else if (force_slots == 2 || (force_slots != 4 && (long)grid.x * grid.y > 320))
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 2>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
   else
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 4>), dim3((a.M + 127) / 128, chunks), dim3(GT), 0, s, a, (const u32x4*)ring);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 4>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
   return 0;
 }
 

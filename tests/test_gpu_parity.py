@@ -972,7 +972,7 @@ def test_conformer_m_and_l_parity(torch_cuda, base, L):
 def test_ring_gemm_path_of_m_and_l_in_a_subprocess(torch_cuda):
     """gemm_ring.hip (dense layers of dmodel 256 / 512 on the split-bf16 pipe, taken from 4096 rows on) forced for a small
     batch (MI355ASR_RING_MIN_M=1): encoder and CTC logits against the oracle for ConformerM and ConformerL, with one and
-    with two row tiles per wave (partial tiles in both), the two-slot ring of the one-tile shape, and the fp32 kernels it replaces (MI355ASR_GEMM_RING=0)."""
+    with two row tiles per wave (partial tiles in both), the two-slot ring of the one-tile shape, several column chunks per workgroup, and the fp32 kernels it replaces (MI355ASR_GEMM_RING=0)."""
     import subprocess
     import sys
     code = r'''
@@ -996,7 +996,9 @@ for base, L in ((co.CONFORMER_M, 32000), (co.CONFORMER_L, 24000)):
 print("RESULT " + " ".join("%.3e" % v for v in res))
 '''
     for extra in ({"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_RT": "1"}, {"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_RT": "2"},
-                  {"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_SLOTS": "2"}, {"MI355ASR_GEMM_RING": "0"}):
+                  {"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_SLOTS": "2"},
+                  {"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_RT": "1", "MI355ASR_RING_CPW": "2"},
+                  {"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_RT": "2", "MI355ASR_RING_CPW": "8"}, {"MI355ASR_GEMM_RING": "0"}):
         env = dict(os.environ, **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900,
                              cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
