@@ -14,6 +14,8 @@
 //   softmax over keys              one pass: max, exp2 (log2 e folded into q), sum -- no running rescale
 //   O^T[feat][query] = V^T P^T     12 MFMAs per key tile; P^T is the S^T accumulator itself (same lane mapping)
 // The 48-wide feature padding of O (3 tiles for 36 features) is the only wasted matrix work.
+#include <cstdlib>
+
 #include "common.h"
 #include "launch.h"
 
@@ -180,13 +182,16 @@ __global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
 }  // namespace
 
 bool attention_lds_applicable(int HS, const AttnArgs& a) {
-  return HS == 36 && a.win_front < 0 && a.Tk <= TP && a.Tk > 16 && a.Tq > 16;
+  // head size 64 (ConformerM / L): K and V^T take 130 KB, one workgroup per CU.  MI355ASR_ATTN_LDS64=0: the L2-streaming kernel
+  static const bool lds64 = [] { const char* v = getenv("MI355ASR_ATTN_LDS64"); return v ? atoi(v) != 0 : true; }();
+  return (HS == 36 || (HS == 64 && lds64)) && a.win_front < 0 && a.Tk <= TP && a.Tk > 16 && a.Tq > 16;
 }
 
 int launch_attention_lds(int HS, const AttnArgs& a, hipStream_t s) {
   if (!attention_lds_applicable(HS, a)) return -1;
   const int qtiles = (a.Tq + 15) / 16;
   dim3 grid((qtiles + AW - 1) / AW, a.H, a.B);
-  hipLaunchKernelGGL((attention_lds_kernel<36>), grid, dim3(ATH), 0, s, a);
+  if (HS == 64) hipLaunchKernelGGL((attention_lds_kernel<64>), grid, dim3(ATH), 0, s, a);
+  else hipLaunchKernelGGL((attention_lds_kernel<36>), grid, dim3(ATH), 0, s, a);
   return 0;
 }

@@ -202,6 +202,16 @@ DEV void dma16(const u32x4* gsrc, u32x4* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+// A weight fragment from the LDS slab, as inline asm: a compiler-visible LDS read makes hipcc wait for vmcnt(0) first
+// whenever an LDS-DMA is in flight (it cannot tell the buffer being read from the one being written), which exposed the
+// latency of the next slab's DMA in every step.  Waits are counted by hand (LDS returns in order).
+template <int OFF>
+DEV u32x4 lds_read16(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
 struct SplitFrag { u32x4 t[3]; };                  // 8 k-slots x 3 terms
 
 // exact three-term bf16 split of eight fp32 values (slots 0..3 = lo, 4..7 = hi), two values per dword
@@ -369,16 +379,20 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
       constexpr int pair = decltype(PI)::value;
       const int s = cb * NPAIR + pair, cur = s & 1;
       const bool more = s + 1 < NK32;
-      if (more && DIAG != 3) {
-        // next slab: global -> LDS directly (global_load_lds_dwordx4: lane i of a wave lands at base + 16 i); buffer
-        // cur ^ 1 was last read in step s - 1, whose barrier every wave has passed
-        const u32x4* src = wg + (size_t)(s + 1) * SLABF;
+      // next slab: global -> LDS directly (global_load_lds_dwordx4: lane i of a wave lands at base + 16 i); buffer
+      // cur ^ 1 was last read in step s - 1, whose barrier every wave has passed.  Issued right before this wave's
+      // MFMAs: hipcc waits for vmcnt(0) in front of every LDS read it can see while a DMA is in flight (the conv1
+      // window reads), so no such read may follow the DMA closely.
+      auto slab_dma = [&]() {
+        if (more && DIAG != 3) {
+          const u32x4* src = wg + (size_t)(s + 1) * SLABF;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int w0 = SCT * q + 64 * wv;                    // wave-uniform
-          if (w0 < SLABF) dma16(src + w0 + lane, &wl[cur ^ 1][w0]);
+          for (int q = 0; q < NQ; ++q) {
+            const int w0 = SCT * q + 64 * wv;                    // wave-uniform
+            if (w0 < SLABF) dma16(src + w0 + lane, &wl[cur ^ 1][w0]);
+          }
         }
-      }
+      };
       // operand of the next step (VALU + LDS reads) and the MFMAs of this one are independent.  hipcc puts the ~270
       // VALU instructions in front of the 108 MFMAs, and an in-order wave cannot fill the matrix pipe's shadow that
       // way; since all waves meet at the barrier of every step the two waves of a SIMD would also be in the same phase.
@@ -397,32 +411,69 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
           frags_for<0, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cbn, g4));
         }
       };
+      // fragments of G column tiles at a time (one with nine tiles: registers; two with eight), the next group requested
+      // before the MFMAs of the current one; lgkmcnt(3 G) = "all but the newest group"
       auto mfma_cur = [&]() {
-        bf16x8 wf[3];
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          if (DIAG != 2 || n == 0) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t) wf[t] = __builtin_bit_cast(bf16x8, wl[cur][(n * 3 + t) * 64 + lane]);
-          }
+        constexpr int G = NB % 2 == 0 ? 2 : 1, NG = NB / G;
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&wl[cur][lane]);
+        u32x4 wa[G][3], wb[G][3];
+        auto fetch = [&](u32x4 (&w)[G][3], auto GI) {
+          constexpr int gi = decltype(GI)::value;
+          static_for<0, G>([&](auto HI) {
+            constexpr int h = decltype(HI)::value;
+            w[h][0] = lds_read16<((gi * G + h) * 3 + 0) * 1024>(base);
+            w[h][1] = lds_read16<((gi * G + h) * 3 + 1) * 1024>(base);
+            w[h][2] = lds_read16<((gi * G + h) * 3 + 2) * 1024>(base);
+          });
+        };
+        auto wait = [&](u32x4 (&w)[G][3], auto N_T) {
+          constexpr int N = decltype(N_T)::value;
+          if constexpr (G == 1)
+            asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]) : "n"(N));
+          else
+            asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[1][0]), "+v"(w[1][1]),
+                         "+v"(w[1][2]) : "n"(N));
+        };
+        auto mma = [&](const u32x4 (&w)[G][3], auto GI) {
+          constexpr int gi = decltype(GI)::value;
 #pragma unroll
           for (int ord = 2; ord >= 0; --ord)
 #pragma unroll
             for (int p = 0; p <= ord; ++p)
 #pragma unroll
-              for (int rt = 0; rt < SRT; ++rt)
-                acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ord - p], __builtin_bit_cast(bf16x8, xa[rt].t[p]),
-                                                                     acc[rt][n], 0, 0, 0);
-        }
+              for (int h = 0; h < G; ++h)
+#pragma unroll
+                for (int rt = 0; rt < SRT; ++rt)
+                  acc[rt][gi * G + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[h][ord - p]),
+                      __builtin_bit_cast(bf16x8, xa[rt].t[p]), acc[rt][gi * G + h], 0, 0, 0);
+        };
+        fetch(wa, std::integral_constant<int, 0>{});
+        static_for<0, NG>([&](auto GI) {
+          constexpr int gi = decltype(GI)::value;
+          if constexpr (gi % 2 == 0) {
+            if constexpr (gi + 1 < NG) { fetch(wb, std::integral_constant<int, gi + 1>{}); wait(wa, std::integral_constant<int, 3 * G>{}); }
+            else wait(wa, std::integral_constant<int, 0>{});
+            mma(wa, GI);
+          } else {
+            if constexpr (gi + 1 < NG) { fetch(wa, std::integral_constant<int, gi + 1>{}); wait(wb, std::integral_constant<int, 3 * G>{}); }
+            else wait(wb, std::integral_constant<int, 0>{});
+            mma(wb, GI);
+          }
+        });
       };
       if constexpr (DIAG == 1) {
+        slab_dma();
         mfma_cur();
       } else if constexpr (LATE) {
+        slab_dma();
+        __builtin_amdgcn_sched_barrier(0);
         mfma_cur();
         __builtin_amdgcn_sched_barrier(0);
         frags_next();
       } else {
         frags_this();
+        __builtin_amdgcn_sched_barrier(0);
+        slab_dma();
         __builtin_amdgcn_sched_barrier(0);
         mfma_cur();
       }
