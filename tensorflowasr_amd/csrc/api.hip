@@ -180,23 +180,26 @@ FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vecto
 // chunk holds four value tiles and the four gate tiles that go with them.
 void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int N, bool glu) {
   if (K % 128 != 0 || N % (glu ? 128 * 2 : 128) != 0) return;
+  const int terms = ab.ring_terms;
   const std::vector<float> sp = pack_split32(f, K, N);       // [step][NT][3 terms][64 lanes][8 bf16]
-  constexpr size_t TILE = 3 * 64 * 8 / 2;                     // floats per (step, column tile)
+  constexpr size_t TERM = 64 * 8 / 2;                         // floats per (step, column tile, term)
   const int steps = K / 32, NT = N / 16, chunks = NT / 8, half = NT / 2;
-  std::vector<float> ring((size_t)chunks * steps * 8 * TILE);
+  std::vector<float> ring((size_t)chunks * steps * 8 * terms * TERM);
   for (int ch = 0; ch < chunks; ++ch)
     for (int st = 0; st < steps; ++st)
       for (int i = 0; i < 8; ++i) {
         const int tile = glu ? (i < 4 ? 4 * ch + i : half + 4 * ch + (i - 4)) : 8 * ch + i;
-        std::memcpy(ring.data() + (((size_t)ch * steps + st) * 8 + i) * TILE, sp.data() + ((size_t)st * NT + tile) * TILE,
-                    TILE * sizeof(float));
+        // bf16 mode keeps term 0 only: round-to-nearest-even bf16 of the weight, what the bf16 arena holds as well
+        std::memcpy(ring.data() + (((size_t)ch * steps + st) * 8 + i) * terms * TERM, sp.data() + ((size_t)st * NT + tile) * 3 * TERM,
+                    terms * TERM * sizeof(float));
       }
   ab.ring_pairs.emplace_back(p16_off, ab.put(ring));
 }
-// MI355ASR_GEMM_RING=0: the dense layers of dmodel 256 / 512 stay on the fp32-MFMA kernels (chain2 / gemm16<PF32>)
+// MI355ASR_GEMM_RING=0: the dense layers of dmodel 256 / 512 stay on the fp32-MFMA kernels (chain2 / gemm16<PF32>), or
+// in bf16 mode on gemm16<PBf16>
 bool ring_packs_wanted(const mi355asr_model* m) {
   static const bool on = [] { const char* v = getenv("MI355ASR_GEMM_RING"); return v ? atoi(v) != 0 : true; }();
-  return on && m->cfg.gemm_dtype == 0 && m->cfg.dmodel % 128 == 0;
+  return on && m->cfg.dmodel % 128 == 0;
 }
 void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base) {
   for (const auto& pr : ab.ring_pairs) m->ring_of[base + pr.first] = base + pr.second;
@@ -391,14 +394,16 @@ bool gemm16_for(const mi355asr_model* m, size_t M) {
   return use_gemm16(m) || (long)M <= small_m;
 }
 int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s) {
-  if (m->cfg.gemm_dtype == 1) { g.wp = m->w16(wp); return launch_gemm16_bf16(epi, ln, g, s); }
-  g.wp = wp;
-  // long batches of dmodel 256 / 512: the same layer on the bf16 pipe with exactly split operands (gemm_ring.hip)
+  // long batches of dmodel 256 / 512: the same layer with the weights as a slab ring shared by eight waves
+  // (gemm_ring.hip): fp32 operands exactly split into three bf16 terms, or one bf16 term in bf16 mode
   static const long ring_min_m = [] { const char* v = getenv("MI355ASR_RING_MIN_M"); return v ? atol(v) : 4096L; }();
   if ((long)g.M >= ring_min_m && !m->ring_of.empty()) {
     const auto it = m->ring_of.find(wp);
-    if (it != m->ring_of.end() && launch_gemm_ring(epi, ln, g, it->second, s) == 0) return 0;
+    g.wp = wp;
+    if (it != m->ring_of.end() && launch_gemm_ring(epi, ln, g, it->second, m->cfg.gemm_dtype == 1 ? 1 : 3, s) == 0) return 0;
   }
+  if (m->cfg.gemm_dtype == 1) { g.wp = m->w16(wp); return launch_gemm16_bf16(epi, ln, g, s); }
+  g.wp = wp;
   return launch_gemm16_f32(epi, ln, g, s);
 }
 
@@ -1158,6 +1163,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   const Dims& dm = m->dm;
   const int d = c.dmodel;
   ArenaBuilder ab;
+  ab.ring_terms = m->cfg.gemm_dtype == 1 ? 1 : 3;
   size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0;
   FftOff fo;
   std::vector<BlockOff> eo, co;

@@ -128,6 +128,7 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   const Dims& dm = m->dm;
   const int d = c.dmodel, nb = dm.nbins;
   ArenaBuilder ab;
+  ab.ring_terms = m->cfg.gemm_dtype == 1 ? 1 : 3;
   const auto& re = m->host["front/mel_layer/real_kernels"].data;
   const auto& im = m->host["front/mel_layer/imag_kernels"].data;
   const size_t o_dft = ab.put(pack_p16(

@@ -32,6 +32,7 @@ int finalize_translator(mi355asr_model* m, hipStream_t s) {
   const auto& tc = m->tcfg;
   const int d = c.dmodel, H = c.num_heads, hs = c.head_size, V = tc.tar_classes;
   ArenaBuilder ab;
+  ab.ring_terms = m->cfg.gemm_dtype == 1 ? 1 : 3;
   const size_t o_emb = ab.put(m->host["inp_embedding/embeddings"].data);
   // positional_encoding.py:19-36: pe[pos, 2i] = sin(pos / 10000^(2i/d)), pe[pos, 2i+1] = cos(pos / 10000^(2i/d))
   std::vector<float> pe((size_t)kMaxTokens * d);

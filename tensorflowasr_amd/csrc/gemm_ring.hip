@@ -32,7 +32,7 @@ namespace {
 
 constexpr int GW = 8, GT = GW * 64;               // waves / threads per workgroup
 constexpr int GNB = 8;                            // column tiles per workgroup
-constexpr int GSLAB = GNB * 3 * 64;               // 16-byte fragments per k-step (24 KB)
+// 16-byte fragments per k-step: GNB x TERMS x 64 (24 KB with three terms, 8 KB in bf16 mode)
 constexpr int GLN_MAX = 512;                      // widest prologue LayerNorm (dmodel)
 constexpr int GUNR = 4;                           // unroll of the step loop (slab slots and operand stages divide it)
 
@@ -51,33 +51,51 @@ DEV u32x4 lds_read16(unsigned addr) {             // not visible to the compiler
   return v;
 }
 
-struct Frag { u32x4 t[3]; };                      // 8 k-slots x 3 terms
+// TERMS = 3: fp32 operands, exactly split.  TERMS = 1: bf16 mode (BASELINE config 3) -- weights rounded once on the host,
+// activations rounded to nearest even at the operand, one MFMA per tile and step; same arithmetic as bf16.hip.
+template <int TERMS>
+struct Frag { u32x4 t[TERMS]; };                  // 8 k-slots x TERMS terms
 
-// exact three-term bf16 split of eight fp32 values by truncation (remainders exact), two values per dword
-DEV Frag split8(f32x4 lo, f32x4 hi) {
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// exact three-term bf16 split of eight fp32 values by truncation (remainders exact), two values per dword; or the eight
+// values rounded to nearest-even bf16
+template <int TERMS>
+DEV Frag<TERMS> split8(f32x4 lo, f32x4 hi) {
   float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  Frag f;
-#pragma unroll
-  for (int term = 0; term < 3; ++term) {
+  Frag<TERMS> f;
+  if constexpr (TERMS == 1) {
     unsigned d[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * k]), a1 = __builtin_bit_cast(unsigned, v[2 * k + 1]);
-      d[k] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);           // (a0 >> 16) | (a1 & 0xffff0000)
-      if (term < 2) {
-        v[2 * k] -= __builtin_bit_cast(float, a0 & 0xffff0000u);
-        v[2 * k + 1] -= __builtin_bit_cast(float, a1 & 0xffff0000u);
-      }
+      const f32x2 pr = {v[2 * k], v[2 * k + 1]};
+      d[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_t));     // v_cvt_pk_bf16_f32
     }
-    f.t[term] = u32x4{d[0], d[1], d[2], d[3]};
+    f.t[0] = u32x4{d[0], d[1], d[2], d[3]};
+  } else {
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      unsigned d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * k]), a1 = __builtin_bit_cast(unsigned, v[2 * k + 1]);
+        d[k] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);           // (a0 >> 16) | (a1 & 0xffff0000)
+        if (term < 2) {
+          v[2 * k] -= __builtin_bit_cast(float, a0 & 0xffff0000u);
+          v[2 * k + 1] -= __builtin_bit_cast(float, a1 & 0xffff0000u);
+        }
+      }
+      f.t[term] = u32x4{d[0], d[1], d[2], d[3]};
+    }
   }
   return f;
 }
 
 struct XRegs { f32x4 lo, hi; };                   // one lane's eight operand values of one k-step, before LN / split
 
-template <int EPI, bool LN, int RT, int RING>
+template <int EPI, bool LN, int RT, int RING, int TERMS>
 __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u32x4* __restrict__ wring, int cpw) {
+  constexpr int GSLAB = GNB * TERMS * 64;
   __shared__ __attribute__((aligned(16))) u32x4 wl[RING][GSLAB];
   __shared__ __attribute__((aligned(16))) float p_gb[2 * (LN ? GLN_MAX : 4)];   // LayerNorm gamma, then beta
   float* const p_g = p_gb;
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   const int chunk0 = blockIdx.y * cpw;
   const int steps = a.K / 32, total = cpw * steps;
   const u32x4* __restrict__ wg = wring + (size_t)chunk0 * steps * GSLAB;
-  constexpr int NQ = GSLAB / GT;                  // 3 DMA instructions per wave and slab
+  constexpr int NQ = (GSLAB + GT - 1) / GT;       // DMA instructions per wave and slab: 3, or 1 in bf16 mode
   const int wv = __builtin_amdgcn_readfirstlane(wave);
 
   // the first RING - 1 slabs
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   // compiler-visible LDS read would again cost a vmcnt(0) while slabs are in flight)
   const unsigned ln_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(p_g + g4);
   constexpr unsigned LN_B = sizeof(float) * (LN ? GLN_MAX : 4);      // p_b follows p_g
-  auto xsplit = [&](int st, const XRegs (&x)[RT], Frag (&f)[RT]) {
+  auto xsplit = [&](int st, const XRegs (&x)[RT], Frag<TERMS> (&f)[RT]) {
     const int sc = st >= steps ? st - steps : st;
     u32x4 gl = {}, gh = {}, bl = {}, bh = {};
     if (LN) {
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
         lo = (lo - m) * r * __builtin_bit_cast(f32x4, gl) + __builtin_bit_cast(f32x4, bl);
         hi = (hi - m) * r * __builtin_bit_cast(f32x4, gh) + __builtin_bit_cast(f32x4, bh);
       }
-      f[rt] = split8(lo, hi);
+      f[rt] = split8<TERMS>(lo, hi);
     }
   };
 
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   // operand register stages: four steps ahead with one row tile, two with two (256 registers)
   constexpr int XST = (RT == 1 && RING == 4) ? GUNR : 2;
   XRegs xq[XST][RT];
-  Frag xa[RT];
+  Frag<TERMS> xa[RT];
 #pragma unroll
   for (int st = 0; st < XST; ++st) xload(st, xq[st]);
   __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0): the first slabs and operands
@@ -233,35 +251,50 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   // newest reads".
   auto mfma_step = [&](int slot) {
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&wl[slot][lane]);
-    u32x4 wa[2][3], wb[2][3];
-#define RING_FETCH(W, PAIR) \
-    W[0][0] = lds_read16<((2 * (PAIR) + 0) * 3 + 0) * 1024>(base); W[0][1] = lds_read16<((2 * (PAIR) + 0) * 3 + 1) * 1024>(base); \
-    W[0][2] = lds_read16<((2 * (PAIR) + 0) * 3 + 2) * 1024>(base); W[1][0] = lds_read16<((2 * (PAIR) + 1) * 3 + 0) * 1024>(base); \
-    W[1][1] = lds_read16<((2 * (PAIR) + 1) * 3 + 1) * 1024>(base); W[1][2] = lds_read16<((2 * (PAIR) + 1) * 3 + 2) * 1024>(base);
-#define RING_WAIT(W, N) \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(W[0][0]), "+v"(W[0][1]), "+v"(W[0][2]), "+v"(W[1][0]), "+v"(W[1][1]), "+v"(W[1][2]))
-#define RING_MMA(W, PAIR) \
-    _Pragma("unroll") for (int ord = 2; ord >= 0; --ord) \
-      _Pragma("unroll") for (int p = 0; p <= ord; ++p) \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) \
-          _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) \
-            acc[rt][2 * (PAIR) + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[h][ord - p]), \
-                __builtin_bit_cast(bf16x8, xa[rt].t[p]), acc[rt][2 * (PAIR) + h], 0, 0, 0);
-    RING_FETCH(wa, 0)
-    RING_FETCH(wb, 1)
-    RING_WAIT(wa, 6);
-    RING_MMA(wa, 0)
-    RING_FETCH(wa, 2)
-    RING_WAIT(wb, 6);
-    RING_MMA(wb, 1)
-    RING_FETCH(wb, 3)
-    RING_WAIT(wa, 6);
-    RING_MMA(wa, 2)
-    RING_WAIT(wb, 0);
-    RING_MMA(wb, 3)
-#undef RING_FETCH
-#undef RING_WAIT
-#undef RING_MMA
+    u32x4 wa[2][TERMS], wb[2][TERMS];
+    auto fetch = [&](u32x4 (&w)[2][TERMS], auto PAIR_T) {
+      constexpr int PAIR = decltype(PAIR_T)::value;
+      static_for<0, 2>([&](auto H_T) {
+        constexpr int h = decltype(H_T)::value;
+        static_for<0, TERMS>([&](auto T_T) {
+          constexpr int t = decltype(T_T)::value;
+          w[h][t] = lds_read16<((2 * PAIR + h) * TERMS + t) * 1024>(base);
+        });
+      });
+    };
+    auto wait = [&](u32x4 (&w)[2][TERMS], auto N_T) {
+      constexpr int N = decltype(N_T)::value;
+      if constexpr (TERMS == 3)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]) : "n"(N));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0][0]), "+v"(w[1][0]) : "n"(N));
+    };
+    auto mma = [&](const u32x4 (&w)[2][TERMS], auto PAIR_T) {
+      constexpr int PAIR = decltype(PAIR_T)::value;
+#pragma unroll
+      for (int ord = TERMS - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int p = 0; p <= ord; ++p)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              acc[rt][2 * PAIR + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[h][ord - p]),
+                  __builtin_bit_cast(bf16x8, xa[rt].t[p]), acc[rt][2 * PAIR + h], 0, 0, 0);
+    };
+    constexpr int NEW = 2 * TERMS;                // reads of one pair: "all but the newest pair" = lgkmcnt(NEW)
+    fetch(wa, std::integral_constant<int, 0>{});
+    fetch(wb, std::integral_constant<int, 1>{});
+    wait(wa, std::integral_constant<int, NEW>{});
+    mma(wa, std::integral_constant<int, 0>{});
+    fetch(wa, std::integral_constant<int, 2>{});
+    wait(wb, std::integral_constant<int, NEW>{});
+    mma(wb, std::integral_constant<int, 1>{});
+    fetch(wb, std::integral_constant<int, 3>{});
+    wait(wa, std::integral_constant<int, NEW>{});
+    mma(wa, std::integral_constant<int, 2>{});
+    wait(wb, std::integral_constant<int, 0>{});
+    mma(wb, std::integral_constant<int, 3>{});
   };
   auto slab_dma = [&](int st, int slot) {         // slab `st` into a slot last read in step st - RING
     const u32x4* src = wg + (size_t)min(st, total - 1) * GSLAB;
@@ -275,7 +308,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
     slab_dma(gs + RING - 1, PV % RING);           // the slot of step gs - 1: every wave is past that step's barrier
     __builtin_amdgcn_sched_barrier(0);
     // operand loads of a stage are followed by XST - 1 whole iterations (3 slab pieces + 2 RT loads) and this one's slab
-    constexpr int XAFTER = (XST - 1) * (3 + 2 * RT) + 3;
+    constexpr int XAFTER = (XST - 1) * (NQ + 2 * RT) + NQ;
     if constexpr (!LATE) {
       xwait(xq[SL % XST], std::integral_constant<int, XAFTER>{});
       xsplit(s, xq[SL % XST], xa);
@@ -292,7 +325,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
     __builtin_amdgcn_sched_barrier(0);
     // slab s + 1 was issued RING - 2 iterations ago; what was issued after it -- the operand loads of that iteration and
     // everything of the iterations since (3 slab pieces + 2 RT operand loads each) -- may stay in flight
-    constexpr int INFLIGHT = 2 * RT + (RING - 2) * (3 + 2 * RT);
+    constexpr int INFLIGHT = 2 * RT + (RING - 2) * (NQ + 2 * RT);
     __builtin_amdgcn_s_waitcnt(0x0f70 | (INFLIGHT & 15) | ((INFLIGHT >> 4) << 14));
     // a bare s_barrier: __syncthreads() carries a workgroup fence, for which hipcc waits for vmcnt(0) -- every slab and
     // operand load in flight.  What must be visible after this barrier is the slab of step s + 1 (waited for above by
@@ -401,7 +434,7 @@ __global__ __launch_bounds__(256) void ring_layernorm_rows_kernel(float* y, cons
     stg4(p + i, (ldg4(p + i) - splat4(mean)) * splat4(rstd) * ldg4(g + i) + ldg4(b + i));
 }
 
-template <int EPI, bool LN>
+template <int EPI, bool LN, int TERMS>
 int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   const int chunks = (EPI == E16_GLU ? a.NT / 2 : a.NT) / (EPI == E16_GLU ? GNB / 2 : GNB);
   // Shape of the launch: RT row tiles per wave (256 or 128 rows per workgroup) and cpw column chunks per workgroup, so
@@ -429,13 +462,13 @@ int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   const int cpw = best_cpw;
   const dim3 grid((a.M + 128 * best_rt - 1) / (128 * best_rt), chunks / cpw);
   if (best_rt == 2 && force_slots != 2)
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4, TERMS>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
   else if (best_rt == 2)
     return -1;
   else if (force_slots == 2 || (force_slots != 4 && (long)grid.x * grid.y > 320))
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 2>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 2, TERMS>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
   else
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 4>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 4, TERMS>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
   return 0;
 }
 
@@ -455,21 +488,27 @@ bool gemm_ring_applicable(int epi, bool ln, const Gemm16Args& a) {
   }
 }
 
-int launch_gemm_ring(int epi, bool ln, const Gemm16Args& a, const void* ring, hipStream_t s) {
-  if (!ring || !gemm_ring_applicable(epi, ln, a)) return -1;
+template <int TERMS>
+static int launch_terms(int epi, bool ln, const Gemm16Args& a, const void* ring, hipStream_t s) {
   switch (epi) {
-    case E16_BIAS: go<E16_BIAS, false>(a, ring, s); break;
-    case E16_SWISH: go<E16_SWISH, true>(a, ring, s); break;
-    case E16_QKV: go<E16_QKV, true>(a, ring, s); break;
-    case E16_GLU: go<E16_GLU, true>(a, ring, s); break;
-    case E16_AFFSWISH: go<E16_AFFSWISH, false>(a, ring, s); break;
-    case E16_RES:
-      go<E16_RES, false>(a, ring, s);
+    case E16_BIAS: return go<E16_BIAS, false, TERMS>(a, ring, s);
+    case E16_SWISH: return go<E16_SWISH, true, TERMS>(a, ring, s);
+    case E16_QKV: return go<E16_QKV, true, TERMS>(a, ring, s);
+    case E16_GLU: return go<E16_GLU, true, TERMS>(a, ring, s);
+    case E16_AFFSWISH: return go<E16_AFFSWISH, false, TERMS>(a, ring, s);
+    case E16_RES: {
+      const int rc = go<E16_RES, false, TERMS>(a, ring, s);
       // the optional LayerNorm over the output row needs all of it: a second pass over y (as bf16.hip does for wide rows)
-      if (a.fln_g)
+      if (rc == 0 && a.fln_g)
         hipLaunchKernelGGL(ring_layernorm_rows_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a.y, a.fln_g, a.fln_b, a.M, 16 * a.NT, a.ldy, a.eps);
-      break;
+      return rc;
+    }
     default: return -1;
   }
-  return 0;
+}
+
+// terms = 3: fp32 operands exactly split; 1: bf16 mode (ring of host-rounded bf16 weights, activations rounded at the operand)
+int launch_gemm_ring(int epi, bool ln, const Gemm16Args& a, const void* ring, int terms, hipStream_t s) {
+  if (!ring || !gemm_ring_applicable(epi, ln, a)) return -1;
+  return terms == 1 ? launch_terms<1>(epi, ln, a, ring, s) : launch_terms<3>(epi, ln, a, ring, s);
 }

@@ -221,9 +221,9 @@ int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s);
 int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s);   // wp = fp32 P16 weights
 int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // gemm_ring.hip: the same contract on the bf16 pipe with exactly split fp32 operands, weights as a slab ring
-// [N / 128 chunks][K / 32 steps][8 tiles][3 terms][64 lanes][8 bf16] (api.hip: pack_ring); -1: shape not taken
+// [N / 128 chunks][K / 32 steps][8 tiles][3 terms (1 in bf16 mode)][64 lanes][8 bf16] (api.hip: put_ring); -1: shape not taken
 bool gemm_ring_applicable(int epi, bool ln, const Gemm16Args& a);
-int launch_gemm_ring(int epi, bool ln, const Gemm16Args& a, const void* ring, hipStream_t s);
+int launch_gemm_ring(int epi, bool ln, const Gemm16Args& a, const void* ring, int terms, hipStream_t s);   // terms: 3 (fp32) or 1 (bf16 mode)
 // block-level fused kernels (fused.hip, dmodel 144)
 struct Ff1QkvArgs {
   const float* x0; float* x1; float* qkv;

@@ -174,6 +174,7 @@ struct ArenaBuilder {
   // (offset of a P16 weight pack, offset of the same matrix as a gemm_ring.hip slab ring): resolved into
   // mi355asr_model::ring_of once the arena is on the device
   std::vector<std::pair<size_t, size_t>> ring_pairs;
+  int ring_terms = 3;   // 3: fp32 weights as three bf16 terms; 1: bf16 mode (round-to-nearest-even bf16)
   size_t put(const std::vector<float>& v) {
     size_t off = (buf.size() + 63) & ~(size_t)63;  // 256-byte alignment
     buf.resize(off + v.size());

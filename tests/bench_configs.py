@@ -122,11 +122,14 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--only", type=int, default=0)
+    ap.add_argument("--c3-dtype", default="both", choices=["both", "bf16", "f32"])
     ap.add_argument("--variants", default="", help="comma-separated subset of the --only 2 variants (S_mel, M_mel, L_mel, ...)")
     a = ap.parse_args()
     if a.only in (0, 3):
-        print(json.dumps(config3(a.steps, "bfloat16")), flush=True)
-        print(json.dumps(config3(a.steps, "float32")), flush=True)
+        if a.c3_dtype in ("both", "bf16"):
+            print(json.dumps(config3(a.steps, "bfloat16")), flush=True)
+        if a.c3_dtype in ("both", "f32"):
+            print(json.dumps(config3(a.steps, "float32")), flush=True)
     if a.only in (0, 5):
         print(json.dumps(config5(a.steps)), flush=True)
     if a.only in (0, 2):

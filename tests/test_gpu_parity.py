@@ -1009,6 +1009,43 @@ print("RESULT " + " ".join("%.3e" % v for v in res))
         assert max(errs) < TOL, (extra, errs)
 
 
+def test_ring_gemm_bf16_mode_in_a_subprocess(torch_cuda):
+    """bf16 mode (BASELINE config 3) through gemm_ring.hip's one-term ring, forced for a small batch: one ConformerBlock
+    of the streaming configuration (dmodel 256) on an exact fp32 input against the oracle with both GEMM operands rounded
+    to bf16 -- the same bounds as test_bf16_block_matches_rounding_oracle, which runs the per-wave bf16 kernels."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, small_cfg
+from tensorflowasr_amd.models import ConformerCTC
+cfg = small_cfg(1, co.STREAMING_S)
+w = co.encoder_weights(cfg, seed=5)
+w.update(co.ctc_decoder_weights(cfg, 100, seed=6))
+m = ConformerCTC(100, gemm_dtype="bfloat16", **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+m.load_weights(w, by_name=False)
+x = np.random.default_rng(2).standard_normal((5, 77, cfg["dmodel"])).astype(np.float32)
+got = m.conformer_block(0, x).cpu().numpy()
+co.GEMM_ROUND_BF16 = True
+ref = co.conformer_block(x.astype(np.float64), w, "conformer_block_0", cfg["head_size"], cfg["fc_factor"])
+co.GEMM_ROUND_BF16 = False
+exact = co.conformer_block(x.astype(np.float64), w, "conformer_block_0", cfg["head_size"], cfg["fc_factor"])
+e = np.abs(got - ref)
+print("RESULT %.3e %.3e %.3e" % (e.max(), e.mean(), np.abs(got - exact).max()))
+'''
+    for extra in ({"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_RT": "1"}, {"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_RT": "2"},
+                  {"MI355ASR_RING_MIN_M": "1", "MI355ASR_RING_SLOTS": "2"}):
+        env = dict(os.environ, **extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+        assert line, out.stderr[-2000:]
+        emax, emean, vs_exact = (float(v) for v in line[0].split()[1:])
+        print(extra, emax, emean, vs_exact)
+        assert emax < 6e-3 and emean < 3e-4 and vs_exact > 10 * emean, (extra, emax, emean, vs_exact)
+
+
 def test_translator_dmodel_512(torch_cuda):
     """conformerL.yml Translator (dmodel 512, 8 heads x 64): cross-attention through the layer-at-a-time GEMM path."""
     from tensorflowasr_amd.models import Translator
