@@ -21,13 +21,13 @@
 
 namespace {
 
-constexpr int TP = 256;        // padded key count held in LDS
-constexpr int VS = TP + 4;     // row stride of V^T (floats): 16-byte aligned rows, 2-way bank conflicts at most
+constexpr int TP_MAX = 272;    // most keys held in LDS: 256 (offline 10 s), or 272 at head size 64 (the streaming CTC's 260 frames)
 constexpr int AW = 8;          // waves (query tiles) per workgroup
 constexpr int ATH = AW * 64;
 
-template <int HS>
+template <int HS, int TP>       // TP = padded key count held in LDS
 __global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
+  constexpr int VS = TP + 4;           // row stride of V^T (floats): 16-byte aligned rows, 2-way bank conflicts at most
   constexpr int FB = HS / 16;          // full 16-wide feature blocks
   constexpr int TS = (HS % 16) / 4;    // tail k-steps (feature = 16*FB + 4*ts + g)
   constexpr int OT = (HS + 15) / 16;   // output feature tiles
@@ -184,14 +184,15 @@ __global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
 bool attention_lds_applicable(int HS, const AttnArgs& a) {
   // head size 64 (ConformerM / L): K and V^T take 130 KB, one workgroup per CU.  MI355ASR_ATTN_LDS64=0: the L2-streaming kernel
   static const bool lds64 = [] { const char* v = getenv("MI355ASR_ATTN_LDS64"); return v ? atoi(v) != 0 : true; }();
-  return (HS == 36 || (HS == 64 && lds64)) && a.win_front < 0 && a.Tk <= TP && a.Tk > 16 && a.Tq > 16;
+  return (HS == 36 || (HS == 64 && lds64)) && a.win_front < 0 && a.Tk <= (HS == 64 ? TP_MAX : 256) && a.Tk > 16 && a.Tq > 16;
 }
 
 int launch_attention_lds(int HS, const AttnArgs& a, hipStream_t s) {
   if (!attention_lds_applicable(HS, a)) return -1;
   const int qtiles = (a.Tq + 15) / 16;
   dim3 grid((qtiles + AW - 1) / AW, a.H, a.B);
-  if (HS == 64) hipLaunchKernelGGL((attention_lds_kernel<64>), grid, dim3(ATH), 0, s, a);
-  else hipLaunchKernelGGL((attention_lds_kernel<36>), grid, dim3(ATH), 0, s, a);
+  if (HS == 64 && a.Tk > 256) hipLaunchKernelGGL((attention_lds_kernel<64, TP_MAX>), grid, dim3(ATH), 0, s, a);
+  else if (HS == 64) hipLaunchKernelGGL((attention_lds_kernel<64, 256>), grid, dim3(ATH), 0, s, a);
+  else hipLaunchKernelGGL((attention_lds_kernel<36, 256>), grid, dim3(ATH), 0, s, a);
   return 0;
 }

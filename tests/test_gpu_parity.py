@@ -969,6 +969,22 @@ def test_conformer_m_and_l_parity(torch_cuda, base, L):
     assert (ids.cpu().numpy() == rid).all() and (lens.cpu().numpy() == rlen).all()
 
 
+@pytest.mark.parametrize("T", [260, 272, 250, 273])
+def test_head_size_64_block_at_streaming_ctc_lengths(torch_cuda, T):
+    """One dmodel-256 block (4 heads x 64) on 260 frames -- the "global CTC" history of BASELINE config 3 (20 chunks x 13
+    frames) -- and around the 256 / 272-key limits of the LDS-staged attention kernel (273: the L2-streaming kernel)."""
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = small_cfg(1, co.CONFORMER_M)
+    w = co.encoder_weights(cfg, seed=15)
+    w.update(co.ctc_decoder_weights(cfg, 100, seed=16))
+    m = ConformerCTC(100, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+    m.load_weights(w, by_name=False)
+    x = np.random.default_rng(T).standard_normal((2, T, cfg["dmodel"])).astype(np.float32)
+    got = m.conformer_block(0, x).cpu().numpy()
+    ref = co.conformer_block(x.astype(np.float64), w, "conformer_block_0", cfg["head_size"], cfg["fc_factor"])
+    assert maxdiff(got, ref) < TOL
+
+
 def test_ring_gemm_path_of_m_and_l_in_a_subprocess(torch_cuda):
     """gemm_ring.hip (dense layers of dmodel 256 / 512 on the split-bf16 pipe, taken from 4096 rows on) forced for a small
     batch (MI355ASR_RING_MIN_M=1): encoder and CTC logits against the oracle for ConformerM and ConformerL, with one and
