@@ -67,7 +67,9 @@ typedef struct {
                               *    LayerNorm / softmax / activations / frontend (BASELINE config 3)               */
   int32_t mel_layer_type;    /* speech_config.mel_layer_type: 0 = 'Melspectrogram' (default), 1 = 'leaf' (LEAF frontend,
                               *    leaf_audio/frontend.py: Gabor filters + Gaussian pooling + PCEN + instance norm;
-                              *    needs n_mels 80, stride_ms 10 at 16 kHz)                                       */
+                              *    needs n_mels 80, stride_ms 10 at 16 kHz), 2 = 'Spectrogram' (any other value in the
+                              *    reference, conformer_blocks.py:318-323: the n_dft/2+1 = 513 dB bins without the mel
+                              *    matrix; n_mels is ignored and no freq2mel tensor exists)                        */
   int32_t add_wav_info;      /* speech_config.add_wav_info: 1 adds WavePickModel(waveform) (asr/models/wav_model.py:108-146)
                               *    to the subsampled features (conformer_blocks.py:344-348); needs L % hop_size == 0   */
 } mi355asr_config;

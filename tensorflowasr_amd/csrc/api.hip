@@ -709,7 +709,8 @@ int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, fl
   me.logp = logp; me.umax = umax; me.mel = mel; me.wp = m->mel_wp;
   me.B = Bp; me.F = F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
   me.NM = c.n_mels; me.FT = FT; me.floor_db = -80.0f;
-  { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel(me, s), "dB + mel"); }
+  if (c.mel_layer_type == 2) { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_db_norm(me, s), "dB (Spectrogram layer)"); }
+  else { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel(me, s), "dB + mel"); }
   return 0;
 }
 
@@ -742,7 +743,15 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
     PROF(MI355ASR_K_SUBLINEAR);
     if (launch_sublinear_split(lg, m->lin_wsplit, s) == 0) return 0;
   }
-  { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear"); }
+  {
+    PROF(MI355ASR_K_SUBLINEAR);
+    if (launch_stream_gemm(d, lg, s) == 0) return 0;
+  }
+  // K = F2 * dmodel that is not a multiple of 32 (the plain Spectrogram layer: F2 = 129): the layer-at-a-time kernel
+  Gemm16Args g16{};
+  g16.x = sub; g16.ldx = m->dm.F2 * d; g16.bias = m->lin_b; g16.y = out; g16.ldy = d;
+  g16.M = Bp * T2; g16.K = m->dm.F2 * d; g16.NT = d / 16; g16.n_valid = d; g16.eps = kLnEps;
+  { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_gemm16(m, E16_BIAS, false, g16, m->lin_wp, s), "subsampling linear"); }
   return 0;
 }
 
@@ -927,7 +936,10 @@ const char* mi355asr_version(void) { return "mi355asr 0.1 (gfx950, fp32 + split-
 
 int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
   if (!cfg || !out) return fail(MI355ASR_EINVAL, "null argument");
-  const auto& c = *cfg;
+  mi355asr_config c = *cfg;
+  // the plain Spectrogram layer feeds all n_dft / 2 + 1 dB bins to the subsampling convs: from here on they are the
+  // "mel" axis of every shape (n_mels of the config is not used by that layer, conformer_blocks.py:318-323)
+  if (c.mel_layer_type == 2) c.n_mels = c.n_dft / 2 + 1;
   if (c.dmodel != 144 && (c.dmodel % 128 != 0 || c.dmodel < 128 || c.dmodel > 1024))
     return fail(MI355ASR_EINVAL, "dmodel=%d: supported are 144 (ConformerS), 256 (ConformerM / StreamingS) and other multiples of 128 up to 1024 (512 = ConformerL)", c.dmodel);
   if (c.num_heads * c.head_size != c.dmodel)
@@ -939,12 +951,14 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
   if (c.num_classes > 0 && c.ctc_kernel_size != 32 && c.ctc_kernel_size != 5)
     return fail(MI355ASR_EINVAL, "ctc_kernel_size=%d unsupported", c.ctc_kernel_size);
   if (c.reduction_factor != 4) return fail(MI355ASR_EINVAL, "reduction_factor=%d: only 4 is supported", c.reduction_factor);
-  if (c.mel_layer_type != 0 && c.mel_layer_type != 1) return fail(MI355ASR_EINVAL, "mel_layer_type=%d: 0 (Melspectrogram) or 1 (leaf)", c.mel_layer_type);
+  if (c.mel_layer_type < 0 || c.mel_layer_type > 2)
+    return fail(MI355ASR_EINVAL, "mel_layer_type=%d: 0 (Melspectrogram), 1 (leaf) or 2 (Spectrogram)", c.mel_layer_type);
   if (c.mel_layer_type == 1 && (c.n_mels != 80 || c.stride_ms * c.sample_rate / 1000 != 160 || c.sample_rate != 16000))
     return fail(MI355ASR_EINVAL, "leaf frontend: instantiated for 80 filters, 16 kHz, 10 ms stride (window 401, hop 160)");
   if (c.gemm_dtype != 0 && c.gemm_dtype != 1) return fail(MI355ASR_EINVAL, "gemm_dtype=%d: 0 (fp32 MFMA) or 1 (bf16 MFMA)", c.gemm_dtype);
   if (c.n_dft != 1024) return fail(MI355ASR_EINVAL, "n_dft=%d: the reference hard-codes 1024 (conformer_blocks.py:312)", c.n_dft);
-  if (c.n_mels != 80 && c.n_mels != 128) return fail(MI355ASR_EINVAL, "n_mels=%d: mel kernel instantiated for 80 and 128", c.n_mels);
+  if (c.mel_layer_type != 2 && c.n_mels != 80 && c.n_mels != 128)
+    return fail(MI355ASR_EINVAL, "n_mels=%d: mel kernel instantiated for 80 and 128", c.n_mels);
   if (c.num_blocks < 0 || c.ctc_num_blocks < 0 || c.chunk_size < 0 || c.num_classes < 0)
     return fail(MI355ASR_EINVAL, "negative count in config");
   auto* m = new mi355asr_model();
@@ -979,10 +993,10 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
     ex.push_back({"mel_layer/tfbanks_instancenorm/beta", {c.n_mels}});
   }
   if (c.has_encoder) {
-    if (c.mel_layer_type == 0) {
+    if (c.mel_layer_type != 1) {
     ex.push_back({"mel_layer/real_kernels", {c.n_dft, 1, 1, dm.nbins}});
     ex.push_back({"mel_layer/imag_kernels", {c.n_dft, 1, 1, dm.nbins}});
-    ex.push_back({"mel_layer/freq2mel", {dm.nbins, c.n_mels}});
+    if (c.mel_layer_type == 0) ex.push_back({"mel_layer/freq2mel", {dm.nbins, c.n_mels}});
     }
     ex.push_back({"conv_subsampling/conv1/kernel", {3, 3, 1, d}});
     ex.push_back({"conv_subsampling/conv1/bias", {d}});
@@ -1229,7 +1243,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   }
   if (c.has_encoder) {
   const int nb = dm.nbins;
-  if (c.mel_layer_type == 0) {
+  if (c.mel_layer_type != 1) {
   const auto& re = m->host["mel_layer/real_kernels"].data;
   const auto& im = m->host["mel_layer/imag_kernels"].data;
   // DFT columns interleaved (re, im) per bin so that power = x^2 + y^2 / z^2 + w^2 inside one lane
@@ -1237,8 +1251,10 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
       [&](int k, int n) { const int bin = n >> 1; return (n & 1) ? im[(size_t)k * nb + bin] : re[(size_t)k * nb + bin]; },
       c.n_dft, 2 * nb, dm.NT_dft));
   fo = pack_fft(ab, re, im, c.n_dft, nb);
+  if (c.mel_layer_type == 0) {
   const auto& f2m = m->host["mel_layer/freq2mel"].data;
   o_mel = ab.put(pack_p16([&](int k, int n) { return k < nb ? f2m[(size_t)k * c.n_mels + n] : 0.f; }, dm.KBm * 16, c.n_mels, dm.NTm));
+  }
   }
   (void)nb;
   o_c1w = ab.put(m->host["conv_subsampling/conv1/kernel"].data);  // [3][3][1][d] == [(i*3+j)*d + c]

@@ -167,6 +167,27 @@ __global__ __launch_bounds__(BLOCK_THREADS) void mel_kernel(MelArgs a) {
   }
 }
 
+// dB normalisation alone: the plain Spectrogram layer (time_frequency.py:7-123 with return_decibel_spectrogram = True --
+// mel_layer_type 'Spectrogram', conformer_blocks.py:318-323): out[b, f, k] = max(logp[b, f, k] - max_b, -80), k < nbins.
+// Melspectrogram is this followed by freq2mel (mel_kernel above does both in one pass).
+__global__ __launch_bounds__(256) void db_norm_kernel(MelArgs a) {
+  const size_t n = (size_t)a.B * a.F * a.nbins;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / a.nbins;
+    const int k = (int)(i - row * a.nbins);
+    const int b = (int)(row / a.F);
+    float x = a.logp[row * a.LP + k];
+    if (a.umax) x = fmaxf(x - a.umax[b], a.floor_db);
+    a.mel[row * a.NM + k] = x;
+  }
+}
+int launch_db_norm(const MelArgs& a, hipStream_t s) {
+  if (a.NM != a.nbins) return -1;
+  const size_t n = (size_t)a.B * a.F * a.nbins;
+  hipLaunchKernelGGL(db_norm_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, s, a);
+  return 0;
+}
+
 int launch_mel(const MelArgs& a, hipStream_t s) {
   dim3 grid((a.B * a.FT + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
   if (a.NTm == 5) hipLaunchKernelGGL((mel_kernel<5>), grid, dim3(BLOCK_THREADS), 0, s, a);

@@ -269,6 +269,7 @@ int launch_dwconv(int K, const DwArgs& a, hipStream_t s);
 int launch_stft(const StftArgs& a, hipStream_t s);
 int launch_utt_max(const UttMaxArgs& a, int B, hipStream_t s);
 int launch_mel(const MelArgs& a, hipStream_t s);
+int launch_db_norm(const MelArgs& a, hipStream_t s);   // mel_layer_type 'Spectrogram': the dB normalisation without the mel matrix
 int launch_subconv(int D, const SubConvArgs& a, hipStream_t s);
 int launch_subconv144(const SubConvArgs& a, hipStream_t s);
 int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s);   // split-bf16 ring kernel (dmodel 144 / 256 / 512); -1: not supported, nothing launched

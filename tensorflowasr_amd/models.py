@@ -287,8 +287,13 @@ def _wav_layer_shapes(d):
     return s
 
 
-def _encoder_shapes(d, H, hs, k, num_blocks, n_mels, n_dft=1024, leaf=False, add_wav_info=False):
+_MEL_LAYER_CODE = {"Melspectrogram": 0, "leaf": 1, "Spectrogram": 2}      # mi355asr_config.mel_layer_type
+
+
+def _encoder_shapes(d, H, hs, k, num_blocks, n_mels, n_dft=1024, leaf=False, add_wav_info=False, spectrogram=False):
     nb = n_dft // 2 + 1
+    if spectrogram:                      # the plain Spectrogram layer: all nb dB bins go to the subsampling convs
+        n_mels = nb
     f2 = -(-(-(-n_mels // 2)) // 2)
     if leaf:
         s = {"mel_layer/tfbanks_preemp/kernel": (2, 1, 1), "mel_layer/tfbanks_complex_conv/kernel": (n_mels, 2),
@@ -296,8 +301,9 @@ def _encoder_shapes(d, H, hs, k, num_blocks, n_mels, n_dft=1024, leaf=False, add
              "mel_layer/PCEN/delta": (n_mels,), "mel_layer/PCEN/root": (n_mels,), "mel_layer/PCEN/EMA/smooth": (n_mels,),
              "mel_layer/tfbanks_instancenorm/gamma": (n_mels,), "mel_layer/tfbanks_instancenorm/beta": (n_mels,)}
     else:
-        s = {"mel_layer/real_kernels": (n_dft, 1, 1, nb), "mel_layer/imag_kernels": (n_dft, 1, 1, nb),
-             "mel_layer/freq2mel": (nb, n_mels)}
+        s = {"mel_layer/real_kernels": (n_dft, 1, 1, nb), "mel_layer/imag_kernels": (n_dft, 1, 1, nb)}
+        if not spectrogram:
+            s["mel_layer/freq2mel"] = (nb, n_mels)
     s.update({
          "conv_subsampling/conv1/kernel": (3, 3, 1, d), "conv_subsampling/conv1/bias": (d,),
          "conv_subsampling/conv2/kernel": (3, 3, d, d), "conv_subsampling/conv2/bias": (d,),
@@ -320,8 +326,9 @@ def _ctc_shapes(d, H, hs, k, num_blocks, num_classes):
 
 class ConformerEncoder(_ModelBase):
     """asr/models/conformer_blocks.py:277-384.  `mel_layer_type`: 'Melspectrogram' (the default of
-    asr/configs/am_data.yml:3) or 'leaf'; `add_wav_info=True` adds the WavePickModel branch (wav_model.py:108-146) to
-    the subsampled features."""
+    asr/configs/am_data.yml:3), 'leaf', or -- as in the reference, any other value -- the plain 'Spectrogram' layer
+    (conformer_blocks.py:318-323: 513 dB bins, no mel matrix); `add_wav_info=True` adds the WavePickModel branch
+    (wav_model.py:108-146) to the subsampled features."""
 
     def __init__(self, dmodel=144, reduction_factor=4, num_blocks=16, head_size=36, num_heads=4, kernel_size=32,
                  fc_factor=0.5, dropout=0.0, add_wav_info=False, sample_rate=16000, n_mels=80,
@@ -330,10 +337,7 @@ class ConformerEncoder(_ModelBase):
         """gemm_dtype (not in the reference): "float32" (default, the reference's arithmetic) or "bfloat16" = bf16 MFMA
         inputs with fp32 accumulation for the dense layers (BASELINE config 3)."""
         self.gemm_dtype = _gemm_dtype(gemm_dtype)
-        if mel_layer_type not in ("Melspectrogram", "leaf"):
-            raise NotImplementedError("mel_layer_type=%r: 'Melspectrogram' and 'leaf' are implemented (the reference's "
-                                      "third choice, the plain Spectrogram layer, is not)" % mel_layer_type)
-        self.mel_layer_type = mel_layer_type
+        self.mel_layer_type = mel_layer_type if mel_layer_type in ("Melspectrogram", "leaf") else "Spectrogram"
         self.name = name
         self.dmodel, self.num_heads, self.head_size = dmodel, num_heads, head_size
         self.fc_factor, self.dropout = fc_factor, dropout      # dropout is identity at inference
@@ -353,13 +357,14 @@ class ConformerEncoder(_ModelBase):
                           reduction_factor=self.reduction_factor, n_mels=self.n_mels, sample_rate=self.sample_rate,
                           stride_ms=self.stride_ms, n_dft=1024, chunk_size=self.chunk_size, has_encoder=1,
                           num_classes=0, ctc_num_blocks=0, ctc_kernel_size=32, ctc_fc_factor=0.5,
-                          gemm_dtype=self.gemm_dtype, mel_layer_type=int(self.mel_layer_type == "leaf"),
+                          gemm_dtype=self.gemm_dtype, mel_layer_type=_MEL_LAYER_CODE[self.mel_layer_type],
                           add_wav_info=int(self.add_wav_info))
         self._h = _Handle(cfg, self._device)
 
     def _expected_shapes(self):
         return _encoder_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks,
-                               self.n_mels, leaf=self.mel_layer_type == "leaf", add_wav_info=self.add_wav_info)
+                               self.n_mels, leaf=self.mel_layer_type == "leaf", add_wav_info=self.add_wav_info,
+                               spectrogram=self.mel_layer_type == "Spectrogram")
 
     def __call__(self, inputs, training=False, **kwargs):
         """wav [B, L, 1] (or [B, L]) float32 -> torch.Tensor [B, T, dmodel] on the device."""
@@ -384,7 +389,8 @@ class ConformerEncoder(_ModelBase):
         B, L = x.shape
         F, _ = h.out_frames(L)
         nblk = L // self.chunk_size if self.chunk_size else 1
-        out = torch.empty((B * nblk, F // nblk, self.n_mels), dtype=torch.float32, device=h.device)
+        nm = 513 if self.mel_layer_type == "Spectrogram" else self.n_mels      # n_dft / 2 + 1 bins without the mel matrix
+        out = torch.empty((B * nblk, F // nblk, nm), dtype=torch.float32, device=h.device)
         ws, n = h.ws_for_wave(B, L)
         with torch.cuda.device(h.device):
             _lib.check(h.lib.mi355asr_melspectrogram(h.ptr, _p(x), B, L, _p(out), _p(ws), n, h._stream()))
@@ -585,9 +591,8 @@ class ConformerCTC(_ModelBase):
                  add_wav_info=False, **kwargs):
         self.name = name
         self.add_wav_info = bool(add_wav_info)
-        if mel_layer_type not in ("Melspectrogram", "leaf"):
-            raise NotImplementedError("mel_layer_type=%r" % mel_layer_type)
-        self.mel_layer_type = mel_layer_type
+        # as in the reference (conformer_blocks.py:309-323): any other value selects the plain Spectrogram layer
+        self.mel_layer_type = mel_layer_type = mel_layer_type if mel_layer_type in ("Melspectrogram", "leaf") else "Spectrogram"
         self.num_classes, self.dmodel = num_classes, dmodel
         self.blank = num_classes - 1               # utils/text_featurizers.py:65-70 (blank_at_zero: False)
         self.num_blocks, self.head_size, self.num_heads, self.kernel_size = num_blocks, head_size, num_heads, kernel_size
@@ -601,7 +606,7 @@ class ConformerCTC(_ModelBase):
                           chunk_size=self.chunk_size, has_encoder=1, num_classes=num_classes,
                           ctc_num_blocks=ctcdecoder_num_blocks, ctc_kernel_size=ctcdecoder_kernel_size,
                           ctc_fc_factor=ctcdecoder_fc_factor, gemm_dtype=_gemm_dtype(gemm_dtype),
-                          mel_layer_type=int(mel_layer_type == "leaf"), add_wav_info=int(self.add_wav_info))
+                          mel_layer_type=_MEL_LAYER_CODE[mel_layer_type], add_wav_info=int(self.add_wav_info))
         self._h = _Handle(cfg, device)
 
     @classmethod
@@ -619,7 +624,8 @@ class ConformerCTC(_ModelBase):
 
     def _expected_shapes(self):
         s = _encoder_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks, self.n_mels,
-                            leaf=self.mel_layer_type == "leaf", add_wav_info=self.add_wav_info)
+                            leaf=self.mel_layer_type == "leaf", add_wav_info=self.add_wav_info,
+                            spectrogram=self.mel_layer_type == "Spectrogram")
         s.update(_ctc_shapes(self.dmodel, self.num_heads, self.head_size, self.ctc_kernel, self.ctc_blocks,
                              self.num_classes))
         return s

@@ -447,6 +447,23 @@ def test_prefix_beam_device_search_equals_host_search(torch_cuda, beam):
             assert hyp(d, 0) == hyp(h, 0) or (n > 1 and h[2][b, 0] == h[2][b, 1])
 
 
+def test_plain_spectrogram_frontend_encoder_parity(torch_cuda):
+    """mel_layer_type = anything but 'Melspectrogram' / 'leaf' builds the plain Spectrogram layer in the reference
+    (conformer_blocks.py:318-323): 513 dB bins straight into the subsampling convs (F2 = 129, Dense 129 d -> d)."""
+    from tensorflowasr_amd.models import ConformerEncoder
+    cfg = dict(small_cfg(1), mel_layer_type="Spectrogram")
+    w = co.encoder_weights(cfg, seed=9)
+    assert "mel_layer/freq2mel" not in w and w["conv_subsampling/linear/kernel"].shape[0] == 129 * cfg["dmodel"]
+    kw = dict(encoder_kwargs(cfg), mel_layer_type="Spectrogram")
+    e = ConformerEncoder(**kw)
+    assert set(e._expected_shapes()) == set(e._h.weight_names())
+    e.load_weights(w, by_name=False)
+    x = waves(2, 16000, 31)
+    ref, inter = co.conformer_encoder(x.astype(np.float64), w, cfg, return_intermediates=True)
+    assert maxdiff(e.melspectrogram(x).cpu().numpy(), inter["mel"]) < 1e-3 * 80      # dB values in [-80, 0]
+    assert maxdiff(e(x).cpu().numpy(), ref) < TOL
+
+
 # ---- row a15: ChunkConformer offline predict (parity unpinned in the reference; oracle = restatement) ----------------
 def _chunk_model(cfg, w):
     from tensorflowasr_amd.models import ChunkConformer

@@ -136,8 +136,16 @@ def test_python_models_mirror_reference_constructor_surface():
                            name="conformer_encoder")
     assert enc.hop_size == 640                                           # conformer_blocks.py:302
     assert enc.count_params() == sum(int(np.prod(v.shape)) for v in co.encoder_weights(cfg, 0).values())
-    with pytest.raises(NotImplementedError):
-        ConformerEncoder(mel_layer_type="Spectrogram")
+    # any other mel_layer_type builds the plain Spectrogram layer, as in the reference (conformer_blocks.py:318-323):
+    # 513 dB bins, no freq2mel, Dense over F2 = 129 subsampled bins
+    sp = ConformerEncoder(mel_layer_type="Spectrogram", num_blocks=1)
+    sp_names = {n: tuple(s) for n, s in sp._names_and_shapes()}
+    assert "mel_layer/freq2mel" not in sp_names and sp_names["mel_layer/real_kernels"] == (1024, 1, 1, 513)
+    assert sp_names["conv_subsampling/linear/kernel"] == (129 * 144, 144)
+    assert set(sp_names) == set(sp._h.weight_names())
+    ow = co.encoder_weights(dict(small_cfg(1), mel_layer_type="Spectrogram"), 0)      # the oracle's tensors (DFT kernels 2-D)
+    assert set(ow) == set(sp_names)
+    assert all(int(np.prod(ow[k].shape)) == int(np.prod(sp_names[k])) for k in ow)
     leaf = ConformerEncoder(mel_layer_type="leaf", num_blocks=1)       # the reference's default frontend
     assert "mel_layer/tfbanks_complex_conv/kernel" in leaf._h.weight_names()
     assert "mel_layer/real_kernels" not in leaf._h.weight_names()
