@@ -77,13 +77,29 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((sizeof(typename P::W) > 8 && CT ==
   // prologue LayerNorm statistics (two-pass, biased variance, eps inside the sqrt: Keras semantics)
   float mean = 0.f, rstd = 1.f;
   if (LN) {
+    // eight row chunks requested at a time: one load per trip costs a memory latency each (32 trips for dmodel 256 --
+    // the whole kernel at streaming sizes, where nothing else covers it)
     float s = 0.f;
-    for (int kb = 0; kb < KB; ++kb) { const f32x4 v = ldg4(xr + 16 * kb); s += (v.x + v.y) + (v.z + v.w); }
+    for (int kb0 = 0; kb0 < KB; kb0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ldg4(xr + 16 * min(kb0 + i, KB - 1));
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (kb0 + i < KB) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
     mean = group_sum(s) / (float)a.K;
     float q = 0.f;
-    for (int kb = 0; kb < KB; ++kb) {
-      const f32x4 d = ldg4(xr + 16 * kb) - splat4(mean);
-      q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    for (int kb0 = 0; kb0 < KB; kb0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ldg4(xr + 16 * min(kb0 + i, KB - 1));
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (kb0 + i < KB) {
+          const f32x4 d = v[i] - splat4(mean);
+          q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
     }
     rstd = 1.0f / sqrtf(group_sum(q) / (float)a.K + a.eps);
   }
