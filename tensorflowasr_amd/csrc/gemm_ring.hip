@@ -93,7 +93,7 @@ DEV Frag<TERMS> split8(f32x4 lo, f32x4 hi) {
 
 struct XRegs { f32x4 lo, hi; };                   // one lane's eight operand values of one k-step, before LN / split
 
-template <int EPI, bool LN, int RT, int RING, int TERMS>
+template <int EPI, bool LN, int RT, int RING, int TERMS, bool EDMA>
 __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u32x4* __restrict__ wring, int cpw) {
   constexpr int GSLAB = GNB * TERMS * 64;
   __shared__ __attribute__((aligned(16))) u32x4 wl[RING][GSLAB];
@@ -109,14 +109,26 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   const int steps = a.K / 32, total = cpw * steps;
   const u32x4* __restrict__ wg = wring + (size_t)chunk0 * steps * GSLAB;
   constexpr int NQ = (GSLAB + GT - 1) / GT;       // DMA instructions per wave and slab: 3, or 1 in bf16 mode
+  // EDMA: only the lower four waves (the ones that split before their MFMAs) issue slab DMAs, twice as many each: an
+  // LDS-DMA instruction holds the issuing wave for ~100 cycles, and the upper waves' MFMAs are what the SIMD should be
+  // doing at the top of a step
+  constexpr int NQE = GSLAB / 64 / (GW / 2);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
 
   // the first RING - 1 slabs
 #pragma unroll
-  for (int st = 0; st < RING - 1; ++st)
+  for (int st = 0; st < RING - 1; ++st) {
+    const u32x4* src = wg + (size_t)min(st, total - 1) * GSLAB;
+    if constexpr (EDMA) {
+      if (wv < GW / 2) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      dma16(wg + (size_t)min(st, total - 1) * GSLAB + GT * q + 64 * wv + lane, &wl[st][GT * q + 64 * wv]);
+        for (int q = 0; q < NQE; ++q) dma16(src + 64 * ((GW / 2) * q + wv) + lane, &wl[st][64 * ((GW / 2) * q + wv)]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) dma16(src + GT * q + 64 * wv + lane, &wl[st][GT * q + 64 * wv]);
+    }
+  }
   if (LN) {
     for (int i = threadIdx.x; i < a.K; i += GT) { p_g[i] = a.ln_g[i]; p_b[i] = a.ln_b[i]; }
   }
@@ -296,19 +308,27 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
     wait(wb, std::integral_constant<int, 0>{});
     mma(wb, std::integral_constant<int, 3>{});
   };
-  auto slab_dma = [&](int st, int slot) {         // slab `st` into a slot last read in step st - RING
+  auto slab_dma = [&](int st, int slot, auto LATE_T) {     // slab `st` into a slot last read in step st - RING
     const u32x4* src = wg + (size_t)min(st, total - 1) * GSLAB;
+    if constexpr (EDMA) {
+      if constexpr (!decltype(LATE_T)::value) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) dma16(src + GT * q + 64 * wv + lane, &wl[slot][GT * q + 64 * wv]);
+        for (int q = 0; q < NQE; ++q) dma16(src + 64 * ((GW / 2) * q + wv) + lane, &wl[slot][64 * ((GW / 2) * q + wv)]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) dma16(src + GT * q + 64 * wv + lane, &wl[slot][GT * q + 64 * wv]);
+    }
   };
   // one k-step; SL = s mod GUNR (slab slot SL % RING, operand stage SL % XST), LATE = this wave splits after its MFMAs
   auto step = [&](int s, int gs, auto SL_T, auto LATE_T) {     // s: step within the chunk, gs: within the slab stream
     constexpr int SL = decltype(SL_T)::value, NX = (SL + 1) % GUNR, PV = (SL + GUNR - 1) % GUNR;
     constexpr bool LATE = decltype(LATE_T)::value;
-    slab_dma(gs + RING - 1, PV % RING);           // the slot of step gs - 1: every wave is past that step's barrier
+    slab_dma(gs + RING - 1, PV % RING, LATE_T);   // the slot of step gs - 1: every wave is past that step's barrier
+    constexpr int NQR = EDMA ? (LATE ? 0 : NQE) : NQ;     // slab pieces this wave issues per step
     __builtin_amdgcn_sched_barrier(0);
     // operand loads of a stage are followed by XST - 1 whole iterations (3 slab pieces + 2 RT loads) and this one's slab
-    constexpr int XAFTER = (XST - 1) * (NQ + 2 * RT) + NQ;
+    constexpr int XAFTER = (XST - 1) * (NQR + 2 * RT) + NQR;
     if constexpr (!LATE) {
       xwait(xq[SL % XST], std::integral_constant<int, XAFTER>{});
       xsplit(s, xq[SL % XST], xa);
@@ -325,7 +345,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
     __builtin_amdgcn_sched_barrier(0);
     // slab s + 1 was issued RING - 2 iterations ago; what was issued after it -- the operand loads of that iteration and
     // everything of the iterations since (3 slab pieces + 2 RT operand loads each) -- may stay in flight
-    constexpr int INFLIGHT = 2 * RT + (RING - 2) * (NQ + 2 * RT);
+    constexpr int INFLIGHT = 2 * RT + (RING - 2) * (NQR + 2 * RT);
     __builtin_amdgcn_s_waitcnt(0x0f70 | (INFLIGHT & 15) | ((INFLIGHT >> 4) << 14));
     // a bare s_barrier: __syncthreads() carries a workgroup fence, for which hipcc waits for vmcnt(0) -- every slab and
     // operand load in flight.  What must be visible after this barrier is the slab of step s + 1 (waited for above by
@@ -434,7 +454,7 @@ __global__ __launch_bounds__(256) void ring_layernorm_rows_kernel(float* y, cons
     stg4(p + i, (ldg4(p + i) - splat4(mean)) * splat4(rstd) * ldg4(g + i) + ldg4(b + i));
 }
 
-template <int EPI, bool LN, int TERMS>
+template <int EPI, bool LN, int TERMS, bool EDMA>
 int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   const int chunks = (EPI == E16_GLU ? a.NT / 2 : a.NT) / (EPI == E16_GLU ? GNB / 2 : GNB);
   // Shape of the launch: RT row tiles per wave (256 or 128 rows per workgroup) and cpw column chunks per workgroup, so
@@ -462,13 +482,13 @@ int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   const int cpw = best_cpw;
   const dim3 grid((a.M + 128 * best_rt - 1) / (128 * best_rt), chunks / cpw);
   if (best_rt == 2 && force_slots != 2)
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4, TERMS>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4, TERMS, EDMA>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
   else if (best_rt == 2)
     return -1;
   else if (force_slots == 2 || (force_slots != 4 && (long)grid.x * grid.y > 320))
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 2, TERMS>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 2, TERMS, EDMA>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
   else
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 4, TERMS>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 4, TERMS, EDMA>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
   return 0;
 }
 
@@ -488,16 +508,16 @@ bool gemm_ring_applicable(int epi, bool ln, const Gemm16Args& a) {
   }
 }
 
-template <int TERMS>
+template <int TERMS, bool EDMA>
 static int launch_terms(int epi, bool ln, const Gemm16Args& a, const void* ring, hipStream_t s) {
   switch (epi) {
-    case E16_BIAS: return go<E16_BIAS, false, TERMS>(a, ring, s);
-    case E16_SWISH: return go<E16_SWISH, true, TERMS>(a, ring, s);
-    case E16_QKV: return go<E16_QKV, true, TERMS>(a, ring, s);
-    case E16_GLU: return go<E16_GLU, true, TERMS>(a, ring, s);
-    case E16_AFFSWISH: return go<E16_AFFSWISH, false, TERMS>(a, ring, s);
+    case E16_BIAS: return go<E16_BIAS, false, TERMS, EDMA>(a, ring, s);
+    case E16_SWISH: return go<E16_SWISH, true, TERMS, EDMA>(a, ring, s);
+    case E16_QKV: return go<E16_QKV, true, TERMS, EDMA>(a, ring, s);
+    case E16_GLU: return go<E16_GLU, true, TERMS, EDMA>(a, ring, s);
+    case E16_AFFSWISH: return go<E16_AFFSWISH, false, TERMS, EDMA>(a, ring, s);
     case E16_RES: {
-      const int rc = go<E16_RES, false, TERMS>(a, ring, s);
+      const int rc = go<E16_RES, false, TERMS, EDMA>(a, ring, s);
       // the optional LayerNorm over the output row needs all of it: a second pass over y (as bf16.hip does for wide rows)
       if (rc == 0 && a.fln_g)
         hipLaunchKernelGGL(ring_layernorm_rows_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a.y, a.fln_g, a.fln_b, a.M, 16 * a.NT, a.ldy, a.eps);
@@ -510,5 +530,8 @@ static int launch_terms(int epi, bool ln, const Gemm16Args& a, const void* ring,
 // terms = 3: fp32 operands exactly split; 1: bf16 mode (ring of host-rounded bf16 weights, activations rounded at the operand)
 int launch_gemm_ring(int epi, bool ln, const Gemm16Args& a, const void* ring, int terms, hipStream_t s) {
   if (!ring || !gemm_ring_applicable(epi, ln, a)) return -1;
-  return terms == 1 ? launch_terms<1>(epi, ln, a, ring, s) : launch_terms<3>(epi, ln, a, ring, s);
+  // MI355ASR_RING_EDMA=0: every wave issues its share of the slab DMAs (the first version) instead of the lower four
+  static const bool edma = [] { const char* v = getenv("MI355ASR_RING_EDMA"); return v ? atoi(v) != 0 : true; }();
+  if (edma) return terms == 1 ? launch_terms<1, true>(epi, ln, a, ring, s) : launch_terms<3, true>(epi, ln, a, ring, s);
+  return terms == 1 ? launch_terms<1, false>(epi, ln, a, ring, s) : launch_terms<3, false>(epi, ln, a, ring, s);
 }
