@@ -413,7 +413,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
       };
       // fragments of G column tiles at a time (one with nine tiles: registers; two with eight), the next group requested
       // before the MFMAs of the current one; lgkmcnt(3 G) = "all but the newest group"
-      auto mfma_cur = [&]() {
+      auto mfma_cur = [&](auto&& after_first_group) {
         constexpr int G = NB % 2 == 0 ? 2 : 1, NG = NB / G;
         const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&wl[cur][lane]);
         u32x4 wa[G][3], wb[G][3];
@@ -454,6 +454,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
             if constexpr (gi + 1 < NG) { fetch(wb, std::integral_constant<int, gi + 1>{}); wait(wa, std::integral_constant<int, 3 * G>{}); }
             else wait(wa, std::integral_constant<int, 0>{});
             mma(wa, GI);
+            if constexpr (gi == 0) after_first_group();
           } else {
             if constexpr (gi + 1 < NG) { fetch(wa, std::integral_constant<int, gi + 1>{}); wait(wb, std::integral_constant<int, 3 * G>{}); }
             else wait(wb, std::integral_constant<int, 0>{});
@@ -461,13 +462,19 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
           }
         });
       };
+      auto nothing = [] {};
       if constexpr (DIAG == 1) {
         slab_dma();
-        mfma_cur();
+        mfma_cur(nothing);
       } else if constexpr (LATE) {
-        slab_dma();
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_cur();
+        // the DMA pieces go out behind the first group of MFMAs: this wave's matrix work starts at once (its partner is in
+        // its VALU phase), and by the end of the MFMAs the pieces have landed -- the vmcnt(0) hipcc puts in front of the
+        // window reads of frags_next() costs nothing
+        mfma_cur([&] {
+          __builtin_amdgcn_sched_barrier(0);
+          slab_dma();
+          __builtin_amdgcn_sched_barrier(0);
+        });
         __builtin_amdgcn_sched_barrier(0);
         frags_next();
       } else {
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
         __builtin_amdgcn_sched_barrier(0);
         slab_dma();
         __builtin_amdgcn_sched_barrier(0);
-        mfma_cur();
+        mfma_cur(nothing);
       }
       __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's part of the slab has landed
       if constexpr (DIAG != 4) __syncthreads();
