@@ -1295,6 +1295,83 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void sublinear_split_kernel(Strea
   }
 }
 
+// The same with loader waves (round 2, as the block ring kernels): nine LDS-DMA instructions per wave and step hold the
+// issuing wave for about as long as its 54 MFMAs take, and with one wave per SIMD nothing overlaps them.  Waves 4..7 only
+// issue the DMAs (the pieces waves 0..3 issued before), wait for "slab s + 1 has landed" and meet the consumers at the
+// barrier; waves 0..3 read, split and multiply.
+__global__ __launch_bounds__(2 * BLOCK_THREADS, 1) void sublinear_split_ld_kernel(StreamGemmArgs a, const u32x4_t* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring0[SL_SLOT], ring1[SL_SLOT], ring2[SL_SLOT], ring3[SL_SLOT];
+  __shared__ __attribute__((aligned(16))) float p_b[D];
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool loader = wave >= WAVES_PER_BLOCK;
+  const int wv = loader ? wave - WAVES_PER_BLOCK : wave;          // piece owner / row tile
+  const int ltid = 64 * wv + lane;
+  const int row0 = blockIdx.x * 64;
+  const int steps = a.K / 32;
+  const float* xsrc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int p = ltid + BLOCK_THREADS * q;
+    const int row = min(row0 + (p & 63), a.M - 1);
+    xsrc[q] = a.x + (size_t)row * a.K + 4 * (p >> 6);
+  }
+  auto fill = [&](int s, u32x4_t* slot) {             // slab of step s -> ring slot (loader waves)
+    const u32x4_t* wsrc = ws + (size_t)s * SL_WFR;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) dma16(wsrc + BLOCK_THREADS * q + 64 * wv + lane, slot + BLOCK_THREADS * q + 64 * wv);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      dma16(reinterpret_cast<const u32x4_t*>(xsrc[q] + 32 * s), slot + SL_WFR + BLOCK_THREADS * q + 64 * wv);
+  };
+  if (loader) {
+    fill(0, ring0);
+    fill(min(1, steps - 1), ring1);
+    fill(min(2, steps - 1), ring2);
+    constexpr int kWait = 0x0f70 | (((SL_RING - 2) * SL_DMA) & 15) | ((((SL_RING - 2) * SL_DMA) >> 4) << 14);
+    __builtin_amdgcn_s_waitcnt(kWait);
+  } else {
+    for (int i = ltid; i < D; i += BLOCK_THREADS) p_b[i] = a.bias[i];
+  }
+  __syncthreads();
+  if (loader) {
+    auto lstep = [&](int s, u32x4_t* refill) {
+      if (s + SL_RING - 1 < steps) fill(s + SL_RING - 1, refill);
+      wait_dma_ahead<SL_DMA, SL_RING - 2>(max(min(SL_RING - 2, steps - 2 - s), 0));
+      __builtin_amdgcn_s_barrier();
+    };
+    int s = 0;
+#pragma unroll 1
+    for (; s + 4 <= steps; s += 4) { lstep(s, ring3); lstep(s + 1, ring0); lstep(s + 2, ring1); lstep(s + 3, ring2); }
+    if (s < steps) lstep(s++, ring3);
+    if (s < steps) lstep(s++, ring0);
+    if (s < steps) lstep(s++, ring1);
+    return;
+  }
+  f32x4 acc[KB];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) acc[i] = lds4(p_b, i, 4 * g);
+  auto step = [&](const u32x4_t* cur) {
+    const f32x4 lo = __builtin_bit_cast(f32x4, cur[SL_WFR + g * 64 + 16 * wv + c]);
+    const f32x4 hi = __builtin_bit_cast(f32x4, cur[SL_WFR + (4 + g) * 64 + 16 * wv + c]);
+    const Split8 xf = split8(lo, hi);
+    split_step<KB>(acc, xf, cur, lane);
+    __builtin_amdgcn_s_barrier();          // the loaders arrive once slab s + 1 has landed; this wave's reads of the slot are done
+  };
+  int s = 0;
+#pragma unroll 1
+  for (; s + 4 <= steps; s += 4) { step(ring0); step(ring1); step(ring2); step(ring3); }
+  if (s < steps) { step(ring0); ++s; }
+  if (s < steps) { step(ring1); ++s; }
+  if (s < steps) { step(ring2); ++s; }
+  const int tok = row0 + 16 * wv + c;
+  if (tok < a.M) {
+    float* yrow = a.y + (size_t)tok * a.ldy;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(yrow + 16 * i + 4 * g, acc[i]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void tail_ff2_kernel(TailFf2Args a) {
   __shared__ __attribute__((aligned(16))) float p_pcb[2 * D], p_bns[2 * D], p_bnt[2 * D], p_pw2b[D], p_lng[D], p_lnb[D], p_b1[4 * D],
@@ -1379,6 +1456,12 @@ int launch_out_glu(const OutGluArgs& a, hipStream_t s) {
 // split-bf16 ring-DMA kernel for the subsampling Dense; ws = pack_split32 fragments padded to 1792 per step
 int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s) {
   if (a.NT != KB || a.K % 32 != 0 || a.M <= 0 || !ws) return -1;
+  // MI355ASR_SUBLINEAR_LD=0: every wave issues its own DMAs (round 1) instead of the loader-wave kernel
+  static const bool ld = [] { const char* v = getenv("MI355ASR_SUBLINEAR_LD"); return v ? atoi(v) != 0 : true; }();
+  if (ld)
+    hipLaunchKernelGGL(sublinear_split_ld_kernel, dim3((a.M + 63) / 64), dim3(2 * BLOCK_THREADS), 0, s, a,
+                       reinterpret_cast<const u32x4_t*>(ws));
+  else
   hipLaunchKernelGGL(sublinear_split_kernel, dim3((a.M + 63) / 64), dim3(BLOCK_THREADS), 0, s, a,
                      reinterpret_cast<const u32x4_t*>(ws));
   return 0;

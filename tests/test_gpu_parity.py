@@ -1251,7 +1251,8 @@ enc = maxdiff(e(wav).cpu().numpy(), co.conformer_encoder(wav.astype(np.float64),
 print("RESULT %.3e %.3e" % (blk, enc))
 '''
     for extra in ({"MI355ASR_OUTGLU_SPLIT": "1"}, {"MI355ASR_OUTGLU_SPLIT": "0"}, {"MI355ASR_SUBCONV_F32": "1"},
-                  {"MI355ASR_SUBLINEAR_SPLIT": "2"}, {"MI355ASR_SUBLINEAR_SPLIT": "0"}, {"MI355ASR_FF1QKV_RING": "0"},
+                  {"MI355ASR_SUBLINEAR_SPLIT": "2"}, {"MI355ASR_SUBLINEAR_SPLIT": "0"},
+                  {"MI355ASR_SUBLINEAR_SPLIT": "2", "MI355ASR_SUBLINEAR_LD": "0"}, {"MI355ASR_FF1QKV_RING": "0"},
                   {"MI355ASR_TAILFF2_RING": "0"}):
         env = dict(os.environ, MI355ASR_SMALL_M="0", **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
