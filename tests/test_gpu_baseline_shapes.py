@@ -12,6 +12,8 @@ oracle's unless the oracle's own margin between the two candidates is inside ten
 fp32 forward cannot resolve such a frame against an fp64 one -- the reference's TF fp32 forward could not either);
 those frames are listed, bounded in number, and the ids must then equal the collapse of the oracle argmax with exactly
 those frames patched.  Nothing is skipped."""
+import os
+
 import numpy as np
 import pytest
 
@@ -241,3 +243,59 @@ def test_config5_chunk_conformer_2x30s_stages_and_beam_vs_oracle(torch_cuda):
                 assert abs(sa[hyp] - sb[hyp]) < 1e-4 * counts[u] + 1e-3
         print("config 5 beam %d: %d / %d hypotheses identical in rank, %d in common" % (beam, same, tot, common))
         assert common >= 0.9 * tot
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dmodel 256 / 512 at the benched row counts: the slab-ring GEMM path against the kernels it replaces
+# ---------------------------------------------------------------------------------------------------------------
+def test_ring_gemm_at_16000_rows_equals_the_fp32_and_bf16_kernels(torch_cuda, tmp_path):
+    """gemm_ring.hip takes over from 4096 rows on, where the oracle is too slow to follow (its own parity tests force it
+    for small batches).  Here the launch shapes of the benched sizes themselves -- ConformerM and ConformerL on 64 x 10 s
+    (16 000 rows: two row tiles per wave, several column chunks per workgroup), and the bf16 CTC decoder on 64 x 260
+    history frames -- against the same build with MI355ASR_GEMM_RING=0 (fp32-MFMA chains / per-wave bf16 streams, both
+    pinned to the oracle at small sizes)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from helpers import co, waves
+from tensorflowasr_amd.models import ConformerCTC, CTCDecoder
+out = {}
+x = waves(64, 160000, 77)
+for name, kw in (("M", dict(dmodel=256, num_blocks=2, head_size=64, num_heads=4)), ("L", dict(dmodel=512, num_blocks=1, head_size=64, num_heads=8))):
+    m = ConformerCTC(1332, **kw)
+    m._build(seed=3)
+    enc = m.encode(x)
+    logits = m.ctc_logits(enc)
+    out[name + "_enc"] = enc.cpu().numpy()[::7]
+    out[name + "_logits"] = logits.cpu().numpy()[::7]
+    del m
+    torch.cuda.empty_cache()
+ctc = CTCDecoder(num_classes=1332, dmodel=256, num_blocks=1, head_size=64, num_heads=4, kernel_size=32, fc_factor=0.5,
+                 gemm_dtype="bfloat16")
+ctc._build(seed=4)
+h = torch.from_numpy(np.random.default_rng(5).standard_normal((64, 260, 256)).astype(np.float32)).cuda()
+lg, am = ctc(h, return_argmax=True)
+out["bf16_logits"] = lg.cpu().numpy()
+out["bf16_argmax"] = am.cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    res = {}
+    for tag, extra in (("ring", {}), ("plain", {"MI355ASR_GEMM_RING": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True,
+                           timeout=1200, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(f)
+    for k in ("M_enc", "M_logits", "L_enc", "L_logits"):
+        d = maxdiff(res["ring"][k], res["plain"][k])
+        print(k, "ring vs fp32-MFMA kernels: max |d| = %.3g" % d)
+        assert d < TOL, (k, d)
+        assert np.abs(res["plain"][k]).max() > 0.1                      # not a comparison of zeros
+    # bf16 mode: same rounding points, other summation order -- a handful of activations land on the other side of a
+    # bf16 rounding boundary (one bf16 ulp each)
+    e = np.abs(res["ring"]["bf16_logits"] - res["plain"]["bf16_logits"])
+    agree = float((res["ring"]["bf16_argmax"] == res["plain"]["bf16_argmax"]).mean())
+    print("bf16 CTC decoder, ring vs per-wave kernels: max %.3g mean %.3g, argmax agreement %.4f" % (e.max(), e.mean(), agree))
+    assert e.max() < 4e-2 and e.mean() < 1e-3 and agree > 0.99
