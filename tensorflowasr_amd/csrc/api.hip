@@ -195,6 +195,12 @@ void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, i
       }
   ab.ring_pairs.emplace_back(p16_off, ab.put(ring));
 }
+// The class head W[K, V] as a slab ring: V padded with zero columns to whole chunks of 128 (the kernel never looks at
+// classes >= V).
+void put_ring_head(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int V) {
+  if (K % 128 != 0 || V < 1) return;
+  put_ring(ab, p16_off, [&](int k, int n) { return n < V ? f(k, n) : 0.f; }, K, ceil_div(V, 128) * 128, false);
+}
 // MI355ASR_GEMM_RING=0: the dense layers of dmodel 256 / 512 stay on the fp32-MFMA kernels (chain2 / gemm16<PF32>), or
 // in bf16 mode on gemm16<PBf16>
 bool ring_packs_wanted(const mi355asr_model* m) {
@@ -1354,6 +1360,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
     const int ct = gemm_ct(d, EPI_HEAD);
     m->NT_fc = ceil_div(ceil_div(V, 16), ct) * ct;
     o_fw = ab.put(pack_p16([&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, m->NT_fc));
+    if (ring_packs_wanted(m)) put_ring_head(ab, o_fw, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V);
     o_fb = ab.put_padded(m->host["fully_connected/bias"].data.data(), V, (size_t)m->NT_fc * 16);
   }
   if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }

@@ -22,6 +22,7 @@
 // X is re-read and re-split per column chunk (N / 128 times); at 48-96 MFMAs per ~60 VALU instructions of split that
 // is hidden, and the re-reads come from L2.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -355,11 +356,40 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   };
   // ---- epilogue of one column chunk: lane holds Y[token c of row tile rt][feature 16 * tile + g4 + 0..3]
   const int half = a.NT / 2;
+  float best_v[RT];
+  int best_i[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) { best_v[rt] = -INFINITY; best_i[rt] = 0; }
   auto epilogue = [&](int chunk) {
     float* yrow[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) yrow[rt] = a.y + (size_t)tok[rt] * a.ldy;
-    if constexpr (EPI == E16_GLU) {
+    for (int rt = 0; rt < RT; ++rt) yrow[rt] = a.y ? a.y + (size_t)tok[rt] * a.ldy : nullptr;
+    if constexpr (EPI == E16_HEAD) {
+      // logits (optional) + running arg-max over the classes this lane sees; the ring is padded to whole chunks, the
+      // bias to NT tiles: tiles past NT and classes past n_valid do not exist
+#pragma unroll
+      for (int i = 0; i < GNB; ++i) {
+        const int tile = chunk * GNB + i, f0 = 16 * tile + g4;
+        if (tile < a.NT) {                    // wave-uniform
+          const f32x4 bv = ldg4(a.bias + f0);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 v = acc[rt][i] + bv;
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (f0 + j < a.n_valid && vv[j] > best_v[rt]) { best_v[rt] = vv[j]; best_i[rt] = f0 + j; }   // first maximum wins
+            if (yrow[rt] && live[rt]) {
+              if (f0 + 3 < a.n_valid && (a.ldy & 3) == 0) stg4(yrow[rt] + f0, v);
+              else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (f0 + j < a.n_valid) yrow[rt][f0 + j] = vv[j];
+            }
+          }
+        }
+        if (i & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (EPI == E16_GLU) {
 #pragma unroll
       for (int i = 0; i < GNB / 2; ++i) {
         const int f0 = 16 * (chunk * (GNB / 2) + i) + g4;
@@ -427,6 +457,23 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   // written: keep them until the loads have landed
 #pragma unroll
   for (int st = 0; st < XST; ++st) xwait(xq[st], std::integral_constant<int, 0>{});
+  if constexpr (EPI == E16_HEAD) {
+    // the four lane groups of a token hold disjoint classes: max over the groups, lowest class on ties
+    if (a.argmax_out) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float bv = best_v[rt];
+        int bi = best_i[rt];
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+          const float ov = __shfl_xor(bv, off);
+          const int oi = __shfl_xor(bi, off);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (live[rt] && lane < 16) a.argmax_out[tok[rt]] = bi;
+      }
+    }
+  }
 }
 
 // y[row] = LayerNorm(y[row]) in place, one wave per row (two-pass statistics, Keras semantics): the block's final
@@ -456,7 +503,7 @@ __global__ __launch_bounds__(256) void ring_layernorm_rows_kernel(float* y, cons
 
 template <int EPI, bool LN, int TERMS, bool EDMA>
 int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
-  const int chunks = (EPI == E16_GLU ? a.NT / 2 : a.NT) / (EPI == E16_GLU ? GNB / 2 : GNB);
+  const int chunks = EPI == E16_HEAD ? (a.NT + GNB - 1) / GNB : (EPI == E16_GLU ? a.NT / 2 : a.NT) / (EPI == E16_GLU ? GNB / 2 : GNB);
   // Shape of the launch: RT row tiles per wave (256 or 128 rows per workgroup) and cpw column chunks per workgroup, so
   // that the workgroups come as close as possible to a whole number of rounds over the 256 CUs (short K: every
   // workgroup pays a prologue -- first slabs, LayerNorm statistics -- worth several k-steps, and a second, half-empty
@@ -468,9 +515,11 @@ int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   int best_rt = 1, best_cpw = 1;
   double best = 1e30;
   for (int rt = 2; rt >= 1; --rt) {
-    if (force_rt && rt != force_rt) continue;
+    if (EPI == E16_HEAD && rt == 2) continue;               // the head runs one row tile per wave (registers)
+    if (EPI != E16_HEAD && force_rt && rt != force_rt) continue;
     const int rows = (a.M + 128 * rt - 1) / (128 * rt);
     for (int cpw = chunks; cpw >= 1; --cpw) {
+      if (EPI == E16_HEAD && cpw != chunks) continue;       // the arg-max needs every class of a row in one workgroup
       if (chunks % cpw != 0 || (force_cpw && cpw != std::min(force_cpw, chunks) && chunks % std::min(force_cpw, chunks) == 0)) continue;
       const long wgs = (long)rows * (chunks / cpw);
       const long rounds = (wgs + 255) / 256;
@@ -481,9 +530,10 @@ int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   }
   const int cpw = best_cpw;
   const dim3 grid((a.M + 128 * best_rt - 1) / (128 * best_rt), chunks / cpw);
-  if (best_rt == 2 && force_slots != 2)
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4, TERMS, EDMA>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
-  else if (best_rt == 2)
+  if (best_rt == 2 && force_slots != 2) {
+    if constexpr (EPI != E16_HEAD)
+      hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4, TERMS, EDMA>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
+  } else if (best_rt == 2)
     return -1;
   else if (force_slots == 2 || (force_slots != 4 && (long)grid.x * grid.y > 320))
     hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 2, TERMS, EDMA>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);
@@ -496,10 +546,13 @@ int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
 
 // Shapes the ring kernel takes; the pack (api.hip: pack_ring) exists for the dense layers of dmodel 256 / 512 blocks.
 bool gemm_ring_applicable(int epi, bool ln, const Gemm16Args& a) {
+  if (a.K % 128 != 0 || a.K < 128 || (a.ldx & 3) != 0) return false;
+  if (epi == E16_HEAD)                          // logits optional; the ring is padded to whole chunks of 8 tiles
+    return !ln && a.NT >= 1 && a.n_valid <= 16 * a.NT && (a.y || a.argmax_out) && a.rpb == 0;
   const int ntc = epi == E16_GLU ? a.NT / 2 : a.NT;
-  if (a.K % 128 != 0 || a.K < 128 || ntc % (epi == E16_GLU ? 4 : 8) != 0 || a.n_valid != (epi == E16_GLU ? 16 * ntc : 16 * a.NT)) return false;
+  if (ntc % (epi == E16_GLU ? 4 : 8) != 0 || a.n_valid != (epi == E16_GLU ? 16 * ntc : 16 * a.NT)) return false;
   if (ln && a.K > GLN_MAX) return false;
-  if ((a.ldx & 3) != 0 || (a.ldy & 3) != 0 || !a.y) return false;
+  if ((a.ldy & 3) != 0 || !a.y) return false;
   switch (epi) {
     case E16_BIAS: return !ln;
     case E16_SWISH: case E16_QKV: case E16_GLU: return ln;
@@ -516,6 +569,7 @@ static int launch_terms(int epi, bool ln, const Gemm16Args& a, const void* ring,
     case E16_QKV: return go<E16_QKV, true, TERMS, EDMA>(a, ring, s);
     case E16_GLU: return go<E16_GLU, true, TERMS, EDMA>(a, ring, s);
     case E16_AFFSWISH: return go<E16_AFFSWISH, false, TERMS, EDMA>(a, ring, s);
+    case E16_HEAD: return go<E16_HEAD, false, TERMS, EDMA>(a, ring, s);
     case E16_RES: {
       const int rc = go<E16_RES, false, TERMS, EDMA>(a, ring, s);
       // the optional LayerNorm over the output row needs all of it: a second pass over y (as bf16.hip does for wide rows)

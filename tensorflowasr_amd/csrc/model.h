@@ -238,6 +238,7 @@ std::vector<float> pack_split32(const std::function<float(int, int)>& f, int K, 
 void append_slabs(std::vector<float>& stream, const std::function<float(int, int)>& f, int K, int N, bool group_major);
 // W[K, N] as the slab ring of gemm_ring.hip, registered in ab.ring_pairs against the P16 pack at p16_off
 void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int N, bool glu);
+void put_ring_head(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int V);
 bool ring_packs_wanted(const mi355asr_model* m);
 void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base);
 FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vector<float>& im, int n_dft, int nb);

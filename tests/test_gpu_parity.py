@@ -1024,7 +1024,11 @@ for base, L in ((co.CONFORMER_M, 32000), (co.CONFORMER_L, 24000)):
     enc_ref = co.conformer_encoder(x.astype(np.float64), w, cfg)
     logits_ref = co.ctc_decoder(enc_ref, w, cfg)
     enc = m.encode(x)
-    logits = m.ctc_logits(enc)
+    logits, amax = m.ctc_logits(enc, return_argmax=True)
+    assert (amax.cpu().numpy() == logits.cpu().numpy().argmax(-1)).all()      # the head's fused arg-max (first maximum)
+    ids, lens = m.recognize(x)                                                  # logits not materialised on this path
+    rid, rlen = co.ctc_greedy(logits.cpu().numpy(), [logits.shape[1]] * 3, 199)
+    assert (ids.cpu().numpy() == rid).all() and (lens.cpu().numpy() == rlen).all()
     res += [maxdiff(enc.cpu().numpy(), enc_ref), maxdiff(logits.cpu().numpy(), logits_ref)]
 print("RESULT " + " ".join("%.3e" % v for v in res))
 '''
