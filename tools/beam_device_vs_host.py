@@ -1,3 +1,7 @@
+"""Lists every hypothesis in which the device prefix search (beam_device.hip) and the host search (beam.hip) differ, for the
+input mix of tests/test_gpu_parity.py::test_prefix_beam_device_search_equals_host_search: score, length, positions that
+differ, and whether the sets of hypotheses agree.  Differences are expected only inside groups of equal float score (the
+reference leaves their order to std::sort / std::nth_element).  Run on a GPU box: python tools/beam_device_vs_host.py"""
 import numpy as np, torch, sys
 sys.path.insert(0, ".")
 from tensorflowasr_amd.models import ctc_prefix_beam_decode
