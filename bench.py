@@ -199,11 +199,28 @@ def main():
     T = model.prepare(B, L)
     h = model._h
 
+    pending = []                                                 # RCCL work handles of the batches still in exchange
+
+    # data-parallel runs rotate three output sets: the ids of batch n travel over RCCL (its own stream) while batch
+    # n + 1 is recognised into the next set
+    rot = [(torch.empty((B, T), dtype=torch.int32, device=device), torch.empty((B,), dtype=torch.int32, device=device))
+           for _ in range(3)] if use_dist else None
+    nstep = [0]
+
     def step():
-        ids, lens = model.recognize(wav, reuse_buffers=True)     # the C-ABI call writes into pre-allocated outputs
         if use_dist:
-            return all_gather_ids(ids, lens)
-        return ids, lens
+            ids, lens = model.recognize(wav, out=rot[nstep[0] % 3])
+            nstep[0] += 1
+            if os.environ.get("MI355ASR_BENCH_DEBUG_NO_GATHER") == "1":     # diagnosis only: what the exchange itself costs
+                return ids, lens
+            # every handle is waited for before the timed region ends; at most two exchanges are left in flight, so a
+            # buffer set is never rewritten while its exchange reads it
+            work, all_ids, all_lens = all_gather_ids(ids, lens, async_op=True)
+            pending.append(work)
+            while len(pending) > 2:
+                pending.pop(0).wait()
+            return all_ids, all_lens
+        return model.recognize(wav, reuse_buffers=True)          # the C-ABI call writes into pre-allocated outputs
 
     lib = _lib.lib()
     nk = len(_lib.KERNEL_NAMES)
@@ -217,6 +234,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step()
+        while pending:
+            pending.pop().wait()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -230,6 +249,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    while pending:
+        pending.pop().wait()
     # region 1: the headline number -- exactly K steps, no instrumentation
     _lib.check(lib.mi355asr_profile_enable(h.ptr, 0))
     elapsed = timed_region(args.steps)

@@ -642,11 +642,13 @@ class ConformerCTC(_ModelBase):
         self._lens = torch.empty((B,), dtype=torch.int32, device=h.device)
         return T
 
-    def recognize(self, wav, input_length=None, reuse_buffers=False):
+    def recognize(self, wav, input_length=None, reuse_buffers=False, out=None):
         """wav [B,L(,1)] on device -> (ids int32 [B,T] padded -1, lengths int32 [B]).  Asynchronous.
         reuse_buffers=True returns the model's own pre-allocated output tensors (no allocation, no copy -- what the
         C-ABI call writes into); the NEXT recognize() of the same shape overwrites them, so only use it when the
-        results are consumed before the next call."""
+        results are consumed before the next call.  out=(ids, lens): the C-ABI call writes into these contiguous int32
+        device tensors of shapes [B, T] and [B] instead (a caller that keeps several batches in flight, e.g. while
+        their ids travel over RCCL, rotates its own buffers)."""
         h = self._h
         if not h.built:
             self._build()
@@ -660,11 +662,16 @@ class ConformerCTC(_ModelBase):
         il = None
         if input_length is not None:
             il = h.to_device(input_length, torch.int32)
+        o_ids, o_lens = (self._ids, self._lens) if out is None else out
+        if out is not None and not (o_ids.is_cuda and o_ids.dtype == torch.int32 and o_ids.is_contiguous() and
+                                    tuple(o_ids.shape) == (B, T) and o_lens.is_cuda and o_lens.dtype == torch.int32 and
+                                    o_lens.is_contiguous() and tuple(o_lens.shape) == (B,)):
+            raise ValueError("out=(ids, lens): contiguous int32 device tensors of shapes [%d, %d] and [%d]" % (B, T, B))
         with torch.cuda.device(h.device):
-            _lib.check(h.lib.mi355asr_recognize(h.ptr, _p(x), B, L, _p(il), _p(self._ids), _p(self._lens), _p(ws), n,
+            _lib.check(h.lib.mi355asr_recognize(h.ptr, _p(x), B, L, _p(il), _p(o_ids), _p(o_lens), _p(ws), n,
                                                 h._stream()))
-        if reuse_buffers:
-            return self._ids, self._lens
+        if reuse_buffers or out is not None:
+            return o_ids, o_lens
         return self._ids.clone(), self._lens.clone()
 
     __call__ = recognize

@@ -34,11 +34,28 @@ def broadcast_weights(weights, src=0, device=None, group=None):
     return out
 
 
-def all_gather_ids(ids, lens, group=None):
+def all_gather_ids(ids, lens, group=None, async_op=False):
     """ids int32 [B_local, T] (-1 padded), lens int32 [B_local] -> ([B_total, T], [B_total]) on every rank,
-    in rank order (requires equal B_local on all ranks, which shard_range gives when world | B_total)."""
+    in rank order (requires equal B_local on all ranks, which shard_range gives when world | B_total).
+
+    async_op=True returns (work, ids_all, lens_all) at once: the collective runs on RCCL's stream behind the kernels
+    already queued, the caller's stream goes on with the next batch and `work.wait()` (or a device synchronise) makes
+    the views valid -- one batch's exchange then overlaps the next batch's recognition."""
     world = dist.get_world_size(group)
     B, T = ids.shape
+    if async_op:
+        # nothing on the caller's stream: the two tensors go out as they are (the caller keeps them untouched until the
+        # work is done -- rotating output buffers, recognize(out=...)), both collectives on RCCL's stream
+        all_ids = torch.empty((world * B, T), dtype=ids.dtype, device=ids.device)
+        all_lens = torch.empty((world * B,), dtype=lens.dtype, device=lens.device)
+        w1 = dist.all_gather_into_tensor(all_ids, ids, group=group, async_op=True)
+        w2 = dist.all_gather_into_tensor(all_lens, lens, group=group, async_op=True)
+
+        class _Both:
+            def wait(self):
+                w1.wait()
+                w2.wait()
+        return _Both(), all_ids, all_lens
     # one collective per batch: the lengths ride in an extra column of the id matrix (xGMI is latency-, not
     # bandwidth-bound at 64 KB per rank, so the second all_gather would double the exchange time)
     packed = torch.empty((B, T + 1), dtype=ids.dtype, device=ids.device)

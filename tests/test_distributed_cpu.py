@@ -43,6 +43,14 @@ def _worker(rank, world, port, tmpdir):
         all_ids, all_lens = all_gather_ids(torch.from_numpy(ids), torch.from_numpy(lens))
         full_ids, full_lens = co.ctc_collapse(frames, in_len, blank)
         assert np.array_equal(all_ids.numpy(), full_ids) and np.array_equal(all_lens.numpy(), full_lens)
+        # the pipelined form bench.py uses: several exchanges in flight, waited for at the end
+        works = []
+        for shift in range(3):
+            w_, a_ids, a_lens = all_gather_ids(torch.from_numpy(ids + shift), torch.from_numpy(lens), async_op=True)
+            works.append((w_, a_ids, a_lens, shift))
+        for w_, a_ids, a_lens, shift in works:
+            w_.wait()
+            assert np.array_equal(a_ids.numpy(), full_ids + shift) and np.array_equal(a_lens.numpy(), full_lens)
         open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
