@@ -391,12 +391,13 @@ bool use_gemm16(const mi355asr_model* m) {
   return force || m->cfg.gemm_dtype == 1 || (m->cfg.dmodel != 144 && m->cfg.dmodel != 256) ||
          (m->cfg.dmodel == 256 && !m->ring_of.empty());
 }
-// Few rows (single utterances, small batches, the Translator's token stream): the fused / chained kernels give each
-// 16-row tile to ONE wave that walks a whole run of layers serially (~70 us per fused kernel however small M is); below
-// ~4k rows most SIMDs idle meanwhile, and one launch per layer with K / column splitting is faster (64 x 10 s: 4.5 ms
-// fused vs 8.5 ms; 16 x 10 s: 3.0 vs 2.6 ms; one 10 s utterance: 2.6 vs 1.4 ms).  MI355ASR_SMALL_M overrides.
+// Few rows (single utterances, the Translator's token stream): the fused kernels give each 16-row tile to ONE wave that
+// walks a whole run of layers serially -- a fused launch takes as long for 250 rows as for 16 000 -- and one launch per
+// layer with K / column splitting is faster.  With the round-2 ring kernels the crossover is at ~800 rows (10 s
+// utterances, ms per batch, fused vs layer-at-a-time: B = 1: 1.67 vs 1.41, 2: 1.69 vs 1.54, 4: 1.70 vs 1.74, 8: 1.76 vs
+// 2.20, 16: 1.92 vs 2.60; the round-1 kernels crossed at ~4k rows).  MI355ASR_SMALL_M overrides.
 bool gemm16_for(const mi355asr_model* m, size_t M) {
-  static const long small_m = [] { const char* v = getenv("MI355ASR_SMALL_M"); return v ? atol(v) : 4096L; }();
+  static const long small_m = [] { const char* v = getenv("MI355ASR_SMALL_M"); return v ? atol(v) : 800L; }();
   return use_gemm16(m) || (long)M <= small_m;
 }
 int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s) {

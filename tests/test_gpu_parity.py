@@ -151,23 +151,25 @@ def test_conformer_block_parity(enc2, B, T):
 
 
 def test_conformer_block_is_batch_size_invariant_per_path(enc2):
-    """The block runs through one of three kernel families depending on the row count (layer-at-a-time below 4 096
-    rows, fused above, two row tiles per wave in the chained kernels from 65 536): inside a family an utterance's result
-    does not depend on what else is in the batch (bit-identical), across families it agrees to fp32 rounding."""
+    """The block runs through one of two kernel families depending on the row count (layer-at-a-time up to 800 rows,
+    fused ring kernels above): inside a family an utterance's result does not depend on what else is in the batch
+    (bit-identical), across families it agrees to fp32 rounding."""
     e, w, _ = enc2
     rng = np.random.default_rng(11)
     x = rng.standard_normal((8, 250, 144)).astype(np.float32)
     big = np.tile(x, (34, 1, 1))                       # 272 x 250 = 68 000 tokens
-    mid = np.tile(x, (4, 1, 1))                        # 32 x 250 = 8 000 tokens (fused)
-    small = e.conformer_block(0, x).cpu().numpy()      # 2 000 tokens (layer-at-a-time)
+    mid = np.tile(x, (4, 1, 1))                        # 32 x 250 = 8 000 tokens
+    few = e.conformer_block(0, x).cpu().numpy()        # 2 000 tokens: fused as well
     got = e.conformer_block(0, big).cpu().numpy()
     gmid = e.conformer_block(0, mid).cpu().numpy()
     assert np.array_equal(got[:8], got[-8:]) and np.array_equal(gmid[:8], gmid[-8:])
-    assert np.array_equal(got[:8], gmid[:8])
-    assert np.array_equal(e.conformer_block(0, x[:3]).cpu().numpy(), small[:3])
-    assert maxdiff(got[:8], small) < 2e-5
+    assert np.array_equal(got[:8], gmid[:8]) and np.array_equal(got[:8], few)
+    lat = e.conformer_block(0, x[:3]).cpu().numpy()    # 750 tokens: layer-at-a-time
+    assert np.array_equal(e.conformer_block(0, x[:2]).cpu().numpy(), lat[:2])
+    assert np.array_equal(e.conformer_block(0, x[:1]).cpu().numpy(), lat[:1])
+    assert maxdiff(got[:3], lat) < 2e-5
     ref = co.conformer_block(x[:1].astype(np.float64), w, "conformer_block_0", 36)
-    assert maxdiff(got[:1], ref) < TOL
+    assert maxdiff(got[:1], ref) < TOL and maxdiff(lat[:1], ref) < TOL
 
 
 def test_encoder_parity_two_blocks(enc2):

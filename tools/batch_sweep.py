@@ -1,4 +1,6 @@
-"""recognize() ms/step and audio-frames/s of ConformerCTC(S), 10 s utterances, over the batch size."""
+"""recognize() ms/step and audio-frames/s of ConformerCTC(S), 10 s utterances, over the batch size.
+
+    python tools/batch_sweep.py [B1,B2,...]        (MI355ASR_SMALL_M=<rows> moves the fused / layer-at-a-time threshold)"""
 import json
 import sys
 import time
@@ -12,7 +14,8 @@ L = 160000
 m = ConformerCTC(1332)
 m._build()
 out = {}
-for B in (1, 8, 16, 32, 64, 128, 256):
+BATCHES = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 8, 16, 32, 64, 128, 256]
+for B in BATCHES:
     x = torch.randn(B, L, device="cuda:0") * 0.1
     m.prepare(B, L)
     for _ in range(3):
