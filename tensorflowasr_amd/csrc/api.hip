@@ -403,7 +403,9 @@ bool gemm16_for(const mi355asr_model* m, size_t M) {
 int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s) {
   // long batches of dmodel 256 / 512: the same layer with the weights as a slab ring shared by eight waves
   // (gemm_ring.hip): fp32 operands exactly split into three bf16 terms, or one bf16 term in bf16 mode
-  static const long ring_min_m = [] { const char* v = getenv("MI355ASR_RING_MIN_M"); return v ? atol(v) : 4096L; }();
+  // crossover measured with 10 s utterances (tools/model_batch_sweep.py; ms per batch, ring vs per-wave streams):
+  // ConformerM B = 4: 3.81 vs 3.10, 8: 4.09 vs 4.26, 16: 4.47 vs 5.19; ConformerL 4: 6.95 vs 6.57, 8: 7.59 vs 9.63, 16: 10.3 vs 18.5
+  static const long ring_min_m = [] { const char* v = getenv("MI355ASR_RING_MIN_M"); return v ? atol(v) : 1500L; }();
   if ((long)g.M >= ring_min_m && !m->ring_of.empty()) {
     const auto it = m->ring_of.find(wp);
     g.wp = wp;

@@ -249,7 +249,7 @@ def test_config5_chunk_conformer_2x30s_stages_and_beam_vs_oracle(torch_cuda):
 # dmodel 256 / 512 at the benched row counts: the slab-ring GEMM path against the kernels it replaces
 # ---------------------------------------------------------------------------------------------------------------
 def test_ring_gemm_at_16000_rows_equals_the_fp32_and_bf16_kernels(torch_cuda, tmp_path):
-    """gemm_ring.hip takes over from 4096 rows on, where the oracle is too slow to follow (its own parity tests force it
+    """gemm_ring.hip takes over from 1500 rows on, where the oracle is too slow to follow (its own parity tests force it
     for small batches).  Here the launch shapes of the benched sizes themselves -- ConformerM and ConformerL on 64 x 10 s
     (16 000 rows: two row tiles per wave, several column chunks per workgroup), and the bf16 CTC decoder on 64 x 260
     history frames -- against the same build with MI355ASR_GEMM_RING=0 (fp32-MFMA chains / per-wave bf16 streams, both

@@ -1005,7 +1005,7 @@ def test_head_size_64_block_at_streaming_ctc_lengths(torch_cuda, T):
 
 
 def test_ring_gemm_path_of_m_and_l_in_a_subprocess(torch_cuda):
-    """gemm_ring.hip (dense layers of dmodel 256 / 512 on the split-bf16 pipe, taken from 4096 rows on) forced for a small
+    """gemm_ring.hip (dense layers of dmodel 256 / 512 on the split-bf16 pipe, taken from 1500 rows on) forced for a small
     batch (MI355ASR_RING_MIN_M=1): encoder and CTC logits against the oracle for ConformerM and ConformerL, with one and
     with two row tiles per wave (partial tiles in both), the two-slot ring of the one-tile shape, several column chunks per workgroup, and the fp32 kernels it replaces (MI355ASR_GEMM_RING=0)."""
     import subprocess
