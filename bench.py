@@ -52,11 +52,12 @@ S_CFG = dict(dmodel=144, reduction_factor=4, num_blocks=13, head_size=36, num_he
 NUM_CLASSES = 1332    # pinyin vocabulary 1331 + blank (test_asr.py:180)
 
 
-def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES, stft_mode=0):
+def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES, stft_mode=0, mel_nnz=None):
     """ALGORITHMIC flops per launch of each kernel category, counted as the reference computes the op
     (1 MAC = 2 flop).  The STFT is priced by what the selected kernel executes: the dense DFT conv
     the reference runs (time_frequency.py:108-115) for stft_mode 0, the two 32-point DFT stages of the 32x32
-    Cooley-Tukey kernel for stft_mode 1 (8x fewer flops for the same spectrum -- not credited as dense flops)."""
+    Cooley-Tukey kernel for stft_mode 1 (8x fewer flops for the same spectrum -- not credited as dense flops).  The mel
+    projection likewise: the banded kernel multiplies the non-zeros of freq2mel only (mel_nnz of 513 x 80)."""
     d, k, H = cfg["dmodel"], cfg["kernel_size"], cfg["num_heads"]
     F = -(-L // 160)
     T1 = -(-F // 2)
@@ -66,7 +67,7 @@ def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES, stft_mode=0):
     return {
         "stft": 2.0 * 2 * B * F * 1024 * 513 if stft_mode == 0 else 2.0 * B * F * (32 * 32 * 64 + 32 * 64 * 32),
         "utt_max": 0.0,
-        "mel": 2.0 * B * F * 513 * 80,
+        "mel": 2.0 * B * F * (513 * 80 if mel_nnz is None else mel_nnz),
         "subconv": 2.0 * B * T1 * F1 * d * 9 + 2.0 * B * T * F2 * d * 9 * d,
         "sublinear": 2.0 * M * (F2 * d) * d,
         "ffn": 2.0 * 2 * M * d * 4 * d,
@@ -323,7 +324,12 @@ def main():
         frames_per_utt = L // 160
         total_frames = world * B * frames_per_utt * args.steps
         value = total_frames / elapsed
-        fl = algorithmic_flops(B, L, stft_mode=int(lib.mi355asr_stft_mode(h.ptr)))
+        # the banded mel kernel runs unless MI355ASR_MEL_BAND=0 (the default freq2mel has no filter wider than 64 bins)
+        mel_nnz = None
+        if os.environ.get("MI355ASR_MEL_BAND", "1") != "0":
+            from tensorflowasr_amd import frontend_consts
+            mel_nnz = int(np.count_nonzero(frontend_consts.freq2mel(16000, 1024, 80)))
+        fl = algorithmic_flops(B, L, stft_mode=int(lib.mi355asr_stft_mode(h.ptr)), mel_nnz=mel_nnz)
         kern = {}
         for i, name in enumerate(_lib.KERNEL_NAMES):
             if cnt[i]:

@@ -176,6 +176,48 @@ FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vecto
 }
 
 
+MelBandOff pack_mel_band(ArenaBuilder& ab, const std::vector<float>& f2m, int nb, int n_mels) {
+  MelBandOff o;
+  // MI355ASR_MEL_BAND=0: always the dense mel GEMM
+  static const bool on = [] { const char* v = getenv("MI355ASR_MEL_BAND"); return v ? atoi(v) != 0 : true; }();
+  if (!on) return o;
+  std::vector<int> band(2 * (size_t)n_mels, 0);
+  int bw = 4;
+  for (int m = 0; m < n_mels; ++m) {
+    int lo = -1, hi = -1;
+    for (int k = 0; k < nb; ++k)
+      if (f2m[(size_t)k * n_mels + m] != 0.f) { if (lo < 0) lo = k; hi = k; }
+    if (lo >= 0) { band[2 * m] = lo; band[2 * m + 1] = hi - lo + 1; bw = std::max(bw, hi - lo + 1); }
+  }
+  if (bw > 64) return o;
+  bw = (bw + 3) & ~3;
+  const int lp = ((nb + 15) / 16) * 16;                          // the kernel reads bins [lo, lo + bw) of a row of >= lp floats
+  for (int m = 0; m < n_mels; ++m)
+    if (band[2 * m] + bw > lp) return o;
+  std::vector<float> w((size_t)n_mels * bw, 0.f);
+  for (int m = 0; m < n_mels; ++m)
+    for (int j = 0; j < band[2 * m + 1]; ++j) w[(size_t)m * bw + j] = f2m[(size_t)(band[2 * m] + j) * n_mels + m];
+  std::vector<float> band_f(band.size());
+  std::memcpy(band_f.data(), band.data(), band.size() * sizeof(int));   // the arena is a float array: raw bits
+  o.band = ab.put(band_f);
+  o.bw = ab.put(w);
+  o.BW = bw;
+  o.ok = true;
+  return o;
+}
+void use_mel_band(mi355asr_model* m, const MelBandOff& o, const float* base) {
+  m->mel_band = o.ok ? reinterpret_cast<const int*>(base + o.band) : nullptr;
+  m->mel_bw = o.ok ? base + o.bw : nullptr;
+  m->mel_BW = o.ok ? o.BW : 0;
+}
+int launch_mel_auto(const mi355asr_model* m, MelArgs& me, hipStream_t s) {
+  if (m->mel_band) {
+    me.band = m->mel_band; me.bw = m->mel_bw; me.BW = m->mel_BW;
+    if (launch_mel_band(me, s) == 0) return 0;
+  }
+  return launch_mel(me, s);
+}
+
 // Slab ring of gemm_ring.hip: [N / 128 chunks][K / 32 steps][8 column tiles][3 terms][64 lanes][8 bf16]; a GLU layer's
 // chunk holds four value tiles and the four gate tiles that go with them.
 void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int N, bool glu) {
@@ -719,7 +761,7 @@ int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, fl
   me.B = Bp; me.F = F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
   me.NM = c.n_mels; me.FT = FT; me.floor_db = -80.0f;
   if (c.mel_layer_type == 2) { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_db_norm(me, s), "dB (Spectrogram layer)"); }
-  else { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel(me, s), "dB + mel"); }
+  else { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel_auto(m, me, s), "dB + mel"); }
   return 0;
 }
 
@@ -1189,6 +1231,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   ab.ring_terms = m->cfg.gemm_dtype == 1 ? 1 : 3;
   size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0;
   FftOff fo;
+  MelBandOff mbo;
   std::vector<BlockOff> eo, co;
   size_t o_leafw = 0, o_leafs = 0, o_lg = 0, o_la = 0, o_ld = 0, o_lr = 0, o_ls = 0, o_lga = 0, o_lbe = 0;
   if (c.has_encoder && c.mel_layer_type == 1) {
@@ -1263,6 +1306,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   if (c.mel_layer_type == 0) {
   const auto& f2m = m->host["mel_layer/freq2mel"].data;
   o_mel = ab.put(pack_p16([&](int k, int n) { return k < nb ? f2m[(size_t)k * c.n_mels + n] : 0.f; }, dm.KBm * 16, c.n_mels, dm.NTm));
+  mbo = pack_mel_band(ab, f2m, nb, c.n_mels);
   }
   }
   (void)nb;
@@ -1377,6 +1421,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   register_rings(m, ab, base);
   m->dft_wp = base + o_dft; m->mel_wp = base + o_mel;
   m->fft_ok = fo.ok;
+  use_mel_band(m, mbo, base);
   m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;
   m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = ((d == 144 || d == 256 || d == 512) && c.has_encoder) ? base + o_c2s : nullptr;

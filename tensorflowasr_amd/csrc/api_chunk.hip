@@ -139,6 +139,7 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   const auto& f2m = m->host["front/mel_layer/freq2mel"].data;
   const size_t o_mel = ab.put(pack_p16([&](int k, int n) { return k < nb ? f2m[(size_t)k * c.n_mels + n] : 0.f; },
                                        dm.KBm * 16, c.n_mels, dm.NTm));
+  const MelBandOff mbo = pack_mel_band(ab, f2m, nb, c.n_mels);
   const size_t o_c1w = ab.put(m->host["front/conv_subsampling/conv1/kernel"].data);
   const size_t o_c1b = ab.put(m->host["front/conv_subsampling/conv1/bias"].data);
   const auto& c2 = m->host["front/conv_subsampling/conv2/kernel"].data;
@@ -166,6 +167,7 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   register_rings(m, ab, base);
   m->dft_wp = base + o_dft; m->mel_wp = base + o_mel;
   m->fft_ok = fo.ok;
+  use_mel_band(m, mbo, base);
   m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;
   m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
@@ -403,7 +405,7 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     me.logp = st.logp; me.umax = nullptr; me.mel = (float*)(ws + p.mel); me.wp = m->mel_wp;
     me.B = B; me.F = g.F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
     me.NM = c.n_mels; me.FT = FT; me.floor_db = 0.f;
-    { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel(me, s), "mel (valid)"); }
+    { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel_auto(m, me, s), "mel (valid)"); }
     SubConvArgs sa{};
     sa.mel = me.mel; sa.out = (float*)(ws + p.sub); sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
     sa.B = B; sa.F = g.F; sa.NM = c.n_mels; sa.T1 = g.T1; sa.F1 = m->dm.F1; sa.T2 = T; sa.F2 = m->dm.F2;
@@ -550,7 +552,7 @@ int mi355asr_chunk_front_stream(mi355asr_model* m, const float* wav, int32_t Lw,
   me.logp = logp; me.umax = nullptr; me.mel = mel; me.wp = m->mel_wp;
   me.B = 1; me.F = F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
   me.NM = c.n_mels; me.FT = FT; me.floor_db = 0.f;
-  { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel(me, s), "mel (valid)"); }
+  { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel_auto(m, me, s), "mel (valid)"); }
   // new_sub = [sub cache ; last nf mel frames]  (ConvSubsampling.stream_call :75)
   const size_t mrow = (size_t)c.n_mels * 4;
   if (S > 0) HIP_TRY(hipMemcpyAsync(new_sub, sub_cache, S * mrow, hipMemcpyDeviceToDevice, s));

@@ -167,6 +167,83 @@ __global__ __launch_bounds__(BLOCK_THREADS) void mel_kernel(MelArgs a) {
   }
 }
 
+// dB normalisation + mel projection for a BANDED freq2mel -- what backend.mel() builds: triangular filters, each over a few
+// dozen neighbouring bins, 90 % of the 513 x 80 matrix is zero.  The dense GEMM above spends 77 TFLOP/s of fp32 MFMA on
+// those zeros (69 us: MFMA-bound); this kernel reads the 135 MB of log-power once (HBM-bound) and does ~1000 FMAs per frame.
+// A workgroup stages 16 normalised frames in LDS; thread t sums outputs t, t + 256, ... (frame-major, mel-minor).
+// finalize chooses it when every filter's support is at most MEL_BW bins (a trained, dense freq2mel keeps mel_kernel).
+constexpr int MEL_BW = 64, MEL_FT = 16;
+__global__ __launch_bounds__(256) void mel_band_kernel(MelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];    // rows [MEL_FT][RS] | weights [NM][BW] | band [NM][2]
+  const int nbins = a.nbins, RS = ((nbins + 15) / 16) * 16, RS4 = RS / 4;   // staged row: the bins, padded to 16 (<= LP)
+  float* rows = lds;
+  float* wl = lds + MEL_FT * RS;
+  int* bl = reinterpret_cast<int*>(wl + a.NM * a.BW);
+  const int b = blockIdx.y, f0 = blockIdx.x * MEL_FT;
+  const int nf = min(MEL_FT, a.F - f0);
+  const bool norm = a.umax != nullptr;
+  const float um = norm ? a.umax[b] : 0.f, floor_db = a.floor_db;
+  const float* __restrict__ src = a.logp + ((size_t)b * a.F + f0) * a.LP;
+  // every load of the workgroup -- rows, band weights, band table -- is requested before the first is used (a load per
+  // trip would cost a memory latency each: the whole kernel): up to RMAX + WMAX float4 per thread in flight
+  constexpr int RMAX = 9, WMAX = 5;            // 16 rows x 132 float4 / 256 threads; 80 x 64 floats / 4 / 256
+  const int NM = a.NM, BW = a.BW;
+  const int total = nf * RS4, wtotal = NM * BW / 4;
+  f32x4 vv[RMAX], ww[WMAX];
+  int kk[RMAX];
+#pragma unroll
+  for (int u = 0; u < RMAX; ++u) {
+    const int i = min((int)threadIdx.x + 256 * u, total - 1);
+    const int fr = i / RS4;
+    kk[u] = 4 * (i - fr * RS4);
+    vv[u] = ldg4(src + (size_t)fr * a.LP + kk[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < WMAX; ++u) ww[u] = reinterpret_cast<const f32x4*>(a.bw)[min((int)threadIdx.x + 256 * u, wtotal - 1)];
+  const int bnd = threadIdx.x < 2 * NM ? a.band[threadIdx.x] : 0;
+#pragma unroll
+  for (int u = 0; u < RMAX; ++u) {
+    const int i = threadIdx.x + 256 * u, k = kk[u];
+    if (i < total) {
+      f32x4 v = vv[u];
+      if (norm) { v.x = fmaxf(v.x - um, floor_db); v.y = fmaxf(v.y - um, floor_db); v.z = fmaxf(v.z - um, floor_db); v.w = fmaxf(v.w - um, floor_db); }
+      // the padding bins of a row meet zero weights below: they must be finite
+      v.x = k + 0 < nbins ? v.x : 0.f; v.y = k + 1 < nbins ? v.y : 0.f; v.z = k + 2 < nbins ? v.z : 0.f; v.w = k + 3 < nbins ? v.w : 0.f;
+      reinterpret_cast<f32x4*>(rows)[i] = v;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < WMAX; ++u)
+    if ((int)threadIdx.x + 256 * u < wtotal) reinterpret_cast<f32x4*>(wl)[threadIdx.x + 256 * u] = ww[u];
+  if (threadIdx.x < 2 * NM) bl[threadIdx.x] = bnd;
+  __syncthreads();
+  for (int o = threadIdx.x; o < nf * NM; o += 256) {
+    const int fr = o / NM, m = o - fr * NM;
+    const int lo = bl[2 * m], len4 = (bl[2 * m + 1] + 3) & ~3;     // weights are zero-padded to BW, rows to RS >= lo + BW
+    const float* x = rows + fr * RS + lo;
+    const float* w = wl + m * BW;
+    float acc = 0.f;
+#pragma unroll 2
+    for (int j = 0; j < len4; j += 4) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + j);
+      acc = __builtin_fmaf(x[j + 0], w4.x, acc);
+      acc = __builtin_fmaf(x[j + 1], w4.y, acc);
+      acc = __builtin_fmaf(x[j + 2], w4.z, acc);
+      acc = __builtin_fmaf(x[j + 3], w4.w, acc);
+    }
+    a.mel[((size_t)b * a.F + f0 + fr) * NM + m] = acc;
+  }
+}
+int launch_mel_band(const MelArgs& a, hipStream_t s) {
+  if (!a.band || !a.bw || a.BW > MEL_BW || (a.BW & 3) != 0 || (a.LP & 3) != 0) return -1;
+  const int RS = ((a.nbins + 15) / 16) * 16;
+  // the kernel's fixed load counts: 16 rows of RS floats in 9 float4 per thread, the band weights in 5, the table in 1
+  if (RS > a.LP || MEL_FT * (RS / 4) > 9 * 256 || a.NM * a.BW / 4 > 5 * 256 || 2 * a.NM > 256) return -1;
+  const size_t lds = ((size_t)MEL_FT * RS + (size_t)a.NM * a.BW + 2 * (size_t)a.NM) * sizeof(float);
+  hipLaunchKernelGGL(mel_band_kernel, dim3((a.F + MEL_FT - 1) / MEL_FT, a.B), dim3(256), lds, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // dB normalisation alone: the plain Spectrogram layer (time_frequency.py:7-123 with return_decibel_spectrogram = True --
 // mel_layer_type 'Spectrogram', conformer_blocks.py:318-323): out[b, f, k] = max(logp[b, f, k] - max_b, -80), k < nbins.
 // Melspectrogram is this followed by freq2mel (mel_kernel above does both in one pass).

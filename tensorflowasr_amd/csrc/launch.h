@@ -101,6 +101,11 @@ struct MelArgs {
   const float* wp;    // packed freq2mel [KBm][NTm][64][4]
   int B, F, LP, nbins, KBm, NTm, NM, FT;
   float floor_db;
+  // banded form of freq2mel (mel_band_kernel), or null: band[m] = (first bin, number of bins) of mel filter m, bw[m][j] =
+  // its weight at bin first + j, rows of BW floats
+  const int* band = nullptr;
+  const float* bw = nullptr;
+  int BW = 0;
 };
 struct SubConvArgs {
   const float* mel;   // [B, F, NM]
@@ -269,6 +274,7 @@ int launch_dwconv(int K, const DwArgs& a, hipStream_t s);
 int launch_stft(const StftArgs& a, hipStream_t s);
 int launch_utt_max(const UttMaxArgs& a, int B, hipStream_t s);
 int launch_mel(const MelArgs& a, hipStream_t s);
+int launch_mel_band(const MelArgs& a, hipStream_t s);   // freq2mel as the banded matrix it is (triangular filters): HBM-bound
 int launch_db_norm(const MelArgs& a, hipStream_t s);   // mel_layer_type 'Spectrogram': the dB normalisation without the mel matrix
 int launch_subconv(int D, const SubConvArgs& a, hipStream_t s);
 int launch_subconv144(const SubConvArgs& a, hipStream_t s);

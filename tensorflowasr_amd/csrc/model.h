@@ -106,6 +106,10 @@ struct mi355asr_model {
               *c2_b = nullptr, *lin_wp = nullptr, *lin_b = nullptr, *proj_wp = nullptr, *proj_b = nullptr,
               *fc_wp = nullptr, *fc_b = nullptr;
   int NT_fc = 0;
+  // freq2mel as a banded matrix (mel_band_kernel) when every filter's support is narrow, else null (pack_mel_band)
+  const int* mel_band = nullptr;
+  const float* mel_bw = nullptr;
+  int mel_BW = 0;
   // FFT-as-GEMM STFT operands; fft_ok only when the loaded DFT kernels are window * exp(-2 pi i k n / N) (pack_fft)
   bool fft_ok = false;
   const float *fft_w1p = nullptr, *fft_w2p = nullptr, *fft_twc = nullptr, *fft_tws = nullptr, *fft_win = nullptr;
@@ -189,6 +193,11 @@ struct ArenaBuilder {
 };
 
 struct FftOff { bool ok = false; size_t w1 = 0, w2 = 0, twc = 0, tws = 0, win = 0; };
+struct MelBandOff { bool ok = false; size_t band = 0, bw = 0; int BW = 0; };
+// band form of freq2mel [nb, n_mels] for mel_band_kernel; ok = false when a filter spans more than 64 bins (a trained, dense matrix)
+MelBandOff pack_mel_band(ArenaBuilder& ab, const std::vector<float>& f2m, int nb, int n_mels);
+void use_mel_band(mi355asr_model* m, const MelBandOff& o, const float* base);
+int launch_mel_auto(const mi355asr_model* m, MelArgs& me, hipStream_t s);   // banded kernel when available, else the GEMM
 
 struct BlockOff {
   size_t ff_ln_g[2], ff_ln_b[2], ff_w1p[2], ff_b1[2], ff_w2p[2], ff_b2[2];

@@ -65,6 +65,29 @@ def test_melspectrogram_parity(enc2, L, scale):
     assert maxdiff(got, ref) < TOL
 
 
+def test_melspectrogram_with_a_dense_trained_filterbank(torch_cuda):
+    """backend.mel()'s triangular filters run through the banded kernel; a freq2mel whose filters have wide support (the
+    layer is trainable: mel_layer_trainable) must take the dense GEMM -- and a banded one with a few wide filters too."""
+    from tensorflowasr_amd.models import ConformerEncoder
+    cfg = small_cfg(1)
+    x = waves(2, 16000, 41)
+    rng = np.random.default_rng(3)
+    base = co.encoder_weights(cfg, seed=2)
+    for kind in ("dense", "one_wide_filter", "banded"):
+        w = dict(base)
+        f2m = base["mel_layer/freq2mel"].copy()
+        if kind == "dense":
+            f2m = (f2m + 1e-3 * rng.standard_normal(f2m.shape)).astype(np.float32)
+        elif kind == "one_wide_filter":
+            f2m[100:300, 7] = 0.01
+        w["mel_layer/freq2mel"] = f2m
+        e = ConformerEncoder(**encoder_kwargs(cfg))
+        e.load_weights(w, by_name=False)
+        got = e.melspectrogram(x).cpu().numpy()
+        ref = co.melspectrogram(x.astype(np.float64), w)
+        assert maxdiff(got, ref) < TOL, kind
+
+
 def test_melspectrogram_silence_and_padding_dependence(enc2):
     """dB max-normalisation makes features depend on the (zero-padded) utterance as a whole; all-zero input hits
     the amin floor everywhere (max-normalised to 0 dB)."""
@@ -1258,7 +1281,8 @@ print("RESULT %.3e %.3e" % (blk, enc))
 '''
     for extra in ({"MI355ASR_OUTGLU_SPLIT": "1"}, {"MI355ASR_OUTGLU_SPLIT": "0"}, {"MI355ASR_SUBCONV_F32": "1"},
                   {"MI355ASR_SUBLINEAR_SPLIT": "2"}, {"MI355ASR_SUBLINEAR_SPLIT": "0"},
-                  {"MI355ASR_SUBLINEAR_SPLIT": "2", "MI355ASR_SUBLINEAR_LD": "0"}, {"MI355ASR_FF1QKV_RING": "0"},
+                  {"MI355ASR_SUBLINEAR_SPLIT": "2", "MI355ASR_SUBLINEAR_LD": "0"}, {"MI355ASR_MEL_BAND": "0"},
+                  {"MI355ASR_FF1QKV_RING": "0"},
                   {"MI355ASR_TAILFF2_RING": "0"}):
         env = dict(os.environ, MI355ASR_SMALL_M="0", **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
