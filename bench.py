@@ -40,7 +40,7 @@ def kernel_peak(name):
     if name == "sublinear" and int(os.environ.get("MI355ASR_SUBLINEAR_SPLIT", "1") or 0):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     ring = {"ff1_qkv": ("MI355ASR_FF1QKV_RING", "2"), "tail_ff2": ("MI355ASR_TAILFF2_RING", "2"), "out_glu": ("MI355ASR_OUTGLU_SPLIT", "3"),
-            "tail_ff1": ("MI355ASR_TAILFF2_RING", "2")}
+            "tail_ff1": ("MI355ASR_TAILFF2_RING", "2"), "ctc_head": ("MI355ASR_HEAD_RING", "1")}
     if name in ring and int(os.environ.get(*ring[name]) or 0):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA"

@@ -251,6 +251,22 @@ bool ring_packs_wanted(const mi355asr_model* m) {
 }
 void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base) {
   for (const auto& pr : ab.ring_pairs) m->ring_of[base + pr.first] = base + pr.second;
+  m->head_of.clear();
+  for (const auto& hp : ab.head_pairs) m->head_of[base + hp.p16] = {base + hp.slabs, hp.groups};
+}
+void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int d, int V) {
+  if (d != 144 || V < 1) return;
+  const int groups = ceil_div(ceil_div(V, 16), 9);
+  std::vector<float> st;
+  append_slabs(st, [&](int k, int n) { return n < V ? f(k, n) : 0.f; }, d, 144 * groups, true);
+  ab.head_pairs.push_back({p16_off, ab.put(st), groups});
+}
+int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s) {
+  // a launch of the ring kernel costs as much for 250 rows as for 16 000: from 2048 rows on
+  if (m->cfg.gemm_dtype != 0 || m->head_of.empty() || hd.M < 2048) return -1;
+  const auto it = m->head_of.find(hd.wp);
+  if (it == m->head_of.end()) return -1;
+  return launch_head_ld(hd, it->second.first, it->second.second, s);
 }
 
 BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k,
@@ -970,7 +986,11 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   hd.x = sc.xa; hd.y = logits; hd.wp = m->fc_wp; hd.bias = m->fc_b;
   hd.M = M; hd.NT = m->NT_fc; hd.ldy = m->cfg.num_classes; hd.n_valid = m->cfg.num_classes; hd.eps = kLnEps;
   hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
-  { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "ctc head"); }
+  {
+    PROF(MI355ASR_K_CTC_HEAD);
+    if (try_head_ld(m, hd, s) == 0) return 0;
+    LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "ctc head");
+  }
   return 0;
 }
 
@@ -1408,6 +1428,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
     m->NT_fc = ceil_div(ceil_div(V, 16), ct) * ct;
     o_fw = ab.put(pack_p16([&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, m->NT_fc));
     if (ring_packs_wanted(m)) put_ring_head(ab, o_fw, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V);
+    put_head_slabs(ab, o_fw, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V);
     o_fb = ab.put_padded(m->host["fully_connected/bias"].data.data(), V, (size_t)m->NT_fc * 16);
   }
   if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }

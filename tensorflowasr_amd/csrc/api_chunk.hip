@@ -74,6 +74,7 @@ StackOff pack_stack(mi355asr_model* m, ArenaBuilder& ab, const std::string& pref
     so.NT_fc = ceil_div(ceil_div(V, 16), ct) * ct;
     so.fc_w = ab.put(pack_p16([&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, so.NT_fc));
     if (ring_packs_wanted(m)) put_ring_head(ab, so.fc_w, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V);
+    put_head_slabs(ab, so.fc_w, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V);
     so.fc_b = ab.put_padded(m->host[prefix + "/fully_connected/bias"].data.data(), V, (size_t)so.NT_fc * 16);
   }
   return so;
@@ -107,7 +108,10 @@ int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int 
     hd.x = sc.xa; hd.y = logits; hd.wp = st.fc_wp; hd.bias = st.fc_b;
     hd.M = M; hd.NT = st.NT_fc; hd.ldy = st.num_classes; hd.n_valid = st.num_classes; hd.eps = kLnEps;
     hd.argmax_out = amax;
-    { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "fully_connected"); }
+    {
+      PROF(MI355ASR_K_CTC_HEAD);
+      if (try_head_ld(m, hd, s) != 0) LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "fully_connected");
+    }
   }
   return 0;
 }

@@ -1112,6 +1112,77 @@ __global__ __launch_bounds__(LD_THREADS) void out_glu_ld_kernel(OutGluArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// CTC class head for dmodel 144 on the slab ring (round 2): logits = x W + b over V classes (1332: 84 column tiles, swept
+// in groups of nine like q / k / v above, the last group padded with zero columns), per-frame arg-max fused (first
+// maximum wins, as test_asr.py's argmax over the softmax), logits stored only when asked for.  The fp32-MFMA
+// gemm_rows_kernel<HEAD> it replaces ran 66-72 us (91 TFLOP/s); this is G x 5 slabs of the same stream design.
+// slabs: append_slabs(W padded to 144 G columns, group_major) -- group g = column tiles 9 g .. 9 g + 8, five steps each.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LD_THREADS) void head_ld_kernel(GemmArgs a, const u32x4_t* __restrict__ slabs, int groups) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wv >= WAVES_PER_BLOCK) {
+    RingLoader<5>{ring, slabs, nullptr, KS32X * groups, KS32X * groups, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    return;
+  }
+  const WaveCtx c = wave_ctx(a.M);
+  RingReader<5> st{ring, c.lane};
+  f32x4 xs[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x + c.row + 16 * kb + c.g4);
+  Split8 xf[KS32X];
+#pragma unroll
+  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], 2 * t + 1 < KB ? xs[2 * t + 1 < KB ? 2 * t + 1 : 0] : splat4(0.f));
+  st.sync();
+  WG3 wg;
+  grp_prime(wg, st.cur_addr());
+  float best_v = -INFINITY;
+  int best_i = 0;
+#pragma unroll 1
+  for (int g = 0; g < groups; ++g) {
+    // the group's bias rides in the accumulators: requested before the slabs, landed long before the epilogue reads it
+    f32x4 acc[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) acc[i] = KB * g + i < a.NT ? ldg4(a.bias + 16 * (KB * g + i) + c.g4) : splat4(0.f);
+    static_for<0, KS32X>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      slab_step_p(acc, xf[t], wg, st.cur_addr(), st.next_addr());
+      st.advance();
+    });
+    const WaveCtx e = wave_ctx_fresh(a.M);
+    float* yrow = a.y ? a.y + (size_t)e.tok * a.ldy : nullptr;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int tile = KB * g + i, f0 = 16 * tile + e.g4;
+      if (tile < a.NT) {                         // wave-uniform: the bias holds NT tiles; the rest are padding columns
+        const f32x4 v = acc[i];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (f0 + j < a.n_valid && vv[j] > best_v) { best_v = vv[j]; best_i = f0 + j; }
+        if (yrow && e.live) {
+          if (f0 + 3 < a.n_valid && (a.ldy & 3) == 0) stg4(yrow + f0, v);
+          else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (f0 + j < a.n_valid) yrow[f0 + j] = vv[j];
+        }
+      }
+    }
+  }
+  // the four lane groups of a token hold disjoint classes: max over the groups, lowest class on ties
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) {
+    const float ov = __shfl_xor(best_v, off);
+    const int oi = __shfl_xor(best_i, off);
+    if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+  }
+  const WaveCtx e = wave_ctx_fresh(a.M);
+  if (a.argmax_out && e.live && c.lane < 16) a.argmax_out[e.tok] = best_i;
+  if (a.maxval_out && e.live && c.lane < 16) a.maxval_out[e.tok] = best_v;
+}
+
+
 constexpr int KS32 = 5;                       // 32-wide steps over K = 144 (the last half step is zero)
 constexpr int OG_SLAB = 2 * KB * 3 * 64;      // fragments of the larger slab (18 tiles)
 
@@ -1454,6 +1525,15 @@ int launch_out_glu(const OutGluArgs& a, hipStream_t s) {
   return 0;
 }
 // split-bf16 ring-DMA kernel for the subsampling Dense; ws = pack_split32 fragments padded to 1792 per step
+int launch_head_ld(const GemmArgs& a, const float* slabs, int groups, hipStream_t s) {
+  // MI355ASR_HEAD_RING=0: the fp32-MFMA gemm_rows_kernel<HEAD>
+  static const bool on = [] { const char* v = getenv("MI355ASR_HEAD_RING"); return v ? atoi(v) != 0 : true; }();
+  if (!on || !slabs || groups < 1 || a.NT > KB * groups || a.M <= 0) return -1;
+  const int tiles = (a.M + 15) / 16;
+  hipLaunchKernelGGL(head_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(slabs), groups);
+  return 0;
+}
+
 int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s) {
   if (a.NT != KB || a.K % 32 != 0 || a.M <= 0 || !ws) return -1;
   // MI355ASR_SUBLINEAR_LD=0: every wave issues its own DMAs (round 1) instead of the loader-wave kernel

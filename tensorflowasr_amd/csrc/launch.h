@@ -273,6 +273,7 @@ int launch_attention_split(int HS, const AttnArgs& a, hipStream_t s);
 int launch_dwconv(int K, const DwArgs& a, hipStream_t s);
 int launch_stft(const StftArgs& a, hipStream_t s);
 int launch_utt_max(const UttMaxArgs& a, int B, hipStream_t s);
+int launch_head_ld(const GemmArgs& a, const float* slabs, int groups, hipStream_t s);   // dmodel-144 class head on the slab ring; -1: not taken
 int launch_mel(const MelArgs& a, hipStream_t s);
 int launch_mel_band(const MelArgs& a, hipStream_t s);   // freq2mel as the banded matrix it is (triangular filters): HBM-bound
 int launch_db_norm(const MelArgs& a, hipStream_t s);   // mel_layer_type 'Spectrogram': the dB normalisation without the mel matrix

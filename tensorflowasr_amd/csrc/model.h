@@ -102,6 +102,8 @@ struct mi355asr_model {
   const void* w16(const float* p) const { return arena16 + (p - arena); }
   // fp32 P16 pack -> split-bf16 slab ring of the same matrix (gemm_ring.hip; dmodel 256 / 512 dense layers)
   std::unordered_map<const float*, const float*> ring_of;
+  // dmodel 144: class-head P16 pack -> (slab stream of head_ld_kernel, column groups)
+  std::unordered_map<const float*, std::pair<const float*, int>> head_of;
   const float *dft_wp = nullptr, *mel_wp = nullptr, *c1_w = nullptr, *c1_b = nullptr, *c2_wp = nullptr,
               *c2_b = nullptr, *lin_wp = nullptr, *lin_b = nullptr, *proj_wp = nullptr, *proj_b = nullptr,
               *fc_wp = nullptr, *fc_b = nullptr;
@@ -179,6 +181,9 @@ struct ArenaBuilder {
   // mi355asr_model::ring_of once the arena is on the device
   std::vector<std::pair<size_t, size_t>> ring_pairs;
   int ring_terms = 3;   // 3: fp32 weights as three bf16 terms; 1: bf16 mode (round-to-nearest-even bf16)
+  // (offset of a dmodel-144 class head's P16 pack, offset of its slab stream for head_ld_kernel, column groups of nine tiles)
+  struct HeadPair { size_t p16, slabs; int groups; };
+  std::vector<HeadPair> head_pairs;
   size_t put(const std::vector<float>& v) {
     size_t off = (buf.size() + 63) & ~(size_t)63;  // 256-byte alignment
     buf.resize(off + v.size());
@@ -250,6 +255,10 @@ void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, i
 void put_ring_head(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int V);
 bool ring_packs_wanted(const mi355asr_model* m);
 void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base);
+// W[144, V] of a class head as the slab stream of head_ld_kernel (fused.hip), registered against its P16 pack
+void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int d, int V);
+// the head on the slab ring when the handle has a stream for hd.wp (fp32 mode, dmodel 144); -1: not taken
+int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s);
 FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vector<float>& im, int n_dft, int nb);
 BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k, bool keras_mha = false);
 BlockDev resolve(const BlockOff& o, const float* base);
