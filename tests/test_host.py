@@ -704,7 +704,7 @@ def test_chunk_checkpoint_keys_map_onto_every_chunk_tensor():
 
 
 @pytest.mark.parametrize("tag,dom,dom_kernel", [("r01h", "tail_ff2", "tail_ff2_ring_kernel"), ("r02a", "tail_ff1", "tail_ff1_ld_kernel"),
-                                                ("r02b", "tail_ff1", "tail_ff1_ld_kernel"), ("r02c", "tail_ff1", "tail_ff1_ld_kernel"), ("r02d", "tail_ff1", "tail_ff1_ld_kernel")])
+                                                ("r02b", "tail_ff1", "tail_ff1_ld_kernel"), ("r02c", "tail_ff1", "tail_ff1_ld_kernel"), ("r02d", "tail_ff1", "tail_ff1_ld_kernel"), ("r02e", "tail_ff1", "tail_ff1_ld_kernel")])
 def test_profile_artifacts_and_kernel_categories(tag, dom, dom_kernel):
     """the committed rocprofv3 summary of a round's final build names every kernel of the step, tools/summarize_rocprof.py
     files each of them under a category that bench.py's kernel table knows, and the rocprof duration of the dominant
