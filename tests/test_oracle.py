@@ -112,6 +112,36 @@ def test_mel_filterbank_properties():
     assert abs((peaks[2] - peaks[1]) - (peaks[1] - peaks[0])) <= 1
 
 
+def test_mel_filters_are_narrow_bands_which_the_banded_kernel_relies_on():
+    """mel_band_kernel (frontend.hip) is chosen when every column of freq2mel has its non-zeros inside one run of at most 64
+    bins: true for backend.mel()'s triangles (the widest, at the top of the scale, spans 37 bins at 80 mels / 1024-point DFT),
+    and the band form reproduces the dense product exactly as a sum over the band."""
+    from tensorflowasr_amd import frontend_consts
+    f2m = frontend_consts.freq2mel(16000, 1024, 80)                      # [513, 80], what ConformerEncoder._build loads
+    assert np.array_equal(f2m, co.mel_filterbank(16000, 1024, 80, 0.0, 8000.0, False, 1).T)
+    widths, x = [], np.random.default_rng(0).standard_normal((5, 513))
+    banded = np.zeros((5, 80))
+    for m in range(80):
+        nz = np.flatnonzero(f2m[:, m])
+        assert nz.size and np.array_equal(nz, np.arange(nz[0], nz[-1] + 1))     # one contiguous run, no holes
+        widths.append(nz.size)
+        banded[:, m] = x[:, nz[0]:nz[-1] + 1] @ f2m[nz[0]:nz[-1] + 1, m].astype(np.float64)
+    assert max(widths) <= 64 and int(np.count_nonzero(f2m)) == sum(widths) == 1001
+    assert np.allclose(banded, x @ f2m.astype(np.float64), rtol=0, atol=1e-12)
+
+
+def test_plain_spectrogram_layer_is_the_input_of_the_mel_matrix():
+    """Spectrogram.call (time_frequency.py:74-89) is what Melspectrogram.call multiplies by freq2mel (:173-181): the oracle's
+    two frontends must agree on that, and the Spectrogram encoder consumes 513 bins (F2 = 129)."""
+    w = co.encoder_weights(dict(co.CONFORMER_S, num_blocks=0), seed=1)
+    x = np.random.default_rng(2).standard_normal((2, 4000))
+    sp = co.spectrogram(x, w)
+    assert sp.shape == (2, 25, 513) and sp.max() == 0.0 and sp.min() >= -80.0
+    assert np.allclose(co.melspectrogram(x, w), sp @ w["mel_layer/freq2mel"].astype(np.float64))
+    ws = co.encoder_weights(dict(co.CONFORMER_S, num_blocks=0, mel_layer_type="Spectrogram"), seed=1)
+    assert "mel_layer/freq2mel" not in ws and ws["conv_subsampling/linear/kernel"].shape == (129 * 144, 144)
+
+
 def test_conv2d_same_matches_torch():
     import torch
     import torch.nn.functional as F
