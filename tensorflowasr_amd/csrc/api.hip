@@ -129,6 +129,44 @@ void append_slabs(std::vector<float>& stream, const std::function<float(int, int
 }
 
 
+// ---- pair-pipelined streams (fused_pp.hip; layout tables generated by tools/gen_pp.py) -----------------------------------
+#include "pp_layout.inc"
+namespace {
+// one ring slot: 30 fragments of 1 KB (256 floats) in the order of `lay`; src(desc) = the fragment's 256 floats
+void put_pp_slot(std::vector<float>& stream, const PpFragDesc (&lay)[kPpSlot], const std::function<const float*(const PpFragDesc&)>& src) {
+  const size_t at = stream.size();
+  stream.resize(at + (size_t)kPpSlot * 256, 0.f);
+  for (int i = 0; i < kPpSlot; ++i)
+    if (lay[i].kind != 0) std::memcpy(stream.data() + at + (size_t)i * 256, src(lay[i]), 256 * sizeof(float));
+}
+}  // namespace
+// Chain y += W2 act(W1aug [x ; 1]) over P = H / 32 hidden pairs, units A, AP, (P - 2) x F, BP, B (2 P ring slots):
+// an A fragment = W1aug step a, hidden tile 2 pair + b; a B fragment = W2 step `pair`, column tile a.
+void append_pp_chain(std::vector<float>& stream, const std::function<float(int, int)>& w1aug, int H, const std::function<float(int, int)>& w2) {
+  const int P = H / 32, NT1 = H / 16;
+  const std::vector<float> sp1 = pack_split32(w1aug, 145, H);      // [5 steps][NT1][3 terms][256]
+  const std::vector<float> sp2 = pack_split32(w2, H, 144);         // [P steps][9][3][256]
+  auto fa = [&](int pair, const PpFragDesc& d) { return sp1.data() + (((size_t)d.a * NT1 + 2 * pair + d.b) * 3 + d.term) * 256; };
+  auto fb = [&](int pair, const PpFragDesc& d) { return sp2.data() + (((size_t)pair * 9 + d.a) * 3 + d.term) * 256; };
+  auto unit = [&](const PpFragDesc (&lay)[kPpSlot], int pa, int pb) {
+    put_pp_slot(stream, lay, [&](const PpFragDesc& d) { return d.kind == 1 ? fa(pa, d) : fb(pb, d); });
+  };
+  unit(kPpLayout_A0, 0, -1);
+  unit(kPpLayout_AP0, 1, -1);
+  for (int p = 0; p + 2 < P; ++p) { unit(kPpLayout_F0, p + 2, p); unit(kPpLayout_F1, p + 2, p); }
+  unit(kPpLayout_BP0, -1, P - 2);
+  unit(kPpLayout_B0, -1, P - 1);
+}
+// A plain layer [145 (row 144 = bias), 144 * groups] in column groups of nine tiles, five S units (ring slots) per group
+void append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups) {
+  const int NT = 9 * groups;
+  const std::vector<float> sp = pack_split32(waug, 145, 144 * groups);
+  for (int g = 0; g < groups; ++g)
+    for (int st = 0; st < 5; ++st)
+      put_pp_slot(stream, kPpLayout_S0, [&](const PpFragDesc& d) { return sp.data() + (((size_t)st * NT + 9 * g + d.a) * 3 + d.term) * 256; });
+}
+
+
 // The DFT kernels are model variables (time_frequency.py:62-75 creates them from backend.py:27-69 and a checkpoint
 // may overwrite them).  When they are exactly window[n] * (cos, -+sin)(2 pi k n / 1024) the STFT runs as a
 // 32 x 32 Cooley-Tukey factorisation (fft_stft.hip); otherwise the dense DFT GEMM stays.  MI355ASR_FFT=0 forces dense.
@@ -356,6 +394,20 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
     }
     append_slabs(st, qkv_at, d, 3 * d, true);
     o.ff1_slabs = ab.put(st);
+    // pair-pipelined stream (fused_pp.hip): ff_module_1 as 18 hidden pairs, bias in row 144 of W1; then q, k, v with the
+    // q / k / v bias (zero for the reference's own attention layer) in row 144
+    const auto& b1 = T(p + "/ff_module_1/ffn1/bias");
+    const std::vector<float> qb = keras_mha ? [&] {
+      std::vector<float> v(3 * d);
+      const auto &bq = T(a + "/mha/query/bias"), &bk = T(a + "/mha/key/bias"), &bv = T(a + "/mha/value/bias");
+      for (int i = 0; i < d; ++i) { v[i] = bq[i]; v[d + i] = bk[i]; v[2 * d + i] = bv[i]; }
+      return v;
+    }() : std::vector<float>(3 * d, 0.f);
+    std::vector<float> pp;
+    append_pp_chain(pp, [&](int kk, int n) { return kk < d ? f1[(size_t)kk * 4 * d + n] : b1[n]; }, 4 * d,
+                    [&](int kk, int n) { return f2[(size_t)kk * d + n]; });
+    append_pp_plain(pp, [&](int kk, int n) { return kk < d ? qkv_at(kk, n) : qb[n]; }, 3);
+    o.pp_ff1 = ab.put(pp);
   }
   const std::string c = p + "/conv_module";
   o.cv_ln_g = ab.put(T(c + "/ln/gamma"));
@@ -407,6 +459,23 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
       append_slabs(st, [&](int kk, int n) { return f2[(size_t)(d * ch + kk) * d + n]; }, d, d, false);
     }
     o.tail_slabs = ab.put(st);
+    // pair-pipelined stream: the conv tail as 9 hidden pairs with the folded BatchNorm in the weights -- column n of the
+    // pointwise kernel times scale[n], row 144 = bias[n] * scale[n] + shift[n] (products formed in double, rounded once) --
+    // then ff_module_2 as 18 pairs with its bias in row 144
+    const auto& pcb = T(c + "/dw_conv/bias");
+    const auto& fb1 = T(p + "/ff_module_2/ffn1/bias");
+    std::vector<float> bs(2 * d), bt(2 * d);
+    {
+      const auto &g = T(c + "/bn/gamma"), &b = T(c + "/bn/beta"), &mu = T(c + "/bn/moving_mean"), &var = T(c + "/bn/moving_variance");
+      for (int i = 0; i < 2 * d; ++i) { bs[i] = g[i] / std::sqrt(var[i] + kBnEps); bt[i] = b[i] - mu[i] * bs[i]; }
+    }
+    std::vector<float> pp;
+    append_pp_chain(pp, [&](int kk, int n) {
+      return kk < d ? (float)((double)pc[(size_t)kk * 2 * d + n] * (double)bs[n]) : (float)((double)pcb[n] * (double)bs[n] + (double)bt[n]);
+    }, 2 * d, [&](int kk, int n) { return pw2[(size_t)kk * d + n]; });
+    append_pp_chain(pp, [&](int kk, int n) { return kk < d ? f1[(size_t)kk * 4 * d + n] : fb1[n]; }, 4 * d,
+                    [&](int kk, int n) { return f2[(size_t)kk * d + n]; });
+    o.pp_tail = ab.put(pp);
   }
   o.pw2_b = ab.put(T(c + "/pw_conv_2/bias"));
   o.ln_g = ab.put(T(p + "/ln/gamma"));
@@ -432,7 +501,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
-  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; }
+  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; }
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
   b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
@@ -615,7 +684,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       k1.ff_ln_g = bw.ff_ln_g[0]; k1.ff_ln_b = bw.ff_ln_b[0]; k1.ff_w1p = bw.ff_w1p[0]; k1.ff_b1 = bw.ff_b1[0];
       k1.ff_w2p = bw.ff_w2p[0]; k1.ff_b2 = bw.ff_b2[0];
       k1.att_ln_g = bw.att_ln_g; k1.att_ln_b = bw.att_ln_b; k1.qkv_wp = bw.qkv_wp; k1.qkv_b = bw.qkv_b;
-      k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M; k1.slabs = bw.ff1_slabs;
+      k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M; k1.slabs = bw.ff1_slabs; k1.pp_slabs = bw.pp_ff1;
       return k1;
     };
     if (!skip_ff1) {
@@ -642,7 +711,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k4.pc_w1p = w.pc_w1p; k4.pc_b1 = w.pc_b1; k4.bn_s = w.bn_s; k4.bn_t = w.bn_t; k4.pw2_wp = w.pw2_wp; k4.pw2_b = w.pw2_b;
     k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];
     k4.ff_w2p = w.ff_w2p[1]; k4.ff_b2 = w.ff_b2[1]; k4.ln_g = w.ln_g; k4.ln_b = w.ln_b;
-    k4.fc = fc; k4.eps = kLnEps; k4.M = M; k4.slabs = w.tail_slabs;
+    k4.fc = fc; k4.eps = kLnEps; k4.M = M; k4.slabs = w.tail_slabs; k4.pp_slabs = w.pp_tail;
     if (next && !out && ff1_done && tail_ff1_available() && k4.slabs && next->ff1_slabs) {
       // the block output feeds only the next block's ff_module_1: keep it in registers, write x1 (into the buffer the
       // next block knows as sc.xb after the swap below -- this block's x2, which each workgroup has consumed) and qkv

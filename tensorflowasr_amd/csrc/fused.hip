@@ -1491,7 +1491,8 @@ int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
   // MI355ASR_FF1QKV_RING: 1 (default) = split-bf16 MFMAs on the five-slot slab ring (54 us at 16 000 tokens),
   // 0 = the fp32-MFMA register-stream kernel (69 us)
   static const int ringk = [] { const char* v = getenv("MI355ASR_FF1QKV_RING"); return v ? atoi(v) : 2; }();
-  if (ringk == 2 && a.slabs) {     // 2 (default): loader-wave ring kernel
+  if (ringk == 2 && a.slabs) {     // 2 (default): loader-wave ring kernel; round 3: pair-pipelined (fused_pp.hip) unless MI355ASR_PP=0
+    if (launch_pp_ff1_qkv(a, s) == 0) return 0;
     const int tiles = (a.M + 15) / 16;
     hipLaunchKernelGGL(ff1_qkv_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
     return 0;
@@ -1558,6 +1559,7 @@ bool tail_ff1_available() {
 }
 int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s) {
   if (!tail_ff1_available() || !a.slabs || !b.slabs || a.M != b.M) return -1;
+  if (launch_pp_tail_ff1(a, b, s) == 0) return 0;
   const int tiles = (a.M + 15) / 16;
   hipLaunchKernelGGL(tail_ff1_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, b);
   return 0;
@@ -1567,7 +1569,8 @@ int launch_tail_ff2(const TailFf2Args& a, hipStream_t s) {
   // MI355ASR_TAILFF2_RING: 1 (default) = split-bf16 MFMAs on the five-slot slab ring (60 us at 16 000 tokens),
   // 0 = the fp32-MFMA register-stream kernel (74 us)
   static const int ringk = [] { const char* v = getenv("MI355ASR_TAILFF2_RING"); return v ? atoi(v) : 2; }();
-  if (ringk == 2 && a.slabs) {     // 2 (default): loader-wave ring kernel
+  if (ringk == 2 && a.slabs) {     // 2 (default): loader-wave ring kernel; round 3: pair-pipelined (fused_pp.hip) unless MI355ASR_PP=0
+    if (launch_pp_tail_ff2(a, s) == 0) return 0;
     hipLaunchKernelGGL(tail_ff2_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
     return 0;
   }

@@ -237,6 +237,7 @@ struct Ff1QkvArgs {
   float fc, qscale, eps;
   int M;
   const float* slabs = nullptr;   // slab stream of ff1_qkv_ring_kernel (55 slabs of 1792 fragments), or null
+  const float* pp_slabs = nullptr;   // pair-pipelined stream (fused_pp.hip: 51 ring slots of 30 fragments; biases in row 144), or null
 };
 struct OutGluArgs {
   const float* ctx; const float* x1; float* x2; float* u;
@@ -253,12 +254,18 @@ struct TailFf2Args {
   float fc, eps;
   int M;
   const float* slabs = nullptr;   // slab stream of tail_ff2_ring_kernel (60 slabs of 1792 fragments), or null
+  const float* pp_slabs = nullptr;   // pair-pipelined stream (fused_pp.hip: 54 ring slots; BatchNorm and biases folded into W1), or null
 };
 int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s);
 int launch_out_glu(const OutGluArgs& a, hipStream_t s);
 int launch_tail_ff2(const TailFf2Args& a, hipStream_t s);
 bool tail_ff1_available();
 int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);   // -1: not available, nothing launched
+// pair-pipelined versions (fused_pp.hip); -1: switched off (MI355ASR_PP=0) or no pp_slabs, nothing launched
+bool pp_enabled();
+int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);
+int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);
+int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
 int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s);   // -1: shape not supported
 int launch_pick(const PickArgs& a, hipStream_t s);
 int launch_row_argmax(const float* x, int32_t* out, int M, int V, hipStream_t s);

@@ -1,0 +1,345 @@
+"""Generates the pair-pipelined ("pp") stream of the dmodel-144 block kernels (fused_pp.hip):
+
+    python tools/gen_pp.py            # writes tensorflowasr_amd/csrc/pp_units.inc and pp_layout.inc
+    python tools/gen_pp.py --check    # only runs the dataflow simulator (also run by tests/test_host.py)
+
+Why ("Pair-pipelined chains", round 3).  The round-2 ring kernels walk a hidden chunk of nine tiles as
+W1 x 5 slabs -> activation + operand split -> W2 x 5 slabs.  The activation / split VALU work of a chunk can only run
+behind the MFMAs of the W2 slabs (1.7 VALU per MFMA, above the ~1 per MFMA that is free), the ninth hidden tile pairs
+with zero padding (10 slabs for 9.5 slabs of work) and bias / folded BatchNorm come from LDS reads inside the stream.
+Here the hidden dimension is walked in PAIRS of tiles (32 hidden features = one 32-wide k-step of W2):
+
+    unit p:   B(p)    y     += W2[pair p]^T  hf(p)          54 MFMAs   (27 fragments: 9 column tiles x 3 terms)
+              A(p+2)  h(p+2) = W1[:, pair p+2]^T xf         60 MFMAs   (30 fragments: 5 k-steps x 2 tiles x 3 terms)
+              prep(p+1)  hf(p+1) = split(swish(h(p+1)))     48 slots of <= 2 VALU instructions, one behind every ~2nd MFMA
+
+so every MFMA of a chain carries the same small VALU load, no hidden tile is padding (FFN: 18 pairs x 114 = 2052 MFMAs
+instead of 2160), h is 2 x 2 tiles instead of 9, and the bias (and the folded BatchNorm shift) ride in row 144 of W1 --
+the K padding of the fifth k-step -- against a constant 1.0 operand, so nothing in the loop reads parameters from LDS.
+
+The fragment stream is a linear sequence of 1 KB fragments in consumption order, cut into ring slots of 30 fragments.
+A wave keeps NPOOL = 9 fragment registers; the fragment at stream position q lives in pool slot q % 9 and the read of
+position q + 9 is issued as soon as the MFMAs of position q have issued (same depth as the round-2 in-place refill).
+Every unit's stream length is a multiple of 9 (padded with idle positions before the unit's last block), so each unit starts and ends in the same state:
+the first nine fragments of the next slab in flight, in order, in slots 0..8.  LDS returns in order, hence every wait
+is a counted `s_waitcnt lgkmcnt(n)`; the simulator below checks each count, each slot reuse, each ring-slot hand-over
+and that every (accumulator tile, k-step) receives its six term pairs exactly once.
+"""
+import os
+import sys
+
+NPOOL = 9
+SLOT = 30          # fragments (KB) per ring slot
+NPREP = 48         # slots of the activation + split schedule (prep_sched.inc, AFF = false, FULL = true)
+
+
+def a_block(k):
+    """W1 step k for the two tiles of a pair: fragments (tile, term) in use order, batches = (positions, x terms)"""
+    frags = [("A", k, 0, 2), ("A", k, 1, 2), ("A", k, 0, 1), ("A", k, 1, 1), ("A", k, 0, 0), ("A", k, 1, 0)]
+    batches = [([0, 1], [0]), ([2, 3], [1, 0]), ([4, 5], [2, 1, 0])]
+    acc = lambda f: "ha[%d]" % f[2]
+    x = lambda t: "xf[%d].t[%d]" % (k, t)
+    return frags, batches, acc, x
+
+
+def b_block(cg, kind):
+    """column group cg (tiles 3 cg .. 3 cg + 2) of one 32-wide step: kind 'B' (W2 of a pair, operand hfc) or 'S' (plain slab, operand xs)"""
+    frags = [(kind, 3 * cg + i, 0, term) for term in (2, 1, 0) for i in range(3)]
+    batches = [([0, 1, 2], [0]), ([3, 4, 5], [1, 0]), ([6, 7, 8], [2, 1, 0])]
+    accname = "y" if kind == "B" else "acc"
+    acc = lambda f: "%s[%d]" % (accname, f[1])
+    xname = "hfc" if kind == "B" else "xs"
+    x = lambda t: "%s.t[%d]" % (xname, t)
+    return frags, batches, acc, x
+
+
+# name: (blocks per ring slot, prep?, idle positions).  A unit's stream length must be a multiple of 9 so that it hands the
+# pool over in the canonical state; the A / AP / F units have 30 / 57 fragments, so six stream positions stay empty (the pool
+# slot idles for one turn).  Where they sit decides how long before its first use a fragment is requested: an empty position
+# before fragment index r shortens the lead of the reads that cross it.  The placements below maximise the minimum lead
+# (found by search, tools/gen_pp.py history): 8 MFMAs for F, 7 for A / AP (the round-2 in-place refill: 9).
+UNITS = {
+    "A": ([[("A", 0), ("A", 1), ("A", 2), ("A", 3), ("A", 4)]], False, (11, 16, 17, 19, 20, 22)),
+    "AP": ([[("A", 0), ("A", 1), ("A", 2), ("A", 3), ("A", 4)]], True, (11, 16, 17, 19, 20, 22)),
+    "F": ([[("B", 0), ("A", 0), ("A", 1), ("B", 1)], [("A", 2), ("A", 3), ("B", 2), ("A", 4)]], True, (15, 28, 35, 38, 41, 48)),
+    "BP": ([[("B", 0), ("B", 1), ("B", 2)]], True),
+    "B": ([[("B", 0), ("B", 1), ("B", 2)]], False),
+    "S": ([[("S", 0), ("S", 1), ("S", 2)]], False),
+}
+
+
+class Unit:
+    def __init__(self, name):
+        self.name = name
+        slabs, self.prep = UNITS[name][:2]
+        vat = set(UNITS[name][2]) if len(UNITS[name]) > 2 else set()   # an idle position before each of these fragment indices
+        nreal = 0
+        self.pos = []          # stream positions: dict(frag, slab, off, acc, ) or None for a dummy
+        self.blocks = []       # (first position, batches, accfn, xfn)
+        self.slabs = []        # per slab: list of fragment descriptors (the host layout)
+        for si, blks in enumerate(slabs):
+            lay = []
+            for kind, arg in blks:
+                frags, batches, acc, x = a_block(arg) if kind == "A" else b_block(arg, kind)
+                self.blocks.append((len(self.pos), batches, acc, x, si))
+                first = None
+                for f in frags:
+                    if nreal in vat:
+                        self.pos.append(None)
+                    if first is None:
+                        first = len(self.pos)
+                    self.pos.append({"frag": f, "slab": si, "off": len(lay)})
+                    lay.append(f)
+                    nreal += 1
+                self.blocks[-1] = (first,) + self.blocks[-1][1:]
+            assert len(lay) <= SLOT
+            self.slabs.append(lay)
+        self.real = sum(p is not None for p in self.pos)
+        self.length = len(self.pos)
+        assert self.length % NPOOL == 0, (name, self.length)
+        self.nslabs = len(slabs)
+        self.program()
+
+    def program(self):
+        ops = []
+        L = self.length
+        nm = sum(len(b[0]) * len(b[1]) for blk in self.blocks for b in blk[1])
+        # prep slot s behind MFMA index prep_at[s]
+        prep_at = {}
+        if self.prep:
+            first, last = 3, nm - 2
+            for s in range(NPREP):
+                prep_at.setdefault(first + (s * (last - first)) // (NPREP - 1), []).append(s)
+            assert all(len(v) == 1 for v in prep_at.values()), "more than one prep slot behind an MFMA"
+        issued = []            # read log: (target position or 'dummy', slab index of the read, unit-relative slab, off)
+        self.ops = ops
+        cur_slab = 0
+        mi = 0                 # MFMA counter
+        # reads outstanding at entry: positions 0..8, in order
+        order = list(range(NPOOL))            # issue order of positions whose read may still be outstanding
+        first_use_lead = {}
+
+        def issue(q):
+            # read of stream position q into slot q % NPOOL; a position without a fragment passes its turn on to q + 9
+            while q < L and self.pos[q] is None:
+                q += NPOOL
+            if q >= L + NPOOL:
+                return
+            if q < L:
+                p = self.pos[q]
+                rel = p["slab"] - cur_slab
+                ops.append(("rd", q % NPOOL, rel, p["off"], q))
+            else:
+                rel = self.nslabs - cur_slab
+                ops.append(("rd", q % NPOOL, rel, q - L, q))    # head q - L of the next unit's first slab
+            order.append(q)
+            first_use_lead[q] = mi
+
+        for bi, (p0, batches, acc, x, si) in enumerate(self.blocks):
+            for positions, xterms in batches:
+                real_pos = [i for i in range(p0, L) if self.pos[i] is not None]
+                qs = [real_pos[i] for i in positions]
+                # all reads up to the newest needed one have returned
+                newest = max([order.index(q) for q in qs if q in order], default=-1)
+                n_after = len(order) - 1 - newest
+                ops.append(("wt", n_after, [q % NPOOL for q in qs]))     # (also ties the MFMAs below to the reads above)
+                del order[:newest + 1]
+                for xt in xterms:
+                    for q in qs:
+                        ops.append(("mm", acc(self.pos[q]["frag"]), q % NPOOL, x(xt), q, xt))
+                        for s in prep_at.get(mi, []):
+                            ops.append(("prep", s))
+                        mi += 1
+                for q in qs:
+                    issue(q + NPOOL)
+            last_of_slab = bi + 1 == len(self.blocks) or self.blocks[bi + 1][4] != si
+            if last_of_slab:
+                # every read of this ring slot has returned: outstanding may be only reads of later slabs
+                def targets_cur(q):
+                    return q < L and self.pos[q]["slab"] == cur_slab
+                keep = 0
+                for i, q in enumerate(order):
+                    if targets_cur(q):
+                        keep = i + 1
+                if keep:
+                    ops.append(("wt", len(order) - keep, []))
+                    del order[:keep]
+                ops.append(("adv",))
+                cur_slab += 1
+        self.nm = nm
+        heads = list(range(L, L + NPOOL))
+        assert order == heads[len(heads) - len(order):], order      # a suffix of the heads, in order
+        assert [o[4] for o in ops if o[0] == "rd" and o[4] >= L] == heads
+        self.lead = first_use_lead
+
+
+def simulate(u):
+    """replays the unit's ops; raises on any slot / count / coverage error.  Returns the minimum read lead in MFMAs."""
+    L = u.length
+    pool = {s: {"pos": s, "landed": False} for s in range(NPOOL)}     # entry: heads 0..8 in flight in slots 0..8
+    queue = list(range(NPOOL))                                         # in-order outstanding reads (by position)
+    slot_of = {q: q for q in range(NPOOL)}
+    cur_slab = 0
+    used = {}           # position -> number of MFMAs that used it
+    products = {}       # (acc, step key) -> list of (wterm, xterm)
+    mi = 0
+    issue_mi = {q: None for q in range(NPOOL)}
+    min_lead = 10 ** 9
+    prep_seen = []
+    for op in u.ops:
+        if op[0] == "rd":
+            _, slot, rel, off, q = op
+            old = pool[slot]["pos"]
+            if old is not None and old < L and u.pos[old] is not None:
+                f = u.pos[old]["frag"]
+                need = {2: 1, 1: 2, 0: 3}[f[3]]
+                assert used.get(old, 0) == need, "slot %d reused before position %d finished (%s uses)" % (slot, old, used.get(old, 0))
+            assert old is None or (q - old) % NPOOL == 0 and q > old, (old, q)
+            for mid in range(old + NPOOL, q, NPOOL):
+                assert u.pos[mid] is None, "skipped a real fragment"
+            assert rel in (0, 1), "read two slabs ahead"
+            if q < L:
+                assert u.pos[q]["slab"] == cur_slab + rel and u.pos[q]["off"] == off
+            else:
+                assert cur_slab + rel == u.nslabs and off == q - L
+            pool[slot] = {"pos": q, "landed": False, "slab": cur_slab + rel}
+            queue.append(q)
+            issue_mi[q] = mi
+        elif op[0] == "wt":
+            n = op[1]
+            assert n <= len(queue)
+            while len(queue) > n:
+                q = queue.pop(0)
+                pool[q % NPOOL]["landed"] = pool[q % NPOOL]["pos"] == q or pool[q % NPOOL]["landed"]
+                if pool[q % NPOOL]["pos"] == q:
+                    pool[q % NPOOL]["landed"] = True
+        elif op[0] == "mm":
+            _, acc, slot, x, q, xt = op
+            assert pool[slot]["pos"] == q and pool[slot]["landed"], "MFMA %d reads slot %d before position %d landed" % (mi, slot, q)
+            f = u.pos[q]["frag"]
+            assert f[3] + xt <= 2
+            key = (acc, f[0], f[1] if f[0] == "A" else None)
+            products.setdefault(key, []).append((f[3], xt))
+            if used.get(q, 0) == 0 and issue_mi[q] is not None:
+                min_lead = min(min_lead, mi - issue_mi[q])
+            used[q] = used.get(q, 0) + 1
+            mi += 1
+        elif op[0] == "prep":
+            prep_seen.append(op[1])
+        elif op[0] == "adv":
+            for q in queue:
+                if q < L:
+                    assert u.pos[q]["slab"] != cur_slab, "ring slot handed over with a read of it outstanding"
+            for p in u.pos:
+                if p is not None and p["slab"] == cur_slab:
+                    q = u.pos.index(p)
+                    need = {2: 1, 1: 2, 0: 3}[p["frag"][3]]
+                    assert used.get(q, 0) == need, "ring slot handed over before position %d was multiplied" % q
+            cur_slab += 1
+    assert cur_slab == u.nslabs
+    want = sorted([(2, 0), (1, 1), (1, 0), (0, 2), (0, 1), (0, 0)])
+    for key, prods in products.items():
+        assert sorted(prods) == want, (key, prods)
+    # every fragment of every slab was multiplied
+    nacc = {"A": 2 * 5, "B": 9, "S": 9}
+    kinds = {}
+    for key in products:
+        kinds[key[1]] = kinds.get(key[1], 0) + 1
+    for k, n in kinds.items():
+        assert n == nacc[k], (k, n)
+    if u.prep:
+        assert prep_seen == list(range(NPREP)), prep_seen
+    else:
+        assert not prep_seen
+    # exit state: heads of the next slab requested in order, slot j <- head j; outstanding = a suffix of them
+    heads = list(range(L, L + NPOOL))
+    assert queue == heads[len(heads) - len(queue):], queue
+    for j in range(NPOOL):
+        assert pool[j]["pos"] == L + j
+    return min_lead
+
+
+def emit_units(units):
+    out = []
+    w = out.append
+    w("// GENERATED by tools/gen_pp.py -- do not edit.  One function per unit kind of the pair-pipelined stream (see the")
+    w("// generator's docstring).  Macros (fused_pp.hip): PP_RD(slot, addr, OFF) = ds_read_b128 into pool slot; PP_WTn(N, slots...) =")
+    w("// s_waitcnt lgkmcnt(N) tied to the slots; PP_MM(acc, slot, x) = one v_mfma_f32_16x16x32_bf16; PP_PREP(k) = slot k of the")
+    w("// activation + split schedule on (pc.lo, pc.hi) -> pc.out; PP_FENCE = sched_barrier(0).")
+    for u in units:
+        args = {
+            "A": "f32x4 (&ha)[2], const Split8 (&xf)[KS32X]",
+            "AP": "f32x4 (&ha)[2], const Split8 (&xf)[KS32X], PrepCtx& pc",
+            "F": "f32x4 (&y)[KB], f32x4 (&ha)[2], const Split8 (&xf)[KS32X], const Split8& hfc, PrepCtx& pc",
+            "BP": "f32x4 (&y)[KB], const Split8& hfc, PrepCtx& pc",
+            "B": "f32x4 (&y)[KB], const Split8& hfc",
+            "S": "f32x4* acc, const Split8& xs",
+        }[u.name]
+        w("// unit %s: %d fragments (+%d idle positions), %d MFMAs, %d ring slot(s)" % (u.name, u.real, u.length - u.real, u.nm, u.nslabs))
+        w("template <class ST>")
+        w("DEV void pp_unit_%s(%s, PpPool& pl, ST& st) {" % (u.name, args))
+        w("  unsigned a0 = st.cur_addr(), a1 = st.next_addr();")
+        for op in u.ops:
+            if op[0] == "rd":
+                _, slot, rel, off, q = op
+                w("  PP_RD(%d, a%d, %d);" % (slot, rel, off * 1024))
+            elif op[0] == "wt":
+                n, slots = op[1], op[2]
+                if slots:
+                    w("  PP_WT%d(%d, %s);" % (len(slots), n, ", ".join(str(s) for s in slots)))
+                else:
+                    w("  PP_WT0(%d);" % n)
+            elif op[0] == "mm":
+                _, acc, slot, x, q, xt = op
+                w("  PP_MM(%s, %d, %s);" % (acc, slot, x))
+            elif op[0] == "prep":
+                w("  PP_FENCE; PP_PREP(%d); PP_FENCE;" % op[1])
+            elif op[0] == "adv":
+                w("  st.advance(); a0 = st.cur_addr(); a1 = st.next_addr();")
+        w("}")
+        w("")
+    return "\n".join(out)
+
+
+def emit_layout(units):
+    out = []
+    w = out.append
+    w("// GENERATED by tools/gen_pp.py -- do not edit.  Host-side layout of the pair-pipelined stream: for every unit kind the")
+    w("// fragments of its ring slots in LDS order.  kind 0 = padding, 1 = A (W1 step a, local tile b of the pair), 2 = B (W2 step")
+    w("// of the pair, column tile a), 3 = S (plain step, column tile a of the group of nine); term = bf16 term.")
+    w("struct PpFragDesc { unsigned char kind, a, b, term; };")
+    w("constexpr int kPpSlot = %d;" % SLOT)
+    code = {"A": 1, "B": 2, "S": 3}
+    for u in units:
+        for si, lay in enumerate(u.slabs):
+            ents = ["{%d, %d, %d, %d}" % (code[f[0]], f[1], f[2], f[3]) for f in lay]
+            ents += ["{0, 0, 0, 0}"] * (SLOT - len(lay))
+            w("constexpr PpFragDesc kPpLayout_%s%d[kPpSlot] = {%s};" % (u.name, si, ", ".join(ents)))
+    return "\n".join(out) + "\n"
+
+
+def build_all():
+    units = [Unit(n) for n in ("A", "AP", "F", "BP", "B", "S")]
+    stats = {}
+    for u in units:
+        stats[u.name] = simulate(u)
+    return units, stats
+
+
+def main():
+    units, stats = build_all()
+    for u in units:
+        print("unit %-2s: %3d fragments, length %3d, %3d MFMAs, %d slab(s), min read lead %d MFMAs" %
+              (u.name, u.real, u.length, u.nm, u.nslabs, stats[u.name]), file=sys.stderr)
+    if "--check" in sys.argv:
+        return
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "..", "tensorflowasr_amd", "csrc")
+    with open(os.path.join(csrc, "pp_units.inc"), "w") as f:
+        f.write(emit_units(units) + "\n")
+    with open(os.path.join(csrc, "pp_layout.inc"), "w") as f:
+        f.write(emit_layout(units))
+
+
+if __name__ == "__main__":
+    main()

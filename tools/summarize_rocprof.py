@@ -30,6 +30,9 @@ CATEGORY = [
 
 
 def category(name):
+    if "pp_block_kernel" in name:       # fused_pp.hip: <TAIL, FF1>
+        a = [v.strip() for v in name[name.index("<") + 1:name.index(">")].split(",")]
+        return {("true", "true"): "tail_ff1", ("true", "false"): "tail_ff2", ("false", "true"): "ff1_qkv"}[(a[0], a[1])]
     for key, cat in CATEGORY:
         if key in name:
             return cat
