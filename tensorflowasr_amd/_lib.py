@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355asr.so")
+# MI355ASR_LIB: another build of the same library (kernel-variant experiments, tools/build_variant.py); still a HIP library
+LIB_PATH = os.environ.get("MI355ASR_LIB") or os.path.join(_HERE, "libmi355asr.so")
 
 
 class Config(ctypes.Structure):

@@ -705,8 +705,11 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     DwArgs dwa{};
     dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
     dwa.pad_left = bo.causal ? ksz - 1 : (ksz - 1) / 2;
-    { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
+    // round 3: the depthwise conv rides in the prologue of the pair-pipelined tail kernel (no launch, dw never in HBM)
+    const bool dw_fold = w.pp_tail && w.tail_slabs && tail_pp_selected() && pp_dw_fold_ok(T, ksz);
+    if (!dw_fold) { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
     TailFf2Args k4{};
+    if (dw_fold) { k4.dw_u = sc.u; k4.dw_wd = w.dw_w; k4.dw_T = T; k4.dw_pad = dwa.pad_left; }
     k4.dw = sc.dw; k4.x2 = sc.xa; k4.y = out ? out : sc.xb;
     k4.pc_w1p = w.pc_w1p; k4.pc_b1 = w.pc_b1; k4.bn_s = w.bn_s; k4.bn_t = w.bn_t; k4.pw2_wp = w.pw2_wp; k4.pw2_b = w.pw2_b;
     k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];

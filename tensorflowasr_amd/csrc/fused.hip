@@ -1547,6 +1547,11 @@ int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t
                      reinterpret_cast<const u32x4_t*>(ws));
   return 0;
 }
+// the conv tail will run on the pair-pipelined kernels (fused_pp.hip): api.hip then folds the depthwise conv into them
+bool tail_pp_selected() {
+  static const bool ring2 = [] { const char* r = getenv("MI355ASR_TAILFF2_RING"); return !r || atoi(r) == 2; }();
+  return ring2 && pp_enabled();
+}
 // tail of one block + ff1_qkv of the next in one launch; -1 when the loader-wave kernels are switched off
 bool tail_ff1_available() {
   // MI355ASR_TAIL_FF1=0: separate tail_ff2 / ff1_qkv launches (also whenever one of the two is switched to an older kernel)

@@ -19,6 +19,7 @@
 // tools/gen_pp.py -> pp_units.inc (device) / pp_layout.inc (host packing, api.hip: append_pp_chain).
 // Workgroup = 8 waves as in fused.hip: waves 0-3 consume (16 tokens each), waves 4-7 issue the slab DMAs; ring = 5 slots of
 // 30 fragments (30 KB).  Reference semantics: asr/models/conformer_blocks.py:126-134, :164-170, :209-219, :259-265.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -100,30 +101,38 @@ struct WaveCtx {
   size_t row;
   bool live;
 };
-DEV WaveCtx wave_ctx(int M) {
-  WaveCtx c;
-  c.lane = threadIdx.x & 63;
+// T > 0: utterance-aligned tiling (depthwise conv folded in): workgroup (blockIdx.x, blockIdx.y) = 64-frame chunk blockIdx.x of
+// utterance blockIdx.y, so that the conv window of a workgroup never crosses an utterance; T = 0: tokens tiled flat
+DEV void tok_of(WaveCtx& c, unsigned tid, int M, int T) {
+  c.lane = tid & 63;
   c.g4 = (c.lane >> 4) * 4;
   c.t = c.lane & 15;
-  const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int wv = (int)(tid >> 6);
+  if (T > 0) {
+    const int f = (blockIdx.x * WAVES_PER_BLOCK + wv) * 16 + c.t;      // frame inside the utterance
+    c.live = f < T;
+    c.tok = blockIdx.y * T + min(f, T - 1);                             // frames past the end recompute the last one
+    c.row = (size_t)c.tok * D;
+    return;
+  }
+  const int wid = blockIdx.x * WAVES_PER_BLOCK + wv;
   c.tok = wid * 16 + c.t;
   c.live = c.tok < M;
   c.row = (size_t)min(c.tok, M - 1) * D;     // waves past the end recompute the last token and store nothing
+  if (!c.live) c.tok = M - 1;
+}
+DEV WaveCtx wave_ctx(int M, int T = 0) {
+  WaveCtx c;
+  tok_of(c, threadIdx.x, M, T);
   return c;
 }
 // recomputed from an opaque copy of the thread index before the stores (keeps the 64-bit row offset out of the stream's
 // live ranges: it was the value the register allocator spilled in the round-2 kernels)
-DEV WaveCtx wave_ctx_fresh(int M) {
+DEV WaveCtx wave_ctx_fresh(int M, int T = 0) {
   unsigned tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   WaveCtx c;
-  c.lane = tid & 63;
-  c.g4 = (c.lane >> 4) * 4;
-  c.t = c.lane & 15;
-  const int wid = blockIdx.x * WAVES_PER_BLOCK + (int)(tid >> 6);
-  c.tok = wid * 16 + c.t;
-  c.live = c.tok < M;
-  c.row = (size_t)min(c.tok, M - 1) * D;
+  tok_of(c, tid, M, T);
   return c;
 }
 DEV void ln_lds(f32x4 (&xs)[KB], const float* ga, const float* be, int g4, float eps) {
@@ -143,15 +152,24 @@ struct PrepCtx {
 template <bool AFF, bool FULL> struct PrepSlots;
 #include "prep_sched.inc"
 
+DEV void pp_fake_prep(PrepCtx& pc) {     // DG bit 0: consumes the hidden tiles and defines the operand without any work
+  asm volatile("; no prep" : "=v"(pc.out.t[0]), "=v"(pc.out.t[1]), "=v"(pc.out.t[2]) : "v"(pc.lo), "v"(pc.hi));
+}
 // ---- the generated units ---------------------------------------------------------------------------------------------------
-struct PpPool { u32x4_t f[9]; };
-#define PP_RD(S, A, OFF) pl.f[S] = lds_read16<OFF>(A)
-#define PP_WT0(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory")
-#define PP_WT2(N, S0, S1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(pl.f[S0]), "+v"(pl.f[S1]))
-#define PP_WT3(N, S0, S1, S2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(pl.f[S0]), "+v"(pl.f[S1]), "+v"(pl.f[S2]))
+// DG (diagnostics, timing only -- wrong results; instantiated only with -DMI355ASR_DIAG_KERNELS and selected by
+// MI355ASR_PP_DIAG): bit 0 = no activation / split work, 1 = no fragment reads, 2 = no MFMAs, 3 = no barriers, 4 = no DMA
+// (the diagnostic stand-ins are opaque definitions: with plain constants the compiler merges MFMAs that become identical)
+#define PP_RD(S, A, OFF) \
+  do { if constexpr (!(DG & 2)) pl.f[S] = lds_read16<OFF>(A); else asm volatile("; no read" : "=v"(pl.f[S]) : "v"(A)); } while (0)
+#define PP_WT0(N) do { if constexpr (!(DG & 2)) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); } while (0)
+#define PP_WT2(N, S0, S1) \
+  do { if constexpr (!(DG & 2)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(pl.f[S0]), "+v"(pl.f[S1])); } while (0)
+#define PP_WT3(N, S0, S1, S2) \
+  do { if constexpr (!(DG & 2)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(pl.f[S0]), "+v"(pl.f[S1]), "+v"(pl.f[S2])); } while (0)
 #define PP_MM(ACC, S, X) \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pl.f[S]), __builtin_bit_cast(bf16x8_t, X), ACC, 0, 0, 0)
-#define PP_PREP(K) prep_slot<K, false, true>(pc)
+  do { if constexpr (!(DG & 4)) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pl.f[S]), __builtin_bit_cast(bf16x8_t, X), ACC, 0, 0, 0); } while (0)
+#define PP_PREP(K) \
+  do { if constexpr (!(DG & 1)) prep_slot<K, false, true>(pc); else if constexpr (K == 47) pp_fake_prep(pc); } while (0)
 #define PP_FENCE __builtin_amdgcn_sched_barrier(0)
 #include "pp_units.inc"
 
@@ -162,7 +180,7 @@ constexpr int PP_RING = 5;
 // waves 4..7: fragment f of a slab is fetched by loader wave f % 4 -- waves 0, 1 issue eight 1 KB pieces per slab, waves 2, 3
 // seven -- into the ring slot the consumers read in the previous step; "slab s + 2 has landed" (this wave's pieces: counted
 // vmcnt) before the barrier that ends step s, so that the consumers' fragment pipeline may run into slab s + 1 during step s.
-template <int RING>
+template <int RING, int DG>
 struct PpLoader {
   u32x4_t* ring;
   const u32x4_t *src, *src2;    // slabs [0, n1) from src, [n1, total) from src2
@@ -171,14 +189,30 @@ struct PpLoader {
   DEV void issue(int slab, int slot) const {
     const u32x4_t* g = (slab < n1 ? src + (size_t)slab * PP_SLB : src2 + (size_t)(slab - n1) * PP_SLB) + 64 * wv + lane;
     u32x4_t* l = ring + slot * PP_SLB + 64 * wv;
+    if constexpr (DG & 16) return;
 #pragma unroll
     for (int q = 0; q < PER; ++q) dma16(g + BLOCK_THREADS * q, l + BLOCK_THREADS * q);
   }
-  template <int PER>
-  DEV void run_() const {
+  // prologue slabs (depthwise-conv fold): all thirty pieces from waves 6 and 7, so that waves 4 and 5 -- which stage and
+  // compute with the consumers -- have no DMA in flight (hipcc waits for every pending LDS-DMA before an LDS read it sees)
+  DEV void issue_pro(int slab, int slot) const {
+    if (wv < 2) return;
+    const u32x4_t* g = (slab < n1 ? src + (size_t)slab * PP_SLB : src2 + (size_t)(slab - n1) * PP_SLB) + 64 * (wv - 2) + lane;
+    u32x4_t* l = ring + slot * PP_SLB + 64 * (wv - 2);
+#pragma unroll
+    for (int q = 0; q < PP_FR / 2; ++q) dma16(g + 128 * q, l + 128 * q);
+  }
+  // pro(): work between the first slabs and the rest of the prefill (the depthwise-conv prologue: PRE0 = 2, the LDS of
+  // ring slots 2.. is scratch until pro() returns); every barrier inside pro() has its twin on the consumer side
+  template <int PER, int PRE0, class PRO>
+  DEV void run_(PRO&& pro) const {
     static_assert(RING >= 4, "slab s + 1 is read ahead while slab s + RING - 1 is written");
     const int pre = min(RING - 1, total);
-    for (int i = 0; i < pre; ++i) issue<PER>(i, i);
+    for (int i = 0; i < min(PRE0, pre); ++i) {
+      if constexpr (PRE0 == RING - 1) issue<PER>(i, i); else issue_pro(i, i);
+    }
+    pro();
+    for (int i = min(PRE0, pre); i < pre; ++i) issue<PER>(i, i);
     wait_dma_ahead<PER, RING - 3>(min(RING - 3, max(pre - 2, 0)));   // slabs 0 and 1 have landed
     __builtin_amdgcn_s_barrier();                                    // B0 (consumers: inputs + parameter stash)
     int rd = 0;
@@ -186,16 +220,18 @@ struct PpLoader {
     for (int s = 0; s < total; ++s) {
       if (s + RING - 1 < total) issue<PER>(s + RING - 1, rd == 0 ? RING - 1 : rd - 1);
       wait_dma_ahead<PER, RING - 3>(max(min(RING - 3, total - 3 - s), 0));     // slab s + 2 has landed
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(DG & 8)) __builtin_amdgcn_s_barrier();
       rd = rd + 1 == RING ? 0 : rd + 1;
     }
   }
-  DEV void run() const {
-    if (wv < 2) run_<8>(); else run_<7>();
+  template <int PRE0, class PRO>
+  DEV void run(PRO&& pro) const {
+    if (wv < 2) run_<8, PRE0>(pro); else run_<7, PRE0>(pro);
   }
+  DEV void run() const { run<RING - 1>([] {}); }
 };
 
-template <int RING>
+template <int RING, int DG>
 struct PpReader {               // waves 0..3
   u32x4_t* ring;
   int lane;
@@ -210,35 +246,26 @@ struct PpReader {               // waves 0..3
   DEV unsigned cur_addr() const { return slot_addr(rd); }
   DEV unsigned next_addr() const { return slot_addr(rd + 1 == RING ? 0 : rd + 1); }
   DEV void advance() {          // every read of the slot has landed (the generated wait in front of each call covers them)
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(DG & 8)) __builtin_amdgcn_s_barrier();
     rd = rd + 1 == RING ? 0 : rd + 1;
     __builtin_amdgcn_sched_barrier(0);
   }
 };
 
-// the first nine fragments of the first slab (the state every unit starts from and leaves behind for the next slab)
-template <class ST>
-DEV void pp_prime(PpPool& pl, ST& st) {
-  const unsigned a0 = st.cur_addr();
-  PP_RD(0, a0, 0 * 1024); PP_RD(1, a0, 1 * 1024); PP_RD(2, a0, 2 * 1024);
-  PP_RD(3, a0, 3 * 1024); PP_RD(4, a0, 4 * 1024); PP_RD(5, a0, 5 * 1024);
-  PP_RD(6, a0, 6 * 1024); PP_RD(7, a0, 7 * 1024); PP_RD(8, a0, 8 * 1024);
-}
-
 // y += W2 swish(W1aug [x ; 1]) over P hidden pairs (2 P ring slots): units A, AP, P - 2 x F, BP, B.  h0 / h1 and f0 / f1
 // swap roles from unit to unit (accumulate <-> being prepared, operand in use <-> operand being built).
-template <int P, class ST>
+template <int P, int DG, class ST>
 DEV void pp_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS32X], PpPool& pl, ST& st) {
   static_assert(P >= 3, "at least one full unit");
   f32x4 h0[2], h1[2];
   Split8 f0, f1;
   const f32x4 one = splat4(1.f), zero = splat4(0.f);
   h0[0] = zero; h0[1] = zero;
-  pp_unit_A(h0, xf, pl, st);                                   // h(0)
+  pp_unit_A<DG>(h0, xf, pl, st);                                   // h(0)
   h1[0] = zero; h1[1] = zero;
   {
     PrepCtx pc{h0[0], h0[1], one, zero, one, zero, f0, 0.f, 0.f, 0.f, 0.f};
-    pp_unit_AP(h1, xf, pc, pl, st);                            // h(1) ; hf(0)
+    pp_unit_AP<DG>(h1, xf, pc, pl, st);                            // h(1) ; hf(0)
   }
   constexpr int NF = P - 2;
 #pragma unroll 1
@@ -246,31 +273,31 @@ DEV void pp_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS32X], PpPool& pl, ST& st)
     h0[0] = zero; h0[1] = zero;
     {
       PrepCtx pc{h1[0], h1[1], one, zero, one, zero, f1, 0.f, 0.f, 0.f, 0.f};
-      pp_unit_F(y, h0, xf, f0, pc, pl, st);                    // p even: B(p) with f0, A(p + 2) -> h0, h1 -> f1
+      pp_unit_F<DG>(y, h0, xf, f0, pc, pl, st);                    // p even: B(p) with f0, A(p + 2) -> h0, h1 -> f1
     }
     h1[0] = zero; h1[1] = zero;
     {
       PrepCtx pc{h0[0], h0[1], one, zero, one, zero, f0, 0.f, 0.f, 0.f, 0.f};
-      pp_unit_F(y, h1, xf, f1, pc, pl, st);                    // p odd: B(p) with f1, A(p + 2) -> h1, h0 -> f0
+      pp_unit_F<DG>(y, h1, xf, f1, pc, pl, st);                    // p odd: B(p) with f1, A(p + 2) -> h1, h0 -> f0
     }
   }
   if constexpr (NF & 1) {
     h0[0] = zero; h0[1] = zero;
     {
       PrepCtx pc{h1[0], h1[1], one, zero, one, zero, f1, 0.f, 0.f, 0.f, 0.f};
-      pp_unit_F(y, h0, xf, f0, pc, pl, st);
+      pp_unit_F<DG>(y, h0, xf, f0, pc, pl, st);
     }
     {
       PrepCtx pc{h0[0], h0[1], one, zero, one, zero, f0, 0.f, 0.f, 0.f, 0.f};
-      pp_unit_BP(y, f1, pc, pl, st);                           // B(P - 2) with f1 ; h(P - 1) -> f0
+      pp_unit_BP<DG>(y, f1, pc, pl, st);                           // B(P - 2) with f1 ; h(P - 1) -> f0
     }
-    pp_unit_B(y, f0, pl, st);
+    pp_unit_B<DG>(y, f0, pl, st);
   } else {
     {
       PrepCtx pc{h1[0], h1[1], one, zero, one, zero, f1, 0.f, 0.f, 0.f, 0.f};
-      pp_unit_BP(y, f0, pc, pl, st);                           // B(P - 2) with f0 ; h(P - 1) -> f1
+      pp_unit_BP<DG>(y, f0, pc, pl, st);                           // B(P - 2) with f0 ; h(P - 1) -> f1
     }
-    pp_unit_B(y, f1, pl, st);
+    pp_unit_B<DG>(y, f1, pl, st);
   }
 }
 
@@ -304,13 +331,13 @@ constexpr int PP_TAIL_SLABS = 2 * 9 + 2 * 18;     // conv tail (9 pairs) + ff_mo
 constexpr int PP_FF1_SLABS = 2 * 18 + 3 * KS32X;  // ff_module_1 (18 pairs) + q, k, v (five plain steps each)
 
 // conv-module tail + ff_module_2 + block-final LayerNorm: xs = dw rows, y = x2 rows on entry; y = the block's output on exit
-template <class ST>
+template <int DG, class ST>
 DEV void pp_tail_consume(const TailFf2Args& a, const PpTailLds& p, int g4, ST& st, PpPool& pl, f32x4 (&xs)[KB], f32x4 (&y)[KB]) {
 #pragma unroll
   for (int i = 0; i < KB; ++i) y[i] += lds4(p.pw2b, i, g4);
   Split8 xf[KS32X];
   split_operand(xf, xs, g4);
-  pp_chain<9>(y, xf, pl, st);                                                        // x3 = x2 + conv module
+  pp_chain<9, DG>(y, xf, pl, st);                                                        // x3 = x2 + conv module
   const float inv_fc = 1.0f / a.fc;
 #pragma unroll
   for (int i = 0; i < KB; ++i) {
@@ -319,15 +346,15 @@ DEV void pp_tail_consume(const TailFf2Args& a, const PpTailLds& p, int g4, ST& s
   }
   ln_lds(xs, p.lng, p.lnb, g4, a.eps);
   split_operand(xf, xs, g4);
-  pp_chain<18>(y, xf, pl, st);
+  pp_chain<18, DG>(y, xf, pl, st);
 #pragma unroll
   for (int i = 0; i < KB; ++i) y[i] = splat4(a.fc) * y[i];
   ln_lds(y, p.fg, p.fb, g4, a.eps);                                                  // block-final LayerNorm
 }
 
 // ff_module_1 + q / k / v projections of the 16 tokens in xs (x0 rows); stores x1 and qkv
-template <class ST>
-DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, PpPool& pl, f32x4 (&xs)[KB]) {
+template <int DG, class ST>
+DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, PpPool& pl, f32x4 (&xs)[KB], int T) {
   f32x4 y[KB];
   const float inv_fc = 1.0f / a.fc;
 #pragma unroll
@@ -335,11 +362,11 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
   ln_lds(xs, p.ln1g, p.ln1b, g4, a.eps);
   Split8 xf[KS32X];
   split_operand(xf, xs, g4);
-  pp_chain<18>(y, xf, pl, st);
+  pp_chain<18, DG>(y, xf, pl, st);
 #pragma unroll
   for (int i = 0; i < KB; ++i) { y[i] = splat4(a.fc) * y[i]; xs[i] = y[i]; }        // x1 = x0 + fc * (ffn + b2)
   {
-    const WaveCtx e = wave_ctx_fresh(a.M);
+    const WaveCtx e = wave_ctx_fresh(a.M, T);
     if (e.live) {
 #pragma unroll
       for (int i = 0; i < KB; ++i) stg4(a.x1 + e.row + 16 * i + e.g4, y[i]);
@@ -354,10 +381,10 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
     for (int i = 0; i < KB; ++i) acc[i] = splat4(0.f);
     static_for<0, KS32X>([&](auto T) {
       constexpr int t = decltype(T)::value;
-      pp_unit_S(acc, xf[t], pl, st);
+      pp_unit_S<DG>(acc, xf[t], pl, st);
     });
     const float sc = q == 0 ? a.qscale : 1.0f;
-    const WaveCtx e = wave_ctx_fresh(a.M);
+    const WaveCtx e = wave_ctx_fresh(a.M, T);
     if (e.live) {
       float* qrow = a.qkv + (size_t)e.tok * (3 * D) + 16 * q * KB + e.g4;
 #pragma unroll
@@ -366,43 +393,133 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
   }
 }
 
+// ---- depthwise conv in the prologue (DWF) -------------------------------------------------------------------------------------
+// conformer_blocks.py:205 (SeparableConv1D's depthwise half, 'same': 15 / 16 zeros) and chunk_conformer_blocks.py:262 ('causal':
+// 31 zeros in front).  The round-2 path ran it as its own launch (dwconv_tile_kernel: 10 us, of which the work is ~2) and sent
+// dw through HBM.  Here the workgroup's 64 frames + 31 halo rows of u and the 32 x 144 taps are staged in the LDS of ring slots
+// 2..4 (the loaders fetch only slabs 0 and 1 until the prologue is over), 288 threads compute 8 frames x 4 channels each from
+// register windows (the tile kernel's scheme), the results go back through the same LDS in token-major order and the consumer
+// waves pick up their operand rows.  Tiling per utterance (tok_of) keeps the window inside one utterance: rows outside it are
+// the conv's zero padding.
+constexpr int DW_K = 32, DW_ROWS = 64 + DW_K - 1, DW_C4 = D / 4;
+constexpr int DW_WORK = 6 * 64;                 // waves 0..5 stage and compute; waves 6, 7 have the slab DMAs in flight
+DEV void pp_bar_lds() {                         // this wave's LDS operations are done; workgroup barrier; no fence (DMAs stay in flight)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+// all eight waves call this; on return (consumer waves) xs = the depthwise conv output rows of the wave's 16 frames
+DEV void pp_dw_prologue(float* scratch, const TailFf2Args& a, f32x4 (&xs)[KB]) {
+  float* win = scratch;                         // [DW_ROWS][D], later the conv output [64][D]
+  float* wt = scratch + DW_ROWS * D;            // [DW_K][D]
+  const int tid = threadIdx.x;
+  const int T = a.dw_T, f0 = blockIdx.x * 64 - a.dw_pad;        // utterance frame of window row 0
+  const float* __restrict__ ub = a.dw_u + (size_t)blockIdx.y * T * D;
+  constexpr int NL = (DW_ROWS * DW_C4 + DW_WORK - 1) / DW_WORK, NW = (DW_K * DW_C4 + DW_WORK - 1) / DW_WORK;
+  if (tid < DW_WORK) {
+    f32x4 stage[NL], wstage[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) wstage[k] = ldg4(a.dw_wd + 4 * min(tid + k * DW_WORK, DW_K * DW_C4 - 1));
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + k * DW_WORK, r = i / DW_C4, c4 = i - r * DW_C4, f = f0 + r;
+      stage[k] = (i < DW_ROWS * DW_C4 && f >= 0 && f < T) ? ldg4(ub + (size_t)f * D + 4 * c4) : splat4(0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + k * DW_WORK;
+      if (i < DW_ROWS * DW_C4) *reinterpret_cast<f32x4*>(&win[4 * i]) = stage[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const int i = tid + k * DW_WORK;
+      if (i < DW_K * DW_C4) *reinterpret_cast<f32x4*>(&wt[4 * i]) = wstage[k];
+    }
+  }
+  pp_bar_lds();                                                       // P1: window + taps staged
+  constexpr int TS = 8, GJ = 8;
+  f32x4 acc[TS];
+  const int c4 = tid % DW_C4, tg = tid / DW_C4;
+  const bool worker = tid < (64 / TS) * DW_C4;                         // 288 threads: 8 frame groups x 36 channel groups
+  if (worker) {
+    const float* __restrict__ trow = &win[(tg * TS) * D + 4 * c4];
+    const float* __restrict__ wrow = &wt[4 * c4];
+#pragma unroll
+    for (int i = 0; i < TS; ++i) acc[i] = splat4(0.f);
+#pragma unroll 1
+    for (int j0 = 0; j0 < DW_K; j0 += GJ) {
+      f32x4 w8[TS + GJ - 1], tp[GJ];
+#pragma unroll
+      for (int r = 0; r < TS + GJ - 1; ++r) w8[r] = *reinterpret_cast<const f32x4*>(trow + (j0 + r) * D);
+#pragma unroll
+      for (int j = 0; j < GJ; ++j) tp[j] = *reinterpret_cast<const f32x4*>(wrow + (j0 + j) * D);
+#pragma unroll
+      for (int j = 0; j < GJ; ++j)
+#pragma unroll
+        for (int i = 0; i < TS; ++i) acc[i] += w8[i + j] * tp[j];
+    }
+  }
+  pp_bar_lds();                                                       // P2: every window read is done
+  if (worker) {
+#pragma unroll
+    for (int i = 0; i < TS; ++i) *reinterpret_cast<f32x4*>(&win[(tg * TS + i) * D + 4 * c4]) = acc[i];
+  }
+  pp_bar_lds();                                                       // P3: conv output in LDS, token-major
+  if (tid < BLOCK_THREADS) {
+    const int lane = tid & 63, row = (tid >> 6) * 16 + (lane & 15), g4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xs[kb] = *reinterpret_cast<const f32x4*>(&win[row * D + 16 * kb + g4]);
+  }
+  pp_bar_lds();                                                       // P4: the scratch is free: the loaders fill the ring
+}
+
 // TAIL: conv tail + ff_module_2 + LayerNorm of one block (a);  FF1: ff_module_1 + qkv of a block (b) -- of the NEXT block
-// when both are set (the block output stays in registers; a.y may be null then)
-template <bool TAIL, bool FF1>
+// when both are set (the block output stays in registers; a.y may be null then).  DWF: the depthwise conv runs in the
+// prologue (a.dw_u / dw_wd / dw_T / dw_pad) and the grid is (ceil(T / 64), utterances).
+template <bool TAIL, bool FF1, int DG = 0, bool DWF = false>
 __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1QkvArgs b) {
+  static_assert(TAIL || !DWF, "the depthwise conv feeds the conv tail");
   __shared__ __attribute__((aligned(16))) u32x4_t ring[PP_RING * PP_SLB];
   __shared__ __attribute__((aligned(16))) PpTailLds pt;
   __shared__ __attribute__((aligned(16))) PpFf1Lds pf;
+  static_assert((PP_RING - 2) * PP_SLB * 16 >= (DW_ROWS + DW_K) * D * 4, "the prologue scratch is ring slots 2..");
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int N1 = TAIL ? PP_TAIL_SLABS : PP_FF1_SLABS, TOTAL = (TAIL ? PP_TAIL_SLABS : 0) + (FF1 ? PP_FF1_SLABS : 0);
+  float* scratch = reinterpret_cast<float*>(ring + 2 * PP_SLB);
+  f32x4 xs[KB], y[KB];
   if (wv >= WAVES_PER_BLOCK) {
     const u32x4_t* s1 = reinterpret_cast<const u32x4_t*>(TAIL ? a.pp_slabs : b.pp_slabs);
     const u32x4_t* s2 = reinterpret_cast<const u32x4_t*>(b.pp_slabs);
-    PpLoader<PP_RING>{ring, s1, s2, N1, TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    const PpLoader<PP_RING, DG> ld{ring, s1, s2, N1, TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)};
+    if constexpr (DWF) ld.template run<2>([&] { pp_dw_prologue(scratch, a, xs); });
+    else ld.run();
     return;
   }
-  const int M = TAIL ? a.M : b.M;
-  const WaveCtx c = wave_ctx(M);
-  PpReader<PP_RING> st{ring, c.lane};
-  f32x4 xs[KB], y[KB];
+  const int M = TAIL ? a.M : b.M, TT = DWF ? a.dw_T : 0;
+  const WaveCtx c = wave_ctx(M, TT);
+  PpReader<PP_RING, DG> st{ring, c.lane};
   if constexpr (TAIL) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
-#pragma unroll
     for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + c.row + 16 * kb + c.g4);     // residuals ride in the accumulators
+    if constexpr (!DWF) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
+    }
     pp_tail_stash(pt, a);
   } else {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(b.x0 + c.row + 16 * kb + c.g4);
   }
   if constexpr (FF1) pp_ff1_stash(pf, b);
+  if constexpr (DWF) pp_dw_prologue(scratch, a, xs);     // after the parameter loads: their latency hides under the prologue
   st.sync();
   PpPool pl;
-  pp_prime(pl, st);
+  pp_prime<DG>(pl, st);
   if constexpr (TAIL) {
-    pp_tail_consume(a, pt, c.g4, st, pl, xs, y);
+    pp_tail_consume<DG>(a, pt, c.g4, st, pl, xs, y);
     if (a.y) {
-      const WaveCtx e = wave_ctx_fresh(M);
+      const WaveCtx e = wave_ctx_fresh(M, TT);
       if (e.live) {
 #pragma unroll
         for (int i = 0; i < KB; ++i) stg4(a.y + e.row + 16 * i + e.g4, y[i]);
@@ -411,13 +528,22 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
 #pragma unroll
     for (int i = 0; i < KB; ++i) xs[i] = y[i];
   }
-  if constexpr (FF1) pp_ff1_consume(b, pf, c.g4, st, pl, xs);
+  if constexpr (FF1) pp_ff1_consume<DG>(b, pf, c.g4, st, pl, xs, TT);
   // the pool still holds nine reads of the slot after the last one: drain them before the wave ends
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 }  // namespace
 
+// the depthwise conv rides in the tail kernel's prologue when the caller asked for it (dw_u) and the per-utterance tiling wastes
+// little: ceil(T / 64) chunks of 64 frames per utterance (T = 250: 2.4 % idle rows; T = 100 would idle 22 %)
+bool pp_dw_fold_ok(int T, int ksz) {
+  // MI355ASR_PP_DW=0: depthwise conv as its own launch (dwconv_tile_kernel)
+  static const bool on = [] { const char* v = getenv("MI355ASR_PP_DW"); return v ? atoi(v) != 0 : true; }();
+  return on && pp_enabled() && ksz == DW_K && T >= 64 && 64 * ((T + 63) / 64) * 10 <= 11 * T;
+}
+bool pp_enabled();
+static bool pp_dw_fold(const TailFf2Args& a) { return a.dw_u && a.dw_wd && a.dw_T > 0 && a.M % a.dw_T == 0; }
 bool pp_enabled() {
   // MI355ASR_PP=0: the round-2 chunk-wise ring kernels (fused.hip) instead of the pair-pipelined ones
   static const bool on = [] { const char* v = getenv("MI355ASR_PP"); return v ? atoi(v) != 0 : true; }();
@@ -426,12 +552,35 @@ bool pp_enabled() {
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s) {
   if (!pp_enabled() || !a.pp_slabs || !b.pp_slabs || a.M != b.M || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
+#ifdef MI355ASR_DIAG_KERNELS
+  static const int dg = [] { const char* v = getenv("MI355ASR_PP_DIAG"); return v ? atoi(v) : 0; }();
+  if (dg) {
+    static bool warned = false;
+    if (!warned) { fprintf(stderr, "MI355ASR_PP_DIAG=%d: timing-only kernel variant, results are WRONG\n", dg); warned = true; }
+    const dim3 g((tiles + 3) / 4), t(LD_THREADS);
+#define PP_DIAG_CASE(N) case N: hipLaunchKernelGGL((pp_block_kernel<true, true, N>), g, t, 0, s, a, b); return 0;
+    switch (dg) {
+      PP_DIAG_CASE(1) PP_DIAG_CASE(2) PP_DIAG_CASE(3) PP_DIAG_CASE(4) PP_DIAG_CASE(8) PP_DIAG_CASE(16) PP_DIAG_CASE(24)
+      PP_DIAG_CASE(26) PP_DIAG_CASE(27) PP_DIAG_CASE(25) PP_DIAG_CASE(7) PP_DIAG_CASE(10) PP_DIAG_CASE(18)
+      default: break;
+    }
+#undef PP_DIAG_CASE
+  }
+#endif
+  if (pp_dw_fold(a)) {
+    hipLaunchKernelGGL((pp_block_kernel<true, true, 0, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, b);
+    return 0;
+  }
   hipLaunchKernelGGL((pp_block_kernel<true, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, b);
   return 0;
 }
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s) {
   if (!pp_enabled() || !a.pp_slabs || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
+  if (pp_dw_fold(a)) {
+    hipLaunchKernelGGL((pp_block_kernel<true, false, 0, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{});
+    return 0;
+  }
   hipLaunchKernelGGL((pp_block_kernel<true, false>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{});
   return 0;
 }

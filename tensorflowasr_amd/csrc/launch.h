@@ -255,14 +255,22 @@ struct TailFf2Args {
   int M;
   const float* slabs = nullptr;   // slab stream of tail_ff2_ring_kernel (60 slabs of 1792 fragments), or null
   const float* pp_slabs = nullptr;   // pair-pipelined stream (fused_pp.hip: 54 ring slots; BatchNorm and biases folded into W1), or null
+  // depthwise conv folded into the pair-pipelined kernel's prologue (fused_pp.hip): when dw_u is set, `dw` is not read -- the
+  // kernel tiles the tokens per utterance (64-token chunks of the dw_T frames of each of M / dw_T utterances) and computes
+  // dw = depthwise_k32(u) (taps dw_wd [32, 144], dw_pad zeros in front) from a 95-row window in LDS
+  const float* dw_u = nullptr;
+  const float* dw_wd = nullptr;
+  int dw_T = 0, dw_pad = 0;
 };
 int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s);
 int launch_out_glu(const OutGluArgs& a, hipStream_t s);
 int launch_tail_ff2(const TailFf2Args& a, hipStream_t s);
 bool tail_ff1_available();
+bool tail_pp_selected();   // launch_tail_ff1 / launch_tail_ff2 will take the pair-pipelined kernels when the block has their streams
 int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);   // -1: not available, nothing launched
 // pair-pipelined versions (fused_pp.hip); -1: switched off (MI355ASR_PP=0) or no pp_slabs, nothing launched
 bool pp_enabled();
+bool pp_dw_fold_ok(int T, int ksz);   // the tail kernels can take the depthwise conv (kernel size ksz, T frames per utterance) in their prologue
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);

@@ -18,8 +18,8 @@ instead of 2160), h is 2 x 2 tiles instead of 9, and the bias (and the folded Ba
 the K padding of the fifth k-step -- against a constant 1.0 operand, so nothing in the loop reads parameters from LDS.
 
 The fragment stream is a linear sequence of 1 KB fragments in consumption order, cut into ring slots of 30 fragments.
-A wave keeps NPOOL = 9 fragment registers; the fragment at stream position q lives in pool slot q % 9 and the read of
-position q + 9 is issued as soon as the MFMAs of position q have issued (same depth as the round-2 in-place refill).
+A wave keeps NPOOL fragment registers; the fragment at stream position q lives in pool slot q % NPOOL and the read of
+position q + NPOOL is issued as soon as the MFMAs of position q have issued (same depth as the round-2 in-place refill).
 Every unit's stream length is a multiple of 9 (padded with idle positions before the unit's last block), so each unit starts and ends in the same state:
 the first nine fragments of the next slab in flight, in order, in slots 0..8.  LDS returns in order, hence every wait
 is a counted `s_waitcnt lgkmcnt(n)`; the simulator below checks each count, each slot reuse, each ring-slot hand-over
@@ -28,7 +28,7 @@ and that every (accumulator tile, k-step) receives its six term pairs exactly on
 import os
 import sys
 
-NPOOL = 9
+NPOOL = int(os.environ.get("PP_NPOOL", "9"))     # fragment registers of a wave (the pool); 9 / 12 / 15 / 18 measure the same on the GPU
 SLOT = 30          # fragments (KB) per ring slot
 NPREP = 48         # slots of the activation + split schedule (prep_sched.inc, AFF = false, FULL = true)
 
@@ -53,26 +53,30 @@ def b_block(cg, kind):
     return frags, batches, acc, x
 
 
-# name: (blocks per ring slot, prep?, idle positions).  A unit's stream length must be a multiple of 9 so that it hands the
-# pool over in the canonical state; the A / AP / F units have 30 / 57 fragments, so six stream positions stay empty (the pool
-# slot idles for one turn).  Where they sit decides how long before its first use a fragment is requested: an empty position
-# before fragment index r shortens the lead of the reads that cross it.  The placements below maximise the minimum lead
-# (found by search, tools/gen_pp.py history): 8 MFMAs for F, 7 for A / AP (the round-2 in-place refill: 9).
+# name: (blocks per ring slot, prep?).  A unit's stream length must be a multiple of NPOOL so that it hands the pool over in
+# the canonical state; the fragment counts (30 / 57 / 27) are not, so some stream positions stay empty (the pool slot idles
+# for one turn).  Where they sit decides how long before its first use a fragment is requested: an empty position before
+# fragment index r shortens the lead of the reads that cross it.  VPADS holds, per pool size, the placements that maximise
+# the minimum lead in MFMAs (found by `python tools/gen_pp.py --search`, exhaustive or random search).
 UNITS = {
-    "A": ([[("A", 0), ("A", 1), ("A", 2), ("A", 3), ("A", 4)]], False, (11, 16, 17, 19, 20, 22)),
-    "AP": ([[("A", 0), ("A", 1), ("A", 2), ("A", 3), ("A", 4)]], True, (11, 16, 17, 19, 20, 22)),
-    "F": ([[("B", 0), ("A", 0), ("A", 1), ("B", 1)], [("A", 2), ("A", 3), ("B", 2), ("A", 4)]], True, (15, 28, 35, 38, 41, 48)),
+    "A": ([[("A", 0), ("A", 1), ("A", 2), ("A", 3), ("A", 4)]], False),
+    "AP": ([[("A", 0), ("A", 1), ("A", 2), ("A", 3), ("A", 4)]], True),
+    "F": ([[("B", 0), ("A", 0), ("A", 1), ("B", 1)], [("A", 2), ("A", 3), ("B", 2), ("A", 4)]], True),
     "BP": ([[("B", 0), ("B", 1), ("B", 2)]], True),
     "B": ([[("B", 0), ("B", 1), ("B", 2)]], False),
     "S": ([[("S", 0), ("S", 1), ("S", 2)]], False),
 }
+VPADS = {
+    9: {"A": (11, 16, 17, 19, 20, 22), "AP": (11, 16, 17, 19, 20, 22), "F": (15, 28, 35, 38, 41, 48), "BP": (), "B": (), "S": ()},
+    15: {"A": (), "AP": (), "F": (21, 27, 42), "BP": (15, 15, 15), "B": (15, 15, 15), "S": (15, 15, 15)},
+}
 
 
 class Unit:
-    def __init__(self, name):
+    def __init__(self, name, vpads=None):
         self.name = name
-        slabs, self.prep = UNITS[name][:2]
-        vat = set(UNITS[name][2]) if len(UNITS[name]) > 2 else set()   # an idle position before each of these fragment indices
+        slabs, self.prep = UNITS[name]
+        vat = sorted(VPADS[NPOOL][name] if vpads is None else vpads)    # an idle position before each of these fragment indices (repeats allowed)
         nreal = 0
         self.pos = []          # stream positions: dict(frag, slab, off, acc, ) or None for a dummy
         self.blocks = []       # (first position, batches, accfn, xfn)
@@ -84,8 +88,7 @@ class Unit:
                 self.blocks.append((len(self.pos), batches, acc, x, si))
                 first = None
                 for f in frags:
-                    if nreal in vat:
-                        self.pos.append(None)
+                    self.pos += [None] * vat.count(nreal)
                     if first is None:
                         first = len(self.pos)
                     self.pos.append({"frag": f, "slab": si, "off": len(lay)})
@@ -266,6 +269,20 @@ def emit_units(units):
     w("// generator's docstring).  Macros (fused_pp.hip): PP_RD(slot, addr, OFF) = ds_read_b128 into pool slot; PP_WTn(N, slots...) =")
     w("// s_waitcnt lgkmcnt(N) tied to the slots; PP_MM(acc, slot, x) = one v_mfma_f32_16x16x32_bf16; PP_PREP(k) = slot k of the")
     w("// activation + split schedule on (pc.lo, pc.hi) -> pc.out; PP_FENCE = sched_barrier(0).")
+    w("constexpr int PP_NPOOL = %d;" % NPOOL)
+    w("struct PpPool { u32x4_t f[PP_NPOOL]; };")
+    w("// the first PP_NPOOL fragments of the first slab (the state every unit starts from and leaves behind for the next slab)")
+    w("template <int DG, class ST>")
+    w("DEV void pp_prime(PpPool& pl, ST& st) {")
+    w("  const unsigned a0 = st.cur_addr();")
+    w("  if constexpr (DG & 2) {")
+    w("#pragma unroll")
+    w("    for (int i = 0; i < PP_NPOOL; ++i) pl.f[i] = u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};")
+    w("  }")
+    for i in range(NPOOL):
+        w("  PP_RD(%d, a0, %d);" % (i, i * 1024))
+    w("}")
+    w("")
     for u in units:
         args = {
             "A": "f32x4 (&ha)[2], const Split8 (&xf)[KS32X]",
@@ -276,7 +293,7 @@ def emit_units(units):
             "S": "f32x4* acc, const Split8& xs",
         }[u.name]
         w("// unit %s: %d fragments (+%d idle positions), %d MFMAs, %d ring slot(s)" % (u.name, u.real, u.length - u.real, u.nm, u.nslabs))
-        w("template <class ST>")
+        w("template <int DG, class ST>")
         w("DEV void pp_unit_%s(%s, PpPool& pl, ST& st) {" % (u.name, args))
         w("  unsigned a0 = st.cur_addr(), a1 = st.next_addr();")
         for op in u.ops:
@@ -285,6 +302,7 @@ def emit_units(units):
                 w("  PP_RD(%d, a%d, %d);" % (slot, rel, off * 1024))
             elif op[0] == "wt":
                 n, slots = op[1], op[2]
+                n = min(n, 15)          # lgkmcnt is a 4-bit field: a smaller count only waits for more
                 if slots:
                     w("  PP_WT%d(%d, %s);" % (len(slots), n, ", ".join(str(s) for s in slots)))
                 else:
@@ -318,7 +336,58 @@ def emit_layout(units):
     return "\n".join(out) + "\n"
 
 
+def lead_profile(u):
+    mi, issue, first = 0, {}, {}
+    for op in u.ops:
+        if op[0] == "rd":
+            issue[op[4]] = mi
+        if op[0] == "mm":
+            if op[4] not in first:
+                first[op[4]] = mi
+            mi += 1
+    return sorted(first[q] - issue[q] for q in first if q in issue)
+
+
+def search(name, iters=4000, seed=0):
+    """idle-position placement for unit `name` at the current NPOOL: maximise (min lead, sum of the six smallest leads)"""
+    import itertools
+    import random
+    blocks = [b for slab in UNITS[name][0] for b in slab]
+    nreal = sum(6 if k == "A" else 9 for k, _ in blocks)
+    nv = (-nreal) % NPOOL
+    if nv == 0:
+        return ()
+    rng = random.Random(seed)
+    cands = itertools.combinations_with_replacement(range(NPOOL, nreal), nv)
+    total = 1
+    for i in range(nv):
+        total = total * (nreal - NPOOL + i) // (i + 1)
+    if total > iters:
+        fixed = [(a,) * k + (b,) * (nv - k) for a in range(NPOOL, nreal) for b in range(a, nreal) for k in range(1, nv + 1)]
+        cands = itertools.chain(fixed, (tuple(sorted(rng.randrange(NPOOL, nreal) for _ in range(nv))) for _ in range(iters)))
+    best = None
+    for c in cands:
+        try:
+            u = Unit(name, c)
+            simulate(u)
+        except (AssertionError, ValueError, IndexError):
+            continue
+        l = lead_profile(u)
+        key = (l[0], sum(l[:6]))
+        if best is None or key > best[0]:
+            best = (key, c)
+    assert best is not None, "no valid placement for " + name
+    return best[1]
+
+
 def build_all():
+    if NPOOL not in VPADS:
+        VPADS[NPOOL] = {}
+        for n in ("A", "F", "B"):
+            VPADS[NPOOL][n] = search(n)
+        VPADS[NPOOL]["AP"] = VPADS[NPOOL]["A"]
+        VPADS[NPOOL]["BP"] = VPADS[NPOOL]["S"] = VPADS[NPOOL]["B"]
+        print("VPADS[%d] = %r" % (NPOOL, VPADS[NPOOL]), file=sys.stderr)
     units = [Unit(n) for n in ("A", "AP", "F", "BP", "B", "S")]
     stats = {}
     for u in units:
