@@ -109,6 +109,34 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
     Kf[2][wv][lane] = kf.t[2];
     Kt[wv][lane] = ktl;
   }
+  __syncthreads();                     // K fragments staged; the V rows are still in flight / in registers
+  const bool active = qt * 16 < TQ;    // (waves without queries still stage their share of V)
+  const int nkt = (T + 15) / 16;       // key tiles that hold at least one real key (uniform)
+  const Split8 qf = split8(qlo * splat4(LOG2E), qhi * splat4(LOG2E));
+
+  // ---- S^T = K Q^T: lane holds S^T[key = 16 kt + 4 g + j][query c] in log2 units
+  f32x4 sc[NKT];
+  auto qk_tile = [&](int kt) {
+    const u32x4_t kf[3] = {Kf[0][kt][lane], Kf[1][kt][lane], Kf[2][kt][lane]};
+    const float kl = Kt[kt][lane];
+    f32x4 acc = mma_split(kf, qf, splat4(0.f));
+    sc[kt] = mfma4(kl, qtl, acc);
+  };
+  const bool full = (nkt == NKT);
+  if (active) {
+    if (full) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) qk_tile(kt);
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) qk_tile(kt); else sc[kt] = splat4(-INFINITY);
+      }
+    }
+  }
+
+  // ---- stage V behind the Q K^T products (round 3: the loads were issued before the K staging, so their latency and the
+  // scattered 16-bit LDS writes below no longer sit in front of the first MFMA; the writes drain under the softmax)
   unsigned short* vh = reinterpret_cast<unsigned short*>(&Vf[0][0][0][0]);
 #pragma unroll
   for (int it = 0; it < NV; ++it) {
@@ -132,29 +160,7 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
       }
     }
   }
-  __syncthreads();
-  if (qt * 16 >= TQ) return;
-  const int nkt = (T + 15) / 16;       // key tiles that hold at least one real key (uniform)
-  const Split8 qf = split8(qlo * splat4(LOG2E), qhi * splat4(LOG2E));
-
-  // ---- S^T = K Q^T: lane holds S^T[key = 16 kt + 4 g + j][query c] in log2 units
-  f32x4 sc[NKT];
-  auto qk_tile = [&](int kt) {
-    const u32x4_t kf[3] = {Kf[0][kt][lane], Kf[1][kt][lane], Kf[2][kt][lane]};
-    const float kl = Kt[kt][lane];
-    f32x4 acc = mma_split(kf, qf, splat4(0.f));
-    sc[kt] = mfma4(kl, qtl, acc);
-  };
-  const bool full = (nkt == NKT);
-  if (full) {
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) qk_tile(kt);
-  } else {
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt < nkt) qk_tile(kt); else sc[kt] = splat4(-INFINITY);
-    }
-  }
+  if (!active) { __syncthreads(); return; }
 
   // ---- softmax over keys: keys >= T are masked, which only the last real tile can contain
   float mx = -INFINITY;
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
     psum += (sc[kt].x + sc[kt].y) + (sc[kt].z + sc[kt].w);
   }
 
+  __syncthreads();                     // V fragments staged
   // ---- O^T[feat][query] += V^T[feat][key] P^T[key][query], 32 keys per step
   f32x4 o[OT];
 #pragma unroll
