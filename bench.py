@@ -43,6 +43,9 @@ def kernel_peak(name):
             "tail_ff1": ("MI355ASR_TAILFF2_RING", "2"), "ctc_head": ("MI355ASR_HEAD_RING", "1")}
     if name in ring and int(os.environ.get(*ring[name]) or 0):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
+    if name == "attention" and int(os.environ.get("MI355ASR_ATTN_SPLIT", "1") or 0):
+        # attention_split_kernel (head size 36, T <= 256): Q K^T and P V on the bf16 pipe with split operands
+        return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA"
 PEAK_HBM_GBS = 8000.0
 
@@ -161,6 +164,270 @@ def cpu_baseline(seconds_budget=12.0):
             "published_tf2_1core": PUBLISHED_TF2_1CORE}
 
 
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md); config 3 runs its dense layers with bf16 operands
+
+
+def block_flops(M, B, T, d, k, nblocks):
+    """ALGORITHMIC flops per step of the block-level categories of a stack of `nblocks` ConformerBlocks over M = B * T rows"""
+    one = {"ffn": 2 * (2.0 * 2 * M * d * 4 * d), "qkv": 3 * 2.0 * M * d * d, "attention": 2 * 2.0 * B * T * T * d,
+           "attn_out": 2.0 * M * d * d, "pw1_glu": 2.0 * M * d * 2 * d, "dwconv": 2.0 * M * d * k,
+           "conv_tail": 2.0 * M * d * 2 * d + 2.0 * M * 2 * d * d}
+    return {n: v * nblocks for n, v in one.items()}
+
+
+def _read_profile(lib, h, nk, steps):
+    ms, cnt = (ctypes.c_double * nk)(), (ctypes.c_int64 * nk)()
+    _lib.check(lib.mi355asr_profile_read(h.ptr, ms, cnt, nk, 1))
+    return {n: (ms[i] / steps, cnt[i] // max(steps, 1)) for i, n in enumerate(_lib.KERNEL_NAMES) if cnt[i]}
+
+
+def _timed(fn, steps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_config3(lib, device, steps=20, with_cpu=True):
+    """BASELINE.json configs[2]: StreamingConformerCTC (d = 256, 4 blocks, k = 5; CTCDecoder 1 block, k = 32), 64 streaming
+    chunks of 0.5 s per step, dense layers with bf16 operands: one encoder pass over the 64 new chunks + the reference's
+    "global CTC" over 10 s of history per stream (conformer_blocks.py:574-594, :385-438) + greedy collapse."""
+    from tensorflowasr_amd.models import CTCDecoder, StreamingConformerEncoder, ctc_greedy_decode
+    B, chunk, hist, d, V = 64, 8000, 20, 256, NUM_CLASSES
+    enc = StreamingConformerEncoder(dmodel=d, reduction_factor=4, num_blocks=4, head_size=64, num_heads=4, kernel_size=5,
+                                    fc_factor=0.5, sample_rate=16000, n_mels=80, stride_ms=10,
+                                    mel_layer_type="Melspectrogram", gemm_dtype="bfloat16", device=device)
+    enc.add_chunk_size(chunk, 80, 640)
+    enc._build(seed=0)
+    ctc = CTCDecoder(num_classes=V, dmodel=d, num_blocks=1, head_size=64, num_heads=4, kernel_size=32, fc_factor=0.5,
+                     gemm_dtype="bfloat16", device=device)
+    ctc._build(seed=1)
+    wav = torch.from_numpy(synth_batch(0, B, chunk)).to(device)
+    history = torch.randn(B, hist * 13, d, device=device)
+
+    def step():
+        e = enc(wav)
+        h = torch.cat([history[:, 13:], e], 1)
+        _, amax = ctc(h, return_argmax=True)
+        return ctc_greedy_decode(amax, None, blank=V - 1)
+
+    t = _timed(step, steps)
+    nk = len(_lib.KERNEL_NAMES)
+    for m in (enc, ctc):
+        _lib.check(lib.mi355asr_profile_enable(m._h.ptr, 1))
+        torch.cuda.synchronize()
+        _read_profile(lib, m._h, nk, 1)
+    _timed(step, steps, warmup=0)
+    pe, pc = _read_profile(lib, enc._h, nk, steps), _read_profile(lib, ctc._h, nk, steps)
+    for m in (enc, ctc):
+        _lib.check(lib.mi355asr_profile_enable(m._h.ptr, 0))
+    # flops per step: encoder over 64 x 13 rows (frontend: 50 mel frames per chunk), CTCDecoder over 64 x 260 rows
+    Me, Te, Mc, Tc = B * 13, 13, B * hist * 13, hist * 13
+    fe = block_flops(Me, B, Te, d, 5, 4)
+    fe.update({"stft": 2.0 * B * 50 * (32 * 32 * 64 + 32 * 64 * 32), "subconv": 2.0 * B * 25 * 40 * d * 9 + 2.0 * Me * 20 * d * 9 * d,
+               "sublinear": 2.0 * Me * 20 * d * d})
+    fc = block_flops(Mc, B, Tc, d, 32, 1)
+    fc.update({"ctc_project": 2.0 * Mc * d * d, "ctc_head": 2.0 * Mc * d * V})
+    dense = ("ffn", "qkv", "attn_out", "pw1_glu", "conv_tail", "ctc_project", "ctc_head", "sublinear")
+    kern = {}
+    for tag, prof, fl in (("enc", pe, fe), ("ctc", pc, fc)):
+        for n, (ms_step, launches) in prof.items():
+            f = fl.get(n, 0.0)
+            peak = PEAK_BF16_TFLOPS if n in dense else (PEAK_SPLIT3_TFLOPS if n == "subconv" else PEAK_FP32_MFMA_TFLOPS)
+            kern[tag + "." + n] = {"launches_per_step": launches, "ms_per_step": round(ms_step, 4),
+                                   "tflops": round(f / (ms_step * 1e-3) / 1e12, 2) if f else None,
+                                   "frac_of_peak": round(f / (ms_step * 1e-3) / 1e12 / peak, 4) if f else None}
+    dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
+    dpeak = PEAK_BF16_TFLOPS if dom.split(".")[1] in dense else (PEAK_SPLIT3_TFLOPS if dom.endswith("subconv") else PEAK_FP32_MFMA_TFLOPS)
+    out = {"workload": "StreamingConformerCTC 15M, batch=64 streaming chunks of 0.5 s, bf16 MFMA operands, global CTC over 10 s of history",
+           "dtype": "bf16 (GEMM operands; f32 accumulate, LayerNorm, softmax, frontend)", "steps": steps,
+           "ms_per_step": round(t * 1e3, 3), "chunks_per_s": round(B / t, 1), "frames_per_s": round(B * 50 / t, 1),
+           "rtf_per_stream": round(t / 0.5, 6),
+           "roofline": {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": dpeak, "unit": "TFLOP/s",
+                        "frac": kern[dom]["frac_of_peak"], "traffic": None,
+                        "note": "categories are (handle).(layer kind) summed over their launches of one step; at 832 encoder rows "
+                                "the step is launch- and latency-bound (DESIGN.md section 3, bf16 mode)"},
+           "kernels": kern}
+    if with_cpu:
+        from oracle import conformer_oracle as co          # checker only: the CPU baseline leg
+        cfg = dict(co.STREAMING_S)
+        w = co.encoder_weights(cfg, seed=0)
+        w.update(co.ctc_decoder_weights(cfg, V))
+        x1 = co.synth_wave(0, chunk)[None]
+        h1 = np.random.default_rng(0).standard_normal((1, Tc, d)).astype(np.float32)
+        reps, tt = 0, 0.0
+        while reps < 1 or (tt < 5.0 and reps < 6):
+            t0 = time.perf_counter()
+            co.streaming_conformer_encoder(x1, w, cfg, chunk, dtype=np.float32)
+            lg = co.ctc_decoder(h1, w, cfg, dtype=np.float32)
+            co.ctc_greedy(lg, [lg.shape[1]], V - 1)
+            tt += time.perf_counter() - t0
+            reps += 1
+        out["cpu_baseline"] = {"value": round(50.0 * reps / tt, 1), "unit": "audio-frames/s", "kind": "port",
+                               "cores": int(os.cpu_count() or 1),
+                               "sample": "%d x (1 stream: one 0.5 s chunk through the encoder + CTCDecoder over 260 history frames), "
+                                         "fp32 NumPy oracle, %.1f s total" % (reps, tt)}
+    del enc, ctc
+    return out
+
+
+def extra_config5(lib, device, steps=5, with_cpu=True):
+    """BASELINE.json configs[4] per GPU: ChunkConformer `predict` (front, 15-block band-attention encoder, phone picker,
+    feature_pick, context helper, text decoder: chunk_conformer_blocks.py:815-822) over 16 x 30 s utterances + CTC prefix
+    beam search (beam 10, cutoff_top_n 40) of the text logits on the device."""
+    from tensorflowasr_amd.config import load_yaml
+    from tensorflowasr_amd.models import ChunkConformer, ctc_prefix_beam_decode
+    cfg = load_yaml(os.path.join(ROOT, "tensorflowasr_amd", "configs", "chunk_conformerS.yml"))
+    Vp, Vt = NUM_CLASSES, 9160
+    m = ChunkConformer(cfg, phone=Vp, txt=Vt, device=device)
+    m._build(seed=0)
+    B, L, d = 16, 480000, 144
+    wav = torch.from_numpy(synth_batch(0, B, L)).to(device)
+    out = {}
+
+    def predict():
+        out["logits"], out["counts"] = m.predict(wav)
+
+    def decode():
+        return ctc_prefix_beam_decode(out["logits"], out["counts"], beam_width=10, cutoff_prob=0.99, cutoff_top_n=40, is_logits=True)
+
+    def step():
+        predict()
+        return decode()
+
+    t = _timed(step, steps)
+    tp = _timed(predict, steps, warmup=0)
+    # the same work with the beam search of batch n on a second stream while batch n + 1 is predicted
+    from tensorflowasr_amd.models import ChunkBeamPipeline
+    pipe = ChunkBeamPipeline(m, beam_width=10, cutoff_prob=0.99, cutoff_top_n=40)
+    pipe.push(wav)
+    pipe.push(wav)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.push(wav)
+    pipe.flush()
+    torch.cuda.synchronize()
+    t_pipe = (time.perf_counter() - t0) / steps
+    pipe.close()
+    nk = len(_lib.KERNEL_NAMES)
+    _lib.check(lib.mi355asr_profile_enable(m._h.ptr, 1))
+    torch.cuda.synchronize()
+    _read_profile(lib, m._h, nk, 1)
+    _timed(predict, steps, warmup=0)
+    prof = _read_profile(lib, m._h, nk, steps)
+    _lib.check(lib.mi355asr_profile_enable(m._h.ptr, 0))
+    T = m.out_frames(L)[1]
+    Tp = int(out["logits"].shape[1])
+    M, Mp = B * T, B * Tp
+    mc = cfg["model_config"]
+    nb = {k: mc[n]["num_blocks"] for k, n in (("enc", "ChunkConformerEncoder"), ("pick", "ChunkCTCPicker"),
+                                              ("help", "ContextHelper"), ("dec", "ChunkCTCDecoder"))}
+    f_tail = lambda rows: 2.0 * rows * d * 2 * d + 2.0 * rows * 2 * d * d + 2.0 * 2 * rows * d * 4 * d      # conv tail + ff_module_2
+    f_ff1 = lambda rows: 2.0 * 2 * rows * d * 4 * d + 3 * 2.0 * rows * d * d                               # ff_module_1 + qkv
+    # launches of one predict(): a stack of n blocks = 1 x ff1_qkv, (n - 1) x tail_ff1, 1 x tail_ff2
+    fl = {"tail_ff1": (nb["enc"] - 1 + nb["pick"] - 1) * (f_tail(M) + f_ff1(M)) + (nb["help"] - 1 + nb["dec"] - 1) * (f_tail(Mp) + f_ff1(Mp)),
+          "tail_ff2": 2 * f_tail(M) + 2 * f_tail(Mp), "ff1_qkv": 2 * f_ff1(M) + 2 * f_ff1(Mp),
+          "out_glu": (nb["enc"] + nb["pick"]) * 3 * 2.0 * M * d * d + (nb["help"] + nb["dec"]) * 3 * 2.0 * Mp * d * d,
+          "ctc_head": 2.0 * M * d * Vp + 2.0 * Mp * d * Vt, "subconv": 2.0 * B * 1501 * 40 * d * 9 + 2.0 * M * 20 * d * 9 * d,
+          "sublinear": 2.0 * M * 20 * d * d}
+    split = ("tail_ff1", "tail_ff2", "ff1_qkv", "out_glu", "ctc_head")
+    kern = {}
+    for n, (ms_step, launches) in prof.items():
+        f = fl.get(n, 0.0)
+        peak = PEAK_SPLIT3_TFLOPS if n in split else PEAK_FP32_MFMA_TFLOPS
+        kern[n] = {"launches_per_step": launches, "ms_per_step": round(ms_step, 4),
+                   "tflops": round(f / (ms_step * 1e-3) / 1e12, 2) if f else None,
+                   "frac_of_peak": round(f / (ms_step * 1e-3) / 1e12 / peak, 4) if f else None}
+    dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
+    res = {"workload": "ChunkConformer 15M + CTC prefix beam (beam 10), 16 x 30 s utterances per GPU (batch=128 over 8 GPUs), fp32",
+           "dtype": "f32", "steps": steps, "ms_per_step": round(t * 1e3, 3), "ms_predict": round(tp * 1e3, 3),
+           "ms_beam10": round((t - tp) * 1e3, 3), "frames_per_s": round(B * 3000 / t, 1), "picked_frames_max": Tp,
+           "pipelined": {"ms_per_step": round(t_pipe * 1e3, 3), "frames_per_s": round(B * 3000 / t_pipe, 1),
+                         "how": "beam search of batch n on a second stream (helper thread) while batch n + 1 is predicted (models.ChunkBeamPipeline)"},
+           "roofline": {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"],
+                        "peak": round(PEAK_SPLIT3_TFLOPS if dom in split else PEAK_FP32_MFMA_TFLOPS, 1), "unit": "TFLOP/s",
+                        "frac": kern[dom]["frac_of_peak"], "traffic": None,
+                        "note": "categories of predict() summed over their launches of one step; the prefix beam search is a latency "
+                                "chain (16 utterances x T_pick dependent frames), not a roofline kernel"},
+           "kernels": kern}
+    if with_cpu:
+        from oracle import conformer_oracle as co          # checker only: the CPU baseline leg
+        c5 = dict(co.CHUNK_S)
+        w5 = co.chunk_weights(c5, seed=0)
+        x5 = co.synth_wave(0, L)[None]
+        t0 = time.perf_counter()
+        co.chunk_predict(x5, w5, c5, dtype=np.float32)
+        tt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(3000.0 / tt, 1), "unit": "audio-frames/s", "kind": "port", "cores": int(os.cpu_count() or 1),
+                               "sample": "1 x (one 30 s utterance through chunk_predict, fp32 NumPy oracle; beam search not included), %.1f s" % tt}
+    del m
+    return res
+
+
+def config5_main(args, world, rank, device, use_dist):
+    """`bench.py --config 5 [--gpus N]`: BASELINE.json configs[4] as its own contract line -- ChunkConformer predict + device
+    prefix beam search (beam 10) over 16 x 30 s utterances per GPU (weak scaling: 128 utterances over 8 GPUs), the beams of
+    all ranks exchanged with parallel.all_gather_hypotheses.  Same timing rules as the headline line."""
+    from tensorflowasr_amd.config import load_yaml
+    from tensorflowasr_amd.models import ChunkConformer, ctc_prefix_beam_decode
+    dist = None
+    if use_dist:
+        import torch.distributed as dist
+        from tensorflowasr_amd.parallel import all_gather_hypotheses, broadcast_weights
+    cfg = load_yaml(os.path.join(ROOT, "tensorflowasr_amd", "configs", "chunk_conformerS.yml"))
+    m = ChunkConformer(cfg, phone=NUM_CLASSES, txt=9160, device=device)
+    m._build(seed=0)
+    if use_dist:
+        m.load_weights(broadcast_weights(m.get_weights_dict(), src=0, device=device), by_name=False)
+    B, L = 16, 480000
+    wav = torch.from_numpy(synth_batch(rank * B, B, L)).to(device)
+
+    def step():
+        logits, counts = m.predict(wav)
+        hyp = ctc_prefix_beam_decode(logits, counts, beam_width=10, cutoff_prob=0.99, cutoff_top_n=40, is_logits=True)
+        return all_gather_hypotheses(*hyp, device=device) if use_dist else hyp
+
+    for _ in range(args.warmup):
+        step()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        del m
+        torch.cuda.empty_cache()
+        extra = extra_config5(_lib.lib(), device, steps=max(2, min(args.steps, 5)), with_cpu=(world == 1 and not args.no_cpu_baseline))
+        line = {"metric": "audio-frames/sec, ChunkConformer 15M + CTC prefix beam (beam 10), 30 s utts, 16 per MI355X",
+                "value": round(world * B * 3000 * args.steps / dt, 1), "unit": "audio-frames/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": extra["workload"], "global_batch": world * B, "samples_per_utt": L,
+                           "parallelism": "dp%d" % world, "weights": "random-init (Keras defaults)"},
+                "roofline": extra["roofline"], "kernels": extra["kernels"], "ms_predict": extra["ms_predict"],
+                "ms_beam10": extra["ms_beam10"]}
+        if "cpu_baseline" in extra:
+            line["cpu_baseline"] = extra["cpu_baseline"]
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +437,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer (PCIe-inclusive) variant")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5],
+                    help="2 (default): the headline ConformerCTC(S) line; 5: ChunkConformer + prefix beam as its own line")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip BASELINE configs 3 (streaming, bf16) and 5 (ChunkConformer + prefix beam) after the headline region")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-kernel HIP events in the timed region (roofline fields become null)")
     args = ap.parse_args()
@@ -194,6 +465,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
         from tensorflowasr_amd.parallel import all_gather_ids
 
+    if args.config == 5:
+        return config5_main(args, world, rank, device, use_dist)
     B, L = args.batch, int(args.seconds * 16000)
     model = build_model(device, rank, world, use_dist)
     wav = torch.from_numpy(synth_batch(rank * B, B, L)).to(device)      # inputs resident in HBM
@@ -377,8 +650,20 @@ def main():
             "h2d_inclusive": h2d,
             "kernels": kern,
         }
+        if os.environ.get("MI355ASR_BENCH_DEBUG_NO_GATHER") == "1":
+            line["debug_no_gather"] = True       # the id exchange was removed from the timed step: not a data-parallel measurement
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_extra_configs:
+            # BASELINE.json configs 3 and 5 on the same box, after (never inside) the headline region: their own keys,
+            # each with its dominant kernel category against its roofline and a bounded CPU sample of the oracle
+            del model
+            torch.cuda.empty_cache()
+            for key, fn in (("config3", extra_config3), ("config5", extra_config5)):
+                try:
+                    line[key] = fn(lib, device, with_cpu=not args.no_cpu_baseline)
+                except Exception as e:           # the headline line must not die with an extra
+                    line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

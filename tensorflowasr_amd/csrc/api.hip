@@ -129,6 +129,43 @@ void append_slabs(std::vector<float>& stream, const std::function<float(int, int
 }
 
 
+// conv2 kernel [3][3][d][d] (HWIO) as split-bf16 fragments for subconv_split_ring_kernel: column chunks of NTc tiles (all
+// nine at dmodel 144, eight otherwise); step s = 5 cb + pair; lane (r = lane & 15, g = lane >> 4) of column tile nt holds,
+// for out channel 16 nt + r, in-channels 16 cb + 4 g + (j & 3) at tap 2 pair + (j >> 2) (the tenth tap is zero); term t =
+// round-to-nearest-even bf16 of what the terms before it left
+std::vector<float> pack_conv2_split(const std::vector<float>& c2, int d) {
+  const int steps = (d / 16) * 5, NTc = d == 144 ? 9 : 8, chunks = (d / 16) / NTc;
+  std::vector<uint16_t> frag((size_t)chunks * steps * NTc * 3 * 64 * 8);
+  auto rne = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); };
+  for (int ch = 0; ch < chunks; ++ch)
+    for (int st = 0; st < steps; ++st)
+      for (int nt = 0; nt < NTc; ++nt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int cb = st / 5, pair = st % 5, q = 2 * pair + (j >> 2);
+            const int cin = 16 * cb + 4 * (lane >> 4) + (j & 3), cout = 16 * (ch * NTc + nt) + (lane & 15);
+            float r = q < 9 ? c2[((size_t)q * d + cin) * d + cout] : 0.f;
+            for (int t = 0; t < 3; ++t) {
+              const uint16_t hb = rne(r);
+              const uint32_t back = (uint32_t)hb << 16;
+              float hf; std::memcpy(&hf, &back, 4);
+              r -= hf;
+              frag[(((((size_t)ch * steps + st) * NTc + nt) * 3 + t) * 64 + lane) * 8 + j] = hb;
+            }
+          }
+  std::vector<float> as_f(frag.size() / 2);
+  std::memcpy(as_f.data(), frag.data(), frag.size() * 2);
+  return as_f;
+}
+// the subsampling Dense [K, 144] for sublinear_split_kernel: 1728 fragments per 32-wide step, padded to 7 x 256 (4 floats each)
+std::vector<float> pack_linear_split(const std::vector<float>& lin, int K, int d) {
+  const std::vector<float> sp = pack_split32([&](int k, int n) { return lin[(size_t)k * d + n]; }, K, d);
+  const size_t steps = (size_t)ceil_div(K, 32), used = 1728 * 4, stride = 1792 * 4;
+  std::vector<float> padded(steps * stride, 0.f);
+  for (size_t st = 0; st < steps; ++st) std::memcpy(padded.data() + st * stride, sp.data() + st * used, used * sizeof(float));
+  return padded;
+}
+
 // ---- pair-pipelined streams (fused_pp.hip; layout tables generated by tools/gen_pp.py) -----------------------------------
 #include "pp_layout.inc"
 namespace {
@@ -1419,28 +1456,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
     // otherwise); step s = 5 cb + pair; lane (r = lane & 15, g = lane >> 4) of column tile nt holds, for out channel
     // 16 nt + r, in-channels 16 cb + 4 g + (j & 3) at tap 2 pair + (j >> 2) (the tenth tap is zero); term t =
     // round-to-nearest-even bf16 of what the terms before it left
-    const int steps = (d / 16) * 5, NTc = d == 144 ? 9 : 8, chunks = (d / 16) / NTc;
-    std::vector<uint16_t> frag((size_t)chunks * steps * NTc * 3 * 64 * 8);
-    auto rne = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); };
-    for (int ch = 0; ch < chunks; ++ch)
-    for (int st = 0; st < steps; ++st)
-      for (int nt = 0; nt < NTc; ++nt)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
-            const int cb = st / 5, pair = st % 5, q = 2 * pair + (j >> 2);
-            const int cin = 16 * cb + 4 * (lane >> 4) + (j & 3), cout = 16 * (ch * NTc + nt) + (lane & 15);
-            float r = q < 9 ? c2[((size_t)q * d + cin) * d + cout] : 0.f;
-            for (int t = 0; t < 3; ++t) {
-              const uint16_t hb = rne(r);
-              const uint32_t back = (uint32_t)hb << 16;
-              float hf; std::memcpy(&hf, &back, 4);
-              r -= hf;
-              frag[(((((size_t)ch * steps + st) * NTc + nt) * 3 + t) * 64 + lane) * 8 + j] = hb;
-            }
-          }
-    std::vector<float> as_f(frag.size() / 2);
-    std::memcpy(as_f.data(), frag.data(), frag.size() * 2);
-    o_c2s = ab.put(as_f);
+    o_c2s = ab.put(pack_conv2_split(c2, d));
   }
   const auto& lin = m->host["conv_subsampling/linear/kernel"].data;
   o_lw = ab.put(pack_p16([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d, d / 16));
@@ -1448,11 +1464,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   o_lb = ab.put(m->host["conv_subsampling/linear/bias"].data);
   if (d == 144) {
     // the same kernel for sublinear_split_kernel: 1728 fragments per 32-wide step, padded to 7 x 256 (4 floats each)
-    const std::vector<float> sp = pack_split32([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d);
-    const size_t steps = (size_t)ceil_div(dm.F2 * d, 32), used = 1728 * 4, stride = 1792 * 4;
-    std::vector<float> padded(steps * stride, 0.f);
-    for (size_t st = 0; st < steps; ++st) std::memcpy(padded.data() + st * stride, sp.data() + st * used, used * sizeof(float));
-    o_lws = ab.put(padded);
+    o_lws = ab.put(pack_linear_split(lin, dm.F2 * d, d));
   }
   for (int i = 0; i < c.num_blocks; ++i)
     eo.push_back(pack_block(m, ab, "conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size, c.kernel_size));

@@ -157,6 +157,11 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   const auto& lin = m->host["front/conv_subsampling/linear/kernel"].data;
   const size_t o_lw = ab.put(pack_p16([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d, d / 16));
   const size_t o_lb = ab.put(m->host["front/conv_subsampling/linear/bias"].data);
+  // round 3: the front runs the split-bf16 subsampling kernels of the offline encoder (the explicit front padding and the
+  // VALID geometry are index offsets of the same kernels: subconv.hip reads pt1 / pf1 / pt2 / pf2 / T1 / F1 from its arguments)
+  const bool split_front = d == 144 && c.gemm_dtype == 0;
+  const size_t o_c2s = split_front ? ab.put(pack_conv2_split(c2, d)) : 0;
+  const size_t o_lws = split_front && (dm.F2 * d) % 32 == 0 ? ab.put(pack_linear_split(lin, dm.F2 * d, d)) : 0;
   StackOff e = pack_stack(m, ab, "encoder", "chunk_conformer_block_", cc.enc_num_blocks, false, 0);
   StackOff pk = pack_stack(m, ab, "picker", "block_", cc.picker_num_blocks, true, cc.picker_num_classes);
   StackOff hp = pack_stack(m, ab, "helper", "block_", cc.helper_num_blocks, false, 0);
@@ -176,6 +181,8 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
+  m->c2_wsplit = o_c2s ? base + o_c2s : nullptr;
+  m->lin_wsplit = o_lws ? base + o_lws : nullptr;
   resolve_stack(m->c_enc, e, base, false, 0);
   resolve_stack(m->c_picker, pk, base, true, cc.picker_num_classes);
   resolve_stack(m->c_helper, hp, base, false, 0);
@@ -412,13 +419,19 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel_auto(m, me, s), "mel (valid)"); }
     SubConvArgs sa{};
     sa.mel = me.mel; sa.out = (float*)(ws + p.sub); sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
+    sa.w2s = m->c2_wsplit;
     sa.B = B; sa.F = g.F; sa.NM = c.n_mels; sa.T1 = g.T1; sa.F1 = m->dm.F1; sa.T2 = T; sa.F2 = m->dm.F2;
     sa.st1 = 2; sa.pt1 = 4; sa.pf1 = 2; sa.pt2 = 0; sa.pf2 = 0;
     { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling (valid)"); }
     StreamGemmArgs lg{};
     lg.x = sa.out; lg.y = sc.xa; lg.wp = m->lin_wp; lg.bias = m->lin_b;
     lg.M = B * T; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.ldy = d; lg.n_valid = d;
-    { PROF(MI355ASR_K_SUBLINEAR); LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear"); }
+    {
+      PROF(MI355ASR_K_SUBLINEAR);
+      // the split-bf16 ring-DMA Dense from 4096 rows on (as run_subsampling in api.hip), else the fp32-MFMA stream kernel
+      if (!(m->lin_wsplit && lg.M >= 4096 && launch_sublinear_split(lg, m->lin_wsplit, s) == 0))
+        LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear");
+    }
   }
   if (outs->front_out) HIP_TRY(hipMemcpyAsync(outs->front_out, sc.xa, act, hipMemcpyDeviceToDevice, s));
   // ---- encoder

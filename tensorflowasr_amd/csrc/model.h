@@ -251,6 +251,8 @@ void same_pad(int n, int k, int s, int* out, int* before);
 void add_block_expected(std::vector<Expected>& ex, const std::string& p, int d, int H, int hs, int k, bool keras_mha = false);
 std::vector<float> pack_p16(const std::function<float(int, int)>& f, int K, int N, int NTpad);
 std::vector<float> pack_split32(const std::function<float(int, int)>& f, int K, int N);
+std::vector<float> pack_conv2_split(const std::vector<float>& c2, int d);          // conv2 kernel -> subconv_split_ring_kernel fragments
+std::vector<float> pack_linear_split(const std::vector<float>& lin, int K, int d);  // subsampling Dense -> sublinear_split_kernel slabs
 void append_slabs(std::vector<float>& stream, const std::function<float(int, int)>& f, int K, int N, bool group_major);
 // pair-pipelined stream of one chain y += W2 act(W1 x + b1) (fused_pp.hip, tools/gen_pp.py): w1(k, n) with k <= K1 (row K1 = the
 // bias), H hidden features, w2(k, n) [H, 144]; and of a plain layer [145, 144 G] in column groups of nine tiles

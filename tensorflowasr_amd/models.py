@@ -746,6 +746,47 @@ def ctc_prefix_beam_decode(x, input_length=None, beam_width=10, cutoff_prob=0.99
     return ids, lens, scores, n_hyp
 
 
+class ChunkBeamPipeline:
+    """ChunkConformer `predict` of batch n + 1 overlapped with the prefix beam search of batch n (round 3).
+
+    The device beam search is a latency chain -- one workgroup per utterance walking T_pick dependent frames, 16 of the
+    256 CUs busy for milliseconds -- and `predict` is a run of short chip-wide kernels, so the two share the GPU well:
+    the search runs on a second HIP stream from a helper thread (ctypes releases the GIL) behind an event recorded after
+    `predict`, while the caller's stream already recognises the next batch.  `push(wav)` returns the beams of the PREVIOUS
+    batch (None for the first), `flush()` the last one's: (ids, lens, scores, n_hyp) as `ctc_prefix_beam_decode`."""
+
+    def __init__(self, model, beam_width=10, cutoff_prob=0.99, cutoff_top_n=40):
+        from concurrent.futures import ThreadPoolExecutor
+        self.model, self.kw = model, dict(beam_width=beam_width, cutoff_prob=cutoff_prob, cutoff_top_n=cutoff_top_n)
+        self.device = model._h.device
+        self.side = torch.cuda.Stream(device=self.device)
+        self.pool = ThreadPoolExecutor(max_workers=1)
+        self.pending = None
+
+    def _decode(self, logits, counts, ready):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            return ctc_prefix_beam_decode(logits, counts, is_logits=True, **self.kw)
+
+    def push(self, wav):
+        logits, counts = self.model.predict(wav)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        logits.record_stream(self.side)                    # the caching allocator must not hand the logits out again early
+        prev = self.pending.result() if self.pending is not None else None
+        self.pending = self.pool.submit(self._decode, logits, counts, ready)
+        return prev
+
+    def flush(self):
+        prev = self.pending.result() if self.pending is not None else None
+        self.pending = None
+        return prev
+
+    def close(self):
+        self.flush()
+        self.pool.shutdown()
+
+
 class BeamDecoder:
     """Stateful prefix beam search: externals/ctc_decoders `BeamDecoder(vocabulary, beam_size, cutoff_prob,
     cutoff_top_n)` with `.decode(probs_seq)` / `.reset()` (ctc_beam_search_decoder.cpp:217-405, no external scorer).

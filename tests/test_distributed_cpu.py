@@ -60,3 +60,42 @@ def test_dp_shard_broadcast_allgather_world2(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def _beam_worker(rank, world, port, tmpdir):
+    """BASELINE config 5's exchange: every rank runs the prefix beam search on its utterance shard (here the host search of
+    libmi355asr.so, which needs no GPU; on the GPU box the device search) and all ranks end up with the beams of the whole
+    batch, ragged hypothesis lengths padded to the global maximum."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    from tensorflowasr_amd.parallel import all_gather_hypotheses, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, T, V, beam = 6, 24, 12, 5
+        rng = np.random.default_rng(3)
+        logits = rng.standard_normal((B, T, V)).astype(np.float32) * 2.0
+        probs = np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)
+        in_len = np.array([24, 9, 1, 17, 24, 5], np.int32)
+        lo, hi = shard_range(B, rank, world)
+        # a rank's max_len is data dependent on the real path (frames kept by feature_pick): make them differ here
+        mine = ctc_prefix_beam_decode(probs[lo:hi], in_len[lo:hi], beam_width=beam, cutoff_prob=1.0, cutoff_top_n=40,
+                                      max_len=int(in_len[lo:hi].max()))
+        ids, lens, scores, n_hyp = all_gather_hypotheses(*mine)
+        full = ctc_prefix_beam_decode(probs, in_len, beam_width=beam, cutoff_prob=1.0, cutoff_top_n=40, max_len=int(in_len.max()))
+        assert ids.shape == (B, beam, int(in_len.max())) and np.array_equal(n_hyp, full[3])
+        for b in range(B):
+            for k in range(int(n_hyp[b])):
+                assert lens[b, k] == full[1][b, k] and scores[b, k] == full[2][b, k]
+                assert np.array_equal(ids[b, k, :lens[b, k]], full[0][b, k, :lens[b, k]])
+                assert (ids[b, k, lens[b, k]:] == -1).all()
+        open(os.path.join(tmpdir, "beam_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_prefix_beam_hypotheses_allgather_world2(tmp_path):
+    world = 2
+    mp.spawn(_beam_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("beam_ok%d" % r)).exists() for r in range(world))

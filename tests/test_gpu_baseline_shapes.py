@@ -245,12 +245,68 @@ def test_config5_chunk_conformer_2x30s_stages_and_beam_vs_oracle(torch_cuda):
         assert common >= 0.9 * tot
 
 
+def test_config5_batch16_as_benched_vs_oracle_and_pipelined_beam(torch_cuda):
+    """BASELINE config 5 at the per-GPU batch bench.py runs (16 x 30 s): grid shapes of pick / gather / beam kernels and the
+    ragged T_pick padding differ from the 2-utterance test above.  The oracle follows two sampled utterances (an utterance's
+    result does not depend on its batch); the prefix beam search of the whole batch is compared with the host search
+    (bit-exact against the reference decoder's KATs) on the same GPU logits, sequentially and through ChunkBeamPipeline
+    (search of batch n on a second stream while batch n + 1 is predicted)."""
+    from tensorflowasr_amd.models import ChunkBeamPipeline, ChunkConformer, ctc_prefix_beam_decode
+    from test_gpu_parity import _pick_bias_for_ragged_counts
+    torch = torch_cuda
+    cfg = dict(co.CHUNK_S)
+    w = co.chunk_weights(cfg, seed=5)
+    B = 16
+    x = waves(B, 480000, 200)
+    w["picker/fully_connected/bias"][-1] = _pick_bias_for_ragged_counts(cfg, w, x[[1, 13]])   # no frame of the two sampled
+    m = ChunkConformer(chunk_config_dict(cfg), cfg["picker_num_classes"], cfg["decoder_num_classes"])   # utterances sits on the pick boundary
+    m.load_weights(w, by_name=False)
+    got = m.predict(x, stages=True)
+    counts = got["counts"]
+    assert counts.shape == (B,) and len(set(counts.tolist())) > 4, counts          # ragged
+    Tp = got["text_logits"].shape[1]
+    assert Tp == counts.max()
+    lg = got["text_logits"].cpu().numpy()
+    for u in (1, 13):
+        ref = co.chunk_predict(x[u:u + 1].astype(np.float64), w, cfg)
+        n = int(ref["counts"][0])
+        assert counts[u] == n
+        for k in ("enc", "picker_hidden"):
+            assert maxdiff(got[k][u].cpu().numpy(), ref[k][0]) < TOL, (k, u)
+        e = maxdiff(lg[u, :n], ref["text_logits"][0, :n])
+        print("config 5, batch 16, utterance %d: %d picked frames, text logits max|d| %.3g" % (u, n, e))
+        assert e < TOL
+        assert not lg[u, n:].any()                                                  # zero padding up to the batch maximum
+        assert np.array_equal(got["text_argmax"][u, :n].cpu().numpy(), lg[u, :n].argmax(-1))
+    # beam search of the 16 utterances: device search == host search on the same logits (best hypothesis and score bit for
+    # bit; the rest of the beam as sets: equal float scores are ordered by std::sort in the reference)
+    dev = ctc_prefix_beam_decode(got["text_logits"], counts, 10, 0.99, 40, is_logits=True)
+    probs = torch.softmax(got["text_logits"], -1).cpu().numpy()
+    host = ctc_prefix_beam_decode(probs, counts, 10, 0.99, 40)
+    for u in range(B):
+        n = dev[1][u, 0]
+        assert n == host[1][u, 0] and np.array_equal(dev[0][u, 0, :n], host[0][u, 0, :n]), u
+        assert abs(dev[2][u, 0] - host[2][u, 0]) < 1e-4 * counts[u] + 1e-3
+    # pipelined: three batches through ChunkBeamPipeline == the sequential calls
+    pipe = ChunkBeamPipeline(m, beam_width=10, cutoff_prob=0.99, cutoff_top_n=40)
+    xs = [x, x[::-1].copy(), x]
+    outs = [pipe.push(xx) for xx in xs] + [pipe.flush()]
+    pipe.close()
+    assert outs[0] is None
+    for xx, res in zip(xs, outs[1:]):
+        lgs, cs = m.predict(xx)
+        seq = ctc_prefix_beam_decode(lgs, cs, 10, 0.99, 40, is_logits=True)
+        for a, b in zip(res, seq):
+            assert np.array_equal(a, b)
+    assert np.array_equal(outs[1][3], outs[3][3]) and np.array_equal(outs[1][1], outs[3][1])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # dmodel 256 / 512 at the benched row counts: the slab-ring GEMM path against the kernels it replaces
 # ---------------------------------------------------------------------------------------------------------------
 def test_ring_gemm_at_16000_rows_equals_the_fp32_and_bf16_kernels(torch_cuda, tmp_path):
-    """gemm_ring.hip takes over from 1500 rows on, where the oracle is too slow to follow (its own parity tests force it
-    for small batches).  Here the launch shapes of the benched sizes themselves -- ConformerM and ConformerL on 64 x 10 s
+    """gemm_ring.hip takes over from 1500 rows on, where the oracle is too slow to follow every utterance (its own parity
+    tests force it for small batches; here it follows ONE sampled utterance of the ConformerM batch).  Here the launch shapes of the benched sizes themselves -- ConformerM and ConformerL on 64 x 10 s
     (16 000 rows: two row tiles per wave, several column chunks per workgroup), and the bf16 CTC decoder on 64 x 260
     history frames -- against the same build with MI355ASR_GEMM_RING=0 (fp32-MFMA chains / per-wave bf16 streams, both
     pinned to the oracle at small sizes)."""
@@ -270,6 +326,10 @@ for name, kw in (("M", dict(dmodel=256, num_blocks=2, head_size=64, num_heads=4)
     logits = m.ctc_logits(enc)
     out[name + "_enc"] = enc.cpu().numpy()[::7]
     out[name + "_logits"] = logits.cpu().numpy()[::7]
+    if name == "M" and len(sys.argv) > 2:           # the oracle follows one sampled utterance through the benched launch shapes
+        cfg = dict(co.CONFORMER_S, dmodel=256, num_blocks=2, head_size=64, num_heads=4)
+        out["M_oracle_enc21"] = co.conformer_encoder(x[21:22].astype(np.float64), m.get_weights_dict(), cfg)
+        out["M_gpu_enc21"] = enc[21:22].cpu().numpy()
     del m
     torch.cuda.empty_cache()
 ctc = CTCDecoder(num_classes=1332, dmodel=256, num_blocks=1, head_size=64, num_heads=4, kernel_size=32, fc_factor=0.5,
@@ -284,10 +344,13 @@ np.savez(sys.argv[1], **out)
     res = {}
     for tag, extra in (("ring", {}), ("plain", {"MI355ASR_GEMM_RING": "0"})):
         f = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True,
+        r = subprocess.run([sys.executable, "-c", code, f] + (["oracle"] if tag == "ring" else []), env=dict(os.environ, **extra), capture_output=True, text=True,
                            timeout=1200, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = np.load(f)
+    d_or = maxdiff(res["ring"]["M_gpu_enc21"], res["ring"]["M_oracle_enc21"])
+    print("ConformerM (2 blocks) at 64 x 10 s, utterance 21, ring kernels vs the fp64 oracle: max |d| = %.3g" % d_or)
+    assert d_or < TOL
     for k in ("M_enc", "M_logits", "L_enc", "L_logits"):
         d = maxdiff(res["ring"][k], res["plain"][k])
         print(k, "ring vs fp32-MFMA kernels: max |d| = %.3g" % d)
