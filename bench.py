@@ -335,7 +335,11 @@ def extra_config5(lib, device, steps=5, with_cpu=True):
           "out_glu": (nb["enc"] + nb["pick"]) * 3 * 2.0 * M * d * d + (nb["help"] + nb["dec"]) * 3 * 2.0 * Mp * d * d,
           "ctc_head": 2.0 * M * d * Vp + 2.0 * Mp * d * Vt, "subconv": 2.0 * B * 1501 * 40 * d * 9 + 2.0 * M * 20 * d * 9 * d,
           "sublinear": 2.0 * M * 20 * d * d}
-    split = ("tail_ff1", "tail_ff2", "ff1_qkv", "out_glu", "ctc_head")
+    wf = {k: (mc[n]["win_front"] + mc[n]["win_back"] + 1) for k, n in (("enc", "ChunkConformerEncoder"), ("pick", "ChunkCTCPicker"),
+                                                                       ("help", "ContextHelper"), ("dec", "ChunkCTCDecoder"))}
+    # band attention (chunk_conformer_blocks.py:158-176): a query sees win_front + win_back + 1 keys
+    fl["attention"] = sum(nb[k] * 2 * 2.0 * (M if k in ("enc", "pick") else Mp) * wf[k] * d for k in nb)
+    split = ("tail_ff1", "tail_ff2", "ff1_qkv", "out_glu", "ctc_head", "subconv", "sublinear")
     kern = {}
     for n, (ms_step, launches) in prof.items():
         f = fl.get(n, 0.0)
