@@ -49,12 +49,14 @@ def _parse_resource_remarks(text):
 
 
 def resource_report():
-    """{kernel: resources} of the last build (tensorflowasr_amd/build/*.resources.json)"""
+    """{kernel: resources} of the last build: the reports of the current SOURCES only (a stale report of a removed source
+    must not fail or pass the check)"""
     rep = {}
     objdir = os.path.join(HERE, "build")
-    for f in sorted(os.listdir(objdir)) if os.path.isdir(objdir) else []:
-        if f.endswith(".resources.json"):
-            rep.update(json.load(open(os.path.join(objdir, f))))
+    for src in SOURCES:
+        f = os.path.join(objdir, src.replace(".hip", ".resources.json"))
+        if os.path.exists(f):
+            rep.update(json.load(open(f)))
     return rep
 
 
@@ -64,11 +66,18 @@ def resource_report():
 SCRATCH_ALLOWED = ()   # none: every kernel of the library is scratch-free
 
 
-def check_no_scratch(report=None):
+def check_no_scratch(report=None, strict=None):
+    """strict (default: MI355ASR_BUILD_STRICT != 0, i.e. on): raise when a kernel spills; otherwise only warn -- another
+    compiler version or extra flags (-O0, -g) can make a kernel spill, and the library that was just linked is still usable."""
+    if strict is None:
+        strict = os.environ.get("MI355ASR_BUILD_STRICT", "1") != "0"
     bad = {k: v["scratch"] for k, v in (report or resource_report()).items()
            if v.get("scratch", 0) > 0 and not any(a in k for a in SCRATCH_ALLOWED)}
     if bad:
-        raise RuntimeError("kernels with scratch (register spills): %s" % bad)
+        msg = "kernels with scratch (register spills): %s" % bad
+        if strict:
+            raise RuntimeError(msg + "  (MI355ASR_BUILD_STRICT=0 turns this into a warning)")
+        sys.stderr.write("warning: " + msg + "\n")
 
 
 def build(force=False, verbose=True):
@@ -89,6 +98,11 @@ def build(force=False, verbose=True):
             if r.returncode != 0:
                 sys.stderr.write(r.stderr)
                 raise subprocess.CalledProcessError(r.returncode, cmd)
+            # the resource remarks are parsed below; everything else the compiler said (warnings) stays visible
+            noise = ("remark:", "-Rpass-analysis", "^", "~")
+            for ln in r.stderr.splitlines():
+                if "warning:" in ln or "error:" in ln:
+                    sys.stderr.write(ln + "\n")
             with open(rep, "w") as f:
                 json.dump(_parse_resource_remarks(r.stderr), f, indent=1, sort_keys=True)
         return obj

@@ -1652,16 +1652,13 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
     BeamDeviceArgs a{};
     a.top_idx = d_idx; a.top_p = d_p; a.B = B; a.T = T; a.V = V; a.N = N; a.beam = beam_size;
     a.cutoff_top_n = cutoff_top_n; a.max_len = max_len; a.cutoff_prob = cutoff_prob;
-    a.arena = (int2*)w;                  w += (size_t)B * ((size_t)T * beam_size + 1) * sizeof(int2);
-    a.ids = (int32_t*)w;                 w += (size_t)B * beam_size * max_len * sizeof(int32_t);
-    a.lens = (int32_t*)w;                w += (size_t)B * beam_size * sizeof(int32_t);
-    a.scores = (float*)w;                w += (size_t)B * beam_size * sizeof(float);
-    a.n_hyp = (int32_t*)w;               w += (size_t)B * sizeof(int32_t);
-    int32_t* d_len = (int32_t*)w;        w += (((size_t)B * sizeof(int32_t)) + 7) & ~(size_t)7;
+    int32_t* d_len = nullptr;
+    long long* d_prof = nullptr;
+    (void)mi355asr_beam_device_carve(w, B, T, beam_size, max_len, &a, &d_len, &d_prof);   // the same layout the size query adds up
     // MI355ASR_BEAM_PROF=1: clock counters of utterance 0's search, printed per call (where a frame's time goes)
     static const bool prof_env = [] { const char* v = getenv("MI355ASR_BEAM_PROF"); return v && atoi(v) != 0; }();
     if (prof_env) {
-      a.prof = (long long*)w;
+      a.prof = d_prof;
       HIP_TRY(hipMemsetAsync(a.prof, 0, 9 * sizeof(long long), s));
     }
     if (in_len) {

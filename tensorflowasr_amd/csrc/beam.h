@@ -30,6 +30,9 @@ struct BeamDeviceArgs {
 };
 bool mi355asr_beam_device_applicable(int V, int N, int beam);
 size_t mi355asr_beam_device_ws_bytes(int B, int T, int beam, int max_len);
+// the ONE place that lays the device search's buffers out in its workspace (16-byte aligned segments; ws null: size only):
+// fills a->arena / ids / lens / scores / n_hyp, *d_len (staging of in_len) and *prof (9 x int64 counters); returns the bytes used
+size_t mi355asr_beam_device_carve(char* ws, int B, int T, int beam, int max_len, BeamDeviceArgs* a, int32_t** d_len, long long** prof);
 int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s);
 int mi355asr_launch_topn(const float* x_dev, int frames, int V, int N, int is_logits, int32_t* idx_dev, float* p_dev,
                          hipStream_t s);

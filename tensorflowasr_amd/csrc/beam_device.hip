@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     long long t1 = 0;
     if (profiling) { t1 = clock64(); p_entries += t1 - t0; }
 
-    int newn;
+    int newn = 0;
     bool redo = !SMALL;
     if (SMALL) {
       // ---- 3s. slots [0, nbm) = existing entries, nbm + j * ncap + k = child of entry j by candidate k; one thread
@@ -519,10 +519,23 @@ extern "C" {
 
 bool mi355asr_beam_device_applicable(int V, int N, int beam) { return beam >= 1 && beam <= BMAX && N >= 1 && N <= NMAX && V <= 65534; }
 
+size_t mi355asr_beam_device_carve(char* ws, int B, int T, int beam, int max_len, BeamDeviceArgs* a, int32_t** d_len, long long** prof) {
+  size_t off = 0;
+  auto seg = [&](size_t bytes) { char* p = ws ? ws + off : nullptr; off += (bytes + 15) & ~(size_t)15; return p; };
+  char* arena = seg((size_t)B * ((size_t)T * beam + 1) * sizeof(int2));
+  char* ids = seg((size_t)B * beam * max_len * sizeof(int32_t));
+  char* lens = seg((size_t)B * beam * sizeof(int32_t));
+  char* scores = seg((size_t)B * beam * sizeof(float));
+  char* n_hyp = seg((size_t)B * sizeof(int32_t));
+  char* len = seg((size_t)B * sizeof(int32_t));
+  char* pr = seg(9 * sizeof(long long));
+  if (a) { a->arena = (int2*)arena; a->ids = (int32_t*)ids; a->lens = (int32_t*)lens; a->scores = (float*)scores; a->n_hyp = (int32_t*)n_hyp; }
+  if (d_len) *d_len = (int32_t*)len;
+  if (prof) *prof = (long long*)pr;
+  return off;
+}
 size_t mi355asr_beam_device_ws_bytes(int B, int T, int beam, int max_len) {
-  const size_t arena = (size_t)B * ((size_t)T * beam + 1) * sizeof(int2);
-  const size_t out = (size_t)B * beam * ((size_t)max_len * 4 + 8) + (size_t)B * 4;
-  return arena + out + (size_t)B * 4 /* in_len */ + 128 /* profile counters */ + 256;
+  return mi355asr_beam_device_carve(nullptr, B, T, beam, max_len, nullptr, nullptr, nullptr);
 }
 
 int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s) {

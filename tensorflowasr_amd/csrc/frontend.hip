@@ -594,7 +594,10 @@ int launch_collapse(const CollapseArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void pick_kernel(PickArgs a) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int32_t* __restrict__ src = a.frame_ids + (size_t)b * a.T;
+  // no __restrict__: mi355asr_feature_pick_count runs this in place (idx == frame_ids).  That is safe by construction -- a
+  // 64-frame group is read before its ballot, and kept frames land at or before positions already read -- but only as long
+  // as the compiler may not assume the two pointers are distinct
+  const int32_t* src = a.frame_ids + (size_t)b * a.T;
   int32_t* dst = a.idx + (size_t)b * a.T;
   int count = 0;
   for (int t0 = 0; t0 < a.T; t0 += 64) {

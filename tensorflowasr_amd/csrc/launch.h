@@ -136,7 +136,7 @@ struct CollapseArgs {
 
 struct PickArgs {
   const int32_t* frame_ids;  // [B, T] phone argmax
-  int32_t* idx;              // [B, T] indices of kept frames (first cnt[b] entries valid)
+  int32_t* idx;              // [B, T] indices of kept frames (first cnt[b] entries valid); may alias frame_ids (in place)
   int32_t* cnt;              // [B]
   int B, T, blank;
 };
