@@ -70,7 +70,7 @@ def test_config2_batch64_10s_as_benched_ids_and_logits_vs_oracle(bench_model, to
     e_enc = maxdiff(enc[SAMPLED], enc_ref)
     assert e_enc < TOL
     err, report = assert_frames_and_ids(logits[SAMPLED], amax[SAMPLED], ids[SAMPLED], lens[SAMPLED], lg_ref,
-                                        [250] * len(SAMPLED), 1331)
+                                        [250] * len(SAMPLED), 1331, tag="config2_as_benched_trained_ctc_head")
     print("config 2 as benched: encoder max|d| %.3g, logits max|d| %.3g, undecided frames %d / %d"
           % (e_enc, err, len(report), 250 * len(SAMPLED)))
     # every one of the 64: the integer path is exact given the kernel's own logits
@@ -100,7 +100,7 @@ def test_config2_batch64_10s_nonblank_head_ids_vs_oracle(torch_cuda):
     logits, amax = m.ctc_logits(m.encode(xd), return_argmax=True)
     logits, amax = logits.cpu().numpy(), amax.cpu().numpy()
     err, report = assert_frames_and_ids(logits[SAMPLED], amax[SAMPLED], ids[SAMPLED], lens[SAMPLED], lg_ref,
-                                        [250] * len(SAMPLED), 1331, max_undecided=0.02)
+                                        [250] * len(SAMPLED), 1331, max_undecided=0.02, tag="config2_token_emitting_head")
     assert lens[SAMPLED].min() > 100                      # real token sequences
     print("config 2, token-emitting head: logits max|d| %.3g, undecided frames %d / 1000 %s" % (err, len(report), report[:4]))
 

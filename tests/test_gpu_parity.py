@@ -241,6 +241,16 @@ def test_head_argmax_tie_breaks_to_lowest_index(torch_cuda):
     assert (am.cpu().numpy() == 7).all()
 
 
+def test_frame_argmax_on_a_sub_ulp_tie_keeps_the_larger_logit(torch_cuda):
+    """the documented deviation (tests/test_oracle.py): on two logits one ulp apart the device arg-max
+    returns the class of the larger logit, where the reference's fp32 log(softmax + 1e-7) ties and returns the lower index"""
+    from tensorflowasr_amd.models import frame_argmax
+    from test_oracle import _tf_greedy_argmax_fp32, sub_ulp_tie_row
+    row = sub_ulp_tie_row(1332)
+    got = frame_argmax(torch_cuda.from_numpy(np.tile(row, (3, 4, 1))).cuda()).cpu().numpy()
+    assert (got == 5).all() and _tf_greedy_argmax_fp32(row) == 2
+
+
 def test_greedy_kats_bit_exact(torch_cuda):
     from tensorflowasr_amd.models import ctc_greedy_decode
     kats = json.load(open(os.path.join(GOLDEN, "greedy_kat.json")))

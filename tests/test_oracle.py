@@ -355,3 +355,38 @@ def test_wave_pick_model_against_torch_convs():
         t = conv(t, "wav_layer/res_%d/shortcut" % i, pad=False) + a
     t = conv(t, "wav_layer/final")
     assert np.abs(t.permute(0, 2, 1).numpy() - got).max() < 1e-10
+
+
+def _tf_greedy_argmax_fp32(row):
+    """per-frame class of the reference's greedy path in its own arithmetic: tf.nn.softmax (fp32) -> ctc_decode's
+    log(p + 1e-7) (fp32) -> argmax with strict '<' (test_asr.py:196-198, ctc_greedy_decoder.h:9-20)"""
+    x = np.asarray(row, np.float32)
+    e = np.exp(x - x.max(), dtype=np.float32)
+    p = (e / e.sum(dtype=np.float32)).astype(np.float32)
+    return int(np.argmax(np.log(p + np.float32(1e-7), dtype=np.float32)))
+
+
+def sub_ulp_tie_row(V=8):
+    """two top logits one ulp apart (0.25 and the next float above it), the LARGER one at the higher class index: exp()
+    maps both onto the same fp32 value, so the reference's log(softmax + 1e-7) ties and its strict '<' keeps the lower index,
+    while an argmax on the logits themselves keeps the higher one"""
+    row = np.full(V, -3.0, np.float32)
+    row[2] = 0.25
+    row[5] = np.nextafter(np.float32(0.25), np.float32(1.0))
+    return row
+
+
+def test_documented_deviation_argmax_on_logits_vs_log_softmax_on_sub_ulp_ties():
+    """the head takes the per-frame argmax on the logits.  It differs from the reference's
+    log(softmax + 1e-7) argmax only when two logits are closer than fp32 exp() resolves (|x| < 0.5: one ulp); this test
+    constructs that case so that the difference is a known, pinned one -- and shows that a gap exp() does resolve
+    (eight ulps) gives the same class on both routes."""
+    row = sub_ulp_tie_row()
+    assert row[5] > row[2] and row[5] - row[2] < 3e-8
+    assert _tf_greedy_argmax_fp32(row) == 2            # the reference: tie after exp -> first maximum
+    assert int(co.frame_argmax(row[None, None])[0, 0]) == 2     # the oracle restates the reference's formula
+    assert int(np.argmax(row)) == 5                    # the device kernels (head epilogue, mi355asr_frame_argmax): the larger
+    wide = row.copy()                                  # logit -- asserted on the GPU in tests/test_gpu_parity.py
+    for _ in range(8):
+        wide[5] = np.nextafter(wide[5], np.float32(1.0))
+    assert _tf_greedy_argmax_fp32(wide) == 5 == int(co.frame_argmax(wide[None, None])[0, 0]) == int(np.argmax(wide))
