@@ -130,11 +130,12 @@ void append_slabs(std::vector<float>& stream, const std::function<float(int, int
 
 
 // conv2 kernel [3][3][d][d] (HWIO) as split-bf16 fragments for subconv_split_ring_kernel: column chunks of NTc tiles (all
-// nine at dmodel 144, eight otherwise); step s = 5 cb + pair; lane (r = lane & 15, g = lane >> 4) of column tile nt holds,
-// for out channel 16 nt + r, in-channels 16 cb + 4 g + (j & 3) at tap 2 pair + (j >> 2) (the tenth tap is zero); term t =
-// round-to-nearest-even bf16 of what the terms before it left
+// nine at dmodel 144, eight otherwise).  Steps (subconv.hip): s < 4 KB: channel block cb = s / 4, tap pair p = s % 4 -- lane
+// (r = lane & 15, g = lane >> 4) of column tile nt holds, for out channel 16 nt + r, in-channels 16 cb + 4 g + (j & 3) at tap
+// 2 p + (j >> 2); then ceil(KB / 2) steps with the NINTH tap of two channel blocks: j < 4 -> block 2 i, j >= 4 -> block
+// 2 i + 1 (zero past the last block).  Term t = round-to-nearest-even bf16 of what the terms before it left.
 std::vector<float> pack_conv2_split(const std::vector<float>& c2, int d) {
-  const int steps = (d / 16) * 5, NTc = d == 144 ? 9 : 8, chunks = (d / 16) / NTc;
+  const int KBn = d / 16, steps = KBn * 4 + (KBn + 1) / 2, NTc = d == 144 ? 9 : 8, chunks = KBn / NTc;
   std::vector<uint16_t> frag((size_t)chunks * steps * NTc * 3 * 64 * 8);
   auto rne = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); };
   for (int ch = 0; ch < chunks; ++ch)
@@ -142,9 +143,11 @@ std::vector<float> pack_conv2_split(const std::vector<float>& c2, int d) {
       for (int nt = 0; nt < NTc; ++nt)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 8; ++j) {
-            const int cb = st / 5, pair = st % 5, q = 2 * pair + (j >> 2);
+            int cb, q;
+            if (st < KBn * 4) { cb = st / 4; q = 2 * (st % 4) + (j >> 2); }
+            else { cb = 2 * (st - KBn * 4) + (j >> 2); q = 8; }
             const int cin = 16 * cb + 4 * (lane >> 4) + (j & 3), cout = 16 * (ch * NTc + nt) + (lane & 15);
-            float r = q < 9 ? c2[((size_t)q * d + cin) * d + cout] : 0.f;
+            float r = cb < KBn ? c2[((size_t)q * d + cin) * d + cout] : 0.f;
             for (int t = 0; t < 3; ++t) {
               const uint16_t hb = rne(r);
               const uint32_t back = (uint32_t)hb << 16;

@@ -58,6 +58,12 @@ DEV f32x4 mma_split(const u32x4_t (&a)[3], const Split8& b, f32x4 c) {
   return c;
 }
 
+#ifndef MI355ASR_ATTN_DIAG
+#define MI355ASR_ATTN_DIAG 0
+#endif
+// timing experiments (tools/build_variant.py ... -DMI355ASR_ATTN_DIAG=n; WRONG results): bit 0 = no Q K^T products, 1 = no exp2,
+// 2 = no P V products (and no split of P), 3 = no V fragment writes, 4 = no operand loads of K / V
+constexpr int ADG = MI355ASR_ATTN_DIAG;
 constexpr int HS = 36;
 constexpr int TPK = 256;        // keys held in LDS
 constexpr int NKT = TPK / 16;   // key tiles
@@ -92,14 +98,23 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
   const float* krow = kbase + (size_t)min(skey, T - 1) * ld;
   f32x4 klo = ldg4(krow + 8 * g), khi = ldg4(krow + 8 * g + 4);
   float ktl = krow[32 + g];
-  // ---- stage V: 256 keys x 9 chunks of 4 features, three per thread
-  constexpr int NV = (TPK * (HS / 4) + ATH - 1) / ATH;
-  f32x4 vv[NV];
+  // ---- stage V (round 3): a thread owns whole 16-byte fragment entries -- entry (step s, feature tile ot, lane (kg, fc)) =
+  // feature 16 ot + fc of the eight keys 32 s + 4 kg + {0..3} and 32 s + 16 + 4 kg + {0..3}, in that k-slot order (see the
+  // header) -- loads its eight values, splits them and writes three conflict-free ds_write_b128.  (Round 2 walked V row-major
+  // and scattered 36 ds_write_b16 per thread into the fragments: 31 % of the kernel's LDS cycles were bank conflicts.)
+  constexpr int NVE = NST * OT * 64, NVT = (NVE + ATH - 1) / ATH;      // 1536 entries, two rounds of the 1024 threads
+  float ve[NVT][8];
 #pragma unroll
-  for (int it = 0; it < NV; ++it) {
-    const int idx = min(tid + it * ATH, TPK * (HS / 4) - 1);
-    const int key = idx / (HS / 4), ch = idx - key * (HS / 4);
-    vv[it] = ldg4(vbase + (size_t)min(key, T - 1) * ld + 4 * ch);
+  for (int it = 0; it < NVT; ++it) {
+    const int en = tid + it * ATH;
+    const int s = en / (OT * 64), rem = en - s * (OT * 64), ot = rem >> 6, l = rem & 63, kg = l >> 4, fc = l & 15;
+    const int f = 16 * ot + fc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = 32 * s + 16 * (j >> 2) + 4 * kg + (j & 3);
+      // padded keys and the padding features 36..47 must be exact zeros (0 x garbage = NaN)
+      ve[it][j] = (!(ADG & 16) && en < NVE && f < HS && key < T) ? vbase[(size_t)key * ld + f] : 0.f;
+    }
   }
   if (skey >= T) { klo = splat4(0.f); khi = splat4(0.f); ktl = 0.f; }
   {
@@ -119,6 +134,7 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
   auto qk_tile = [&](int kt) {
     const u32x4_t kf[3] = {Kf[0][kt][lane], Kf[1][kt][lane], Kf[2][kt][lane]};
     const float kl = Kt[kt][lane];
+    if constexpr (ADG & 1) { sc[kt] = splat4(kl) + __builtin_bit_cast(f32x4, kf[0]); return; }
     f32x4 acc = mma_split(kf, qf, splat4(0.f));
     sc[kt] = mfma4(kl, qtl, acc);
   };
@@ -135,29 +151,18 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
     }
   }
 
-  // ---- stage V behind the Q K^T products (round 3: the loads were issued before the K staging, so their latency and the
-  // scattered 16-bit LDS writes below no longer sit in front of the first MFMA; the writes drain under the softmax)
-  unsigned short* vh = reinterpret_cast<unsigned short*>(&Vf[0][0][0][0]);
+  // ---- the V fragments behind the Q K^T products (round 3: the loads were issued before the K staging, so their latency no
+  // longer sits in front of the first MFMA; the LDS writes drain under the softmax)
 #pragma unroll
-  for (int it = 0; it < NV; ++it) {
-    const int idx = tid + it * ATH;
-    if (idx < TPK * (HS / 4)) {
-      const int key = idx / (HS / 4), ch = idx - key * (HS / 4);
-      const f32x4 v = key < T ? vv[it] : splat4(0.f);            // padded keys must be exact zeros (0 x garbage = NaN)
-      // k-slot of `key` inside its 32-key step (see the header): lane group kg = (key & 15) >> 2, slot 4 * tile + (key & 3)
-      const int s = key >> 5, r = key & 31, kg = (r & 15) >> 2, slot = 4 * (r >> 4) + (r & 3);
-      float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = 4 * ch + q, ot = f >> 4, fc = f & 15;
-        float x = e[q];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const unsigned bits = __builtin_bit_cast(unsigned, x);
-          vh[((((t * NST + s) * OT + ot) * 64 + 16 * kg + fc) << 3) + slot] = (unsigned short)(bits >> 16);
-          x -= __builtin_bit_cast(float, bits & 0xffff0000u);
-        }
-      }
+  for (int it = 0; it < NVT; ++it) {
+    const int en = tid + it * ATH;
+    if (en < NVE && !(ADG & 8)) {
+      const f32x4 lo = {ve[it][0], ve[it][1], ve[it][2], ve[it][3]}, hi = {ve[it][4], ve[it][5], ve[it][6], ve[it][7]};
+      const Split8 vf = split8(lo, hi);
+      u32x4_t* dst = &Vf[0][0][0][0] + en;                         // [t][s][ot][lane]: en = (s * OT + ot) * 64 + lane
+      dst[0] = vf.t[0];
+      dst[NVE] = vf.t[1];
+      dst[2 * NVE] = vf.t[2];
     }
   }
   if (!active) { __syncthreads(); return; }
@@ -179,10 +184,12 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
   float psum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
-    sc[kt].x = __builtin_amdgcn_exp2f(sc[kt].x - mx);      // exp2(-inf) = 0 for masked keys
-    sc[kt].y = __builtin_amdgcn_exp2f(sc[kt].y - mx);
-    sc[kt].z = __builtin_amdgcn_exp2f(sc[kt].z - mx);
-    sc[kt].w = __builtin_amdgcn_exp2f(sc[kt].w - mx);
+    if constexpr (!(ADG & 2)) {
+      sc[kt].x = __builtin_amdgcn_exp2f(sc[kt].x - mx);      // exp2(-inf) = 0 for masked keys
+      sc[kt].y = __builtin_amdgcn_exp2f(sc[kt].y - mx);
+      sc[kt].z = __builtin_amdgcn_exp2f(sc[kt].z - mx);
+      sc[kt].w = __builtin_amdgcn_exp2f(sc[kt].w - mx);
+    }
     psum += (sc[kt].x + sc[kt].y) + (sc[kt].z + sc[kt].w);
   }
 
@@ -194,7 +201,8 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
   const int nst = (nkt + 1) / 2;
 #pragma unroll
   for (int s = 0; s < NST; ++s) {
-    if (s < nst) {
+    if constexpr (ADG & 4) { o[0] += sc[2 * s]; o[1] += sc[2 * s + 1]; }
+    else if (s < nst) {
       const Split8 pf = split8(sc[2 * s], sc[2 * s + 1]);
 #pragma unroll
       for (int i = 0; i < OT; ++i) {

@@ -114,7 +114,7 @@ struct SubConvArgs {
   const float* b1;    // [D]
   const float* w2p;   // packed conv2 kernel, K order = (cblock, kt, kf, 16) -> [9*D/16][D/16][64][4]
   const float* b2;    // [D]
-  const float* w2s;   // conv2 kernel as split-bf16 fragments [column chunk][5 d/16 steps][9 or 8 tiles][3 terms][64 lanes][8] (subconv.hip), or null
+  const float* w2s;   // conv2 kernel as split-bf16 fragments [column chunk][4 d/16 + ceil(d/32) steps][9 or 8 tiles][3 terms][64 lanes][8] (subconv.hip), or null
   int B, F, NM, T1, F1, T2, F2;
   int st1;            // conv1 time stride (reduction_factor/2)
   int pt1, pf1, pt2, pf2;  // pad-before of conv1 (time,freq) and conv2 (time,freq)

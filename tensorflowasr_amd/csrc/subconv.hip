@@ -189,7 +189,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv144_kernel(SubConvArg
 //     partners) those of step s + 1 after the MFMAs of step s: one wave's VALU phase always faces the other's MFMAs;
 //   * the split is by truncation (x & 0xffff0000, remainder exact), packed with v_perm_b32: 11 VALU per value pair.
 constexpr int SCW = 8, SCT = SCW * 64, SRT = 2, SPOSG = SCW * 16 * SRT;   // 256 positions per workgroup
-constexpr int NPAIR = 5;                           // MFMA steps per channel block of 16 (nine taps in pairs)
+constexpr int NPAIR = 4;                           // regular MFMA steps per channel block of 16: taps (0,1) (2,3) (4,5) (6,7)
+// round 3: the ninth taps of TWO channel blocks share one step (slots 0..3 = tap 8 of block 2 i, 4..7 = tap 8 of block
+// 2 i + 1): 4 KB + ceil(KB / 2) steps instead of 5 KB (dmodel 144: 41 instead of 45 -- the round-2 kernel paired every ninth
+// tap with zeros)
+constexpr int ninth_steps(int kb) { return (kb + 1) / 2; }
 constexpr int MELP = 8192;                         // floats of LDS for the mel patch
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -268,8 +272,7 @@ DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitL
 #pragma unroll
   for (int rt = 0; rt < SRT; ++rt) {
     const f32x4 lo = conv1_at<2 * PAIR, DIAG>(melp, RS, sl, rt, w1r, b1v);
-    f32x4 hi = splat4(0.f);
-    if constexpr (2 * PAIR + 1 < 9) hi = conv1_at<2 * PAIR + 1, DIAG>(melp, RS, sl, rt, w1r, b1v);
+    const f32x4 hi = conv1_at<2 * PAIR + 1, DIAG>(melp, RS, sl, rt, w1r, b1v);
     if constexpr (DIAG == 6) {               // no split: the raw bits as three "terms"
       const u32x4 l = __builtin_bit_cast(u32x4, lo), h = __builtin_bit_cast(u32x4, hi);
       xf[rt].t[0] = l; xf[rt].t[1] = h; xf[rt].t[2] = l ^ h;
@@ -277,6 +280,27 @@ DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitL
       xf[rt] = split8(lo, hi);
     }
   }
+}
+
+// operand of a ninth-tap step: conv1 at tap 8 for channel block cbA (slots 0..3) and cbA + 1 (slots 4..7; zeros past the
+// last block); the conv1 taps of the two blocks pass through the same registers one after the other
+template <int DIAG, class LT>
+DEV void frags_ninth(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitLane& sl, f32x4 (&w1r)[9], const float* p_b1,
+                     int g4, int cbA, int KBn, LT&& load_taps) {
+  f32x4 lo[SRT], hi[SRT];
+  load_taps(cbA);
+#pragma unroll
+  for (int rt = 0; rt < SRT; ++rt) lo[rt] = conv1_at<8, DIAG>(melp, RS, sl, rt, w1r, lds4(p_b1, cbA, g4));
+  if (cbA + 1 < KBn) {
+    load_taps(cbA + 1);
+#pragma unroll
+    for (int rt = 0; rt < SRT; ++rt) hi[rt] = conv1_at<8, DIAG>(melp, RS, sl, rt, w1r, lds4(p_b1, cbA + 1, g4));
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < SRT; ++rt) hi[rt] = splat4(0.f);
+  }
+#pragma unroll
+  for (int rt = 0; rt < SRT; ++rt) xf[rt] = split8(lo[rt], hi[rt]);
 }
 
 // DIAG != 0: timing experiments only (results are wrong): 1 = no conv1 / split work, 2 = one weight-fragment read per
@@ -287,7 +311,7 @@ DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitL
 // MFMA ratio per step as at 144.  Weight fragments: [chunk][step][NBW tiles][3 terms][64 lanes][8].
 template <int DIAG, int DM, int NBW>
 __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, int RS, int rows, int late_mode) {
-  constexpr int KB = DM / 16, NB = NBW, NK32 = KB * NPAIR, SLABF = NBW * 3 * 64, D = DM;
+  constexpr int KB = DM / 16, NB = NBW, NI = ninth_steps(KB), NK32 = KB * NPAIR + NI, SLABF = NBW * 3 * 64, D = DM;
   const int c0 = blockIdx.z * NBW;               // first output column tile of this workgroup
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][SLABF];
   __shared__ __attribute__((aligned(16))) float melp[MELP];
@@ -373,11 +397,10 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
     load_taps(0);
     frags_for<0, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, 0, g4));
   }
-#pragma unroll 1
-  for (int cb = 0; cb < KB; ++cb) {
-    static_for<0, NPAIR>([&](auto PI) {
-      constexpr int pair = decltype(PI)::value;
-      const int s = cb * NPAIR + pair, cur = s & 1;
+  // one MFMA step s: slab s is in wl[s & 1]; frags_this() = the operand of this step (early waves, before the MFMAs),
+  // frags_next() = the operand of step s + 1 (late waves, after the MFMAs)
+  auto step_body = [&](int s, auto&& frags_this, auto&& frags_next) {
+      const int cur = s & 1;
       const bool more = s + 1 < NK32;
       // next slab: global -> LDS directly (global_load_lds_dwordx4: lane i of a wave lands at base + 16 i); buffer
       // cur ^ 1 was last read in step s - 1, whose barrier every wave has passed.  Issued right before this wave's
@@ -391,24 +414,6 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
             const int w0 = SCT * q + 64 * wv;                    // wave-uniform
             if (w0 < SLABF) dma16(src + w0 + lane, &wl[cur ^ 1][w0]);
           }
-        }
-      };
-      // operand of the next step (VALU + LDS reads) and the MFMAs of this one are independent.  hipcc puts the ~270
-      // VALU instructions in front of the 108 MFMAs, and an in-order wave cannot fill the matrix pipe's shadow that
-      // way; since all waves meet at the barrier of every step the two waves of a SIMD would also be in the same phase.
-      // So the waves of the upper half of the workgroup (the SIMD partners of the lower half) run the two parts in
-      // the opposite order: one wave's conv1 / split VALU work always faces its partner's MFMAs.
-      auto frags_this = [&]() {              // early waves: the operand of this step, just before its MFMAs
-        if constexpr (pair == 0) load_taps(cb);
-        frags_for<pair, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
-      };
-      auto frags_next = [&]() {              // late waves: the operand of the next step, after this step's MFMAs
-        if constexpr (pair + 1 < NPAIR) {
-          frags_for<pair + 1, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
-        } else {
-          const int cbn = min(cb + 1, KB - 1);
-          load_taps(cbn);
-          frags_for<0, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cbn, g4));
         }
       };
       // fragments of G column tiles at a time (one with nine tiles: registers; two with eight), the next group requested
@@ -486,7 +491,38 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
       }
       __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's part of the slab has landed
       if constexpr (DIAG != 4) __syncthreads();
+  };
+  // operand of the next step (VALU + LDS reads) and the MFMAs of this one are independent.  hipcc puts the ~270
+  // VALU instructions in front of the 108 MFMAs, and an in-order wave cannot fill the matrix pipe's shadow that
+  // way; since all waves meet at the barrier of every step the two waves of a SIMD would also be in the same phase.
+  // So the waves of the upper half of the workgroup (the SIMD partners of the lower half) run the two parts in
+  // the opposite order: one wave's conv1 / split VALU work always faces its partner's MFMAs.
+#pragma unroll 1
+  for (int cb = 0; cb < KB; ++cb) {
+    static_for<0, NPAIR>([&](auto PI) {
+      constexpr int pair = decltype(PI)::value;
+      step_body(cb * NPAIR + pair,
+                [&]() {                      // early waves: the operand of this step, just before its MFMAs
+                  if constexpr (pair == 0) load_taps(cb);
+                  frags_for<pair, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+                },
+                [&]() {                      // late waves: the operand of the next step, after this step's MFMAs
+                  if constexpr (pair + 1 < NPAIR) {
+                    frags_for<pair + 1, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+                  } else if (cb + 1 < KB) {
+                    load_taps(cb + 1);
+                    frags_for<0, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb + 1, g4));
+                  } else {
+                    frags_ninth<DIAG>(xa, melp, RS, sl, w1r, p_b1, g4, 0, KB, load_taps);
+                  }
+                });
     });
+  }
+#pragma unroll 1
+  for (int i = 0; i < NI; ++i) {             // the ninth taps, two channel blocks per step
+    step_body(KB * NPAIR + i,
+              [&]() { frags_ninth<DIAG>(xa, melp, RS, sl, w1r, p_b1, g4, 2 * i, KB, load_taps); },
+              [&]() { if (i + 1 < NI) frags_ninth<DIAG>(xa, melp, RS, sl, w1r, p_b1, g4, 2 * i + 2, KB, load_taps); });
   }
   };
   if (late) run(std::integral_constant<bool, true>{});

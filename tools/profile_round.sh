@@ -18,6 +18,17 @@ cd $R
 python tools/summarize_rocprof.py $TAG $O/prof_${TAG}_stats $O/prof_${TAG}_fetch $O/prof_${TAG}_write $O/prof_${TAG}_mfma > $O/prof_${TAG}_summary.log 2>&1
 mkdir -p $O/profiles_${TAG}
 cp profiles/${TAG}_summary.md profiles/${TAG}_kernel_stats.csv profiles/pmc_traffic.json $O/profiles_${TAG}/
+MI355ASR_PARITY_LOG=$O/profiles_${TAG}/${TAG}_parity_excused_frames.jsonl python -m pytest tests/test_gpu_baseline_shapes.py -m gpu -q -k config2 > $O/prof_${TAG}_parity.log 2>&1
 python bench.py > $O/profiles_${TAG}/${TAG}_bench_n1.json 2> $O/prof_${TAG}_bench.log
 tail -30 profiles/${TAG}_summary.md
 tail -1 $O/profiles_${TAG}/${TAG}_bench_n1.json
+# BASELINE configs 3 and 5 on the same build: kernel-trace / stats of tests/bench_configs.py (their timings are in the bench line's
+# config3 / config5 keys; these traces are the per-kernel evidence behind them)
+cd /tmp
+for c in 3 5; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c$c -- python $R/tests/bench_configs.py --only $c --steps 5 --c3-dtype bf16 > $O/prof_${TAG}_c$c.log 2>&1
+  f=$(find $O/prof_${TAG}_c$c -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $O/profiles_${TAG}/${TAG}_config${c}_kernel_stats.csv
+  tail -2 $O/prof_${TAG}_c$c.log > $O/profiles_${TAG}/${TAG}_config${c}_bench_configs.json
+done
+cd $R
