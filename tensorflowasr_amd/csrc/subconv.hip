@@ -245,18 +245,25 @@ struct SplitLane {
 };
 
 // conv1 + ReLU (+ conv2's zero padding) at tap q for channels 16 cb + 4 g .. + 3 of row tile rt
+// Mel patch layout (round 3): row stride RS.row floats, and inside a row the bins de-interleaved by four -- bin c of the patch
+// sits at (c & 3) * RS.seg + (c >> 2).  The sixteen positions of a row tile read bins 4 f2 + m (m = 2 kf + j fixed per
+// instruction), i.e. CONSECUTIVE floats f2 + const: no bank conflicts (the plain layout read stride-4 floats: two-way
+// conflicts, 25 % of the kernel's LDS cycles); RS.row = 4 seg + pad with 4 RS.row = 20 (mod 32), so that a tile that wraps
+// into the next output row (f2: 19 -> 0, + 4 patch rows) continues on the next banks as well.
+struct PatchGeom { int row, seg; };
 template <int Q, int DIAG = 0>
-DEV f32x4 conv1_at(const float* melp, int RS, const SplitLane& sl, int rt, const f32x4 (&w1r)[9], f32x4 b1v) {
+DEV f32x4 conv1_at(const float* melp, PatchGeom RS, const SplitLane& sl, int rt, const f32x4 (&w1r)[9], f32x4 b1v) {
   constexpr int kt = Q / 3, kf = Q % 3;
   f32x4 v = b1v;
   int off = sl.mb[rt];
   asm volatile("" : "+v"(off));            // opaque: otherwise the window reads are hoisted out of the channel-block loop
-  const float* mp = melp + off + (2 * kt) * RS + 2 * kf;
+  const float* mp = melp + off + (2 * kt) * RS.row;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const float m = DIAG == 5 ? __builtin_bit_cast(float, off + i * RS + j) : mp[i * RS + j];
+      const int mc = 2 * kf + j, col = (mc & 3) * RS.seg + (mc >> 2);
+      const float m = DIAG == 5 ? __builtin_bit_cast(float, off + i * RS.row + col) : mp[i * RS.row + col];
       const f32x4 w = w1r[i * 3 + j];
       v.x = __builtin_fmaf(m, w.x, v.x); v.y = __builtin_fmaf(m, w.y, v.y);
       v.z = __builtin_fmaf(m, w.z, v.z); v.w = __builtin_fmaf(m, w.w, v.w);
@@ -268,7 +275,7 @@ DEV f32x4 conv1_at(const float* melp, int RS, const SplitLane& sl, int rt, const
 }
 
 template <int PAIR, int DIAG = 0>
-DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitLane& sl, const f32x4 (&w1r)[9], f32x4 b1v) {
+DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, const SplitLane& sl, const f32x4 (&w1r)[9], f32x4 b1v) {
 #pragma unroll
   for (int rt = 0; rt < SRT; ++rt) {
     const f32x4 lo = conv1_at<2 * PAIR, DIAG>(melp, RS, sl, rt, w1r, b1v);
@@ -285,7 +292,7 @@ DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitL
 // operand of a ninth-tap step: conv1 at tap 8 for channel block cbA (slots 0..3) and cbA + 1 (slots 4..7; zeros past the
 // last block); the conv1 taps of the two blocks pass through the same registers one after the other
 template <int DIAG, class LT>
-DEV void frags_ninth(SplitFrag (&xf)[SRT], const float* melp, int RS, const SplitLane& sl, f32x4 (&w1r)[9], const float* p_b1,
+DEV void frags_ninth(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, const SplitLane& sl, f32x4 (&w1r)[9], const float* p_b1,
                      int g4, int cbA, int KBn, LT&& load_taps) {
   f32x4 lo[SRT], hi[SRT];
   load_taps(cbA);
@@ -310,7 +317,7 @@ DEV void frags_ninth(SplitFrag (&xf)[SRT], const float* melp, int RS, const Spli
 // 144; eight (128 channels) for 256 / 512, the chunks on grid.z -- conv1 is then recomputed per chunk, the same VALU to
 // MFMA ratio per step as at 144.  Weight fragments: [chunk][step][NBW tiles][3 terms][64 lanes][8].
 template <int DIAG, int DM, int NBW>
-__global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, int RS, int rows, int late_mode) {
+__global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, PatchGeom RS, int rows, int late_mode) {
   constexpr int KB = DM / 16, NB = NBW, NI = ninth_steps(KB), NK32 = KB * NPAIR + NI, SLABF = NBW * 3 * 64, D = DM;
   const int c0 = blockIdx.z * NBW;               // first output column tile of this workgroup
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][SLABF];
@@ -332,10 +339,12 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   const int t2a = r0 / a.F2;
   const int tm_base = 4 * t2a - 2 * a.pt2 - a.pt1, fm_base = -2 * a.pf2 - a.pf1;
   const float* __restrict__ mbp = a.mel + (size_t)b * a.F * a.NM;
-  for (int i = threadIdx.x; i < rows * RS; i += SCT) {
-    const int rr = i / RS, jj = i - rr * RS;
+  const int RSL = 4 * RS.seg;                    // bins per patch row
+  for (int i = threadIdx.x; i < rows * RSL; i += SCT) {
+    const int rr = i / RSL, jj = i - rr * RSL;
     const int tm = tm_base + rr, fm = fm_base + jj;
-    melp[i] = (tm >= 0 && tm < a.F && fm >= 0 && fm < a.NM) ? mbp[(size_t)tm * a.NM + fm] : 0.f;
+    melp[rr * RS.row + (jj & 3) * RS.seg + (jj >> 2)] =
+        (tm >= 0 && tm < a.F && fm >= 0 && fm < a.NM) ? mbp[(size_t)tm * a.NM + fm] : 0.f;
   }
   for (int i = threadIdx.x; i < 9 * D; i += SCT) p_w1[i] = a.w1[i];
   for (int i = threadIdx.x; i < D; i += SCT) { p_b1[i] = a.b1[i]; p_b2[i] = a.b2[i]; }
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   for (int rt = 0; rt < SRT; ++rt) {
     const int r = min(r0 + 32 * wave + 16 * rt + c, PU - 1);
     const int t2 = r / a.F2, f2 = r - t2 * a.F2;
-    sl.mb[rt] = 4 * (t2 - t2a) * RS + 4 * f2;
+    sl.mb[rt] = 4 * (t2 - t2a) * RS.row + f2;
     unsigned vm = 0;
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt)
@@ -554,7 +563,7 @@ int launch_subconv144(const SubConvArgs& a, hipStream_t s) {
 // split-bf16 kernel for dmodel 144 / 256 / 512; returns -1 when the shape does not fit its LDS mel patch or the dmodel has
 // no instantiation (the caller falls back)
 template <int DIAG>
-static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, int RS, int rows, int late_mode, hipStream_t s) {
+static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGeom RS, int rows, int late_mode, hipStream_t s) {
   const dim3 g128(g144.x, g144.y, d / 128);
   switch (d) {
     case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 144, 9>), g144, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
@@ -566,10 +575,15 @@ static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, int RS,
 
 int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
   const int PU = a.T2 * a.F2;
-  const int RS = 4 * a.F2 + 4;                               // bins fm_base .. fm_base + 4 (F2 - 1) + 6
+  // patch rows hold bins fm_base .. fm_base + 4 (F2 - 1) + 6, de-interleaved by four into segments of F2 + 1 floats; the row
+  // stride is padded to 5 (mod 8) floats (see PatchGeom)
+  PatchGeom RS;
+  RS.seg = a.F2 + 1;
+  RS.row = 4 * RS.seg;
+  while (RS.row % 8 != 5) ++RS.row;
   const int span = (SPOSG - 1 + a.F2 - 1) / a.F2;            // t2 steps a tile can touch beyond its first
   const int rows = 4 * span + 7;
-  if (!a.w2s || a.st1 != 2 || rows * RS > MELP || PU <= 0) return -1;
+  if (!a.w2s || a.st1 != 2 || rows * RS.row > MELP || PU <= 0) return -1;
   static const int late_mode = [] { const char* v = getenv("MI355ASR_SUBCONV_LATE"); return v ? atoi(v) : 0; }();
   const dim3 grid((PU + SPOSG - 1) / SPOSG, a.B);
 #ifdef MI355ASR_DIAG_KERNELS
