@@ -11,6 +11,9 @@
 // One wave owns whole frames; the 32 x 32 complex transpose between the stages goes through 9 KB of wave-private
 // LDS (no block barrier).  Bin 512 (k1 = 0, k2 = 16) is the alternating sum of A[0][:].
 // The stage weights (cos/sin of 32-point DFTs), the twiddles and the window live in registers for the whole kernel.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 #include "launch.h"
 
@@ -166,12 +169,203 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_kernel(FftStftArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same factorisation on the bf16 matrix pipe (round 3): both DFT-32 stages as v_mfma_f32_16x16x32_bf16 over operands
+// split exactly into three bf16 terms (the six term pairs with i + j <= 2, smallest first: as accurate as the fp32 FMA chain,
+// see subconv.hip / leaf.hip).  Stage 1 is ONE 32-wide step (K = n1), stage 2 two (K = re | im of n2): 96 MFMAs of 16 cycles
+// per frame instead of 128 of 32 -- 1536 matrix-pipe cycles instead of 4096.  The k-slot order of a step (pack_split32:
+// slot j of lane group g <-> k = 16 (j >> 2) + 4 g + (j & 3)) is exactly the pair of float4 fragments the fp32 kernel feeds
+// to its two 16-wide k-blocks, so loads, window, twiddles, the LDS transpose and the epilogue are unchanged; the stage
+// matrices are split on the host (cos / sin of multiples of 2 pi / 32 in fp32, three terms hold every bit).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct Split8 { u32x4_t t[3]; };
+DEV Split8 split8(f32x4 lo, f32x4 hi) {      // exact: x = t0 + t1 + t2 (truncation; the remainders are exact)
+  float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  Split8 f;
+#pragma unroll
+  for (int term = 0; term < 3; ++term) {
+    unsigned d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * k]), a1 = __builtin_bit_cast(unsigned, v[2 * k + 1]);
+      d[k] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+      if (term < 2) {
+        v[2 * k] -= __builtin_bit_cast(float, a0 & 0xffff0000u);
+        v[2 * k + 1] -= __builtin_bit_cast(float, a1 & 0xffff0000u);
+      }
+    }
+    f.t[term] = u32x4_t{d[0], d[1], d[2], d[3]};
+  }
+  return f;
+}
+DEV f32x4 mma32(u32x4_t a, u32x4_t b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStftArgs a) {
+  __shared__ float lds[WAVES_PER_BLOCK][2][32 * LDW];
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, g4 = g * 4, c = lane & 15;
+  const int wave = threadIdx.x >> 6;
+  float* Lre = lds[wave][0];
+  float* Lim = lds[wave][1];
+  const int wid = blockIdx.x * WAVES_PER_BLOCK + wave;
+  const int nwaves = gridDim.x * WAVES_PER_BLOCK;
+  const int total = a.B * a.F;
+
+  // ---- frame-independent operands -> registers: stage matrices as [tile][term] fragments
+  const u32x4_t* __restrict__ w1p = reinterpret_cast<const u32x4_t*>(a.w1s) + lane;   // [4 nt][3 terms]
+  const u32x4_t* __restrict__ w2p = reinterpret_cast<const u32x4_t*>(a.w2s) + lane;   // [2 steps][2 nt][3 terms]
+  u32x4_t w1[4][3], w2[2][2][3];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) w1[nt][t] = w1p[(nt * 3 + t) * 64];
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) w2[st][nt][t] = w2p[((st * 2 + nt) * 3 + t) * 64];
+  f32x4 hw[2][2], twc[2][2], tws[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int n2 = 16 * rt + c;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      hw[rt][kb].x = a.window[32 * (16 * kb + g4 + 0) + n2];
+      hw[rt][kb].y = a.window[32 * (16 * kb + g4 + 1) + n2];
+      hw[rt][kb].z = a.window[32 * (16 * kb + g4 + 2) + n2];
+      hw[rt][kb].w = a.window[32 * (16 * kb + g4 + 3) + n2];
+      twc[rt][kb].x = a.tw_c[(16 * kb + g4 + 0) * 32 + n2]; tws[rt][kb].x = a.tw_s[(16 * kb + g4 + 0) * 32 + n2];
+      twc[rt][kb].y = a.tw_c[(16 * kb + g4 + 1) * 32 + n2]; tws[rt][kb].y = a.tw_s[(16 * kb + g4 + 1) * 32 + n2];
+      twc[rt][kb].z = a.tw_c[(16 * kb + g4 + 2) * 32 + n2]; tws[rt][kb].z = a.tw_s[(16 * kb + g4 + 2) * 32 + n2];
+      twc[rt][kb].w = a.tw_c[(16 * kb + g4 + 3) * 32 + n2]; tws[rt][kb].w = a.tw_s[(16 * kb + g4 + 3) * 32 + n2];
+    }
+  }
+  const int L = a.L;
+  // acc += W^T x over the six term pairs, smallest first, for NT tiles and two row tiles: MFMAs on one accumulator 2 NT apart
+  auto mma6 = [&](auto& acc, const auto& w, const Split8 (&x)[2], auto NT_T) {
+    constexpr int NT = decltype(NT_T)::value;
+#pragma unroll
+    for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+      for (int p = 0; p <= ord; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc[rt][nt] = mma32(w[nt][ord - p], x[rt].t[p], acc[rt][nt]);
+  };
+
+#pragma unroll 1
+  for (int fidx = wid; fidx < total; fidx += nwaves) {
+    const int b = fidx / a.F, f = fidx - b * a.F;
+    const float* __restrict__ wav = a.wav + (size_t)b * L;
+    const int base = f * a.hop - a.pad_left;
+    // ---- stage-1 operand: xw[32*n1 + n2], zero outside the signal (TF SAME / left-padded VALID framing)
+    Split8 xs[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      f32x4 xf[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int s0 = base + 32 * (16 * kb + g4) + 16 * rt + c;
+        const bool o0 = (unsigned)(s0) < (unsigned)L, o1 = (unsigned)(s0 + 32) < (unsigned)L;
+        const bool o2 = (unsigned)(s0 + 64) < (unsigned)L, o3 = (unsigned)(s0 + 96) < (unsigned)L;
+        f32x4 v;
+        v.x = wav[o0 ? s0 : 0]; v.y = wav[o1 ? s0 + 32 : 0]; v.z = wav[o2 ? s0 + 64 : 0]; v.w = wav[o3 ? s0 + 96 : 0];
+        v.x = o0 ? v.x : 0.f; v.y = o1 ? v.y : 0.f; v.z = o2 ? v.z : 0.f; v.w = o3 ? v.w : 0.f;
+        xf[kb] = v * hw[rt][kb];
+      }
+      xs[rt] = split8(xf[0], xf[1]);
+    }
+    // ---- stage 1: A = F32 * Xw   (acc1[rt][nt]: nt 0,1 = Re k1 0..31 ; nt 2,3 = Im k1 0..31)
+    f32x4 acc1[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc1[rt][nt] = splat4(0.f);
+    mma6(acc1, w1, xs, std::integral_constant<int, 4>{});
+    // ---- bin 512: sum_n2 (-1)^n2 A_re[0][n2]   (A_re[0][n2] sits in lanes g == 0, tile 0, reg 0)
+    float nyq = (g == 0) ? ((c & 1) ? -1.f : 1.f) * (acc1[0][0].x + acc1[1][0].x) : 0.f;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) nyq += __shfl_xor(nyq, off);
+    // ---- twiddle + transpose through wave-private LDS: L[k1][n2]
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int n2 = 16 * rt + c;
+#pragma unroll
+      for (int nr = 0; nr < 2; ++nr) {
+        const f32x4 are = acc1[rt][nr], aim = acc1[rt][2 + nr];
+        const f32x4 bre = are * twc[rt][nr] + aim * tws[rt][nr];
+        const f32x4 bim = aim * twc[rt][nr] - are * tws[rt][nr];
+        const int k1 = 16 * nr + g4;
+        Lre[(k1 + 0) * LDW + n2] = bre.x; Lre[(k1 + 1) * LDW + n2] = bre.y;
+        Lre[(k1 + 2) * LDW + n2] = bre.z; Lre[(k1 + 3) * LDW + n2] = bre.w;
+        Lim[(k1 + 0) * LDW + n2] = bim.x; Lim[(k1 + 1) * LDW + n2] = bim.y;
+        Lim[(k1 + 2) * LDW + n2] = bim.z; Lim[(k1 + 3) * LDW + n2] = bim.w;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- stage 2: X[k1][k2] = sum_n2 B[k1][n2] W32^(n2 k2); tokens = k1 = 16*rt + c; step 0: K = Re n2, step 1: K = Im n2
+    f32x4 acc2[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      acc2[rt][0] = splat4(0.f);
+      acc2[rt][1] = splat4(0.f);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      Split8 ys[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float* src = (st == 0 ? Lre : Lim) + (16 * rt + c) * LDW + g4;
+        ys[rt] = split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 16));
+      }
+      mma6(acc2, w2[st], ys, std::integral_constant<int, 2>{});
+    }
+    // ---- power, log, store, per-frame max.  lane holds bins k1 + 32*k2, k1 = 16*rt + c, k2 = 4*g + j
+    float mx = -INFINITY;
+    float* orow = a.logp + ((size_t)b * a.F + f) * a.LP;
+    const float kscale = a.db10 ? (10.0f * 0.69314718f / 2.30258509f) : (0.69314718f / 2.30258509f);   // log2 -> dB / log10
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const f32x4 re = acc2[rt][0], im = acc2[rt][1];
+      const f32x4 p = re * re + im * im;
+      const float pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float l = __log2f(fmaxf(pv[j], 1e-10f)) * kscale;
+        orow[16 * rt + c + 32 * (g4 + j)] = l;
+        mx = fmaxf(mx, l);
+      }
+    }
+    if (lane == 0) {
+      const float l = __log2f(fmaxf(nyq * nyq, 1e-10f)) * kscale;
+      orow[512] = l;
+      mx = fmaxf(mx, l);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) a.pmax[fidx] = mx;
+  }
+}
+
 }  // namespace
 
 int launch_fft_stft(const FftStftArgs& a, hipStream_t s) {
   const int total = a.B * a.F;
   // enough waves for 4 per SIMD (their VALU / LDS phases hide under each other's MFMAs), each looping over frames
   const int waves = std::min(total, 4096);
+  // MI355ASR_FFT_SPLIT=0: both DFT stages on the fp32 MFMA (round 1) instead of the split-bf16 pipe
+  static const bool split = [] { const char* v = getenv("MI355ASR_FFT_SPLIT"); return v ? atoi(v) != 0 : true; }();
+  if (split && a.w1s && a.w2s) {
+    hipLaunchKernelGGL(fft_stft_split_kernel, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
+    return 0;
+  }
   hipLaunchKernelGGL(fft_stft_kernel, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
 }

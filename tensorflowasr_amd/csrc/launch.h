@@ -91,6 +91,10 @@ struct FftStftArgs {
   const float* window;  // [1024]
   int B, L, F, hop, pad_left, LP;
   int db10;
+  // the two DFT-32 stage matrices as split-bf16 fragments (pack_split32: [steps][tiles][3 terms][64 lanes][8]) for the bf16
+  // matrix pipe (fft_stft_split_kernel, round 3), or null
+  const float* w1s = nullptr;   // stage 1: K = 32 (n1), 64 columns -> [1][4][3][64][8]
+  const float* w2s = nullptr;   // stage 2: K = 64 (re | im of n2), 32 columns -> [2][2][3][64][8]
 };
 int launch_fft_stft(const FftStftArgs& a, hipStream_t s);
 struct UttMaxArgs { const float* pmax; float* umax; int n; };
