@@ -76,7 +76,29 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((sizeof(typename P::W) > 8 && CT ==
 
   // prologue LayerNorm statistics (two-pass, biased variance, eps inside the sqrt: Keras semantics)
   float mean = 0.f, rstd = 1.f;
-  if (LN) {
+  // (the register-hungry instantiations -- fp32 fragments, more than eight accumulators -- keep the round-1 code: they are not
+  // the streaming shapes, and zero scratch is a hard requirement of this library)
+  constexpr bool LEAN = sizeof(WF) <= 8 && NF <= 8;
+  if (LN && LEAN && KB <= 16) {
+    // round 3: rows of up to 256 features (dmodel 256, the streaming shapes) are requested whole -- ONE memory round trip for
+    // both passes of the statistics instead of four; at 832 rows the prologue's latency chain was half of the kernel
+    f32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = ldg4(xr + 16 * min(i, KB - 1));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < KB) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    mean = group_sum(s) / (float)a.K;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < KB) {
+        const f32x4 d = v[i] - splat4(mean);
+        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+      }
+    rstd = 1.0f / sqrtf(group_sum(q) / (float)a.K + a.eps);
+  } else if (LN) {
     // eight row chunks requested at a time: one load per trip costs a memory latency each (32 trips for dmodel 256 --
     // the whole kernel at streaming sizes, where nothing else covers it)
     float s = 0.f;
@@ -143,14 +165,26 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((sizeof(typename P::W) > 8 && CT ==
         }
       }
     };
+    // round 3: the epilogue's operands (bias, residual rows) are requested BEFORE the k-loop -- at streaming sizes every
+    // dependent memory round trip is a visible part of the kernel -- and a group past the end is not fetched at all
+    f32x4 pbias[NF], pres[EPI == E16_RES ? CT : 1];
+    if (LEAN && (KS == 1 || wave == 0)) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const int f0 = 16 * (c0 + i) + g4;
+        pbias[i] = ldg4(a.bias + f0);
+        if (EPI == E16_GLU) pbias[CT + i] = ldg4(a.bias + 16 * half + f0);
+        if constexpr (EPI == E16_RES) pres[i] = ldg4(a.res + (size_t)min(tok, a.M - 1) * a.ldy + f0);
+      }
+    }
     if (kbeg < kend) {
       load_group(kbeg, wb[0], xb[0]);
       for (int kb0 = kbeg; kb0 < kend; kb0 += 2 * U) {
-        load_group(kb0 + U, wb[1], xb[1]);
+        if (!LEAN || kb0 + U < kend) load_group(kb0 + U, wb[1], xb[1]);
         __builtin_amdgcn_sched_barrier(0);
         mma_group(kb0, wb[0], xb[0]);
         __builtin_amdgcn_sched_barrier(0);
-        load_group(kb0 + 2 * U, wb[0], xb[0]);
+        if (!LEAN || kb0 + 2 * U < kend) load_group(kb0 + 2 * U, wb[0], xb[0]);
         __builtin_amdgcn_sched_barrier(0);
         mma_group(kb0 + U, wb[1], xb[1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -178,7 +212,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((sizeof(typename P::W) > 8 && CT ==
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
         const int f0 = 16 * (c0 + i) + g4;
-        const f32x4 va = acc[i] + ldg4(a.bias + f0), vb = acc[CT + i] + ldg4(a.bias + 16 * half + f0);
+        const f32x4 va = acc[i] + (LEAN ? pbias[i] : ldg4(a.bias + f0)), vb = acc[CT + i] + (LEAN ? pbias[CT + i] : ldg4(a.bias + 16 * half + f0));
         f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
         if (live) stg4(yrow + f0, o);
       }
@@ -188,7 +222,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((sizeof(typename P::W) > 8 && CT ==
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
         const int f0 = 16 * (c0 + i) + g4;
-        v[i] = ldg4(a.res + (size_t)min(tok, a.M - 1) * a.ldy + f0) + splat4(a.scale) * (acc[i] + ldg4(a.bias + f0));
+        if constexpr (LEAN) v[i] = pres[i] + splat4(a.scale) * (acc[i] + pbias[i]);
+        else v[i] = ldg4(a.res + (size_t)min(tok, a.M - 1) * a.ldy + f0) + splat4(a.scale) * (acc[i] + ldg4(a.bias + f0));
       }
       if (a.fln_g) {
         float s = 0.f;
@@ -216,7 +251,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((sizeof(typename P::W) > 8 && CT ==
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
         const int f0 = 16 * (c0 + i) + g4;
-        f32x4 v = acc[i] + ldg4(a.bias + f0);
+        f32x4 v = acc[i] + (LEAN ? pbias[i] : ldg4(a.bias + f0));
         if (EPI == E16_SWISH) v = swish4(v);
         if (EPI == E16_AFFSWISH) v = swish4(v * ldg4(a.aff_s + f0) + ldg4(a.aff_t + f0));
         if (EPI == E16_QKV) { if (c0 + i < a.qtiles) v *= splat4(a.qscale); }

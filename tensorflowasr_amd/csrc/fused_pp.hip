@@ -57,9 +57,15 @@ DEV Split8 split8(f32x4 lo, f32x4 hi) {      // exact: x = t0 + t1 + t2 (truncat
   }
   return f;
 }
+#ifndef PP_DMA_AUX
+#define PP_DMA_AUX 0        // cache-policy bits of the slab DMAs (experiments: tools/build_variant.py ... -DPP_DMA_AUX=n)
+#endif
+#ifndef PP_DMA_SLEEP
+#define PP_DMA_SLEEP 0      // s_sleep units (64 cycles) between the pieces a loader wave issues (experiments)
+#endif
 DEV void dma16(const u32x4_t* gsrc, u32x4_t* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, PP_DMA_AUX);
 }
 // s_waitcnt vmcnt(PER * ahead) lgkmcnt(0) for a wave-uniform run-time `ahead` in [0, MAXA] (the count is an immediate)
 template <int PER, int MAXA>
@@ -191,7 +197,10 @@ struct PpLoader {
     u32x4_t* l = ring + slot * PP_SLB + 64 * wv;
     if constexpr (DG & 16) return;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) dma16(g + BLOCK_THREADS * q, l + BLOCK_THREADS * q);
+    for (int q = 0; q < PER; ++q) {
+      dma16(g + BLOCK_THREADS * q, l + BLOCK_THREADS * q);
+      if constexpr (PP_DMA_SLEEP > 0) __builtin_amdgcn_s_sleep(PP_DMA_SLEEP);
+    }
   }
   // prologue slabs (depthwise-conv fold): all thirty pieces from waves 6 and 7, so that waves 4 and 5 -- which stage and
   // compute with the consumers -- have no DMA in flight (hipcc waits for every pending LDS-DMA before an LDS read it sees)

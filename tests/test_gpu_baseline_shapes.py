@@ -353,7 +353,9 @@ for name, kw in (("M", dict(dmodel=256, num_blocks=2, head_size=64, num_heads=4)
     out[name + "_logits"] = logits.cpu().numpy()[::7]
     if name == "M" and len(sys.argv) > 2:           # the oracle follows one sampled utterance through the benched launch shapes
         cfg = dict(co.CONFORMER_S, dmodel=256, num_blocks=2, head_size=64, num_heads=4)
-        out["M_oracle_enc21"] = co.conformer_encoder(x[21:22].astype(np.float64), m.get_weights_dict(), cfg)
+        wo = {k: (np.asarray(v).reshape(1024, 513) if k.endswith(("mel_layer/real_kernels", "mel_layer/imag_kernels")) else v)
+              for k, v in m.get_weights_dict().items()}
+        out["M_oracle_enc21"] = co.conformer_encoder(x[21:22].astype(np.float64), wo, cfg)
         out["M_gpu_enc21"] = enc[21:22].cpu().numpy()
     del m
     torch.cuda.empty_cache()
