@@ -312,7 +312,11 @@ int dispatch(int epi, bool ln, const Gemm16Args& a, hipStream_t s) {
 #define CASE(E, L) \
   if (epi == E && ln == L) { \
     if constexpr (E == E16_RES) { \
-      if (ntc == 9) go<P, 9, E, L>(a, s); else if (ntc == 16) go<P, 16, E, L>(a, s); \
+      if (ntc == 9) go<P, 9, E, L>(a, s); \
+      /* round 3: few rows (the streaming shapes) and no row LayerNorm: column chunks of four tiles -- four times the */ \
+      /* workgroups (52 row tiles alone leave 200 CUs idle) on the lean code path */ \
+      else if (ntc == 16 && !a.fln_g && tiles < 512) go<P, 4, E, L>(a, s); \
+      else if (ntc == 16) go<P, 16, E, L>(a, s); \
       else if (ntc % 8 == 0) { \
         /* wide rows (dmodel 512): column chunks of 8 tiles, the row LayerNorm as a second pass over y */ \
         Gemm16Args b = a; b.fln_g = nullptr; b.fln_b = nullptr; go<P, 8, E, L>(b, s); \
