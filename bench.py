@@ -89,9 +89,11 @@ def algorithmic_flops(B, L, cfg=S_CFG, V=NUM_CLASSES, stft_mode=0, mel_nnz=None)
         # block-level fused kernels (dmodel 144): sums of the layers they contain
         "ff1_qkv": 2.0 * 2 * M * d * 4 * d + 3 * 2.0 * M * d * d,
         "out_glu": 2.0 * M * d * d + 2.0 * M * d * 2 * d,
-        "tail_ff2": 2.0 * M * d * 2 * d + 2.0 * M * 2 * d * d + 2.0 * 2 * M * d * 4 * d,
+        # (round 3: the depthwise conv runs in the prologue of the tail kernels -- its flops are theirs now; with
+        # MI355ASR_PP_DW=0 it is a launch of its own again and the few per cent are counted twice)
+        "tail_ff2": 2.0 * M * d * k + 2.0 * M * d * 2 * d + 2.0 * M * 2 * d * d + 2.0 * 2 * M * d * 4 * d,
         # tail_ff2 of one block + ff1_qkv of the next in one launch
-        "tail_ff1": 2.0 * M * d * 2 * d + 2.0 * M * 2 * d * d + 2 * (2.0 * 2 * M * d * 4 * d) + 3 * 2.0 * M * d * d,
+        "tail_ff1": 2.0 * M * d * k + 2.0 * M * d * 2 * d + 2.0 * M * 2 * d * d + 2 * (2.0 * 2 * M * d * 4 * d) + 3 * 2.0 * M * d * d,
     }
 
 
