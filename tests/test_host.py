@@ -731,3 +731,25 @@ def test_profile_artifacts_and_kernel_categories(tag, dom, dom_kernel):
     by = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in rows}
     t = next(v for k, v in by.items() if dom_kernel in k)
     assert abs(t - bench["kernels"][dom]["avg_ms"] * 1e3) / t < 0.15      # rocprof and HIP events agree
+
+
+def test_pair_pipelined_stream_generator_simulates_and_matches_the_committed_sources():
+    """tools/gen_pp.py describes the pair-pipelined fragment stream of fused_pp.hip once; its simulator replays every unit
+    (fragment reads into pool slots, counted lgkmcnt waits, MFMAs, ring-slot hand-overs) and the committed device code
+    (pp_units.inc) and host packing table (pp_layout.inc) are exactly what it emits."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_pp", os.path.join(root, "tools", "gen_pp.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    units, leads = g.build_all()                       # raises on any slot / count / coverage error
+    assert {u.name for u in units} == {"A", "AP", "F", "BP", "B", "S"}
+    by = {u.name: u for u in units}
+    assert (by["F"].nm, by["A"].nm, by["B"].nm) == (114, 60, 54) and by["F"].nslabs == 2
+    assert all(u.length % g.NPOOL == 0 and max(len(s) for s in u.slabs) <= g.SLOT for u in units)
+    assert min(leads.values()) >= 7                    # no fragment is requested less than 7 MFMAs before its first use
+    csrc = os.path.join(root, "tensorflowasr_amd", "csrc")
+    assert open(os.path.join(csrc, "pp_units.inc")).read() == g.emit_units(units) + "\n"
+    assert open(os.path.join(csrc, "pp_layout.inc")).read() == g.emit_layout(units)
+    # a chain of P hidden pairs = units A, AP, (P - 2) x F, BP, B = 2 P ring slots; every MFMA of the FFN (18 pairs) once
+    assert by["A"].nm + by["AP"].nm + 16 * by["F"].nm + by["BP"].nm + by["B"].nm == 2052
