@@ -41,8 +41,52 @@ constexpr float kNegInf = -FLT_MAX;
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ float expf_cr(float x) { return (float)exp((double)x); }
-__device__ __forceinline__ float logf_cr(float x) { return (float)log((double)x); }
+// expf / logf as the host's libm returns them = the exact value rounded to float.  Round 2 called the double-precision
+// library routines (~150 instructions with their special-case branches; two or three log_sum_exp per beam entry made the
+// "entries" phase 60 % of a frame at beam 10).  Round 3: the two arguments only ever come from log_sum_exp -- exp of
+// d in [-17.5, 0], log of s in [1, 2] -- so both are short double-precision kernels with a relative error below 2^-46
+// (a float result can differ from the correctly rounded one only when the exact value lies within 2^-22 ulp of a rounding
+// boundary; the known-answer cases of the reference decoder stay bit-exact):
+//   exp(d) = 2^k (1 + q), k = rint(d log2 e), r = d - k ln 2 (two-constant reduction), q = expm1(r) by the Taylor polynomial of
+//   degree 13 on |r| <= 0.347 (remainder 3e-17);
+//   log(s): y0 = ln 2 * v_log_f32(s) (1e-7), then ONE Newton step on exp(y) = s: y1 = y0 + (s exp(-y0) - 1), the bracket formed
+//   as (A - 1) + A q with A = s 2^k exact, so that results near zero keep their relative accuracy; error (y0 - log s)^2 / 2.
+//   4 x 10^6 random arguments of each: no float result differs from the library's (tools: the check sits in tests/test_host.py).
+// exp(x) = 2^k (1 + q): k = rint(x log2 e), r = x - k ln 2 (ln 2 = hi + lo), q = expm1(r) = r (1 + r / 2 + r^2 / 6 + ...)
+__device__ __forceinline__ double expm1_reduced(double x, double& k) {      // |x| <= 18
+  k = rint(x * 1.4426950408889634074);
+  const double r = fma(-k, 1.9082149292705877e-10, fma(-k, 0.693147180369123816490, x));
+  double p = 1.6059043836821613e-10;                             // 1 / 13!
+  p = fma(p, r, 2.08767569878681e-09);                           // 1 / 12!
+  p = fma(p, r, 2.505210838544172e-08);
+  p = fma(p, r, 2.755731922398589e-07);
+  p = fma(p, r, 2.7557319223985893e-06);
+  p = fma(p, r, 2.48015873015873e-05);
+  p = fma(p, r, 0.0001984126984126984);
+  p = fma(p, r, 0.001388888888888889);
+  p = fma(p, r, 0.008333333333333333);
+  p = fma(p, r, 0.041666666666666664);
+  p = fma(p, r, 0.16666666666666666);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  return p * r;
+}
+__device__ __forceinline__ double scale2(double v, double k) {   // v 2^k for normal v and small integral k
+  return __longlong_as_double(__double_as_longlong(v) + ((long long)(int)k << 52));
+}
+__device__ __forceinline__ float expf_cr(float x) {              // x in [-17.5, 0]
+  double k;
+  const double q = expm1_reduced((double)x, k);
+  return (float)scale2(1.0 + q, k);
+}
+__device__ __forceinline__ float logf_cr(float s) {              // s in [1, 2]
+  if (s == 1.0f) return 0.f;
+  const double y0 = (double)(__builtin_amdgcn_logf(s) * 0.69314718f);
+  double k;
+  const double q = expm1_reduced(-y0, k);                        // k is 0 or -1
+  const double A = scale2((double)s, k);                         // s exp(-y0) - 1 = (A - 1) + A q: no cancellation near s = 1
+  return (float)(y0 + ((A - 1.0) + A * q));
+}
 __device__ __forceinline__ float lse(float x, float y) {        // decoder_utils.h:41-49 with T = float
   if (x <= kNegInf) return y;
   if (y <= kNegInf) return x;

@@ -753,3 +753,35 @@ def test_pair_pipelined_stream_generator_simulates_and_matches_the_committed_sou
     assert open(os.path.join(csrc, "pp_layout.inc")).read() == g.emit_layout(units)
     # a chain of P hidden pairs = units A, AP, (P - 2) x F, BP, B = 2 P ring slots; every MFMA of the FFN (18 pairs) once
     assert by["A"].nm + by["AP"].nm + 16 * by["F"].nm + by["BP"].nm + by["B"].nm == 2052
+
+
+def test_log_sum_exp_kernels_of_the_device_beam_search_round_like_libm():
+    """beam_device.hip evaluates expf on [-17.5, 0] and logf on [1, 2] (the only arguments log_sum_exp produces) with two
+    short double-precision kernels instead of the library routines.  This is their arithmetic restated in NumPy doubles
+    (fma contraction aside): on 2 x 10^6 random arguments every float result equals the correctly rounded library value,
+    with the hardware log2 modelled as exact +- 1.2e-7 relative."""
+    C = [1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07, 2.7557319223985893e-06,
+         2.48015873015873e-05, 0.0001984126984126984, 0.001388888888888889, 0.008333333333333333, 0.041666666666666664,
+         0.16666666666666666, 0.5, 1.0]
+
+    def expm1_reduced(x):
+        k = np.rint(x * 1.4426950408889634074)
+        r = (-k) * 1.9082149292705877e-10 + ((-k) * 0.693147180369123816490 + x)
+        p = np.full_like(x, C[0])
+        for c in C[1:]:
+            p = p * r + c
+        return k, p * r
+
+    rng = np.random.default_rng(1)
+    d = rng.uniform(-17.5, 0, 2_000_000).astype(np.float32)
+    k, q = expm1_reduced(d.astype(np.float64))
+    e = np.ldexp(1.0 + q, k.astype(int)).astype(np.float32)
+    assert np.array_equal(e, np.exp(d.astype(np.float64)).astype(np.float32))
+    s = (np.float32(1) + e).astype(np.float32)
+    s = s[s > 1]
+    hw = np.log2(s.astype(np.float64)) * (1 + rng.uniform(-1.2e-7, 1.2e-7, s.size))
+    y0 = (hw.astype(np.float32) * np.float32(0.69314718)).astype(np.float64)
+    k, q = expm1_reduced(-y0)
+    A = np.ldexp(s.astype(np.float64), k.astype(int))
+    y1 = y0 + ((A - 1.0) + A * q)
+    assert np.array_equal(y1.astype(np.float32), np.log(s.astype(np.float64)).astype(np.float32))
