@@ -1666,7 +1666,7 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
     static const bool prof_env = [] { const char* v = getenv("MI355ASR_BEAM_PROF"); return v && atoi(v) != 0; }();
     if (prof_env) {
       a.prof = d_prof;
-      HIP_TRY(hipMemsetAsync(a.prof, 0, 9 * sizeof(long long), s));
+      HIP_TRY(hipMemsetAsync(a.prof, 0, 16 * sizeof(long long), s));
     }
     if (in_len) {
       HIP_TRY(hipMemcpyAsync(d_len, in_len, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -1677,14 +1677,16 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
     HIP_TRY(hipMemcpyAsync(lens, a.lens, (size_t)B * beam_size * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(scores, a.scores, (size_t)B * beam_size * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(n_hyp, a.n_hyp, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof[16] = {0};
     if (a.prof) HIP_TRY(hipMemcpyAsync(prof, a.prof, sizeof(prof), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (a.prof) {
       const double f = (double)std::max(1ll, prof[8]);
       fprintf(stderr, "[mi355asr] beam %d, utterance 0: %lld frames (%lld redone by the radix path); clocks per frame: entries %.0f, "
-              "keys+ranks %.0f, keep %.0f, radix path %.0f (keys %.0f, select %.0f, compaction %.0f)\n", beam_size, prof[8],
-              prof[4], prof[0] / f, prof[1] / f, prof[2] / f, prof[3] / f, prof[5] / f, prof[6] / f, prof[7] / f);
+              "keys+ranks %.0f, keep %.0f, radix path %.0f (keys %.0f, select %.0f, compaction %.0f); inside the entry phase: thread 0 "
+              "%.0f (%.0f up to the parent search), wave 3's candidate list %.0f (%.0f cumulative cut-off)\n", beam_size, prof[8],
+              prof[4], prof[0] / f, prof[1] / f, prof[2] / f, prof[3] / f, prof[5] / f, prof[6] / f, prof[7] / f, prof[9] / f, prof[10] / f,
+              prof[11] / f, prof[12] / f);
     }
     return 0;
   }

@@ -36,7 +36,10 @@ namespace {
 constexpr int NT = 256;          // threads per utterance
 constexpr int BMAX = 128;        // beam entries
 constexpr int NMAX = 40;         // candidates per frame (cutoff_top_n)
-constexpr int SMALL_BEAM = 16;   // widest beam of the one-key-per-thread kernel
+constexpr int HASH = 1024;       // cells of the parent hash
+static_assert(HASH == 4 * NT && 4 * BMAX <= HASH, "four cells per thread to clear; the set stays sparse");
+constexpr int SMALL_BEAM = 16;
+__host__ __device__ constexpr int tab_stride(int V) { return (V + 15) & ~15; }   // bytes of one class table   // widest beam of the one-key-per-thread kernel
 constexpr float kNegInf = -FLT_MAX;
 
 typedef unsigned long long u64;
@@ -53,7 +56,7 @@ typedef unsigned long long u64;
 //   as (A - 1) + A q with A = s 2^k exact, so that results near zero keep their relative accuracy; error (y0 - log s)^2 / 2.
 //   4 x 10^6 random arguments of each: no float result differs from the library's (tools: the check sits in tests/test_host.py).
 // exp(x) = 2^k (1 + q): k = rint(x log2 e), r = x - k ln 2 (ln 2 = hi + lo), q = expm1(r) = r (1 + r / 2 + r^2 / 6 + ...)
-__device__ __forceinline__ double expm1_reduced(double x, double& k) {      // |x| <= 18
+__device__ __forceinline__ double expm1_reduced(double x, double& k) {      // |x| <= 90
   k = rint(x * 1.4426950408889634074);
   const double r = fma(-k, 1.9082149292705877e-10, fma(-k, 0.693147180369123816490, x));
   double p = 1.6059043836821613e-10;                             // 1 / 13!
@@ -85,7 +88,18 @@ __device__ __forceinline__ float logf_cr(float s) {              // s in [1, 2]
   double k;
   const double q = expm1_reduced(-y0, k);                        // k is 0 or -1
   const double A = scale2((double)s, k);                         // s exp(-y0) - 1 = (A - 1) + A q: no cancellation near s = 1
-  return (float)(y0 + ((A - 1.0) + A * q));
+  const double e = (A - 1.0) + A * q;                             // log s = y0 + log1p(e), |e| < 2^-22: two terms are exact to 2^-68
+  return (float)(y0 + fma(-0.5 * e, e, e));
+}
+// log of a double in [2^-126, 2]: the candidates' log-probabilities (the reference takes log(p + FLT_MIN) in double,
+// ctc_beam_search_decoder.cpp:57-59, and rounds to float)
+__device__ __forceinline__ double log_pos(double x) {
+  const double y0 = (double)__builtin_amdgcn_logf((float)x) * 0.6931471805599453094;
+  double k;
+  const double q = expm1_reduced(-y0, k);                        // |k| <= 127
+  const double A = scale2(x, k);
+  const double e = (A - 1.0) + A * q;                             // |e| < 2^-16 (one ulp of a float log2 of up to 126)
+  return y0 + fma(-0.5 * e, e, e);
 }
 __device__ __forceinline__ float lse(float x, float y) {        // decoder_utils.h:41-49 with T = float
   if (x <= kNegInf) return y;
@@ -96,11 +110,28 @@ __device__ __forceinline__ float lse(float x, float y) {        // decoder_utils
   if (d < -17.5f) return 0.f + m;
   return logf_cr(1.0f + expf_cr(d)) + m;
 }
-__device__ __forceinline__ u64 mix(u64 parent, int c) {        // prefix identity
-  u64 z = parent * 0x9E3779B97F4A7C15ull + (u64)(unsigned)(c + 2) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
+// inclusive prefix sum over the wave: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then lane 15 of a row into the next
+// row and lane 31 into the upper half (DPP; lanes without a source add 0)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROWS, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWS, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_prefix_sum(double v) {
+  v += dpp_f64<0x111, 0xf>(v);
+  v += dpp_f64<0x112, 0xf>(v);
+  v += dpp_f64<0x114, 0xf>(v);
+  v += dpp_f64<0x118, 0xf>(v);
+  v += dpp_f64<0x142, 0xa>(v);                                    // row_bcast:15 into rows 1 and 3
+  v += dpp_f64<0x143, 0xc>(v);                                    // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// Prefix identity: one 64-bit multiply on the per-frame path (four of them cost ~250 clocks of every frame's install
+// step).  The shift-xor in front keeps the ids from being a polynomial in the characters modulo 2^64.
+__device__ __forceinline__ u64 mix(u64 parent, int c) {
+  const u64 z = (parent ^ (parent >> 29)) * 0x9E3779B97F4A7C15ull + (u64)(unsigned)(c + 2);
   return z ? z : 1;
 }
 // ascending key order = better first: score descending, character ascending, slot ascending
@@ -114,6 +145,7 @@ struct Beam {
   __align__(16) u64 id[BMAX];
   u64 par[BMAX];
   int ch[BMAX], arena[BMAX];
+  int kc[BMAX];        // position of ch among the candidates of the frame this beam is extended with (-1: not one)
   float score[BMAX], b[BMAX], nb[BMAX];
 };
 
@@ -160,6 +192,19 @@ struct Shared {
   float max_score;
   u64 diff, kmin[2];
   int kept_j[BMAX];
+  __align__(16) int hpos[2][HASH];   // [beam buffer]: open-addressed set of 1 + entry position, keyed by id mod HASH (0: free cell)
+};
+// Two lookups replace list scans on the per-frame path (a thread scanning 40 candidates and up to 128 ids cost 2 500 of
+// the 3 400 clocks of the entry phase):
+//   class table (dynamic LDS, V bytes per frame parity): tab[c] = 1 + position of class c among the frame's candidates,
+//     written by the wave that prepares the candidates (which also clears the entries of the frame two back); an entry's
+//     `kc` is read from it when the entry is installed, one frame ahead.
+//   parent hash: hpos above, linear probing; an entry claims the first free cell from id mod HASH on when it is installed
+//     (atomicCAS), a lookup walks from there until the id matches or a cell is free.  At most 2 x BMAX of the 1 024 cells
+//     are ever taken (the small path may install a frame twice: stale cells fail the id test and are walked over).
+struct Lookup {
+  const unsigned char* tab_next;   // class table of the frame the new beam meets
+  int* hnx;                        // parent hash of the new beam
 };
 
 // extension of entry j by candidate k (ctc_beam_search_decoder.cpp:99-113)
@@ -168,14 +213,32 @@ __device__ __forceinline__ float child_lp(const Beam& C, const Cands& K, int j, 
   if (c == C.ch[j]) return C.b[j] > kNegInf ? K.lp[k] + C.b[j] : kNegInf;
   return K.lp[k] + C.score[j];
 }
-__device__ __forceinline__ void keep_entry(Shared& sh, const Beam& C, Beam& Nx, int s, int pos) {
-  Nx.id[pos] = C.id[s]; Nx.par[pos] = C.par[s]; Nx.ch[pos] = C.ch[s]; Nx.arena[pos] = C.arena[s];
-  Nx.score[pos] = sh.cscore[s]; Nx.b[pos] = sh.cb[s]; Nx.nb[pos] = sh.cnb[s];
+__device__ __forceinline__ void hash_claim(int* cells, u64 id, int pos) {
+  unsigned h = (unsigned)id & (HASH - 1);
+  while (atomicCAS(&cells[h], 0, pos + 1) != 0) h = (h + 1) & (HASH - 1);
 }
-__device__ __forceinline__ void keep_child(const Beam& C, Beam& Nx, int2* arena, int ai, int j, int c, float lp, int pos) {
+__device__ __forceinline__ int hash_find(const int* cells, const Beam& C, int nbm, u64 id) {
+  for (unsigned h = (unsigned)id & (HASH - 1);; h = (h + 1) & (HASH - 1)) {
+    const int v = cells[h];
+    if (v == 0) return -1;
+    if (v <= nbm && C.id[v - 1] == id) return v - 1;
+  }
+}
+__device__ __forceinline__ void keep_entry(Shared& sh, const Beam& C, Beam& Nx, const Lookup& L, int s, int pos) {
+  const u64 id = C.id[s];
+  const int ch = C.ch[s];
+  Nx.id[pos] = id; Nx.par[pos] = C.par[s]; Nx.ch[pos] = ch; Nx.arena[pos] = C.arena[s];
+  Nx.score[pos] = sh.cscore[s]; Nx.b[pos] = sh.cb[s]; Nx.nb[pos] = sh.cnb[s];
+  Nx.kc[pos] = ch >= 0 ? (int)L.tab_next[ch] - 1 : -1;
+  hash_claim(L.hnx, id, pos);
+}
+__device__ __forceinline__ void keep_child(const Beam& C, Beam& Nx, const Lookup& L, int2* arena, int ai, int j, int c, float lp, int pos) {
+  const u64 pid = C.id[j], id = mix(pid, c);
   arena[ai] = make_int2(C.arena[j], c);
-  Nx.id[pos] = mix(C.id[j], c); Nx.par[pos] = C.id[j]; Nx.ch[pos] = c; Nx.arena[pos] = ai;
+  Nx.id[pos] = id; Nx.par[pos] = pid; Nx.ch[pos] = c; Nx.arena[pos] = ai;
   Nx.score[pos] = lp; Nx.b[pos] = kNegInf; Nx.nb[pos] = lp;
+  Nx.kc[pos] = (int)L.tab_next[c] - 1;
+  hash_claim(L.hnx, id, pos);
 }
 
 __device__ __forceinline__ float key_score(u64 key) {             // inverse of make_key's first word
@@ -194,7 +257,7 @@ constexpr unsigned kNegHi = 0xFF7FFFFFu;   // first key word of a score of -FLT_
 struct RadixProf { long long keys, select, install; };
 template <int JPT>                         // entries per wave: nbm <= 4 * JPT
 __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx, const Cands& K, const u64* exist, int nbm,
-                                            int beam, int t, int2* arena, bool profiling, RadixProf& rp) {
+                                            int beam, int t, int2* arena, const Lookup& L, bool profiling, RadixProf& rp) {
   const int tid = threadIdx.x, k = tid & 63, w = tid >> 6;
   long long c0 = 0;
   if (profiling) c0 = clock64();
@@ -210,33 +273,30 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
     counts += 1 + (((unsigned)(ekey >> 32) != kNegHi) << 16);
     kmin = ekey;
   }
+  // what depends on the entry: lane l fetches entry w + 4 l's words once, each use is a v_readlane (scalar operand) --
+  // no LDS latency inside the loop over the wave's entries
+  static_assert(JPT <= 64, "one lane per entry of the wave");
+  const int jl = min(w + 4 * k, nbm - 1);
+  const u64 ex_l = exist[jl];
+  const int ch_l = C.ch[jl];
+  const float b_l = C.b[jl], s_l = C.score[jl];
 #pragma unroll
-  for (int g = 0; g < JPT; g += 4) {
-    if (w + 4 * g >= nbm) {                 // wave-uniform
-#pragma unroll
-      for (int u = 0; u < 4; ++u) ck[g + u] = ~0ull;
-      continue;
-    }
-    u64 ex[4];
-    int chj[4];
-    float bj[4], sj[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {           // four entries' broadcast reads in flight together
-      const int j = min(w + 4 * (g + u), nbm - 1);
-      ex[u] = exist[j]; chj[u] = C.ch[j]; bj[u] = C.b[j]; sj[u] = C.score[j];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = w + 4 * (g + u);
-      u64 key = ~0ull;
-      if (j < nbm && cand && !((ex[u] >> k) & 1ull)) {
-        const float lp = c == chj[u] ? (bj[u] > kNegInf ? clp + bj[u] : kNegInf) : clp + sj[u];
+  for (int g = 0; g < JPT; ++g) {
+    const int j = w + 4 * g;
+    u64 key = ~0ull;
+    if (j < nbm) {                          // wave-uniform
+      const u64 ex = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(ex_l >> 32), g) << 32) | (unsigned)__builtin_amdgcn_readlane((int)ex_l, g);
+      const int chj = __builtin_amdgcn_readlane(ch_l, g);
+      const float bj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), g));
+      const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s_l), g));
+      if (cand && !((ex >> k) & 1ull)) {
+        const float lp = c == chj ? (bj > kNegInf ? clp + bj : kNegInf) : clp + sj;
         key = make_key(lp, c, nbm + j * nc + k);
         counts += 1 + (((unsigned)(key >> 32) != kNegHi) << 16);
         kmin = key < kmin ? key : kmin;
       }
-      ck[g + u] = key;
     }
+    ck[g] = key;
   }
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -311,8 +371,8 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
   if (tid < newn) {
     const u64 key = sh.keys[tid];
     const int j = sh.kept_j[tid];
-    if (j < 0) keep_entry(sh, C, Nx, -1 - j, tid);
-    else keep_child(C, Nx, arena, 1 + t * beam + tid, j, (int)((key >> 16) & 0xffff) - 1, key_score(key), tid);
+    if (j < 0) keep_entry(sh, C, Nx, L, -1 - j, tid);
+    else keep_child(C, Nx, L, arena, 1 + t * beam + tid, j, (int)((key >> 16) & 0xffff) - 1, key_score(key), tid);
   }
   __syncthreads();
   if (profiling) rp.install += clock64() - c0;
@@ -329,21 +389,28 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
 template <bool SMALL>
 __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   __shared__ Shared sh;
+  extern __shared__ __align__(16) unsigned char class_tab[];     // [frame parity][tab_stride(V)]
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int T = a.T, N = a.N, V = a.V, beam = a.beam;
+  const int vstride = tab_stride(V);
+  for (int i = tid; i < 2 * vstride / 16; i += NT) reinterpret_cast<int4*>(class_tab)[i] = make_int4(0, 0, 0, 0);
+  for (int i = tid; i < 2 * HASH / 4; i += NT) reinterpret_cast<int4*>(sh.hpos)[i] = make_int4(0, 0, 0, 0);
+  if (tid < 2) sh.cands[tid].n = 0;
   const int frames = a.in_len ? max(0, min(a.in_len[b], T)) : T;
   int2* arena = a.arena + (size_t)b * ((size_t)T * beam + 1);
   int cur = 0, nbm = 1;                     // current beam buffer, number of entries
   if (tid == 0) {
     Beam& B0 = sh.beams[0];
-    B0.id[0] = 1; B0.par[0] = 0; B0.ch[0] = -1; B0.arena[0] = 0;
+    B0.id[0] = 1; B0.par[0] = 0; B0.ch[0] = -1; B0.arena[0] = 0; B0.kc[0] = -1;
     B0.score[0] = 0.f; B0.b[0] = 0.f; B0.nb[0] = kNegInf;
     arena[0] = make_int2(-1, -1);
   }
   long long p_entries = 0, p_keys = 0, p_keep = 0, p_radix = 0, p_redone = 0;
   RadixProf rprof = {0, 0, 0};
   const bool profiling = a.prof != nullptr && b == 0 && tid == 0;
+  const bool profiling3 = a.prof != nullptr && b == 0 && tid == NT - 64;   // wave 3's share of the entry phase
+  long long p_own = 0, p_scan = 0, p_prep = 0, p_cum = 0;
 
   // wave 3 holds the top-n list of the frame it prepares next in registers (lane k = position k); the list of the frame
   // after that is requested as soon as this one is consumed, so no global load sits on the per-frame path
@@ -356,21 +423,37 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   }
   auto prepare = [&](int tt) {              // wave 3 only: candidates of frame tt into cands[tt & 1]
     Cands& K = sh.cands[tt & 1];
-    double cum = 0.0;
-    int n = 0;
-    bool open = true;
-    for (int i = 0; i < N; ++i) {
-      const float pi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_nx), i));
-      if (open) {
-        cum += (double)pi;
-        ++n;
-        if (cum >= a.cutoff_prob || n >= a.cutoff_top_n) open = false;
+    unsigned char* tab = class_tab + (tt & 1) * vstride;
+    long long q0 = 0;
+    if (profiling3) q0 = clock64();
+    if (pl < K.n) tab[K.c[pl]] = 0;         // the list of frame tt - 2
+    // number of candidates = 1 + the first position whose running sum (in doubles, position order:
+    // ctc_beam_search_decoder.cpp:44-55) reaches cutoff_prob, capped by cutoff_top_n.  The sums come from a wave scan;
+    // its association differs from the reference's left-to-right loop by a few ulps, so when any sum lies within 1e-9
+    // of the threshold the loop below decides instead.
+    int n;
+    {
+      const double ps = wave_prefix_sum((double)p_nx);             // lanes >= N hold 0
+      const double gap = ps - (double)a.cutoff_prob;
+      const u64 reach = __ballot(pl < N && gap >= 0.0);
+      const u64 close = __ballot(pl < N && fabs(gap) <= 1e-9);
+      n = reach ? (int)__builtin_ctzll(reach) + 1 : N;
+      if (close) {
+        double cum = 0.0;
+        n = N;
+        for (int i = 0; i < N; ++i) {
+          cum += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_nx), i));
+          if (cum >= a.cutoff_prob) { n = i + 1; break; }
+        }
       }
+      n = max(1, min(n, a.cutoff_top_n));
     }
     const bool mine = pl < n;
+    if (profiling3) p_cum += clock64() - q0;
     if (mine) {
+      tab[c_nx] = (unsigned char)(pl + 1);
       K.c[pl] = c_nx;
-      K.lp[pl] = (float)log((double)p_nx + (double)FLT_MIN);
+      K.lp[pl] = (float)log_pos((double)p_nx + (double)FLT_MIN);
     }
     const u64 bm = __ballot(mine && c_nx == V - 1);
     if (pl == 0) {
@@ -382,7 +465,10 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
       p_nx = a.top_p[fn];
       c_nx = a.top_idx[fn];
     }
+    if (profiling3) p_prep += clock64() - q0;
   };
+  __syncthreads();                          // the cleared tables, K.n = 0
+  if (tid == 0) sh.hpos[0][1 & (HASH - 1)] = 1;      // the root's id is 1
   if (pl >= 0 && frames > 0) prepare(0);
   sh.hist[0][tid] = 0;
   sh.hist[1][tid] = 0;
@@ -401,6 +487,8 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     // ---- 1. (wave 3) the next frame's candidates
     if (pl >= 0 && t + 1 < frames) prepare(t + 1);
     if (tid < BMAX) sh.exist_mask[(t + 1) & 1][tid] = 0;
+    reinterpret_cast<int4*>(sh.hpos[cur ^ 1])[tid] = make_int4(0, 0, 0, 0);   // HASH = 4 NT cells
+    const Lookup L = {class_tab + ((t + 1) & 1) * vstride, sh.hpos[cur ^ 1]};
     if (!SMALL && tid == 0) sh.kmin[(t + 1) & 1] = ~0ull;   // select_radix's best key, per frame parity
     if (SMALL && (tid >> 6) == 2) {         // wave 2: the best entry score, for the acceptance test of the small path
       float best = kNegInf;
@@ -412,38 +500,15 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     // ---- 2. existing entries: blank update, repetition, extension by the parent if that is in the beam
     if (tid < nbm) {
       const int i = tid;
-      const int ci = C.ch[i];
+      const int kc = C.kc[i];
+      const u64 pid = C.par[i];
+      const float nb_i = C.nb[i];
       const float bc = kb >= 0 ? K.lp[kb] + C.score[i] : kNegInf;  // log_sum_exp(-inf, x) = x
       float nbc = kNegInf;
-      // position of the entry's own character among the candidates: all NMAX classes are fetched at once (a loop of
-      // dependent LDS reads would cost a latency each)
-      int kc = -1;
-      {
-        int4 cc[NMAX / 4];
-#pragma unroll
-        for (int q = 0; q < NMAX / 4; ++q) cc[q] = reinterpret_cast<const int4*>(K.c)[q];
-#pragma unroll
-        for (int q = 0; q < NMAX / 4; ++q) {
-          if (cc[q].x == ci && 4 * q + 0 < nc) kc = 4 * q + 0;
-          if (cc[q].y == ci && 4 * q + 1 < nc) kc = 4 * q + 1;
-          if (cc[q].z == ci && 4 * q + 2 < nc) kc = 4 * q + 2;
-          if (cc[q].w == ci && 4 * q + 3 < nc) kc = 4 * q + 3;
-        }
-      }
       if (kc >= 0) {
-        nbc = K.lp[kc] + C.nb[i];
-        const u64 pid = C.par[i];
-        int j = -1;
-        for (int j0 = 0; j0 < nbm; j0 += 16) {
-          ulonglong2 ii[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) ii[q] = reinterpret_cast<const ulonglong2*>(C.id + j0)[q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if (ii[q].x == pid && j0 + 2 * q < nbm) j = j0 + 2 * q;
-            if (ii[q].y == pid && j0 + 2 * q + 1 < nbm) j = j0 + 2 * q + 1;
-          }
-        }
+        nbc = K.lp[kc] + nb_i;
+        const int j = hash_find(sh.hpos[cur], C, nbm, pid);
+        if (profiling) p_scan += clock64() - t0;
         if (j >= 0) {
           nbc = lse(nbc, child_lp(C, K, j, kc));
           atomicOr(&exist[j], 1ull << kc);
@@ -453,6 +518,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
       sh.cnb[i] = nbc;
       sh.cscore[i] = lse(bc, nbc);
     }
+    if (profiling) p_own += clock64() - t0;
     __syncthreads();
     long long t1 = 0;
     if (profiling) { t1 = clock64(); p_entries += t1 - t0; }
@@ -475,11 +541,16 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
         lp = sh.cscore[slot];
         key = make_key(lp, C.ch[slot], slot);
       } else if (slot < S) {
-        j = (slot - nbm) / ncap;
+        // (slot - nbm) / ncap without the integer-division sequence: (x + 0.5) / n is at least 0.5 / n away from an integer
+        j = (int)(((float)(slot - nbm) + 0.5f) * __builtin_amdgcn_rcpf((float)ncap));
         k = (slot - nbm) - j * ncap;
-        if (k != kb && !((exist[j] >> k) & 1ull)) {
-          lp = child_lp(C, K, j, k);
-          key = make_key(lp, K.c[k], slot);
+        // every operand is requested before any is looked at: one LDS latency instead of three
+        const u64 ex = exist[j];
+        const int c = K.c[k], cj = C.ch[j];
+        const float lk = K.lp[k], bj = C.b[j], sj = C.score[j];
+        if (k != kb && !((ex >> k) & 1ull)) {
+          lp = c == cj ? (bj > kNegInf ? lk + bj : kNegInf) : lk + sj;    // child_lp
+          key = make_key(lp, c, slot);
         }
       }
       if (half == 0) sh.keys[slot] = key;
@@ -501,8 +572,8 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
       long long t2 = 0;
       if (profiling) { t2 = clock64(); p_keys += t2 - t1; }
       if (keep) {
-        if (slot < nbm) keep_entry(sh, C, Nx, slot, rank);
-        else keep_child(C, Nx, arena, 1 + t * beam + rank, j, K.c[k], lp, rank);
+        if (slot < nbm) keep_entry(sh, C, Nx, L, slot, rank);
+        else keep_child(C, Nx, L, arena, 1 + t * beam + rank, j, K.c[k], lp, rank);
         if (rank == beam - 1 && ncap < nc && lp > K.lp[ncap] + sh.max_score) sh.thr_ok = 1;
       }
       newn = __syncthreads_count(keep);
@@ -516,7 +587,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
         if (tid == 0) sh.kmin[t & 1] = ~0ull;
         __syncthreads();
       }
-      newn = select_radix<SMALL ? SMALL_BEAM / 4 : BMAX / 4>(sh, C, Nx, K, exist, nbm, beam, t, arena, profiling, rprof);
+      newn = select_radix<SMALL ? SMALL_BEAM / 4 : BMAX / 4>(sh, C, Nx, K, exist, nbm, beam, t, arena, L, profiling, rprof);
       if (profiling) p_radix += clock64() - t3;
     }
     cur ^= 1;
@@ -525,7 +596,9 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   if (profiling) {
     a.prof[0] = p_entries; a.prof[1] = p_keys; a.prof[2] = p_keep; a.prof[3] = p_radix; a.prof[4] = p_redone;
     a.prof[5] = rprof.keys; a.prof[6] = rprof.select; a.prof[7] = rprof.install; a.prof[8] = frames;
+    a.prof[9] = p_own; a.prof[10] = p_scan;
   }
+  if (profiling3) { a.prof[11] = p_prep; a.prof[12] = p_cum; }
 
   // ---- finish: rank by prefix_compare (+ slot), read the paths back
   const Beam& C = sh.beams[cur];
@@ -572,7 +645,7 @@ size_t mi355asr_beam_device_carve(char* ws, int B, int T, int beam, int max_len,
   char* scores = seg((size_t)B * beam * sizeof(float));
   char* n_hyp = seg((size_t)B * sizeof(int32_t));
   char* len = seg((size_t)B * sizeof(int32_t));
-  char* pr = seg(9 * sizeof(long long));
+  char* pr = seg(16 * sizeof(long long));
   if (a) { a->arena = (int2*)arena; a->ids = (int32_t*)ids; a->lens = (int32_t*)lens; a->scores = (float*)scores; a->n_hyp = (int32_t*)n_hyp; }
   if (d_len) *d_len = (int32_t*)len;
   if (prof) *prof = (long long*)pr;
@@ -584,8 +657,14 @@ size_t mi355asr_beam_device_ws_bytes(int B, int T, int beam, int max_len) {
 
 int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s) {
   const bool small = a->beam <= SMALL_BEAM && a->beam * (std::min(a->N, a->beam + 2) + 1) <= NT;
-  if (small) hipLaunchKernelGGL(beam_search_kernel<true>, dim3(a->B), dim3(NT), 0, s, *a);
-  else hipLaunchKernelGGL(beam_search_kernel<false>, dim3(a->B), dim3(NT), 0, s, *a);
+  const int dyn = 2 * tab_stride(a->V);     // the class tables
+  // V <= 65534 (mi355asr_beam_device_applicable): at most 131 072 + 21 520 bytes of the CU's 163 840
+  static const bool allowed =
+      hipFuncSetAttribute((const void*)beam_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(65534)) == hipSuccess &&
+      hipFuncSetAttribute((const void*)beam_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(65534)) == hipSuccess;
+  if (!allowed) return -2;
+  if (small) hipLaunchKernelGGL(beam_search_kernel<true>, dim3(a->B), dim3(NT), dyn, s, *a);
+  else hipLaunchKernelGGL(beam_search_kernel<false>, dim3(a->B), dim3(NT), dyn, s, *a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -783,5 +783,18 @@ def test_log_sum_exp_kernels_of_the_device_beam_search_round_like_libm():
     y0 = (hw.astype(np.float32) * np.float32(0.69314718)).astype(np.float64)
     k, q = expm1_reduced(-y0)
     A = np.ldexp(s.astype(np.float64), k.astype(int))
-    y1 = y0 + ((A - 1.0) + A * q)
+    e1 = (A - 1.0) + A * q
+    y1 = y0 + (e1 - 0.5 * e1 * e1)
     assert np.array_equal(y1.astype(np.float32), np.log(s.astype(np.float64)).astype(np.float32))
+    # log_pos: the candidates' log(p + FLT_MIN) in double, over the whole range of float probabilities
+    p32 = np.concatenate([np.exp(rng.uniform(np.log(1.2e-38), 0, 1_500_000)), rng.uniform(0, 1, 500_000)]).astype(np.float32)
+    x = p32.astype(np.float64) + float(np.finfo(np.float32).tiny)
+    hw = np.log2(x.astype(np.float32).astype(np.float64)) * (1 + rng.uniform(-1.2e-7, 1.2e-7, x.size))
+    y0 = hw.astype(np.float32).astype(np.float64) * 0.6931471805599453094
+    k, q = expm1_reduced(-y0)
+    A = np.ldexp(x, k.astype(int))
+    e1 = (A - 1.0) + A * q
+    y = y0 + (e1 - 0.5 * e1 * e1)
+    ref = np.log(x)
+    assert np.max(np.abs(y - ref) / np.maximum(np.abs(ref), 1e-300)) < 7e-16    # three ulps of a double
+    assert np.array_equal(y.astype(np.float32), ref.astype(np.float32))
