@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -393,6 +394,126 @@ __global__ __launch_bounds__(64) void topn_kernel(const float* __restrict__ x, i
   }
 }
 
+
+// The same selection with the frame's row in REGISTERS (V <= 64 NR): lane l holds classes l, l + 64, ... -- the order the
+// LDS kernel's soft-max sum walks them in, so the denominators are bit-identical.  No staging pass, no 36 KB of LDS per
+// wave (four waves per CU, each alone on its SIMD: 0.96 TB/s at V = 9 160), ~1 700 instructions per frame instead of three
+// latency-bound sweeps over LDS.  More than GT_CAP classes above T0 (adversarial rows) are finished by rounds over the
+// registers.
+template <int NR>
+__global__ __launch_bounds__(64) void topn_reg_kernel(const float* __restrict__ x, int V, int N, int is_logits,
+                                                      int32_t* __restrict__ out_idx, float* __restrict__ out_p) {
+  __shared__ float cv[GT_CAP + EQ_CAP];
+  __shared__ int ci[GT_CAP + EQ_CAP];
+  const int lane = threadIdx.x;
+  const size_t frame = blockIdx.x;
+  const float* row = x + frame * V;
+  out_idx += frame * N;
+  out_p += frame * N;
+  // The row through buffer loads: one offset register for all NR requests (per-request 64-bit addresses would double the
+  // register count), reads past the row return 0 and are turned into -inf.  Classes >= V are then never above T0 and
+  // come behind every real class in class order -- with V >= 64 >= N (the launch checks) they are never selected, so
+  // nothing below needs an `i < V` test.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, V * 4, 0x00020000);
+  float v[NR];
+#pragma unroll
+  for (int m = 0; m < NR; ++m) v[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, m * 256, 0));
+  const int vfull = V >> 6;                 // registers every lane of which holds a class
+#pragma unroll
+  for (int m = 0; m < NR; ++m)
+    if (m >= vfull && lane + 64 * m >= V) v[m] = -INFINITY;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int m = 0; m < NR; ++m) mx = fmaxf(mx, v[m]);
+  const float lane_max = mx;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float denom = 1.f;
+  if (is_logits) {
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < NR; ++m) s += __expf(v[m] - mx);        // + 0 for the padding: the LDS kernel's sum, bit for bit
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
+    denom = s;
+  }
+  int rank = 0;
+#pragma unroll
+  for (int l = 0; l < 64; ++l) {
+    const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_max), l));
+    rank += (o > lane_max) || (o == lane_max && l < lane);
+  }
+  const unsigned long long pick = __ballot(rank == N - 1);
+  const float T0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_max), (int)__builtin_ctzll(pick)));
+  const unsigned long long lt = (1ull << lane) - 1;
+  int G = 0, E = 0;
+#pragma unroll
+  for (int m = 0; m < NR; ++m) {
+    const bool gt = v[m] > T0, eq = v[m] == T0;
+    const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+    if ((bg | be) == 0) continue;
+    int lane_here = lane;                   // opaque: NR class numbers computed ahead of the branches would cost NR registers
+    asm volatile("" : "+v"(lane_here));
+    const int i = lane_here + 64 * m;
+    const int pg = G + __popcll(bg & lt), pe = E + __popcll(be & lt);
+    if (gt && pg < GT_CAP) { cv[pg] = v[m]; ci[pg] = i; }
+    if (eq && pe < EQ_CAP) { cv[GT_CAP + pe] = v[m]; ci[GT_CAP + pe] = i; }
+    G += __popcll(bg);
+    E = min(E + __popcll(be), EQ_CAP);
+  }
+  if (G > GT_CAP) {                         // rounds of (lane arg-max, wave arg-max with lowest-class tie break, knock-out)
+    for (int n = 0; n < N; ++n) {
+      float best = -INFINITY;
+      int bm = -1;                          // register of the lane's best (no per-register class numbers kept live)
+#pragma unroll
+      for (int m = 0; m < NR; ++m)
+        if (v[m] > best) { best = v[m]; bm = m; }
+      int bi = bm >= 0 ? lane + 64 * bm : 0x7fffffff;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (lane == 0) {
+        out_idx[n] = bi;
+        out_p[n] = is_logits ? __expf(best - mx) / denom : best;
+      }
+      const int km = __builtin_amdgcn_readfirstlane(bi >> 6);
+      const bool me = (bi & 63) == lane;
+#pragma unroll
+      for (int m = 0; m < NR; ++m)
+        if (m == km && me) v[m] = -INFINITY;
+    }
+    return;
+  }
+  const int Eu = min(E, N);
+  const int M = G + Eu;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    const int m = m0 + lane;
+    const int slot = m < G ? m : GT_CAP + (m - G);
+    const float val = m < M ? cv[slot] : 0.f;
+    const int id = m < M ? ci[slot] : 0;
+    int before = 0;
+#pragma unroll 8
+    for (int q = 0; q < G; ++q) {
+      const float ov = cv[q];
+      const int oi = ci[q];
+      before += (ov > val) || (ov == val && oi < id);
+    }
+#pragma unroll 8
+    for (int q = 0; q < Eu; ++q) {
+      const float ov = cv[GT_CAP + q];
+      const int oi = ci[GT_CAP + q];
+      before += (ov > val) || (ov == val && oi < id);
+    }
+    if (m < M && before < N) {
+      out_idx[before] = id;
+      out_p[before] = is_logits ? __expf(val - mx) / denom : val;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -437,6 +558,17 @@ int mi355asr_beam_topn_impl(const int32_t* top_idx, const float* top_p, const in
 
 int mi355asr_launch_topn(const float* x_dev, int frames, int V, int N, int is_logits, int32_t* idx_dev, float* p_dev,
                          hipStream_t s) {
+  static const bool reg_off = [] { const char* e = getenv("MI355ASR_TOPN_REG"); return e && atoi(e) == 0; }();
+  if (N <= 64 && V >= 64 && V <= 64 * 144 && !reg_off) {
+    const int nr = (V + 63) / 64;
+#define TOPN_REG(NR) hipLaunchKernelGGL(topn_reg_kernel<NR>, dim3(frames), dim3(64), 0, s, x_dev, V, N, is_logits, idx_dev, p_dev)
+    if (nr <= 24) TOPN_REG(24);
+    else if (nr <= 64) TOPN_REG(64);
+    else if (nr <= 96) TOPN_REG(96);
+    else TOPN_REG(144);
+#undef TOPN_REG
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   const size_t lds = (size_t)V * sizeof(float);
   if (lds > 160 * 1024) return -1;
   if (lds > 64 * 1024) {

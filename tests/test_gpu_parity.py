@@ -436,6 +436,29 @@ def test_prefix_beam_topn_ties_and_zero_rows(torch_cuda):
             assert np.array_equal(d[0], h[0]) and np.array_equal(d[2], h[2])
 
 
+def test_prefix_beam_topn_when_few_lanes_hold_all_the_large_classes(torch_cuda):
+    """The selection kernels' threshold T0 is the cutoff_top_n-th largest LANE maximum (classes are dealt to 64 lanes
+    round-robin).  Rows whose large values all sit in classes = l mod 64 for a few l put hundreds of classes above T0:
+    more than the kernels' candidate list holds, so the rounds path (arg-max, knock-out) has to produce the same list --
+    in the register-resident kernel (V <= 9 216) and in the LDS kernel (V above)."""
+    torch = torch_cuda
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    rng = np.random.default_rng(78)
+    for V in (1332, 9160, 9300):
+        B, T = 2, 12
+        p = (rng.random((B, T, V)).astype(np.float32) * 1e-4 + 1e-6)
+        cls = np.arange(V)
+        hot = (cls % 64) < 20                                  # 20 lanes own every large class: > 256 of them
+        p[:, :, hot] = rng.random((B, T, int(hot.sum()))).astype(np.float32) + 0.5
+        p[1] = np.where(hot[None, :], np.round(p[1] * 8) / 8, p[1])   # and ties among them
+        p /= p.sum(-1, keepdims=True)
+        for top_n in (40, 25):
+            d = ctc_prefix_beam_decode(torch.from_numpy(p).cuda(), None, 1, 0.9999, top_n)
+            h = ctc_prefix_beam_decode(p, None, 1, 0.9999, top_n)
+            assert np.array_equal(d[3], h[3]) and np.array_equal(d[1], h[1])
+            assert np.array_equal(d[0], h[0]) and np.array_equal(d[2], h[2])
+
+
 @pytest.mark.parametrize("beam", [1, 4, 10, 14, 15, 40, 100])
 def test_prefix_beam_device_search_equals_host_search(torch_cuda, beam):
     """The device search (beam_device.hip: one-key-per-thread path up to beam 14, radix path above, and the radix
