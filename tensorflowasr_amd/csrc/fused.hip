@@ -1119,9 +1119,14 @@ __global__ __launch_bounds__(LD_THREADS) void out_glu_ld_kernel(OutGluArgs a) {
 // gemm_rows_kernel<HEAD> it replaces ran 66-72 us (91 TFLOP/s); this is G x 5 slabs of the same stream design.
 // slabs: append_slabs(W padded to 144 G columns, group_major) -- group g = column tiles 9 g .. 9 g + 8, five steps each.
 // ---------------------------------------------------------------------------------------------------------
+// The bias of the next group is requested BEFORE the current group's logits are stored: loads and stores retire through
+// one in-order counter, and a bias request behind nine stores waited for all of them (415 -> 330 us at 12 000 frames x
+// 9 160 classes; what remains is the slab stream, 1.66 GB from L2 into LDS -- splitting the classes over workgroups to
+// fill the 68 idle CUs of a 188-workgroup launch changed nothing).
 __global__ __launch_bounds__(LD_THREADS) void head_ld_kernel(GemmArgs a, const u32x4_t* __restrict__ slabs, int groups) {
   __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g_begin = 0, g_end = groups;
   if (wv >= WAVES_PER_BLOCK) {
     RingLoader<5>{ring, slabs, nullptr, KS32X * groups, KS32X * groups, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
     return;
@@ -1139,17 +1144,26 @@ __global__ __launch_bounds__(LD_THREADS) void head_ld_kernel(GemmArgs a, const u
   grp_prime(wg, st.cur_addr());
   float best_v = -INFINITY;
   int best_i = 0;
+  const bool want_max = a.argmax_out != nullptr || a.maxval_out != nullptr;
+  auto bias_of = [&](int g, int i) { return KB * g + i < a.NT ? ldg4(a.bias + 16 * (KB * g + i) + c.g4) : splat4(0.f); };
+  f32x4 nb[KB];                               // the next group's bias
+#pragma unroll
+  for (int i = 0; i < KB; ++i) nb[i] = bias_of(g_begin, i);
 #pragma unroll 1
-  for (int g = 0; g < groups; ++g) {
-    // the group's bias rides in the accumulators: requested before the slabs, landed long before the epilogue reads it
+  for (int g = g_begin; g < g_end; ++g) {
+    // the group's bias rides in the accumulators
     f32x4 acc[KB];
 #pragma unroll
-    for (int i = 0; i < KB; ++i) acc[i] = KB * g + i < a.NT ? ldg4(a.bias + 16 * (KB * g + i) + c.g4) : splat4(0.f);
+    for (int i = 0; i < KB; ++i) acc[i] = nb[i];
     static_for<0, KS32X>([&](auto T) {
       constexpr int t = decltype(T)::value;
       slab_step_p(acc, xf[t], wg, st.cur_addr(), st.next_addr());
       st.advance();
     });
+    if (g + 1 < g_end) {
+#pragma unroll
+      for (int i = 0; i < KB; ++i) nb[i] = bias_of(g + 1, i);
+    }
     const WaveCtx e = wave_ctx_fresh(a.M);
     float* yrow = a.y ? a.y + (size_t)e.tok * a.ldy : nullptr;
 #pragma unroll
@@ -1158,9 +1172,11 @@ __global__ __launch_bounds__(LD_THREADS) void head_ld_kernel(GemmArgs a, const u
       if (tile < a.NT) {                         // wave-uniform: the bias holds NT tiles; the rest are padding columns
         const f32x4 v = acc[i];
         const float vv[4] = {v.x, v.y, v.z, v.w};
+        if (want_max) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (f0 + j < a.n_valid && vv[j] > best_v) { best_v = vv[j]; best_i = f0 + j; }
+          for (int j = 0; j < 4; ++j)
+            if (f0 + j < a.n_valid && vv[j] > best_v) { best_v = vv[j]; best_i = f0 + j; }
+        }
         if (yrow && e.live) {
           if (f0 + 3 < a.n_valid && (a.ldy & 3) == 0) stg4(yrow + f0, v);
           else
@@ -1170,6 +1186,7 @@ __global__ __launch_bounds__(LD_THREADS) void head_ld_kernel(GemmArgs a, const u
       }
     }
   }
+  if (!want_max) return;
   // the four lane groups of a token hold disjoint classes: max over the groups, lowest class on ties
 #pragma unroll
   for (int off = 16; off < 64; off <<= 1) {

@@ -918,9 +918,9 @@ class ChunkConformer(_ModelBase):
         _lib.check(h.lib.mi355asr_chunk_workspace_bytes(h.ptr, B, L, ctypes.byref(n)))
         ws = h.workspace(n.value)
         dev = h.device
-        bufs = {"text_logits": torch.empty((B, T, V), dtype=torch.float32, device=dev),
-                "text_argmax": torch.empty((B, T), dtype=torch.int32, device=dev)}
-        if stages:
+        bufs = {"text_logits": torch.empty((B, T, V), dtype=torch.float32, device=dev)}
+        if stages:                           # logits alone let the class head split its columns over workgroups
+            bufs["text_argmax"] = torch.empty((B, T), dtype=torch.int32, device=dev)
             for k in ("front_out", "enc_out", "picker_hidden", "picked", "helper_out"):
                 bufs[k] = torch.empty((B, T, d), dtype=torch.float32, device=dev)
             bufs["picker_logits"] = torch.empty((B, T, self.phone_num_classes), dtype=torch.float32, device=dev)
