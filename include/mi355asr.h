@@ -103,6 +103,11 @@ int mi355asr_weight_shape(const mi355asr_model* m, int32_t i, int32_t* rank, int
 /* replaces: model._build() (test_asr.py:85-87): checks every tensor is present, packs the matrices into
  * MFMA fragment order, folds BatchNorm into (scale, shift), uploads to HBM. */
 int mi355asr_finalize_weights(mi355asr_model* m, void* stream);
+/* optional, before mi355asr_finalize_weights: the most rows (batch x encoder frames) one call will bring.  Handles of
+ * dmodel 256 / 512 pack every dense layer a second time as a split-bf16 slab ring for batches of >= 1500 rows (1.5 x the
+ * dense weights' bytes, and their packing time); a handle that will only see single utterances or streaming chunks says
+ * so here and keeps the per-wave kernels (and, at dmodel 256, the fused chains).  rows < 0 = unknown (the default: pack). */
+int mi355asr_set_expected_rows(mi355asr_model* m, int64_t rows);
 /* which STFT kernel mi355asr_finalize_weights selected: 1 = 32x32 Cooley-Tukey on the matrix cores (the loaded
  * mel_layer/{real,imag}_kernels are window[n]*exp(-2*pi*i*k*n/1024), as backend.py:27-69 builds them), 0 = dense DFT
  * GEMM with the kernels as loaded (a checkpoint changed them), -1 = no frontend / not finalized. */

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mi355asr_weight_name": (ctypes.c_char_p, [_P, _I]),
     "mi355asr_weight_shape": (ctypes.c_int, [_P, _I, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64), _I]),
     "mi355asr_finalize_weights": (ctypes.c_int, [_P, _P]),
+    "mi355asr_set_expected_rows": (ctypes.c_int, [_P, ctypes.c_int64]),
     "mi355asr_out_frames": (ctypes.c_int, [_P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "mi355asr_workspace_bytes": (ctypes.c_int, [_P, _I, _I, ctypes.POINTER(_SZ)]),
     "mi355asr_ctc_workspace_bytes": (ctypes.c_int, [_P, _I, _I, ctypes.POINTER(_SZ)]),

@@ -325,9 +325,14 @@ void put_ring_head(ArenaBuilder& ab, size_t p16_off, const std::function<float(i
 }
 // MI355ASR_GEMM_RING=0: the dense layers of dmodel 256 / 512 stay on the fp32-MFMA kernels (chain2 / gemm16<PF32>), or
 // in bf16 mode on gemm16<PBf16>
+// rows from which launch_gemm16 hands a dense layer to the ring kernels (crossover measured below)
+long ring_min_rows() {
+  static const long v = [] { const char* e = getenv("MI355ASR_RING_MIN_M"); return e ? atol(e) : 1500L; }();
+  return v;
+}
 bool ring_packs_wanted(const mi355asr_model* m) {
   static const bool on = [] { const char* v = getenv("MI355ASR_GEMM_RING"); return v ? atoi(v) != 0 : true; }();
-  return on && m->cfg.dmodel % 128 == 0;
+  return on && m->cfg.dmodel % 128 == 0 && (m->expected_rows < 0 || m->expected_rows >= ring_min_rows());
 }
 void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base) {
   for (const auto& pr : ab.ring_pairs) m->ring_of[base + pr.first] = base + pr.second;
@@ -574,8 +579,7 @@ int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, cons
   // (gemm_ring.hip): fp32 operands exactly split into three bf16 terms, or one bf16 term in bf16 mode
   // crossover measured with 10 s utterances (tools/model_batch_sweep.py; ms per batch, ring vs per-wave streams):
   // ConformerM B = 4: 3.81 vs 3.10, 8: 4.09 vs 4.26, 16: 4.47 vs 5.19; ConformerL 4: 6.95 vs 6.57, 8: 7.59 vs 9.63, 16: 10.3 vs 18.5
-  static const long ring_min_m = [] { const char* v = getenv("MI355ASR_RING_MIN_M"); return v ? atol(v) : 1500L; }();
-  if ((long)g.M >= ring_min_m && !m->ring_of.empty()) {
+  if ((long)g.M >= ring_min_rows() && !m->ring_of.empty()) {
     const auto it = m->ring_of.find(wp);
     g.wp = wp;
     if (it != m->ring_of.end() && launch_gemm_ring(epi, ln, g, it->second, m->cfg.gemm_dtype == 1 ? 1 : 3, s) == 0) return 0;
@@ -1269,6 +1273,13 @@ int mi355asr_destroy(mi355asr_model* m) {
   if (m->arena) (void)hipFree(m->arena);
   if (m->arena16) (void)hipFree(m->arena16);
   delete m;
+  return 0;
+}
+
+int mi355asr_set_expected_rows(mi355asr_model* m, int64_t rows) {
+  if (!m) return fail(MI355ASR_EINVAL, "null handle");
+  if (m->finalized) return fail(MI355ASR_ESTATE, "mi355asr_set_expected_rows must come before mi355asr_finalize_weights");
+  m->expected_rows = rows < 0 ? -1 : (long)std::min<int64_t>(rows, 1L << 40);
   return 0;
 }
 

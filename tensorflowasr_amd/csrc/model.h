@@ -104,6 +104,9 @@ struct mi355asr_model {
   const void* w16(const float* p) const { return arena16 + (p - arena); }
   // fp32 P16 pack -> split-bf16 slab ring of the same matrix (gemm_ring.hip; dmodel 256 / 512 dense layers)
   std::unordered_map<const float*, const float*> ring_of;
+  // mi355asr_set_expected_rows: the most rows (batch x frames) a call will bring, -1 = unknown.  Below the ring
+  // kernels' crossover the rings are not packed at all (they cost 1.5 x the dense weights' bytes and their packing time).
+  long expected_rows = -1;
   // dmodel 144: class-head P16 pack -> (slab stream of head_ld_kernel, column groups)
   std::unordered_map<const float*, std::pair<const float*, int>> head_of;
   const float *dft_wp = nullptr, *mel_wp = nullptr, *c1_w = nullptr, *c1_b = nullptr, *c2_wp = nullptr,

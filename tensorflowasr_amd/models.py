@@ -98,6 +98,11 @@ class _Handle:
             _lib.check(self.lib.mi355asr_load_weight_typed(self.ptr, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
                                                            dt, a.ndim, dims))
 
+    def set_expected_rows(self, rows):
+        """Before finalize(): the most rows (batch x encoder frames) a call will bring; below the ring kernels' crossover
+        (1 500) the dmodel-256 / 512 dense layers are not packed a second time as slab rings.  None / negative = unknown."""
+        _lib.check(self.lib.mi355asr_set_expected_rows(self.ptr, -1 if rows is None else int(rows)))
+
     def finalize(self):
         if self.device.type != "cuda":
             raise _lib.Mi355AsrError("mi355asr needs a ROCm device (got %s); there is no CPU path" % self.device)

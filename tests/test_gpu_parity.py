@@ -1104,6 +1104,27 @@ print("RESULT " + " ".join("%.3e" % v for v in res))
         assert max(errs) < TOL, (extra, errs)
 
 
+def test_expected_rows_hint_keeps_a_small_batch_handle_off_the_ring_packs(torch_cuda):
+    """mi355asr_set_expected_rows (before finalisation): a dmodel-256 handle that announces 300 rows packs no slab rings
+    and runs the fused fp32 chains -- same outputs within the oracle tolerance; the hint is refused once the weights are
+    finalised."""
+    from tensorflowasr_amd import _lib
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = small_cfg(2, co.CONFORMER_M)
+    w = co.encoder_weights(cfg, seed=43)
+    w.update(co.ctc_decoder_weights(cfg, 120, seed=44))
+    m = ConformerCTC(120, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+    m._h.set_expected_rows(300)
+    m.load_weights(w, by_name=False)
+    x = waves(2, 24000, 29)
+    enc_ref = co.conformer_encoder(x.astype(np.float64), w, cfg)
+    enc = m.encode(x)
+    assert maxdiff(enc.cpu().numpy(), enc_ref) < TOL
+    assert maxdiff(m.ctc_logits(enc).cpu().numpy(), co.ctc_decoder(enc_ref, w, cfg)) < TOL
+    with pytest.raises(_lib.Mi355AsrError):
+        m._h.set_expected_rows(5000)
+
+
 def test_ring_gemm_bf16_mode_in_a_subprocess(torch_cuda):
     """bf16 mode (BASELINE config 3) through gemm_ring.hip's one-term ring, forced for a small batch: one ConformerBlock
     of the streaming configuration (dmodel 256) on an exact fp32 input against the oracle with both GEMM operands rounded
