@@ -634,7 +634,11 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
 
 extern "C" {
 
-bool mi355asr_beam_device_applicable(int V, int N, int beam) { return beam >= 1 && beam <= BMAX && N >= 1 && N <= NMAX && V <= 65534; }
+// the class tables (2 V bytes of dynamic LDS) sit next to the kernel's static LDS in the CU's 160 KB
+constexpr int kLdsBytes = 160 * 1024;
+constexpr int kMaxClasses = std::min(65534, ((kLdsBytes - (int)sizeof(Shared) - 512) / 2) & ~15);
+static_assert(kMaxClasses >= 32768, "the static LDS of the search left too little for the class tables");
+bool mi355asr_beam_device_applicable(int V, int N, int beam) { return beam >= 1 && beam <= BMAX && N >= 1 && N <= NMAX && V <= kMaxClasses; }
 
 size_t mi355asr_beam_device_carve(char* ws, int B, int T, int beam, int max_len, BeamDeviceArgs* a, int32_t** d_len, long long** prof) {
   size_t off = 0;
@@ -658,10 +662,10 @@ size_t mi355asr_beam_device_ws_bytes(int B, int T, int beam, int max_len) {
 int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s) {
   const bool small = a->beam <= SMALL_BEAM && a->beam * (std::min(a->N, a->beam + 2) + 1) <= NT;
   const int dyn = 2 * tab_stride(a->V);     // the class tables
-  // V <= 65534 (mi355asr_beam_device_applicable): at most 131 072 + 21 520 bytes of the CU's 163 840
+  if (a->V > kMaxClasses) return -2;       // mi355asr_beam_device_applicable
   static const bool allowed =
-      hipFuncSetAttribute((const void*)beam_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(65534)) == hipSuccess &&
-      hipFuncSetAttribute((const void*)beam_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(65534)) == hipSuccess;
+      hipFuncSetAttribute((const void*)beam_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(kMaxClasses)) == hipSuccess &&
+      hipFuncSetAttribute((const void*)beam_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(kMaxClasses)) == hipSuccess;
   if (!allowed) return -2;
   if (small) hipLaunchKernelGGL(beam_search_kernel<true>, dim3(a->B), dim3(NT), dyn, s, *a);
   else hipLaunchKernelGGL(beam_search_kernel<false>, dim3(a->B), dim3(NT), dyn, s, *a);

@@ -1548,6 +1548,15 @@ int launch_head_ld(const GemmArgs& a, const float* slabs, int groups, hipStream_
   static const bool on = [] { const char* v = getenv("MI355ASR_HEAD_RING"); return v ? atoi(v) != 0 : true; }();
   if (!on || !slabs || groups < 1 || a.NT > KB * groups || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
+#ifdef MI355ASR_DIAG_KERNELS
+  static const bool nostore = [] { const char* v = getenv("MI355ASR_HEAD_NOSTORE"); return v && atoi(v) != 0; }();
+  if (nostore) {                            // timing only: what the logit stores cost
+    GemmArgs t = a;
+    t.y = nullptr;
+    hipLaunchKernelGGL(head_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, t, reinterpret_cast<const u32x4_t*>(slabs), groups);
+    return 0;
+  }
+#endif
   hipLaunchKernelGGL(head_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(slabs), groups);
   return 0;
 }
