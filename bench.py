@@ -31,11 +31,15 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 
 # Kernels that compute fp32 products as six bf16 MFMAs (operands split into three bf16 terms: subconv.hip, leaf.hip)
 # are priced against the dense bf16 MFMA peak (~2.5 PFLOP/s) / 6, in fp32-equivalent (algorithmic) FLOP/s.
 PEAK_SPLIT3_TFLOPS = 2500.0 / 6.0
+# two-term scheme: fp32 operands as hi + lo fp16 terms, three fp16 MFMAs per product (the fp16 dense peak is the bf16 one)
+PEAK_HALF2_TFLOPS = 2500.0 / 3.0
 
 
 def kernel_peak(name):
     if name == "subconv" and not int(os.environ.get("MI355ASR_SUBCONV_F32", "0") or 0) \
             and not int(os.environ.get("MI355ASR_SUBCONV_V1", "0") or 0):
+        if int(os.environ.get("MI355ASR_SUBCONV_TERMS", "2") or 2) != 3:
+            return PEAK_HALF2_TFLOPS, "fp16 MFMA x3 (fp32 operands as two fp16 terms)"
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     if name == "sublinear" and int(os.environ.get("MI355ASR_SUBLINEAR_SPLIT", "1") or 0):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
@@ -242,12 +246,12 @@ def extra_config3(lib, device, steps=20, with_cpu=True):
     for tag, prof, fl in (("enc", pe, fe), ("ctc", pc, fc)):
         for n, (ms_step, launches) in prof.items():
             f = fl.get(n, 0.0)
-            peak = PEAK_BF16_TFLOPS if n in dense else (PEAK_SPLIT3_TFLOPS if n == "subconv" else PEAK_FP32_MFMA_TFLOPS)
+            peak = PEAK_BF16_TFLOPS if n in dense else (kernel_peak("subconv")[0] if n == "subconv" else PEAK_FP32_MFMA_TFLOPS)
             kern[tag + "." + n] = {"launches_per_step": launches, "ms_per_step": round(ms_step, 4),
                                    "tflops": round(f / (ms_step * 1e-3) / 1e12, 2) if f else None,
                                    "frac_of_peak": round(f / (ms_step * 1e-3) / 1e12 / peak, 4) if f else None}
     dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
-    dpeak = PEAK_BF16_TFLOPS if dom.split(".")[1] in dense else (PEAK_SPLIT3_TFLOPS if dom.endswith("subconv") else PEAK_FP32_MFMA_TFLOPS)
+    dpeak = PEAK_BF16_TFLOPS if dom.split(".")[1] in dense else (kernel_peak("subconv")[0] if dom.endswith("subconv") else PEAK_FP32_MFMA_TFLOPS)
     out = {"workload": "StreamingConformerCTC 15M, batch=64 streaming chunks of 0.5 s, bf16 MFMA operands, global CTC over 10 s of history",
            "dtype": "bf16 (GEMM operands; f32 accumulate, LayerNorm, softmax, frontend)", "steps": steps,
            "ms_per_step": round(t * 1e3, 3), "chunks_per_s": round(B / t, 1), "frames_per_s": round(B * 50 / t, 1),

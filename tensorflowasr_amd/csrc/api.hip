@@ -160,6 +160,64 @@ std::vector<float> pack_conv2_split(const std::vector<float>& c2, int d) {
   std::memcpy(as_f.data(), frag.data(), frag.size() * 2);
   return as_f;
 }
+// round-to-nearest-even fp16 of a float (host side of the two-term scheme; subnormals and overflow to infinity included)
+uint16_t f16_rne(float v) {
+  uint32_t u; std::memcpy(&u, &v, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          // rounds to >= 65520: infinity
+  if (u < 0x38800000u) {                                             // below 2^-14: subnormal, spacing 2^-24
+    float f; std::memcpy(&f, &u, 4);
+    const float r = f * 16777216.0f;                                  // exact
+    const float q = std::nearbyintf(r);                               // ties to even
+    return (uint16_t)(sign | (uint32_t)q);                            // q == 1024 is the smallest normal
+  }
+  const uint32_t mant = u & 0x7fffffu, exp = (u >> 23) - 112;         // 1 .. 30
+  uint32_t h = (exp << 10) | (mant >> 13);
+  const uint32_t rem = mant & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;             // carries into the exponent as it should
+  return (uint16_t)(sign | h);
+}
+float f16_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, mnt = h & 1023u;
+  float f;
+  if (e == 0) f = (float)mnt * 5.9604644775390625e-8f;                // 2^-24
+  else if (e == 31) f = mnt ? NAN : INFINITY;
+  else { const uint32_t u = ((e + 112) << 23) | (mnt << 13); std::memcpy(&f, &u, 4); }
+  uint32_t u; std::memcpy(&u, &f, 4); u |= sign; std::memcpy(&f, &u, 4);
+  return f;
+}
+// largest power of two s with bound * s <= 2^15 (fp16's largest finite value is 65504: a factor of two to spare)
+float half_scale_for(double bound) {
+  if (!(bound > 0.0) || !std::isfinite(bound)) return 0.f;
+  int e; std::frexp(bound, &e);                                       // bound = f 2^e, f in [0.5, 1)
+  const int k = std::max(-100, std::min(100, 15 - e));
+  return std::ldexp(1.0f, k);
+}
+// pack_conv2_split's fragment order with TWO fp16 terms of kernel * wscale (subconv.hip, two-term scheme)
+std::vector<float> pack_conv2_half(const std::vector<float>& c2, int d, float wscale) {
+  const int KBn = d / 16, steps = KBn * 4 + (KBn + 1) / 2, NTc = d == 144 ? 9 : 8, chunks = KBn / NTc;
+  std::vector<uint16_t> frag((size_t)chunks * steps * NTc * 2 * 64 * 8);
+  for (int ch = 0; ch < chunks; ++ch)
+    for (int st = 0; st < steps; ++st)
+      for (int nt = 0; nt < NTc; ++nt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            int cb, q;
+            if (st < KBn * 4) { cb = st / 4; q = 2 * (st % 4) + (j >> 2); }
+            else { cb = 2 * (st - KBn * 4) + (j >> 2); q = 8; }
+            const int cin = 16 * cb + 4 * (lane >> 4) + (j & 3), cout = 16 * (ch * NTc + nt) + (lane & 15);
+            const float v = (cb < KBn ? c2[((size_t)q * d + cin) * d + cout] : 0.f) * wscale;
+            const uint16_t hi = f16_rne(v), lo = f16_rne(v - f16_to_float(hi));
+            const size_t at = ((((size_t)ch * steps + st) * NTc + nt) * 2 * 64 + lane) * 8 + j;
+            frag[at] = hi;
+            frag[at + 64 * 8] = lo;
+          }
+  std::vector<float> as_f(frag.size() / 2);
+  std::memcpy(as_f.data(), frag.data(), frag.size() * 2);
+  return as_f;
+}
 // the subsampling Dense [K, 144] for sublinear_split_kernel: 1728 fragments per 32-wide step, padded to 7 x 256 (4 floats each)
 std::vector<float> pack_linear_split(const std::vector<float>& lin, int K, int d) {
   const std::vector<float> sp = pack_split32([&](int k, int n) { return lin[(size_t)k * d + n]; }, K, d);
@@ -900,8 +958,10 @@ int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, fl
   return 0;
 }
 
+// mel_bounded: the features come from this handle's own frontend (|mel| <= 80 x the filters' L1 norm), which the two-term
+// fp16 kernel's operand scale relies on; features handed in by the caller take the three-term bf16 kernel
 int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, float* sub, float* out,
-                    hipStream_t s) {
+                    hipStream_t s, bool mel_bounded) {
   const auto& c = m->cfg;
   const int d = c.dmodel;
   int T1, pt1, T2, pt2;
@@ -909,6 +969,8 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   same_pad(T1, 3, 2, &T2, &pt2);
   SubConvArgs sa{};
   sa.mel = mel; sa.out = sub; sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b; sa.w2s = m->c2_wsplit;
+  static const bool force_half = [] { const char* v = getenv("MI355ASR_SUBCONV_TERMS"); return v && atoi(v) == 22; }();   // 22: also for caller-supplied features (tests)
+  if (m->c2_whalf && (mel_bounded || force_half)) { sa.w2h = m->c2_whalf; sa.h_scale = m->c2_hscale; sa.h_wscale = m->c2_wscale; }
   sa.B = Bp; sa.F = F; sa.NM = c.n_mels; sa.T1 = T1; sa.F1 = m->dm.F1; sa.T2 = T2; sa.F2 = m->dm.F2;
   sa.st1 = m->dm.st1; sa.pt1 = pt1; sa.pf1 = m->dm.pf1; sa.pt2 = pt2; sa.pf2 = m->dm.pf2;
   { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling"); }
@@ -1046,7 +1108,7 @@ int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const P
   Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
   sc.h4 = (float*)(ws + p.h4);
-  rc = run_subsampling(m, mel, g.Bp, g.F, (float*)(ws + p.sub), sc.xa, s);
+  rc = run_subsampling(m, mel, g.Bp, g.F, (float*)(ws + p.sub), sc.xa, s, true);
   if (rc) return rc;
   if (m->cfg.add_wav_info) {
     rc = run_wavpick(m, wav, g.Bp, g.Lb, g.T, sc.xa, (float*)(ws + p.wv), s);
@@ -1276,6 +1338,11 @@ int mi355asr_destroy(mi355asr_model* m) {
   return 0;
 }
 
+// test hook (not in the public header): the host's fp16 rounding of the two-term scheme's weight packs
+void mi355asr_test_f16_rne(const float* in, int32_t n, uint16_t* half_bits, float* back) {
+  for (int i = 0; i < n; ++i) { half_bits[i] = f16_rne(in[i]); back[i] = f16_to_float(half_bits[i]); }
+}
+
 int mi355asr_set_expected_rows(mi355asr_model* m, int64_t rows) {
   if (!m) return fail(MI355ASR_EINVAL, "null handle");
   if (m->finalized) return fail(MI355ASR_ESTATE, "mi355asr_set_expected_rows must come before mi355asr_finalize_weights");
@@ -1375,7 +1442,8 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   const int d = c.dmodel;
   ArenaBuilder ab;
   ab.ring_terms = m->cfg.gemm_dtype == 1 ? 1 : 3;
-  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0;
+  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0, o_c2h = 0;
+  float c2_hs = 0.f, c2_ws = 0.f;
   FftOff fo;
   MelBandOff mbo;
   std::vector<BlockOff> eo, co;
@@ -1474,6 +1542,34 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
     // 16 nt + r, in-channels 16 cb + 4 g + (j & 3) at tap 2 pair + (j >> 2) (the tenth tap is zero); term t =
     // round-to-nearest-even bf16 of what the terms before it left
     o_c2s = ab.put(pack_conv2_split(c2, d));
+    // Two-term fp16 scheme (subconv.hip): needs a bound of conv1's output.  The frontend's dB values lie in [-80, 0]
+    // (floor_db, relative to the utterance maximum), a mel value in 80 x the filter's L1 norm; LEAF features have no bound.
+    static const int terms_env = [] { const char* v = getenv("MI355ASR_SUBCONV_TERMS"); return v ? atoi(v) : 2; }();
+    if ((terms_env == 2 || terms_env == 22) && c.mel_layer_type != 1) {
+      double mb = 80.0;
+      if (c.mel_layer_type == 0) {
+        const auto& f2m = m->host["mel_layer/freq2mel"].data;
+        double l1 = 0.0;
+        for (int mm = 0; mm < c.n_mels; ++mm) {
+          double sum = 0.0;
+          for (int k = 0; k < dm.nbins; ++k) sum += std::fabs((double)f2m[(size_t)k * c.n_mels + mm]);
+          l1 = std::max(l1, sum);
+        }
+        mb *= l1;
+      }
+      const auto& w1 = m->host["conv_subsampling/conv1/kernel"].data;
+      const auto& b1 = m->host["conv_subsampling/conv1/bias"].data;
+      double bx = 0.0, wmax = 0.0;
+      for (int ch = 0; ch < d; ++ch) {
+        double sum = 0.0;
+        for (int t = 0; t < 9; ++t) sum += std::fabs((double)w1[(size_t)t * d + ch]);
+        bx = std::max(bx, std::fabs((double)b1[ch]) + mb * sum);
+      }
+      for (float v : c2) wmax = std::max(wmax, std::fabs((double)v));
+      c2_hs = half_scale_for(bx);
+      c2_ws = half_scale_for(wmax);
+      if (c2_hs > 0.f && c2_ws > 0.f) o_c2h = ab.put(pack_conv2_half(c2, d, c2_ws));
+    }
   }
   const auto& lin = m->host["conv_subsampling/linear/kernel"].data;
   o_lw = ab.put(pack_p16([&](int k, int n) { return lin[(size_t)k * d + n]; }, dm.F2 * d, d, d / 16));
@@ -1548,6 +1644,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->fft_w1s = base + fo.w1s; m->fft_w2s = base + fo.w2s;
   m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = ((d == 144 || d == 256 || d == 512) && c.has_encoder) ? base + o_c2s : nullptr;
+  m->c2_whalf = o_c2h ? base + o_c2h : nullptr; m->c2_hscale = c2_hs; m->c2_wscale = c2_ws;
   m->lin_wsplit = (d == 144 && c.has_encoder) ? base + o_lws : nullptr;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
@@ -1766,7 +1863,7 @@ int mi355asr_conv_subsampling(mi355asr_model* m, const float* mel, int32_t B, in
   const int T = ceil_div(ceil_div(F, m->dm.st1), 2);
   const Plan p = make_plan(m, B, F, T);
   if (ws_bytes < p.total) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total);
-  return run_subsampling(m, mel, B, F, (float*)((char*)ws + p.sub), out, (hipStream_t)stream);
+  return run_subsampling(m, mel, B, F, (float*)((char*)ws + p.sub), out, (hipStream_t)stream, false);
 }
 
 int mi355asr_conformer_block(mi355asr_model* m, int32_t stack, int32_t index, const float* x, int32_t B, int32_t T,

@@ -174,6 +174,8 @@ DEV void pp_fake_prep(PrepCtx& pc) {     // DG bit 0: consumes the hidden tiles 
   do { if constexpr (!(DG & 2)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(pl.f[S0]), "+v"(pl.f[S1]), "+v"(pl.f[S2])); } while (0)
 #define PP_MM(ACC, S, X) \
   do { if constexpr (!(DG & 4)) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pl.f[S]), __builtin_bit_cast(bf16x8_t, X), ACC, 0, 0, 0); } while (0)
+// bit 6 (timing only): without the three products of order 2^-16 -- the MFMA count of a two-term operand scheme
+#define PP_MM2(ACC, S, X) do { if constexpr (!(DG & 64)) PP_MM(ACC, S, X); } while (0)
 #define PP_PREP(K) \
   do { if constexpr (!(DG & 1)) prep_slot<K, false, true>(pc); else if constexpr (K == 47) pp_fake_prep(pc); } while (0)
 #define PP_FENCE __builtin_amdgcn_sched_barrier(0)
@@ -570,7 +572,7 @@ int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s)
 #define PP_DIAG_CASE(N) case N: hipLaunchKernelGGL((pp_block_kernel<true, true, N>), g, t, 0, s, a, b); return 0;
     switch (dg) {
       PP_DIAG_CASE(1) PP_DIAG_CASE(2) PP_DIAG_CASE(3) PP_DIAG_CASE(4) PP_DIAG_CASE(8) PP_DIAG_CASE(16) PP_DIAG_CASE(24)
-      PP_DIAG_CASE(26) PP_DIAG_CASE(27) PP_DIAG_CASE(25) PP_DIAG_CASE(7) PP_DIAG_CASE(10) PP_DIAG_CASE(18)
+      PP_DIAG_CASE(26) PP_DIAG_CASE(27) PP_DIAG_CASE(25) PP_DIAG_CASE(7) PP_DIAG_CASE(10) PP_DIAG_CASE(18) PP_DIAG_CASE(64) PP_DIAG_CASE(65)
       default: break;
     }
 #undef PP_DIAG_CASE

@@ -503,7 +503,10 @@ __global__ __launch_bounds__(256) void ring_layernorm_rows_kernel(float* y, cons
 
 template <int EPI, bool LN, int TERMS, bool EDMA>
 int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
-  const int chunks = EPI == E16_HEAD ? (a.NT + GNB - 1) / GNB : (EPI == E16_GLU ? a.NT / 2 : a.NT) / (EPI == E16_GLU ? GNB / 2 : GNB);
+  // the head's ring holds ceil(V / 128) chunks (api.hip: put_ring_head), whatever tile count the P16 pack of the same matrix
+  // was padded to: a.NT = 24 at V = 200 walked a third chunk that is not there (garbage columns nobody looked at, but
+  // 393 KB read past the ring -- past the arena when the ring is its last entry)
+  const int chunks = EPI == E16_HEAD ? ((a.n_valid + 15) / 16 + GNB - 1) / GNB : (EPI == E16_GLU ? a.NT / 2 : a.NT) / (EPI == E16_GLU ? GNB / 2 : GNB);
   // Shape of the launch: RT row tiles per wave (256 or 128 rows per workgroup) and cpw column chunks per workgroup, so
   // that the workgroups come as close as possible to a whole number of rounds over the 256 CUs (short K: every
   // workgroup pays a prologue -- first slabs, LayerNorm statistics -- worth several k-steps, and a second, half-empty
@@ -530,6 +533,7 @@ int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   }
   const int cpw = best_cpw;
   const dim3 grid((a.M + 128 * best_rt - 1) / (128 * best_rt), chunks / cpw);
+
   if (best_rt == 2 && force_slots != 2) {
     if constexpr (EPI != E16_HEAD)
       hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 2, 4, TERMS, EDMA>), grid, dim3(GT), 0, s, a, (const u32x4*)ring, cpw);

@@ -119,6 +119,11 @@ struct SubConvArgs {
   const float* w2p;   // packed conv2 kernel, K order = (cblock, kt, kf, 16) -> [9*D/16][D/16][64][4]
   const float* b2;    // [D]
   const float* w2s;   // conv2 kernel as split-bf16 fragments [column chunk][4 d/16 + ceil(d/32) steps][9 or 8 tiles][3 terms][64 lanes][8] (subconv.hip), or null
+  // the same kernel as TWO fp16 terms (round-to-nearest hi + lo of the kernel times h_wscale, a power of two), or null: the
+  // conv1 values are then scaled by h_scale (a power of two with bound(conv1) * h_scale <= 2^15), three products per
+  // fragment pair instead of six, the accumulators carry h_scale * h_wscale (subconv.hip, "two-term scheme")
+  const float* w2h = nullptr;
+  float h_scale = 1.f, h_wscale = 1.f;
   int B, F, NM, T1, F1, T2, F2;
   int st1;            // conv1 time stride (reduction_factor/2)
   int pt1, pf1, pt2, pf2;  // pad-before of conv1 (time,freq) and conv2 (time,freq)

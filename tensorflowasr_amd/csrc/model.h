@@ -127,6 +127,8 @@ struct mi355asr_model {
   float leaf_p0 = 0.f, leaf_p1 = 1.f;
   const float* lin_wsplit = nullptr;    // subsampling Dense kernel as split-bf16 fragments, 1792 per 32-wide step (fused.hip)
   const float* c2_wsplit = nullptr;     // conv2 kernel as split-bf16 fragments (subconv.hip; dmodel 144 / 256 / 512)
+  const float* c2_whalf = nullptr;      // ... as two fp16 terms of kernel * c2_wscale (two-term scheme), conv1 values times c2_hscale
+  float c2_hscale = 0.f, c2_wscale = 0.f;
   const float* leaf_wsplit = nullptr;   // Gabor filters as split-bf16 MFMA fragments (leaf.hip)
   int leaf_terms = 3;                   // bf16 terms per fp32 operand in the Gabor conv (0: fp32 MFMA kernel)
   // add_wav_info: WavePickModel weights (conv kernels P16-packed with K = k * Cin)

@@ -239,6 +239,40 @@ DEV SplitFrag split8(f32x4 lo, f32x4 hi) {
   return f;
 }
 
+// Two-term scheme (round 3): x * scale = hi + lo with hi = fp16(x * scale), lo = fp16(x * scale - hi), both round-to-nearest:
+// |x * scale - hi - lo| <= 2^-22 |x * scale| as long as lo is a normal fp16 (|x * scale| >= 2^-2; below that the error is
+// 2^-25 absolute -- the scale puts the layer's bound at 2^15).  a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi: three MFMAs instead
+// of six, the dropped a_lo b_lo and the representation errors are of the size of the terms the six-product bf16 scheme
+// drops (measured: the same distance from the fp64 oracle; Ootomo & Yokota's error-corrected fp16 GEMM without its
+// second accumulator, which the power-of-two scales make unnecessary here).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+DEV SplitFrag split8h(f32x4 lo, f32x4 hi) {
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  SplitFrag f;
+  unsigned d0[4], d1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const _Float16 h0 = (_Float16)v[2 * k], h1 = (_Float16)v[2 * k + 1];
+    const float r0 = v[2 * k] - (float)h0, r1 = v[2 * k + 1] - (float)h1;
+    d0[k] = __builtin_bit_cast(unsigned, f16x2{h0, h1});
+    d1[k] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
+  }
+  f.t[0] = u32x4{d0[0], d0[1], d0[2], d0[3]};
+  f.t[1] = u32x4{d1[0], d1[1], d1[2], d1[3]};
+  f.t[2] = u32x4{0u, 0u, 0u, 0u};
+  return f;
+}
+template <int TM>
+DEV SplitFrag split_terms(f32x4 lo, f32x4 hi) {
+  if constexpr (TM == 2) return split8h(lo, hi); else return split8(lo, hi);
+}
+template <int TM>
+DEV f32x4 mma_terms(u32x4 w, u32x4 x, f32x4 c) {
+  if constexpr (TM == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+
 struct SplitLane {
   int mb[SRT];                // float offset of the lane's 7x7 mel window in the LDS patch, per row tile
   unsigned valid[SRT];        // bit kt*3+kf: conv1 position inside [0,T1) x [0,F1)
@@ -274,7 +308,7 @@ DEV f32x4 conv1_at(const float* melp, PatchGeom RS, const SplitLane& sl, int rt,
   return v;
 }
 
-template <int PAIR, int DIAG = 0>
+template <int PAIR, int DIAG = 0, int TM = 3>
 DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, const SplitLane& sl, const f32x4 (&w1r)[9], f32x4 b1v) {
 #pragma unroll
   for (int rt = 0; rt < SRT; ++rt) {
@@ -284,14 +318,14 @@ DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, const 
       const u32x4 l = __builtin_bit_cast(u32x4, lo), h = __builtin_bit_cast(u32x4, hi);
       xf[rt].t[0] = l; xf[rt].t[1] = h; xf[rt].t[2] = l ^ h;
     } else {
-      xf[rt] = split8(lo, hi);
+      xf[rt] = split_terms<TM>(lo, hi);
     }
   }
 }
 
 // operand of a ninth-tap step: conv1 at tap 8 for channel block cbA (slots 0..3) and cbA + 1 (slots 4..7; zeros past the
 // last block); the conv1 taps of the two blocks pass through the same registers one after the other
-template <int DIAG, class LT>
+template <int DIAG, int TM, class LT>
 DEV void frags_ninth(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, const SplitLane& sl, f32x4 (&w1r)[9], const float* p_b1,
                      int g4, int cbA, int KBn, LT&& load_taps) {
   f32x4 lo[SRT], hi[SRT];
@@ -307,18 +341,21 @@ DEV void frags_ninth(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, cons
     for (int rt = 0; rt < SRT; ++rt) hi[rt] = splat4(0.f);
   }
 #pragma unroll
-  for (int rt = 0; rt < SRT; ++rt) xf[rt] = split8(lo[rt], hi[rt]);
+  for (int rt = 0; rt < SRT; ++rt) xf[rt] = split_terms<TM>(lo[rt], hi[rt]);
 }
 
 // DIAG != 0: timing experiments only (results are wrong): 1 = no conv1 / split work, 2 = one weight-fragment read per
 // step instead of nine, 3 = no slab traffic (global -> LDS), 4 = no barrier in the step loop, 5 = conv1 without its mel
-// reads from LDS, 6 = no operand split
+// reads from LDS, 6 = no operand split, 7 = three products per fragment triple instead of six (a two-term operand scheme's MFMA count)
 // DM = dmodel (conv1 channels = conv2 in / out channels), NBW = output column tiles of a workgroup: all nine for dmodel
 // 144; eight (128 channels) for 256 / 512, the chunks on grid.z -- conv1 is then recomputed per chunk, the same VALU to
 // MFMA ratio per step as at 144.  Weight fragments: [chunk][step][NBW tiles][3 terms][64 lanes][8].
-template <int DIAG, int DM, int NBW>
+// TM = 3: bf16 terms (exact), six products; TM = 2: fp16 terms, three products (see split8h): a.w2h, conv1 scaled by a.h_scale
+// (folded into the staged conv1 kernel and bias: relu(s v) = s relu(v)), accumulators in units of h_scale * h_wscale.
+template <int DIAG, int DM, int NBW, int TM = 3>
 __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, PatchGeom RS, int rows, int late_mode) {
-  constexpr int KB = DM / 16, NB = NBW, NI = ninth_steps(KB), NK32 = KB * NPAIR + NI, SLABF = NBW * 3 * 64, D = DM;
+  static_assert(TM == 3 || DIAG == 0, "the timing variants are those of the three-term kernel");
+  constexpr int KB = DM / 16, NB = NBW, NI = ninth_steps(KB), NK32 = KB * NPAIR + NI, SLABF = NBW * TM * 64, D = DM;
   const int c0 = blockIdx.z * NBW;               // first output column tile of this workgroup
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][SLABF];
   __shared__ __attribute__((aligned(16))) float melp[MELP];
@@ -326,7 +363,8 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g4 = (lane >> 4) * 4, c = lane & 15;
   const int b = blockIdx.y, r0 = blockIdx.x * SPOSG, PU = a.T2 * a.F2;
-  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(a.w2s) + (size_t)blockIdx.z * NK32 * SLABF;
+  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(TM == 2 ? a.w2h : a.w2s) + (size_t)blockIdx.z * NK32 * SLABF;
+  const float s1 = TM == 2 ? a.h_scale : 1.f, s2 = TM == 2 ? a.h_scale * a.h_wscale : 1.f;
   constexpr int NQ = (SLABF + SCT - 1) / SCT;
   u32x4 nw[NQ];
 #pragma unroll
@@ -346,8 +384,8 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
     melp[rr * RS.row + (jj & 3) * RS.seg + (jj >> 2)] =
         (tm >= 0 && tm < a.F && fm >= 0 && fm < a.NM) ? mbp[(size_t)tm * a.NM + fm] : 0.f;
   }
-  for (int i = threadIdx.x; i < 9 * D; i += SCT) p_w1[i] = a.w1[i];
-  for (int i = threadIdx.x; i < D; i += SCT) { p_b1[i] = a.b1[i]; p_b2[i] = a.b2[i]; }
+  for (int i = threadIdx.x; i < 9 * D; i += SCT) p_w1[i] = a.w1[i] * s1;
+  for (int i = threadIdx.x; i < D; i += SCT) { p_b1[i] = a.b1[i] * s1; p_b2[i] = a.b2[i] * s2; }
   SplitLane sl;
 #pragma unroll
   for (int rt = 0; rt < SRT; ++rt) {
@@ -404,7 +442,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   constexpr bool LATE = decltype(LATE_T)::value;
   if constexpr (LATE) {
     load_taps(0);
-    frags_for<0, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, 0, g4));
+    frags_for<0, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, 0, g4));
   }
   // one MFMA step s: slab s is in wl[s & 1]; frags_this() = the operand of this step (early waves, before the MFMAs),
   // frags_next() = the operand of step s + 1 (late waves, after the MFMAs)
@@ -435,14 +473,18 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
           constexpr int gi = decltype(GI)::value;
           static_for<0, G>([&](auto HI) {
             constexpr int h = decltype(HI)::value;
-            w[h][0] = lds_read16<((gi * G + h) * 3 + 0) * 1024>(base);
-            w[h][1] = lds_read16<((gi * G + h) * 3 + 1) * 1024>(base);
-            w[h][2] = lds_read16<((gi * G + h) * 3 + 2) * 1024>(base);
+            w[h][0] = lds_read16<((gi * G + h) * TM + 0) * 1024>(base);
+            w[h][1] = lds_read16<((gi * G + h) * TM + 1) * 1024>(base);
+            if constexpr (TM == 3) w[h][2] = lds_read16<((gi * G + h) * TM + 2) * 1024>(base);
           });
         };
         auto wait = [&](u32x4 (&w)[G][3], auto N_T) {
           constexpr int N = decltype(N_T)::value;
-          if constexpr (G == 1)
+          if constexpr (TM == 2 && G == 1)
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0][0]), "+v"(w[0][1]) : "n"(N));
+          else if constexpr (TM == 2)
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]) : "n"(N));
+          else if constexpr (G == 1)
             asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]) : "n"(N));
           else
             asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[1][0]), "+v"(w[1][1]),
@@ -451,26 +493,25 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
         auto mma = [&](const u32x4 (&w)[G][3], auto GI) {
           constexpr int gi = decltype(GI)::value;
 #pragma unroll
-          for (int ord = 2; ord >= 0; --ord)
+          for (int ord = DIAG == 7 ? 1 : TM - 1; ord >= 0; --ord)   // DIAG 7: without the three products of order 2^-16
 #pragma unroll
             for (int p = 0; p <= ord; ++p)
 #pragma unroll
               for (int h = 0; h < G; ++h)
 #pragma unroll
                 for (int rt = 0; rt < SRT; ++rt)
-                  acc[rt][gi * G + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[h][ord - p]),
-                      __builtin_bit_cast(bf16x8, xa[rt].t[p]), acc[rt][gi * G + h], 0, 0, 0);
+                  acc[rt][gi * G + h] = mma_terms<TM>(w[h][ord - p], xa[rt].t[p], acc[rt][gi * G + h]);
         };
         fetch(wa, std::integral_constant<int, 0>{});
         static_for<0, NG>([&](auto GI) {
           constexpr int gi = decltype(GI)::value;
           if constexpr (gi % 2 == 0) {
-            if constexpr (gi + 1 < NG) { fetch(wb, std::integral_constant<int, gi + 1>{}); wait(wa, std::integral_constant<int, 3 * G>{}); }
+            if constexpr (gi + 1 < NG) { fetch(wb, std::integral_constant<int, gi + 1>{}); wait(wa, std::integral_constant<int, TM * G>{}); }
             else wait(wa, std::integral_constant<int, 0>{});
             mma(wa, GI);
             if constexpr (gi == 0) after_first_group();
           } else {
-            if constexpr (gi + 1 < NG) { fetch(wa, std::integral_constant<int, gi + 1>{}); wait(wb, std::integral_constant<int, 3 * G>{}); }
+            if constexpr (gi + 1 < NG) { fetch(wa, std::integral_constant<int, gi + 1>{}); wait(wb, std::integral_constant<int, TM * G>{}); }
             else wait(wb, std::integral_constant<int, 0>{});
             mma(wb, GI);
           }
@@ -513,16 +554,16 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
       step_body(cb * NPAIR + pair,
                 [&]() {                      // early waves: the operand of this step, just before its MFMAs
                   if constexpr (pair == 0) load_taps(cb);
-                  frags_for<pair, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+                  frags_for<pair, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
                 },
                 [&]() {                      // late waves: the operand of the next step, after this step's MFMAs
                   if constexpr (pair + 1 < NPAIR) {
-                    frags_for<pair + 1, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+                    frags_for<pair + 1, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
                   } else if (cb + 1 < KB) {
                     load_taps(cb + 1);
-                    frags_for<0, DIAG>(xa, melp, RS, sl, w1r, lds4(p_b1, cb + 1, g4));
+                    frags_for<0, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, cb + 1, g4));
                   } else {
-                    frags_ninth<DIAG>(xa, melp, RS, sl, w1r, p_b1, g4, 0, KB, load_taps);
+                    frags_ninth<DIAG, TM>(xa, melp, RS, sl, w1r, p_b1, g4, 0, KB, load_taps);
                   }
                 });
     });
@@ -530,12 +571,13 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
 #pragma unroll 1
   for (int i = 0; i < NI; ++i) {             // the ninth taps, two channel blocks per step
     step_body(KB * NPAIR + i,
-              [&]() { frags_ninth<DIAG>(xa, melp, RS, sl, w1r, p_b1, g4, 2 * i, KB, load_taps); },
-              [&]() { if (i + 1 < NI) frags_ninth<DIAG>(xa, melp, RS, sl, w1r, p_b1, g4, 2 * i + 2, KB, load_taps); });
+              [&]() { frags_ninth<DIAG, TM>(xa, melp, RS, sl, w1r, p_b1, g4, 2 * i, KB, load_taps); },
+              [&]() { if (i + 1 < NI) frags_ninth<DIAG, TM>(xa, melp, RS, sl, w1r, p_b1, g4, 2 * i + 2, KB, load_taps); });
   }
   };
   if (late) run(std::integral_constant<bool, true>{});
   else run(std::integral_constant<bool, false>{});
+  const float inv2 = 1.0f / s2;            // a power of two
 #pragma unroll
   for (int rt = 0; rt < SRT; ++rt) {
     const int r = r0 + 32 * wave + 16 * rt + c;
@@ -545,6 +587,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
       for (int n = 0; n < NB; ++n) {
         f32x4 v = acc[rt][n];
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if constexpr (TM == 2) v = v * splat4(inv2);
         stg4(orow + 16 * (c0 + n) + g4, v);
       }
     }
@@ -565,6 +608,16 @@ int launch_subconv144(const SubConvArgs& a, hipStream_t s) {
 template <int DIAG>
 static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGeom RS, int rows, int late_mode, hipStream_t s) {
   const dim3 g128(g144.x, g144.y, d / 128);
+  if constexpr (DIAG == 0) {
+    if (a.w2h) {
+      switch (d) {
+        case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2>), g144, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+        case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 256, 8, 2>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+        case 512: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 512, 8, 2>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+        default: return -1;
+      }
+    }
+  }
   switch (d) {
     case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 144, 9>), g144, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
     case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 256, 8>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
@@ -583,7 +636,7 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
   while (RS.row % 8 != 5) ++RS.row;
   const int span = (SPOSG - 1 + a.F2 - 1) / a.F2;            // t2 steps a tile can touch beyond its first
   const int rows = 4 * span + 7;
-  if (!a.w2s || a.st1 != 2 || rows * RS.row > MELP || PU <= 0) return -1;
+  if ((!a.w2s && !a.w2h) || a.st1 != 2 || rows * RS.row > MELP || PU <= 0) return -1;
   static const int late_mode = [] { const char* v = getenv("MI355ASR_SUBCONV_LATE"); return v ? atoi(v) : 0; }();
   const dim3 grid((PU + SPOSG - 1) / SPOSG, a.B);
 #ifdef MI355ASR_DIAG_KERNELS
@@ -601,6 +654,7 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
     case 4: return launch_split_d<4>(d, grid, a, RS, rows, late_mode, s);
     case 5: return launch_split_d<5>(d, grid, a, RS, rows, late_mode, s);
     case 6: return launch_split_d<6>(d, grid, a, RS, rows, late_mode, s);
+    case 7: return launch_split_d<7>(d, grid, a, RS, rows, late_mode, s);
     default: break;
   }
 #endif

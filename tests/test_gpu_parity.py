@@ -163,6 +163,50 @@ def test_conv_subsampling_parity(enc2, F):
     assert maxdiff(got, ref) < TOL
 
 
+def test_two_term_fp16_subsampling_conv_against_the_three_term_kernel_and_the_oracle(torch_cuda):
+    """subconv_split_ring_kernel<..., TM = 2>: conv1 values and conv2 kernel as hi + lo fp16 terms (power-of-two scales from
+    the weights and the frontend's [-80, 0] dB range), three MFMAs per fragment pair instead of six.  The stage API feeds
+    caller-supplied features, which take the three-term kernel; MI355ASR_SUBCONV_TERMS=22 (subprocess) sends them through
+    the two-term one.  On features inside the bound both are equally far from the fp64 oracle (dmodel 144, 256, 512:
+    one column chunk and chunks on grid.z), including rows at the edge of the bound and a batch of exact zeros."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, maxdiff, small_cfg
+from tensorflowasr_amd.models import ConformerEncoder
+res = []
+for base in (co.CONFORMER_S, co.CONFORMER_M, co.CONFORMER_L):
+    cfg = small_cfg(1, base)
+    w = co.encoder_weights(cfg, seed=61)
+    e = ConformerEncoder(**encoder_kwargs(cfg))
+    e.load_weights(w, by_name=False)
+    rng = np.random.default_rng(62)
+    mel = (-80.0 * rng.random((4, 123, 80))).astype(np.float32)
+    mel[1, :, ::2] = -80.0                     # the bound itself
+    mel[2] = 0.0
+    mel[3] *= 1e-3                             # small features: the lo terms go subnormal
+    ref = co.conv_subsampling(mel.astype(np.float64), w)
+    got = e.conv_subsampling(mel).cpu().numpy()
+    res += [maxdiff(got, ref), float(np.abs(ref).max())]
+print("RESULT " + " ".join("%.4e" % v for v in res))
+'''
+    errs = {}
+    for terms in ("3", "22"):
+        env = dict(os.environ, MI355ASR_SUBCONV_TERMS=terms)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+        assert line, out.stderr[-2000:]
+        errs[terms] = [float(v) for v in line[0].split()[1:]]
+    print(errs)
+    for i in range(0, 6, 2):
+        e3, e2, scale = errs["3"][i], errs["22"][i], errs["3"][i + 1]
+        assert e3 < TOL and e2 < TOL
+        assert e2 <= 2.0 * e3 + 2e-7 * scale, (i, e3, e2, scale)   # the same distance from the oracle (fp32 accumulation noise)
+
+
 @pytest.mark.parametrize("B,T", [(2, 50), (3, 250), (1, 300), (2, 7), (1, 16), (1, 17), (1, 750)])
 def test_conformer_block_parity(enc2, B, T):
     e, w, _ = enc2

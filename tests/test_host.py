@@ -798,3 +798,27 @@ def test_log_sum_exp_kernels_of_the_device_beam_search_round_like_libm():
     ref = np.log(x)
     assert np.max(np.abs(y - ref) / np.maximum(np.abs(ref), 1e-300)) < 7e-16    # three ulps of a double
     assert np.array_equal(y.astype(np.float32), ref.astype(np.float32))
+
+
+def test_host_fp16_rounding_of_the_two_term_weight_packs_equals_numpy():
+    """api.hip's f16_rne / f16_to_float (the hi and lo terms of the two-term fp16 weight packs are rounded on the host):
+    normal and subnormal values, overflow, exact ties between neighbouring halves -- bit-equal to NumPy's float16."""
+    import ctypes
+    from tensorflowasr_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(50000).astype(np.float32) * np.float32(s) for s in (1e-8, 1e-6, 1e-4, 1e-2, 1, 100, 30000, 70000)]
+                       + [np.array([0, -0.0, 65504, 65519.99, 65520, 6.1e-5, 6.09e-5, 5.96e-8, 2.98e-8, 2.99e-8, 1e-9, np.inf, -np.inf], np.float32)])
+    h = np.arange(0, 0x7bff, dtype=np.uint16).view(np.float16).astype(np.float64)
+    ties = ((h[:-1] + h[1:]) / 2).astype(np.float32)
+    x = np.ascontiguousarray(np.concatenate([x, ties, -ties]))
+    bits = np.zeros(x.size, np.uint16)
+    back = np.zeros(x.size, np.float32)
+    fn = lib.mi355asr_test_f16_rne
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    fn(x.ctypes.data, x.size, bits.ctypes.data, back.ctypes.data)
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16)
+    assert np.array_equal(bits, ref.view(np.uint16))
+    assert np.array_equal(back, ref.astype(np.float32))

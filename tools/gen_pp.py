@@ -267,7 +267,7 @@ def emit_units(units):
     w = out.append
     w("// GENERATED by tools/gen_pp.py -- do not edit.  One function per unit kind of the pair-pipelined stream (see the")
     w("// generator's docstring).  Macros (fused_pp.hip): PP_RD(slot, addr, OFF) = ds_read_b128 into pool slot; PP_WTn(N, slots...) =")
-    w("// s_waitcnt lgkmcnt(N) tied to the slots; PP_MM(acc, slot, x) = one v_mfma_f32_16x16x32_bf16; PP_PREP(k) = slot k of the")
+    w("// s_waitcnt lgkmcnt(N) tied to the slots; PP_MM(acc, slot, x) = one v_mfma_f32_16x16x32_bf16 (PP_MM2: a product of order 2^-16); PP_PREP(k) = slot k of the")
     w("// activation + split schedule on (pc.lo, pc.hi) -> pc.out; PP_FENCE = sched_barrier(0).")
     w("constexpr int PP_NPOOL = %d;" % NPOOL)
     w("struct PpPool { u32x4_t f[PP_NPOOL]; };")
@@ -309,7 +309,8 @@ def emit_units(units):
                     w("  PP_WT0(%d);" % n)
             elif op[0] == "mm":
                 _, acc, slot, x, q, xt = op
-                w("  PP_MM(%s, %d, %s);" % (acc, slot, x))
+                order = u.pos[q]["frag"][3] + xt       # 0, 1 or 2: which power of 2^-8 the product carries
+                w("  %s(%s, %d, %s);" % ("PP_MM2" if order == 2 else "PP_MM", acc, slot, x))
             elif op[0] == "prep":
                 w("  PP_FENCE; PP_PREP(%d); PP_FENCE;" % op[1])
             elif op[0] == "adv":
