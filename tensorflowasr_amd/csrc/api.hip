@@ -230,7 +230,7 @@ std::vector<float> pack_linear_split(const std::vector<float>& lin, int K, int d
 // ---- pair-pipelined streams (fused_pp.hip; layout tables generated by tools/gen_pp.py) -----------------------------------
 #include "pp_layout.inc"
 namespace {
-// one ring slot: 30 fragments of 1 KB (256 floats) in the order of `lay`; src(desc) = the fragment's 256 floats
+// one ring slot: kPpSlot fragments of 1 KB (256 floats) in the order of `lay`; src(desc) = the fragment's 256 floats
 void put_pp_slot(std::vector<float>& stream, const PpFragDesc (&lay)[kPpSlot], const std::function<const float*(const PpFragDesc&)>& src) {
   const size_t at = stream.size();
   stream.resize(at + (size_t)kPpSlot * 256, 0.f);
@@ -238,14 +238,55 @@ void put_pp_slot(std::vector<float>& stream, const PpFragDesc (&lay)[kPpSlot], c
     if (lay[i].kind != 0) std::memcpy(stream.data() + at + (size_t)i * 256, src(lay[i]), 256 * sizeof(float));
 }
 }  // namespace
+// pack_split32's fragment order with TWO fp16 terms of f * scale: [steps][NT][2 terms][64 lanes][8] (two-term scheme)
+std::vector<float> pack_half32(const std::function<float(int, int)>& f, int K, int N, float scale) {
+  const int steps = ceil_div(K, 32), NT = N / 16;
+  std::vector<uint16_t> frag((size_t)steps * NT * 2 * 64 * 8, 0);
+  for (int st = 0; st < steps; ++st)
+    for (int nt = 0; nt < NT; ++nt)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * st + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3), n = 16 * nt + (lane & 15);
+          const float v = (k < K ? f(k, n) : 0.f) * scale;
+          const uint16_t hi = f16_rne(v), lo = f16_rne(v - f16_to_float(hi));
+          const size_t at = ((((size_t)st * NT + nt) * 2) * 64 + lane) * 8 + j;
+          frag[at] = hi;
+          frag[at + 64 * 8] = lo;
+        }
+  std::vector<float> as_f(frag.size() / 2);
+  std::memcpy(as_f.data(), frag.data(), frag.size() * 2);
+  return as_f;
+}
+namespace {
+float matrix_scale(const std::function<float(int, int)>& f, int K, int N) {   // power of two: max |f| * s in [2^14, 2^15)
+  double mx = 0.0;
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) mx = std::max(mx, std::fabs((double)f(k, n)));
+  const float s = half_scale_for(mx);
+  return s > 0.f ? s : 1.0f;                  // an all-zero matrix
+}
+}  // namespace
 // Chain y += W2 act(W1aug [x ; 1]) over P = H / 32 hidden pairs, units A, AP, (P - 2) x F, BP, B (2 P ring slots):
-// an A fragment = W1aug step a, hidden tile 2 pair + b; a B fragment = W2 step `pair`, column tile a.
-void append_pp_chain(std::vector<float>& stream, const std::function<float(int, int)>& w1aug, int H, const std::function<float(int, int)>& w2) {
+// an A fragment = W1aug step a, hidden tile 2 pair + b; a B fragment = W2 step `pair`, column tile a.  Returns the scales the
+// two matrices were packed with and the bounds the kernel derives the operand scales from.
+PpChainSc append_pp_chain(std::vector<float>& stream, const std::function<float(int, int)>& w1aug, int H, const std::function<float(int, int)>& w2) {
   const int P = H / 32, NT1 = H / 16;
-  const std::vector<float> sp1 = pack_split32(w1aug, 145, H);      // [5 steps][NT1][3 terms][256]
-  const std::vector<float> sp2 = pack_split32(w2, H, 144);         // [P steps][9][3][256]
-  auto fa = [&](int pair, const PpFragDesc& d) { return sp1.data() + (((size_t)d.a * NT1 + 2 * pair + d.b) * 3 + d.term) * 256; };
-  auto fb = [&](int pair, const PpFragDesc& d) { return sp2.data() + (((size_t)pair * 9 + d.a) * 3 + d.term) * 256; };
+  PpChainSc sc;
+  sc.sw1 = matrix_scale(w1aug, 145, H);
+  sc.sw2 = matrix_scale(w2, H, 144);
+  double l1 = 0.0, bm = 0.0;
+  for (int n = 0; n < H; ++n) {
+    double sum = 0.0;
+    for (int k = 0; k < 144; ++k) sum += std::fabs((double)w1aug(k, n));
+    l1 = std::max(l1, sum);
+    bm = std::max(bm, std::fabs((double)w1aug(144, n)));
+  }
+  sc.l1 = (float)(l1 * (1.0 + 1e-6));         // rounded up: the bound has to hold in float
+  sc.bmax = (float)(bm * (1.0 + 1e-6));
+  const std::vector<float> sp1 = pack_half32(w1aug, 145, H, sc.sw1);      // [5 steps][NT1][2 terms][256]
+  const std::vector<float> sp2 = pack_half32(w2, H, 144, sc.sw2);         // [P steps][9][2][256]
+  auto fa = [&](int pair, const PpFragDesc& d) { return sp1.data() + (((size_t)d.a * NT1 + 2 * pair + d.b) * 2 + d.term) * 256; };
+  auto fb = [&](int pair, const PpFragDesc& d) { return sp2.data() + (((size_t)pair * 9 + d.a) * 2 + d.term) * 256; };
   auto unit = [&](const PpFragDesc (&lay)[kPpSlot], int pa, int pb) {
     put_pp_slot(stream, lay, [&](const PpFragDesc& d) { return d.kind == 1 ? fa(pa, d) : fb(pb, d); });
   };
@@ -254,14 +295,18 @@ void append_pp_chain(std::vector<float>& stream, const std::function<float(int, 
   for (int p = 0; p + 2 < P; ++p) { unit(kPpLayout_F0, p + 2, p); unit(kPpLayout_F1, p + 2, p); }
   unit(kPpLayout_BP0, -1, P - 2);
   unit(kPpLayout_B0, -1, P - 1);
+  return sc;
 }
-// A plain layer [145 (row 144 = bias), 144 * groups] in column groups of nine tiles, five S units (ring slots) per group
-void append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups) {
+// A plain layer [145 (row 144 = bias), 144 * groups] in column groups of nine tiles, five S units (ring slots) per group;
+// returns the power of two the matrix was packed with
+float append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups) {
   const int NT = 9 * groups;
-  const std::vector<float> sp = pack_split32(waug, 145, 144 * groups);
+  const float sw = matrix_scale(waug, 145, 144 * groups);
+  const std::vector<float> sp = pack_half32(waug, 145, 144 * groups, sw);
   for (int g = 0; g < groups; ++g)
     for (int st = 0; st < 5; ++st)
-      put_pp_slot(stream, kPpLayout_S0, [&](const PpFragDesc& d) { return sp.data() + (((size_t)st * NT + 9 * g + d.a) * 3 + d.term) * 256; });
+      put_pp_slot(stream, kPpLayout_S0, [&](const PpFragDesc& d) { return sp.data() + (((size_t)st * NT + 9 * g + d.a) * 2 + d.term) * 256; });
+  return sw;
 }
 
 
@@ -509,9 +554,9 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
       return v;
     }() : std::vector<float>(3 * d, 0.f);
     std::vector<float> pp;
-    append_pp_chain(pp, [&](int kk, int n) { return kk < d ? f1[(size_t)kk * 4 * d + n] : b1[n]; }, 4 * d,
-                    [&](int kk, int n) { return f2[(size_t)kk * d + n]; });
-    append_pp_plain(pp, [&](int kk, int n) { return kk < d ? qkv_at(kk, n) : qb[n]; }, 3);
+    o.pp_ff1_sc = append_pp_chain(pp, [&](int kk, int n) { return kk < d ? f1[(size_t)kk * 4 * d + n] : b1[n]; }, 4 * d,
+                                  [&](int kk, int n) { return f2[(size_t)kk * d + n]; });
+    o.pp_sw_qkv = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? qkv_at(kk, n) : qb[n]; }, 3);
     o.pp_ff1 = ab.put(pp);
   }
   const std::string c = p + "/conv_module";
@@ -575,11 +620,11 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
       for (int i = 0; i < 2 * d; ++i) { bs[i] = g[i] / std::sqrt(var[i] + kBnEps); bt[i] = b[i] - mu[i] * bs[i]; }
     }
     std::vector<float> pp;
-    append_pp_chain(pp, [&](int kk, int n) {
+    o.pp_tail_sc[0] = append_pp_chain(pp, [&](int kk, int n) {
       return kk < d ? (float)((double)pc[(size_t)kk * 2 * d + n] * (double)bs[n]) : (float)((double)pcb[n] * (double)bs[n] + (double)bt[n]);
     }, 2 * d, [&](int kk, int n) { return pw2[(size_t)kk * d + n]; });
-    append_pp_chain(pp, [&](int kk, int n) { return kk < d ? f1[(size_t)kk * 4 * d + n] : fb1[n]; }, 4 * d,
-                    [&](int kk, int n) { return f2[(size_t)kk * d + n]; });
+    o.pp_tail_sc[1] = append_pp_chain(pp, [&](int kk, int n) { return kk < d ? f1[(size_t)kk * 4 * d + n] : fb1[n]; }, 4 * d,
+                                      [&](int kk, int n) { return f2[(size_t)kk * d + n]; });
     o.pp_tail = ab.put(pp);
   }
   o.pw2_b = ab.put(T(c + "/pw_conv_2/bias"));
@@ -606,7 +651,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
-  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; }
+  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; }
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
   b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
@@ -788,7 +833,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       k1.ff_ln_g = bw.ff_ln_g[0]; k1.ff_ln_b = bw.ff_ln_b[0]; k1.ff_w1p = bw.ff_w1p[0]; k1.ff_b1 = bw.ff_b1[0];
       k1.ff_w2p = bw.ff_w2p[0]; k1.ff_b2 = bw.ff_b2[0];
       k1.att_ln_g = bw.att_ln_g; k1.att_ln_b = bw.att_ln_b; k1.qkv_wp = bw.qkv_wp; k1.qkv_b = bw.qkv_b;
-      k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M; k1.slabs = bw.ff1_slabs; k1.pp_slabs = bw.pp_ff1;
+      k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M; k1.slabs = bw.ff1_slabs; k1.pp_slabs = bw.pp_ff1; k1.pp_sc = bw.pp_ff1_sc; k1.pp_sw_qkv = bw.pp_sw_qkv;
       return k1;
     };
     if (!skip_ff1) {
@@ -818,7 +863,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k4.pc_w1p = w.pc_w1p; k4.pc_b1 = w.pc_b1; k4.bn_s = w.bn_s; k4.bn_t = w.bn_t; k4.pw2_wp = w.pw2_wp; k4.pw2_b = w.pw2_b;
     k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];
     k4.ff_w2p = w.ff_w2p[1]; k4.ff_b2 = w.ff_b2[1]; k4.ln_g = w.ln_g; k4.ln_b = w.ln_b;
-    k4.fc = fc; k4.eps = kLnEps; k4.M = M; k4.slabs = w.tail_slabs; k4.pp_slabs = w.pp_tail;
+    k4.fc = fc; k4.eps = kLnEps; k4.M = M; k4.slabs = w.tail_slabs; k4.pp_slabs = w.pp_tail; k4.pp_sc[0] = w.pp_tail_sc[0]; k4.pp_sc[1] = w.pp_tail_sc[1];
     if (next && !out && ff1_done && tail_ff1_available() && k4.slabs && next->ff1_slabs) {
       // the block output feeds only the next block's ff_module_1: keep it in registers, write x1 (into the buffer the
       // next block knows as sc.xb after the swap below -- this block's x2, which each workgroup has consumed) and qkv

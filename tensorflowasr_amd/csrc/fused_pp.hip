@@ -17,8 +17,21 @@
 //   * h is 2 x 2 tiles instead of 9 (+ 1 padding) tiles.
 // The stream itself (fragment order, pool slots, counted waits, ring-slot hand-over) is generated and checked by
 // tools/gen_pp.py -> pp_units.inc (device) / pp_layout.inc (host packing, api.hip: append_pp_chain).
-// Workgroup = 8 waves as in fused.hip: waves 0-3 consume (16 tokens each), waves 4-7 issue the slab DMAs; ring = 5 slots of
-// 30 fragments (30 KB).  Reference semantics: asr/models/conformer_blocks.py:126-134, :164-170, :209-219, :259-265.
+// Workgroup = 8 waves as in fused.hip: waves 0-3 consume (16 tokens each), waves 4-7 issue the slab DMAs; ring = 7 slots of
+// 20 fragments (20 KB).  Reference semantics: asr/models/conformer_blocks.py:126-134, :164-170, :209-219, :259-265.
+//
+// Operand scheme (round 3, second half): TWO fp16 terms, THREE products.  A weight matrix is streamed as hi + lo fp16 terms of
+// W * sw (sw = the power of two that puts max |W| in [2^14, 2^15); api.hip: append_pp_chain), an operand row x as hi + lo of
+// x * sx with sx the power of two that puts the ROW's largest magnitude in [2^13, 2^14) (pp_row_max: the rows are this lane's
+// token, so every scale is a per-lane register), hi = fp16(v), lo = fp16(v - hi), both round-to-nearest: |v - hi - lo| <=
+// 2^-22 |v| while lo is a normal fp16 (|v| >= 2^-2), 2^-25 absolute below.  a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi: three
+// v_mfma_f32_16x16x32_f16 per fragment pair; what is dropped (a_lo b_lo, the representation errors) is of the size of the
+// terms the six-product bf16 scheme dropped -- both sit at the same distance from the fp64 oracle (the error-corrected fp16
+// GEMM of Ootomo & Yokota; their second accumulator for the correction terms is what the power-of-two scales replace).
+// Accumulators carry sw * sx (hidden tiles) or sw2 * sh (outputs; sh = the power of two for the bound L1 * max|x| + max|b| of
+// the token's hidden row); the activation schedule takes the unit out inside its first and third instruction
+// (prep2_sched.inc), residuals are multiplied into the accumulator's unit when they are loaded, outputs are multiplied out
+// of it once per chain: powers of two, exact.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -34,28 +47,39 @@ constexpr int KB = D / 16;      // 9
 constexpr int KS32X = 5;        // 32-wide steps over K = 144 (+ the bias row 144)
 constexpr int LD_THREADS = 2 * BLOCK_THREADS;
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-struct Split8 { u32x4_t t[3]; };
+struct Split8 { u32x4_t t[2]; };             // 8 k-slots x (hi, lo) fp16 terms
 
-DEV Split8 split8(f32x4 lo, f32x4 hi) {      // exact: x = t0 + t1 + t2 (truncation, remainders are exact)
-  float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  Split8 f;
+DEV unsigned pp_pk_f16(float a, float b) {   // v_cvt_pk_f16_f32: both halves round to nearest
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));
+}
+DEV float pp_f16_lo(unsigned p) { return (float)__builtin_bit_cast(f16x2_t, p).x; }
+DEV float pp_f16_hi(unsigned p) { return (float)__builtin_bit_cast(f16x2_t, p).y; }
+DEV Split8 split8(f32x4 lo, f32x4 hi) {      // the values are already in the operand's unit (x * sx)
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  unsigned d0[4], d1[4];
 #pragma unroll
-  for (int term = 0; term < 3; ++term) {
-    unsigned d[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * k]), a1 = __builtin_bit_cast(unsigned, v[2 * k + 1]);
-      d[k] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
-      if (term < 2) {
-        v[2 * k] -= __builtin_bit_cast(float, a0 & 0xffff0000u);
-        v[2 * k + 1] -= __builtin_bit_cast(float, a1 & 0xffff0000u);
-      }
-    }
-    f.t[term] = u32x4_t{d[0], d[1], d[2], d[3]};
+  for (int k = 0; k < 4; ++k) {
+    d0[k] = pp_pk_f16(v[2 * k], v[2 * k + 1]);
+    d1[k] = pp_pk_f16(v[2 * k] - pp_f16_lo(d0[k]), v[2 * k + 1] - pp_f16_hi(d0[k]));
   }
+  Split8 f;
+  f.t[0] = u32x4_t{d0[0], d0[1], d0[2], d0[3]};
+  f.t[1] = u32x4_t{d1[0], d1[1], d1[2], d1[3]};
   return f;
+}
+// 2^k with bound * 2^k in [2^13, 2^14), k clamped to [-14, 15] (the scale itself is an fp16 operand: the bias slot), from the
+// exponent field of `bound` (>= 0; 0 gives 2^15)
+DEV float pp_pow2_scale(float bound) {
+  const int e = (int)((__builtin_bit_cast(unsigned, bound) >> 23) & 255u);          // bound in [2^(e - 127), 2^(e - 126))
+  const int k = min(15, max(-14, 140 - e));
+  return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+DEV float pp_recip_pow2(float s) {            // 1 / s for a power of two (exact; exponent field 1 .. 253)
+  return __builtin_bit_cast(float, 0x7f000000u - __builtin_bit_cast(unsigned, s));
 }
 #ifndef PP_DMA_AUX
 #define PP_DMA_AUX 0        // cache-policy bits of the slab DMAs (experiments: tools/build_variant.py ... -DPP_DMA_AUX=n)
@@ -148,18 +172,20 @@ DEV void ln_lds(f32x4 (&xs)[KB], const float* ga, const float* be, int g4, float
   for (int kb = 0; kb < KB; ++kb) xs[kb] = (xs[kb] - splat4(mean)) * splat4(rstd) * lds4(ga, kb, g4) + lds4(be, kb, g4);
 }
 
-// activation + exact three-term split of two finished hidden tiles, in slots of <= 2 instructions (prep_sched.inc)
-struct PrepCtx {
+// activation + two-term split of two finished hidden tiles, in slots of <= 2 instructions (prep2_sched.inc).  k1 = -log2 e /
+// (unit of the hidden accumulators), ik2 = that unit / (unit of the operand being built): per-lane values
+struct Prep2Ctx {
   f32x4 &lo, &hi;
-  const f32x4 &slo, &tlo, &shi, &thi;   // unused here (AFF = false): the BatchNorm is folded into the weight stream
   Split8& out;
+  float k1, ik2;
   float ta, tb, m0, m1;
+  unsigned hp;
 };
-template <bool AFF, bool FULL> struct PrepSlots;
-#include "prep_sched.inc"
+using PpPrep = Prep2Ctx;
+#include "prep2_sched.inc"
 
-DEV void pp_fake_prep(PrepCtx& pc) {     // DG bit 0: consumes the hidden tiles and defines the operand without any work
-  asm volatile("; no prep" : "=v"(pc.out.t[0]), "=v"(pc.out.t[1]), "=v"(pc.out.t[2]) : "v"(pc.lo), "v"(pc.hi));
+DEV void pp_fake_prep(PpPrep& pc) {      // DG bit 0: consumes the hidden tiles and defines the operand without any work
+  asm volatile("; no prep" : "=v"(pc.out.t[0]), "=v"(pc.out.t[1]) : "v"(pc.lo), "v"(pc.hi));
 }
 // ---- the generated units ---------------------------------------------------------------------------------------------------
 // DG (diagnostics, timing only -- wrong results; instantiated only with -DMI355ASR_DIAG_KERNELS and selected by
@@ -173,20 +199,20 @@ DEV void pp_fake_prep(PrepCtx& pc) {     // DG bit 0: consumes the hidden tiles 
 #define PP_WT3(N, S0, S1, S2) \
   do { if constexpr (!(DG & 2)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(pl.f[S0]), "+v"(pl.f[S1]), "+v"(pl.f[S2])); } while (0)
 #define PP_MM(ACC, S, X) \
-  do { if constexpr (!(DG & 4)) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pl.f[S]), __builtin_bit_cast(bf16x8_t, X), ACC, 0, 0, 0); } while (0)
+  do { if constexpr (!(DG & 4)) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, pl.f[S]), __builtin_bit_cast(f16x8_t, X), ACC, 0, 0, 0); } while (0)
 // bit 6 (timing only): without the three products of order 2^-16 -- the MFMA count of a two-term operand scheme
 #define PP_MM2(ACC, S, X) do { if constexpr (!(DG & 64)) PP_MM(ACC, S, X); } while (0)
 #define PP_PREP(K) \
-  do { if constexpr (!(DG & 1)) prep_slot<K, false, true>(pc); else if constexpr (K == 47) pp_fake_prep(pc); } while (0)
+  do { if constexpr (!(DG & 1)) prep2_slot<K>(pc); else if constexpr (K == PREP2_SLOTS - 1) pp_fake_prep(pc); } while (0)
 #define PP_FENCE __builtin_amdgcn_sched_barrier(0)
 #include "pp_units.inc"
 
-constexpr int PP_FR = 30;                 // fragments per ring slot (pp_layout.inc: kPpSlot)
-constexpr int PP_SLB = PP_FR * 64;        // u32x4 per ring slot (30 KB)
-constexpr int PP_RING = 5;
+constexpr int PP_FR = 20;                 // fragments per ring slot (pp_layout.inc: kPpSlot)
+constexpr int PP_SLB = PP_FR * 64;        // u32x4 per ring slot (20 KB)
+constexpr int PP_RING = 7;
+constexpr int PP_PER = PP_FR / 4;         // 1 KB pieces of a slab per loader wave
 
-// waves 4..7: fragment f of a slab is fetched by loader wave f % 4 -- waves 0, 1 issue eight 1 KB pieces per slab, waves 2, 3
-// seven -- into the ring slot the consumers read in the previous step; "slab s + 2 has landed" (this wave's pieces: counted
+// waves 4..7: fragment f of a slab is fetched by loader wave f % 4 -- five 1 KB pieces per slab and wave -- into the ring slot the consumers read in the previous step; "slab s + 2 has landed" (this wave's pieces: counted
 // vmcnt) before the barrier that ends step s, so that the consumers' fragment pipeline may run into slab s + 1 during step s.
 template <int RING, int DG>
 struct PpLoader {
@@ -237,7 +263,7 @@ struct PpLoader {
   }
   template <int PRE0, class PRO>
   DEV void run(PRO&& pro) const {
-    if (wv < 2) run_<8, PRE0>(pro); else run_<7, PRE0>(pro);
+    run_<PP_PER, PRE0>(pro);
   }
   DEV void run() const { run<RING - 1>([] {}); }
 };
@@ -266,16 +292,16 @@ struct PpReader {               // waves 0..3
 // y += W2 swish(W1aug [x ; 1]) over P hidden pairs (2 P ring slots): units A, AP, P - 2 x F, BP, B.  h0 / h1 and f0 / f1
 // swap roles from unit to unit (accumulate <-> being prepared, operand in use <-> operand being built).
 template <int P, int DG, class ST>
-DEV void pp_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS32X], PpPool& pl, ST& st) {
+DEV void pp_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS32X], PpPool& pl, ST& st, float k1, float ik2) {
   static_assert(P >= 3, "at least one full unit");
   f32x4 h0[2], h1[2];
   Split8 f0, f1;
-  const f32x4 one = splat4(1.f), zero = splat4(0.f);
+  const f32x4 zero = splat4(0.f);
   h0[0] = zero; h0[1] = zero;
   pp_unit_A<DG>(h0, xf, pl, st);                                   // h(0)
   h1[0] = zero; h1[1] = zero;
   {
-    PrepCtx pc{h0[0], h0[1], one, zero, one, zero, f0, 0.f, 0.f, 0.f, 0.f};
+    PpPrep pc{h0[0], h0[1], f0, k1, ik2, 0.f, 0.f, 0.f, 0.f, 0u};
     pp_unit_AP<DG>(h1, xf, pc, pl, st);                            // h(1) ; hf(0)
   }
   constexpr int NF = P - 2;
@@ -283,43 +309,67 @@ DEV void pp_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS32X], PpPool& pl, ST& st)
   for (int i = 0; i < NF / 2; ++i) {
     h0[0] = zero; h0[1] = zero;
     {
-      PrepCtx pc{h1[0], h1[1], one, zero, one, zero, f1, 0.f, 0.f, 0.f, 0.f};
+      PpPrep pc{h1[0], h1[1], f1, k1, ik2, 0.f, 0.f, 0.f, 0.f, 0u};
       pp_unit_F<DG>(y, h0, xf, f0, pc, pl, st);                    // p even: B(p) with f0, A(p + 2) -> h0, h1 -> f1
     }
     h1[0] = zero; h1[1] = zero;
     {
-      PrepCtx pc{h0[0], h0[1], one, zero, one, zero, f0, 0.f, 0.f, 0.f, 0.f};
+      PpPrep pc{h0[0], h0[1], f0, k1, ik2, 0.f, 0.f, 0.f, 0.f, 0u};
       pp_unit_F<DG>(y, h1, xf, f1, pc, pl, st);                    // p odd: B(p) with f1, A(p + 2) -> h1, h0 -> f0
     }
   }
   if constexpr (NF & 1) {
     h0[0] = zero; h0[1] = zero;
     {
-      PrepCtx pc{h1[0], h1[1], one, zero, one, zero, f1, 0.f, 0.f, 0.f, 0.f};
+      PpPrep pc{h1[0], h1[1], f1, k1, ik2, 0.f, 0.f, 0.f, 0.f, 0u};
       pp_unit_F<DG>(y, h0, xf, f0, pc, pl, st);
     }
     {
-      PrepCtx pc{h0[0], h0[1], one, zero, one, zero, f0, 0.f, 0.f, 0.f, 0.f};
+      PpPrep pc{h0[0], h0[1], f0, k1, ik2, 0.f, 0.f, 0.f, 0.f, 0u};
       pp_unit_BP<DG>(y, f1, pc, pl, st);                           // B(P - 2) with f1 ; h(P - 1) -> f0
     }
     pp_unit_B<DG>(y, f0, pl, st);
   } else {
     {
-      PrepCtx pc{h1[0], h1[1], one, zero, one, zero, f1, 0.f, 0.f, 0.f, 0.f};
+      PpPrep pc{h1[0], h1[1], f1, k1, ik2, 0.f, 0.f, 0.f, 0.f, 0u};
       pp_unit_BP<DG>(y, f0, pc, pl, st);                           // B(P - 2) with f0 ; h(P - 1) -> f1
     }
     pp_unit_B<DG>(y, f1, pl, st);
   }
 }
 
-// the five split operands of a 16-token tile for the W1 steps; k-slot 144 (the first padding slot of step 4) carries 1.0:
-// row 144 of the streamed W1 holds the bias
-DEV void split_operand(Split8 (&xf)[KS32X], const f32x4 (&xs)[KB], int g4) {
+// largest magnitude of this lane's token row (the row is spread over the four lanes c, c + 16, c + 32, c + 48)
+DEV float pp_row_max(const f32x4 (&xs)[KB]) {
+  float m = 0.f;
 #pragma unroll
-  for (int t = 0; t < KS32X - 1; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
+  for (int i = 0; i < KB; ++i)
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(xs[i].x), fabsf(xs[i].y))), fmaxf(fabsf(xs[i].z), fabsf(xs[i].w)));
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  return m;
+}
+// scales of one chain y += W2 act(W1aug [x ; 1]) for this lane's token (ChainSc: the chain's host-side constants)
+struct PpTok { float sx, k1, ik2, s2, inv2; };
+DEV PpTok pp_chain_scales(const PpChainSc& c, float xmax) {
+  PpTok t;
+  t.sx = pp_pow2_scale(xmax);
+  const float sh = pp_pow2_scale(fmaf(c.l1, xmax, c.bmax));      // |swish(h)| <= |h| <= l1 max|x| + max|b|
+  const float u1 = c.sw1 * t.sx;                                  // unit of the hidden accumulators
+  t.k1 = -1.4426950408889634f * pp_recip_pow2(u1);
+  t.ik2 = u1 * pp_recip_pow2(sh);
+  t.s2 = c.sw2 * sh;                                              // unit of the output accumulators
+  t.inv2 = pp_recip_pow2(t.s2);
+  return t;
+}
+// the five split operands of a 16-token tile for the W1 steps, in units of sx; k-slot 144 (the first padding slot of step 4)
+// carries 1.0 (= sx in those units): row 144 of the streamed W1 holds the bias
+DEV void split_operand(Split8 (&xf)[KS32X], const f32x4 (&xs)[KB], int g4, float sx) {
+  const f32x4 s4 = splat4(sx);
+#pragma unroll
+  for (int t = 0; t < KS32X - 1; ++t) xf[t] = split8(xs[2 * t] * s4, xs[2 * t + 1] * s4);
   f32x4 oh = splat4(0.f);
-  oh.x = g4 == 0 ? 1.0f : 0.0f;
-  xf[KS32X - 1] = split8(xs[KB - 1], oh);
+  oh.x = g4 == 0 ? sx : 0.0f;
+  xf[KS32X - 1] = split8(xs[KB - 1] * s4, oh);
 }
 
 struct PpTailLds { float pw2b[D], lng[D], lnb[D], b2[D], fg[D], fb[D]; };
@@ -344,22 +394,29 @@ constexpr int PP_FF1_SLABS = 2 * 18 + 3 * KS32X;  // ff_module_1 (18 pairs) + q,
 // conv-module tail + ff_module_2 + block-final LayerNorm: xs = dw rows, y = x2 rows on entry; y = the block's output on exit
 template <int DG, class ST>
 DEV void pp_tail_consume(const TailFf2Args& a, const PpTailLds& p, int g4, ST& st, PpPool& pl, f32x4 (&xs)[KB], f32x4 (&y)[KB]) {
-#pragma unroll
-  for (int i = 0; i < KB; ++i) y[i] += lds4(p.pw2b, i, g4);
   Split8 xf[KS32X];
-  split_operand(xf, xs, g4);
-  pp_chain<9, DG>(y, xf, pl, st);                                                        // x3 = x2 + conv module
+  {
+    const PpTok t = pp_chain_scales(a.pp_sc[0], pp_row_max(xs));
+#pragma unroll
+    for (int i = 0; i < KB; ++i) y[i] = (y[i] + lds4(p.pw2b, i, g4)) * splat4(t.s2);
+    split_operand(xf, xs, g4, t.sx);
+    pp_chain<9, DG>(y, xf, pl, st, t.k1, t.ik2);                                         // x3 = x2 + conv module
+#pragma unroll
+    for (int i = 0; i < KB; ++i) y[i] = y[i] * splat4(t.inv2);
+  }
   const float inv_fc = 1.0f / a.fc;
 #pragma unroll
-  for (int i = 0; i < KB; ++i) {
-    xs[i] = y[i];
-    y[i] = lds4(p.b2, i, g4) + splat4(inv_fc) * y[i];                                // x3 / fc + b2 (+ W2 h)
-  }
+  for (int i = 0; i < KB; ++i) xs[i] = y[i];
   ln_lds(xs, p.lng, p.lnb, g4, a.eps);
-  split_operand(xf, xs, g4);
-  pp_chain<18, DG>(y, xf, pl, st);
+  {
+    const PpTok t = pp_chain_scales(a.pp_sc[1], pp_row_max(xs));
 #pragma unroll
-  for (int i = 0; i < KB; ++i) y[i] = splat4(a.fc) * y[i];
+    for (int i = 0; i < KB; ++i) y[i] = (lds4(p.b2, i, g4) + splat4(inv_fc) * y[i]) * splat4(t.s2);   // x3 / fc + b2 (+ W2 h)
+    split_operand(xf, xs, g4, t.sx);
+    pp_chain<18, DG>(y, xf, pl, st, t.k1, t.ik2);
+#pragma unroll
+    for (int i = 0; i < KB; ++i) y[i] = splat4(a.fc * t.inv2) * y[i];
+  }
   ln_lds(y, p.fg, p.fb, g4, a.eps);                                                  // block-final LayerNorm
 }
 
@@ -372,10 +429,15 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
   for (int kb = 0; kb < KB; ++kb) y[kb] = lds4(p.b2, kb, g4) + splat4(inv_fc) * xs[kb];
   ln_lds(xs, p.ln1g, p.ln1b, g4, a.eps);
   Split8 xf[KS32X];
-  split_operand(xf, xs, g4);
-  pp_chain<18, DG>(y, xf, pl, st);
+  {
+    const PpTok t = pp_chain_scales(a.pp_sc, pp_row_max(xs));
 #pragma unroll
-  for (int i = 0; i < KB; ++i) { y[i] = splat4(a.fc) * y[i]; xs[i] = y[i]; }        // x1 = x0 + fc * (ffn + b2)
+    for (int i = 0; i < KB; ++i) y[i] = y[i] * splat4(t.s2);
+    split_operand(xf, xs, g4, t.sx);
+    pp_chain<18, DG>(y, xf, pl, st, t.k1, t.ik2);
+#pragma unroll
+    for (int i = 0; i < KB; ++i) { y[i] = splat4(a.fc * t.inv2) * y[i]; xs[i] = y[i]; }   // x1 = x0 + fc * (ffn + b2)
+  }
   {
     const WaveCtx e = wave_ctx_fresh(a.M, T);
     if (e.live) {
@@ -384,7 +446,9 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
     }
   }
   ln_lds(xs, p.ln2g, p.ln2b, g4, a.eps);
-  split_operand(xf, xs, g4);                                                         // the q / k / v bias rides in row 144 too
+  const float sx = pp_pow2_scale(pp_row_max(xs));
+  split_operand(xf, xs, g4, sx);                                                     // the q / k / v bias rides in row 144 too
+  const float invq = pp_recip_pow2(a.pp_sw_qkv * sx);
 #pragma unroll 1
   for (int q = 0; q < 3; ++q) {
     f32x4 acc[KB];
@@ -394,7 +458,7 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
       constexpr int t = decltype(T)::value;
       pp_unit_S<DG>(acc, xf[t], pl, st);
     });
-    const float sc = q == 0 ? a.qscale : 1.0f;
+    const float sc = (q == 0 ? a.qscale : 1.0f) * invq;
     const WaveCtx e = wave_ctx_fresh(a.M, T);
     if (e.live) {
       float* qrow = a.qkv + (size_t)e.tok * (3 * D) + 16 * q * KB + e.g4;

@@ -239,6 +239,9 @@ int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 bool gemm_ring_applicable(int epi, bool ln, const Gemm16Args& a);
 int launch_gemm_ring(int epi, bool ln, const Gemm16Args& a, const void* ring, int terms, hipStream_t s);   // terms: 3 (fp32) or 1 (bf16 mode)
 // block-level fused kernels (fused.hip, dmodel 144)
+// host-side constants of one pair-pipelined chain y += W2 act(W1aug [x ; 1]) in the two-term fp16 scheme (fused_pp.hip): the
+// powers of two the streamed matrices were multiplied by, the largest column L1 norm of W1 and the largest |bias| (row 144)
+struct PpChainSc { float sw1 = 1.f, sw2 = 1.f, l1 = 0.f, bmax = 0.f; };
 struct Ff1QkvArgs {
   const float* x0; float* x1; float* qkv;
   const float *ff_ln_g, *ff_ln_b, *ff_w1p, *ff_b1, *ff_w2p, *ff_b2;
@@ -246,7 +249,9 @@ struct Ff1QkvArgs {
   float fc, qscale, eps;
   int M;
   const float* slabs = nullptr;   // slab stream of ff1_qkv_ring_kernel (55 slabs of 1792 fragments), or null
-  const float* pp_slabs = nullptr;   // pair-pipelined stream (fused_pp.hip: 51 ring slots of 30 fragments; biases in row 144), or null
+  const float* pp_slabs = nullptr;   // pair-pipelined stream (fused_pp.hip: 51 ring slots of 20 fragments; biases in row 144), or null
+  PpChainSc pp_sc;                   // ... the scales its ff_module_1 chain was packed with (api.hip: append_pp_chain)
+  float pp_sw_qkv = 1.f;             // ... and its q / k / v matrix
 };
 struct OutGluArgs {
   const float* ctx; const float* x1; float* x2; float* u;
@@ -264,6 +269,7 @@ struct TailFf2Args {
   int M;
   const float* slabs = nullptr;   // slab stream of tail_ff2_ring_kernel (60 slabs of 1792 fragments), or null
   const float* pp_slabs = nullptr;   // pair-pipelined stream (fused_pp.hip: 54 ring slots; BatchNorm and biases folded into W1), or null
+  PpChainSc pp_sc[2];                // ... the scales of its conv-tail chain and of its ff_module_2 chain
   // depthwise conv folded into the pair-pipelined kernel's prologue (fused_pp.hip): when dw_u is set, `dw` is not read -- the
   // kernel tiles the tokens per utterance (64-token chunks of the dw_T frames of each of M / dw_T utterances) and computes
   // dw = depthwise_k32(u) (taps dw_wd [32, 144], dw_pad zeros in front) from a 95-row window in LDS

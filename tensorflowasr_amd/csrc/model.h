@@ -65,6 +65,8 @@ struct BlockDev {
   const float *out_ws = nullptr, *pw1_ws = nullptr, *og_slabs = nullptr, *ff1_slabs = nullptr, *tail_slabs = nullptr;
   // the pair-pipelined streams of fused_pp.hip (ff_module_1 + qkv ; conv tail + ff_module_2), or null
   const float *pp_ff1 = nullptr, *pp_tail = nullptr;
+  PpChainSc pp_ff1_sc, pp_tail_sc[2];      // the scales those streams were packed with (two-term fp16 scheme)
+  float pp_sw_qkv = 1.f;
 };
 
 struct Dims {
@@ -220,6 +222,8 @@ struct BlockOff {
   size_t cv_ln_g, cv_ln_b, pw1_wp, pw1_b, dw_w, pc_w1p, pc_b1, bn_s, bn_t, pw2_wp, pw2_b;
   size_t ln_g, ln_b;
   size_t out_ws = 0, pw1_ws = 0, og_slabs = 0, ff1_slabs = 0, tail_slabs = 0, pp_ff1 = 0, pp_tail = 0;
+  PpChainSc pp_ff1_sc, pp_tail_sc[2];
+  float pp_sw_qkv = 1.f;
   bool split = false;
 };
 
@@ -262,8 +266,8 @@ std::vector<float> pack_linear_split(const std::vector<float>& lin, int K, int d
 void append_slabs(std::vector<float>& stream, const std::function<float(int, int)>& f, int K, int N, bool group_major);
 // pair-pipelined stream of one chain y += W2 act(W1 x + b1) (fused_pp.hip, tools/gen_pp.py): w1(k, n) with k <= K1 (row K1 = the
 // bias), H hidden features, w2(k, n) [H, 144]; and of a plain layer [145, 144 G] in column groups of nine tiles
-void append_pp_chain(std::vector<float>& stream, const std::function<float(int, int)>& w1aug, int H, const std::function<float(int, int)>& w2);
-void append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups);
+PpChainSc append_pp_chain(std::vector<float>& stream, const std::function<float(int, int)>& w1aug, int H, const std::function<float(int, int)>& w2);
+float append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups);
 // W[K, N] as the slab ring of gemm_ring.hip, registered in ab.ring_pairs against the P16 pack at p16_off
 void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int N, bool glu);
 void put_ring_head(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int V);

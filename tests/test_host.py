@@ -745,14 +745,15 @@ def test_pair_pipelined_stream_generator_simulates_and_matches_the_committed_sou
     units, leads = g.build_all()                       # raises on any slot / count / coverage error
     assert {u.name for u in units} == {"A", "AP", "F", "BP", "B", "S"}
     by = {u.name: u for u in units}
-    assert (by["F"].nm, by["A"].nm, by["B"].nm) == (114, 60, 54) and by["F"].nslabs == 2
+    # the two-term fp16 scheme: three products per fragment pair (the three-term bf16 stream had 114 / 60 / 54 MFMAs)
+    assert g.TERMS == 2 and (by["F"].nm, by["A"].nm, by["B"].nm) == (57, 30, 27) and by["F"].nslabs == 2
     assert all(u.length % g.NPOOL == 0 and max(len(s) for s in u.slabs) <= g.SLOT for u in units)
-    assert min(leads.values()) >= 7                    # no fragment is requested less than 7 MFMAs before its first use
+    assert min(leads.values()) >= 5                    # no fragment is requested less than 5 MFMAs before its first use
     csrc = os.path.join(root, "tensorflowasr_amd", "csrc")
     assert open(os.path.join(csrc, "pp_units.inc")).read() == g.emit_units(units) + "\n"
     assert open(os.path.join(csrc, "pp_layout.inc")).read() == g.emit_layout(units)
     # a chain of P hidden pairs = units A, AP, (P - 2) x F, BP, B = 2 P ring slots; every MFMA of the FFN (18 pairs) once
-    assert by["A"].nm + by["AP"].nm + 16 * by["F"].nm + by["BP"].nm + by["B"].nm == 2052
+    assert by["A"].nm + by["AP"].nm + 16 * by["F"].nm + by["BP"].nm + by["B"].nm == 1026
 
 
 def test_log_sum_exp_kernels_of_the_device_beam_search_round_like_libm():

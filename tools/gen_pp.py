@@ -28,15 +28,22 @@ and that every (accumulator tile, k-step) receives its six term pairs exactly on
 import os
 import sys
 
-NPOOL = int(os.environ.get("PP_NPOOL", "9"))     # fragment registers of a wave (the pool); 9 / 12 / 15 / 18 measure the same on the GPU
-SLOT = 30          # fragments (KB) per ring slot
-NPREP = 48         # slots of the activation + split schedule (prep_sched.inc, AFF = false, FULL = true)
+# Operand scheme (round 3, second half): TERMS = 2 -- fp32 operands as hi + lo fp16 terms of power-of-two scaled values, the
+# three products (lo, hi), (hi, lo), (hi, hi) per fragment pair; TERMS = 3 (PP_TERMS=3: the first version, kept for the record
+# of profiles/r03_pp_experiments.md) -- three bf16 terms, six products.  Everything below is written for either.
+TERMS = int(os.environ.get("PP_TERMS", "2"))
+NPOOL = int(os.environ.get("PP_NPOOL", "10" if TERMS == 2 else "9"))     # fragment registers of a wave (the pool)
+SLOT = 10 * TERMS  # fragments (KB) per ring slot
+NPREP = 40 if TERMS == 2 else 48    # slots of the activation + split schedule (prep2_sched.inc / prep_sched.inc)
+TOP = TERMS - 1    # highest term index
+# products of a fragment pair, by weight term: x terms it meets, smallest product first
+XT = {t: list(range(TOP - t, -1, -1)) for t in range(TERMS)}      # weight term t meets x terms TOP - t .. 0
 
 
 def a_block(k):
     """W1 step k for the two tiles of a pair: fragments (tile, term) in use order, batches = (positions, x terms)"""
-    frags = [("A", k, 0, 2), ("A", k, 1, 2), ("A", k, 0, 1), ("A", k, 1, 1), ("A", k, 0, 0), ("A", k, 1, 0)]
-    batches = [([0, 1], [0]), ([2, 3], [1, 0]), ([4, 5], [2, 1, 0])]
+    frags = [("A", k, b, t) for t in range(TOP, -1, -1) for b in (0, 1)]
+    batches = [([2 * i, 2 * i + 1], XT[t]) for i, t in enumerate(range(TOP, -1, -1))]
     acc = lambda f: "ha[%d]" % f[2]
     x = lambda t: "xf[%d].t[%d]" % (k, t)
     return frags, batches, acc, x
@@ -44,8 +51,8 @@ def a_block(k):
 
 def b_block(cg, kind):
     """column group cg (tiles 3 cg .. 3 cg + 2) of one 32-wide step: kind 'B' (W2 of a pair, operand hfc) or 'S' (plain slab, operand xs)"""
-    frags = [(kind, 3 * cg + i, 0, term) for term in (2, 1, 0) for i in range(3)]
-    batches = [([0, 1, 2], [0]), ([3, 4, 5], [1, 0]), ([6, 7, 8], [2, 1, 0])]
+    frags = [(kind, 3 * cg + i, 0, term) for term in range(TOP, -1, -1) for i in range(3)]
+    batches = [([3 * i, 3 * i + 1, 3 * i + 2], XT[t]) for i, t in enumerate(range(TOP, -1, -1))]
     accname = "y" if kind == "B" else "acc"
     acc = lambda f: "%s[%d]" % (accname, f[1])
     xname = "hfc" if kind == "B" else "xs"
@@ -66,10 +73,12 @@ UNITS = {
     "B": ([[("B", 0), ("B", 1), ("B", 2)]], False),
     "S": ([[("S", 0), ("S", 1), ("S", 2)]], False),
 }
-VPADS = {
+VPADS3 = {
     9: {"A": (11, 16, 17, 19, 20, 22), "AP": (11, 16, 17, 19, 20, 22), "F": (15, 28, 35, 38, 41, 48), "BP": (), "B": (), "S": ()},
     15: {"A": (), "AP": (), "F": (21, 27, 42), "BP": (15, 15, 15), "B": (15, 15, 15), "S": (15, 15, 15)},
 }
+VPADS2 = {10: {"A": (), "AP": (), "F": (13, 27), "BP": (10, 10), "B": (10, 10), "S": (10, 10)}}
+VPADS = VPADS2 if TERMS == 2 else VPADS3
 
 
 class Unit:
@@ -113,7 +122,8 @@ class Unit:
             first, last = 3, nm - 2
             for s in range(NPREP):
                 prep_at.setdefault(first + (s * (last - first)) // (NPREP - 1), []).append(s)
-            assert all(len(v) == 1 for v in prep_at.values()), "more than one prep slot behind an MFMA"
+            # the two-term units AP (30 MFMAs) and BP (27) are shorter than the schedule: two slots behind most of their MFMAs
+            assert all(len(v) <= -(-NPREP // (last - first + 1)) for v in prep_at.values()), "prep slots bunch up behind an MFMA"
         issued = []            # read log: (target position or 'dummy', slab index of the read, unit-relative slab, off)
         self.ops = ops
         cur_slab = 0
@@ -195,7 +205,7 @@ def simulate(u):
             old = pool[slot]["pos"]
             if old is not None and old < L and u.pos[old] is not None:
                 f = u.pos[old]["frag"]
-                need = {2: 1, 1: 2, 0: 3}[f[3]]
+                need = len(XT[f[3]])
                 assert used.get(old, 0) == need, "slot %d reused before position %d finished (%s uses)" % (slot, old, used.get(old, 0))
             assert old is None or (q - old) % NPOOL == 0 and q > old, (old, q)
             for mid in range(old + NPOOL, q, NPOOL):
@@ -220,7 +230,7 @@ def simulate(u):
             _, acc, slot, x, q, xt = op
             assert pool[slot]["pos"] == q and pool[slot]["landed"], "MFMA %d reads slot %d before position %d landed" % (mi, slot, q)
             f = u.pos[q]["frag"]
-            assert f[3] + xt <= 2
+            assert f[3] + xt <= TOP
             key = (acc, f[0], f[1] if f[0] == "A" else None)
             products.setdefault(key, []).append((f[3], xt))
             if used.get(q, 0) == 0 and issue_mi[q] is not None:
@@ -236,11 +246,11 @@ def simulate(u):
             for p in u.pos:
                 if p is not None and p["slab"] == cur_slab:
                     q = u.pos.index(p)
-                    need = {2: 1, 1: 2, 0: 3}[p["frag"][3]]
+                    need = len(XT[p["frag"][3]])
                     assert used.get(q, 0) == need, "ring slot handed over before position %d was multiplied" % q
             cur_slab += 1
     assert cur_slab == u.nslabs
-    want = sorted([(2, 0), (1, 1), (1, 0), (0, 2), (0, 1), (0, 0)])
+    want = sorted((t, x) for t in range(TERMS) for x in XT[t])
     for key, prods in products.items():
         assert sorted(prods) == want, (key, prods)
     # every fragment of every slab was multiplied
@@ -267,7 +277,7 @@ def emit_units(units):
     w = out.append
     w("// GENERATED by tools/gen_pp.py -- do not edit.  One function per unit kind of the pair-pipelined stream (see the")
     w("// generator's docstring).  Macros (fused_pp.hip): PP_RD(slot, addr, OFF) = ds_read_b128 into pool slot; PP_WTn(N, slots...) =")
-    w("// s_waitcnt lgkmcnt(N) tied to the slots; PP_MM(acc, slot, x) = one v_mfma_f32_16x16x32_bf16 (PP_MM2: a product of order 2^-16); PP_PREP(k) = slot k of the")
+    w("// s_waitcnt lgkmcnt(N) tied to the slots; PP_MM(acc, slot, x) = one v_mfma_f32_16x16x32_f16 / _bf16 (PP_MM2, three-term scheme only: a product of order 2^-16); PP_PREP(k) = slot k of the")
     w("// activation + split schedule on (pc.lo, pc.hi) -> pc.out; PP_FENCE = sched_barrier(0).")
     w("constexpr int PP_NPOOL = %d;" % NPOOL)
     w("struct PpPool { u32x4_t f[PP_NPOOL]; };")
@@ -286,9 +296,9 @@ def emit_units(units):
     for u in units:
         args = {
             "A": "f32x4 (&ha)[2], const Split8 (&xf)[KS32X]",
-            "AP": "f32x4 (&ha)[2], const Split8 (&xf)[KS32X], PrepCtx& pc",
-            "F": "f32x4 (&y)[KB], f32x4 (&ha)[2], const Split8 (&xf)[KS32X], const Split8& hfc, PrepCtx& pc",
-            "BP": "f32x4 (&y)[KB], const Split8& hfc, PrepCtx& pc",
+            "AP": "f32x4 (&ha)[2], const Split8 (&xf)[KS32X], PpPrep& pc",
+            "F": "f32x4 (&y)[KB], f32x4 (&ha)[2], const Split8 (&xf)[KS32X], const Split8& hfc, PpPrep& pc",
+            "BP": "f32x4 (&y)[KB], const Split8& hfc, PpPrep& pc",
             "B": "f32x4 (&y)[KB], const Split8& hfc",
             "S": "f32x4* acc, const Split8& xs",
         }[u.name]
@@ -310,7 +320,7 @@ def emit_units(units):
             elif op[0] == "mm":
                 _, acc, slot, x, q, xt = op
                 order = u.pos[q]["frag"][3] + xt       # 0, 1 or 2: which power of 2^-8 the product carries
-                w("  %s(%s, %d, %s);" % ("PP_MM2" if order == 2 else "PP_MM", acc, slot, x))
+                w("  %s(%s, %d, %s);" % ("PP_MM2" if order == 2 and TERMS == 3 else "PP_MM", acc, slot, x))
             elif op[0] == "prep":
                 w("  PP_FENCE; PP_PREP(%d); PP_FENCE;" % op[1])
             elif op[0] == "adv":
@@ -325,7 +335,7 @@ def emit_layout(units):
     w = out.append
     w("// GENERATED by tools/gen_pp.py -- do not edit.  Host-side layout of the pair-pipelined stream: for every unit kind the")
     w("// fragments of its ring slots in LDS order.  kind 0 = padding, 1 = A (W1 step a, local tile b of the pair), 2 = B (W2 step")
-    w("// of the pair, column tile a), 3 = S (plain step, column tile a of the group of nine); term = bf16 term.")
+    w("// of the pair, column tile a), 3 = S (plain step, column tile a of the group of nine); term = operand term (0 = hi).")
     w("struct PpFragDesc { unsigned char kind, a, b, term; };")
     w("constexpr int kPpSlot = %d;" % SLOT)
     code = {"A": 1, "B": 2, "S": 3}
@@ -354,7 +364,7 @@ def search(name, iters=4000, seed=0):
     import itertools
     import random
     blocks = [b for slab in UNITS[name][0] for b in slab]
-    nreal = sum(6 if k == "A" else 9 for k, _ in blocks)
+    nreal = sum((2 if k == "A" else 3) * TERMS for k, _ in blocks)
     nv = (-nreal) % NPOOL
     if nv == 0:
         return ()
