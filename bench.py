@@ -45,6 +45,11 @@ def kernel_peak(name):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     ring = {"ff1_qkv": ("MI355ASR_FF1QKV_RING", "2"), "tail_ff2": ("MI355ASR_TAILFF2_RING", "2"), "out_glu": ("MI355ASR_OUTGLU_SPLIT", "3"),
             "tail_ff1": ("MI355ASR_TAILFF2_RING", "2"), "ctc_head": ("MI355ASR_HEAD_RING", "1")}
+    pp_env = {"out_glu": "MI355ASR_PP_OUTGLU", "ctc_head": "MI355ASR_PP_HEAD"}
+    if name in ("ff1_qkv", "tail_ff2", "tail_ff1", "out_glu", "ctc_head") and int(os.environ.get("MI355ASR_PP", "1") or 0) \
+            and int(os.environ.get(*ring[name]) or 0) and int(os.environ.get(pp_env.get(name, "MI355ASR_PP"), "1") or 0):
+        # the kernels of fused_pp.hip run the two-term scheme
+        return PEAK_HALF2_TFLOPS, "fp16 MFMA x3 (fp32 operands as two fp16 terms)"
     if name in ring and int(os.environ.get(*ring[name]) or 0):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     if name == "stft" and int(os.environ.get("MI355ASR_FFT", "1") or 0) and int(os.environ.get("MI355ASR_FFT_SPLIT", "1") or 0):
@@ -352,7 +357,7 @@ def extra_config5(lib, device, steps=5, with_cpu=True):
     kern = {}
     for n, (ms_step, launches) in prof.items():
         f = fl.get(n, 0.0)
-        peak = PEAK_SPLIT3_TFLOPS if n in split else PEAK_FP32_MFMA_TFLOPS
+        peak = kernel_peak(n)[0] if n in ("tail_ff1", "tail_ff2", "ff1_qkv", "out_glu", "ctc_head") else (PEAK_SPLIT3_TFLOPS if n in split else PEAK_FP32_MFMA_TFLOPS)
         kern[n] = {"launches_per_step": launches, "ms_per_step": round(ms_step, 4),
                    "tflops": round(f / (ms_step * 1e-3) / 1e12, 2) if f else None,
                    "frac_of_peak": round(f / (ms_step * 1e-3) / 1e12 / peak, 4) if f else None}
@@ -363,7 +368,7 @@ def extra_config5(lib, device, steps=5, with_cpu=True):
            "pipelined": {"ms_per_step": round(t_pipe * 1e3, 3), "frames_per_s": round(B * 3000 / t_pipe, 1),
                          "how": "beam search of batch n on a second stream (helper thread) while batch n + 1 is predicted (models.ChunkBeamPipeline)"},
            "roofline": {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"],
-                        "peak": round(PEAK_SPLIT3_TFLOPS if dom in split else PEAK_FP32_MFMA_TFLOPS, 1), "unit": "TFLOP/s",
+                        "peak": round(kernel_peak(dom)[0] if dom in ("tail_ff1", "tail_ff2", "ff1_qkv", "out_glu", "ctc_head") else (PEAK_SPLIT3_TFLOPS if dom in split else PEAK_FP32_MFMA_TFLOPS), 1), "unit": "TFLOP/s",
                         "frac": kern[dom]["frac_of_peak"], "traffic": None,
                         "note": "categories of predict() summed over their launches of one step; the prefix beam search is a latency "
                                 "chain (16 utterances x T_pick dependent frames), not a roofline kernel"},

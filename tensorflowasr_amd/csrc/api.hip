@@ -440,21 +440,27 @@ bool ring_packs_wanted(const mi355asr_model* m) {
 void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base) {
   for (const auto& pr : ab.ring_pairs) m->ring_of[base + pr.first] = base + pr.second;
   m->head_of.clear();
-  for (const auto& hp : ab.head_pairs) m->head_of[base + hp.p16] = {base + hp.slabs, hp.groups};
+  for (const auto& hp : ab.head_pairs) m->head_of[base + hp.p16] = {base + hp.slabs, hp.groups, base + hp.pp, hp.pp_sw};
 }
-void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int d, int V) {
+void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int d, int V, const float* bias) {
   if (d != 144 || V < 1) return;
   const int groups = ceil_div(ceil_div(V, 16), 9);
   std::vector<float> st;
   append_slabs(st, [&](int k, int n) { return n < V ? f(k, n) : 0.f; }, d, 144 * groups, true);
-  ab.head_pairs.push_back({p16_off, ab.put(st), groups});
+  const size_t o_st = ab.put(st);
+  // the same matrix as the two-term fp16 stream of pp_head_kernel: column groups of nine tiles, five plain ring slots each,
+  // the bias in row 144
+  std::vector<float> pp;
+  const float sw = append_pp_plain(pp, [&](int k, int n) { return n < V ? (k < d ? f(k, n) : bias[n]) : 0.f; }, groups);
+  ab.head_pairs.push_back({p16_off, o_st, groups, ab.put(pp), sw});
 }
 int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s) {
   // a launch of the ring kernel costs as much for 250 rows as for 16 000: from 2048 rows on
   if (m->cfg.gemm_dtype != 0 || m->head_of.empty() || hd.M < 2048) return -1;
   const auto it = m->head_of.find(hd.wp);
   if (it == m->head_of.end()) return -1;
-  return launch_head_ld(hd, it->second.first, it->second.second, s);
+  if (launch_pp_head(hd, it->second.pp, it->second.pp_sw, it->second.groups, s) == 0) return 0;
+  return launch_head_ld(hd, it->second.slabs, it->second.groups, s);
 }
 
 BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k,
@@ -573,6 +579,14 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
     append_slabs(st, [&](int kk, int n) { return pk2[(size_t)kk * d + n]; }, d, d, false);
     append_slabs(st, [&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d, false);
     o.og_slabs = ab.put(st);
+    // two-term fp16 stream of pp_out_glu_kernel: out projection (one group of nine tiles), then pw_conv_1's value tiles and
+    // gate tiles (two groups), five plain ring slots each, the biases in row 144
+    const auto& ob = keras_mha ? T(a + "/mha/attention_output/bias") : T(a + "/mha/projection_bias");
+    const auto& p1b = T(c + "/pw_conv_1/bias");
+    std::vector<float> pp;
+    o.pp_sw_out = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? pk2[(size_t)kk * d + n] : ob[n]; }, 1);
+    o.pp_sw_pw1 = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? pw1[(size_t)kk * 2 * d + n] : p1b[n]; }, 2);
+    o.pp_og = ab.put(pp);
   }
   o.pw1_b = ab.put(T(c + "/pw_conv_1/bias"));
   o.dw_w = ab.put(T(c + "/dw_conv/depthwise_kernel"));  // [k, d, 1] == [k][d]
@@ -651,7 +665,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
-  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; }
+  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; b.pp_og = base + o.pp_og; b.pp_sw_out = o.pp_sw_out; b.pp_sw_pw1 = o.pp_sw_pw1; }
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
   b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
@@ -849,7 +863,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k2.ctx = sc.ctx; k2.x1 = sc.xb; k2.x2 = sc.xa; k2.u = sc.u;
     k2.out_wp = w.out_wp; k2.out_b = w.out_b; k2.cv_ln_g = w.cv_ln_g; k2.cv_ln_b = w.cv_ln_b;
     k2.pw1_wp = w.pw1_wp; k2.pw1_b = w.pw1_b; k2.eps = kLnEps; k2.M = M;
-    k2.out_ws = w.out_ws; k2.pw1_ws = w.pw1_ws; k2.og_slabs = w.og_slabs;
+    k2.out_ws = w.out_ws; k2.pw1_ws = w.pw1_ws; k2.og_slabs = w.og_slabs; k2.pp_slabs = w.pp_og; k2.pp_sw_out = w.pp_sw_out; k2.pp_sw_pw1 = w.pp_sw_pw1;
     { PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU"); }
     DwArgs dwa{};
     dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
@@ -1670,7 +1684,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
     m->NT_fc = ceil_div(ceil_div(V, 16), ct) * ct;
     o_fw = ab.put(pack_p16([&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, m->NT_fc));
     if (ring_packs_wanted(m)) put_ring_head(ab, o_fw, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V);
-    put_head_slabs(ab, o_fw, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V);
+    put_head_slabs(ab, o_fw, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, m->host["fully_connected/bias"].data.data());
     o_fb = ab.put_padded(m->host["fully_connected/bias"].data.data(), V, (size_t)m->NT_fc * 16);
   }
   if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }

@@ -65,7 +65,7 @@ int finalize_translator(mi355asr_model* m, hipStream_t s) {
   so.NT_fc = ceil_div(ceil_div(V, 16), ct) * ct;
   so.fc_w = ab.put(pack_p16([&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, so.NT_fc));
   if (ring_packs_wanted(m)) put_ring_head(ab, so.fc_w, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V);
-  put_head_slabs(ab, so.fc_w, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V);
+  put_head_slabs(ab, so.fc_w, [&](int k, int n) { return fc[(size_t)k * V + n]; }, d, V, m->host["fully_connected/bias"].data.data());
   so.fc_b = ab.put_padded(m->host["fully_connected/bias"].data.data(), V, (size_t)so.NT_fc * 16);
   if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }
   HIP_TRY(hipMalloc((void**)&m->arena, ab.buf.size() * sizeof(float)));

@@ -1532,6 +1532,7 @@ int launch_out_glu(const OutGluArgs& a, hipStream_t s) {
   // double-buffered LDS slabs (28.4 us: a slab's MFMAs last 0.4-0.8 us, less than the latency of the one DMA in flight);
   // 2 (default) = the same on the four-slot slab ring, three slabs of DMA in flight (23.3 us)
   static const int split = [] { const char* v = getenv("MI355ASR_OUTGLU_SPLIT"); return v ? atoi(v) : 3; }();
+  if (a.og_slabs && split == 3 && launch_pp_out_glu(a, s) == 0) return 0;   // the two-term fp16 stream (fused_pp.hip)
   if (a.og_slabs && split == 3)     // 3 (default): loader-wave ring kernel
     hipLaunchKernelGGL(out_glu_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
   else if (a.og_slabs && split == 2)

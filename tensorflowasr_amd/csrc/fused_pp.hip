@@ -206,6 +206,16 @@ DEV void pp_fake_prep(PpPrep& pc) {      // DG bit 0: consumes the hidden tiles 
   do { if constexpr (!(DG & 1)) prep2_slot<K>(pc); else if constexpr (K == PREP2_SLOTS - 1) pp_fake_prep(pc); } while (0)
 #define PP_FENCE __builtin_amdgcn_sched_barrier(0)
 #include "pp_units.inc"
+// Every unit leaves the first PP_NPOOL fragments of the next slab in flight into the pool registers (asm reads the compiler knows
+// nothing about).  Unit follows unit without a gap inside a chain; wherever OTHER code follows -- epilogues, LayerNorm, the
+// operand split of the next chain -- the reads are landed first, with the pool tied to the wait: code the compiler is free to
+// schedule must never see a pool register that is still being written (it may copy it).
+DEV void pp_pool_land(PpPool& pl) {
+  static_assert(PP_NPOOL == 10, "one operand per pool register");
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(pl.f[0]), "+v"(pl.f[1]), "+v"(pl.f[2]), "+v"(pl.f[3]), "+v"(pl.f[4]), "+v"(pl.f[5]), "+v"(pl.f[6]), "+v"(pl.f[7]),
+                 "+v"(pl.f[8]), "+v"(pl.f[9]));
+}
 
 constexpr int PP_FR = 20;                 // fragments per ring slot (pp_layout.inc: kPpSlot)
 constexpr int PP_SLB = PP_FR * 64;        // u32x4 per ring slot (20 KB)
@@ -401,6 +411,7 @@ DEV void pp_tail_consume(const TailFf2Args& a, const PpTailLds& p, int g4, ST& s
     for (int i = 0; i < KB; ++i) y[i] = (y[i] + lds4(p.pw2b, i, g4)) * splat4(t.s2);
     split_operand(xf, xs, g4, t.sx);
     pp_chain<9, DG>(y, xf, pl, st, t.k1, t.ik2);                                         // x3 = x2 + conv module
+    pp_pool_land(pl);
 #pragma unroll
     for (int i = 0; i < KB; ++i) y[i] = y[i] * splat4(t.inv2);
   }
@@ -414,6 +425,7 @@ DEV void pp_tail_consume(const TailFf2Args& a, const PpTailLds& p, int g4, ST& s
     for (int i = 0; i < KB; ++i) y[i] = (lds4(p.b2, i, g4) + splat4(inv_fc) * y[i]) * splat4(t.s2);   // x3 / fc + b2 (+ W2 h)
     split_operand(xf, xs, g4, t.sx);
     pp_chain<18, DG>(y, xf, pl, st, t.k1, t.ik2);
+    pp_pool_land(pl);
 #pragma unroll
     for (int i = 0; i < KB; ++i) y[i] = splat4(a.fc * t.inv2) * y[i];
   }
@@ -435,6 +447,7 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
     for (int i = 0; i < KB; ++i) y[i] = y[i] * splat4(t.s2);
     split_operand(xf, xs, g4, t.sx);
     pp_chain<18, DG>(y, xf, pl, st, t.k1, t.ik2);
+    pp_pool_land(pl);
 #pragma unroll
     for (int i = 0; i < KB; ++i) { y[i] = splat4(a.fc * t.inv2) * y[i]; xs[i] = y[i]; }   // x1 = x0 + fc * (ffn + b2)
   }
@@ -458,6 +471,7 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
       constexpr int t = decltype(T)::value;
       pp_unit_S<DG>(acc, xf[t], pl, st);
     });
+    pp_pool_land(pl);
     const float sc = (q == 0 ? a.qscale : 1.0f) * invq;
     const WaveCtx e = wave_ctx_fresh(a.M, T);
     if (e.live) {
@@ -591,6 +605,7 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
   st.sync();
   PpPool pl;
   pp_prime<DG>(pl, st);
+  pp_pool_land(pl);
   if constexpr (TAIL) {
     pp_tail_consume<DG>(a, pt, c.g4, st, pl, xs, y);
     if (a.y) {
@@ -608,6 +623,164 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+
+// attention out-projection + residual, conv-module LayerNorm, pw_conv_1 + GLU (conformer_blocks.py:164-170, :209-213) on the
+// same stream machinery: 15 plain ring slots (five of the out projection, five of pw_conv_1's value tiles, five of its gate
+// tiles; the three biases in row 144), 405 MFMAs per wave where the three-term out_glu_ld_kernel (fused.hip) ran 810
+struct PpOgLds { float lng[D], lnb[D]; };
+__global__ __launch_bounds__(LD_THREADS) void pp_out_glu_kernel(OutGluArgs a) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[PP_RING * PP_SLB];
+  __shared__ __attribute__((aligned(16))) PpOgLds p;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  constexpr int TOTAL = 3 * KS32X;
+  if (wv >= WAVES_PER_BLOCK) {
+    const u32x4_t* s1 = reinterpret_cast<const u32x4_t*>(a.pp_slabs);
+    PpLoader<PP_RING, 0>{ring, s1, s1, TOTAL, TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    return;
+  }
+  constexpr int DG = 0;
+  const WaveCtx c = wave_ctx(a.M);
+  PpReader<PP_RING, 0> st{ring, c.lane};
+  f32x4 xs[KB], x2[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + c.row + 16 * kb + c.g4);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) x2[kb] = ldg4(a.x1 + c.row + 16 * kb + c.g4);
+  {
+    const auto r0 = stash_load<D>(a.cv_ln_g), r1 = stash_load<D>(a.cv_ln_b);
+    stash_store<D>(p.lng, r0); stash_store<D>(p.lnb, r1);
+  }
+  st.sync();
+  PpPool pl;
+  pp_prime<DG>(pl, st);
+  pp_pool_land(pl);
+  Split8 xf[KS32X];
+  {
+    const float sx = pp_pow2_scale(pp_row_max(xs));
+    split_operand(xf, xs, c.g4, sx);
+    f32x4 acc[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) acc[i] = splat4(0.f);
+    static_for<0, KS32X>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      pp_unit_S<DG>(acc, xf[t], pl, st);
+    });
+    pp_pool_land(pl);
+    const f32x4 inv = splat4(pp_recip_pow2(a.pp_sw_out * sx));
+#pragma unroll
+    for (int i = 0; i < KB; ++i) { x2[i] += acc[i] * inv; xs[i] = x2[i]; }                // x2 = x1 + attention (+ bias: row 144)
+  }
+  {
+    const WaveCtx e = wave_ctx_fresh(a.M);
+    if (e.live) {
+#pragma unroll
+      for (int i = 0; i < KB; ++i) stg4(a.x2 + e.row + 16 * i + e.g4, x2[i]);
+    }
+  }
+  ln_lds(xs, p.lng, p.lnb, c.g4, a.eps);
+  const float sx = pp_pow2_scale(pp_row_max(xs));
+  split_operand(xf, xs, c.g4, sx);
+  f32x4 val[KB], gate[KB];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) { val[i] = splat4(0.f); gate[i] = splat4(0.f); }
+  static_for<0, KS32X>([&](auto T) {
+    constexpr int t = decltype(T)::value;
+    pp_unit_S<DG>(val, xf[t], pl, st);
+  });
+  static_for<0, KS32X>([&](auto T) {
+    constexpr int t = decltype(T)::value;
+    pp_unit_S<DG>(gate, xf[t], pl, st);
+  });
+  pp_pool_land(pl);                                       // the pool's reads past the last slot
+  const float inv = pp_recip_pow2(a.pp_sw_pw1 * sx);
+  const WaveCtx e = wave_ctx_fresh(a.M);
+  if (e.live) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const f32x4 va = val[i] * splat4(inv), vb = gate[i] * splat4(inv);
+      f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
+      stg4(a.u + e.row + 16 * i + e.g4, o);
+    }
+  }
+}
+
+
+// CTC class head of dmodel 144: logits = x W + b over `groups` column groups of nine tiles (five plain ring slots each, the
+// bias in row 144), per-frame arg-max (first maximum wins) and / or the logits themselves -- head_ld_kernel's contract
+// (fused.hip) on the two-term stream: 135 MFMAs per group and wave instead of 270, nothing to fetch for the bias
+__global__ __launch_bounds__(LD_THREADS) void pp_head_kernel(GemmArgs a, const u32x4_t* __restrict__ pp, float pp_sw, int groups) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[PP_RING * PP_SLB];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wv >= WAVES_PER_BLOCK) {
+    PpLoader<PP_RING, 0>{ring, pp, pp, KS32X * groups, KS32X * groups, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    return;
+  }
+  constexpr int DG = 0;
+  const WaveCtx c = wave_ctx(a.M);
+  PpReader<PP_RING, 0> st{ring, c.lane};
+  Split8 xf[KS32X];
+  float inv;
+  {
+    f32x4 xs[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x + c.row + 16 * kb + c.g4);
+    const float sx = pp_pow2_scale(pp_row_max(xs));
+    split_operand(xf, xs, c.g4, sx);
+    inv = pp_recip_pow2(pp_sw * sx);
+  }
+  st.sync();
+  PpPool pl;
+  pp_prime<DG>(pl, st);
+  pp_pool_land(pl);
+  float best_v = -INFINITY;
+  int best_i = 0;
+  const bool want_max = a.argmax_out != nullptr || a.maxval_out != nullptr;
+#pragma unroll 1
+  for (int g = 0; g < groups; ++g) {
+    f32x4 acc[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) acc[i] = splat4(0.f);
+    static_for<0, KS32X>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      pp_unit_S<DG>(acc, xf[t], pl, st);
+    });
+    pp_pool_land(pl);
+    const WaveCtx e = wave_ctx_fresh(a.M);
+    float* yrow = a.y ? a.y + (size_t)e.tok * a.ldy : nullptr;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int tile = KB * g + i, f0 = 16 * tile + e.g4;
+      if (16 * tile < a.n_valid) {               // wave-uniform: the last group is padded with zero columns
+        const f32x4 v = acc[i] * splat4(inv);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        if (want_max) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (f0 + j < a.n_valid && vv[j] > best_v) { best_v = vv[j]; best_i = f0 + j; }
+        }
+        if (yrow && e.live) {
+          if (f0 + 3 < a.n_valid && (a.ldy & 3) == 0) stg4(yrow + f0, v);
+          else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (f0 + j < a.n_valid) yrow[f0 + j] = vv[j];
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the pool's reads past the last slot
+  if (!want_max) return;
+  // the four lane groups of a token hold disjoint classes: max over the groups, lowest class on ties
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) {
+    const float ov = __shfl_xor(best_v, off);
+    const int oi = __shfl_xor(best_i, off);
+    if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+  }
+  const WaveCtx e = wave_ctx_fresh(a.M);
+  if (a.argmax_out && e.live && c.lane < 16) a.argmax_out[e.tok] = best_i;
+  if (a.maxval_out && e.live && c.lane < 16) a.maxval_out[e.tok] = best_v;
+}
+
 }  // namespace
 
 // the depthwise conv rides in the tail kernel's prologue when the caller asked for it (dw_u) and the per-utterance tiling wastes
@@ -623,6 +796,23 @@ bool pp_enabled() {
   // MI355ASR_PP=0: the round-2 chunk-wise ring kernels (fused.hip) instead of the pair-pipelined ones
   static const bool on = [] { const char* v = getenv("MI355ASR_PP"); return v ? atoi(v) != 0 : true; }();
   return on;
+}
+int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, hipStream_t s) {
+  // MI355ASR_PP_HEAD=0: the three-term head_ld_kernel (fused.hip)
+  static const bool on = [] { const char* v = getenv("MI355ASR_PP_HEAD"); return v ? atoi(v) != 0 : true; }();
+  static const bool ring_on = [] { const char* v = getenv("MI355ASR_HEAD_RING"); return v ? atoi(v) != 0 : true; }();
+  if (!on || !ring_on || !pp_enabled() || !pp || groups < 1 || a.n_valid > 144 * groups || a.M <= 0) return -1;
+  const int tiles = (a.M + 15) / 16;
+  hipLaunchKernelGGL(pp_head_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, groups);
+  return 0;
+}
+int launch_pp_out_glu(const OutGluArgs& a, hipStream_t s) {
+  // MI355ASR_PP_OUTGLU=0: the three-term out_glu_ld_kernel (fused.hip)
+  static const bool on = [] { const char* v = getenv("MI355ASR_PP_OUTGLU"); return v ? atoi(v) != 0 : true; }();
+  if (!on || !pp_enabled() || !a.pp_slabs || a.M <= 0) return -1;
+  const int tiles = (a.M + 15) / 16;
+  hipLaunchKernelGGL(pp_out_glu_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
+  return 0;
 }
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s) {
   if (!pp_enabled() || !a.pp_slabs || !b.pp_slabs || a.M != b.M || a.M <= 0) return -1;

@@ -260,6 +260,10 @@ struct OutGluArgs {
   int M;
   const float *out_ws = nullptr, *pw1_ws = nullptr;   // the same kernels as split-bf16 fragments [5][NT][3][64][8] (fused.hip)
   const float* og_slabs = nullptr;                     // ... and as the slab stream of out_glu_ring_kernel (15 slabs of 1792 fragments)
+  // ... and as the two-term fp16 stream of pp_out_glu_kernel (fused_pp.hip: 15 ring slots -- out projection, pw_conv_1 value
+  // tiles, gate tiles; biases in row 144), packed with these powers of two
+  const float* pp_slabs = nullptr;
+  float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
 };
 struct TailFf2Args {
   const float* dw; const float* x2; float* y;
@@ -285,6 +289,9 @@ bool tail_pp_selected();   // launch_tail_ff1 / launch_tail_ff2 will take the pa
 int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);   // -1: not available, nothing launched
 // pair-pipelined versions (fused_pp.hip); -1: switched off (MI355ASR_PP=0) or no pp_slabs, nothing launched
 bool pp_enabled();
+int launch_pp_out_glu(const OutGluArgs& a, hipStream_t s);
+// class head of dmodel 144 on the two-term fp16 stream (pp: append_pp_plain of [W ; b] over `groups` column groups, packed with pp_sw)
+int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, hipStream_t s);
 bool pp_dw_fold_ok(int T, int ksz);   // the tail kernels can take the depthwise conv (kernel size ksz, T frames per utterance) in their prologue
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);

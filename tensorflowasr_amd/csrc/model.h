@@ -64,7 +64,8 @@ struct BlockDev {
   // out-projection / pw_conv_1 kernels as split-bf16 fragments (dmodel 144, Keras-layout MHA; fused.hip), or null
   const float *out_ws = nullptr, *pw1_ws = nullptr, *og_slabs = nullptr, *ff1_slabs = nullptr, *tail_slabs = nullptr;
   // the pair-pipelined streams of fused_pp.hip (ff_module_1 + qkv ; conv tail + ff_module_2), or null
-  const float *pp_ff1 = nullptr, *pp_tail = nullptr;
+  const float *pp_ff1 = nullptr, *pp_tail = nullptr, *pp_og = nullptr;
+  float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
   PpChainSc pp_ff1_sc, pp_tail_sc[2];      // the scales those streams were packed with (two-term fp16 scheme)
   float pp_sw_qkv = 1.f;
 };
@@ -110,7 +111,8 @@ struct mi355asr_model {
   // kernels' crossover the rings are not packed at all (they cost 1.5 x the dense weights' bytes and their packing time).
   long expected_rows = -1;
   // dmodel 144: class-head P16 pack -> (slab stream of head_ld_kernel, column groups)
-  std::unordered_map<const float*, std::pair<const float*, int>> head_of;
+  struct HeadStreams { const float* slabs; int groups; const float* pp; float pp_sw; };   // pp: two-term fp16 stream (fused_pp.hip)
+  std::unordered_map<const float*, HeadStreams> head_of;
   const float *dft_wp = nullptr, *mel_wp = nullptr, *c1_w = nullptr, *c1_b = nullptr, *c2_wp = nullptr,
               *c2_b = nullptr, *lin_wp = nullptr, *lin_b = nullptr, *proj_wp = nullptr, *proj_b = nullptr,
               *fc_wp = nullptr, *fc_b = nullptr;
@@ -192,7 +194,7 @@ struct ArenaBuilder {
   std::vector<std::pair<size_t, size_t>> ring_pairs;
   int ring_terms = 3;   // 3: fp32 weights as three bf16 terms; 1: bf16 mode (round-to-nearest-even bf16)
   // (offset of a dmodel-144 class head's P16 pack, offset of its slab stream for head_ld_kernel, column groups of nine tiles)
-  struct HeadPair { size_t p16, slabs; int groups; };
+  struct HeadPair { size_t p16, slabs; int groups; size_t pp; float pp_sw; };
   std::vector<HeadPair> head_pairs;
   size_t put(const std::vector<float>& v) {
     size_t off = (buf.size() + 63) & ~(size_t)63;  // 256-byte alignment
@@ -221,7 +223,8 @@ struct BlockOff {
   bool cross = false;
   size_t cv_ln_g, cv_ln_b, pw1_wp, pw1_b, dw_w, pc_w1p, pc_b1, bn_s, bn_t, pw2_wp, pw2_b;
   size_t ln_g, ln_b;
-  size_t out_ws = 0, pw1_ws = 0, og_slabs = 0, ff1_slabs = 0, tail_slabs = 0, pp_ff1 = 0, pp_tail = 0;
+  size_t out_ws = 0, pw1_ws = 0, og_slabs = 0, ff1_slabs = 0, tail_slabs = 0, pp_ff1 = 0, pp_tail = 0, pp_og = 0;
+  float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
   PpChainSc pp_ff1_sc, pp_tail_sc[2];
   float pp_sw_qkv = 1.f;
   bool split = false;
@@ -274,7 +277,7 @@ void put_ring_head(ArenaBuilder& ab, size_t p16_off, const std::function<float(i
 bool ring_packs_wanted(const mi355asr_model* m);
 void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base);
 // W[144, V] of a class head as the slab stream of head_ld_kernel (fused.hip), registered against its P16 pack
-void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int d, int V);
+void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int d, int V, const float* bias);
 // the head on the slab ring when the handle has a stream for hd.wp (fp32 mode, dmodel 144); -1: not taken
 int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s);
 FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vector<float>& im, int n_dft, int nb);
