@@ -56,7 +56,9 @@ def kernel_peak(name):
         # fft_stft_split_kernel: both DFT-32 stages on the bf16 pipe with split operands (the dense fallback is fp32 MFMA)
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     if name == "attention" and int(os.environ.get("MI355ASR_ATTN_SPLIT", "1") or 0):
-        # attention_split_kernel (head size 36, T <= 256): Q K^T and P V on the bf16 pipe with split operands
+        # attention_split_kernel (head size 36, T <= 256): Q K^T and P V on the matrix pipe with split operands
+        if int(os.environ.get("MI355ASR_ATTN_TERMS", "2") or 2) != 3:
+            return PEAK_HALF2_TFLOPS, "fp16 MFMA x3 (fp32 operands as two fp16 terms)"
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA"
 PEAK_HBM_GBS = 8000.0

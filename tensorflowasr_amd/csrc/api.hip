@@ -564,6 +564,23 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
                                   [&](int kk, int n) { return f2[(size_t)kk * d + n]; });
     o.pp_sw_qkv = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? qkv_at(kk, n) : qb[n]; }, 3);
     o.pp_ff1 = ab.put(pp);
+    // Operand bounds for the two-term attention kernel: a LayerNorm output lies in sqrt(d - 1) |gamma_i| + |beta_i|, so
+    // |q_n|, |k_n|, |v_n| <= sum_i |W_in| (sqrt(d - 1) |gamma_i| + |beta_i|) + |b_n| (q times the query scale and log2 e,
+    // which the kernel folds into it)
+    {
+      const auto &lg = T(a + "/ln/gamma"), &lb = T(a + "/ln/beta");
+      const double lnb = std::sqrt((double)(d - 1));
+      double bnd[3] = {0.0, 0.0, 0.0};
+      for (int n = 0; n < 3 * d; ++n) {
+        double sum = std::fabs((double)qb[n]);
+        for (int i = 0; i < d; ++i) sum += std::fabs((double)qkv_at(i, n)) * (lnb * std::fabs((double)lg[i]) + std::fabs((double)lb[i]));
+        bnd[n / d] = std::max(bnd[n / d], sum);
+      }
+      bnd[0] *= 1.4426950408889634 / std::sqrt((double)hs);
+      o.att_h2[0] = half_scale_for(bnd[0] * 1.0001);
+      o.att_h2[1] = half_scale_for(bnd[1] * 1.0001);
+      o.att_h2[2] = half_scale_for(bnd[2] * 1.0001);
+    }
   }
   const std::string c = p + "/conv_module";
   o.cv_ln_g = ab.put(T(c + "/ln/gamma"));
@@ -665,7 +682,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
-  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; b.pp_og = base + o.pp_og; b.pp_sw_out = o.pp_sw_out; b.pp_sw_pw1 = o.pp_sw_pw1; }
+  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; b.pp_og = base + o.pp_og; b.pp_sw_out = o.pp_sw_out; b.pp_sw_pw1 = o.pp_sw_pw1; b.att_h2[0] = o.att_h2[0]; b.att_h2[1] = o.att_h2[1]; b.att_h2[2] = o.att_h2[2]; }
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
   b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
@@ -858,6 +875,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ctx = sc.ctx;
   at.B = B; at.Tq = T; at.Tk = T; at.H = H; at.D = d; at.ldq = 3 * d; at.ldk = 3 * d;
     at.win_front = bo.win_front; at.win_back = bo.win_back;
+    at.h2_sq = w.att_h2[0]; at.h2_sk = w.att_h2[1]; at.h2_sv = w.att_h2[2];      // q / k / v are this block's own projections
     { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
     OutGluArgs k2{};
     k2.ctx = sc.ctx; k2.x1 = sc.xb; k2.x2 = sc.xa; k2.u = sc.u;

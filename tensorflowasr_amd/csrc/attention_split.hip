@@ -16,6 +16,8 @@
 //     staged in that order): 18 MFMAs of 16 cycles per 32 keys instead of 24 of 32.
 // 4352 matrix-pipe cycles per wave instead of 10 752.  Grid (ceil(Tq / 256), H, B): at 64 x 10 s exactly one workgroup
 // per CU, four waves per SIMD.
+#include <cstdlib>
+
 #include "common.h"
 #include "launch.h"
 
@@ -58,6 +60,47 @@ DEV f32x4 mma_split(const u32x4_t (&a)[3], const Split8& b, f32x4 c) {
   return c;
 }
 
+// Two-term scheme (see subconv.hip / fused_pp.hip): hi + lo fp16 terms of values already multiplied by their power-of-two
+// scale, three products per fragment pair.  Split8::t[2] is unused then.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+DEV unsigned pk_f16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, f16x2_t)); }
+DEV Split8 split8h(f32x4 lo, f32x4 hi) {
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  unsigned d0[4], d1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    d0[k] = pk_f16(v[2 * k], v[2 * k + 1]);
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, d0[k]);
+    d1[k] = pk_f16(v[2 * k] - (float)h.x, v[2 * k + 1] - (float)h.y);
+  }
+  Split8 f;
+  f.t[0] = u32x4_t{d0[0], d0[1], d0[2], d0[3]};
+  f.t[1] = u32x4_t{d1[0], d1[1], d1[2], d1[3]};
+  f.t[2] = u32x4_t{0u, 0u, 0u, 0u};
+  return f;
+}
+DEV f32x4 mma32h(u32x4_t a, u32x4_t b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+template <int TM>
+DEV Split8 split_tm(f32x4 lo, f32x4 hi) {
+  if constexpr (TM == 2) return split8h(lo, hi); else return split8(lo, hi);
+}
+// c += A B: TM = 3 the six bf16 term pairs, TM = 2 the three fp16 ones (lo x hi, hi x lo, hi x hi)
+template <int TM>
+DEV f32x4 mma_tm(const u32x4_t (&a)[3], const Split8& b, f32x4 c) {
+  if constexpr (TM == 2) {
+    c = mma32h(a[1], b.t[0], c);
+    c = mma32h(a[0], b.t[1], c);
+    c = mma32h(a[0], b.t[0], c);
+    return c;
+  } else {
+    return mma_split(a, b, c);
+  }
+}
+
 #ifndef MI355ASR_ATTN_DIAG
 #define MI355ASR_ATTN_DIAG 0
 #endif
@@ -72,10 +115,15 @@ constexpr int OT = 3;           // output feature tiles (48 >= 36)
 constexpr int AW = 16;          // waves = query tiles per workgroup
 constexpr int ATH = AW * 64;
 
+template <int TM>
 __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) u32x4_t Kf[3][NKT][64];        // 48 KB  K fragments (dims 0..31), three terms
+  static_assert(TM == 3 || ADG == 0, "the timing variants are those of the three-term kernel");
+  __shared__ __attribute__((aligned(16))) u32x4_t Kf[TM][NKT][64];       // 48 KB  K fragments (dims 0..31), TM terms
   __shared__ __attribute__((aligned(16))) float Kt[NKT][64];              //  4 KB  K[key][32 + g] for the fp32 tail step
-  __shared__ __attribute__((aligned(16))) u32x4_t Vf[3][NST][OT][64];     // 72 KB  V^T fragments in step order, three terms
+  __shared__ __attribute__((aligned(16))) u32x4_t Vf[TM][NST][OT][64];    // 72 KB  V^T fragments in step order, TM terms
+  // two-term scheme: operands times their power-of-two scale, the score / output accumulators in units of sq sk / 2^14 sv
+  const float sq = TM == 2 ? a.h2_sq : 1.f, sk = TM == 2 ? a.h2_sk : 1.f, sv = TM == 2 ? a.h2_sv : 1.f;
+  constexpr float SP = TM == 2 ? 16384.f : 1.f;                          // probabilities lie in [0, 1]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane >> 4, g4 = g * 4, c = lane & 15;
@@ -91,7 +139,7 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
   const float* qrow = a.q + ((size_t)b * TQ + min(tq, TQ - 1)) * a.ldq + h * HS;
   constexpr float LOG2E = 1.4426950408889634f;
   const f32x4 qlo = ldg4(qrow + 8 * g), qhi = ldg4(qrow + 8 * g + 4);
-  const float qtl = qrow[32 + g] * LOG2E;
+  const float qtl = qrow[32 + g] * (LOG2E * sq);
 
   // ---- stage K: thread (tile wv, lane) owns exactly one fragment triple; all global loads first, then the LDS writes
   const int skey = 16 * wv + c;
@@ -118,25 +166,27 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
   }
   if (skey >= T) { klo = splat4(0.f); khi = splat4(0.f); ktl = 0.f; }
   {
-    const Split8 kf = split8(klo, khi);
+    const Split8 kf = split_tm<TM>(klo * splat4(sk), khi * splat4(sk));
     Kf[0][wv][lane] = kf.t[0];
     Kf[1][wv][lane] = kf.t[1];
-    Kf[2][wv][lane] = kf.t[2];
-    Kt[wv][lane] = ktl;
+    if constexpr (TM == 3) Kf[2][wv][lane] = kf.t[2];
+    Kt[wv][lane] = ktl * sk;
   }
   __syncthreads();                     // K fragments staged; the V rows are still in flight / in registers
   const bool active = qt * 16 < TQ;    // (waves without queries still stage their share of V)
   const int nkt = (T + 15) / 16;       // key tiles that hold at least one real key (uniform)
-  const Split8 qf = split8(qlo * splat4(LOG2E), qhi * splat4(LOG2E));
+  const Split8 qf = split_tm<TM>(qlo * splat4(LOG2E * sq), qhi * splat4(LOG2E * sq));
+  const f32x4 inv_qk = splat4(1.0f / (sq * sk));                        // powers of two
 
   // ---- S^T = K Q^T: lane holds S^T[key = 16 kt + 4 g + j][query c] in log2 units
   f32x4 sc[NKT];
   auto qk_tile = [&](int kt) {
-    const u32x4_t kf[3] = {Kf[0][kt][lane], Kf[1][kt][lane], Kf[2][kt][lane]};
+    const u32x4_t kf[3] = {Kf[0][kt][lane], Kf[1][kt][lane], Kf[TM - 1][kt][lane]};
     const float kl = Kt[kt][lane];
     if constexpr (ADG & 1) { sc[kt] = splat4(kl) + __builtin_bit_cast(f32x4, kf[0]); return; }
-    f32x4 acc = mma_split(kf, qf, splat4(0.f));
+    f32x4 acc = mma_tm<TM>(kf, qf, splat4(0.f));
     sc[kt] = mfma4(kl, qtl, acc);
+    if constexpr (TM == 2) sc[kt] = sc[kt] * inv_qk;
   };
   const bool full = (nkt == NKT);
   if (active) {
@@ -158,11 +208,11 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
     const int en = tid + it * ATH;
     if (en < NVE && !(ADG & 8)) {
       const f32x4 lo = {ve[it][0], ve[it][1], ve[it][2], ve[it][3]}, hi = {ve[it][4], ve[it][5], ve[it][6], ve[it][7]};
-      const Split8 vf = split8(lo, hi);
+      const Split8 vf = split_tm<TM>(lo * splat4(sv), hi * splat4(sv));
       u32x4_t* dst = &Vf[0][0][0][0] + en;                         // [t][s][ot][lane]: en = (s * OT + ot) * 64 + lane
       dst[0] = vf.t[0];
       dst[NVE] = vf.t[1];
-      dst[2 * NVE] = vf.t[2];
+      if constexpr (TM == 3) dst[2 * NVE] = vf.t[2];
     }
   }
   if (!active) { __syncthreads(); return; }
@@ -203,15 +253,15 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
   for (int s = 0; s < NST; ++s) {
     if constexpr (ADG & 4) { o[0] += sc[2 * s]; o[1] += sc[2 * s + 1]; }
     else if (s < nst) {
-      const Split8 pf = split8(sc[2 * s], sc[2 * s + 1]);
+      const Split8 pf = split_tm<TM>(sc[2 * s] * splat4(SP), sc[2 * s + 1] * splat4(SP));
 #pragma unroll
       for (int i = 0; i < OT; ++i) {
-        const u32x4_t vf[3] = {Vf[0][s][i][lane], Vf[1][s][i][lane], Vf[2][s][i][lane]};
-        o[i] = mma_split(vf, pf, o[i]);
+        const u32x4_t vf[3] = {Vf[0][s][i][lane], Vf[1][s][i][lane], Vf[TM - 1][s][i][lane]};
+        o[i] = mma_tm<TM>(vf, pf, o[i]);
       }
     }
   }
-  const float inv = 1.0f / group_sum(psum);
+  const float inv = (1.0f / group_sum(psum)) * (1.0f / (SP * sv));      // the second factor is a power of two
   if (tq < TQ) {
     float* orow = a.ctx + ((size_t)b * TQ + tq) * D + h * HS;
 #pragma unroll
@@ -230,6 +280,11 @@ bool attention_split_applicable(int hs, const AttnArgs& a) {
 int launch_attention_split(int hs, const AttnArgs& a, hipStream_t s) {
   if (!attention_split_applicable(hs, a)) return -1;
   const int qtiles = (a.Tq + 15) / 16;
-  hipLaunchKernelGGL(attention_split_kernel, dim3((qtiles + AW - 1) / AW, a.H, a.B), dim3(ATH), 0, s, a);
+  // MI355ASR_ATTN_TERMS=3: the three-term bf16 kernel also where the operand bounds are known
+  static const bool three = [] { const char* v = getenv("MI355ASR_ATTN_TERMS"); return v && atoi(v) == 3; }();
+  if (a.h2_sq > 0.f && a.h2_sk > 0.f && a.h2_sv > 0.f && !three && ADG == 0)
+    hipLaunchKernelGGL(attention_split_kernel<2>, dim3((qtiles + AW - 1) / AW, a.H, a.B), dim3(ATH), 0, s, a);
+  else
+    hipLaunchKernelGGL(attention_split_kernel<3>, dim3((qtiles + AW - 1) / AW, a.H, a.B), dim3(ATH), 0, s, a);
   return 0;
 }

@@ -61,6 +61,10 @@ struct AttnArgs {
   // [min(max(i-win_front,0), T-win_back), max(min(i+win_back,T), win_back)]; win_front < 0 = full attention
   // (band attention is self-attention only: Tq == Tk == T)
   int win_front, win_back;
+  // two-term fp16 scheme of attention_split_kernel: powers of two with bound(|q| log2 e) * h2_sq, bound(|k|) * h2_sk,
+  // bound(|v|) * h2_sv <= 2^15 (api.hip derives the bounds from the q / k / v weights and the LayerNorm in front of them);
+  // 0 = unknown bounds (stage calls on caller-supplied q / k / v): the three-term bf16 kernel
+  float h2_sq = 0.f, h2_sk = 0.f, h2_sv = 0.f;
 };
 
 struct DwArgs {
