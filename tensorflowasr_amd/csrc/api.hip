@@ -1261,7 +1261,7 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
 extern "C" {
 
 const char* mi355asr_last_error(void) { return g_err; }
-const char* mi355asr_version(void) { return "mi355asr 0.1 (gfx950, fp32 + split-bf16 MFMA)"; }
+const char* mi355asr_version(void) { return "mi355asr 0.1 (gfx950, fp32 operands as fp16 pairs / bf16 triples on the MFMA pipe)"; }
 
 int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
   if (!cfg || !out) return fail(MI355ASR_EINVAL, "null argument");

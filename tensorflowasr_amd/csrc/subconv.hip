@@ -247,16 +247,19 @@ DEV SplitFrag split8(f32x4 lo, f32x4 hi) {
 // second accumulator, which the power-of-two scales make unnecessary here).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEV unsigned pk_f16(float a, float b) {      // v_cvt_pk_f16_f32: both halves round to nearest
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
 DEV SplitFrag split8h(f32x4 lo, f32x4 hi) {
   const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   SplitFrag f;
   unsigned d0[4], d1[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const _Float16 h0 = (_Float16)v[2 * k], h1 = (_Float16)v[2 * k + 1];
-    const float r0 = v[2 * k] - (float)h0, r1 = v[2 * k + 1] - (float)h1;
-    d0[k] = __builtin_bit_cast(unsigned, f16x2{h0, h1});
-    d1[k] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
+    d0[k] = pk_f16(v[2 * k], v[2 * k + 1]);
+    const f16x2 h = __builtin_bit_cast(f16x2, d0[k]);
+    d1[k] = pk_f16(v[2 * k] - (float)h.x, v[2 * k + 1] - (float)h.y);
   }
   f.t[0] = u32x4{d0[0], d0[1], d0[2], d0[3]};
   f.t[1] = u32x4{d1[0], d1[1], d1[2], d1[3]};
