@@ -16,11 +16,14 @@
  *     asynchronously on it; nothing synchronises the device
  *   - a handle is not re-entrant: one in-flight call per handle (the reference's C++ Session has the
  *     same contract, asr_session.h keeps mutable buffers); distinct handles are independent
- *   - values and accumulation are fp32 everywhere, matching the reference's dtype.  Products are formed either by the
- *     fp32 matrix instruction (v_mfma_f32_16x16x4_f32, an exact fp32 FMA chain) or, in the large dmodel-144 kernels
- *     (subsampling, the fused block kernels, the LEAF Gabor convolution), on the bf16 matrix pipe from operands that are
- *     split EXACTLY into three bf16 terms each (six v_mfma_f32_16x16x32_bf16 per product group; the dropped term pairs are
- *     below 2^-24 of a product) -- measured error against the fp64 oracle is the same for both.
+ *   - values and accumulation are fp32 everywhere, matching the reference's dtype.  Products are formed by the fp32 matrix
+ *     instruction (v_mfma_f32_16x16x4_f32, an exact fp32 FMA chain) or, in the large dmodel-144 kernels, on the 16-bit
+ *     matrix pipe from SPLIT fp32 operands: three bf16 terms each, exact (six v_mfma_f32_16x16x32_bf16 per product group,
+ *     the dropped term pairs below 2^-24 of a product), or -- where an operand bound is known: the handle's own weights,
+ *     its LayerNorm outputs, its frontend's dB range, a row maximum measured in the kernel -- two fp16 terms of the operand
+ *     times a power of two (hi + lo, round-to-nearest: 2^-22 relative; three v_mfma_f32_16x16x32_f16 per product group).
+ *     Both sit at the same measured distance from the fp64 oracle as the fp32 instruction; stage
+ *     calls on caller-supplied tensors always take the exact three-term or fp32 kernels.
  *     gemm_dtype = 1 is the separate, lossy bf16 mode (operands rounded to bf16).
  */
 #ifndef MI355ASR_H
@@ -62,7 +65,7 @@ typedef struct {
   int32_t ctc_num_blocks;    /* model_config.ctcdecoder_num_blocks        1                    */
   int32_t ctc_kernel_size;   /* model_config.ctcdecoder_kernel_size       32                   */
   float   ctc_fc_factor;     /* model_config.ctcdecoder_fc_factor         0.5                  */
-  int32_t gemm_dtype;        /* 0: fp32 MFMA everywhere (the reference's arithmetic; default)
+  int32_t gemm_dtype;        /* 0: fp32 values, fp32-accurate products everywhere (see the header comment; default)
                               * 1: bf16 MFMA for the dense layers -- bf16 GEMM inputs, fp32 accumulation, fp32
                               *    LayerNorm / softmax / activations / frontend (BASELINE config 3)               */
   int32_t mel_layer_type;    /* speech_config.mel_layer_type: 0 = 'Melspectrogram' (default), 1 = 'leaf' (LEAF frontend,
