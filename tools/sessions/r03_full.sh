@@ -1,5 +1,5 @@
 #!/bin/bash
-# full GPU test suite + headline bench (usage: bash tools/r03_full.sh <tag>)
+# full GPU test suite + headline bench (usage: bash tools/sessions/r03_full.sh <tag>)
 TAG=${1:-r03x}
 O=gpurun_out/$TAG; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1

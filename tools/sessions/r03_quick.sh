@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick check: a pytest -k selection + the headline bench's kernel table (usage: bash tools/r03_quick.sh <tag> "<pytest -k expr>")
+# quick check: a pytest -k selection + the headline bench's kernel table (usage: bash tools/sessions/r03_quick.sh <tag> "<pytest -k expr>")
 TAG=${1:-q}; K=${2:-"native"}
 O=gpurun_out/$TAG; mkdir -p $O
 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_shapes.py -m gpu -x -q -k "$K" > $O/t.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools/r03_var.sh <outtag> <variant names...>   (variant "base" = the regular library)
+# usage: bash tools/sessions/r03_var.sh <outtag> <variant names...>   (variant "base" = the regular library)
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
 V=$PWD/tensorflowasr_amd/build/variants
