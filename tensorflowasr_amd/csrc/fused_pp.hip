@@ -2,18 +2,18 @@
 // hidden CHUNKS of nine tiles (W1 x 5 slabs -> activation + split -> W2 x 5 slabs) are walked here in hidden PAIRS of
 // tiles, software-pipelined three deep:
 //
-//     unit p:   y      += W2[pair p]^T  hf(p)                 B(p)      54 MFMAs, 27 fragments
-//               h(p+2)  = W1[:, pair p + 2]^T xf              A(p + 2)  60 MFMAs, 30 fragments
-//               hf(p+1) = split(swish(h(p + 1)))              prep      48 slots of <= 2 VALU instructions behind the MFMAs
+//     unit p:   y      += W2[pair p]^T  hf(p)                 B(p)      27 MFMAs, 18 fragments
+//               h(p+2)  = W1[:, pair p + 2]^T xf              A(p + 2)  30 MFMAs, 20 fragments
+//               hf(p+1) = split(swish(h(p + 1)))              prep      40 slots of <= 2 VALU instructions behind the MFMAs
 //
-// What that buys over the round-2 kernels (profiles/r02_ring_experiments.md: 17 of tail_ff1's 85 us were activation /
-// split VALU work that only the five W2 slabs of a chunk could carry -- 1.7 VALU per MFMA against ~1 that is free):
-//   * the VALU work of a pair is spread over the 114 MFMAs of a unit: 0.8 instructions per MFMA, uniformly;
-//   * 32 hidden features are exactly one 32-wide k-step of W2: no ninth tile paired with zeros (FFN: 2052 MFMAs, was 2160;
-//     conv tail 1026, was 1080);
+// (counts of the two-term operand scheme below; the first version of this file ran three bf16 terms: 54 / 60 MFMAs, 27 / 30
+// fragments, 48 slots.)  What the pairing buys over the round-2 kernels (profiles/r02_ring_experiments.md: 17 of tail_ff1's
+// 85 us were activation / split VALU work that only the five W2 slabs of a chunk could carry):
+//   * the VALU work of a pair is spread over the MFMAs of a unit, uniformly;
+//   * 32 hidden features are exactly one 32-wide k-step of W2: no ninth tile paired with zeros;
 //   * bias, and for the conv module the folded BatchNorm, are part of the weight stream: W1 carries the BatchNorm scale in its
-//     columns and (bias * scale + shift) in row 144 -- the K padding of the fifth k-step -- against a constant 1.0 operand, so
-//     the loop reads no parameter from LDS and the accumulators start from zero;
+//     columns and (bias * scale + shift) in row 144 -- the K padding of the fifth k-step -- against the operand's unit in that
+//     k-slot, so the loop reads no parameter from LDS and the accumulators start from zero;
 //   * h is 2 x 2 tiles instead of 9 (+ 1 padding) tiles.
 // The stream itself (fragment order, pool slots, counted waits, ring-slot hand-over) is generated and checked by
 // tools/gen_pp.py -> pp_units.inc (device) / pp_layout.inc (host packing, api.hip: append_pp_chain).
