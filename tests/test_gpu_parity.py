@@ -217,6 +217,22 @@ def test_conformer_block_parity(enc2, B, T):
     assert maxdiff(got, ref) < TOL
 
 
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 1e3, 3e4])
+def test_conformer_block_operand_scales_follow_the_input_magnitude(enc2, scale):
+    """The two-term fp16 kernels scale every operand row by the power of two of its own largest magnitude (and hidden rows by
+    a bound derived from it): a block input of any magnitude -- the fused path, 2 000 tokens -- stays within the tolerance of
+    the fp64 oracle, relative to the size of the output (the block ends in a LayerNorm: O(1))."""
+    e, w, _ = enc2
+    rng = np.random.default_rng(int(np.log10(scale) * 10) + 50)
+    x = (rng.standard_normal((8, 250, 144)) * scale).astype(np.float32)
+    x[3, 100:120] = 0.0                                # rows of exact zeros
+    x[5, :, 7] *= 50.0                                 # one dominant feature: the other operands of the row lose their lo terms
+    ref = co.conformer_block(x.astype(np.float64), w, "conformer_block_1", 36)
+    got = e.conformer_block(1, x).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert maxdiff(got, ref) < TOL
+
+
 def test_conformer_block_is_batch_size_invariant_per_path(enc2):
     """The block runs through one of two kernel families depending on the row count (layer-at-a-time up to 800 rows,
     fused ring kernels above): inside a family an utterance's result does not depend on what else is in the batch

@@ -823,3 +823,51 @@ def test_host_fp16_rounding_of_the_two_term_weight_packs_equals_numpy():
         ref = x.astype(np.float16)
     assert np.array_equal(bits, ref.view(np.uint16))
     assert np.array_equal(back, ref.astype(np.float32))
+
+
+def test_two_term_fp16_scheme_is_as_close_to_fp64_as_the_six_product_bf16_scheme_numpy_model():
+    """The operand schemes of DESIGN.md section 2 restated in NumPy on one FFN-sized layer (512 x 144 x 576, fp64 products and
+    sums, so only the operand representation and the dropped term pairs show): three bf16 terms / six products, and two
+    fp16 terms (round-to-nearest hi + lo of the operand times the power of two that puts its bound in [2^13, 2^14) -- the
+    kernels' pp_pow2_scale) / three products.  Both land within 4e-7 of the fp64 result (a plain fp32 matmul: 2e-6, its
+    accumulation); without the scales the lo terms of small weights go subnormal and the scheme is five times worse."""
+    rng = np.random.default_rng(0)
+    M, K, N = 512, 144, 576
+    x = (rng.standard_normal((M, K)) * 1.3 + 0.1).astype(np.float32)
+    lim = np.sqrt(6 / (K + N))
+    W = rng.uniform(-lim, lim, (K, N)).astype(np.float32)
+    ref = x.astype(np.float64) @ W.astype(np.float64)
+
+    def bf16_terms(a):
+        r, out = a.astype(np.float32).copy(), []
+        for _ in range(3):
+            hi = (r.view(np.uint32) & 0xFFFF0000).view(np.float32)
+            out.append(hi.astype(np.float64))
+            r = (r - hi).astype(np.float32)
+        return out
+
+    def pow2_scale(bound):                      # fused_pp.hip: pp_pow2_scale
+        e = (np.float32(bound).view(np.uint32) >> 23) & 255
+        return np.float32(2.0) ** np.clip(140 - e.astype(np.int64), -14, 15)
+
+    def fp16_terms(a, scale):
+        v = (a.astype(np.float32) * scale).astype(np.float32)
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(np.float32)).astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64)
+
+    xa, wa = bf16_terms(x), bf16_terms(W)
+    six = sum(xa[i] @ wa[j] for i in range(3) for j in range(3) if i + j <= 2)
+    sx = pow2_scale(np.abs(x).max(1, keepdims=True))            # one scale per row (token)
+    sw = pow2_scale(np.float32(np.abs(W).max()))
+    xh, xl = fp16_terms(x, sx)
+    wh, wl = fp16_terms(W, sw)
+    assert np.abs(xh).max() < 2 ** 14 and np.abs(wh).max() < 2 ** 14
+    three = (xh @ wh + xh @ wl + xl @ wh) / (sx.astype(np.float64) * float(sw))
+    xh1, xl1 = fp16_terms(x, np.float32(1))
+    wh1, wl1 = fp16_terms(W, np.float32(1))
+    unscaled = xh1 @ wh1 + xh1 @ wl1 + xl1 @ wh1
+    e6, e3, e1 = (np.abs(v - ref).max() for v in (six, three, unscaled))
+    e32 = np.abs((x @ W).astype(np.float64) - ref).max()
+    assert e6 < 4e-7 and e3 < 4e-7 and e3 < 1.5 * e6 + 1e-8
+    assert e32 > 3 * e3 and e1 > 3 * e3
