@@ -670,7 +670,7 @@ def main():
                          "pipe": peak_kind,
                          # last round's line priced this kernel against the six-product bf16 pipe (2500 / 6); kept so that the
                          # two rounds can be compared on one basis -- the kernel now runs three products per fp32 product
-                         "frac_vs_six_product_pipe": round(k[dom]["tflops"] / PEAK_SPLIT3_TFLOPS, 4) if peak == PEAK_HALF2_TFLOPS else None,
+                         "frac_vs_six_product_pipe": round(achieved / PEAK_SPLIT3_TFLOPS, 4) if peak == PEAK_HALF2_TFLOPS else None,
                          "algorithmic_bytes": ab.get(dom), "hbm_frac": kern[dom].get("hbm_frac") if dom else None,
                          "step_hbm_frac": round(step_bytes / (elapsed / args.steps) / (PEAK_HBM_GBS * 1e9), 4)},
             "h2d_inclusive": h2d,
