@@ -53,7 +53,9 @@ def kernel_peak(name):
     if name in ring and int(os.environ.get(*ring[name]) or 0):
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     if name == "stft" and int(os.environ.get("MI355ASR_FFT", "1") or 0) and int(os.environ.get("MI355ASR_FFT_SPLIT", "1") or 0):
-        # fft_stft_split_kernel: both DFT-32 stages on the bf16 pipe with split operands (the dense fallback is fp32 MFMA)
+        # fft_stft_split_kernel: both DFT-32 stages on the matrix pipe with split operands (the dense fallback is fp32 MFMA)
+        if int(os.environ.get("MI355ASR_FFT_TERMS", "2") or 2) != 3:
+            return PEAK_HALF2_TFLOPS, "fp16 MFMA x3 (fp32 operands as two fp16 terms)"
         return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
     if name == "attention" and int(os.environ.get("MI355ASR_ATTN_SPLIT", "1") or 0):
         # attention_split_kernel (head size 36, T <= 256): Q K^T and P V on the matrix pipe with split operands

@@ -348,6 +348,8 @@ FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vecto
   o.w2 = ab.put(pack_p16(f2, 64, 32, 2));
   o.w1s = ab.put(pack_split32(f1, 32, 64));      // the same matrices as exact three-term bf16 fragments (round 3)
   o.w2s = ab.put(pack_split32(f2, 64, 32));
+  o.w1h = ab.put(pack_half32(f1, 32, 64, 16384.f));      // two-term scheme: |cos|, |sin| <= 1 times 2^14
+  o.w2h = ab.put(pack_half32(f2, 64, 32, 16384.f));
   std::vector<float> tc(1024), ts(1024);
   for (int k1 = 0; k1 < 32; ++k1)
     for (int n2 = 0; n2 < 32; ++n2) { tc[k1 * 32 + n2] = (float)ct[k1 * n2]; ts[k1 * 32 + n2] = (float)st[k1 * n2]; }
@@ -1017,7 +1019,7 @@ int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, fl
   if (m->fft_ok) {
     FftStftArgs fa{wav, logp, pmax, m->fft_w1p, m->fft_w2p, m->fft_twc, m->fft_tws, m->fft_win,
                    Bp, Lb, F, m->dm.hop, before, m->dm.LP, 1};
-    fa.w1s = m->fft_w1s; fa.w2s = m->fft_w2s;
+    fa.w1s = m->fft_w1s; fa.w2s = m->fft_w2s; fa.w1h = m->fft_w1h; fa.w2h = m->fft_w2h;
     { PROF(MI355ASR_K_STFT); LAUNCH_TRY(launch_fft_stft(fa, s), "stft (fft)"); }
     npart = F;
   } else {
@@ -1718,7 +1720,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->fft_ok = fo.ok;
   use_mel_band(m, mbo, base);
   m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;
-  m->fft_w1s = base + fo.w1s; m->fft_w2s = base + fo.w2s;
+  m->fft_w1s = base + fo.w1s; m->fft_w2s = base + fo.w2s; m->fft_w1h = base + fo.w1h; m->fft_w2h = base + fo.w2h;
   m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = ((d == 144 || d == 256 || d == 512) && c.has_encoder) ? base + o_c2s : nullptr;
   m->c2_whalf = o_c2h ? base + o_c2h : nullptr; m->c2_hscale = c2_hs; m->c2_wscale = c2_ws;

@@ -178,7 +178,7 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   m->fft_ok = fo.ok;
   use_mel_band(m, mbo, base);
   m->fft_w1p = base + fo.w1; m->fft_w2p = base + fo.w2; m->fft_twc = base + fo.twc; m->fft_tws = base + fo.tws;
-  m->fft_w1s = base + fo.w1s; m->fft_w2s = base + fo.w2s;
+  m->fft_w1s = base + fo.w1s; m->fft_w2s = base + fo.w2s; m->fft_w1h = base + fo.w1h; m->fft_w2h = base + fo.w2h;
   m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
@@ -407,7 +407,7 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     if (m->fft_ok) {
       FftStftArgs fa{wav, st.logp, st.pmax, m->fft_w1p, m->fft_w2p, m->fft_twc, m->fft_tws, m->fft_win,
                      B, L, g.F, m->dm.hop, c.n_dft - 1, m->dm.LP, 0};
-    fa.w1s = m->fft_w1s; fa.w2s = m->fft_w2s;
+    fa.w1s = m->fft_w1s; fa.w2s = m->fft_w2s; fa.w1h = m->fft_w1h; fa.w2h = m->fft_w2h;
       PROF(MI355ASR_K_STFT);
       LAUNCH_TRY(launch_fft_stft(fa, s), "stft (valid, fft)");
     } else {
@@ -556,7 +556,7 @@ int mi355asr_chunk_front_stream(mi355asr_model* m, const float* wav, int32_t Lw,
   if (m->fft_ok) {
     FftStftArgs fa{wav, logp, (float*)(ws + p.pmax), m->fft_w1p, m->fft_w2p, m->fft_twc, m->fft_tws, m->fft_win,
                    1, Lw, F, m->dm.hop, c.n_dft - 1, m->dm.LP, 0};
-    fa.w1s = m->fft_w1s; fa.w2s = m->fft_w2s;
+    fa.w1s = m->fft_w1s; fa.w2s = m->fft_w2s; fa.w1h = m->fft_w1h; fa.w2h = m->fft_w2h;
     PROF(MI355ASR_K_STFT);
     LAUNCH_TRY(launch_fft_stft(fa, s), "stft (valid, fft)");
   } else {

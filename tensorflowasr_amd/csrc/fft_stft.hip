@@ -202,7 +202,47 @@ DEV Split8 split8(f32x4 lo, f32x4 hi) {      // exact: x = t0 + t1 + t2 (truncat
 DEV f32x4 mma32(u32x4_t a, u32x4_t b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// Two-term scheme (TM = 2 below): the stage matrices (cos / sin: |w| <= 1) as hi + lo fp16 of w * 2^14,
+// an operand column (one n2 of stage 1, one k1 of stage 2: this lane's token, spread over the four lanes c, c + 16, c + 32,
+// c + 48) as hi + lo fp16 of the column times the power of two of its largest magnitude; three products per fragment pair.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr float kStageScale = 16384.f;
+DEV unsigned pk_f16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, f16x2_t)); }
+DEV Split8 split8h(f32x4 lo, f32x4 hi) {
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  unsigned d0[4], d1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    d0[k] = pk_f16(v[2 * k], v[2 * k + 1]);
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, d0[k]);
+    d1[k] = pk_f16(v[2 * k] - (float)h.x, v[2 * k + 1] - (float)h.y);
+  }
+  Split8 f;
+  f.t[0] = u32x4_t{d0[0], d0[1], d0[2], d0[3]};
+  f.t[1] = u32x4_t{d1[0], d1[1], d1[2], d1[3]};
+  f.t[2] = u32x4_t{0u, 0u, 0u, 0u};
+  return f;
+}
+DEV f32x4 mma32h(u32x4_t a, u32x4_t b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// 2^k with m * 2^k in [2^13, 2^14), k in [-14, 15] (0 gives 2^15), and its reciprocal
+DEV float pow2_scale(float m) {
+  const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u);
+  return __builtin_bit_cast(float, (unsigned)(127 + min(15, max(-14, 140 - e))) << 23);
+}
+DEV float recip_pow2(float s) { return __builtin_bit_cast(float, 0x7f000000u - __builtin_bit_cast(unsigned, s)); }
+DEV float max8(f32x4 a, f32x4 b) {
+  return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+}
+DEV float col_max(float m) {                  // over the four lanes of a column
+  m = fmaxf(m, __shfl_xor(m, 16));
+  return fmaxf(m, __shfl_xor(m, 32));
+}
 
+template <int TM>
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStftArgs a) {
   __shared__ float lds[WAVES_PER_BLOCK][2][32 * LDW];
   const int lane = threadIdx.x & 63;
@@ -215,19 +255,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
   const int total = a.B * a.F;
 
   // ---- frame-independent operands -> registers: stage matrices as [tile][term] fragments
-  const u32x4_t* __restrict__ w1p = reinterpret_cast<const u32x4_t*>(a.w1s) + lane;   // [4 nt][3 terms]
-  const u32x4_t* __restrict__ w2p = reinterpret_cast<const u32x4_t*>(a.w2s) + lane;   // [2 steps][2 nt][3 terms]
-  u32x4_t w1[4][3], w2[2][2][3];
+  const u32x4_t* __restrict__ w1p = reinterpret_cast<const u32x4_t*>(TM == 2 ? a.w1h : a.w1s) + lane;   // [4 nt][TM terms]
+  const u32x4_t* __restrict__ w2p = reinterpret_cast<const u32x4_t*>(TM == 2 ? a.w2h : a.w2s) + lane;   // [2 steps][2 nt][TM terms]
+  u32x4_t w1[4][TM], w2[2][2][TM];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) w1[nt][t] = w1p[(nt * 3 + t) * 64];
+    for (int t = 0; t < TM; ++t) w1[nt][t] = w1p[(nt * TM + t) * 64];
 #pragma unroll
   for (int st = 0; st < 2; ++st)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) w2[st][nt][t] = w2p[((st * 2 + nt) * 3 + t) * 64];
+      for (int t = 0; t < TM; ++t) w2[st][nt][t] = w2p[((st * 2 + nt) * TM + t) * 64];
   f32x4 hw[2][2], twc[2][2], tws[2][2];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
@@ -249,13 +289,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
   auto mma6 = [&](auto& acc, const auto& w, const Split8 (&x)[2], auto NT_T) {
     constexpr int NT = decltype(NT_T)::value;
 #pragma unroll
-    for (int ord = 2; ord >= 0; --ord)
+    for (int ord = TM - 1; ord >= 0; --ord)
 #pragma unroll
       for (int p = 0; p <= ord; ++p)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) acc[rt][nt] = mma32(w[nt][ord - p], x[rt].t[p], acc[rt][nt]);
+          for (int rt = 0; rt < 2; ++rt)
+            acc[rt][nt] = TM == 2 ? mma32h(w[nt][ord - p], x[rt].t[p], acc[rt][nt]) : mma32(w[nt][ord - p], x[rt].t[p], acc[rt][nt]);
   };
 
 #pragma unroll 1
@@ -265,6 +306,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
     const int base = f * a.hop - a.pad_left;
     // ---- stage-1 operand: xw[32*n1 + n2], zero outside the signal (TF SAME / left-padded VALID framing)
     Split8 xs[2];
+    float un1[2];                              // two-term: 1 / (stage scale x column scale) of the stage-1 accumulators
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       f32x4 xf[2];
@@ -278,7 +320,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
         v.x = o0 ? v.x : 0.f; v.y = o1 ? v.y : 0.f; v.z = o2 ? v.z : 0.f; v.w = o3 ? v.w : 0.f;
         xf[kb] = v * hw[rt][kb];
       }
-      xs[rt] = split8(xf[0], xf[1]);
+      if constexpr (TM == 2) {
+        const float sx = pow2_scale(col_max(max8(xf[0], xf[1])));
+        un1[rt] = recip_pow2(sx * kStageScale);
+        xs[rt] = split8h(xf[0] * splat4(sx), xf[1] * splat4(sx));
+      } else {
+        un1[rt] = 1.f;
+        xs[rt] = split8(xf[0], xf[1]);
+      }
     }
     // ---- stage 1: A = F32 * Xw   (acc1[rt][nt]: nt 0,1 = Re k1 0..31 ; nt 2,3 = Im k1 0..31)
     f32x4 acc1[2][4];
@@ -287,6 +336,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc1[rt][nt] = splat4(0.f);
     mma6(acc1, w1, xs, std::integral_constant<int, 4>{});
+    if constexpr (TM == 2) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc1[rt][nt] = acc1[rt][nt] * splat4(un1[rt]);
+    }
     // ---- bin 512: sum_n2 (-1)^n2 A_re[0][n2]   (A_re[0][n2] sits in lanes g == 0, tile 0, reg 0)
     float nyq = (g == 0) ? ((c & 1) ? -1.f : 1.f) * (acc1[0][0].x + acc1[1][0].x) : 0.f;
 #pragma unroll
@@ -317,15 +372,42 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
       acc2[rt][0] = splat4(0.f);
       acc2[rt][1] = splat4(0.f);
     }
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      Split8 ys[2];
+    if constexpr (TM == 2) {
+      // one scale per row k1 for its real and its imaginary half: they meet in the same accumulator
+      f32x4 yr[2][2], yi[2][2];
+      float sy[2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const float* src = (st == 0 ? Lre : Lim) + (16 * rt + c) * LDW + g4;
-        ys[rt] = split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 16));
+        const float* sr = Lre + (16 * rt + c) * LDW + g4;
+        const float* si = Lim + (16 * rt + c) * LDW + g4;
+        yr[rt][0] = *reinterpret_cast<const f32x4*>(sr); yr[rt][1] = *reinterpret_cast<const f32x4*>(sr + 16);
+        yi[rt][0] = *reinterpret_cast<const f32x4*>(si); yi[rt][1] = *reinterpret_cast<const f32x4*>(si + 16);
+        sy[rt] = pow2_scale(col_max(fmaxf(max8(yr[rt][0], yr[rt][1]), max8(yi[rt][0], yi[rt][1]))));
       }
-      mma6(acc2, w2[st], ys, std::integral_constant<int, 2>{});
+      Split8 ys[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) ys[rt] = split8h(yr[rt][0] * splat4(sy[rt]), yr[rt][1] * splat4(sy[rt]));
+      mma6(acc2, w2[0], ys, std::integral_constant<int, 2>{});
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) ys[rt] = split8h(yi[rt][0] * splat4(sy[rt]), yi[rt][1] * splat4(sy[rt]));
+      mma6(acc2, w2[1], ys, std::integral_constant<int, 2>{});
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 un = splat4(recip_pow2(sy[rt] * kStageScale));
+        acc2[rt][0] = acc2[rt][0] * un;
+        acc2[rt][1] = acc2[rt][1] * un;
+      }
+    } else {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        Split8 ys[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const float* src = (st == 0 ? Lre : Lim) + (16 * rt + c) * LDW + g4;
+          ys[rt] = split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 16));
+        }
+        mma6(acc2, w2[st], ys, std::integral_constant<int, 2>{});
+      }
     }
     // ---- power, log, store, per-frame max.  lane holds bins k1 + 32*k2, k1 = 16*rt + c, k2 = 4*g + j
     float mx = -INFINITY;
@@ -362,8 +444,15 @@ int launch_fft_stft(const FftStftArgs& a, hipStream_t s) {
   const int waves = std::min(total, 4096);
   // MI355ASR_FFT_SPLIT=0: both DFT stages on the fp32 MFMA (round 1) instead of the split-bf16 pipe
   static const bool split = [] { const char* v = getenv("MI355ASR_FFT_SPLIT"); return v ? atoi(v) != 0 : true; }();
+  // MI355ASR_FFT_TERMS=3: three bf16 terms instead of two fp16 terms (the stage matrices and the per-column scales make the
+  // two-term kernel independent of the signal's amplitude: no bound is assumed)
+  static const bool three = [] { const char* v = getenv("MI355ASR_FFT_TERMS"); return v && atoi(v) == 3; }();
+  if (split && a.w1h && a.w2h && !three) {
+    hipLaunchKernelGGL(fft_stft_split_kernel<2>, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
+    return 0;
+  }
   if (split && a.w1s && a.w2s) {
-    hipLaunchKernelGGL(fft_stft_split_kernel, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
+    hipLaunchKernelGGL(fft_stft_split_kernel<3>, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
     return 0;
   }
   hipLaunchKernelGGL(fft_stft_kernel, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);

@@ -99,6 +99,7 @@ struct FftStftArgs {
   // matrix pipe (fft_stft_split_kernel, round 3), or null
   const float* w1s = nullptr;   // stage 1: K = 32 (n1), 64 columns -> [1][4][3][64][8]
   const float* w2s = nullptr;   // stage 2: K = 64 (re | im of n2), 32 columns -> [2][2][3][64][8]
+  const float *w1h = nullptr, *w2h = nullptr;   // the same two matrices times 2^14 as hi + lo fp16 terms ([..][2][64][8]; two-term scheme)
 };
 int launch_fft_stft(const FftStftArgs& a, hipStream_t s);
 struct UttMaxArgs { const float* pmax; float* umax; int n; };

@@ -126,6 +126,7 @@ struct mi355asr_model {
   bool fft_ok = false;
   const float *fft_w1p = nullptr, *fft_w2p = nullptr, *fft_twc = nullptr, *fft_tws = nullptr, *fft_win = nullptr;
   const float *fft_w1s = nullptr, *fft_w2s = nullptr;   // the stage matrices as split-bf16 fragments (fft_stft_split_kernel)
+  const float *fft_w1h = nullptr, *fft_w2h = nullptr;   // ... and times 2^14 as fp16 pairs
   // LEAF frontend (mel_layer_type 1): packed Gabor filters, pooling coefficients, PCEN / instance-norm vectors
   const float *leaf_wp = nullptr, *leaf_gcoef = nullptr, *leaf_alpha = nullptr, *leaf_delta = nullptr, *leaf_root = nullptr,
               *leaf_smooth = nullptr, *leaf_gamma = nullptr, *leaf_beta = nullptr;
@@ -210,7 +211,7 @@ struct ArenaBuilder {
   }
 };
 
-struct FftOff { bool ok = false; size_t w1 = 0, w2 = 0, twc = 0, tws = 0, win = 0, w1s = 0, w2s = 0; };
+struct FftOff { bool ok = false; size_t w1 = 0, w2 = 0, twc = 0, tws = 0, win = 0, w1s = 0, w2s = 0, w1h = 0, w2h = 0; };
 struct MelBandOff { bool ok = false; size_t band = 0, bw = 0; int BW = 0; };
 // band form of freq2mel [nb, n_mels] for mel_band_kernel; ok = false when a filter spans more than 64 bins (a trained, dense matrix)
 MelBandOff pack_mel_band(ArenaBuilder& ab, const std::vector<float>& f2m, int nb, int n_mels);

@@ -1400,7 +1400,7 @@ print("RESULT %.3e %.3e" % (blk, enc))
                   {"MI355ASR_TAILFF2_RING": "0"}, {"MI355ASR_PP": "0"}, {"MI355ASR_PP": "0", "MI355ASR_TAIL_FF1": "0"},
                   {"MI355ASR_TAIL_FF1": "0"},
                   # the three-term bf16 versions of the kernels that default to the two-term fp16 scheme
-                  {"MI355ASR_SUBCONV_TERMS": "3"}, {"MI355ASR_ATTN_TERMS": "3"}, {"MI355ASR_PP_OUTGLU": "0"},
+                  {"MI355ASR_SUBCONV_TERMS": "3"}, {"MI355ASR_ATTN_TERMS": "3"}, {"MI355ASR_PP_OUTGLU": "0"}, {"MI355ASR_FFT_TERMS": "3"},
                   {"MI355ASR_SUBCONV_TERMS": "3", "MI355ASR_ATTN_TERMS": "3", "MI355ASR_PP": "0"}):
         env = dict(os.environ, MI355ASR_SMALL_M="0", **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
