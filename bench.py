@@ -662,7 +662,7 @@ def main():
             "value_is": "whole-job aggregate over n_gpus (driver contract); the metric's per-GPU rate is frames_per_s_per_gpu",
             "arithmetic": "fp32 values and fp32 accumulation; products on the 16-bit matrix pipe from split fp32 operands -- two fp16 terms of "
                           "power-of-two scaled operands (three MFMAs) where a bound is known, else three exact bf16 terms (six) or the fp32 "
-                          "instruction; same measured distance from the fp64 oracle (DESIGN.md section 2, profiles/r03c_parity_excused_frames.jsonl)",
+                          "instruction; same measured distance from the fp64 oracle (DESIGN.md section 2, profiles/r03d_parity_excused_frames.jsonl)",
             "frames_per_s_per_gpu": round(value / world, 1),
             "ms_per_step_with_kernel_events": round(elapsed_ev / args.steps * 1e3, 3) if elapsed_ev else None,
             "rtf": round(elapsed / args.steps / (world * B * args.seconds), 8),
