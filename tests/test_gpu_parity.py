@@ -1411,6 +1411,38 @@ print("RESULT %.3e %.3e" % (blk, enc))
         assert blk < TOL and enc < TOL, (extra, blk, enc)
 
 
+def test_fused_block_path_at_short_utterances_in_a_subprocess(torch_cuda):
+    """The fused dmodel-144 block kernels (taken above 800 rows by default) forced for every row count
+    (MI355ASR_SMALL_M=0): many short utterances -- the shapes a large batch of short clips or of streaming chunks brings -- and
+    utterance lengths around the 64-frame tiling of the depthwise-conv fold (63 / 64 / 65, below it the separate kernel),
+    around the 16-key limit of the split attention kernel, and single utterances.  Each against the fp64 oracle."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, maxdiff, small_cfg
+from tensorflowasr_amd.models import ConformerEncoder
+cfg = small_cfg(2)
+w = co.encoder_weights(cfg, seed=3)
+e = ConformerEncoder(**encoder_kwargs(cfg)); e.load_weights(w, by_name=False)
+res = []
+for B, T in ((64, 13), (40, 30), (12, 75), (3, 100), (2, 130), (5, 63), (5, 64), (5, 65), (3, 16), (3, 17), (70, 7), (1, 250)):
+    rng = np.random.default_rng(B * 1000 + T)
+    x = rng.standard_normal((B, T, 144)).astype(np.float32)
+    ref = co.conformer_block(x.astype(np.float64), w, "conformer_block_1", 36)
+    res.append(maxdiff(e.conformer_block(1, x).cpu().numpy(), ref))
+print("RESULT " + " ".join("%.3e" % v for v in res))
+'''
+    env = dict(os.environ, MI355ASR_SMALL_M="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, out.stderr[-2000:]
+    errs = [float(v) for v in line[0].split()[1:]]
+    assert len(errs) == 12 and max(errs) < 1e-4, errs
+
+
 def test_cpp_session_example_runs(torch_cuda):
     """examples/asr_session.cpp -- the reference's C++ Session on the C ABI, no Python in the process: enumerates the
     tensors with mi355asr_weight_shape, fills them, recognises a synthetic utterance twice with identical ids."""
