@@ -170,6 +170,14 @@ int mi355asr_ctc_prefix_beam(const float* x_dev, int32_t is_logits, const int32_
                              int32_t num_threads, int32_t max_len, int32_t* ids_host, int32_t* lens_host,
                              float* scores_host, int32_t* n_hyp_host, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* The score arithmetic of the device prefix search, exposed for verification.  The reference's scores are defined by the
+ * C library it is compiled against: log_sum_exp<float> = logf(expf(x - m) + expf(y - m)) + m (zip:ctc_decoders/
+ * decoder_utils.h:41-49) and (float)log((double)p + FLT_MIN) (ctc_beam_search_decoder.cpp:57-59); the device search
+ * evaluates glibc's own algorithms (csrc/refmath.h).  kind 0: out f32[i] = expf(in[i]), in [-17.5, 0];
+ * 1: out f32[i] = logf(in[i]), in [1, 2]; 2: out f64[i] = log((double)in[i] + FLT_MIN), in [0, 1];
+ * 3: out f32[i] = log_sum_exp(in[i], in[n + i]) (in holds 2 n values).  Device pointers. */
+int mi355asr_beam_math_eval(int32_t kind, const float* in_dev, void* out_dev, int32_t n, void* stream);
+
 /* Stateful prefix beam search for streaming recognition.
  * replaces: class BeamDecoder (zip:ctc_decoders/ctc_beam_search_decoder.h: BeamDecoder(vocabulary, beam_size,
  * cutoff_prob, cutoff_top_n, ext_scorer = nullptr), .decode(probs_seq), .reset(); .cpp:217-405).  decode() consumes

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mi355asr_ctc_prefix_beam_host": (ctypes.c_int, [_P, _P, _I, _I, _I, _I, ctypes.c_double, _I, _I, _I, _P, _P, _P, _P]),
     "mi355asr_ctc_prefix_beam": (ctypes.c_int, [_P, _I, _P, _I, _I, _I, _I, ctypes.c_double, _I, _I, _I, _P, _P, _P, _P,
                                                 _P, _SZ, _P]),
+    "mi355asr_beam_math_eval": (ctypes.c_int, [_I, _P, _P, _I, _P]),
     "mi355asr_beam_create": (ctypes.c_int, [_I, _I, ctypes.c_double, _I, ctypes.POINTER(_P)]),
     "mi355asr_beam_decode": (ctypes.c_int, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "mi355asr_beam_reset": (ctypes.c_int, [_P]),

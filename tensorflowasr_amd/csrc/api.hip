@@ -1886,6 +1886,13 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
                                  num_threads, max_len, ids, lens, scores, n_hyp);
 }
 
+int mi355asr_beam_math_eval(int32_t kind, const float* in_dev, void* out_dev, int32_t n, void* stream) {
+  if (!in_dev || !out_dev || n < 0 || kind < 0 || kind > 3) return fail(MI355ASR_EINVAL, "bad argument");
+  if (mi355asr_launch_refmath_eval(kind, in_dev, out_dev, n, (hipStream_t)stream) != 0)
+    return fail(MI355ASR_EHIP, "refmath kernel launch failed");
+  return 0;
+}
+
 int mi355asr_ctc_prefix_beam_workspace_bytes(int32_t B, int32_t T, int32_t cutoff_top_n, int32_t beam_size, int32_t max_len,
                                              size_t* bytes) {
   if (!bytes || B <= 0 || T <= 0 || cutoff_top_n <= 0 || beam_size <= 0 || max_len <= 0) return fail(MI355ASR_EINVAL, "bad argument");

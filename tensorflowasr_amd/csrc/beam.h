@@ -34,6 +34,9 @@ size_t mi355asr_beam_device_ws_bytes(int B, int T, int beam, int max_len);
 // fills a->arena / ids / lens / scores / n_hyp, *d_len (staging of in_len) and *prof (9 x int64 counters); returns the bytes used
 size_t mi355asr_beam_device_carve(char* ws, int B, int T, int beam, int max_len, BeamDeviceArgs* a, int32_t** d_len, long long** prof);
 int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s);
+// kind 0 expf(in[i]) -> float, 1 logf -> float, 2 log((double)in[i] + FLT_MIN) -> double, 3 log_sum_exp(in[i], in[n + i]) -> float,
+// evaluated by the device search's own routines (refmath.h)
+int mi355asr_launch_refmath_eval(int kind, const float* in, void* out, int n, hipStream_t s);
 int mi355asr_launch_topn(const float* x_dev, int frames, int V, int N, int is_logits, int32_t* idx_dev, float* p_dev,
                          hipStream_t s);
 }

@@ -45,6 +45,7 @@ struct Node {
   int ch, parent, first_child, next_sibling;
   float b_prev, nb_prev, b_cur, nb_cur, score;
   int stamp;      // frame at which the node was last put on the candidate list
+  int slot;       // this frame's tie-break word (Search::better)
   bool exists;
 };
 
@@ -60,7 +61,7 @@ class Trie {
     Node& n = nodes[id];
     n.ch = ch; n.parent = parent; n.first_child = -1; n.next_sibling = -1;
     n.b_prev = n.nb_prev = n.b_cur = n.nb_cur = n.score = kNegInf;
-    n.stamp = -1; n.exists = true;
+    n.stamp = -1; n.slot = 0; n.exists = true;
     return id;
   }
   // PathTrie::get_path_trie (path_trie.cpp:37-91, dictionary-less branch)
@@ -148,20 +149,32 @@ struct Search {
     prefixes.assign(1, root);
   }
 
-  bool better(int x, int y) const {   // prefix_compare (decoder_utils.cpp:137-147) + node id as the last word
+  // prefix_compare (decoder_utils.cpp:137-147): score descending, then last character ascending -- and nothing else: the
+  // reference leaves prefixes that agree in both to std::nth_element / std::sort.  That is not a corner case: at scores of
+  // -1000 ... -5000 a float32 ulp is 1e-4 ... 5e-4, neighbouring hypotheses collide in their scores, and two tied parents
+  // extended by the same character give tied children with the same last character (16 x 30 s, utterance 11, frame 138).
+  // The order is therefore DEFINED here, in terms both this search and the device search (beam_device.hip) can evaluate:
+  // the beam is kept sorted; among equals an entry that was in the beam comes before a new child, beam entries in the
+  // order of their beam positions, children in the order of (parent's beam position, candidate's position in the frame's
+  // descending list).  slot = that rank: position for beam entries, nbm + parent position * candidates + candidate position.
+  bool better(int x, int y) const {
     const Node &a = trie.nodes[x], &b = trie.nodes[y];
     if (a.score != b.score) return a.score > b.score;
     if (a.ch != b.ch) return a.ch < b.ch;
-    return x < y;
+    return a.slot < b.slot;
   }
 
   void step(int t, const std::vector<Cand>& cands) {
     touched.clear();
-    for (int p : prefixes) trie.nodes[p].stamp = t;
-    for (const Cand& cd : cands) {
-      const int c = cd.c;
-      const float lp = cd.lp;
-      for (size_t i = 0; i < prefixes.size(); ++i) {
+    const int nbm = (int)prefixes.size(), nc = (int)cands.size();
+    for (int i = 0; i < nbm; ++i) {
+      trie.nodes[prefixes[i]].stamp = t;
+      trie.nodes[prefixes[i]].slot = i;
+    }
+    for (int k = 0; k < nc; ++k) {
+      const int c = cands[k].c;
+      const float lp = cands[k].lp;
+      for (int i = 0; i < nbm; ++i) {
         const int pi = prefixes[i];
         if (c == blank) {
           Node& p = trie.nodes[pi];
@@ -179,7 +192,7 @@ struct Search {
         if (c == p.ch && p.b_prev > kNegInf) log_p = lp + p.b_prev;
         else if (c != p.ch) log_p = lp + p.score;
         q.nb_cur = log_sum_exp(q.nb_cur, log_p);
-        if (q.stamp != t) { q.stamp = t; touched.push_back(qi); }
+        if (q.stamp != t) { q.stamp = t; q.slot = nbm + i * nc + k; touched.push_back(qi); }
       }
     }
     // PathTrie::iterate_to_vec (path_trie.cpp:113-127) over every existing node = beam + touched
@@ -198,6 +211,7 @@ struct Search {
       for (size_t i = beam; i < prefixes.size(); ++i) trie.remove(prefixes[i]);
       prefixes.resize(beam);
     }
+    std::sort(prefixes.begin(), prefixes.end(), [&](int x, int y) { return better(x, y); });   // beam positions = ranks
   }
 
   // -> number of hypotheses written
@@ -410,14 +424,16 @@ __global__ __launch_bounds__(64) void topn_reg_kernel(const float* __restrict__ 
   const float* row = x + frame * V;
   out_idx += frame * N;
   out_p += frame * N;
-  // The row through buffer loads: one offset register for all NR requests (per-request 64-bit addresses would double the
-  // register count), reads past the row return 0 and are turned into -inf.  Classes >= V are then never above T0 and
+  // The row through buffer loads (per-request 64-bit addresses would double the register count).  The whole offset
+  // lane * 4 + m * 256 goes into the bounds-CHECKED operand (voffset + the instruction's immediate; an soffset would be
+  // excluded from the check and let the last registers of a short row read up to 6 KB past the tensor): reads past the
+  // row return 0 and are turned into -inf.  Classes >= V are then never above T0 and
   // come behind every real class in class order -- with V >= 64 >= N (the launch checks) they are never selected, so
   // nothing below needs an `i < V` test.
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, V * 4, 0x00020000);
   float v[NR];
 #pragma unroll
-  for (int m = 0; m < NR; ++m) v[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, m * 256, 0));
+  for (int m = 0; m < NR; ++m) v[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4 + m * 256, 0, 0));
   const int vfull = V >> 6;                 // registers every lane of which holds a class
 #pragma unroll
   for (int m = 0; m < NR; ++m)

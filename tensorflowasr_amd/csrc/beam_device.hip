@@ -19,10 +19,12 @@
 //      ascending -- prefix_compare -- then slot), early exit as soon as the selected bin is wanted whole
 //   5. compact into the next beam; a kept child appends (parent link, character) to a back-pointer arena in HBM.
 // After the last frame the beam is ranked (prefix_compare) and the paths are read back through the arena.
-// float32 scores as the reference; expf / logf are evaluated in double and rounded to float (the host's libm float
-// functions are correctly rounded in all but ~1e-8 of the cases, so is that), which reproduces the host search bit for bit
-// on the known-answer vectors.  Ties of (score, character) between different prefixes -- the reference leaves their order
-// to std::nth_element -- are broken by slot (existing entries first, then children in (entry, candidate) order).
+// float32 scores as the reference; expf / logf / log are the host C library's own evaluation (refmath.h -- glibc's float
+// routines are NOT correctly rounded, so "the exact value rounded once" is a different function), which reproduces the
+// host search bit for bit: known-answer vectors and the benched 16 x 30 s shape alike.  Ties of (score, character) between
+// different prefixes -- the reference leaves their order to std::nth_element -- are broken by slot (existing entries first
+// in beam order, then children in (entry, candidate) order) with the beam kept in rank order: the order beam.hip's
+// Search::better defines, so both searches resolve them alike (float32 scores of -1000 ... -5000 tie all the time).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -30,6 +32,7 @@
 #include <cstdint>
 
 #include "beam.h"
+#include "refmath.h"
 
 namespace {
 
@@ -44,71 +47,33 @@ constexpr float kNegInf = -FLT_MAX;
 
 typedef unsigned long long u64;
 
-// expf / logf as the host's libm returns them = the exact value rounded to float.  Round 2 called the double-precision
-// library routines (~150 instructions with their special-case branches; two or three log_sum_exp per beam entry made the
-// "entries" phase 60 % of a frame at beam 10).  Round 3: the two arguments only ever come from log_sum_exp -- exp of
-// d in [-17.5, 0], log of s in [1, 2] -- so both are short double-precision kernels with a relative error below 2^-46
-// (a float result can differ from the correctly rounded one only when the exact value lies within 2^-22 ulp of a rounding
-// boundary; the known-answer cases of the reference decoder stay bit-exact):
-//   exp(d) = 2^k (1 + q), k = rint(d log2 e), r = d - k ln 2 (two-constant reduction), q = expm1(r) by the Taylor polynomial of
-//   degree 13 on |r| <= 0.347 (remainder 3e-17);
-//   log(s): y0 = ln 2 * v_log_f32(s) (1e-7), then ONE Newton step on exp(y) = s: y1 = y0 + (s exp(-y0) - 1), the bracket formed
-//   as (A - 1) + A q with A = s 2^k exact, so that results near zero keep their relative accuracy; error (y0 - log s)^2 / 2.
-//   4 x 10^6 random arguments of each: no float result differs from the library's (tools: the check sits in tests/test_host.py).
-// exp(x) = 2^k (1 + q): k = rint(x log2 e), r = x - k ln 2 (ln 2 = hi + lo), q = expm1(r) = r (1 + r / 2 + r^2 / 6 + ...)
-__device__ __forceinline__ double expm1_reduced(double x, double& k) {      // |x| <= 90
-  k = rint(x * 1.4426950408889634074);
-  const double r = fma(-k, 1.9082149292705877e-10, fma(-k, 0.693147180369123816490, x));
-  double p = 1.6059043836821613e-10;                             // 1 / 13!
-  p = fma(p, r, 2.08767569878681e-09);                           // 1 / 12!
-  p = fma(p, r, 2.505210838544172e-08);
-  p = fma(p, r, 2.755731922398589e-07);
-  p = fma(p, r, 2.7557319223985893e-06);
-  p = fma(p, r, 2.48015873015873e-05);
-  p = fma(p, r, 0.0001984126984126984);
-  p = fma(p, r, 0.001388888888888889);
-  p = fma(p, r, 0.008333333333333333);
-  p = fma(p, r, 0.041666666666666664);
-  p = fma(p, r, 0.16666666666666666);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  return p * r;
+// expf / logf / log as the HOST's libm returns them (refmath.h: glibc's own evaluation, restated operation by operation
+// and proven equal to the installed library on every argument the search can form).  Rounds 2-3 evaluated the exact
+// functions and rounded once; glibc's float routines are not correctly rounded (logf(1 + expf(d)) differs for 0.5 % of
+// all d), which made the device's scores drift from the host search's by an ulp every few hundred calls and reordered
+// beam entries on long utterances (round-3 verdict: 78 of 88 hypotheses at 16 x 30 s).  The tables (2.5 KB) are copied to
+// LDS once per workgroup: the per-lane index makes them a gather, which LDS serves at full rate.
+__constant__ uint64_t kExp2fTab[refmath::kExp2fTabWords] = REFMATH_EXP2F_TAB;
+__constant__ double kLogfTab[refmath::kLogfTabWords] = REFMATH_LOGF_TAB;
+__constant__ double kLogTab[refmath::kLogTabWords] = REFMATH_LOG_TAB;
+struct MathTabs {
+  uint64_t exp2f[refmath::kExp2fTabWords];
+  double logf[refmath::kLogfTabWords];
+  double log[refmath::kLogTabWords];
+};
+__device__ __forceinline__ void load_math_tabs(MathTabs& m, int tid, int nthreads) {   // followed by a barrier at the caller
+  for (int i = tid; i < refmath::kExp2fTabWords; i += nthreads) m.exp2f[i] = kExp2fTab[i];
+  for (int i = tid; i < refmath::kLogfTabWords; i += nthreads) m.logf[i] = kLogfTab[i];
+  for (int i = tid; i < refmath::kLogTabWords; i += nthreads) m.log[i] = kLogTab[i];
 }
-__device__ __forceinline__ double scale2(double v, double k) {   // v 2^k for normal v and small integral k
-  return __longlong_as_double(__double_as_longlong(v) + ((long long)(int)k << 52));
-}
-__device__ __forceinline__ float expf_cr(float x) {              // x in [-17.5, 0]
-  double k;
-  const double q = expm1_reduced((double)x, k);
-  return (float)scale2(1.0 + q, k);
-}
-__device__ __forceinline__ float logf_cr(float s) {              // s in [1, 2]
-  if (s == 1.0f) return 0.f;
-  const double y0 = (double)(__builtin_amdgcn_logf(s) * 0.69314718f);
-  double k;
-  const double q = expm1_reduced(-y0, k);                        // k is 0 or -1
-  const double A = scale2((double)s, k);                         // s exp(-y0) - 1 = (A - 1) + A q: no cancellation near s = 1
-  const double e = (A - 1.0) + A * q;                             // log s = y0 + log1p(e), |e| < 2^-22: two terms are exact to 2^-68
-  return (float)(y0 + fma(-0.5 * e, e, e));
-}
-// log of a double in [2^-126, 2]: the candidates' log-probabilities (the reference takes log(p + FLT_MIN) in double,
-// ctc_beam_search_decoder.cpp:57-59, and rounds to float)
-__device__ __forceinline__ double log_pos(double x) {
-  const double y0 = (double)__builtin_amdgcn_logf((float)x) * 0.6931471805599453094;
-  double k;
-  const double q = expm1_reduced(-y0, k);                        // |k| <= 127
-  const double A = scale2(x, k);
-  const double e = (A - 1.0) + A * q;                             // |e| < 2^-16 (one ulp of a float log2 of up to 126)
-  return y0 + fma(-0.5 * e, e, e);
-}
-__device__ __forceinline__ float lse(float x, float y) {        // decoder_utils.h:41-49 with T = float
+__device__ __forceinline__ float lse(const MathTabs& m, float x, float y) {        // decoder_utils.h:41-49 with T = float
   if (x <= kNegInf) return y;
   if (y <= kNegInf) return x;
-  // logf(expf(x - m) + expf(y - m)) + m: the larger argument contributes expf(0) = 1 exactly; below 2^-25 the other one
-  // is absorbed by the float addition and logf(1) = 0
-  const float m = fmaxf(x, y), d = fminf(x, y) - m;
-  if (d < -17.5f) return 0.f + m;
-  return logf_cr(1.0f + expf_cr(d)) + m;
+  // logf(expf(x - m) + expf(y - m)) + m: the larger argument contributes expf(0) = 1 exactly; below exp(-17.5) < 2^-25
+  // the other one is absorbed by the float addition whatever its last bit, and logf(1) = 0
+  const float mx = fmaxf(x, y), d = fminf(x, y) - mx;
+  if (d < -17.5f) return 0.f + mx;
+  return refmath::ref_logf(1.0f + refmath::ref_expf(d, m.exp2f), m.logf) + mx;
 }
 // inclusive prefix sum over the wave: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then lane 15 of a row into the next
 // row and lane 31 into the upper half (DPP; lanes without a source add 0)
@@ -182,6 +147,7 @@ struct Cands {
 
 struct Shared {
   Beam beams[2];
+  MathTabs math;
   __align__(16) u64 keys[NT];   // SMALL path: one key per thread
   u64 exist_mask[2][BMAX];      // [frame parity][entry]: bit k = the child by candidate k is a beam entry itself
   float cb[BMAX], cnb[BMAX], cscore[BMAX];
@@ -369,10 +335,18 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
   }
   __syncthreads();
   if (tid < newn) {
+    // beam positions = ranks (the tie-break word of the next frame's keys is the position: beam.hip Search::better defines
+    // the order among prefixes of equal score and last character through it, and both searches have to agree on it).
+    // Keys are distinct (their low word is the slot): rank = number of kept keys below this one.
     const u64 key = sh.keys[tid];
     const int j = sh.kept_j[tid];
-    if (j < 0) keep_entry(sh, C, Nx, L, -1 - j, tid);
-    else keep_child(C, Nx, L, arena, 1 + t * beam + tid, j, (int)((key >> 16) & 0xffff) - 1, key_score(key), tid);
+    int rank = 0;
+    for (int q = 0; q < newn; q += 2) {      // keys[newn] may be stale: it only counts when it is a kept key
+      const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(sh.keys + q);
+      rank += (kk.x < key) + (q + 1 < newn && kk.y < key);
+    }
+    if (j < 0) keep_entry(sh, C, Nx, L, -1 - j, rank);
+    else keep_child(C, Nx, L, arena, 1 + t * beam + rank, j, (int)((key >> 16) & 0xffff) - 1, key_score(key), rank);
   }
   __syncthreads();
   if (profiling) rp.install += clock64() - c0;
@@ -397,6 +371,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   for (int i = tid; i < 2 * vstride / 16; i += NT) reinterpret_cast<int4*>(class_tab)[i] = make_int4(0, 0, 0, 0);
   for (int i = tid; i < 2 * HASH / 4; i += NT) reinterpret_cast<int4*>(sh.hpos)[i] = make_int4(0, 0, 0, 0);
   if (tid < 2) sh.cands[tid].n = 0;
+  load_math_tabs(sh.math, tid, NT);
   const int frames = a.in_len ? max(0, min(a.in_len[b], T)) : T;
   int2* arena = a.arena + (size_t)b * ((size_t)T * beam + 1);
   int cur = 0, nbm = 1;                     // current beam buffer, number of entries
@@ -453,7 +428,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     if (mine) {
       tab[c_nx] = (unsigned char)(pl + 1);
       K.c[pl] = c_nx;
-      K.lp[pl] = (float)log_pos((double)p_nx + (double)FLT_MIN);
+      K.lp[pl] = (float)refmath::ref_log((double)p_nx + (double)FLT_MIN, sh.math.log);
     }
     const u64 bm = __ballot(mine && c_nx == V - 1);
     if (pl == 0) {
@@ -510,13 +485,13 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
         const int j = hash_find(sh.hpos[cur], C, nbm, pid);
         if (profiling) p_scan += clock64() - t0;
         if (j >= 0) {
-          nbc = lse(nbc, child_lp(C, K, j, kc));
+          nbc = lse(sh.math, nbc, child_lp(C, K, j, kc));
           atomicOr(&exist[j], 1ull << kc);
         }
       }
       sh.cb[i] = bc;
       sh.cnb[i] = nbc;
-      sh.cscore[i] = lse(bc, nbc);
+      sh.cscore[i] = lse(sh.math, bc, nbc);
     }
     if (profiling) p_own += clock64() - t0;
     __syncthreads();
@@ -630,9 +605,30 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   }
 }
 
+// the device's evaluation of refmath.h, for the parity test against the host's libm (tests/test_gpu_parity.py)
+__global__ __launch_bounds__(256) void refmath_eval_kernel(int kind, const float* __restrict__ in, void* __restrict__ out, int n) {
+  __shared__ MathTabs m;
+  load_math_tabs(m, threadIdx.x, 256);
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float x = in[i];
+    if (kind == 0) static_cast<float*>(out)[i] = refmath::ref_expf(x, m.exp2f);
+    else if (kind == 1) static_cast<float*>(out)[i] = refmath::ref_logf(x, m.logf);
+    else if (kind == 2) static_cast<double*>(out)[i] = refmath::ref_log((double)x + (double)FLT_MIN, m.log);
+    else static_cast<float*>(out)[i] = lse(m, x, in[n + i]);   // kind 3: log_sum_exp(in[i], in[n + i])
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int mi355asr_launch_refmath_eval(int kind, const float* in, void* out, int n, hipStream_t s) {
+  if (kind < 0 || kind > 3 || n < 0) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(refmath_eval_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, s, kind, in, out, n);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 // the class tables (2 V bytes of dynamic LDS) sit next to the kernel's static LDS in the CU's 160 KB
 constexpr int kLdsBytes = 160 * 1024;
@@ -663,10 +659,17 @@ int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s) {
   const bool small = a->beam <= SMALL_BEAM && a->beam * (std::min(a->N, a->beam + 2) + 1) <= NT;
   const int dyn = 2 * tab_stride(a->V);     // the class tables
   if (a->V > kMaxClasses) return -2;       // mi355asr_beam_device_applicable
-  static const bool allowed =
-      hipFuncSetAttribute((const void*)beam_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(kMaxClasses)) == hipSuccess &&
-      hipFuncSetAttribute((const void*)beam_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(kMaxClasses)) == hipSuccess;
-  if (!allowed) return -2;
+  // per DEVICE: the attribute belongs to the kernel's code object on the device that is current (a process that drives
+  // several GPUs would otherwise launch large-V searches without it everywhere but on the first)
+  static bool allowed_on[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -2;
+  if (!allowed_on[dev]) {
+    if (hipFuncSetAttribute((const void*)beam_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(kMaxClasses)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)beam_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tab_stride(kMaxClasses)) != hipSuccess)
+      return -2;
+    allowed_on[dev] = true;
+  }
   if (small) hipLaunchKernelGGL(beam_search_kernel<true>, dim3(a->B), dim3(NT), dyn, s, *a);
   else hipLaunchKernelGGL(beam_search_kernel<false>, dim3(a->B), dim3(NT), dyn, s, *a);
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -183,6 +183,42 @@ def make_beam_kats():
     print("beam KATs:", len(meta), "cases; best of the last:", out["ids_%d" % (len(cases) - 1)][0][:out["lens_%d" % (len(cases) - 1)][0]][:10])
 
 
+def make_long_beam_kats():
+    """The reference's own decoder on LONG inputs (hundreds of frames, scores of -1000 and below, where a float32 ulp is
+    1e-4 and hypotheses tie in score all the time): beam_long_kat.npz.  prefix_compare orders by (score, last character)
+    only and the reference leaves the rest to std::nth_element over its DFS-ordered vector, so these vectors pin what IS
+    specified -- the ranked float32 scores, bit for bit -- and record how many hypotheses coincide beyond that."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_ctc_beam.so"))
+    lib.ref_ctc_beam_search.restype = ctypes.c_int
+    lib.ref_ctc_beam_search.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(2024)
+    cases = [(500, 120, 10, 0.99, 40, 0.05), (500, 120, 100, 0.99, 40, 1.0), (400, 200, 25, 0.9999, 25, 0.3), (600, 96, 10, 0.99, 40, 2.5)]
+    out, meta = {}, []
+    for k, (T, V, beam, cp, tn, temp) in enumerate(cases):
+        z = rng.standard_normal((T, V)) * temp
+        p = np.exp(z - z.max(-1, keepdims=True))
+        p = (p / p.sum(-1, keepdims=True)).astype(np.float32)
+        pd = np.ascontiguousarray(p, np.float64)
+        sc = (ctypes.c_double * beam)()
+        ids = (ctypes.c_int * (beam * T))()
+        ln = (ctypes.c_int * beam)()
+        n = lib.ref_ctc_beam_search(pd.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), T, V, beam, cp, tn, T, sc, ids, ln)
+        lens = np.array([ln[i] for i in range(n)], np.int32)
+        e_ids = np.full((n, int(lens.max()) if n else 0), -1, np.int32)
+        for i in range(n):
+            e_ids[i, :ln[i]] = [ids[i * T + j] for j in range(ln[i])]
+        out["probs_%d" % k] = p
+        out["ids_%d" % k] = e_ids
+        out["lens_%d" % k] = lens
+        out["scores_%d" % k] = np.array([sc[i] for i in range(n)], np.float64)
+        meta.append({"T": T, "V": V, "beam": beam, "cutoff_prob": cp, "cutoff_top_n": tn, "n": n})
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "beam_long_kat.npz"), **out)
+    print("long beam KATs:", len(meta), "cases")
+
+
 def make_stateful_beam_kats():
     """The reference's stateful BeamDecoder (ctc_beam_search_decoder.cpp:217-405) fed in pieces, with a reset in
     between: the beam after every decode() call."""
@@ -257,3 +293,4 @@ if __name__ == "__main__":
     make_onnx_fixtures()
     make_greedy_kats()
     make_beam_kats()
+    make_long_beam_kats()

@@ -286,29 +286,23 @@ def test_config5_batch16_as_benched_vs_oracle_and_pipelined_beam(torch_cuda):
         print("config 5, batch 16, utterance %d: %d of %d picked frames, text logits max|d| %.3g" % (u, n, Tp, e))
         assert e < TOL
         assert np.array_equal(got["text_argmax"][u].cpu().numpy(), lg[u].argmax(-1))
-    # beam search of the 16 utterances: device search == host search on the same logits (best hypothesis and score bit for
-    # bit; the rest of the beam as sets: equal float scores are ordered by std::sort in the reference)
-    # (both searches read the SAME probabilities.  At ~600 frames x 9171 classes their float32 scores still differ by an ulp or
-    # two of -4800 -- log() of 2 x 10^4 candidate probabilities evaluated by two libraries -- and hypotheses of these random-
-    # weight logits are ~1e-3 apart, so ranks may swap: the hypothesis SETS and the scores of common hypotheses must agree,
-    # as in the 2 x 30 s test above; the small known-answer cases are bit-exact, test_gpu_parity.py)
+    # beam search of the 16 utterances: device search == host search on the SAME probabilities, bit for bit -- ids, lengths,
+    # float32 scores, hypothesis counts, at beam 10 (the one-key-per-thread path) and beam 100 (the radix path).  Rounds 2-3
+    # accepted 80 % set overlap here: their device search rounded expf / logf "correctly", the host's C library does not
+    # (csrc/refmath.h), and over ~600 frames an ulp reordered hypotheses that are ~1e-3 apart.
     probs = torch.softmax(got["text_logits"], -1)
-    dev = ctc_prefix_beam_decode(probs, counts, 10, 0.99, 40)
-    host = ctc_prefix_beam_decode(probs.cpu().numpy(), counts, 10, 0.99, 40)
-    common = tot = best_same = 0
-    for u in range(B):
-        nh = int(min(dev[3][u], host[3][u]))
-        assert dev[3][u] == host[3][u]
-        hd = {tuple(dev[0][u, i, :dev[1][u, i]]): dev[2][u, i] for i in range(nh)}
-        hh = {tuple(host[0][u, i, :host[1][u, i]]): host[2][u, i] for i in range(nh)}
-        for hyp in set(hd) & set(hh):
-            assert abs(hd[hyp] - hh[hyp]) < 1e-4 * counts[u] + 1e-3
-        common += len(set(hd) & set(hh))
-        tot += nh
-        best_same += int(tuple(dev[0][u, 0, :dev[1][u, 0]]) == tuple(host[0][u, 0, :host[1][u, 0]]))
-        assert abs(dev[2][u, 0] - host[2][u, 0]) < 1e-4 * counts[u] + 1e-3
-    print("config 5, batch 16, beam 10: %d / %d hypotheses in common, best hypothesis identical for %d / %d utterances" % (common, tot, best_same, B))
-    assert common >= 0.8 * tot and best_same >= B - 3
+    probs_h = probs.cpu().numpy()
+    for beam in (10, 100):
+        dev = ctc_prefix_beam_decode(probs, counts, beam, 0.99, 40)
+        host = ctc_prefix_beam_decode(probs_h, counts, beam, 0.99, 40)
+        for name, a, b in zip(("ids", "lens", "scores", "n_hyp"), dev, host):
+            bad = np.argwhere(np.asarray(a) != np.asarray(b))
+            assert bad.size == 0, "beam %d: %s differ at %s (%d entries)" % (beam, name, bad[:3].tolist(), len(bad))
+        full = host[3] == beam                 # the other utterances' text logits are blank-dominated: the empty prefix alone survives
+        assert full.sum() >= B // 2 and host[1][full, 0].min() > 20 and (host[3][~full] == 1).all()
+        print("config 5, batch 16, beam %d: device search == host search on %d hypotheses (ids, lens, scores bit for bit)"
+              % (beam, int(host[3].sum())))
+    host = ctc_prefix_beam_decode(probs_h, counts, 10, 0.99, 40)
     fused = ctc_prefix_beam_decode(got["text_logits"], counts, 10, 0.99, 40, is_logits=True)     # softmax fused into the top-n kernel
     for u in range(B):
         assert abs(fused[2][u, 0] - host[2][u, 0]) < 1e-4 * counts[u] + 1e-3
