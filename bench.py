@@ -35,34 +35,29 @@ PEAK_SPLIT3_TFLOPS = 2500.0 / 6.0
 PEAK_HALF2_TFLOPS = 2500.0 / 3.0
 
 
-def kernel_peak(name):
-    if name == "subconv" and not int(os.environ.get("MI355ASR_SUBCONV_F32", "0") or 0) \
-            and not int(os.environ.get("MI355ASR_SUBCONV_V1", "0") or 0):
-        if int(os.environ.get("MI355ASR_SUBCONV_TERMS", "2") or 2) != 3:
-            return PEAK_HALF2_TFLOPS, "fp16 MFMA x3 (fp32 operands as two fp16 terms)"
-        return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
-    if name == "sublinear" and int(os.environ.get("MI355ASR_SUBLINEAR_SPLIT", "1") or 0):
-        return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
-    ring = {"ff1_qkv": ("MI355ASR_FF1QKV_RING", "2"), "tail_ff2": ("MI355ASR_TAILFF2_RING", "2"), "out_glu": ("MI355ASR_OUTGLU_SPLIT", "3"),
-            "tail_ff1": ("MI355ASR_TAILFF2_RING", "2"), "ctc_head": ("MI355ASR_HEAD_RING", "1")}
-    pp_env = {"out_glu": "MI355ASR_PP_OUTGLU", "ctc_head": "MI355ASR_PP_HEAD"}
-    if name in ("ff1_qkv", "tail_ff2", "tail_ff1", "out_glu", "ctc_head") and int(os.environ.get("MI355ASR_PP", "1") or 0) \
-            and int(os.environ.get(*ring[name]) or 0) and int(os.environ.get(pp_env.get(name, "MI355ASR_PP"), "1") or 0):
-        # the kernels of fused_pp.hip run the two-term scheme
-        return PEAK_HALF2_TFLOPS, "fp16 MFMA x3 (fp32 operands as two fp16 terms)"
-    if name in ring and int(os.environ.get(*ring[name]) or 0):
-        return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
-    if name == "stft" and int(os.environ.get("MI355ASR_FFT", "1") or 0) and int(os.environ.get("MI355ASR_FFT_SPLIT", "1") or 0):
-        # fft_stft_split_kernel: both DFT-32 stages on the matrix pipe with split operands (the dense fallback is fp32 MFMA)
-        if int(os.environ.get("MI355ASR_FFT_TERMS", "2") or 2) != 3:
-            return PEAK_HALF2_TFLOPS, "fp16 MFMA x3 (fp32 operands as two fp16 terms)"
-        return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
-    if name == "attention" and int(os.environ.get("MI355ASR_ATTN_SPLIT", "1") or 0):
-        # attention_split_kernel (head size 36, T <= 256): Q K^T and P V on the matrix pipe with split operands
-        if int(os.environ.get("MI355ASR_ATTN_TERMS", "2") or 2) != 3:
-            return PEAK_HALF2_TFLOPS, "fp16 MFMA x3 (fp32 operands as two fp16 terms)"
-        return PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"
-    return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA"
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
+# operand scheme (include/mi355asr.h MI355ASR_SCHEME_*) -> (peak in fp32-equivalent TFLOP/s, what the kernel executes).
+# The scheme of every kernel category comes from the LIBRARY (mi355asr_profile_schemes: recorded by the launcher that chose
+# the kernel variant), not from this script's reading of the environment.
+SCHEME_PEAK = {0: (PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA"),
+               1: (PEAK_SPLIT3_TFLOPS, "bf16 MFMA x6 (fp32 operands as three bf16 terms)"),
+               2: (PEAK_HALF2_TFLOPS, "fp16 MFMA x3 (fp32 operands as two fp16 terms)"),
+               3: (PEAK_BF16_TFLOPS, "bf16 MFMA (operands rounded to bf16)")}
+SCHEME_NAME = {0: "f32", 1: "bf16x3", 2: "f16x2", 3: "bf16", -1: "not run"}
+
+
+def read_schemes(lib, h):
+    """{kernel category: MI355ASR_SCHEME_*} of the last launch of each category on this handle"""
+    nk = len(_lib.KERNEL_NAMES)
+    out = (ctypes.c_int32 * nk)()
+    _lib.check(lib.mi355asr_profile_schemes(h.ptr, out, nk))
+    return {n: int(out[i]) for i, n in enumerate(_lib.KERNEL_NAMES)}
+
+
+def kernel_peak(name, schemes):
+    return SCHEME_PEAK[max(schemes.get(name, 0), 0)]
+
+
 PEAK_HBM_GBS = 8000.0
 
 S_CFG = dict(dmodel=144, reduction_factor=4, num_blocks=13, head_size=36, num_heads=4, kernel_size=32,
@@ -182,9 +177,6 @@ def cpu_baseline(seconds_budget=12.0):
             "published_tf2_1core": PUBLISHED_TF2_1CORE}
 
 
-PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md); config 3 runs its dense layers with bf16 operands
-
-
 def block_flops(M, B, T, d, k, nblocks):
     """ALGORITHMIC flops per step of the block-level categories of a stack of `nblocks` ConformerBlocks over M = B * T rows"""
     one = {"ffn": 2 * (2.0 * 2 * M * d * 4 * d), "qkv": 3 * 2.0 * M * d * d, "attention": 2 * 2.0 * B * T * T * d,
@@ -243,6 +235,7 @@ def extra_config3(lib, device, steps=20, with_cpu=True):
     pe, pc = _read_profile(lib, enc._h, nk, steps), _read_profile(lib, ctc._h, nk, steps)
     for m in (enc, ctc):
         _lib.check(lib.mi355asr_profile_enable(m._h.ptr, 0))
+    sch = {"enc": read_schemes(lib, enc._h), "ctc": read_schemes(lib, ctc._h)}
     # flops per step: encoder over 64 x 13 rows (frontend: 50 mel frames per chunk), CTCDecoder over 64 x 260 rows
     Me, Te, Mc, Tc = B * 13, 13, B * hist * 13, hist * 13
     fe = block_flops(Me, B, Te, d, 5, 4)
@@ -250,17 +243,16 @@ def extra_config3(lib, device, steps=20, with_cpu=True):
                "sublinear": 2.0 * Me * 20 * d * d})
     fc = block_flops(Mc, B, Tc, d, 32, 1)
     fc.update({"ctc_project": 2.0 * Mc * d * d, "ctc_head": 2.0 * Mc * d * V})
-    dense = ("ffn", "qkv", "attn_out", "pw1_glu", "conv_tail", "ctc_project", "ctc_head", "sublinear")
     kern = {}
     for tag, prof, fl in (("enc", pe, fe), ("ctc", pc, fc)):
         for n, (ms_step, launches) in prof.items():
             f = fl.get(n, 0.0)
-            peak = PEAK_BF16_TFLOPS if n in dense else (kernel_peak("subconv")[0] if n == "subconv" else PEAK_FP32_MFMA_TFLOPS)
-            kern[tag + "." + n] = {"launches_per_step": launches, "ms_per_step": round(ms_step, 4),
+            peak = kernel_peak(n, sch[tag])[0]
+            kern[tag + "." + n] = {"launches_per_step": launches, "ms_per_step": round(ms_step, 4), "scheme": SCHEME_NAME[sch[tag].get(n, -1)],
                                    "tflops": round(f / (ms_step * 1e-3) / 1e12, 2) if f else None,
                                    "frac_of_peak": round(f / (ms_step * 1e-3) / 1e12 / peak, 4) if f else None}
     dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
-    dpeak = PEAK_BF16_TFLOPS if dom.split(".")[1] in dense else (kernel_peak("subconv")[0] if dom.endswith("subconv") else PEAK_FP32_MFMA_TFLOPS)
+    dpeak = kernel_peak(dom.split(".")[1], sch[dom.split(".")[0]])[0]
     out = {"workload": "StreamingConformerCTC 15M, batch=64 streaming chunks of 0.5 s, bf16 MFMA operands, global CTC over 10 s of history",
            "dtype": "bf16 (GEMM operands; f32 accumulate, LayerNorm, softmax, frontend)", "steps": steps,
            "ms_per_step": round(t * 1e3, 3), "chunks_per_s": round(B / t, 1), "frames_per_s": round(B * 50 / t, 1),
@@ -339,6 +331,7 @@ def extra_config5(lib, device, steps=5, with_cpu=True):
     _timed(predict, steps, warmup=0)
     prof = _read_profile(lib, m._h, nk, steps)
     _lib.check(lib.mi355asr_profile_enable(m._h.ptr, 0))
+    sch = read_schemes(lib, m._h)
     T = m.out_frames(L)[1]
     Tp = int(out["logits"].shape[1])
     M, Mp = B * T, B * Tp
@@ -357,12 +350,11 @@ def extra_config5(lib, device, steps=5, with_cpu=True):
                                                                        ("help", "ContextHelper"), ("dec", "ChunkCTCDecoder"))}
     # band attention (chunk_conformer_blocks.py:158-176): a query sees win_front + win_back + 1 keys
     fl["attention"] = sum(nb[k] * 2 * 2.0 * (M if k in ("enc", "pick") else Mp) * wf[k] * d for k in nb)
-    split = ("tail_ff1", "tail_ff2", "ff1_qkv", "out_glu", "ctc_head", "subconv", "sublinear")
     kern = {}
     for n, (ms_step, launches) in prof.items():
         f = fl.get(n, 0.0)
-        peak = kernel_peak(n)[0] if n in ("tail_ff1", "tail_ff2", "ff1_qkv", "out_glu", "ctc_head") else (PEAK_SPLIT3_TFLOPS if n in split else PEAK_FP32_MFMA_TFLOPS)
-        kern[n] = {"launches_per_step": launches, "ms_per_step": round(ms_step, 4),
+        peak = kernel_peak(n, sch)[0]
+        kern[n] = {"launches_per_step": launches, "ms_per_step": round(ms_step, 4), "scheme": SCHEME_NAME[sch.get(n, -1)],
                    "tflops": round(f / (ms_step * 1e-3) / 1e12, 2) if f else None,
                    "frac_of_peak": round(f / (ms_step * 1e-3) / 1e12 / peak, 4) if f else None}
     dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
@@ -372,7 +364,7 @@ def extra_config5(lib, device, steps=5, with_cpu=True):
            "pipelined": {"ms_per_step": round(t_pipe * 1e3, 3), "frames_per_s": round(B * 3000 / t_pipe, 1),
                          "how": "beam search of batch n on a second stream (helper thread) while batch n + 1 is predicted (models.ChunkBeamPipeline)"},
            "roofline": {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"],
-                        "peak": round(kernel_peak(dom)[0] if dom in ("tail_ff1", "tail_ff2", "ff1_qkv", "out_glu", "ctc_head") else (PEAK_SPLIT3_TFLOPS if dom in split else PEAK_FP32_MFMA_TFLOPS), 1), "unit": "TFLOP/s",
+                        "peak": round(kernel_peak(dom, sch)[0], 1), "unit": "TFLOP/s",
                         "frac": kern[dom]["frac_of_peak"], "traffic": None,
                         "note": "categories of predict() summed over their launches of one step; the prefix beam search is a latency "
                                 "chain (16 utterances x T_pick dependent frames), not a roofline kernel"},
@@ -450,6 +442,53 @@ def config5_main(args, world, rank, device, use_dist):
         dist.destroy_process_group()
 
 
+# The same library with every split-operand kernel on its EXACT-product variant: fp32 operands as three bf16 terms, six MFMAs
+# per fragment pair, nothing below 2^-24 of a product dropped (rounds 1-2's arithmetic).  The headline runs two fp16 terms
+# where an operand bound is known; this leg puts the price and the numerical difference of that choice in the same line.
+EXACT_ENV = {"MI355ASR_PP": "0", "MI355ASR_PP_OUTGLU": "0", "MI355ASR_PP_HEAD": "0", "MI355ASR_SUBCONV_TERMS": "3",
+             "MI355ASR_ATTN_TERMS": "3", "MI355ASR_FFT_TERMS": "3"}
+LOGIT_SAMPLE = slice(0, None, 8)      # utterances 0, 8, ..., 56 of the batch
+
+
+def sample_logits(model, wav):
+    return model.ctc_logits(model.encode(wav))[LOGIT_SAMPLE].float().cpu().numpy()
+
+
+def exact_child(args, device):
+    """`bench.py --exact-child OUT.npy` (run by exact_products_leg with EXACT_ENV): K steps of the headline step, one JSON line"""
+    B, L = args.batch, int(args.seconds * 16000)
+    model = build_model(device, 0, 1, False)
+    wav = torch.from_numpy(synth_batch(0, B, L)).to(device)
+    model.prepare(B, L)
+    t = _timed(lambda: model.recognize(wav, reuse_buffers=True), args.steps, warmup=args.warmup)
+    np.save(args.exact_child, sample_logits(model, wav))
+    sch = read_schemes(_lib.lib(), model._h)
+    print(json.dumps({"ms_per_step": round(t * 1e3, 3), "value": round(B * (L // 160) / t, 1),
+                      "schemes": {n: SCHEME_NAME[v] for n, v in sch.items() if v >= 0}}), flush=True)
+
+
+def exact_products_leg(args, model, wav):
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "exact_logits.npy")
+        cmd = [sys.executable, os.path.abspath(__file__), "--exact-child", out, "--steps", str(args.steps), "--warmup", str(max(args.warmup, 2)),
+               "--batch", str(args.batch), "--seconds", str(args.seconds)]
+        r = subprocess.run(cmd, env=dict(os.environ, **EXACT_ENV), capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            return {"error": r.stderr[-400:]}
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        mine = sample_logits(model, wav)
+        theirs = np.load(out)
+    res["max_abs_logit_diff_vs_default"] = float(np.abs(mine - theirs).max())
+    res["argmax_equal_frames"] = "%d / %d" % (int((mine.argmax(-1) == theirs.argmax(-1)).sum()), mine.shape[0] * mine.shape[1])
+    res["unit"] = "audio-frames/s"
+    res["env"] = EXACT_ENV
+    res["what"] = ("the same step with every split-operand kernel on three exact bf16 terms (six MFMAs per product) instead of two fp16 terms; "
+                   "logits of utterances 0, 8, ..., 56 compared with the headline build's")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -463,6 +502,8 @@ def main():
                     help="2 (default): the headline ConformerCTC(S) line; 5: ChunkConformer + prefix beam as its own line")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip BASELINE configs 3 (streaming, bf16) and 5 (ChunkConformer + prefix beam) after the headline region")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the exact-product (three-term) comparison run")
+    ap.add_argument("--exact-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-kernel HIP events in the timed region (roofline fields become null)")
     args = ap.parse_args()
@@ -489,6 +530,8 @@ def main():
 
     if args.config == 5:
         return config5_main(args, world, rank, device, use_dist)
+    if args.exact_child:
+        return exact_child(args, device)
     B, L = args.batch, int(args.seconds * 16000)
     model = build_model(device, rank, world, use_dist)
     wav = torch.from_numpy(synth_batch(rank * B, B, L)).to(device)      # inputs resident in HBM
@@ -634,10 +677,12 @@ def main():
                               "tflops": round(fl[name] / (avg_ms * 1e-3) / 1e12, 2) if fl[name] else None}
         dom = max(kern, key=lambda n: kern[n]["share"]) if kern else None
         achieved = (kern[dom]["tflops"] or 0.0) if dom else 0.0
-        peak, peak_kind = kernel_peak(dom)
+        schemes = read_schemes(lib, h)           # what the library's launchers chose, per kernel category
+        peak, peak_kind = kernel_peak(dom, schemes)
         for n in kern:
+            kern[n]["scheme"] = SCHEME_NAME[schemes.get(n, -1)]
             if kern[n]["tflops"]:
-                kern[n]["frac_of_peak"] = round(kern[n]["tflops"] / kernel_peak(n)[0], 4)
+                kern[n]["frac_of_peak"] = round(kern[n]["tflops"] / kernel_peak(n, schemes)[0], 4)
         ab = algorithmic_bytes(B, L)
         for n in kern:
             if n in ab:
@@ -680,6 +725,8 @@ def main():
         }
         if os.environ.get("MI355ASR_BENCH_DEBUG_NO_GATHER") == "1":
             line["debug_no_gather"] = True       # the id exchange was removed from the timed step: not a data-parallel measurement
+        if world == 1 and not args.no_exact_leg:
+            line["exact_products"] = exact_products_leg(args, model, wav)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_extra_configs:

@@ -353,6 +353,15 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids_dev, const
 #define MI355ASR_K_TAIL_FF1 18    /* tail_ff1_ld_kernel   tail_ff2 of block i + ff1_qkv of block i + 1 in one launch  */
 #define MI355ASR_NUM_KERNELS 19
 int mi355asr_profile_enable(mi355asr_model* m, int32_t on);
+/* Which arithmetic the LAST launch of each kernel category used (recorded whether or not timing is enabled; -1: the category
+ * has not run on this handle).  Several kernels exist for most categories -- chosen by dmodel, row count, whether an operand
+ * bound is known, and the MI355ASR_* experiment switches -- and they run on different pipes; whoever prices a kernel against
+ * a roofline (bench.py) asks the library instead of re-deriving the choice. */
+#define MI355ASR_SCHEME_F32 0     /* exact fp32 products: v_mfma_f32_16x16x4_f32 / fp32 VALU                           */
+#define MI355ASR_SCHEME_BF16X3 1  /* fp32 operands as three bf16 terms, six bf16 MFMAs per fragment pair (exact to 2^-24) */
+#define MI355ASR_SCHEME_F16X2 2   /* fp32 operands as two fp16 terms, three fp16 MFMAs per fragment pair (2^-22 of the bound) */
+#define MI355ASR_SCHEME_BF16 3    /* operands rounded to bf16 (gemm_dtype = 1)                                         */
+int mi355asr_profile_schemes(const mi355asr_model* m, int32_t* scheme_out, int32_t n);
 int mi355asr_profile_read(mi355asr_model* m, double* ms_out, int64_t* count_out, int32_t n, int32_t reset);
 
 #ifdef __cplusplus

@@ -101,6 +101,7 @@ SIGNATURES = {
     "mi355asr_translator_workspace_bytes": (ctypes.c_int, [_P, _I, _I, _I, ctypes.POINTER(_SZ)]),
     "mi355asr_translator_forward": (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "mi355asr_profile_enable": (ctypes.c_int, [_P, _I]),
+    "mi355asr_profile_schemes": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32), _I]),
     "mi355asr_profile_read": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), _I, _I]),
 }
 

@@ -1260,6 +1260,8 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
 // =======================================================================================================
 // C ABI
 // =======================================================================================================
+thread_local int mi355asr_last_scheme = SCHEME_F32;   // launch.h: note_scheme
+
 extern "C" {
 
 const char* mi355asr_last_error(void) { return g_err; }
@@ -1377,6 +1379,13 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
     ex.push_back({"fully_connected/bias", {c.num_classes}});
   }
   *out = m;
+  return 0;
+}
+
+int mi355asr_profile_schemes(const mi355asr_model* m, int32_t* scheme_out, int32_t n) {
+  if (!m || !scheme_out || n < MI355ASR_NUM_KERNELS)
+    return fail(MI355ASR_EINVAL, "profile_schemes needs an array of at least %d entries", MI355ASR_NUM_KERNELS);
+  for (int i = 0; i < MI355ASR_NUM_KERNELS; ++i) scheme_out[i] = m->prof_scheme[i];
   return 0;
 }
 

@@ -282,7 +282,9 @@ int launch_attention_split(int hs, const AttnArgs& a, hipStream_t s) {
   const int qtiles = (a.Tq + 15) / 16;
   // MI355ASR_ATTN_TERMS=3: the three-term bf16 kernel also where the operand bounds are known
   static const bool three = [] { const char* v = getenv("MI355ASR_ATTN_TERMS"); return v && atoi(v) == 3; }();
-  if (a.h2_sq > 0.f && a.h2_sk > 0.f && a.h2_sv > 0.f && !three && ADG == 0)
+  const bool two = a.h2_sq > 0.f && a.h2_sk > 0.f && a.h2_sv > 0.f && !three && ADG == 0;
+  note_scheme(two ? SCHEME_F16X2 : SCHEME_BF16X3);
+  if (two)
     hipLaunchKernelGGL(attention_split_kernel<2>, dim3((qtiles + AW - 1) / AW, a.H, a.B), dim3(ATH), 0, s, a);
   else
     hipLaunchKernelGGL(attention_split_kernel<3>, dim3((qtiles + AW - 1) / AW, a.H, a.B), dim3(ATH), 0, s, a);

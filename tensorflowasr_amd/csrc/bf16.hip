@@ -381,6 +381,6 @@ int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
   return 0;
 }
 
-int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { return dispatch<PBf16>(epi, ln, a, s); }
+int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { note_scheme(SCHEME_BF16); return dispatch<PBf16>(epi, ln, a, s); }
 // same kernel with fp32 operands: wp = the fp32 P16 weights
-int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { return dispatch<PF32>(epi, ln, a, s); }
+int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { note_scheme(SCHEME_F32); return dispatch<PF32>(epi, ln, a, s); }

@@ -615,6 +615,7 @@ int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
   static const bool split_env = [] { const char* v = getenv("MI355ASR_ATTN_SPLIT"); return v ? atoi(v) != 0 : true; }();
   if (lds_env && split_env && attention_split_applicable(HS, a))
     return launch_attention_split(HS, a, s);
+  note_scheme(SCHEME_F32);
   if (lds_env && attention_lds_applicable(HS, a)) return launch_attention_lds(HS, a, s);
   if (HS == 36) launch_attention_t<36>(a, s);
   else if (HS == 64) launch_attention_t<64>(a, s);

@@ -448,13 +448,16 @@ int launch_fft_stft(const FftStftArgs& a, hipStream_t s) {
   // two-term kernel independent of the signal's amplitude: no bound is assumed)
   static const bool three = [] { const char* v = getenv("MI355ASR_FFT_TERMS"); return v && atoi(v) == 3; }();
   if (split && a.w1h && a.w2h && !three) {
+    note_scheme(SCHEME_F16X2);
     hipLaunchKernelGGL(fft_stft_split_kernel<2>, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
     return 0;
   }
   if (split && a.w1s && a.w2s) {
+    note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(fft_stft_split_kernel<3>, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
     return 0;
   }
+  note_scheme(SCHEME_F32);
   hipLaunchKernelGGL(fft_stft_kernel, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
 }

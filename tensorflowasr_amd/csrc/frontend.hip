@@ -487,6 +487,7 @@ int launch_subconv(int D, const SubConvArgs& a, hipStream_t s) {
   // MI355ASR_SUBCONV_F32=1: the fp32-MFMA register-stream kernel instead of the split-bf16 one (both in subconv.hip)
   static const bool f32k = [] { const char* v = getenv("MI355ASR_SUBCONV_F32"); return v && atoi(v) != 0; }();
   if (!v1 && !f32k && launch_subconv_split(D, a, s) == 0) return 0;       // dmodel 144 / 256 / 512 with the split pack
+  note_scheme(SCHEME_F32);
   if (D == 144 && !v1) return launch_subconv144(a, s);
   if (D == 144) { launch_subconv_t<144>(a, s); return 0; }
   static const bool v1_256 = [] { const char* v = getenv("MI355ASR_SUBCONV256_V1"); return v && atoi(v) != 0; }();

@@ -1511,11 +1511,13 @@ int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
   if (ringk == 2 && a.slabs) {     // 2 (default): loader-wave ring kernel; round 3: pair-pipelined (fused_pp.hip) unless MI355ASR_PP=0
     if (launch_pp_ff1_qkv(a, s) == 0) return 0;
     const int tiles = (a.M + 15) / 16;
+    note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(ff1_qkv_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
     return 0;
   }
   if (ringk && a.slabs) {
     const int tiles = (a.M + 15) / 16;
+    note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(ff1_qkv_ring_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
     return 0;
   }
@@ -1523,6 +1525,7 @@ int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
 }
 int launch_ff1_qkv_impl(const Ff1QkvArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
+  note_scheme(SCHEME_F32);
   hipLaunchKernelGGL(ff1_qkv_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
 }
@@ -1533,6 +1536,7 @@ int launch_out_glu(const OutGluArgs& a, hipStream_t s) {
   // 2 (default) = the same on the four-slot slab ring, three slabs of DMA in flight (23.3 us)
   static const int split = [] { const char* v = getenv("MI355ASR_OUTGLU_SPLIT"); return v ? atoi(v) : 3; }();
   if (a.og_slabs && split == 3 && launch_pp_out_glu(a, s) == 0) return 0;   // the two-term fp16 stream (fused_pp.hip)
+  note_scheme((a.og_slabs && (split == 3 || split == 2)) || (a.out_ws && a.pw1_ws && split == 1) ? SCHEME_BF16X3 : SCHEME_F32);
   if (a.og_slabs && split == 3)     // 3 (default): loader-wave ring kernel
     hipLaunchKernelGGL(out_glu_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
   else if (a.og_slabs && split == 2)
@@ -1558,6 +1562,7 @@ int launch_head_ld(const GemmArgs& a, const float* slabs, int groups, hipStream_
     return 0;
   }
 #endif
+  note_scheme(SCHEME_BF16X3);
   hipLaunchKernelGGL(head_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(slabs), groups);
   return 0;
 }
@@ -1566,6 +1571,7 @@ int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t
   if (a.NT != KB || a.K % 32 != 0 || a.M <= 0 || !ws) return -1;
   // MI355ASR_SUBLINEAR_LD=0: every wave issues its own DMAs (round 1) instead of the loader-wave kernel
   static const bool ld = [] { const char* v = getenv("MI355ASR_SUBLINEAR_LD"); return v ? atoi(v) != 0 : true; }();
+  note_scheme(SCHEME_BF16X3);
   if (ld)
     hipLaunchKernelGGL(sublinear_split_ld_kernel, dim3((a.M + 63) / 64), dim3(2 * BLOCK_THREADS), 0, s, a,
                        reinterpret_cast<const u32x4_t*>(ws));
@@ -1593,6 +1599,7 @@ int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s) {
   if (!tail_ff1_available() || !a.slabs || !b.slabs || a.M != b.M) return -1;
   if (launch_pp_tail_ff1(a, b, s) == 0) return 0;
   const int tiles = (a.M + 15) / 16;
+  note_scheme(SCHEME_BF16X3);
   hipLaunchKernelGGL(tail_ff1_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, b);
   return 0;
 }
@@ -1603,13 +1610,16 @@ int launch_tail_ff2(const TailFf2Args& a, hipStream_t s) {
   static const int ringk = [] { const char* v = getenv("MI355ASR_TAILFF2_RING"); return v ? atoi(v) : 2; }();
   if (ringk == 2 && a.slabs) {     // 2 (default): loader-wave ring kernel; round 3: pair-pipelined (fused_pp.hip) unless MI355ASR_PP=0
     if (launch_pp_tail_ff2(a, s) == 0) return 0;
+    note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(tail_ff2_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
     return 0;
   }
   if (ringk && a.slabs) {
+    note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(tail_ff2_ring_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
     return 0;
   }
+  note_scheme(SCHEME_F32);
   hipLaunchKernelGGL(tail_ff2_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
 }

@@ -803,6 +803,7 @@ int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, 
   static const bool ring_on = [] { const char* v = getenv("MI355ASR_HEAD_RING"); return v ? atoi(v) != 0 : true; }();
   if (!on || !ring_on || !pp_enabled() || !pp || groups < 1 || a.n_valid > 144 * groups || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
+  note_scheme(SCHEME_F16X2);
   hipLaunchKernelGGL(pp_head_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, groups);
   return 0;
 }
@@ -811,12 +812,14 @@ int launch_pp_out_glu(const OutGluArgs& a, hipStream_t s) {
   static const bool on = [] { const char* v = getenv("MI355ASR_PP_OUTGLU"); return v ? atoi(v) != 0 : true; }();
   if (!on || !pp_enabled() || !a.pp_slabs || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
+  note_scheme(SCHEME_F16X2);
   hipLaunchKernelGGL(pp_out_glu_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
   return 0;
 }
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s) {
   if (!pp_enabled() || !a.pp_slabs || !b.pp_slabs || a.M != b.M || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
+  note_scheme(SCHEME_F16X2);
 #ifdef MI355ASR_DIAG_KERNELS
   static const int dg = [] { const char* v = getenv("MI355ASR_PP_DIAG"); return v ? atoi(v) : 0; }();
   if (dg) {
@@ -842,6 +845,7 @@ int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s)
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s) {
   if (!pp_enabled() || !a.pp_slabs || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
+  note_scheme(SCHEME_F16X2);
   if (pp_dw_fold(a)) {
     hipLaunchKernelGGL((pp_block_kernel<true, false, 0, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{});
     return 0;
@@ -852,6 +856,7 @@ int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s) {
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
   if (!pp_enabled() || !b.pp_slabs || b.M <= 0) return -1;
   const int tiles = (b.M + 15) / 16;
+  note_scheme(SCHEME_F16X2);
   hipLaunchKernelGGL((pp_block_kernel<false, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, TailFf2Args{}, b);
   return 0;
 }

@@ -588,6 +588,7 @@ static int launch_terms(int epi, bool ln, const Gemm16Args& a, const void* ring,
 // terms = 3: fp32 operands exactly split; 1: bf16 mode (ring of host-rounded bf16 weights, activations rounded at the operand)
 int launch_gemm_ring(int epi, bool ln, const Gemm16Args& a, const void* ring, int terms, hipStream_t s) {
   if (!ring || !gemm_ring_applicable(epi, ln, a)) return -1;
+  note_scheme(terms == 1 ? SCHEME_BF16 : SCHEME_BF16X3);
   // MI355ASR_RING_EDMA=0: every wave issues its share of the slab DMAs (the first version) instead of the lower four
   static const bool edma = [] { const char* v = getenv("MI355ASR_RING_EDMA"); return v ? atoi(v) != 0 : true; }();
   if (edma) return terms == 1 ? launch_terms<1, true>(epi, ln, a, ring, s) : launch_terms<3, true>(epi, ln, a, ring, s);

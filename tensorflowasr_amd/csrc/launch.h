@@ -3,6 +3,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- which arithmetic a launch used (reported to callers through mi355asr_profile_schemes) ----
+// A launch_* function that picks between kernel variants records the operand scheme of the one it launched; the profiling
+// scope around the launch (model.h ProfScope) files it under the kernel category.  bench.py prices each kernel against the
+// peak of the pipe the LIBRARY says it ran on instead of mirroring the environment switches.
+enum OperandScheme {
+  SCHEME_F32 = 0,      // v_mfma_f32_16x16x4_f32 / fp32 VALU: exact fp32 products
+  SCHEME_BF16X3 = 1,   // fp32 operands as three bf16 terms, six v_mfma_f32_16x16x16/32_bf16 per fragment pair
+  SCHEME_F16X2 = 2,    // fp32 operands as two fp16 terms, three v_mfma_f32_16x16x32_f16 per fragment pair
+  SCHEME_BF16 = 3,     // operands rounded to bf16 (gemm_dtype = bfloat16): one MFMA per fragment pair
+};
+extern thread_local int mi355asr_last_scheme;   // api.hip
+static inline void note_scheme(int s) { mi355asr_last_scheme = s; }
+
 enum { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_QKV = 2, EPI_GLU = 3, EPI_HEAD = 4 };
 
 // column-chunk width (in 16-wide tiles) a wave accumulates at once, per (dmodel, epilogue).

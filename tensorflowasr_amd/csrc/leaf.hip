@@ -422,6 +422,7 @@ int launch_leaf_conv_pool(const LeafConvArgs& a, hipStream_t s) {
   return 0;
 }
 int launch_leaf_conv_pool_split(int ns, const LeafConvArgs& a, hipStream_t s) {
+  note_scheme(SCHEME_BF16X3);   // ns bf16 terms per operand (2: the Gabor filters' third term is below fp32 resolution)
   if (ns == 3) hipLaunchKernelGGL(leaf_conv_pool_split_kernel<3>, dim3(a.NH, a.B), dim3(STH), 0, s, a);
   else if (ns == 2) hipLaunchKernelGGL(leaf_conv_pool_split_kernel<2>, dim3(a.NH, a.B), dim3(STH), 0, s, a);
   else return -1;

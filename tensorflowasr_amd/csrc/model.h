@@ -159,6 +159,8 @@ struct mi355asr_model {
   mutable std::vector<Pending> ev_pending;
   mutable double prof_ms[MI355ASR_NUM_KERNELS] = {0};
   mutable int64_t prof_cnt[MI355ASR_NUM_KERNELS] = {0};
+  mutable int prof_scheme[MI355ASR_NUM_KERNELS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // OperandScheme of the last launch
+  static_assert(MI355ASR_NUM_KERNELS == 19, "one initialiser per kernel category");
   hipEvent_t get_event() const {
     if (!ev_free.empty()) { hipEvent_t e = ev_free.back(); ev_free.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -177,9 +179,11 @@ struct ProfScope {
   hipStream_t s;
   hipEvent_t e0 = nullptr;
   ProfScope(const mi355asr_model* m_, int cat_, hipStream_t s_) : m(m_), cat(cat_), s(s_) {
+    mi355asr_last_scheme = SCHEME_F32;      // launchers with a choice of pipes overwrite it (common.h: note_scheme)
     if (m->prof) { e0 = m->get_event(); (void)hipEventRecord(e0, s); }
   }
   ~ProfScope() {
+    m->prof_scheme[cat] = mi355asr_last_scheme;
     if (m->prof && e0) {
       hipEvent_t e1 = m->get_event();
       (void)hipEventRecord(e1, s);

@@ -611,8 +611,10 @@ int launch_subconv144(const SubConvArgs& a, hipStream_t s) {
 template <int DIAG>
 static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGeom RS, int rows, int late_mode, hipStream_t s) {
   const dim3 g128(g144.x, g144.y, d / 128);
+  note_scheme(SCHEME_BF16X3);
   if constexpr (DIAG == 0) {
     if (a.w2h) {
+      note_scheme(SCHEME_F16X2);
       switch (d) {
         case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2>), g144, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
         case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 256, 8, 2>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;

@@ -105,6 +105,70 @@ def test_config2_batch64_10s_nonblank_head_ids_vs_oracle(torch_cuda):
     print("config 2, token-emitting head: logits max|d| %.3g, undecided frames %d / 1000 %s" % (err, len(report), report[:4]))
 
 
+def _all64_against_fixture(m, head, torch):
+    """Every one of the 64 benched utterances against tests/golden/config2_oracle_b64.npz (fp64 oracle, written by
+    tests/golden/make_config2_b64.py): encoder rows, logits (all classes of every 50th frame, the oracle's four largest
+    classes of EVERY frame), per-frame argmax, greedy ids and lengths.  A frame may differ in argmax only when the oracle's
+    own margin between the two classes is within ten times the measured logit error; ids must then equal the collapse of the
+    oracle argmax with exactly those frames patched (helpers.assert_frames_and_ids, on the stored top-4 instead of full rows)."""
+    from helpers import _parity_log
+    from tensorflowasr_amd.synthetic import synth_batch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_oracle_b64.npz"))
+    x = synth_batch(0, 64, 160000)
+    xd = torch.from_numpy(x).cuda()
+    ids, lens = m.recognize(xd)
+    ids, lens = ids.cpu().numpy().copy(), lens.cpu().numpy().copy()
+    enc = m.encode(xd)
+    logits, amax = m.ctc_logits(enc, return_argmax=True)
+    enc, logits, amax = enc.cpu().numpy(), logits.cpu().numpy(), amax.cpu().numpy()
+    e_enc = maxdiff(enc[:, ::10], g[head + "_enc_every10"])
+    top_idx, top_val = g[head + "_top4_idx"].astype(np.int64), g[head + "_top4_val"]
+    e_lg = max(maxdiff(logits[:, ::50], g[head + "_logits_every50"]), maxdiff(np.take_along_axis(logits, top_idx, -1), top_val))
+    assert e_enc < TOL and e_lg < TOL, (e_enc, e_lg)
+    assert np.array_equal(amax, logits.argmax(-1)), "in-kernel argmax != argmax of the kernel's own logits"
+    ra = top_idx[..., 0]
+    report = []
+    for b, t in np.argwhere(amax != ra):
+        pos = np.flatnonzero(top_idx[b, t] == amax[b, t])
+        assert pos.size, "frame (%d, %d): the kernel's class %d is not among the oracle's four largest" % (b, t, amax[b, t])
+        margin = float(top_val[b, t, 0] - top_val[b, t, pos[0]])
+        assert margin <= 10 * e_lg, "argmax differs on a frame the oracle decides clearly: (%d, %d) margin %.3g, logit error %.3g" % (b, t, margin, e_lg)
+        report.append((int(b), int(t), margin))
+    _parity_log({"tag": "config2_all64_" + head, "frames": int(ra.size), "logits_max_abs_err": e_lg, "excused_frames": len(report),
+                 "excused": [{"utt": r[0], "frame": r[1], "oracle_margin": r[2]} for r in report[:20]]})
+    assert len(report) <= 0.005 * ra.size
+    patched = ra.copy()
+    for b, t, _ in report:
+        patched[b, t] = amax[b, t]
+    rid, rlen = co.ctc_collapse(patched.astype(np.int32), [250] * 64, 1331)
+    assert np.array_equal(lens, rlen) and np.array_equal(ids, rid)
+    if not report:
+        assert np.array_equal(ids, g[head + "_ids"]) and np.array_equal(lens, g[head + "_lens"])
+    print("config 2, all 64 utterances, head '%s': encoder max|d| %.3g, logits max|d| %.3g, %d / 16000 frames excused, %d tokens"
+          % (head, e_enc, e_lg, len(report), int(lens.sum())))
+    return e_lg, report
+
+
+def test_config2_all_64_utterances_as_benched_vs_oracle_fixture(bench_model, torch_cuda):
+    m, _ = bench_model
+    _all64_against_fixture(m, "trained", torch_cuda)
+
+
+def test_config2_all_64_utterances_token_emitting_head_vs_oracle_fixture(torch_cuda):
+    """the head that emits tokens (15 411 over the batch): ids of all 64 utterances, every frame's argmax"""
+    from tensorflowasr_amd.models import ConformerCTC
+    import bench
+    cfg = dict(co.CONFORMER_S)
+    w = co.encoder_weights(cfg, seed=0)
+    w.update(co.ctc_decoder_weights(cfg, 1332, seed=1))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_oracle_b64.npz"))
+    w["fully_connected/bias"] = g["tokens_fc_bias"]
+    m = ConformerCTC(1332, **bench.S_CFG)
+    m.load_weights(w, by_name=False)
+    _, report = _all64_against_fixture(m, "tokens", torch_cuda)
+    assert len(report) <= 0.002 * 16000
+
+
 def test_config2_trained_ctc_decoder_at_batch64(torch_cuda):
     """the reference's exported CTCDecoder on 64 x 250 frames (the fused block kernels' row count) with inputs that make
     it emit tokens: argmax identical to the reference graph's own output (tests/golden/ctc_decoder_io.npz, 26 % of

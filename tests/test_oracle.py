@@ -390,3 +390,23 @@ def test_documented_deviation_argmax_on_logits_vs_log_softmax_on_sub_ulp_ties():
     for _ in range(8):
         wide[5] = np.nextafter(wide[5], np.float32(1.0))
     assert _tf_greedy_argmax_fp32(wide) == 5 == int(co.frame_argmax(wide[None, None])[0, 0]) == int(np.argmax(wide))
+
+
+def test_config2_b64_fixture_is_what_its_script_produces():
+    """tests/golden/config2_oracle_b64.npz (all 64 benched utterances through the fp64 oracle) -- one utterance per head is
+    recomputed with tests/golden/make_config2_b64.py's own functions and must reproduce the stored rows."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_config2_b64", os.path.join(root, "tests", "golden", "make_config2_b64.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    fx = np.load(g.OUT)
+    assert fx["trained_top4_idx"].shape == (64, 250, 4) and int(fx["tokens_lens"].sum()) > 10000
+    g._W["trained"] = g.bench_weights()
+    u = 37
+    head, uu, enc10, idx, val, lg50 = g.one(("trained", u))
+    assert np.array_equal(idx, fx["trained_top4_idx"][u]) and np.array_equal(val, fx["trained_top4_val"][u])
+    assert np.array_equal(enc10, fx["trained_enc_every10"][u]) and np.array_equal(lg50, fx["trained_logits_every50"][u])
+    ids, lens = co.ctc_collapse(fx["tokens_top4_idx"][..., 0].astype(np.int32), [250] * 64, 1331)
+    assert np.array_equal(ids, fx["tokens_ids"]) and np.array_equal(lens, fx["tokens_lens"])
+
