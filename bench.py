@@ -527,6 +527,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
         from tensorflowasr_amd.parallel import all_gather_ids
+        # RCCL has to see exactly the N ranks the driver asked for, one GPU each: a count of the ranks through the backend itself
+        probe = torch.ones(1, dtype=torch.int32, device=device)
+        dist.all_reduce(probe)
+        if int(probe.item()) != world or dist.get_world_size() != args.gpus:
+            raise SystemExit("RCCL sees %d ranks (all_reduce counted %d), --gpus %d" % (dist.get_world_size(), int(probe.item()), args.gpus))
 
     if args.config == 5:
         return config5_main(args, world, rank, device, use_dist)
@@ -703,7 +708,8 @@ def main():
             "config": {"workload": "ConformerCTC(S) 10M offline, batch=%d %gs utts per GPU, fp32, waveform->CTC greedy ids"
                                    % (B, args.seconds),
                        "global_batch": world * B, "samples_per_utt": L, "enc_frames": T,
-                       "parallelism": "dp%d" % world, "weights": "random-init encoder + reference-exported CTCDecoder"},
+                       "parallelism": "dp%d" % world, "weights": "random-init encoder + reference-exported CTCDecoder",
+                       "rccl_ranks": (dist.get_world_size() if use_dist else None), "backend": ("nccl (RCCL)" if use_dist else None)},
             "value_is": "whole-job aggregate over n_gpus (driver contract); the metric's per-GPU rate is frames_per_s_per_gpu",
             "arithmetic": "fp32 values and fp32 accumulation; products on the 16-bit matrix pipe from split fp32 operands -- two fp16 terms of "
                           "power-of-two scaled operands (three MFMAs) where a bound is known, else three exact bf16 terms (six) or the fp32 "

@@ -189,10 +189,13 @@ float f16_to_float(uint16_t h) {
   return f;
 }
 // largest power of two s with bound * s <= 2^15 (fp16's largest finite value is 65504: a factor of two to spare)
-float half_scale_for(double bound) {
+// max_shift: kernels that multiply two or three such scales in fp32 (attention: sq * sk, probabilities * sv) pass 40 and get
+// 0 = "no usable bound" (the three-term kernel runs) for degenerate weights instead of a product that overflows to inf
+float half_scale_for(double bound, int max_shift = 100) {
   if (!(bound > 0.0) || !std::isfinite(bound)) return 0.f;
   int e; std::frexp(bound, &e);                                       // bound = f 2^e, f in [0.5, 1)
-  const int k = std::max(-100, std::min(100, 15 - e));
+  const int k = 15 - e;
+  if (k > max_shift || k < -max_shift) return max_shift < 100 ? 0.f : std::ldexp(1.0f, std::max(-100, std::min(100, k)));
   return std::ldexp(1.0f, k);
 }
 // pack_conv2_split's fragment order with TWO fp16 terms of kernel * wscale (subconv.hip, two-term scheme)
@@ -579,9 +582,9 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
         bnd[n / d] = std::max(bnd[n / d], sum);
       }
       bnd[0] *= 1.4426950408889634 / std::sqrt((double)hs);
-      o.att_h2[0] = half_scale_for(bnd[0] * 1.0001);
-      o.att_h2[1] = half_scale_for(bnd[1] * 1.0001);
-      o.att_h2[2] = half_scale_for(bnd[2] * 1.0001);
+      o.att_h2[0] = half_scale_for(bnd[0] * 1.0001, 40);
+      o.att_h2[1] = half_scale_for(bnd[1] * 1.0001, 40);
+      o.att_h2[2] = half_scale_for(bnd[2] * 1.0001, 40);
     }
   }
   const std::string c = p + "/conv_module";

@@ -228,10 +228,12 @@ DEV Split8 split8h(f32x4 lo, f32x4 hi) {
 DEV f32x4 mma32h(u32x4_t a, u32x4_t b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
-// 2^k with m * 2^k in [2^13, 2^14), k in [-14, 15] (0 gives 2^15), and its reciprocal
+// 2^k with m * 2^k in [2^13, 2^14), k in [-14, 100], and its reciprocal.  The scale only ever multiplies fp32 values
+// (operands before the split, accumulators after the MFMAs), so nothing ties it to fp16's range: columns of a quiet signal
+// (peak 1e-8) are normalised like any other and keep both fp16 terms normal.  Below 2^-87 (and for m = 0) k stays at 100.
 DEV float pow2_scale(float m) {
   const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u);
-  return __builtin_bit_cast(float, (unsigned)(127 + min(15, max(-14, 140 - e))) << 23);
+  return __builtin_bit_cast(float, (unsigned)(127 + min(100, max(-14, 140 - e))) << 23);
 }
 DEV float recip_pow2(float s) { return __builtin_bit_cast(float, 0x7f000000u - __builtin_bit_cast(unsigned, s)); }
 DEV float max8(f32x4 a, f32x4 b) {

@@ -721,6 +721,14 @@ def ctc_prefix_beam_decode(x, input_length=None, beam_width=10, cutoff_prob=0.99
     lib = _lib.lib()
     on_gpu = torch.is_tensor(x) and x.is_cuda
     B, T, V = x.shape
+    if T == 0 and B > 0:
+        # no frames at all (ChunkConformer: a batch in which the phone picker kept nothing): every utterance decodes to the
+        # empty prefix with log-probability 0, as T_u = 0 does inside a batch (the C entry points want T >= 1)
+        ml = int(max_len or 1)
+        lens = np.zeros((B, beam_width), np.int32)
+        scores = np.full((B, beam_width), -np.finfo(np.float32).max, np.float32)
+        scores[:, 0] = 0.0
+        return np.full((B, beam_width, ml), -1, np.int32), lens, scores, np.ones((B,), np.int32)
     max_len = int(max_len or T)
     nthreads = int(num_threads or min(B, os.cpu_count() or 1))
     ids = np.empty((B, beam_width, max_len), np.int32)
@@ -778,18 +786,20 @@ class ChunkBeamPipeline:
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
         logits.record_stream(self.side)                    # the caching allocator must not hand the logits out again early
-        prev = self.pending.result() if self.pending is not None else None
-        self.pending = self.pool.submit(self._decode, logits, counts, ready)
-        return prev
+        # the new batch's search is queued BEFORE the previous result is looked at: if that search raised, the exception
+        # surfaces here once, and the pipeline goes on with the batch just predicted instead of re-raising a stale future
+        old, self.pending = self.pending, self.pool.submit(self._decode, logits, counts, ready)
+        return old.result() if old is not None else None
 
     def flush(self):
-        prev = self.pending.result() if self.pending is not None else None
-        self.pending = None
-        return prev
+        old, self.pending = self.pending, None
+        return old.result() if old is not None else None
 
     def close(self):
-        self.flush()
-        self.pool.shutdown()
+        try:
+            self.flush()
+        finally:
+            self.pool.shutdown()
 
 
 class BeamDecoder:

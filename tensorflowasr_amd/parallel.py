@@ -37,62 +37,115 @@ def broadcast_weights(weights, src=0, device=None, group=None):
     return out
 
 
-def all_gather_ids(ids, lens, group=None, async_op=False):
-    """ids int32 [B_local, T] (-1 padded), lens int32 [B_local] -> ([B_total, T], [B_total]) on every rank,
-    in rank order (requires equal B_local on all ranks, which shard_range gives when world | B_total).
+def shard_sizes(n_items, world):
+    """[rows of rank 0, rows of rank 1, ...] under shard_range"""
+    return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
+
+
+def _pad_rows(x, rows, fill):
+    if x.shape[0] == rows:
+        return x
+    pad = torch.full((rows - x.shape[0],) + tuple(x.shape[1:]), fill, dtype=x.dtype, device=x.device)
+    return torch.cat([x, pad], 0)
+
+
+def _valid_rows(n_total, world, b_pad, device):
+    """indices of the real rows in a [world * b_pad, ...] gather of shard_range shards padded to b_pad rows each"""
+    idx = [r * b_pad + i for r, n in enumerate(shard_sizes(n_total, world)) for i in range(n)]
+    return torch.as_tensor(idx, dtype=torch.long, device=device)
+
+
+def _check_local_rows(B, n_total, group):
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    want = shard_sizes(n_total, world)[rank]
+    if B != want:
+        raise ValueError("rank %d holds %d utterances, shard_range(%d, %d, %d) gives %d: every rank has to decode exactly its "
+                         "shard_range slice of the batch" % (rank, B, n_total, rank, world, want))
+
+
+def all_gather_ids(ids, lens, group=None, async_op=False, n_total=None):
+    """ids int32 [B_local, T] (-1 padded), lens int32 [B_local] -> ([B_total, T], [B_total]) on every rank, in rank order.
+
+    n_total = None: every rank holds the same number of utterances (world | B_total; bench.py's weak-scaling batches).
+    all_gather_into_tensor cannot take ragged inputs -- with unequal B_local it fails or, worse, mis-sizes -- so a batch that
+    does not divide (the reference's batch wrapper takes ANY batch: ctc_beam_search_decoder.cpp:426-459) passes n_total =
+    the global utterance count: every rank pads its shard_range slice to ceil(n_total / world) rows, the padding rows are
+    dropped after the exchange (each rank knows every other rank's count from shard_range: no extra collective).
 
     async_op=True returns (work, ids_all, lens_all) at once: the collective runs on RCCL's stream behind the kernels
     already queued, the caller's stream goes on with the next batch and `work.wait()` (or a device synchronise) makes
-    the views valid -- one batch's exchange then overlaps the next batch's recognition."""
+    the views valid -- one batch's exchange then overlaps the next batch's recognition.  (With n_total the padded gather
+    buffers are returned through a view that drops the padding rows after wait(): use `work.result()`.)"""
     world = dist.get_world_size(group)
     B, T = ids.shape
+    b_pad = B
+    if n_total is not None:
+        _check_local_rows(B, n_total, group)
+        b_pad = -(-n_total // world)
+        ids, lens = _pad_rows(ids, b_pad, -1), _pad_rows(lens, b_pad, 0)
     if async_op:
         # nothing on the caller's stream: the two tensors go out as they are (the caller keeps them untouched until the
         # work is done -- rotating output buffers, recognize(out=...)), both collectives on RCCL's stream
-        all_ids = torch.empty((world * B, T), dtype=ids.dtype, device=ids.device)
-        all_lens = torch.empty((world * B,), dtype=lens.dtype, device=lens.device)
+        all_ids = torch.empty((world * b_pad, T), dtype=ids.dtype, device=ids.device)
+        all_lens = torch.empty((world * b_pad,), dtype=lens.dtype, device=lens.device)
         w1 = dist.all_gather_into_tensor(all_ids, ids, group=group, async_op=True)
         w2 = dist.all_gather_into_tensor(all_lens, lens, group=group, async_op=True)
+        keep = _valid_rows(n_total, world, b_pad, ids.device) if n_total is not None and n_total != world * b_pad else None
 
         class _Both:
             def wait(self):
                 w1.wait()
                 w2.wait()
+
+            def result(self):
+                self.wait()
+                return (all_ids, all_lens) if keep is None else (all_ids[keep], all_lens[keep])
+        if keep is not None:
+            return _Both(), None, None          # the padded buffers are not what the caller wants: result() after wait
         return _Both(), all_ids, all_lens
     # one collective per batch: the lengths ride in an extra column of the id matrix (xGMI is latency-, not
     # bandwidth-bound at 64 KB per rank, so the second all_gather would double the exchange time)
-    packed = torch.empty((B, T + 1), dtype=ids.dtype, device=ids.device)
+    packed = torch.empty((b_pad, T + 1), dtype=ids.dtype, device=ids.device)
     packed[:, :T] = ids
     packed[:, T] = lens.to(ids.dtype)
-    out = torch.empty((world * B, T + 1), dtype=ids.dtype, device=ids.device)
+    out = torch.empty((world * b_pad, T + 1), dtype=ids.dtype, device=ids.device)
     dist.all_gather_into_tensor(out, packed, group=group)
+    if n_total is not None and n_total != world * b_pad:
+        out = out[_valid_rows(n_total, world, b_pad, out.device)]
     return out[:, :T], out[:, T].to(lens.dtype)
 
 
-def all_gather_hypotheses(ids, lens, scores, n_hyp, group=None, device=None):
+def all_gather_hypotheses(ids, lens, scores, n_hyp, group=None, device=None, n_total=None):
     """Beams of a local utterance shard -> the beams of the whole batch on every rank, in rank order.
 
     ids int32 [B_local, beam, L_local] (-1 padded), lens int32 [B_local, beam], scores float32 [B_local, beam],
     n_hyp int32 [B_local] -- what `ctc_prefix_beam_decode` returns (NumPy or torch).  L_local is data dependent
     (`feature_pick` keeps a different number of frames per batch), so the ranks first agree on max(L_local) with one
     all_reduce(MAX) and pad; then ONE all_gather moves everything: the float32 scores travel as their int32 bit pattern
-    in the same block.  Returns NumPy arrays (ids [B_total, beam, L_max], lens, scores, n_hyp)."""
+    in the same block.  n_total as in all_gather_ids (batches that do not divide by the world size; a rank whose shard is
+    EMPTY passes arrays with B_local = 0).  Returns NumPy arrays (ids [B_total, beam, L_max], lens, scores, n_hyp)."""
     world = dist.get_world_size(group)
     t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a.cpu().numpy() if torch.is_tensor(a) else a)).to(dt)
     ids_t, lens_t, n_t = t(ids, torch.int32), t(lens, torch.int32), t(n_hyp, torch.int32)
     sc_bits = t(scores, torch.float32).view(torch.int32)
     B, beam, L = ids_t.shape
+    b_pad = B
+    if n_total is not None:
+        _check_local_rows(B, n_total, group)
+        b_pad = -(-n_total // world)
     dev = torch.device(device) if device is not None else ids_t.device
     lmax = torch.tensor([L], dtype=torch.int32, device=dev)
     dist.all_reduce(lmax, op=dist.ReduceOp.MAX, group=group)
     Lm = int(lmax.item())
-    packed = torch.full((B, beam, Lm + 3), -1, dtype=torch.int32, device=dev)
-    packed[:, :, :L] = ids_t.to(dev)
-    packed[:, :, Lm] = lens_t.to(dev)
-    packed[:, :, Lm + 1] = sc_bits.to(dev)
-    packed[:, :, Lm + 2] = n_t.to(dev)[:, None]
-    out = torch.empty((world * B, beam, Lm + 3), dtype=torch.int32, device=dev)
+    packed = torch.full((b_pad, beam, Lm + 3), -1, dtype=torch.int32, device=dev)
+    packed[:B, :, :L] = ids_t.to(dev)
+    packed[:B, :, Lm] = lens_t.to(dev)
+    packed[:B, :, Lm + 1] = sc_bits.to(dev)
+    packed[:B, :, Lm + 2] = n_t.to(dev)[:, None]
+    out = torch.empty((world * b_pad, beam, Lm + 3), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(out, packed, group=group)
+    if n_total is not None and n_total != world * b_pad:
+        out = out[_valid_rows(n_total, world, b_pad, out.device)]
     o = out.cpu()
     return (o[:, :, :Lm].numpy().copy(), o[:, :, Lm].numpy().copy(),
             o[:, :, Lm + 1].contiguous().view(torch.float32).numpy().copy(), o[:, 0, Lm + 2].numpy().copy())

@@ -99,3 +99,72 @@ def test_dp_prefix_beam_hypotheses_allgather_world2(tmp_path):
     world = 2
     mp.spawn(_beam_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("beam_ok%d" % r)).exists() for r in range(world))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# world 8: BASELINE config 4's partition (512 utterances -> 8 x 64) and config 5's (128 -> 8 x 16, ragged lengths), and
+# batches that do NOT divide by the world size (the reference's batch wrapper takes any batch)
+# ---------------------------------------------------------------------------------------------------------------
+def _world8_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    from tensorflowasr_amd.parallel import all_gather_hypotheses, all_gather_ids, shard_range, shard_sizes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        blank = 9
+        # config 4: 512 utterances, 64 per rank (tiny T); then 509 and 5 utterances (uneven, and ranks with EMPTY shards)
+        for B in (512, 509, 5):
+            T = 12
+            frames = np.random.default_rng(B).integers(0, 10, (B, T)).astype(np.int32)
+            in_len = np.random.default_rng(B + 1).integers(0, T + 1, B).astype(np.int32)
+            lo, hi = shard_range(B, rank, world)
+            assert hi - lo == shard_sizes(B, world)[rank] and (B != 512 or hi - lo == 64)
+            ids, lens = co.ctc_collapse(frames[lo:hi], in_len[lo:hi], blank) if hi > lo else (np.zeros((0, T), np.int32), np.zeros((0,), np.int32))
+            full_ids, full_lens = co.ctc_collapse(frames, in_len, blank)
+            a_ids, a_lens = all_gather_ids(torch.from_numpy(ids), torch.from_numpy(lens), n_total=B)
+            assert np.array_equal(a_ids.numpy(), full_ids) and np.array_equal(a_lens.numpy(), full_lens)
+            work, x, y = all_gather_ids(torch.from_numpy(ids), torch.from_numpy(lens), async_op=True, n_total=B)
+            r_ids, r_lens = work.result()
+            assert np.array_equal(r_ids.numpy(), full_ids) and np.array_equal(r_lens.numpy(), full_lens)
+            if B == 512:                    # equal shards: the un-padded form as well
+                a_ids, a_lens = all_gather_ids(torch.from_numpy(ids), torch.from_numpy(lens))
+                assert np.array_equal(a_ids.numpy(), full_ids)
+        # a rank that does not hold its shard_range slice is told so (instead of a collective that mis-sizes)
+        try:
+            all_gather_ids(torch.zeros((3, 4), dtype=torch.int32), torch.zeros(3, dtype=torch.int32), n_total=5 * world + 1)
+            raise AssertionError("expected ValueError")
+        except ValueError as e:
+            assert "shard_range" in str(e)
+        # config 5: 128 utterances -> 16 per rank, ragged frame counts and hypothesis lengths; then 19 (uneven)
+        for B in (128, 19):
+            T, V, beam = 14, 11, 4
+            rng = np.random.default_rng(7 + B)
+            lg = rng.standard_normal((B, T, V)).astype(np.float32) * 2.0
+            probs = np.exp(lg) / np.exp(lg).sum(-1, keepdims=True)
+            in_len = rng.integers(0, T + 1, B).astype(np.int32)
+            lo, hi = shard_range(B, rank, world)
+            assert B != 128 or hi - lo == 16
+            ml = max(int(in_len[lo:hi].max()) if hi > lo else 0, 1)
+            mine = ctc_prefix_beam_decode(probs[lo:hi], in_len[lo:hi], beam_width=beam, cutoff_prob=0.999, cutoff_top_n=8, num_threads=1,
+                                          max_len=ml) if hi > lo else \
+                (np.zeros((0, beam, 1), np.int32), np.zeros((0, beam), np.int32), np.zeros((0, beam), np.float32), np.zeros((0,), np.int32))
+            ids, lens, scores, n_hyp = all_gather_hypotheses(*mine, n_total=B)
+            if rank == 0:
+                full = ctc_prefix_beam_decode(probs, in_len, beam_width=beam, cutoff_prob=0.999, cutoff_top_n=8, num_threads=1, max_len=T)
+                assert ids.shape[0] == B and np.array_equal(n_hyp, full[3]) and np.array_equal(lens, full[1])
+                assert np.array_equal(scores.view(np.int32), full[2].view(np.int32))
+                L = ids.shape[2]
+                assert np.array_equal(ids, full[0][:, :, :L]) and (full[0][:, :, L:] == -1).all()
+        open(os.path.join(tmpdir, "w8_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_world8_config4_and_config5_partitions_and_uneven_batches(tmp_path):
+    world = 8
+    mp.spawn(_world8_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("w8_ok%d" % r)).exists() for r in range(world))
+

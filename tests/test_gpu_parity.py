@@ -55,8 +55,11 @@ def test_native_library_is_loaded(torch_cuda):
     assert "libmi355asr.so" in maps
 
 
-@pytest.mark.parametrize("L,scale", [(32000, 1.0), (67263, 0.05), (1000, 1.0), (16160, 1.0)])
+@pytest.mark.parametrize("L,scale", [(32000, 1.0), (67263, 0.05), (1000, 1.0), (16160, 1.0), (32000, 1e-3), (32000, 3e-5), (32000, 1e-7)])
 def test_melspectrogram_parity(enc2, L, scale):
+    """scales down to 1e-7: the two-term STFT normalises every operand column by the power of two of its own maximum, with no
+    floor on how quiet the column may be (the dB features are relative to the utterance's own maximum: a quiet recording has
+    the same features as a loud one until the power falls under the reference's amin)"""
     e, w, _ = enc2
     x = waves(2, L, 5) * np.float32(scale)
     ref = co.melspectrogram(x.astype(np.float64), w)

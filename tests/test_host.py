@@ -392,6 +392,18 @@ def test_prefix_beam_host_long_inputs_vs_the_reference_decoder():
     _long_kat_check(lambda p, beam, cp, tn: ctc_prefix_beam_decode(p, None, beam, cp, tn, num_threads=1))
 
 
+def test_prefix_beam_decode_of_zero_frames_is_the_empty_prefix():
+    """T = 0 (a ChunkConformer batch in which the picker kept no frame): one hypothesis per utterance, the empty prefix with
+    log-probability 0 -- what an utterance of length 0 inside a longer batch gives -- instead of an error from the C API that
+    would wedge ChunkBeamPipeline (round-3 advice)."""
+    from tensorflowasr_amd.models import ctc_prefix_beam_decode
+    ids, lens, sc, n = ctc_prefix_beam_decode(np.zeros((3, 0, 7), np.float32), None, 4, 0.99, 5)
+    p = np.full((3, 2, 7), 1 / 7, np.float32)
+    ids2, lens2, sc2, n2 = ctc_prefix_beam_decode(p, np.zeros(3, np.int32), 4, 0.99, 5)
+    assert np.array_equal(n, n2) and np.array_equal(lens, lens2) and np.array_equal(sc, sc2)
+    assert (ids == -1).all() and n.tolist() == [1, 1, 1] and sc[:, 0].tolist() == [0.0, 0.0, 0.0]
+
+
 def test_prefix_beam_batch_threads_ragged_lengths():
     import json
     from oracle import ctc_beam_oracle as bo
