@@ -704,13 +704,14 @@ bool use_gemm16(const mi355asr_model* m) {
   return force || m->cfg.gemm_dtype == 1 || (m->cfg.dmodel != 144 && m->cfg.dmodel != 256) ||
          (m->cfg.dmodel == 256 && !m->ring_of.empty());
 }
-// Few rows (single utterances, the Translator's token stream): the fused kernels give each 16-row tile to ONE wave that
-// walks a whole run of layers serially -- a fused launch takes as long for 250 rows as for 16 000 -- and one launch per
-// layer with K / column splitting is faster.  With the round-2 ring kernels the crossover is at ~800 rows (10 s
-// utterances, ms per batch, fused vs layer-at-a-time: B = 1: 1.67 vs 1.41, 2: 1.69 vs 1.54, 4: 1.70 vs 1.74, 8: 1.76 vs
-// 2.20, 16: 1.92 vs 2.60; the round-1 kernels crossed at ~4k rows).  MI355ASR_SMALL_M overrides.
+// Very few rows (one streaming chunk of 13 frames, the Translator's token stream): the fused kernels give each 16-row tile
+// to ONE wave that walks a whole run of layers serially -- a fused launch takes as long for 16 rows as for 16 000 -- and one
+// launch per layer with K / column splitting is as fast.  From a few tiles on the fused path wins: round 4 measured ONE
+// utterance (ms per recognize(), fused vs layer-at-a-time) 10 s / 250 rows 1.234 vs 1.386, 5 s / 125 rows 1.143 vs 1.263,
+// 2 s / 50 rows 1.118 vs 1.224, and B = 2, 3 at 10 s 1.241 / 1.252 vs 1.513 / 1.651 (profiles/r04_batch_sweep.md; the
+// round-2 ring kernels had crossed at ~800 rows, which is where this threshold stood until round 4).  MI355ASR_SMALL_M overrides.
 bool gemm16_for(const mi355asr_model* m, size_t M) {
-  static const long small_m = [] { const char* v = getenv("MI355ASR_SMALL_M"); return v ? atol(v) : 800L; }();
+  static const long small_m = [] { const char* v = getenv("MI355ASR_SMALL_M"); return v ? atol(v) : 48L; }();
   return use_gemm16(m) || (long)M <= small_m;
 }
 int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s) {
@@ -887,15 +888,18 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k2.out_wp = w.out_wp; k2.out_b = w.out_b; k2.cv_ln_g = w.cv_ln_g; k2.cv_ln_b = w.cv_ln_b;
     k2.pw1_wp = w.pw1_wp; k2.pw1_b = w.pw1_b; k2.eps = kLnEps; k2.M = M;
     k2.out_ws = w.out_ws; k2.pw1_ws = w.pw1_ws; k2.og_slabs = w.og_slabs; k2.pp_slabs = w.pp_og; k2.pp_sw_out = w.pp_sw_out; k2.pp_sw_pw1 = w.pp_sw_pw1;
-    { PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU"); }
     DwArgs dwa{};
     dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
     dwa.pad_left = bo.causal ? ksz - 1 : (ksz - 1) / 2;
     // round 3: the depthwise conv rides in the prologue of the pair-pipelined tail kernel (no launch, dw never in HBM)
     const bool dw_fold = w.pp_tail && w.tail_slabs && tail_pp_selected() && pp_dw_fold_ok(T, ksz);
-    if (!dw_fold) { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
     TailFf2Args k4{};
     if (dw_fold) { k4.dw_u = sc.u; k4.dw_wd = w.dw_w; k4.dw_T = T; k4.dw_pad = dwa.pad_left; }
+    k4.M = M; k4.pp_slabs = w.pp_tail;
+    // round 4: so does out-projection + GLU (x2 and u never in HBM either): the block is attention + one launch
+    const bool og_fold = dw_fold && pp_og_fold_ok(k4, k2);
+    if (!og_fold) { PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU"); }
+    if (!dw_fold) { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
     k4.dw = sc.dw; k4.x2 = sc.xa; k4.y = out ? out : sc.xb;
     k4.pc_w1p = w.pc_w1p; k4.pc_b1 = w.pc_b1; k4.bn_s = w.bn_s; k4.bn_t = w.bn_t; k4.pw2_wp = w.pw2_wp; k4.pw2_b = w.pw2_b;
     k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];
@@ -908,7 +912,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       kf.y = nullptr;
       const Ff1QkvArgs kn = ff1_args(*next, nullptr, sc.xa);
       PROF(MI355ASR_K_TAIL_FF1);
-      if (launch_tail_ff1(kf, kn, s) == 0) {
+      if ((og_fold && launch_pp_og_tail_ff1(kf, kn, k2, s) == 0) || launch_tail_ff1(kf, kn, s) == 0) {
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return fail(MI355ASR_EHIP, "conv tail + ff_module_2 + next ff_module_1: %s", hipGetErrorString(e_));
         *ff1_done = true;
@@ -916,7 +920,11 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
         return 0;
       }
     }
-    { PROF(MI355ASR_K_TAIL_FF2); LAUNCH_TRY(launch_tail_ff2(k4, s), "conv tail + ff_module_2"); }
+    {
+      PROF(MI355ASR_K_TAIL_FF2);
+      if (!(og_fold && launch_pp_og_tail_ff2(k4, k2, s) == 0)) LAUNCH_TRY(launch_tail_ff2(k4, s), "conv tail + ff_module_2");
+      else if (hipGetLastError() != hipSuccess) return fail(MI355ASR_EHIP, "out-projection + GLU + conv tail + ff_module_2 launch failed");
+    }
     if (!out) std::swap(sc.xa, sc.xb);
     return 0;
   }

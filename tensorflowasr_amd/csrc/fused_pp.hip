@@ -227,11 +227,17 @@ constexpr int PP_PER = PP_FR / 4;         // 1 KB pieces of a slab per loader wa
 template <int RING, int DG>
 struct PpLoader {
   u32x4_t* ring;
-  const u32x4_t *src, *src2;    // slabs [0, n1) from src, [n1, total) from src2
-  int n1, total, wv, lane;      // wv = 0..3
+  const u32x4_t *src, *src2;    // slabs [n0, n0 + n1) from src, [n0 + n1, total) from src2
+  int n1, total, wv, lane;      // wv = 0..3; n1 and total count from the first slab of the stream (src0's included)
+  const u32x4_t* src0 = nullptr;   // slabs [0, n0): the out-projection + GLU stream in front (OGF kernels)
+  int n0 = 0;
+  DEV const u32x4_t* slab_ptr(int slab) const {
+    if (slab < n0) return src0 + (size_t)slab * PP_SLB;
+    return slab < n1 ? src + (size_t)(slab - n0) * PP_SLB : src2 + (size_t)(slab - n1) * PP_SLB;
+  }
   template <int PER>
   DEV void issue(int slab, int slot) const {
-    const u32x4_t* g = (slab < n1 ? src + (size_t)slab * PP_SLB : src2 + (size_t)(slab - n1) * PP_SLB) + 64 * wv + lane;
+    const u32x4_t* g = slab_ptr(slab) + 64 * wv + lane;
     u32x4_t* l = ring + slot * PP_SLB + 64 * wv;
     if constexpr (DG & 16) return;
 #pragma unroll
@@ -244,7 +250,7 @@ struct PpLoader {
   // compute with the consumers -- have no DMA in flight (hipcc waits for every pending LDS-DMA before an LDS read it sees)
   DEV void issue_pro(int slab, int slot) const {
     if (wv < 2) return;
-    const u32x4_t* g = (slab < n1 ? src + (size_t)slab * PP_SLB : src2 + (size_t)(slab - n1) * PP_SLB) + 64 * (wv - 2) + lane;
+    const u32x4_t* g = slab_ptr(slab) + 64 * (wv - 2) + lane;
     u32x4_t* l = ring + slot * PP_SLB + 64 * (wv - 2);
 #pragma unroll
     for (int q = 0; q < PP_FR / 2; ++q) dma16(g + 128 * q, l + 128 * q);
@@ -262,9 +268,13 @@ struct PpLoader {
     for (int i = min(PRE0, pre); i < pre; ++i) issue<PER>(i, i);
     wait_dma_ahead<PER, RING - 3>(min(RING - 3, max(pre - 2, 0)));   // slabs 0 and 1 have landed
     __builtin_amdgcn_s_barrier();                                    // B0 (consumers: inputs + parameter stash)
-    int rd = 0;
+    main_loop<PER>(0, 0);
+  }
+  // steps s0 .. total - 1 of the steady state: slabs up to s0 + RING - 2 have been issued, slot rd holds slab s0
+  template <int PER>
+  DEV void main_loop(int s0, int rd) const {
 #pragma unroll 1
-    for (int s = 0; s < total; ++s) {
+    for (int s = s0; s < total; ++s) {
       if (s + RING - 1 < total) issue<PER>(s + RING - 1, rd == 0 ? RING - 1 : rd - 1);
       wait_dma_ahead<PER, RING - 3>(max(min(RING - 3, total - 3 - s), 0));     // slab s + 2 has landed
       if constexpr (!(DG & 8)) __builtin_amdgcn_s_barrier();
@@ -276,6 +286,36 @@ struct PpLoader {
     run_<PP_PER, PRE0>(pro);
   }
   DEV void run() const { run<RING - 1>([] {}); }
+
+  // OGF kernels, first phase (loader waves 2 and 3 = waves 6 and 7 of the workgroup; waves 4 and 5 compute the halo tiles):
+  // the n0 out-projection + GLU slabs and the first two slabs of the chain behind them -- HOLD = n0 + 2 slabs in all -- flow
+  // through the ring; nothing beyond is requested, so that when step n0 - 1 ends every DMA has landed and the ring slots
+  // that hold neither slab n0 nor n0 + 1 are free for the depthwise window (pp_block_kernel)
+  DEV void run_og_phase() const {
+    const int hold = n0 + 2;
+    for (int i = 0; i < RING - 1; ++i) issue_pro(i, i);                        // n0 >= RING - 1
+    wait_dma_ahead<PP_FR / 2, RING - 3>(RING - 3);                             // slabs 0 and 1 have landed
+    __builtin_amdgcn_s_barrier();                                              // B0
+    int wr = RING - 1;
+#pragma unroll 1
+    for (int s = 0; s < n0; ++s) {
+      if (s + RING - 1 < hold) issue_pro(s + RING - 1, wr);
+      wr = wr + 1 == RING ? 0 : wr + 1;
+      wait_dma_ahead<PP_FR / 2, RING - 3>(max(min(RING - 3, hold - 3 - s), 0)); // slab s + 2 has landed
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  DEV void barriers_og_phase() const {       // loader waves 0 and 1 only take part in the barriers when they do not compute
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int s = 0; s < n0; ++s) __builtin_amdgcn_s_barrier();
+  }
+  // second phase (all four loader waves, after the prologue): catch up with the steady state of step n0, then run it
+  DEV void run_after_og() const {
+    const int hold = n0 + 2;
+    for (int i = hold; i < min(n0 + RING - 1, total); ++i) issue<PP_PER>(i, i % RING);
+    main_loop<PP_PER>(n0, n0 % RING);
+  }
 };
 
 template <int RING, int DG>
@@ -498,27 +538,32 @@ DEV void pp_bar_lds() {                         // this wave's LDS operations ar
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-// all eight waves call this; on return (consumer waves) xs = the depthwise conv output rows of the wave's 16 frames
+// all eight waves call this; on return (consumer waves) xs = the depthwise conv output rows of the wave's 16 frames.
+// WIN_READY (OGF kernels): the window rows were written by the waves that computed them (pp_og_tile); only the taps are staged
+template <bool WIN_READY = false>
 DEV void pp_dw_prologue(float* scratch, const TailFf2Args& a, f32x4 (&xs)[KB]) {
   float* win = scratch;                         // [DW_ROWS][D], later the conv output [64][D]
   float* wt = scratch + DW_ROWS * D;            // [DW_K][D]
   const int tid = threadIdx.x;
   const int T = a.dw_T, f0 = blockIdx.x * 64 - a.dw_pad;        // utterance frame of window row 0
-  const float* __restrict__ ub = a.dw_u + (size_t)blockIdx.y * T * D;
   constexpr int NL = (DW_ROWS * DW_C4 + DW_WORK - 1) / DW_WORK, NW = (DW_K * DW_C4 + DW_WORK - 1) / DW_WORK;
   if (tid < DW_WORK) {
-    f32x4 stage[NL], wstage[NW];
+    f32x4 wstage[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) wstage[k] = ldg4(a.dw_wd + 4 * min(tid + k * DW_WORK, DW_K * DW_C4 - 1));
+    if constexpr (!WIN_READY) {
+      const float* __restrict__ ub = a.dw_u + (size_t)blockIdx.y * T * D;
+      f32x4 stage[NL];
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const int i = tid + k * DW_WORK, r = i / DW_C4, c4 = i - r * DW_C4, f = f0 + r;
-      stage[k] = (i < DW_ROWS * DW_C4 && f >= 0 && f < T) ? ldg4(ub + (size_t)f * D + 4 * c4) : splat4(0.f);
-    }
+      for (int k = 0; k < NL; ++k) {
+        const int i = tid + k * DW_WORK, r = i / DW_C4, c4 = i - r * DW_C4, f = f0 + r;
+        stage[k] = (i < DW_ROWS * DW_C4 && f >= 0 && f < T) ? ldg4(ub + (size_t)f * D + 4 * c4) : splat4(0.f);
+      }
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const int i = tid + k * DW_WORK;
-      if (i < DW_ROWS * DW_C4) *reinterpret_cast<f32x4*>(&win[4 * i]) = stage[k];
+      for (int k = 0; k < NL; ++k) {
+        const int i = tid + k * DW_WORK;
+        if (i < DW_ROWS * DW_C4) *reinterpret_cast<f32x4*>(&win[4 * i]) = stage[k];
+      }
     }
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
@@ -563,31 +608,154 @@ DEV void pp_dw_prologue(float* scratch, const TailFf2Args& a, f32x4 (&xs)[KB]) {
   pp_bar_lds();                                                       // P4: the scratch is free: the loaders fill the ring
 }
 
+// ---- out-projection + residual + LayerNorm + pw_conv_1 + GLU in the prologue (OGF, round 4) ------------------------------------
+// conformer_blocks.py:164-170 (x2 = x1 + attention output), :209-213 (u = GLU(pw_conv_1(LN(x2)))).  pp_out_glu_kernel ran this
+// as a launch of its own -- 16 us for 2 us of matrix work, x2 and u through HBM.  Here the six waves 0..5 of the workgroup
+// each take ONE 16-frame tile of the 96 frames the depthwise window needs -- waves 0..3 the workgroup's own 64 frames (their
+// x2 rows stay in registers as the residual of the conv tail), waves 4 and 5 the halo: the 16 frames in front and the 16
+// behind for Keras 'same' padding (15 / 16), the 32 in front for 'causal' (31 / 0) -- and walk the fifteen plain ring slots of
+// the out_glu stream (five of the out projection, five of pw_conv_1's value tiles, five of its gate tiles), which precede
+// the conv tail's slots in the same ring (PpLoader::run_og_phase).  The halo is recomputed by both neighbours: 50 % more of a
+// layer that is 6 % of the block's matrix work, against a launch, its fixed ~11 us, and 37 MB of x2 / u traffic per block.
+// The u rows go straight into the depthwise window in LDS; rows outside the utterance are the conv's zero padding.
+struct PpOgLds { float lng[D], lnb[D]; };
+DEV int pp_og_tile_frame0(int wv, int pad) {      // first utterance frame of wave wv's tile (wave-uniform; may be negative)
+  const int own0 = blockIdx.x * 64;
+  if (wv < WAVES_PER_BLOCK) return own0 + 16 * wv;
+  const int nfront = (pad + 15) / 16;             // 'same' (15): one tile in front, one behind; 'causal' (31): two in front
+  const int h = wv - WAVES_PER_BLOCK;             // 0 or 1
+  return h < nfront ? own0 - 16 * (nfront - h) : own0 + 64 + 16 * (h - nfront);
+}
+template <int DG, class ST>
+DEV void pp_og_tile(const OutGluArgs& g, const PpOgLds& p, ST& st, PpPool& pl, f32x4 (&xs)[KB], f32x4 (&x2)[KB], int lane,
+                    int frame0, int T, int f0, float* win) {
+  const int g4 = (lane >> 4) * 4, c = lane & 15;
+  Split8 xf[KS32X];
+  {
+    const float sx = pp_pow2_scale(pp_row_max(xs));
+    split_operand(xf, xs, g4, sx);
+    f32x4 acc[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) acc[i] = splat4(0.f);
+    static_for<0, KS32X>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      pp_unit_S<DG>(acc, xf[t], pl, st);
+    });
+    pp_pool_land(pl);
+    const f32x4 inv = splat4(pp_recip_pow2(g.pp_sw_out * sx));
+#pragma unroll
+    for (int i = 0; i < KB; ++i) { x2[i] += acc[i] * inv; xs[i] = x2[i]; }                // x2 = x1 + attention (+ bias: row 144)
+  }
+  ln_lds(xs, p.lng, p.lnb, g4, g.eps);
+  const float sx = pp_pow2_scale(pp_row_max(xs));
+  split_operand(xf, xs, g4, sx);
+  f32x4 val[KB], gate[KB];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) { val[i] = splat4(0.f); gate[i] = splat4(0.f); }
+  static_for<0, KS32X>([&](auto T_) {
+    constexpr int t = decltype(T_)::value;
+    pp_unit_S<DG>(val, xf[t], pl, st);
+  });
+  static_for<0, KS32X>([&](auto T_) {
+    constexpr int t = decltype(T_)::value;
+    pp_unit_S<DG>(gate, xf[t], pl, st);
+  });
+  pp_pool_land(pl);                                       // the reads into the slot behind the stream: landed, then forgotten
+  const float inv = pp_recip_pow2(g.pp_sw_pw1 * sx);
+  const int f = frame0 + c, r = f - f0;                   // this lane's frame and its window row
+  const bool inside = f >= 0 && f < T;
+  if (r >= 0 && r < DW_ROWS) {
+    float* wrow = win + r * D + g4;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const f32x4 va = val[i] * splat4(inv), vb = gate[i] * splat4(inv);
+      f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
+      *reinterpret_cast<f32x4*>(wrow + 16 * i) = inside ? o : splat4(0.f);
+    }
+  }
+}
+
 // TAIL: conv tail + ff_module_2 + LayerNorm of one block (a);  FF1: ff_module_1 + qkv of a block (b) -- of the NEXT block
 // when both are set (the block output stays in registers; a.y may be null then).  DWF: the depthwise conv runs in the
-// prologue (a.dw_u / dw_wd / dw_T / dw_pad) and the grid is (ceil(T / 64), utterances).
-template <bool TAIL, bool FF1, int DG = 0, bool DWF = false>
-__global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1QkvArgs b) {
+// prologue (a.dw_u / dw_wd / dw_T / dw_pad) and the grid is (ceil(T / 64), utterances).  OGF (needs DWF): the window of the
+// depthwise conv is computed in the prologue too, from the attention output and x1 (g; a.dw_u and a.x2 are not read).
+template <bool TAIL, bool FF1, int DG = 0, bool DWF = false, bool OGF = false>
+__global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1QkvArgs b, OutGluArgs g) {
   static_assert(TAIL || !DWF, "the depthwise conv feeds the conv tail");
+  static_assert(DWF || !OGF, "the out-projection + GLU prologue feeds the depthwise window");
   __shared__ __attribute__((aligned(16))) u32x4_t ring[PP_RING * PP_SLB];
   __shared__ __attribute__((aligned(16))) PpTailLds pt;
   __shared__ __attribute__((aligned(16))) PpFf1Lds pf;
+  __shared__ __attribute__((aligned(16))) PpOgLds pg;
   static_assert((PP_RING - 2) * PP_SLB * 16 >= (DW_ROWS + DW_K) * D * 4, "the prologue scratch is ring slots 2..");
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  constexpr int N1 = TAIL ? PP_TAIL_SLABS : PP_FF1_SLABS, TOTAL = (TAIL ? PP_TAIL_SLABS : 0) + (FF1 ? PP_FF1_SLABS : 0);
-  float* scratch = reinterpret_cast<float*>(ring + 2 * PP_SLB);
+  constexpr int NOG = OGF ? 3 * KS32X : 0;
+  constexpr int N1 = NOG + (TAIL ? PP_TAIL_SLABS : PP_FF1_SLABS), TOTAL = NOG + (TAIL ? PP_TAIL_SLABS : 0) + (FF1 ? PP_FF1_SLABS : 0);
+  // OGF: when the out_glu stream is through, slabs NOG and NOG + 1 sit in ring slots NOG % RING and (NOG + 1) % RING and
+  // every other slot is free: the window + taps take the contiguous run of slots behind them
+  constexpr int OG_SCR = (NOG + 2) % PP_RING;
+  static_assert(!OGF || (OG_SCR + (PP_RING - 3) <= PP_RING && (PP_RING - 3) * PP_SLB * 16 >= (DW_ROWS + DW_K) * D * 4),
+                "the slots behind slab NOG + 1 up to the end of the ring hold the depthwise window and the taps");
+  float* scratch = reinterpret_cast<float*>(ring + (OGF ? OG_SCR : 2) * PP_SLB);
   f32x4 xs[KB], y[KB];
-  if (wv >= WAVES_PER_BLOCK) {
-    const u32x4_t* s1 = reinterpret_cast<const u32x4_t*>(TAIL ? a.pp_slabs : b.pp_slabs);
-    const u32x4_t* s2 = reinterpret_cast<const u32x4_t*>(b.pp_slabs);
-    const PpLoader<PP_RING, DG> ld{ring, s1, s2, N1, TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)};
-    if constexpr (DWF) ld.template run<2>([&] { pp_dw_prologue(scratch, a, xs); });
+  const u32x4_t* s0 = reinterpret_cast<const u32x4_t*>(g.pp_slabs);
+  const u32x4_t* s1 = reinterpret_cast<const u32x4_t*>(TAIL ? a.pp_slabs : b.pp_slabs);
+  const u32x4_t* s2 = reinterpret_cast<const u32x4_t*>(b.pp_slabs);
+  if (wv >= WAVES_PER_BLOCK + (OGF ? 2 : 0)) {
+    const PpLoader<PP_RING, DG> ld{ring, s1, s2, N1, TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63), s0, NOG};
+    if constexpr (OGF) {
+      ld.run_og_phase();
+      pp_dw_prologue<true>(scratch, a, xs);
+      ld.run_after_og();
+    } else if constexpr (DWF) ld.template run<2>([&] { pp_dw_prologue(scratch, a, xs); });
     else ld.run();
     return;
   }
   const int M = TAIL ? a.M : b.M, TT = DWF ? a.dw_T : 0;
   const WaveCtx c = wave_ctx(M, TT);
   PpReader<PP_RING, DG> st{ring, c.lane};
+  if constexpr (OGF) {
+    // waves 0..5: one tile of the window each.  The rows of ctx / x1 (frames outside the utterance: the nearest real frame;
+    // their u is replaced by zeros)
+    const int frame0 = pp_og_tile_frame0(wv, a.dw_pad), T = a.dw_T, f0 = blockIdx.x * 64 - a.dw_pad;
+    const size_t row = ((size_t)blockIdx.y * T + (size_t)min(max(frame0 + (c.lane & 15), 0), T - 1)) * D;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(g.ctx + row + 16 * kb + c.g4);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(g.x1 + row + 16 * kb + c.g4);
+    {
+      const auto r0 = stash_load<D>(g.cv_ln_g), r1 = stash_load<D>(g.cv_ln_b);
+      stash_store<D>(pg.lng, r0); stash_store<D>(pg.lnb, r1);
+    }
+    pp_tail_stash(pt, a);
+    if constexpr (FF1) pp_ff1_stash(pf, b);
+    st.sync();                                           // B0
+    PpPool pl;
+    pp_prime<DG>(pl, st);
+    pp_pool_land(pl);
+    pp_og_tile<DG>(g, pg, st, pl, xs, y, c.lane, frame0, T, f0, scratch);      // y = x2 rows of this wave's tile
+    pp_dw_prologue<true>(scratch, a, xs);                // waves 0..3: xs = depthwise output rows of the wave's own frames
+    if (wv >= WAVES_PER_BLOCK) {                         // the halo waves join the loaders
+      const PpLoader<PP_RING, DG> ld{ring, s1, s2, N1, TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63), s0, NOG};
+      ld.run_after_og();
+      return;
+    }
+    pp_prime<DG>(pl, st);
+    pp_pool_land(pl);
+    pp_tail_consume<DG>(a, pt, c.g4, st, pl, xs, y);
+    if (a.y) {
+      const WaveCtx e = wave_ctx_fresh(M, TT);
+      if (e.live) {
+#pragma unroll
+        for (int i = 0; i < KB; ++i) stg4(a.y + e.row + 16 * i + e.g4, y[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < KB; ++i) xs[i] = y[i];
+    if constexpr (FF1) pp_ff1_consume<DG>(b, pf, c.g4, st, pl, xs, TT);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return;
+  }
   if constexpr (TAIL) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + c.row + 16 * kb + c.g4);     // residuals ride in the accumulators
@@ -627,7 +795,6 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
 // attention out-projection + residual, conv-module LayerNorm, pw_conv_1 + GLU (conformer_blocks.py:164-170, :209-213) on the
 // same stream machinery: 15 plain ring slots (five of the out projection, five of pw_conv_1's value tiles, five of its gate
 // tiles; the three biases in row 144), 405 MFMAs per wave where the three-term out_glu_ld_kernel (fused.hip) ran 810
-struct PpOgLds { float lng[D], lnb[D]; };
 __global__ __launch_bounds__(LD_THREADS) void pp_out_glu_kernel(OutGluArgs a) {
   __shared__ __attribute__((aligned(16))) u32x4_t ring[PP_RING * PP_SLB];
   __shared__ __attribute__((aligned(16))) PpOgLds p;
@@ -826,7 +993,7 @@ int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s)
     static bool warned = false;
     if (!warned) { fprintf(stderr, "MI355ASR_PP_DIAG=%d: timing-only kernel variant, results are WRONG\n", dg); warned = true; }
     const dim3 g((tiles + 3) / 4), t(LD_THREADS);
-#define PP_DIAG_CASE(N) case N: hipLaunchKernelGGL((pp_block_kernel<true, true, N>), g, t, 0, s, a, b); return 0;
+#define PP_DIAG_CASE(N) case N: hipLaunchKernelGGL((pp_block_kernel<true, true, N>), g, t, 0, s, a, b, OutGluArgs{}); return 0;
     switch (dg) {
       PP_DIAG_CASE(1) PP_DIAG_CASE(2) PP_DIAG_CASE(3) PP_DIAG_CASE(4) PP_DIAG_CASE(8) PP_DIAG_CASE(16) PP_DIAG_CASE(24)
       PP_DIAG_CASE(26) PP_DIAG_CASE(27) PP_DIAG_CASE(25) PP_DIAG_CASE(7) PP_DIAG_CASE(10) PP_DIAG_CASE(18) PP_DIAG_CASE(64) PP_DIAG_CASE(65)
@@ -836,10 +1003,10 @@ int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s)
   }
 #endif
   if (pp_dw_fold(a)) {
-    hipLaunchKernelGGL((pp_block_kernel<true, true, 0, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, b);
+    hipLaunchKernelGGL((pp_block_kernel<true, true, 0, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, b, OutGluArgs{});
     return 0;
   }
-  hipLaunchKernelGGL((pp_block_kernel<true, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, b);
+  hipLaunchKernelGGL((pp_block_kernel<true, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, b, OutGluArgs{});
   return 0;
 }
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s) {
@@ -847,16 +1014,38 @@ int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
   if (pp_dw_fold(a)) {
-    hipLaunchKernelGGL((pp_block_kernel<true, false, 0, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{});
+    hipLaunchKernelGGL((pp_block_kernel<true, false, 0, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{}, OutGluArgs{});
     return 0;
   }
-  hipLaunchKernelGGL((pp_block_kernel<true, false>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{});
+  hipLaunchKernelGGL((pp_block_kernel<true, false>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{}, OutGluArgs{});
+  return 0;
+}
+// out-projection + GLU in the prologue of the tail kernels (OGF): the block runs as attention -> this, two launches.
+// g: what pp_out_glu_kernel would have been given (ctx, x1, the LayerNorm parameters, the out_glu stream and its scales;
+// x2 and u are not written).  Needs the depthwise fold (a.dw_wd / dw_T / dw_pad set; a.dw_u is not read).
+bool pp_og_fold_ok(const TailFf2Args& a, const OutGluArgs& g) {
+  // MI355ASR_PP_OGF=0: out-projection + GLU as its own launch (pp_out_glu_kernel)
+  static const bool on = [] { const char* v = getenv("MI355ASR_PP_OGF"); return v ? atoi(v) != 0 : true; }();
+  static const bool og_on = [] { const char* v = getenv("MI355ASR_PP_OUTGLU"); return v ? atoi(v) != 0 : true; }();
+  return on && og_on && pp_enabled() && a.pp_slabs && g.pp_slabs && g.ctx && g.x1 && a.dw_wd && a.dw_T > 0 && a.M > 0 && a.M % a.dw_T == 0 &&
+         a.M == g.M && (a.dw_pad == 15 || a.dw_pad == 31) && pp_dw_fold_ok(a.dw_T, DW_K);
+}
+int launch_pp_og_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, const OutGluArgs& g, hipStream_t s) {
+  if (!pp_og_fold_ok(a, g) || !b.pp_slabs || a.M != b.M) return -1;
+  note_scheme(SCHEME_F16X2);
+  hipLaunchKernelGGL((pp_block_kernel<true, true, 0, true, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, b, g);
+  return 0;
+}
+int launch_pp_og_tail_ff2(const TailFf2Args& a, const OutGluArgs& g, hipStream_t s) {
+  if (!pp_og_fold_ok(a, g)) return -1;
+  note_scheme(SCHEME_F16X2);
+  hipLaunchKernelGGL((pp_block_kernel<true, false, 0, true, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{}, g);
   return 0;
 }
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
   if (!pp_enabled() || !b.pp_slabs || b.M <= 0) return -1;
   const int tiles = (b.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
-  hipLaunchKernelGGL((pp_block_kernel<false, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, TailFf2Args{}, b);
+  hipLaunchKernelGGL((pp_block_kernel<false, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, TailFf2Args{}, b, OutGluArgs{});
   return 0;
 }

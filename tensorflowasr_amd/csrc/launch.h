@@ -314,6 +314,11 @@ bool pp_dw_fold_ok(int T, int ksz);   // the tail kernels can take the depthwise
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
+// round 4: out-projection + residual + LayerNorm + pw_conv_1 + GLU in the prologue of the pair-pipelined tail kernels (the
+// block = attention + ONE launch); -1: not applicable (switched off, no streams, depthwise fold impossible), nothing launched
+bool pp_og_fold_ok(const TailFf2Args& a, const OutGluArgs& g);
+int launch_pp_og_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, const OutGluArgs& g, hipStream_t s);
+int launch_pp_og_tail_ff2(const TailFf2Args& a, const OutGluArgs& g, hipStream_t s);
 int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s);   // -1: shape not supported
 int launch_pick(const PickArgs& a, hipStream_t s);
 int launch_row_argmax(const float* x, int32_t* out, int M, int V, hipStream_t s);

@@ -249,6 +249,53 @@ def test_conformer_block_parity(enc2, B, T):
     assert maxdiff(got, ref) < TOL
 
 
+def test_block_as_two_launches_equals_the_three_launch_path_bit_for_bit(torch_cuda):
+    """Round 4: out-projection + residual + LayerNorm + pw_conv_1 + GLU run in the prologue of the pair-pipelined tail kernel
+    (pp_block_kernel<..., OGF>): six waves compute the 96 frames of the depthwise window, halo included, from the attention
+    output.  Every row goes through the same units in the same order as in pp_out_glu_kernel, so the encoder output must be
+    BIT-IDENTICAL to the build with MI355ASR_PP_OGF=0 (out_glu as its own launch) -- offline 'same' padding at T = 250 / 64 /
+    65 / 127 / 200 (utterance lengths around the 64-frame tiles: partial last tiles, a halo tile entirely past the end) and
+    the ChunkConformer's causal padding (two halo tiles in front)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from helpers import chunk_config_dict, co, encoder_kwargs, small_cfg, waves
+from tensorflowasr_amd.models import ChunkConformer, ConformerEncoder
+out = {}
+cfg = small_cfg(3)
+w = co.encoder_weights(cfg, seed=3)
+e = ConformerEncoder(**encoder_kwargs(cfg))
+e.load_weights(w, by_name=False)
+for B, T in ((9, 250), (13, 64), (13, 65), (7, 127), (5, 200)):
+    x = np.random.default_rng(T).standard_normal((B, T, 144)).astype(np.float32)
+    out["blk_%d" % T] = e.conformer_block(1, x).cpu().numpy()
+x = waves(12, 80000, 3)
+out["enc"] = e(x).cpu().numpy()
+c5 = dict(co.CHUNK_S, enc_num_blocks=2, picker_num_blocks=1, helper_num_blocks=1, decoder_num_blocks=1)
+w5 = co.chunk_weights(c5, seed=4)
+m = ChunkConformer(chunk_config_dict(c5), c5["picker_num_classes"], c5["decoder_num_classes"])
+m.load_weights(w5, by_name=False)
+got = m.predict(waves(4, 160000, 9), stages=True)
+out["chunk_enc"] = got["enc"].cpu().numpy()
+out["chunk_text"] = got["text_logits"].cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("two", {}), ("three", {"MI355ASR_PP_OGF": "0"})):
+            f = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[tag] = dict(np.load(f))
+    for k in res["two"]:
+        assert np.isfinite(res["two"][k]).all() and np.abs(res["two"][k]).max() > 0.1, k
+        assert np.array_equal(res["two"][k], res["three"][k]), (k, float(np.abs(res["two"][k] - res["three"][k]).max()))
+
+
 @pytest.mark.parametrize("scale", [1e-4, 1.0, 1e3, 3e4])
 def test_conformer_block_operand_scales_follow_the_input_magnitude(enc2, scale):
     """The two-term fp16 kernels scale every operand row by the power of two of its own largest magnitude (and hidden rows by

@@ -1,6 +1,6 @@
 """recognize() ms/step and audio-frames/s of ConformerCTC(S), 10 s utterances, over the batch size.
 
-    python tools/batch_sweep.py [B1,B2,...]        (MI355ASR_SMALL_M=<rows> moves the fused / layer-at-a-time threshold)"""
+    python tools/batch_sweep.py [B1,B2,...] [seconds]     (MI355ASR_SMALL_M=<rows> moves the fused / layer-at-a-time threshold)"""
 import json
 import sys
 import time
@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, ".")
 from tensorflowasr_amd.models import ConformerCTC  # noqa: E402
 
-L = 160000
+L = int(float(sys.argv[2]) * 16000) if len(sys.argv) > 2 else 160000
 m = ConformerCTC(1332)
 m._build()
 out = {}
@@ -27,6 +27,6 @@ for B in BATCHES:
         m.recognize(x)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    out[B] = {"ms_step": round(dt * 1e3, 3), "audio_frames_per_s": round(B * 1000 / dt, 1)}
+    out[B] = {"ms_step": round(dt * 1e3, 3), "audio_frames_per_s": round(B * (L // 160) / dt, 1)}
     del x
 print(json.dumps(out))
