@@ -1079,6 +1079,9 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   static const int lin_split = [] { const char* v = std::getenv("MI355ASR_SUBLINEAR_SPLIT"); return v ? std::atoi(v) : 1; }();
   if (lin_split && m->lin_wsplit && (lg.M >= 4096 || lin_split == 2)) {
     PROF(MI355ASR_K_SUBLINEAR);
+    // round 4: two fp16 terms with a scale per (token, 144-wide chunk) -- no bound on the operand needed, so caller-supplied
+    // features take it too; the three-term kernel behind MI355ASR_PP_SUBLINEAR=0 / MI355ASR_PP=0
+    if (m->lin_pp && launch_pp_sublinear(lg, m->lin_pp, m->lin_pp_sw, s) == 0) return 0;
     if (launch_sublinear_split(lg, m->lin_wsplit, s) == 0) return 0;
   }
   {
@@ -1541,7 +1544,8 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   const int d = c.dmodel;
   ArenaBuilder ab;
   ab.ring_terms = m->cfg.gemm_dtype == 1 ? 1 : 3;
-  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0, o_c2h = 0;
+  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0, o_c2h = 0, o_lpp = 0;
+  float lin_pp_sw = 1.f;
   float c2_hs = 0.f, c2_ws = 0.f;
   FftOff fo;
   MelBandOff mbo;
@@ -1677,6 +1681,14 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   if (d == 144) {
     // the same kernel for sublinear_split_kernel: 1728 fragments per 32-wide step, padded to 7 x 256 (4 floats each)
     o_lws = ab.put(pack_linear_split(lin, dm.F2 * d, d));
+    // two-term fp16 stream (pp_sublinear_kernel): chunk f = rows 144 f .. 144 f + 143 of the kernel, the bias in row 144 of chunk 0
+    const auto& lb = m->host["conv_subsampling/linear/bias"].data;
+    std::vector<float> pp;
+    lin_pp_sw = append_pp_plain(pp, [&](int k, int n) {
+      const int f = n / d, col = n - f * d;
+      return k < d ? lin[((size_t)f * d + k) * d + col] : (f == 0 ? lb[col] : 0.f);
+    }, dm.F2);
+    o_lpp = ab.put(pp);
   }
   for (int i = 0; i < c.num_blocks; ++i)
     eo.push_back(pack_block(m, ab, "conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size, c.kernel_size));
@@ -1745,6 +1757,8 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = ((d == 144 || d == 256 || d == 512) && c.has_encoder) ? base + o_c2s : nullptr;
   m->c2_whalf = o_c2h ? base + o_c2h : nullptr; m->c2_hscale = c2_hs; m->c2_wscale = c2_ws;
   m->lin_wsplit = (d == 144 && c.has_encoder) ? base + o_lws : nullptr;
+  m->lin_pp = (d == 144 && c.has_encoder) ? base + o_lpp : nullptr;
+  m->lin_pp_sw = lin_pp_sw;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
   m->leaf_wp = base + o_leafw; m->leaf_wsplit = base + o_leafs; m->leaf_gcoef = base + o_lg; m->leaf_alpha = base + o_la; m->leaf_delta = base + o_ld;

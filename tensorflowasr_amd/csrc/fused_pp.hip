@@ -948,6 +948,62 @@ __global__ __launch_bounds__(LD_THREADS) void pp_head_kernel(GemmArgs a, const u
   if (a.maxval_out && e.live && c.lane < 16) a.maxval_out[e.tok] = best_v;
 }
 
+
+// Subsampling Dense (conformer_blocks.py:93-96): y[t, :] = relu(conv2)[t, f2, ch] W[f2 * 144 + ch, :] + b, K = F2 * 144 = 2880,
+// as F2 chunks of one plain group each (five ring slots per chunk; the bias in row 144 of chunk 0, zeros in the others).  The
+// round-2 kernel (sublinear_split_ld_kernel) runs three bf16 terms = 4 860 MFMAs per wave and streams 6 bytes per weight; the
+// operand here has no static bound (ReLU outputs), so every 144-wide chunk of a token's row gets ITS OWN power-of-two scale
+// from its own maximum -- per-chunk accumulators, multiplied out of their unit into y as each chunk ends (exact) --: 2 430
+// MFMAs, 4 bytes per weight.  The rows of chunk f + 1 are requested before the units of chunk f.
+__global__ __launch_bounds__(LD_THREADS) void pp_sublinear_kernel(StreamGemmArgs a, const u32x4_t* __restrict__ pp, float pp_sw, int chunks) {
+  __shared__ __attribute__((aligned(16))) u32x4_t ring[PP_RING * PP_SLB];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wv >= WAVES_PER_BLOCK) {
+    PpLoader<PP_RING, 0>{ring, pp, pp, KS32X * chunks, KS32X * chunks, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
+    return;
+  }
+  constexpr int DG = 0;
+  const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4;
+  const int tok = (blockIdx.x * WAVES_PER_BLOCK + wv) * 16 + (lane & 15);
+  const bool live = tok < a.M;
+  const float* __restrict__ xrow = a.x + (size_t)min(tok, a.M - 1) * a.K + g4;
+  PpReader<PP_RING, 0> st{ring, lane};
+  f32x4 xs[KB], y[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) { xs[kb] = ldg4(xrow + 16 * kb); y[kb] = splat4(0.f); }
+  st.sync();
+  PpPool pl;
+  pp_prime<DG>(pl, st);
+  pp_pool_land(pl);
+#pragma unroll 1
+  for (int f = 0; f < chunks; ++f) {
+    Split8 xf[KS32X];
+    const float sx = pp_pow2_scale(pp_row_max(xs));
+    split_operand(xf, xs, g4, sx);
+    if (f + 1 < chunks) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(xrow + (size_t)(f + 1) * D + 16 * kb);
+    }
+    f32x4 acc[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) acc[i] = splat4(0.f);
+    static_for<0, KS32X>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      pp_unit_S<DG>(acc, xf[t], pl, st);
+    });
+    pp_pool_land(pl);
+    const f32x4 inv = splat4(pp_recip_pow2(pp_sw * sx));
+#pragma unroll
+    for (int i = 0; i < KB; ++i) y[i] += acc[i] * inv;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the pool's reads past the last slot
+  if (live) {
+    float* yrow = a.y + (size_t)tok * a.ldy + g4;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(yrow + 16 * i, y[i]);
+  }
+}
+
 }  // namespace
 
 // the depthwise conv rides in the tail kernel's prologue when the caller asked for it (dw_u) and the per-utterance tiling wastes
@@ -972,6 +1028,14 @@ int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, 
   const int tiles = (a.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
   hipLaunchKernelGGL(pp_head_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, groups);
+  return 0;
+}
+int launch_pp_sublinear(const StreamGemmArgs& a, const float* pp, float pp_sw, hipStream_t s) {
+  // MI355ASR_PP_SUBLINEAR=0: the three-term sublinear_split_ld_kernel (fused.hip)
+  static const bool on = [] { const char* v = getenv("MI355ASR_PP_SUBLINEAR"); return v ? atoi(v) != 0 : true; }();
+  if (!on || !pp_enabled() || !pp || a.NT != KB || a.K % D != 0 || a.K < D || a.M <= 0 || (a.ldy & 3) != 0) return -1;
+  note_scheme(SCHEME_F16X2);
+  hipLaunchKernelGGL(pp_sublinear_kernel, dim3((a.M + 63) / 64), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, a.K / D);
   return 0;
 }
 int launch_pp_out_glu(const OutGluArgs& a, hipStream_t s) {

@@ -320,6 +320,8 @@ bool pp_og_fold_ok(const TailFf2Args& a, const OutGluArgs& g);
 int launch_pp_og_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, const OutGluArgs& g, hipStream_t s);
 int launch_pp_og_tail_ff2(const TailFf2Args& a, const OutGluArgs& g, hipStream_t s);
 int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s);   // -1: shape not supported
+// the same layer on the two-term fp16 stream (fused_pp.hip; pp = append_pp_plain of K / 144 chunks [W_f ; bias or 0], packed with pp_sw)
+int launch_pp_sublinear(const StreamGemmArgs& a, const float* pp, float pp_sw, hipStream_t s);
 int launch_pick(const PickArgs& a, hipStream_t s);
 int launch_row_argmax(const float* x, int32_t* out, int M, int V, hipStream_t s);
 int launch_gather(const GatherArgs& a, hipStream_t s);

@@ -132,6 +132,8 @@ struct mi355asr_model {
               *leaf_smooth = nullptr, *leaf_gamma = nullptr, *leaf_beta = nullptr;
   float leaf_p0 = 0.f, leaf_p1 = 1.f;
   const float* lin_wsplit = nullptr;    // subsampling Dense kernel as split-bf16 fragments, 1792 per 32-wide step (fused.hip)
+  const float* lin_pp = nullptr;        // ... and as the two-term fp16 stream of pp_sublinear_kernel (F2 chunks of five ring slots), packed with
+  float lin_pp_sw = 1.f;                // ... this power of two
   const float* c2_wsplit = nullptr;     // conv2 kernel as split-bf16 fragments (subconv.hip; dmodel 144 / 256 / 512)
   const float* c2_whalf = nullptr;      // ... as two fp16 terms of kernel * c2_wscale (two-term scheme), conv1 values times c2_hscale
   float c2_hscale = 0.f, c2_wscale = 0.f;

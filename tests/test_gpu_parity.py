@@ -239,6 +239,29 @@ def test_two_term_fp16_block_and_attention_under_adversarial_operand_bounds(torc
             assert e2 < TOL and e3 < TOL, (case, e2, e3)
 
 
+def test_subsampling_dense_two_term_stream_at_5000_rows(torch_cuda):
+    """Dense(2880 -> 144) behind the subsampling convs runs from 4 096 rows on as pp_sublinear_kernel: two fp16 terms, the
+    operand scale taken per (token, 144-wide chunk) from the chunk's own maximum (ReLU outputs have no static bound).  20
+    utterances x 1 000 feature frames = 5 000 rows against the fp64 oracle: in-range features, one utterance of zeros (all-zero
+    chunks), one of tiny features (1e-3 dB) and one whose conv output spans six orders of magnitude across the frequency axis."""
+    from tensorflowasr_amd.models import ConformerEncoder
+    cfg = small_cfg(1)
+    w = co.encoder_weights(cfg, seed=71)
+    e = ConformerEncoder(**encoder_kwargs(cfg))
+    e.load_weights(w, by_name=False)
+    rng = np.random.default_rng(72)
+    mel = (-80.0 * rng.random((20, 1000, 80))).astype(np.float32)
+    mel[3] = 0.0
+    mel[7] *= 1e-3
+    mel[11] *= np.logspace(-6, 0, 80, dtype=np.float32)[None, :]
+    ref = co.conv_subsampling(mel.astype(np.float64), w)
+    got = e.conv_subsampling(mel).cpu().numpy()
+    assert got.shape == ref.shape == (20, 250, 144)
+    err = maxdiff(got, ref)
+    print("subsampling Dense at 5 000 rows: max|d| %.3g of max|ref| %.3g" % (err, np.abs(ref).max()))
+    assert err < 2e-7 * np.abs(ref).max() + 1e-5
+
+
 @pytest.mark.parametrize("B,T", [(2, 50), (3, 250), (1, 300), (2, 7), (1, 16), (1, 17), (1, 750)])
 def test_conformer_block_parity(enc2, B, T):
     e, w, _ = enc2
