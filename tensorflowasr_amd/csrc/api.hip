@@ -541,9 +541,7 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
     put_ring(ab, o.out_wp, [&](int kk, int n) { return pk_r[(size_t)kk * d + n]; }, d, d, false);
   }
   if (d == 144) {
-    // the split-bf16 packs of the ring kernels (fused.hip), for either attention layout
-    const auto& pk_out = keras_mha ? T(a + "/mha/attention_output/kernel") : T(a + "/mha/projection_kernel");
-    o.out_ws = ab.put(pack_split32([&](int kk, int n) { return pk_out[(size_t)kk * d + n]; }, d, d)); o.split = true;
+    o.split = true;                      // the slab streams of the loader-wave kernels (fused.hip) and of the pair-pipelined ones (fused_pp.hip)
     // slab stream of ff1_qkv_ring_kernel: per hidden chunk of 144 the five steps of W1[:, chunk] and of W2[chunk, :],
     // then q, k, v (five steps each)
     const auto& f1 = T(p + "/ff_module_1/ffn1/kernel");
@@ -594,7 +592,6 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
   o.pw1_wp = ab.put(pack_p16([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d, 2 * d / 16));
   if (rings) put_ring(ab, o.pw1_wp, [&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d, true);
   if (o.split) {
-    o.pw1_ws = ab.put(pack_split32([&](int kk, int n) { return pw1[(size_t)kk * 2 * d + n]; }, d, 2 * d));
     // slab stream of out_glu_ring_kernel: out-projection (5 slabs), then pw_conv_1 step by step (value | gate)
     const auto& pk2 = keras_mha ? T(a + "/mha/attention_output/kernel") : T(a + "/mha/projection_kernel");
     std::vector<float> st;
@@ -687,7 +684,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
-  if (o.split) { b.out_ws = base + o.out_ws; b.pw1_ws = base + o.pw1_ws; b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; b.pp_og = base + o.pp_og; b.pp_sw_out = o.pp_sw_out; b.pp_sw_pw1 = o.pp_sw_pw1; b.att_h2[0] = o.att_h2[0]; b.att_h2[1] = o.att_h2[1]; b.att_h2[2] = o.att_h2[2]; }
+  if (o.split) { b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; b.pp_og = base + o.pp_og; b.pp_sw_out = o.pp_sw_out; b.pp_sw_pw1 = o.pp_sw_pw1; b.att_h2[0] = o.att_h2[0]; b.att_h2[1] = o.att_h2[1]; b.att_h2[2] = o.att_h2[2]; }
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
   b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
@@ -887,7 +884,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k2.ctx = sc.ctx; k2.x1 = sc.xb; k2.x2 = sc.xa; k2.u = sc.u;
     k2.out_wp = w.out_wp; k2.out_b = w.out_b; k2.cv_ln_g = w.cv_ln_g; k2.cv_ln_b = w.cv_ln_b;
     k2.pw1_wp = w.pw1_wp; k2.pw1_b = w.pw1_b; k2.eps = kLnEps; k2.M = M;
-    k2.out_ws = w.out_ws; k2.pw1_ws = w.pw1_ws; k2.og_slabs = w.og_slabs; k2.pp_slabs = w.pp_og; k2.pp_sw_out = w.pp_sw_out; k2.pp_sw_pw1 = w.pp_sw_pw1;
+    k2.og_slabs = w.og_slabs; k2.pp_slabs = w.pp_og; k2.pp_sw_out = w.pp_sw_out; k2.pp_sw_pw1 = w.pp_sw_pw1;
     DwArgs dwa{};
     dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
     dwa.pad_left = bo.causal ? ksz - 1 : (ksz - 1) / 2;

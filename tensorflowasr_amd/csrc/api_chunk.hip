@@ -431,7 +431,9 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     {
       PROF(MI355ASR_K_SUBLINEAR);
       // the split-bf16 ring-DMA Dense from 4096 rows on (as run_subsampling in api.hip), else the fp32-MFMA stream kernel
-      if (!(m->lin_wsplit && lg.M >= 4096 && launch_sublinear_split(lg, m->lin_wsplit, s) == 0))
+      // (round 4: the two-term stream with a scale per token and 144-wide chunk first, as run_subsampling in api.hip)
+      if (!(m->lin_wsplit && lg.M >= 4096 && ((m->lin_pp && launch_pp_sublinear(lg, m->lin_pp, m->lin_pp_sw, s) == 0) ||
+                                              launch_sublinear_split(lg, m->lin_wsplit, s) == 0)))
         LAUNCH_TRY(launch_stream_gemm(d, lg, s), "subsampling linear");
     }
   }

@@ -182,9 +182,8 @@ __global__ __launch_bounds__(ATH, 2) void attention_lds_kernel(AttnArgs a) {
 }  // namespace
 
 bool attention_lds_applicable(int HS, const AttnArgs& a) {
-  // head size 64 (ConformerM / L): K and V^T take 130 KB, one workgroup per CU.  MI355ASR_ATTN_LDS64=0: the L2-streaming kernel
-  static const bool lds64 = [] { const char* v = getenv("MI355ASR_ATTN_LDS64"); return v ? atoi(v) != 0 : true; }();
-  return (HS == 36 || (HS == 64 && lds64)) && a.win_front < 0 && a.Tk <= (HS == 64 ? TP_MAX : 256) && a.Tk > 16 && a.Tq > 16;
+  // head size 64 (ConformerM / L): K and V^T take 130 KB, one workgroup per CU.
+  return (HS == 36 || HS == 64) && a.win_front < 0 && a.Tk <= (HS == 64 ? TP_MAX : 256) && a.Tk > 16 && a.Tq > 16;
 }
 
 int launch_attention_lds(int HS, const AttnArgs& a, hipStream_t s) {

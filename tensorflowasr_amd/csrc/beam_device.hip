@@ -334,19 +334,34 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
       if (ck[i] != ~0ull && (ck[i] >> shift_keep) <= thr_s) { sh.keys[pos] = ck[i]; sh.kept_j[pos] = w + 4 * i; ++pos; }
   }
   __syncthreads();
-  if (tid < newn) {
+  {
     // beam positions = ranks (the tie-break word of the next frame's keys is the position: beam.hip Search::better defines
     // the order among prefixes of equal score and last character through it, and both searches have to agree on it).
-    // Keys are distinct (their low word is the slot): rank = number of kept keys below this one.
-    const u64 key = sh.keys[tid];
-    const int j = sh.kept_j[tid];
+    // Keys are distinct (their low word is the slot): rank = number of kept keys below this one.  Two threads per kept key
+    // (newn <= BMAX = NT / 2), each counting over one half of the list, sixteen keys per round requested before any is
+    // compared (one LDS latency per round: the first version walked the list two keys at a time and cost 12 000 of the
+    // 34 000 clocks of a beam-100 frame).
+    const int kidx = tid >> 1, half = tid & 1;
+    const bool mine = kidx < newn;
+    const u64 key = mine ? sh.keys[kidx] : 0;
+    const int j = mine ? sh.kept_j[kidx] : 0;
+    const int hlen = (((newn + 1) >> 1) + 1) & ~1;          // keys per half, even (16-byte reads)
+    const int qb = half * hlen, qe = min(newn, qb + hlen);
     int rank = 0;
-    for (int q = 0; q < newn; q += 2) {      // keys[newn] may be stale: it only counts when it is a kept key
-      const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(sh.keys + q);
-      rank += (kk.x < key) + (q + 1 < newn && kk.y < key);
+    if (mine) {
+      for (int q0 = qb; q0 < qe; q0 += 16) {
+        ulonglong2 kk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) kk[q] = *reinterpret_cast<const ulonglong2*>(sh.keys + min(q0 + 2 * q, NT - 2));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rank += (q0 + 2 * q < qe && kk[q].x < key) + (q0 + 2 * q + 1 < qe && kk[q].y < key);
+      }
     }
-    if (j < 0) keep_entry(sh, C, Nx, L, -1 - j, rank);
-    else keep_child(C, Nx, L, arena, 1 + t * beam + rank, j, (int)((key >> 16) & 0xffff) - 1, key_score(key), rank);
+    rank += __shfl_xor(rank, 1);
+    if (mine && half == 0) {
+      if (j < 0) keep_entry(sh, C, Nx, L, -1 - j, rank);
+      else keep_child(C, Nx, L, arena, 1 + t * beam + rank, j, (int)((key >> 16) & 0xffff) - 1, key_score(key), rank);
+    }
   }
   __syncthreads();
   if (profiling) rp.install += clock64() - c0;

@@ -7,11 +7,6 @@
 #include "common.h"
 #include "launch.h"
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 // =====================================================================================================
 // chain2: y = res + scale * ( act( pro(x) W1 + b1 ) W2 + b2 )      [optionally followed by LayerNorm]
 //   MODE 0 (FFModule, conformer_blocks.py:126-134): pro = LayerNorm, act = swish
@@ -72,7 +67,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((RT == 1 && D <= 144) ? 2 : 1)) voi
     const int h0 = hbase;
     if (r < KB) {
 #pragma unroll
-      for (int i = 0; i < CT1; ++i) dst[i] = w1[(size_t)((r * HT + h0) * a.dbg_wmul + i) * 64];
+      for (int i = 0; i < CT1; ++i) dst[i] = w1[(size_t)((r * HT + h0) + i) * 64];
       if (r == 0) {   // bias of this chunk rides with its first batch
 #pragma unroll
         for (int i = 0; i < CT1; ++i) b1v[i] = ldg4(a.b1 + 16 * (h0 + i) + g4);
@@ -80,7 +75,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((RT == 1 && D <= 144) ? 2 : 1)) voi
     } else {
       const int n1 = r - KB;
 #pragma unroll
-      for (int n2 = 0; n2 < KB; ++n2) dst[n2] = w2[(size_t)((h0 + n1) * KB * a.dbg_wmul + n2) * 64];
+      for (int n2 = 0; n2 < KB; ++n2) dst[n2] = w2[(size_t)((h0 + n1) * KB + n2) * 64];
       if (MODE == 1 && n1 == 0) {
 #pragma unroll
         for (int i = 0; i < CT1; ++i) {
@@ -192,13 +187,10 @@ static void launch_chain2_t(const Chain2Args& a, int rt, hipStream_t s) {
 }
 
 int launch_chain2(int D, int mode, const Chain2Args& a_in, hipStream_t s) {
-  static const int wmul_env = env_int("MI355ASR_DEBUG_WMUL", 1);
-  Chain2Args a = a_in;
-  a.dbg_wmul = wmul_env;
+  const Chain2Args& a = a_in;
   // two token tiles per wave once there are enough tiles to keep every CU busy with tile pairs
-  static const int rt_env = env_int("MI355ASR_CHAIN2_RT", 0);
   const int tiles = (a.M + 15) / 16;
-  const int rt = rt_env ? rt_env : (tiles >= 512 ? 2 : 1);
+  const int rt = tiles >= 512 ? 2 : 1;
   if (D == 144 && mode == 0) launch_chain2_t<144, 36, 4, 9, 0, true>(a, rt, s);
   else if (D == 144 && mode == 1) launch_chain2_t<144, 18, 2, 9, 1, true>(a, rt, s);
   else if (D == 256 && mode == 0) launch_chain2_t<256, 64, 4, 16, 0, false>(a, 1, s);
@@ -368,12 +360,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, (RT == 1 ? 2 : 1)) void gemm_rows_ke
 
 template <int D, int CT, int EPI, bool LN, bool HAS_RT2>
 static void launch_gemm_rows_t(const GemmArgs& a, int ychunks, hipStream_t s) {
-  static const int rt_env = env_int("MI355ASR_GEMM_RT", 0);
   const int tiles = (a.M + 15) / 16;
   // two token tiles per wave halve the L2 weight stream per flop, but at the benchmark shape these short
   // kernels (13-40 us) are bound by ramp-up/tail, and the RT = 2 form measured 10-50 % slower (qkv 40 -> 44 us,
   // out-projection 15 -> 24 us); it pays only with several waves per SIMD left over, i.e. very large batches.
-  const int rt = rt_env ? rt_env : ((tiles / 2) * ychunks >= 8192 ? 2 : 1);
+  const int rt = (tiles / 2) * ychunks >= 8192 ? 2 : 1;
   if (HAS_RT2 && rt == 2) {
     dim3 grid(((tiles + 1) / 2 + 3) / 4, ychunks);
     hipLaunchKernelGGL((gemm_rows_kernel<D, (HAS_RT2 ? 2 : 1), CT, EPI, LN>), grid, dim3(BLOCK_THREADS), 0, s, a);
@@ -740,9 +731,7 @@ static int launch_dwconv_tile(const DwArgs& a, hipStream_t s) {
 }
 
 int launch_dwconv(int K, const DwArgs& a, hipStream_t s) {
-  // MI355ASR_DWCONV_TILE=0: the first-generation kernel (window re-read from L2 per thread)
-  static const int tile = [] { const char* v = getenv("MI355ASR_DWCONV_TILE"); return v ? atoi(v) : 1; }();
-  if (tile && a.T * a.B >= 2048) {
+  if (a.T * a.B >= 2048) {                  // LDS-tiled kernel; below: the first-generation kernel (window re-read from L2 per thread)
     if (K == 32 && a.D == 144) return launch_dwconv_tile<32, 144>(a, s);
     if (K == 32 && a.D % 128 == 0) return launch_dwconv_tile<32, 128>(a, s);
     if (K == 5 && a.D % 128 == 0) return launch_dwconv_tile<5, 128>(a, s);

@@ -273,114 +273,6 @@ int launch_mel(const MelArgs& a, hipStream_t s) {
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Fused ConvSubsampling convs.  Implicit GEMM over K = 9*D with rows = output positions (b, t2, f2).
-// The conv2 operand A[(b,t2,f2)][(kt,kf,c)] = relu(conv1)[b, 2*t2+kt-pt2, 2*f2+kf-pf2, c] is evaluated in
-// registers from a 7x7 mel window (49 values per position) -- the [B,T1,F1,D] conv1 activation
-// (737 MB at B=64) is never materialised.  K is ordered (c-block, kt, kf) so one set of conv1 weights
-// (9 float4 + bias) serves nine k-blocks.
-// ---------------------------------------------------------------------------------------------------
-template <int D, int RT>
-__global__ __launch_bounds__(BLOCK_THREADS) void subconv_kernel(SubConvArgs a) {
-  constexpr int KB = D / 16;
-  const int lane = threadIdx.x & 63;
-  const int g4 = (lane >> 4) * 4, c = lane & 15;
-  const int wid = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  const int P = a.B * a.T2 * a.F2;
-  if ((size_t)wid * RT * 16 >= (size_t)P) return;
-
-  int pos[RT];
-  float win[RT][7][7];
-  bool tv[RT][3], fv[RT][3];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    pos[rt] = (wid * RT + rt) * 16 + c;
-    const int p = min(pos[rt], P - 1);
-    const int b = p / (a.T2 * a.F2);
-    const int r = p % (a.T2 * a.F2);
-    const int t2 = r / a.F2, f2 = r % a.F2;
-    const int tm0 = 4 * t2 - 2 * a.pt2 - a.pt1;
-    const int fm0 = 4 * f2 - 2 * a.pf2 - a.pf1;
-    const float* __restrict__ mb = a.mel + (size_t)b * a.F * a.NM;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int tm = tm0 + i;
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int fm = fm0 + j;
-        win[rt][i][j] = (tm >= 0 && tm < a.F && fm >= 0 && fm < a.NM) ? mb[(size_t)tm * a.NM + fm] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int t1 = 2 * t2 + k - a.pt2;
-      const int f1 = 2 * f2 + k - a.pf2;
-      tv[rt][k] = (t1 >= 0 && t1 < a.T1);
-      fv[rt][k] = (f1 >= 0 && f1 < a.F1);
-    }
-  }
-
-  f32x4 acc[RT][KB];
-#pragma unroll
-  for (int n = 0; n < KB; ++n) {
-    f32x4 bb = ldg4(a.b2 + 16 * n + g4);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[rt][n] = bb;
-  }
-  const f32x4* __restrict__ w2 = reinterpret_cast<const f32x4*>(a.w2p) + lane;
-
-  // weight stream of the implicit GEMM: batch (cb, q) = KB fragments; batch s+1 is in flight during batch s.
-  f32x4 wb[2][KB];
-#pragma unroll
-  for (int n = 0; n < KB; ++n) wb[0][n] = w2[(size_t)(0 * KB + n) * 64];
-#pragma unroll 1
-  for (int cb = 0; cb < KB; ++cb) {
-    f32x4 w1v[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) w1v[i][j] = ldg4(a.w1 + (size_t)(i * 3 + j) * D + 16 * cb + g4);
-    const f32x4 b1v = ldg4(a.b1 + 16 * cb + g4);
-    const int cbn = (cb + 1 < KB) ? cb + 1 : cb;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int kt = q / 3, kf = q % 3;
-      const int kbn = (q + 1 < 9) ? cb * 9 + q + 1 : cbn * 9;
-#pragma unroll
-      for (int n = 0; n < KB; ++n) wb[(q + 1) & 1][n] = w2[(size_t)(kbn * KB + n) * 64];
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 xf[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        f32x4 v = b1v;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) v += splat4(win[rt][2 * kt + i][2 * kf + j]) * w1v[i][j];
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        xf[rt] = (tv[rt][kt] && fv[rt][kf]) ? v : splat4(0.f);
-      }
-      mma_batch_rt<RT, KB>(acc, wb[q & 1], xf);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // nine steps per channel block: the batch prefetched last sits in wb[1]; the next block starts from wb[0]
-#pragma unroll
-    for (int n = 0; n < KB; ++n) wb[0][n] = wb[1][n];
-  }
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    if (pos[rt] < P) {
-      float* orow = a.out + (size_t)pos[rt] * D;
-#pragma unroll
-      for (int n = 0; n < KB; ++n) {
-        f32x4 v = acc[rt][n];
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        stg4(orow + 16 * n + g4, v);
-      }
-    }
-  }
-}
-
 // Same implicit GEMM for any dmodel that is a multiple of 128 (256: ConformerM / StreamingS, 512: ConformerL), with the
 // output channels split over grid.y in chunks of NBW column tiles: a wave keeps 16 positions x NBW tiles of
 // accumulators (32 VGPRs) instead of the whole row, so the kernel fits 256 registers with two waves per SIMD at any
@@ -473,25 +365,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv_split_kernel(SubConv
   }
 }
 
-template <int D>
-static void launch_subconv_t(const SubConvArgs& a, hipStream_t s) {
-  const int P = a.B * a.T2 * a.F2;
-  const int tiles = (P + 15) / 16;
-  // RT = 2 (two position tiles per wave) spills under hipcc 7.2 (49-value window x 2 + 2x accumulators);
-  // one tile per wave fits in 256 VGPRs with no scratch.
-  hipLaunchKernelGGL((subconv_kernel<D, 1>), dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
-}
-
 int launch_subconv(int D, const SubConvArgs& a, hipStream_t s) {
-  static const bool v1 = [] { const char* v = getenv("MI355ASR_SUBCONV_V1"); return v && atoi(v) != 0; }();
-  // MI355ASR_SUBCONV_F32=1: the fp32-MFMA register-stream kernel instead of the split-bf16 one (both in subconv.hip)
+  // MI355ASR_SUBCONV_F32=1: the fp32-MFMA register-stream kernel instead of the split-operand one (both in subconv.hip)
   static const bool f32k = [] { const char* v = getenv("MI355ASR_SUBCONV_F32"); return v && atoi(v) != 0; }();
-  if (!v1 && !f32k && launch_subconv_split(D, a, s) == 0) return 0;       // dmodel 144 / 256 / 512 with the split pack
+  if (!f32k && launch_subconv_split(D, a, s) == 0) return 0;       // dmodel 144 / 256 / 512 with the split pack
   note_scheme(SCHEME_F32);
-  if (D == 144 && !v1) return launch_subconv144(a, s);
-  if (D == 144) { launch_subconv_t<144>(a, s); return 0; }
-  static const bool v1_256 = [] { const char* v = getenv("MI355ASR_SUBCONV256_V1"); return v && atoi(v) != 0; }();
-  if (D == 256 && v1_256) { launch_subconv_t<256>(a, s); return 0; }
+  if (D == 144) return launch_subconv144(a, s);
   if (D % 128 == 0) {
     const int P = a.B * a.T2 * a.F2;
     const int tiles = (P + 15) / 16;

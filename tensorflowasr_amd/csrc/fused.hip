@@ -397,234 +397,8 @@ DEV void slab_step(f32x4* acc, const Split8& xf, unsigned addr) {
 #undef SLAB_MMA
 }
 
-// ff1_qkv on the slab ring (five slots: 150 KB of LDS with the parameter stash).  Slab order: for each of the four
-// hidden chunks (9 tiles) the 5 steps of W1 for that chunk, then the 5 steps of W2 over the chunk's 144 hidden features;
-// then q, k, v (5 steps each): 55 slabs.  LN(x0) is split once and reused by the four chunks.
-__global__ __launch_bounds__(BLOCK_THREADS, 1) void ff1_qkv_ring_kernel(Ff1QkvArgs a) {
-  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
-  __shared__ __attribute__((aligned(16))) float p_ln1g[D], p_ln1b[D], p_b1[4 * D], p_b2[D], p_ln2g[D], p_ln2b[D], p_qb[3 * D];
-  const WaveCtx c = wave_ctx(a.M);
-  SlabStream<5> st{ring, reinterpret_cast<const u32x4_t*>(a.slabs), 55,
-                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
-  f32x4 xs[KB + 1], y[KB];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + c.row + 16 * kb + c.g4);
-  xs[KB] = splat4(0.f);
-  {
-    const auto r0 = stash_load<D>(a.ff_ln_g), r1 = stash_load<D>(a.ff_ln_b), r3 = stash_load<D>(a.ff_b2),
-               r4 = stash_load<D>(a.att_ln_g), r5 = stash_load<D>(a.att_ln_b);
-    const auto r2 = stash_load<4 * D>(a.ff_b1);
-    const auto r6 = stash_load<3 * D>(a.qkv_b);
-    st.begin();                                            // after the input / parameter loads: see sync()
-    stash_store<D>(p_ln1g, r0); stash_store<D>(p_ln1b, r1); stash_store<4 * D>(p_b1, r2); stash_store<D>(p_b2, r3);
-    stash_store<D>(p_ln2g, r4); stash_store<D>(p_ln2b, r5); stash_store<3 * D>(p_qb, r6);
-  }
-  st.sync();                                               // inputs, parameters and slab 0; three slabs still in flight
-  const float inv_fc = 1.0f / a.fc;
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) y[kb] = lds4(p_b2, kb, c.g4) + splat4(inv_fc) * xs[kb];
-  {
-    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
-    ln_lds(xr, p_ln1g, p_ln1b, c.g4, a.eps);
-  }
-  Split8 xf[KS32X];
-#pragma unroll
-  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
-#pragma unroll 1
-  for (int ch = 0; ch < 4; ++ch) {
-    f32x4 h[KB + 1];
-#pragma unroll
-    for (int i = 0; i < KB; ++i) h[i] = lds4(p_b1, ch * KB + i, c.g4);
-    h[KB] = splat4(0.f);
-    static_for<0, KS32X>([&](auto T) {
-      constexpr int t = decltype(T)::value;
-      st.prefetch();
-      slab_step(h, xf[t], st.cur_addr());
-      st.advance();
-    });
-#pragma unroll
-    for (int i = 0; i < KB; ++i) h[i] = swish4(h[i]);
-    static_for<0, KS32X>([&](auto T) {
-      constexpr int t = decltype(T)::value;
-      st.prefetch();
-      const Split8 hf = split8(h[2 * t], h[2 * t + 1]);
-      slab_step(y, hf, st.cur_addr());
-      st.advance();
-    });
-  }
-  f32x4 x1[KB];
-#pragma unroll
-  for (int i = 0; i < KB; ++i) { x1[i] = splat4(a.fc) * y[i]; xs[i] = x1[i]; }     // x1 = x0 + fc * (ffn + b2)
-  {
-    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
-    ln_lds(xr, p_ln2g, p_ln2b, c.g4, a.eps);
-  }
-#pragma unroll
-  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
-  f32x4 acc[3 * KB];
-#pragma unroll
-  for (int i = 0; i < 3 * KB; ++i) acc[i] = lds4(p_qb, i, c.g4);
-  static_for<0, 3>([&](auto Q) {
-    constexpr int q = decltype(Q)::value;
-    static_for<0, KS32X>([&](auto T) {
-      constexpr int t = decltype(T)::value;
-      st.prefetch();
-      slab_step(acc + q * KB, xf[t], st.cur_addr());
-      st.advance();
-    });
-  });
-  if (c.live) {
-    float* qrow = a.qkv + (size_t)c.tok * (3 * D);
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      stg4(a.x1 + c.row + 16 * i + c.g4, x1[i]);
-      stg4(qrow + 16 * i + c.g4, acc[i] * splat4(a.qscale));
-      stg4(qrow + 16 * (KB + i) + c.g4, acc[KB + i]);
-      stg4(qrow + 16 * (2 * KB + i) + c.g4, acc[2 * KB + i]);
-    }
-  }
-}
 
-// tail_ff2 on the slab ring: conv-module tail (two hidden chunks of pointwise + BN + swish + pw_conv_2), FFModule 2
-// (four hidden chunks) -- 60 slabs -- and the block-final LayerNorm.
-__global__ __launch_bounds__(BLOCK_THREADS, 1) void tail_ff2_ring_kernel(TailFf2Args a) {
-  __shared__ __attribute__((aligned(16))) u32x4_t ring[5 * SLB];
-  __shared__ __attribute__((aligned(16))) float p_pcb[2 * D], p_bns[2 * D], p_bnt[2 * D], p_pw2b[D], p_lng[D], p_lnb[D], p_b1[4 * D],
-      p_b2[D], p_fg[D], p_fb[D];
-  const WaveCtx c = wave_ctx(a.M);
-  SlabStream<5> st{ring, reinterpret_cast<const u32x4_t*>(a.slabs), 60,
-                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
-  f32x4 xs[KB + 1], y[KB];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
-  xs[KB] = splat4(0.f);
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + c.row + 16 * kb + c.g4);     // residuals ride in the accumulators
-  {
-    const auto r0 = stash_load<2 * D>(a.pc_b1), r1 = stash_load<2 * D>(a.bn_s), r2 = stash_load<2 * D>(a.bn_t);
-    const auto r3 = stash_load<D>(a.pw2_b), r4 = stash_load<D>(a.ff_ln_g), r5 = stash_load<D>(a.ff_ln_b),
-               r7 = stash_load<D>(a.ff_b2), r8 = stash_load<D>(a.ln_g), r9 = stash_load<D>(a.ln_b);
-    const auto r6 = stash_load<4 * D>(a.ff_b1);
-    st.begin();
-    stash_store<2 * D>(p_pcb, r0); stash_store<2 * D>(p_bns, r1); stash_store<2 * D>(p_bnt, r2); stash_store<D>(p_pw2b, r3);
-    stash_store<D>(p_lng, r4); stash_store<D>(p_lnb, r5); stash_store<4 * D>(p_b1, r6); stash_store<D>(p_b2, r7);
-    stash_store<D>(p_fg, r8); stash_store<D>(p_fb, r9);
-  }
-  st.sync();
-#pragma unroll
-  for (int i = 0; i < KB; ++i) y[i] += lds4(p_pw2b, i, c.g4);
-  Split8 xf[KS32X];
-#pragma unroll
-  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
-  // y += W2 act(W1 x + b1) over NCH hidden chunks of 9 tiles; AFF: act = swish(s (.) + t) (folded BatchNorm)
-  auto chain = [&](int nch, const float* b1, const float* as, const float* at, bool aff) {
-#pragma unroll 1
-    for (int ch = 0; ch < nch; ++ch) {
-      f32x4 h[KB + 1];
-#pragma unroll
-      for (int i = 0; i < KB; ++i) h[i] = lds4(b1, ch * KB + i, c.g4);
-      h[KB] = splat4(0.f);
-      static_for<0, KS32X>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        st.prefetch();
-        slab_step(h, xf[t], st.cur_addr());
-        st.advance();
-      });
-#pragma unroll
-      for (int i = 0; i < KB; ++i) {
-        if (aff) h[i] = h[i] * lds4(as, ch * KB + i, c.g4) + lds4(at, ch * KB + i, c.g4);
-        h[i] = swish4(h[i]);
-      }
-      static_for<0, KS32X>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        st.prefetch();
-        const Split8 hf = split8(h[2 * t], h[2 * t + 1]);
-        slab_step(y, hf, st.cur_addr());
-        st.advance();
-      });
-    }
-  };
-  chain(2, p_pcb, p_bns, p_bnt, true);
-  const float inv_fc = 1.0f / a.fc;
-#pragma unroll
-  for (int i = 0; i < KB; ++i) {
-    xs[i] = y[i];                                                                    // x3 = x2 + conv module
-    y[i] = lds4(p_b2, i, c.g4) + splat4(inv_fc) * y[i];                              // x3/fc + b2 (+ W2 h)
-  }
-  {
-    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
-    ln_lds(xr, p_lng, p_lnb, c.g4, a.eps);
-  }
-#pragma unroll
-  for (int t = 0; t < KS32X; ++t) xf[t] = split8(xs[2 * t], xs[2 * t + 1]);
-  chain(4, p_b1, nullptr, nullptr, false);
-#pragma unroll
-  for (int i = 0; i < KB; ++i) y[i] = splat4(a.fc) * y[i];
-  ln_lds(y, p_fg, p_fb, c.g4, a.eps);                                                // block-final LayerNorm
-  if (c.live) {
-#pragma unroll
-    for (int i = 0; i < KB; ++i) stg4(a.y + c.row + 16 * i + c.g4, y[i]);
-  }
-}
 
-// out_glu on the slab ring: 5 slabs of the out-projection, then per 32-wide step of pw_conv_1 one slab of value tiles
-// and one of gate tiles (15 slabs).  Inputs are loaded before the stream starts; x2 and u are stored after it ends.
-__global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_ring_kernel(OutGluArgs a) {
-  __shared__ __attribute__((aligned(16))) u32x4_t ring[4 * SLB];
-  __shared__ __attribute__((aligned(16))) float p_ob[D], p_lng[D], p_lnb[D], p_pb[2 * D];
-  const WaveCtx c = wave_ctx(a.M);
-  SlabStream<4> st{ring, reinterpret_cast<const u32x4_t*>(a.og_slabs), 15,
-                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c.lane};
-  f32x4 xs[KB + 1], acc[2 * KB], x2[KB];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + c.row + 16 * kb + c.g4);
-  xs[KB] = splat4(0.f);
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) acc[kb] = ldg4(a.x1 + c.row + 16 * kb + c.g4);    // residual rides in the accumulator
-  {
-    const auto r0 = stash_load<D>(a.out_b), r1 = stash_load<D>(a.cv_ln_g), r2 = stash_load<D>(a.cv_ln_b);
-    const auto r3 = stash_load<2 * D>(a.pw1_b);
-    st.begin();
-    stash_store<D>(p_ob, r0); stash_store<D>(p_lng, r1); stash_store<D>(p_lnb, r2); stash_store<2 * D>(p_pb, r3);
-  }
-  st.sync();
-#pragma unroll
-  for (int i = 0; i < KB; ++i) acc[i] += lds4(p_ob, i, c.g4);
-  static_for<0, KS32X>([&](auto T) {
-    constexpr int t = decltype(T)::value;
-    st.prefetch();
-    const Split8 xf = split8(xs[2 * t], xs[2 * t + 1]);
-    slab_step(acc, xf, st.cur_addr());
-    st.advance();
-  });
-#pragma unroll
-  for (int i = 0; i < KB; ++i) { x2[i] = acc[i]; xs[i] = acc[i]; }                  // x2 = x1 + attention
-  {
-    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
-    ln_lds(xr, p_lng, p_lnb, c.g4, a.eps);
-  }
-#pragma unroll
-  for (int i = 0; i < 2 * KB; ++i) acc[i] = lds4(p_pb, i, c.g4);                   // value tiles 0..8, gate tiles 9..17
-  static_for<0, KS32X>([&](auto T) {
-    constexpr int t = decltype(T)::value;
-    const Split8 xf = split8(xs[2 * t], xs[2 * t + 1]);
-    st.prefetch();
-    slab_step(acc, xf, st.cur_addr());
-    st.advance();
-    st.prefetch();
-    slab_step(acc + KB, xf, st.cur_addr());
-    st.advance();
-  });
-  if (c.live) {
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      stg4(a.x2 + c.row + 16 * i + c.g4, x2[i]);
-      const f32x4 va = acc[i], vb = acc[KB + i];
-      f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
-      stg4(a.u + c.row + 16 * i + c.g4, o);
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Loader-wave versions of the three ring kernels (round 2).  The kernels above make every consumer wave issue its share
@@ -1200,8 +974,6 @@ __global__ __launch_bounds__(LD_THREADS) void head_ld_kernel(GemmArgs a, const u
 }
 
 
-constexpr int KS32 = 5;                       // 32-wide steps over K = 144 (the last half step is zero)
-constexpr int OG_SLAB = 2 * KB * 3 * 64;      // fragments of the larger slab (18 tiles)
 
 // acc[0..NT) += W(step)^T x  for one 32-wide step: slab = [NT tiles][3 terms][64 lanes] in LDS
 template <int NT>
@@ -1229,78 +1001,6 @@ DEV void split_step(f32x4* acc, const Split8& xf, const u32x4_t* slab, int lane)
   }
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS, 1) void out_glu_split_kernel(OutGluArgs a) {
-  __shared__ __attribute__((aligned(16))) u32x4_t wl[2][OG_SLAB];
-  __shared__ __attribute__((aligned(16))) float p_ob[D], p_lng[D], p_lnb[D], p_pb[2 * D];
-  const WaveCtx c = wave_ctx(a.M);
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const u32x4_t* wo = reinterpret_cast<const u32x4_t*>(a.out_ws);
-  const u32x4_t* wg = reinterpret_cast<const u32x4_t*>(a.pw1_ws);
-  constexpr int SO = KB * 3 * 64, SG = 2 * KB * 3 * 64;      // slab sizes (fragments)
-  // slab of step s -> buffer s & 1
-  auto fill = [&](int s) {
-    const u32x4_t* src = s < KS32 ? wo + (size_t)s * SO : wg + (size_t)(s - KS32) * SG;
-    const int n = s < KS32 ? SO : SG;
-    for (int w0 = 64 * wv; w0 < n; w0 += BLOCK_THREADS) dma16(src + w0 + c.lane, &wl[s & 1][w0]);
-  };
-  fill(0);
-  f32x4 xs[KB + 1], acc[2 * KB];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + c.row + 16 * kb + c.g4);
-  xs[KB] = splat4(0.f);
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) acc[kb] = ldg4(a.x1 + c.row + 16 * kb + c.g4);    // residual rides in the accumulator
-  stash(p_ob, a.out_b, D); stash(p_lng, a.cv_ln_g, D); stash(p_lnb, a.cv_ln_b, D); stash(p_pb, a.pw1_b, 2 * D);
-  __builtin_amdgcn_s_waitcnt(0x0f70);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < KB; ++i) acc[i] += lds4(p_ob, i, c.g4);
-#pragma unroll 1
-  for (int s = 0; s < KS32; ++s) {
-    fill(s + 1);
-    Split8 xf;
-    // xs[2 s], xs[2 s + 1] with a run-time s: select through a small switch so that xs stays in registers
-    f32x4 lo = xs[0], hi = xs[1];
-    if (s == 1) { lo = xs[2]; hi = xs[3]; } else if (s == 2) { lo = xs[4]; hi = xs[5]; }
-    else if (s == 3) { lo = xs[6]; hi = xs[7]; } else if (s == 4) { lo = xs[8]; hi = xs[9]; }
-    xf = split8(lo, hi);
-    split_step<KB>(acc, xf, wl[s & 1], c.lane);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < KB; ++i) xs[i] = acc[i];                                      // x2 = x1 + attention
-  if (c.live) {
-#pragma unroll
-    for (int i = 0; i < KB; ++i) stg4(a.x2 + c.row + 16 * i + c.g4, xs[i]);
-  }
-  {
-    f32x4 (&xr)[KB] = reinterpret_cast<f32x4 (&)[KB]>(xs);
-    ln_lds(xr, p_lng, p_lnb, c.g4, a.eps);
-  }
-#pragma unroll
-  for (int i = 0; i < 2 * KB; ++i) acc[i] = lds4(p_pb, i, c.g4);                   // value tiles 0..8, gate tiles 9..17
-#pragma unroll 1
-  for (int s = 0; s < KS32; ++s) {
-    if (s + 1 < KS32) fill(KS32 + s + 1);
-    f32x4 lo = xs[0], hi = xs[1];
-    if (s == 1) { lo = xs[2]; hi = xs[3]; } else if (s == 2) { lo = xs[4]; hi = xs[5]; }
-    else if (s == 3) { lo = xs[6]; hi = xs[7]; } else if (s == 4) { lo = xs[8]; hi = xs[9]; }
-    const Split8 xf = split8(lo, hi);
-    split_step<2 * KB>(acc, xf, wl[(KS32 + s) & 1], c.lane);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-  }
-  if (c.live) {
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      const f32x4 va = acc[i], vb = acc[KB + i];
-      f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
-      stg4(a.u + c.row + 16 * i + c.g4, o);
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Dense(F2 d -> d) of the subsampling (K = 2880, N = 144) on the bf16 pipe with split operands: the long-K layer is where
 // a deep DMA ring works -- per 32-wide step a workgroup (4 waves x 16 rows) needs a 27 KB weight slab and its own
@@ -1315,73 +1015,6 @@ constexpr int SL_XFR = 2 * BLOCK_THREADS;            // x slots per slab: 64 row
 constexpr int SL_DMA = 9;                            // DMA instructions per thread and step
 constexpr int SL_SLOT = SL_WFR + SL_XFR;             // fragments per ring slot (36 KB)
 
-__global__ __launch_bounds__(BLOCK_THREADS, 1) void sublinear_split_kernel(StreamGemmArgs a, const u32x4_t* __restrict__ ws) {
-  // four separate LDS objects and a step loop unrolled by four (static slot per step): with one ring[4][..] array the
-  // compiler cannot tell a ds_read of slot s from the pending DMA writes to the other slots and waits vmcnt(0) before it
-  __shared__ __attribute__((aligned(16))) u32x4_t ring0[SL_SLOT], ring1[SL_SLOT], ring2[SL_SLOT], ring3[SL_SLOT];
-  __shared__ __attribute__((aligned(16))) float p_b[D];
-  static_assert(SL_RING == 4, "four ring slots");
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int row0 = blockIdx.x * 64;
-  const int steps = a.K / 32;
-  // this thread's two x chunks per step: slot p = tid + 256 q -> (chunk = p / 64, row = p % 64)
-  const float* xsrc[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int p = threadIdx.x + BLOCK_THREADS * q;
-    const int row = min(row0 + (p & 63), a.M - 1);
-    xsrc[q] = a.x + (size_t)row * a.K + 4 * (p >> 6);
-  }
-  auto fill = [&](int s, u32x4_t* slot) {             // slab of step s -> ring slot
-    const u32x4_t* wsrc = ws + (size_t)s * SL_WFR;
-#pragma unroll
-    for (int q = 0; q < 7; ++q) dma16(wsrc + BLOCK_THREADS * q + 64 * wv + lane, slot + BLOCK_THREADS * q + 64 * wv);
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      dma16(reinterpret_cast<const u32x4_t*>(xsrc[q] + 32 * s), slot + SL_WFR + BLOCK_THREADS * q + 64 * wv);
-  };
-  fill(0, ring0);
-  fill(min(1, steps - 1), ring1);
-  fill(min(2, steps - 1), ring2);
-  for (int i = threadIdx.x; i < D; i += BLOCK_THREADS) p_b[i] = a.bias[i];
-  f32x4 acc[KB];
-  constexpr int kWait = 0x0f70 | (((SL_RING - 2) * SL_DMA) & 15) | ((((SL_RING - 2) * SL_DMA) >> 4) << 14);
-  __builtin_amdgcn_s_waitcnt(kWait);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < KB; ++i) acc[i] = lds4(p_b, i, 4 * g);
-  // one step: refill the slot read in the previous step with the slab RING - 1 steps ahead, then the MFMAs of this slot
-  auto step = [&](int s, const u32x4_t* cur, u32x4_t* refill) {
-    if (s + SL_RING - 1 < steps) fill(s + SL_RING - 1, refill);     // nothing past the end: see SlabStream::prefetch
-    const f32x4 lo = __builtin_bit_cast(f32x4, cur[SL_WFR + g * 64 + 16 * wv + c]);
-    const f32x4 hi = __builtin_bit_cast(f32x4, cur[SL_WFR + (4 + g) * 64 + 16 * wv + c]);
-    const Split8 xf = split8(lo, hi);
-    split_step<KB>(acc, xf, cur, lane);
-    // slab s + 1 has landed (counted: the slabs issued after it -- two, fewer in the last steps -- may still be in
-    // flight) and this wave's LDS reads of the slot are done; a bare s_barrier -- the fence of __syncthreads() would
-    // wait for every outstanding DMA
-    wait_dma_ahead<SL_DMA, SL_RING - 2>(max(min(SL_RING - 2, steps - 2 - s), 0));
-    __builtin_amdgcn_s_barrier();
-  };
-  int s = 0;
-#pragma unroll 1
-  for (; s + 4 <= steps; s += 4) {
-    step(s, ring0, ring3);
-    step(s + 1, ring1, ring0);
-    step(s + 2, ring2, ring1);
-    step(s + 3, ring3, ring2);
-  }
-  if (s < steps) step(s++, ring0, ring3);
-  if (s < steps) step(s++, ring1, ring0);
-  if (s < steps) step(s++, ring2, ring1);
-  const int tok = row0 + 16 * wv + c;
-  if (tok < a.M) {
-    float* yrow = a.y + (size_t)tok * a.ldy;
-#pragma unroll
-    for (int i = 0; i < KB; ++i) stg4(yrow + 16 * i + 4 * g, acc[i]);
-  }
-}
 
 // The same with loader waves (round 2, as the block ring kernels): nine LDS-DMA instructions per wave and step hold the
 // issuing wave for about as long as its 54 MFMAs take, and with one wave per SIMD nothing overlaps them.  Waves 4..7 only
@@ -1503,48 +1136,35 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void tail_ff2_kernel(TailFf2Args 
 
 }  // namespace
 
-int launch_ff1_qkv_impl(const Ff1QkvArgs& a, hipStream_t s);
+// MI355ASR_FF1QKV_RING / MI355ASR_TAILFF2_RING / MI355ASR_OUTGLU_SPLIT = 0: the fp32-MFMA register-stream kernels (exact fp32
+// products on v_mfma_f32_16x16x4_f32; what a handle without slab streams runs anyway).  Otherwise, in order: the pair-pipelined
+// two-term fp16 kernels (fused_pp.hip; MI355ASR_PP=0 switches them off), then the round-2 loader-wave kernels on three bf16 terms.
+// (Rounds 1-2 also had per-wave-DMA ring kernels and a double-buffered out_glu: slower than both, deleted in round 4.)
+static bool env_on(const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; }
 int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
-  // MI355ASR_FF1QKV_RING: 1 (default) = split-bf16 MFMAs on the five-slot slab ring (54 us at 16 000 tokens),
-  // 0 = the fp32-MFMA register-stream kernel (69 us)
-  static const int ringk = [] { const char* v = getenv("MI355ASR_FF1QKV_RING"); return v ? atoi(v) : 2; }();
-  if (ringk == 2 && a.slabs) {     // 2 (default): loader-wave ring kernel; round 3: pair-pipelined (fused_pp.hip) unless MI355ASR_PP=0
+  static const bool ring = env_on("MI355ASR_FF1QKV_RING");
+  const int tiles = (a.M + 15) / 16;
+  if (ring && a.slabs) {
     if (launch_pp_ff1_qkv(a, s) == 0) return 0;
-    const int tiles = (a.M + 15) / 16;
     note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(ff1_qkv_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
     return 0;
   }
-  if (ringk && a.slabs) {
-    const int tiles = (a.M + 15) / 16;
-    note_scheme(SCHEME_BF16X3);
-    hipLaunchKernelGGL(ff1_qkv_ring_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
-    return 0;
-  }
-  return launch_ff1_qkv_impl(a, s);
-}
-int launch_ff1_qkv_impl(const Ff1QkvArgs& a, hipStream_t s) {
-  const int tiles = (a.M + 15) / 16;
   note_scheme(SCHEME_F32);
   hipLaunchKernelGGL(ff1_qkv_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
 }
 int launch_out_glu(const OutGluArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
-  // MI355ASR_OUTGLU_SPLIT: 0 = the fp32-MFMA register-stream kernel (26.6 us at 16 000 tokens); 1 = split-bf16 with
-  // double-buffered LDS slabs (28.4 us: a slab's MFMAs last 0.4-0.8 us, less than the latency of the one DMA in flight);
-  // 2 (default) = the same on the four-slot slab ring, three slabs of DMA in flight (23.3 us)
-  static const int split = [] { const char* v = getenv("MI355ASR_OUTGLU_SPLIT"); return v ? atoi(v) : 3; }();
-  if (a.og_slabs && split == 3 && launch_pp_out_glu(a, s) == 0) return 0;   // the two-term fp16 stream (fused_pp.hip)
-  note_scheme((a.og_slabs && (split == 3 || split == 2)) || (a.out_ws && a.pw1_ws && split == 1) ? SCHEME_BF16X3 : SCHEME_F32);
-  if (a.og_slabs && split == 3)     // 3 (default): loader-wave ring kernel
+  static const bool split = env_on("MI355ASR_OUTGLU_SPLIT");
+  if (a.og_slabs && split) {
+    if (launch_pp_out_glu(a, s) == 0) return 0;   // the two-term fp16 stream (fused_pp.hip)
+    note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(out_glu_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
-  else if (a.og_slabs && split == 2)
-    hipLaunchKernelGGL(out_glu_ring_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
-  else if (a.out_ws && a.pw1_ws && split == 1)
-    hipLaunchKernelGGL(out_glu_split_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
-  else
-    hipLaunchKernelGGL(out_glu_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
+    return 0;
+  }
+  note_scheme(SCHEME_F32);
+  hipLaunchKernelGGL(out_glu_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
 }
 // split-bf16 ring-DMA kernel for the subsampling Dense; ws = pack_split32 fragments padded to 1792 per step
@@ -1569,30 +1189,20 @@ int launch_head_ld(const GemmArgs& a, const float* slabs, int groups, hipStream_
 
 int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s) {
   if (a.NT != KB || a.K % 32 != 0 || a.M <= 0 || !ws) return -1;
-  // MI355ASR_SUBLINEAR_LD=0: every wave issues its own DMAs (round 1) instead of the loader-wave kernel
-  static const bool ld = [] { const char* v = getenv("MI355ASR_SUBLINEAR_LD"); return v ? atoi(v) != 0 : true; }();
   note_scheme(SCHEME_BF16X3);
-  if (ld)
-    hipLaunchKernelGGL(sublinear_split_ld_kernel, dim3((a.M + 63) / 64), dim3(2 * BLOCK_THREADS), 0, s, a,
-                       reinterpret_cast<const u32x4_t*>(ws));
-  else
-  hipLaunchKernelGGL(sublinear_split_kernel, dim3((a.M + 63) / 64), dim3(BLOCK_THREADS), 0, s, a,
+  hipLaunchKernelGGL(sublinear_split_ld_kernel, dim3((a.M + 63) / 64), dim3(2 * BLOCK_THREADS), 0, s, a,
                      reinterpret_cast<const u32x4_t*>(ws));
   return 0;
 }
 // the conv tail will run on the pair-pipelined kernels (fused_pp.hip): api.hip then folds the depthwise conv into them
 bool tail_pp_selected() {
-  static const bool ring2 = [] { const char* r = getenv("MI355ASR_TAILFF2_RING"); return !r || atoi(r) == 2; }();
-  return ring2 && pp_enabled();
+  static const bool ring = env_on("MI355ASR_TAILFF2_RING");
+  return ring && pp_enabled();
 }
 // tail of one block + ff1_qkv of the next in one launch; -1 when the loader-wave kernels are switched off
 bool tail_ff1_available() {
-  // MI355ASR_TAIL_FF1=0: separate tail_ff2 / ff1_qkv launches (also whenever one of the two is switched to an older kernel)
-  static const bool on = [] {
-    const char* v = getenv("MI355ASR_TAIL_FF1");
-    const char *r1 = getenv("MI355ASR_TAILFF2_RING"), *r2 = getenv("MI355ASR_FF1QKV_RING");
-    return (v ? atoi(v) != 0 : true) && (!r1 || atoi(r1) == 2) && (!r2 || atoi(r2) == 2);
-  }();
+  // MI355ASR_TAIL_FF1=0: separate tail_ff2 / ff1_qkv launches (also whenever one of the two is switched to the fp32 kernels)
+  static const bool on = env_on("MI355ASR_TAIL_FF1") && env_on("MI355ASR_TAILFF2_RING") && env_on("MI355ASR_FF1QKV_RING");
   return on;
 }
 int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s) {
@@ -1605,18 +1215,11 @@ int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s) {
 }
 int launch_tail_ff2(const TailFf2Args& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
-  // MI355ASR_TAILFF2_RING: 1 (default) = split-bf16 MFMAs on the five-slot slab ring (60 us at 16 000 tokens),
-  // 0 = the fp32-MFMA register-stream kernel (74 us)
-  static const int ringk = [] { const char* v = getenv("MI355ASR_TAILFF2_RING"); return v ? atoi(v) : 2; }();
-  if (ringk == 2 && a.slabs) {     // 2 (default): loader-wave ring kernel; round 3: pair-pipelined (fused_pp.hip) unless MI355ASR_PP=0
+  static const bool ring = env_on("MI355ASR_TAILFF2_RING");
+  if (ring && a.slabs) {
     if (launch_pp_tail_ff2(a, s) == 0) return 0;
     note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(tail_ff2_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
-    return 0;
-  }
-  if (ringk && a.slabs) {
-    note_scheme(SCHEME_BF16X3);
-    hipLaunchKernelGGL(tail_ff2_ring_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
     return 0;
   }
   note_scheme(SCHEME_F32);

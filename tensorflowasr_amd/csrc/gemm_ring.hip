@@ -589,8 +589,6 @@ static int launch_terms(int epi, bool ln, const Gemm16Args& a, const void* ring,
 int launch_gemm_ring(int epi, bool ln, const Gemm16Args& a, const void* ring, int terms, hipStream_t s) {
   if (!ring || !gemm_ring_applicable(epi, ln, a)) return -1;
   note_scheme(terms == 1 ? SCHEME_BF16 : SCHEME_BF16X3);
-  // MI355ASR_RING_EDMA=0: every wave issues its share of the slab DMAs (the first version) instead of the lower four
-  static const bool edma = [] { const char* v = getenv("MI355ASR_RING_EDMA"); return v ? atoi(v) != 0 : true; }();
-  if (edma) return terms == 1 ? launch_terms<1, true>(epi, ln, a, ring, s) : launch_terms<3, true>(epi, ln, a, ring, s);
-  return terms == 1 ? launch_terms<1, false>(epi, ln, a, ring, s) : launch_terms<3, false>(epi, ln, a, ring, s);
+  // (EDMA = true: only the lower four waves issue slab DMAs; the every-wave version of round 2 lost and its instantiations are gone)
+  return terms == 1 ? launch_terms<1, true>(epi, ln, a, ring, s) : launch_terms<3, true>(epi, ln, a, ring, s);
 }

@@ -43,7 +43,6 @@ struct Chain2Args {
   float scale;
   float eps;
   int M;
-  int dbg_wmul;        // 1 normally; 0 = (debug, wrong results) every weight batch re-reads batch 0: isolates the L2 weight stream
 };
 
 struct GemmArgs {
@@ -276,8 +275,7 @@ struct OutGluArgs {
   const float *out_wp, *out_b, *cv_ln_g, *cv_ln_b, *pw1_wp, *pw1_b;
   float eps;
   int M;
-  const float *out_ws = nullptr, *pw1_ws = nullptr;   // the same kernels as split-bf16 fragments [5][NT][3][64][8] (fused.hip)
-  const float* og_slabs = nullptr;                     // ... and as the slab stream of out_glu_ring_kernel (15 slabs of 1792 fragments)
+  const float* og_slabs = nullptr;                     // the same kernels as the three-term slab stream of out_glu_ld_kernel (15 slabs of 1792 fragments)
   // ... and as the two-term fp16 stream of pp_out_glu_kernel (fused_pp.hip: 15 ring slots -- out projection, pw_conv_1 value
   // tiles, gate tiles; biases in row 144), packed with these powers of two
   const float* pp_slabs = nullptr;

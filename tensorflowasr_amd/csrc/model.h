@@ -62,7 +62,7 @@ struct BlockDev {
   // block-final LayerNorm
   const float *ln_g, *ln_b;
   // out-projection / pw_conv_1 kernels as split-bf16 fragments (dmodel 144, Keras-layout MHA; fused.hip), or null
-  const float *out_ws = nullptr, *pw1_ws = nullptr, *og_slabs = nullptr, *ff1_slabs = nullptr, *tail_slabs = nullptr;
+  const float *og_slabs = nullptr, *ff1_slabs = nullptr, *tail_slabs = nullptr;
   // the pair-pipelined streams of fused_pp.hip (ff_module_1 + qkv ; conv tail + ff_module_2), or null
   const float *pp_ff1 = nullptr, *pp_tail = nullptr, *pp_og = nullptr;
   float att_h2[3] = {0.f, 0.f, 0.f};       // operand scales of the two-term attention kernel (0: no bound)
@@ -231,7 +231,7 @@ struct BlockOff {
   bool cross = false;
   size_t cv_ln_g, cv_ln_b, pw1_wp, pw1_b, dw_w, pc_w1p, pc_b1, bn_s, bn_t, pw2_wp, pw2_b;
   size_t ln_g, ln_b;
-  size_t out_ws = 0, pw1_ws = 0, og_slabs = 0, ff1_slabs = 0, tail_slabs = 0, pp_ff1 = 0, pp_tail = 0, pp_og = 0;
+  size_t og_slabs = 0, ff1_slabs = 0, tail_slabs = 0, pp_ff1 = 0, pp_tail = 0, pp_og = 0;
   float att_h2[3] = {0.f, 0.f, 0.f};
   float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
   PpChainSc pp_ff1_sc, pp_tail_sc[2];

@@ -356,7 +356,7 @@ DEV void frags_ninth(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, cons
 // TM = 3: bf16 terms (exact), six products; TM = 2: fp16 terms, three products (see split8h): a.w2h, conv1 scaled by a.h_scale
 // (folded into the staged conv1 kernel and bias: relu(s v) = s relu(v)), accumulators in units of h_scale * h_wscale.
 template <int DIAG, int DM, int NBW, int TM = 3>
-__global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, PatchGeom RS, int rows, int late_mode) {
+__global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, PatchGeom RS, int rows) {
   static_assert(TM == 3 || DIAG == 0, "the timing variants are those of the three-term kernel");
   constexpr int KB = DM / 16, NB = NBW, NI = ninth_steps(KB), NK32 = KB * NPAIR + NI, SLABF = NBW * TM * 64, D = DM;
   const int c0 = blockIdx.z * NBW;               // first output column tile of this workgroup
@@ -433,12 +433,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   }
   // which waves run MFMAs first: the SIMD partner of a wave must take the other order (see the step loop)
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const bool late = late_mode == 0 ? wv >= SCW / 2
-                  : late_mode == 1 ? (wv & 1) != 0
-                  : late_mode == 2 ? ((wv >> 1) & 1) != 0
-                  : late_mode == 4 ? false
-                  : late_mode == 5 ? true
-                                   : (__builtin_amdgcn_s_getreg(0x1804) & 1) != 0;   // HW_ID.wave_id: slot on the SIMD
+  const bool late = wv >= SCW / 2;     // (other pairings of early / late waves measured the same or worse: round 2)
   // the whole step loop once per order (compile-time LATE): with a run-time order inside one loop hipcc keeps both
   // paths' temporaries alive and spills (256 VGPRs + 232 bytes of scratch instead of 194)
   auto run = [&](auto LATE_T) {
@@ -609,24 +604,24 @@ int launch_subconv144(const SubConvArgs& a, hipStream_t s) {
 // split-bf16 kernel for dmodel 144 / 256 / 512; returns -1 when the shape does not fit its LDS mel patch or the dmodel has
 // no instantiation (the caller falls back)
 template <int DIAG>
-static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGeom RS, int rows, int late_mode, hipStream_t s) {
+static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGeom RS, int rows, hipStream_t s) {
   const dim3 g128(g144.x, g144.y, d / 128);
   note_scheme(SCHEME_BF16X3);
   if constexpr (DIAG == 0) {
     if (a.w2h) {
       note_scheme(SCHEME_F16X2);
       switch (d) {
-        case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2>), g144, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
-        case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 256, 8, 2>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
-        case 512: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 512, 8, 2>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+        case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2>), g144, dim3(SCT), 0, s, a, RS, rows); return 0;
+        case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 256, 8, 2>), g128, dim3(SCT), 0, s, a, RS, rows); return 0;
+        case 512: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 512, 8, 2>), g128, dim3(SCT), 0, s, a, RS, rows); return 0;
         default: return -1;
       }
     }
   }
   switch (d) {
-    case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 144, 9>), g144, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
-    case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 256, 8>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
-    case 512: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 512, 8>), g128, dim3(SCT), 0, s, a, RS, rows, late_mode); return 0;
+    case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 144, 9>), g144, dim3(SCT), 0, s, a, RS, rows); return 0;
+    case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 256, 8>), g128, dim3(SCT), 0, s, a, RS, rows); return 0;
+    case 512: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 512, 8>), g128, dim3(SCT), 0, s, a, RS, rows); return 0;
     default: return -1;
   }
 }
@@ -642,7 +637,6 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
   const int span = (SPOSG - 1 + a.F2 - 1) / a.F2;            // t2 steps a tile can touch beyond its first
   const int rows = 4 * span + 7;
   if ((!a.w2s && !a.w2h) || a.st1 != 2 || rows * RS.row > MELP || PU <= 0) return -1;
-  static const int late_mode = [] { const char* v = getenv("MI355ASR_SUBCONV_LATE"); return v ? atoi(v) : 0; }();
   const dim3 grid((PU + SPOSG - 1) / SPOSG, a.B);
 #ifdef MI355ASR_DIAG_KERNELS
   // timing-only variants (wrong results), compiled in with -DMI355ASR_DIAG_KERNELS: see the DIAG comment above
@@ -653,15 +647,15 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
     return d;
   }();
   switch (diag) {
-    case 1: return launch_split_d<1>(d, grid, a, RS, rows, late_mode, s);
-    case 2: return launch_split_d<2>(d, grid, a, RS, rows, late_mode, s);
-    case 3: return launch_split_d<3>(d, grid, a, RS, rows, late_mode, s);
-    case 4: return launch_split_d<4>(d, grid, a, RS, rows, late_mode, s);
-    case 5: return launch_split_d<5>(d, grid, a, RS, rows, late_mode, s);
-    case 6: return launch_split_d<6>(d, grid, a, RS, rows, late_mode, s);
-    case 7: return launch_split_d<7>(d, grid, a, RS, rows, late_mode, s);
+    case 1: return launch_split_d<1>(d, grid, a, RS, rows, s);
+    case 2: return launch_split_d<2>(d, grid, a, RS, rows, s);
+    case 3: return launch_split_d<3>(d, grid, a, RS, rows, s);
+    case 4: return launch_split_d<4>(d, grid, a, RS, rows, s);
+    case 5: return launch_split_d<5>(d, grid, a, RS, rows, s);
+    case 6: return launch_split_d<6>(d, grid, a, RS, rows, s);
+    case 7: return launch_split_d<7>(d, grid, a, RS, rows, s);
     default: break;
   }
 #endif
-  return launch_split_d<0>(d, grid, a, RS, rows, late_mode, s);
+  return launch_split_d<0>(d, grid, a, RS, rows, s);
 }

@@ -1547,8 +1547,9 @@ def test_add_wav_info_with_leaf_ctc_and_errors(torch_cuda):
 
 
 def test_opt_in_kernel_variants_in_a_subprocess(torch_cuda):
-    """Kernel choices that are read from the environment once per process: the split-bf16 / LDS-slab out_glu kernel
-    (MI355ASR_OUTGLU_SPLIT=1, off by default) and the fp32-MFMA subsampling kernel (MI355ASR_SUBCONV_F32=1), with the
+    """Every kernel-choice switch that survives round 4's pruning (tests/test_host.py::test_environment_switches_...
+    lists them; the library reads each once per process): the fp32-MFMA fallbacks, the three-term bf16 versions of the kernels
+    that default to two fp16 terms, and the structural fallbacks (separate launches instead of folded prologues), with the
     fused block path forced for a small batch (MI355ASR_SMALL_M=0).  Each must agree with the oracle like the defaults."""
     import subprocess
     import sys
@@ -1567,12 +1568,13 @@ wav = waves(2, 16000, 11)
 enc = maxdiff(e(wav).cpu().numpy(), co.conformer_encoder(wav.astype(np.float64), w, cfg))
 print("RESULT %.3e %.3e" % (blk, enc))
 '''
-    for extra in ({"MI355ASR_OUTGLU_SPLIT": "1"}, {"MI355ASR_OUTGLU_SPLIT": "0"}, {"MI355ASR_SUBCONV_F32": "1"},
+    for extra in ({"MI355ASR_OUTGLU_SPLIT": "0"}, {"MI355ASR_SUBCONV_F32": "1"},
                   {"MI355ASR_SUBLINEAR_SPLIT": "2"}, {"MI355ASR_SUBLINEAR_SPLIT": "0"},
-                  {"MI355ASR_SUBLINEAR_SPLIT": "2", "MI355ASR_SUBLINEAR_LD": "0"}, {"MI355ASR_MEL_BAND": "0"},
-                  {"MI355ASR_FF1QKV_RING": "0"},
+                  {"MI355ASR_SUBLINEAR_SPLIT": "2", "MI355ASR_PP_SUBLINEAR": "0"}, {"MI355ASR_MEL_BAND": "0"},
+                  {"MI355ASR_FF1QKV_RING": "0"}, {"MI355ASR_HEAD_RING": "0"}, {"MI355ASR_FUSED": "0"},
                   {"MI355ASR_TAILFF2_RING": "0"}, {"MI355ASR_PP": "0"}, {"MI355ASR_PP": "0", "MI355ASR_TAIL_FF1": "0"},
-                  {"MI355ASR_TAIL_FF1": "0"},
+                  {"MI355ASR_TAIL_FF1": "0"}, {"MI355ASR_PP_DW": "0"}, {"MI355ASR_PP_OGF": "0"}, {"MI355ASR_PP_HEAD": "0"},
+                  {"MI355ASR_ATTN_SPLIT": "0"}, {"MI355ASR_ATTN_LDS": "0"}, {"MI355ASR_FFT_SPLIT": "0"}, {"MI355ASR_FFT": "0"},
                   # the three-term bf16 versions of the kernels that default to the two-term fp16 scheme
                   {"MI355ASR_SUBCONV_TERMS": "3"}, {"MI355ASR_ATTN_TERMS": "3"}, {"MI355ASR_PP_OUTGLU": "0"}, {"MI355ASR_FFT_TERMS": "3"},
                   {"MI355ASR_SUBCONV_TERMS": "3", "MI355ASR_ATTN_TERMS": "3", "MI355ASR_PP": "0"}):

@@ -902,3 +902,62 @@ def test_two_term_fp16_scheme_is_as_close_to_fp64_as_the_six_product_bf16_scheme
     e32 = np.abs((x @ W).astype(np.float64) - ref).max()
     assert e6 < 4e-7 and e3 < 4e-7 and e3 < 1.5 * e6 + 1e-8
     assert e32 > 3 * e3 and e1 > 3 * e3
+
+
+# the environment switches the library reads (each once per process), what each selects, and the test that runs it.
+# Round 3 ended with 41, many of them losers of finished experiments; round 4 deleted those together with their kernels.
+SWITCHES = {
+    # arithmetic: two fp16 terms (default where a bound or a row maximum is available) -> three exact bf16 terms -> fp32 MFMA
+    "MI355ASR_PP": "0: the round-2 loader-wave kernels on three bf16 terms instead of the pair-pipelined two-term ones | test_opt_in_kernel_variants, bench.py exact_products",
+    "MI355ASR_PP_OUTGLU": "0: three-term out_glu_ld_kernel | test_opt_in_kernel_variants, test_two_term_fp16_block_and_attention_under_adversarial_operand_bounds",
+    "MI355ASR_PP_HEAD": "0: three-term head_ld_kernel | test_opt_in_kernel_variants",
+    "MI355ASR_PP_SUBLINEAR": "0: three-term sublinear_split_ld_kernel | test_opt_in_kernel_variants",
+    "MI355ASR_SUBCONV_TERMS": "3: three-term subsampling conv; 22: two-term also for caller-supplied features | test_two_term_fp16_subsampling_conv_...",
+    "MI355ASR_ATTN_TERMS": "3: three-term attention_split_kernel | test_opt_in_kernel_variants, adversarial test",
+    "MI355ASR_FFT_TERMS": "3: three-term STFT | test_opt_in_kernel_variants",
+    "MI355ASR_LEAF_TERMS": "0: fp32 LEAF Gabor convolution | test_leaf_*",
+    "MI355ASR_SUBCONV_F32": "1: fp32-MFMA subsampling conv | test_opt_in_kernel_variants",
+    "MI355ASR_SUBLINEAR_SPLIT": "0: fp32 subsampling Dense; 2: split kernels for any row count | test_opt_in_kernel_variants",
+    "MI355ASR_FF1QKV_RING": "0: fp32-MFMA ff1_qkv_kernel | test_opt_in_kernel_variants",
+    "MI355ASR_TAILFF2_RING": "0: fp32-MFMA tail_ff2_kernel | test_opt_in_kernel_variants",
+    "MI355ASR_OUTGLU_SPLIT": "0: fp32-MFMA out_glu_kernel | test_opt_in_kernel_variants",
+    "MI355ASR_HEAD_RING": "0: fp32-MFMA class head | test_opt_in_kernel_variants",
+    "MI355ASR_ATTN_SPLIT": "0: fp32-MFMA attention_lds_kernel | test_opt_in_kernel_variants",
+    "MI355ASR_ATTN_LDS": "0: online-softmax attention_kernel (K / V from L2) | test_opt_in_kernel_variants",
+    "MI355ASR_FFT_SPLIT": "0: fp32-MFMA Cooley-Tukey STFT | test_opt_in_kernel_variants",
+    "MI355ASR_FFT": "0: dense DFT GEMM | test_opt_in_kernel_variants",
+    "MI355ASR_MEL_BAND": "0: dense mel GEMM | test_opt_in_kernel_variants",
+    # structure: what is folded into which launch
+    "MI355ASR_FUSED": "0: one launch per layer (dmodel 144) | test_opt_in_kernel_variants",
+    "MI355ASR_TAIL_FF1": "0: tail_ff2 and the next block's ff1_qkv as separate launches | test_opt_in_kernel_variants",
+    "MI355ASR_PP_DW": "0: depthwise conv as its own launch | test_opt_in_kernel_variants",
+    "MI355ASR_PP_OGF": "0: out-projection + GLU as its own launch | test_block_as_two_launches_equals_the_three_launch_path_bit_for_bit",
+    "MI355ASR_GEMM16": "1: layer-at-a-time gemm16 kernels for every row count | test_bf16 / gemm16 tests",
+    "MI355ASR_GEMM_RING": "0: dmodel 256 / 512 without the slab-ring GEMMs | test_ring_gemm_at_16000_rows_...",
+    "MI355ASR_SMALL_M": "rows up to which the layer-at-a-time kernels run (default 48) | test_fused_block_path_at_short_utterances",
+    "MI355ASR_RING_MIN_M": "rows from which gemm_ring runs | ring tests",
+    "MI355ASR_RING_RT": "forces the ring GEMM's row tiles per wave (tests) | ring tests",
+    "MI355ASR_RING_SLOTS": "forces the ring depth (tests) | ring tests",
+    "MI355ASR_RING_CPW": "forces column chunks per workgroup (tests) | ring tests",
+    "MI355ASR_TOPN_REG": "0: LDS top-n kernel instead of the register-resident one | test_prefix_beam_topn_*",
+    "MI355ASR_BEAM_DEVICE": "0: prefix search on host threads | test_prefix_beam_device_path_matches_reference_kats",
+    # diagnostics (timing-only kernels need -DMI355ASR_DIAG_KERNELS; results are wrong by construction)
+    "MI355ASR_BEAM_PROF": "1: clock counters of the device search | tools/r03_beamprof.py",
+    "MI355ASR_PP_DIAG": "timing-only variants of pp_block_kernel (diag build) | profiles/r03_pp_experiments.md",
+    "MI355ASR_SUBCONV_DIAG": "timing-only variants of the subsampling kernel (diag build) | profiles/r03_pp_experiments.md",
+    "MI355ASR_HEAD_NOSTORE": "class head without its logit stores (diag build) | profiles",
+}
+
+
+def test_environment_switches_are_the_documented_ones():
+    """no switch without a line in SWITCHES (and in DESIGN.md), no line without a switch: the switchboard cannot grow silently"""
+    csrc = os.path.join(ROOT, "tensorflowasr_amd", "csrc")
+    found = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".inc")):
+            found |= set(re.findall(r'(?:getenv|env_on)\("(MI355ASR_[A-Z0-9_]+)"', open(os.path.join(csrc, f)).read()))
+    assert found == set(SWITCHES), (sorted(found - set(SWITCHES)), sorted(set(SWITCHES) - found))
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    missing = [k for k in SWITCHES if k not in design]
+    assert not missing, missing
+
