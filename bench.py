@@ -346,6 +346,10 @@ def extra_config5(lib, device, steps=5, with_cpu=True):
           "out_glu": (nb["enc"] + nb["pick"]) * 3 * 2.0 * M * d * d + (nb["help"] + nb["dec"]) * 3 * 2.0 * Mp * d * d,
           "ctc_head": 2.0 * M * d * Vp + 2.0 * Mp * d * Vt, "subconv": 2.0 * B * 1501 * 40 * d * 9 + 2.0 * M * 20 * d * 9 * d,
           "sublinear": 2.0 * M * 20 * d * d}
+    if "out_glu" not in prof:        # round 4: out-projection + GLU run in the prologue of the tail kernels
+        og = lambda rows: 3 * 2.0 * rows * d * d
+        fl["tail_ff1"] += (nb["enc"] - 1 + nb["pick"] - 1) * og(M) + (nb["help"] - 1 + nb["dec"] - 1) * og(Mp)
+        fl["tail_ff2"] += 2 * og(M) + 2 * og(Mp)
     wf = {k: (mc[n]["win_front"] + mc[n]["win_back"] + 1) for k, n in (("enc", "ChunkConformerEncoder"), ("pick", "ChunkCTCPicker"),
                                                                        ("help", "ContextHelper"), ("dec", "ChunkCTCDecoder"))}
     # band attention (chunk_conformer_blocks.py:158-176): a query sees win_front + win_back + 1 keys

@@ -191,7 +191,7 @@ float f16_to_float(uint16_t h) {
 // largest power of two s with bound * s <= 2^15 (fp16's largest finite value is 65504: a factor of two to spare)
 // max_shift: kernels that multiply two or three such scales in fp32 (attention: sq * sk, probabilities * sv) pass 40 and get
 // 0 = "no usable bound" (the three-term kernel runs) for degenerate weights instead of a product that overflows to inf
-float half_scale_for(double bound, int max_shift = 100) {
+float half_scale_for(double bound, int max_shift) {
   if (!(bound > 0.0) || !std::isfinite(bound)) return 0.f;
   int e; std::frexp(bound, &e);                                       // bound = f 2^e, f in [0.5, 1)
   const int k = 15 - e;
@@ -403,6 +403,7 @@ int launch_mel_auto(const mi355asr_model* m, MelArgs& me, hipStream_t s) {
     me.band = m->mel_band; me.bw = m->mel_bw; me.BW = m->mel_BW;
     if (launch_mel_band(me, s) == 0) return 0;
   }
+  me.absmax = nullptr;          // the dense kernel does not produce the run-time maximum: the caller must not rely on it
   return launch_mel(me, s);
 }
 
@@ -1542,7 +1543,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   ArenaBuilder ab;
   ab.ring_terms = m->cfg.gemm_dtype == 1 ? 1 : 3;
   size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0, o_c2h = 0, o_lpp = 0;
-  float lin_pp_sw = 1.f;
+  float lin_pp_sw = 1.f, c1_l1 = 0.f, c1_bmax = 0.f;
   float c2_hs = 0.f, c2_ws = 0.f;
   FftOff fo;
   MelBandOff mbo;
@@ -1659,12 +1660,16 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
       }
       const auto& w1 = m->host["conv_subsampling/conv1/kernel"].data;
       const auto& b1 = m->host["conv_subsampling/conv1/bias"].data;
-      double bx = 0.0, wmax = 0.0;
+      double bx = 0.0, wmax = 0.0, l1max = 0.0, bmax = 0.0;
       for (int ch = 0; ch < d; ++ch) {
         double sum = 0.0;
         for (int t = 0; t < 9; ++t) sum += std::fabs((double)w1[(size_t)t * d + ch]);
         bx = std::max(bx, std::fabs((double)b1[ch]) + mb * sum);
+        l1max = std::max(l1max, sum);
+        bmax = std::max(bmax, std::fabs((double)b1[ch]));
       }
+      c1_l1 = (float)(l1max * (1.0 + 1e-6));
+      c1_bmax = (float)(bmax * (1.0 + 1e-6));
       for (float v : c2) wmax = std::max(wmax, std::fabs((double)v));
       c2_hs = half_scale_for(bx);
       c2_ws = half_scale_for(wmax);
@@ -1753,6 +1758,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = ((d == 144 || d == 256 || d == 512) && c.has_encoder) ? base + o_c2s : nullptr;
   m->c2_whalf = o_c2h ? base + o_c2h : nullptr; m->c2_hscale = c2_hs; m->c2_wscale = c2_ws;
+  m->c1_l1 = c1_l1; m->c1_bmax = c1_bmax;
   m->lin_wsplit = (d == 144 && c.has_encoder) ? base + o_lws : nullptr;
   m->lin_pp = (d == 144 && c.has_encoder) ? base + o_lpp : nullptr;
   m->lin_pp_sw = lin_pp_sw;

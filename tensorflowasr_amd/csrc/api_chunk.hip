@@ -162,6 +162,37 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   const bool split_front = d == 144 && c.gemm_dtype == 0;
   const size_t o_c2s = split_front ? ab.put(pack_conv2_split(c2, d)) : 0;
   const size_t o_lws = split_front && (dm.F2 * d) % 32 == 0 ? ab.put(pack_linear_split(lin, dm.F2 * d, d)) : 0;
+  // round 4: the two-term fp16 forms -- conv2 as hi + lo of kernel * 2^k (its operand scale comes from the batch's largest |mel|
+  // at run time: the valid frontend's log10 features have no static bound), the Dense as the stream of pp_sublinear_kernel
+  size_t o_c2h = 0, o_lpp = 0;
+  float c2_ws = 0.f, c1_l1 = 0.f, c1_bmax = 0.f, lin_pp_sw = 1.f;
+  if (split_front) {
+    const auto& w1 = m->host["front/conv_subsampling/conv1/kernel"].data;
+    const auto& b1 = m->host["front/conv_subsampling/conv1/bias"].data;
+    double wmax = 0.0, l1max = 0.0, bmax = 0.0;
+    for (int ch = 0; ch < d; ++ch) {
+      double sum = 0.0;
+      for (int t = 0; t < 9; ++t) sum += std::fabs((double)w1[(size_t)t * d + ch]);
+      l1max = std::max(l1max, sum);
+      bmax = std::max(bmax, std::fabs((double)b1[ch]));
+    }
+    for (float v : c2) wmax = std::max(wmax, std::fabs((double)v));
+    c2_ws = half_scale_for(wmax);
+    if (c2_ws > 0.f && l1max > 0.0) {
+      o_c2h = ab.put(pack_conv2_half(c2, d, c2_ws));
+      c1_l1 = (float)(l1max * (1.0 + 1e-6));
+      c1_bmax = (float)(bmax * (1.0 + 1e-6));
+    }
+    if (o_lws) {
+      const auto& lb = m->host["front/conv_subsampling/linear/bias"].data;
+      std::vector<float> pp;
+      lin_pp_sw = append_pp_plain(pp, [&](int k, int n) {
+        const int f = n / d, col = n - f * d;
+        return k < d ? lin[((size_t)f * d + k) * d + col] : (f == 0 ? lb[col] : 0.f);
+      }, dm.F2);
+      o_lpp = ab.put(pp);
+    }
+  }
   StackOff e = pack_stack(m, ab, "encoder", "chunk_conformer_block_", cc.enc_num_blocks, false, 0);
   StackOff pk = pack_stack(m, ab, "picker", "block_", cc.picker_num_blocks, true, cc.picker_num_classes);
   StackOff hp = pack_stack(m, ab, "helper", "block_", cc.helper_num_blocks, false, 0);
@@ -184,6 +215,8 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->c2_wsplit = o_c2s ? base + o_c2s : nullptr;
   m->lin_wsplit = o_lws ? base + o_lws : nullptr;
+  m->c2_whalf = o_c2h ? base + o_c2h : nullptr; m->c2_wscale = c2_ws; m->c1_l1 = c1_l1; m->c1_bmax = c1_bmax;
+  m->lin_pp = o_lpp ? base + o_lpp : nullptr; m->lin_pp_sw = lin_pp_sw;
   resolve_stack(m->c_enc, e, base, false, 0);
   resolve_stack(m->c_picker, pk, base, true, cc.picker_num_classes);
   resolve_stack(m->c_helper, hp, base, false, 0);
@@ -418,10 +451,16 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     me.logp = st.logp; me.umax = nullptr; me.mel = (float*)(ws + p.mel); me.wp = m->mel_wp;
     me.B = B; me.F = g.F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
     me.NM = c.n_mels; me.FT = FT; me.floor_db = 0.f;
+    // round 4: the valid frontend's log10 features have no static bound; the banded mel kernel leaves the batch's largest
+    // |mel| in the first word of the (by now consumed) per-frame maxima, and the two-term subsampling conv scales by it
+    unsigned* melmax = (m->mel_band && m->c2_whalf && m->c1_l1 > 0.f) ? (unsigned*)(ws + p.pmax) : nullptr;
+    if (melmax) { HIP_TRY(hipMemsetAsync(melmax, 0, sizeof(unsigned), s)); me.absmax = melmax; }
     { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel_auto(m, me, s), "mel (valid)"); }
     SubConvArgs sa{};
     sa.mel = me.mel; sa.out = (float*)(ws + p.sub); sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
     sa.w2s = m->c2_wsplit;
+    static const bool three = [] { const char* v = getenv("MI355ASR_SUBCONV_TERMS"); return v && atoi(v) == 3; }();
+    if (melmax && me.absmax && !three) { sa.w2h = m->c2_whalf; sa.h_wscale = m->c2_wscale; sa.h_melmax = melmax; sa.h_l1 = m->c1_l1; sa.h_bmax = m->c1_bmax; }
     sa.B = B; sa.F = g.F; sa.NM = c.n_mels; sa.T1 = g.T1; sa.F1 = m->dm.F1; sa.T2 = T; sa.F2 = m->dm.F2;
     sa.st1 = 2; sa.pt1 = 4; sa.pf1 = 2; sa.pt2 = 0; sa.pf2 = 0;
     { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling (valid)"); }

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void mel_band_kernel(MelArgs a) {
     if ((int)threadIdx.x + 256 * u < wtotal) reinterpret_cast<f32x4*>(wl)[threadIdx.x + 256 * u] = ww[u];
   if (threadIdx.x < 2 * NM) bl[threadIdx.x] = bnd;
   __syncthreads();
+  float amax = 0.f;
   for (int o = threadIdx.x; o < nf * NM; o += 256) {
     const int fr = o / NM, m = o - fr * NM;
     const int lo = bl[2 * m], len4 = (bl[2 * m + 1] + 3) & ~3;     // weights are zero-padded to BW, rows to RS >= lo + BW
@@ -232,6 +233,21 @@ __global__ __launch_bounds__(256) void mel_band_kernel(MelArgs a) {
       acc = __builtin_fmaf(x[j + 3], w4.w, acc);
     }
     a.mel[((size_t)b * a.F + f0 + fr) * NM + m] = acc;
+    amax = fmaxf(amax, fabsf(acc));
+  }
+  if (a.absmax) {
+    // |x| >= 0, so the float order is the order of the bit patterns.  One candidate per workgroup, and an atomic only when it
+    // beats what is already there (a plain read of the word first): thousands of workgroups hammering one address with
+    // atomicMax cost 115 us of a 35 us kernel
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned mine = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+      if (mine > __hip_atomic_load(a.absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.absmax, mine);
+    }
   }
 }
 int launch_mel_band(const MelArgs& a, hipStream_t s) {

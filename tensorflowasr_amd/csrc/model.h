@@ -137,6 +137,7 @@ struct mi355asr_model {
   const float* c2_wsplit = nullptr;     // conv2 kernel as split-bf16 fragments (subconv.hip; dmodel 144 / 256 / 512)
   const float* c2_whalf = nullptr;      // ... as two fp16 terms of kernel * c2_wscale (two-term scheme), conv1 values times c2_hscale
   float c2_hscale = 0.f, c2_wscale = 0.f;
+  float c1_l1 = 0.f, c1_bmax = 0.f;     // largest L1 norm of a conv1 filter / largest |bias|: the run-time operand bound of the chunk front
   const float* leaf_wsplit = nullptr;   // Gabor filters as split-bf16 MFMA fragments (leaf.hip)
   int leaf_terms = 3;                   // bf16 terms per fp32 operand in the Gabor conv (0: fp32 MFMA kernel)
   // add_wav_info: WavePickModel weights (conv kernels P16-packed with K = k * Cin)
@@ -275,6 +276,8 @@ std::vector<float> pack_p16(const std::function<float(int, int)>& f, int K, int 
 std::vector<float> pack_split32(const std::function<float(int, int)>& f, int K, int N);
 std::vector<float> pack_conv2_split(const std::vector<float>& c2, int d);          // conv2 kernel -> subconv_split_ring_kernel fragments
 std::vector<float> pack_linear_split(const std::vector<float>& lin, int K, int d);  // subsampling Dense -> sublinear_split_kernel slabs
+float half_scale_for(double bound, int max_shift = 100);                            // largest power of two s with bound * s <= 2^15 (0: no usable bound)
+std::vector<float> pack_conv2_half(const std::vector<float>& c2, int d, float wscale);   // conv2 kernel * wscale as hi + lo fp16 fragments (two-term scheme)
 void append_slabs(std::vector<float>& stream, const std::function<float(int, int)>& f, int K, int N, bool group_major);
 // pair-pipelined stream of one chain y += W2 act(W1 x + b1) (fused_pp.hip, tools/gen_pp.py): w1(k, n) with k <= K1 (row K1 = the
 // bias), H hidden features, w2(k, n) [H, 144]; and of a plain layer [145, 144 G] in column groups of nine tiles

@@ -799,6 +799,23 @@ def test_chunk_conformer_predict_stage_parity(torch_cuda, L):
     assert np.array_equal(logits.cpu().numpy(), got["text_logits"].cpu().numpy())      # deterministic
 
 
+@pytest.mark.parametrize("amp", [1.0, 1e-3, 40.0])
+def test_chunk_front_two_term_conv_scales_by_the_batch_maximum(torch_cuda, amp):
+    """The valid ChunkConformer frontend has no dB normalisation: its log10 features have no static bound, so the two-term
+    subsampling conv (round 4) takes its operand scale from the batch's largest |mel|, left by the banded mel kernel as a float
+    bit pattern (atomicMax).  Waveforms of three amplitudes -- log10 power shifts by -6 / +3.2 -- one silent utterance in
+    the batch (its features sit at log10(amin), far from the maximum the scale follows): the front output against the oracle."""
+    cfg = dict(co.CHUNK_S, enc_num_blocks=1, decoder_num_classes=300)
+    w = co.chunk_weights(cfg, seed=6)
+    x = (waves(4, 48000, 70) * np.float32(amp)).astype(np.float32)
+    x[2] = 0.0
+    ref = co.chunk_predict(x.astype(np.float64), w, cfg)
+    got = _chunk_model(cfg, w).predict(x, stages=True)
+    e = maxdiff(got["front"].cpu().numpy(), ref["front"])
+    print("chunk front, amplitude %g: max|d| %.3g of max|ref| %.3g" % (amp, e, np.abs(ref["front"]).max()))
+    assert e < TOL * max(1.0, float(np.abs(ref["front"]).max()) / 50.0)
+
+
 def test_chunk_band_attention_matches_keras_mask_semantics(torch_cuda):
     """win_back > 0 (text decoder, 36/8) at a length that is not a multiple of 16 and shorter than the window."""
     cfg = dict(co.CHUNK_S, enc_num_blocks=1, decoder_num_classes=64, enc_win_front=5, enc_win_back=3,
