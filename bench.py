@@ -507,6 +507,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip BASELINE configs 3 (streaming, bf16) and 5 (ChunkConformer + prefix beam) after the headline region")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the exact-product (three-term) comparison run")
+    ap.add_argument("--no-latency-b1", action="store_true", help="skip the one-utterance latency measurement (kernel traces of the headline shape)")
     ap.add_argument("--exact-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-kernel HIP events in the timed region (roofline fields become null)")
@@ -742,7 +743,7 @@ def main():
         }
         if os.environ.get("MI355ASR_BENCH_DEBUG_NO_GATHER") == "1":
             line["debug_no_gather"] = True       # the id exchange was removed from the timed step: not a data-parallel measurement
-        if world == 1:
+        if world == 1 and not args.no_latency_b1:
             # what a test_asr.py user sees: ONE utterance per call (test_asr.py:186-219), waveform -> greedy ids, resident input
             one = wav[:1].contiguous()
             model.prepare(1, L)

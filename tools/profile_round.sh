@@ -8,7 +8,7 @@ set -u
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra-configs --no-h2d --no-exact-leg"
+BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra-configs --no-h2d --no-exact-leg --no-latency-b1"
 O=$R/gpurun_out
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -- $BENCH > $O/prof_${TAG}_stats.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_${TAG}_fetch -- $BENCH > $O/prof_${TAG}_fetch.log 2>&1
