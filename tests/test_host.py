@@ -777,6 +777,37 @@ def test_profile_artifacts_and_kernel_categories(tag, dom, dom_kernel):
     assert abs(t - bench["kernels"][dom]["avg_ms"] * 1e3) / t < 0.15      # rocprof and HIP events agree
 
 
+def test_round4_profile_artifacts_bench_line_and_library_reported_schemes():
+    """profiles/r04_*: the block is attention + ONE pair-pipelined launch (no out_glu, no dwconv category left), every kernel of
+    the trace has a category, the bench line carries roofline / cpu_baseline / exact_products / latency_b1 and, per kernel, the
+    operand scheme the LIBRARY reported; rocprofv3 and the HIP events agree on the dominant kernel."""
+    import csv
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from summarize_rocprof import category
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_kernel_stats.csv"))))
+    cats = {category(r["Name"]) for r in rows}
+    assert {"stft", "mel", "subconv", "sublinear", "ff1_qkv", "attention", "tail_ff1", "tail_ff2", "ctc_head", "collapse"} <= cats
+    assert "out_glu" not in cats and "dwconv" not in cats
+    assert cats <= set(_lib.KERNEL_NAMES), cats - set(_lib.KERNEL_NAMES)
+    calls = {category(r["Name"]): int(r["Calls"]) for r in rows}
+    steps = calls["subconv"]
+    assert calls["attention"] == 14 * steps and calls["tail_ff1"] == 12 * steps and calls["tail_ff2"] == 2 * steps and calls["ff1_qkv"] == 2 * steps
+    bench = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")).read().strip().splitlines()[-1])
+    assert bench["unit"] == "audio-frames/s" and bench["n_gpus"] == 1 and bench["dtype"] == "f32" and bench["ms_per_step"] < 2.1
+    assert set(bench["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"} and bench["roofline"]["kernel"] == "tail_ff1"
+    assert set(bench["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    ex = bench["exact_products"]
+    assert ex["ms_per_step"] > bench["ms_per_step"] and ex["max_abs_logit_diff_vs_default"] < 1e-3
+    assert set(ex["schemes"].values()) <= {"f32", "bf16x3"} and "bf16x3" in ex["schemes"].values()      # no two-term kernel in that leg
+    assert bench["latency_b1"]["ms"] < 1.3
+    sch = {k: v["scheme"] for k, v in bench["kernels"].items()}
+    assert sch["tail_ff1"] == sch["attention"] == sch["subconv"] == sch["sublinear"] == sch["stft"] == sch["ctc_head"] == "f16x2"
+    assert bench["config3"]["ms_per_step"] < 1.4 and bench["config5"]["ms_predict"] < 2.7
+    t = next(float(r["AverageNs"]) / 1e3 for r in rows if category(r["Name"]) == "tail_ff1")
+    assert abs(t - bench["kernels"]["tail_ff1"]["avg_ms"] * 1e3) / t < 0.15
+
+
 def test_pair_pipelined_stream_generator_simulates_and_matches_the_committed_sources():
     """tools/gen_pp.py describes the pair-pipelined fragment stream of fused_pp.hip once; its simulator replays every unit
     (fragment reads into pool slots, counted lgkmcnt waits, MFMAs, ring-slot hand-overs) and the committed device code
