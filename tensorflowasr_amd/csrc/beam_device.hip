@@ -36,11 +36,12 @@
 
 namespace {
 
-constexpr int NT = 256;          // threads per utterance
+constexpr int NT = 256;          // threads per utterance: beams up to SMALL_BEAM (the one-key-per-thread path)
+constexpr int NTW = 512;         // ... wider beams (round 4): eight waves walk the (entry, candidate) keys of the radix path, two per SIMD
 constexpr int BMAX = 128;        // beam entries
 constexpr int NMAX = 40;         // candidates per frame (cutoff_top_n)
 constexpr int HASH = 1024;       // cells of the parent hash
-static_assert(HASH == 4 * NT && 4 * BMAX <= HASH, "four cells per thread to clear; the set stays sparse");
+static_assert(HASH == 4 * NT && 4 * BMAX <= HASH, "one int4 of cells per thread of the first four waves to clear; the set stays sparse");
 constexpr int SMALL_BEAM = 16;
 __host__ __device__ constexpr int tab_stride(int V) { return (V + 15) & ~15; }   // bytes of one class table   // widest beam of the one-key-per-thread kernel
 constexpr float kNegInf = -FLT_MAX;
@@ -114,8 +115,9 @@ struct Beam {
   float score[BMAX], b[BMAX], nb[BMAX];
 };
 
-// block-wide exclusive scan of one int per thread (NT = 256 = 4 waves); returns the exclusive prefix, *total = sum.
+// block-wide exclusive scan of one int per thread (NW waves); returns the exclusive prefix, *total = sum.
 // One barrier: callers alternate `wave_tot` buffers (or have another barrier before the same one is written again).
+template <int NW>
 __device__ __forceinline__ int block_scan(int v, int* wave_tot, int* total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int inc = v;
@@ -128,7 +130,7 @@ __device__ __forceinline__ int block_scan(int v, int* wave_tot, int* total) {
   __syncthreads();
   int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < NT / 64; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const int t = wave_tot[w];
     if (w < wv) base += t;
     tot += t;
@@ -153,7 +155,7 @@ struct Shared {
   float cb[BMAX], cnb[BMAX], cscore[BMAX];
   Cands cands[2];
   int hist[2][256];
-  int wave_tot[4][NT / 64];
+  int wave_tot[4][NTW / 64];
   int digit, need, done, thr_ok;
   float max_score;
   u64 diff, kmin[2];
@@ -221,7 +223,7 @@ __device__ __forceinline__ float key_score(u64 key) {             // inverse of 
 // by one thread each.  Ends with a barrier; returns the size of the next beam.
 constexpr unsigned kNegHi = 0xFF7FFFFFu;   // first key word of a score of -FLT_MAX: ~(~bits(-FLT_MAX))
 struct RadixProf { long long keys, select, install; };
-template <int JPT>                         // entries per wave: nbm <= 4 * JPT
+template <int JPT, int NW>                 // entries per wave, waves: nbm <= NW * JPT
 __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx, const Cands& K, const u64* exist, int nbm,
                                             int beam, int t, int2* arena, const Lookup& L, bool profiling, RadixProf& rp) {
   const int tid = threadIdx.x, k = tid & 63, w = tid >> 6;
@@ -239,16 +241,16 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
     counts += 1 + (((unsigned)(ekey >> 32) != kNegHi) << 16);
     kmin = ekey;
   }
-  // what depends on the entry: lane l fetches entry w + 4 l's words once, each use is a v_readlane (scalar operand) --
+  // what depends on the entry: lane l fetches entry w + NW l's words once, each use is a v_readlane (scalar operand) --
   // no LDS latency inside the loop over the wave's entries
   static_assert(JPT <= 64, "one lane per entry of the wave");
-  const int jl = min(w + 4 * k, nbm - 1);
+  const int jl = min(w + NW * k, nbm - 1);
   const u64 ex_l = exist[jl];
   const int ch_l = C.ch[jl];
   const float b_l = C.b[jl], s_l = C.score[jl];
 #pragma unroll
   for (int g = 0; g < JPT; ++g) {
-    const int j = w + 4 * g;
+    const int j = w + NW * g;
     u64 key = ~0ull;
     if (j < nbm) {                          // wave-uniform
       const u64 ex = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(ex_l >> 32), g) << 32) | (unsigned)__builtin_amdgcn_readlane((int)ex_l, g);
@@ -272,7 +274,7 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
   if (tid == 0) { sh.diff = 0; }
   if (k == 0) atomicMin(&sh.kmin[t & 1], kmin);
   int Mc;
-  block_scan(counts, sh.wave_tot[3], &Mc);  // its barrier also publishes diff = 0 and the best key
+  block_scan<NW>(counts, sh.wave_tot[3], &Mc);  // its barrier also publishes diff = 0 and the best key
   const int M = Mc & 0xffff, Mfin = Mc >> 16;
   if (profiling) { const long long cc = clock64(); rp.keys += cc - c0; c0 = cc; }
   u64 thr = ~0ull - 1;                      // M <= beam: every valid key (invalid ones are ~0)
@@ -301,11 +303,11 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
       for (int i = 0; i < JPT; ++i)
         if (ck[i] != ~0ull && ((ck[i] ^ pre) & hi_mask) == 0) atomicAdd(&sh.hist[hb][(int)((unsigned)(ck[i] >> shift) & dmask)], 1);
       __syncthreads();
-      const int h = sh.hist[hb][tid];
-      sh.hist[hb][tid] = 0;                 // clean for the pass after the next (and for the next frame)
+      const int h = tid < 256 ? sh.hist[hb][tid] : 0;     // 256 bins; the threads beyond scan zeros
+      if (tid < 256) sh.hist[hb][tid] = 0;  // clean for the pass after the next (and for the next frame)
       int tot;
-      const int ex = block_scan(h, sh.wave_tot[hb], &tot);
-      if (ex < need && need <= ex + h) {    // the bin that holds the need-th smallest key in play
+      const int ex = block_scan<NW>(h, sh.wave_tot[hb], &tot);
+      if (ex < need && need <= ex + h) {    // the bin that holds the need-th smallest key in play (h = 0 never qualifies)
         sh.digit = tid;
         sh.need = need - ex;
         sh.done = (need - ex == h);         // the whole bin is wanted: no need to resolve lower bits
@@ -326,12 +328,12 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
 #pragma unroll
   for (int i = 0; i < JPT; ++i) keep_cnt += (ck[i] != ~0ull && (ck[i] >> shift_keep) <= thr_s);
   int newn;
-  int pos = block_scan(keep_cnt, sh.wave_tot[2], &newn);
+  int pos = block_scan<NW>(keep_cnt, sh.wave_tot[2], &newn);
   if (keep_cnt) {
     if (ekey != ~0ull && (ekey >> shift_keep) <= thr_s) { sh.keys[pos] = ekey; sh.kept_j[pos] = -1 - tid; ++pos; }
 #pragma unroll
     for (int i = 0; i < JPT; ++i)
-      if (ck[i] != ~0ull && (ck[i] >> shift_keep) <= thr_s) { sh.keys[pos] = ck[i]; sh.kept_j[pos] = w + 4 * i; ++pos; }
+      if (ck[i] != ~0ull && (ck[i] >> shift_keep) <= thr_s) { sh.keys[pos] = ck[i]; sh.kept_j[pos] = w + NW * i; ++pos; }
   }
   __syncthreads();
   {
@@ -376,17 +378,18 @@ __device__ __forceinline__ int select_radix(Shared& sh, const Beam& C, Beam& Nx,
 // kept score is strictly above the best score any skipped child could have (lp[ncap] + the best entry score); otherwise
 // (ties at the beam boundary, under-full beams) the frame is redone by select_radix over all candidates.
 template <bool SMALL>
-__global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
+__global__ __launch_bounds__(SMALL ? NT : NTW) void beam_search_kernel(BeamDeviceArgs a) {
+  constexpr int NTT = SMALL ? NT : NTW, NWV = NTT / 64;      // threads / waves of this instantiation
   __shared__ Shared sh;
   extern __shared__ __align__(16) unsigned char class_tab[];     // [frame parity][tab_stride(V)]
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int T = a.T, N = a.N, V = a.V, beam = a.beam;
   const int vstride = tab_stride(V);
-  for (int i = tid; i < 2 * vstride / 16; i += NT) reinterpret_cast<int4*>(class_tab)[i] = make_int4(0, 0, 0, 0);
-  for (int i = tid; i < 2 * HASH / 4; i += NT) reinterpret_cast<int4*>(sh.hpos)[i] = make_int4(0, 0, 0, 0);
+  for (int i = tid; i < 2 * vstride / 16; i += NTT) reinterpret_cast<int4*>(class_tab)[i] = make_int4(0, 0, 0, 0);
+  for (int i = tid; i < 2 * HASH / 4; i += NTT) reinterpret_cast<int4*>(sh.hpos)[i] = make_int4(0, 0, 0, 0);
   if (tid < 2) sh.cands[tid].n = 0;
-  load_math_tabs(sh.math, tid, NT);
+  load_math_tabs(sh.math, tid, NTT);
   const int frames = a.in_len ? max(0, min(a.in_len[b], T)) : T;
   int2* arena = a.arena + (size_t)b * ((size_t)T * beam + 1);
   int cur = 0, nbm = 1;                     // current beam buffer, number of entries
@@ -399,12 +402,12 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   long long p_entries = 0, p_keys = 0, p_keep = 0, p_radix = 0, p_redone = 0;
   RadixProf rprof = {0, 0, 0};
   const bool profiling = a.prof != nullptr && b == 0 && tid == 0;
-  const bool profiling3 = a.prof != nullptr && b == 0 && tid == NT - 64;   // wave 3's share of the entry phase
+  const bool profiling3 = a.prof != nullptr && b == 0 && tid == NTT - 64;   // the last wave's share of the entry phase
   long long p_own = 0, p_scan = 0, p_prep = 0, p_cum = 0;
 
   // wave 3 holds the top-n list of the frame it prepares next in registers (lane k = position k); the list of the frame
   // after that is requested as soon as this one is consumed, so no global load sits on the per-frame path
-  const int pl = tid - (NT - 64);
+  const int pl = tid - (NTT - 64);           // the last wave ("wave 3" in the comments: it is with four waves)
   float p_nx = 0.f;
   int c_nx = 0;
   if (pl >= 0 && pl < N && frames > 0) {
@@ -460,8 +463,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   __syncthreads();                          // the cleared tables, K.n = 0
   if (tid == 0) sh.hpos[0][1 & (HASH - 1)] = 1;      // the root's id is 1
   if (pl >= 0 && frames > 0) prepare(0);
-  sh.hist[0][tid] = 0;
-  sh.hist[1][tid] = 0;
+  if (tid < 256) { sh.hist[0][tid] = 0; sh.hist[1][tid] = 0; }
   if (tid < BMAX) sh.exist_mask[0][tid] = 0;
   if (tid < 2) sh.kmin[tid] = ~0ull;
   __syncthreads();
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     // ---- 1. (wave 3) the next frame's candidates
     if (pl >= 0 && t + 1 < frames) prepare(t + 1);
     if (tid < BMAX) sh.exist_mask[(t + 1) & 1][tid] = 0;
-    reinterpret_cast<int4*>(sh.hpos[cur ^ 1])[tid] = make_int4(0, 0, 0, 0);   // HASH = 4 NT cells
+    if (tid < HASH / 4) reinterpret_cast<int4*>(sh.hpos[cur ^ 1])[tid] = make_int4(0, 0, 0, 0);   // HASH = 1024 cells = 256 int4
     const Lookup L = {class_tab + ((t + 1) & 1) * vstride, sh.hpos[cur ^ 1]};
     if (!SMALL && tid == 0) sh.kmin[(t + 1) & 1] = ~0ull;   // select_radix's best key, per frame parity
     if (SMALL && (tid >> 6) == 2) {         // wave 2: the best entry score, for the acceptance test of the small path
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
         if (tid == 0) sh.kmin[t & 1] = ~0ull;
         __syncthreads();
       }
-      newn = select_radix<SMALL ? SMALL_BEAM / 4 : BMAX / 4>(sh, C, Nx, K, exist, nbm, beam, t, arena, L, profiling, rprof);
+      newn = select_radix<(SMALL ? SMALL_BEAM : BMAX) / NWV, NWV>(sh, C, Nx, K, exist, nbm, beam, t, arena, L, profiling, rprof);
       if (profiling) p_radix += clock64() - t3;
     }
     cur ^= 1;
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
   int32_t* lens = a.lens + (size_t)b * beam;
   float* scores = a.scores + (size_t)b * beam;
   if (tid == 0) a.n_hyp[b] = n;
-  for (int i = tid; i < beam; i += NT) {
+  for (int i = tid; i < beam; i += NTT) {
     if (i >= nbm) continue;
     const u64 ki = make_key(C.score[i], C.ch[i], i);
     int rank = 0;
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(NT) void beam_search_kernel(BeamDeviceArgs a) {
     for (int p = C.arena[i]; p > 0; p = arena[p].x, --q)
       if (q < a.max_len) row[q] = arena[p].y;
   }
-  for (int i = n + tid; i < beam; i += NT) {
+  for (int i = n + tid; i < beam; i += NTT) {
     lens[i] = 0;
     scores[i] = kNegInf;
     for (int q = 0; q < a.max_len; ++q) ids[(size_t)i * a.max_len + q] = -1;
@@ -686,7 +688,7 @@ int mi355asr_launch_beam_device(const BeamDeviceArgs* a, hipStream_t s) {
     allowed_on[dev] = true;
   }
   if (small) hipLaunchKernelGGL(beam_search_kernel<true>, dim3(a->B), dim3(NT), dyn, s, *a);
-  else hipLaunchKernelGGL(beam_search_kernel<false>, dim3(a->B), dim3(NT), dyn, s, *a);
+  else hipLaunchKernelGGL(beam_search_kernel<false>, dim3(a->B), dim3(NTW), dyn, s, *a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
