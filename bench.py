@@ -436,7 +436,8 @@ def config5_main(args, world, rank, device, use_dist):
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": extra["workload"], "global_batch": world * B, "samples_per_utt": L,
-                           "parallelism": "dp%d" % world, "weights": "random-init (Keras defaults)"},
+                           "parallelism": "dp%d" % world, "weights": "random-init (Keras defaults)",
+                           "rccl_ranks": (dist.get_world_size() if use_dist else None)},
                 "roofline": extra["roofline"], "kernels": extra["kernels"], "ms_predict": extra["ms_predict"],
                 "ms_beam10": extra["ms_beam10"]}
         if "cpu_baseline" in extra:
