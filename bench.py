@@ -687,6 +687,13 @@ def main():
             for n in ("tail_ff1", "tail_ff2"):
                 fl[n] += fl["out_glu"]
                 ab[n] += 4.0 * 3 * S_CFG["dmodel"] ** 2
+        n_ff1 = max(cnt[_lib.KERNEL_NAMES.index("ff1_qkv")] // args.steps, 1)
+        for pre in ("sublinear", "ctc_project"):
+            if pre not in launched and "ff1_qkv" in launched:
+                # round 4: the subsampling Dense / the CTC projection run in the prologue of the ff1_qkv launch behind them (two
+                # such launches per step: the per-launch average carries half of each); x0 is neither written nor read
+                fl["ff1_qkv"] += fl[pre] / n_ff1
+                ab["ff1_qkv"] += (ab[pre] - 2 * 4.0 * B * (L // 640) * S_CFG["dmodel"]) / n_ff1
         kern = {}
         for i, name in enumerate(_lib.KERNEL_NAMES):
             if cnt[i]:

@@ -793,6 +793,14 @@ int geometry(const mi355asr_model* m, int B, int L, Geometry* g) {
 // RBlock of the Translator (conformer_blocks.py:455-463, 496-503): the attention is a cross-attention with
 // q = LN(x + PE) and k = v = the encoder output (T_enc frames per utterance), everything else is a ConformerBlock.
 
+static bool fused_env_on() {
+  static const bool on = [] { const char* v = getenv("MI355ASR_FUSED"); return v ? atoi(v) != 0 : true; }();
+  return on;
+}
+bool block_takes_pre(const mi355asr_model* m, const BlockDev& w, size_t M) {
+  return m->cfg.dmodel == 144 && fused_env_on() && !gemm16_for(m, M) && w.pp_ff1 && w.ff1_slabs && ff1_pre_selected();
+}
+
 int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int B, int T,
               float* out, hipStream_t s, const CrossAttn* cross, const BlockDev* next, bool* ff1_done, bool skip_ff1) {
   if (ff1_done) *ff1_done = false;
@@ -800,7 +808,9 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
   const int ksz = bo.ksz;
   const float fc = bo.fc;
   const int M = B * T;
-  static const bool fused_env = [] { const char* v = getenv("MI355ASR_FUSED"); return v ? atoi(v) != 0 : true; }();
+  const bool fused_env = fused_env_on();
+  if (bo.pre_pp && (cross || skip_ff1 || !block_takes_pre(m, w, (size_t)M)))
+    return fail(MI355ASR_ESTATE, "run_block: a layer in front of a block that cannot take it");
   if (gemm16_for(m, M)) {
     // one launch per dense layer (bf16.hip: bf16 or fp32 operands); LayerNorm / softmax / activations / depthwise conv in fp32
     auto g16 = [&](const float* x, int ldx, int K, const float* wp, const float* bias, int NT, float* y, int ldy) {
@@ -872,7 +882,8 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       return k1;
     };
     if (!skip_ff1) {
-      const Ff1QkvArgs k1 = ff1_args(w, sc.xa, sc.xb);
+      Ff1QkvArgs k1 = ff1_args(w, sc.xa, sc.xb);
+      if (bo.pre_pp) { k1.pre_x = bo.pre_x; k1.pre_pp = bo.pre_pp; k1.pre_sw = bo.pre_sw; k1.pre_chunks = bo.pre_chunks; }
       PROF(MI355ASR_K_FF1_QKV); LAUNCH_TRY(launch_ff1_qkv(k1, s), "ff_module_1 + qkv");
     }
     AttnArgs at{};
@@ -1049,7 +1060,8 @@ int run_mel(const mi355asr_model* m, const float* wav, int Bp, int Lb, int F, fl
 // mel_bounded: the features come from this handle's own frontend (|mel| <= 80 x the filters' L1 norm), which the two-term
 // fp16 kernel's operand scale relies on; features handed in by the caller take the three-term bf16 kernel
 int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, float* sub, float* out,
-                    hipStream_t s, bool mel_bounded) {
+                    hipStream_t s, bool mel_bounded, bool* defer_dense) {
+  if (defer_dense) *defer_dense = false;
   const auto& c = m->cfg;
   const int d = c.dmodel;
   int T1, pt1, T2, pt2;
@@ -1076,6 +1088,7 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   // count, 0 = the fp32-MFMA stream_gemm_kernel
   static const int lin_split = [] { const char* v = std::getenv("MI355ASR_SUBLINEAR_SPLIT"); return v ? std::atoi(v) : 1; }();
   if (lin_split && m->lin_wsplit && (lg.M >= 4096 || lin_split == 2)) {
+    if (defer_dense && m->lin_pp && pp_sublinear_ok(lg, m->lin_pp)) { *defer_dense = true; return 0; }   // the caller folds it into the first block
     PROF(MI355ASR_K_SUBLINEAR);
     // round 4: two fp16 terms with a scale per (token, 144-wide chunk) -- no bound on the operand needed, so caller-supplied
     // features take it too; the three-term kernel behind MI355ASR_PP_SUBLINEAR=0 / MI355ASR_PP=0
@@ -1199,18 +1212,22 @@ int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const P
   Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
   sc.h4 = (float*)(ws + p.h4);
-  rc = run_subsampling(m, mel, g.Bp, g.F, (float*)(ws + p.sub), sc.xa, s, true);
+  // round 4: the subsampling Dense rides in the first block's ff_module_1 + qkv launch when both run on the two-term stream
+  const int nb = m->cfg.num_blocks;
+  bool dense_deferred = false;
+  const bool may_defer = nb > 0 && !m->cfg.add_wav_info && block_takes_pre(m, m->enc_blocks[0], (size_t)g.Bp * g.T);
+  rc = run_subsampling(m, mel, g.Bp, g.F, (float*)(ws + p.sub), sc.xa, s, true, may_defer ? &dense_deferred : nullptr);
   if (rc) return rc;
   if (m->cfg.add_wav_info) {
     rc = run_wavpick(m, wav, g.Bp, g.Lb, g.T, sc.xa, (float*)(ws + p.wv), s);
     if (rc) return rc;
   }
-  const int nb = m->cfg.num_blocks;
   bool ff1_done = false;
   for (int i = 0; i < nb; ++i) {
     BlockOpts bo;
     bo.ksz = m->cfg.kernel_size;
     bo.fc = m->cfg.fc_factor;
+    if (i == 0 && dense_deferred) { bo.pre_x = (float*)(ws + p.sub); bo.pre_pp = m->lin_pp; bo.pre_sw = m->lin_pp_sw; bo.pre_chunks = m->dm.F2; }
     const bool skip = ff1_done;
     rc = run_block(m, m->enc_blocks[i], bo, sc, g.Bp, g.T, i == nb - 1 ? enc_out : nullptr, s, nullptr,
                    i + 1 < nb ? &m->enc_blocks[i + 1] : nullptr, &ff1_done, skip);
@@ -1228,21 +1245,31 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
   sc.h4 = (float*)(ws + p.h4);
   const bool bf16 = gemm16_for(m, M);
-  if (bf16) {
+  // round 4: the projection rides in the first decoder block's ff_module_1 + qkv launch
+  const bool proj_fold = m->proj_pp && m->cfg.ctc_num_blocks > 0 && block_takes_pre(m, m->ctc_blocks[0], (size_t)M);
+  if (proj_fold) {
+  } else if (bf16) {
     Gemm16Args pr{};
     pr.x = enc; pr.ldx = d; pr.bias = m->proj_b; pr.y = sc.xa; pr.ldy = d;
     pr.M = M; pr.K = d; pr.NT = d / 16; pr.n_valid = d; pr.eps = kLnEps;
     { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm16(m, E16_BIAS, false, pr, m->proj_wp, s), "ctc project"); }
   } else {
-  GemmArgs pr{};
-  pr.x = enc; pr.y = sc.xa; pr.wp = m->proj_wp; pr.bias = m->proj_b;
-  pr.M = M; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
-  { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "ctc project"); }
+    // on its own: the same two-term stream through pp_sublinear_kernel (one chunk) -- bit-identical to the folded form --, else fp32 MFMA
+    StreamGemmArgs sp{};
+    sp.x = enc; sp.y = sc.xa; sp.M = M; sp.K = d; sp.NT = d / 16; sp.ldy = d; sp.n_valid = d;
+    PROF(MI355ASR_K_CTC_PROJECT);
+    if (!(m->proj_pp && m->cfg.gemm_dtype == 0 && launch_pp_sublinear(sp, m->proj_pp, m->proj_pp_sw, s) == 0)) {
+      GemmArgs pr{};
+      pr.x = enc; pr.y = sc.xa; pr.wp = m->proj_wp; pr.bias = m->proj_b;
+      pr.M = M; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
+      LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "ctc project");
+    }
   }
   for (int i = 0; i < m->cfg.ctc_num_blocks; ++i) {
     BlockOpts bo;
     bo.ksz = m->cfg.ctc_kernel_size;
     bo.fc = m->cfg.ctc_fc_factor;
+    if (i == 0 && proj_fold) { bo.pre_x = enc; bo.pre_pp = m->proj_pp; bo.pre_sw = m->proj_pp_sw; bo.pre_chunks = 1; }
     int rc = run_block(m, m->ctc_blocks[i], bo, sc, B, T, nullptr, s);
     if (rc) return rc;
   }
@@ -1724,11 +1751,18 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
     o_wfw = conv_w("wav_layer/final/kernel", 7 * m->wp_stages.back().c, d);
     o_wfb = ab.put(m->host["wav_layer/final/bias"].data);
   }
-  size_t o_pw = 0, o_pb = 0, o_fw = 0, o_fb = 0;
+  size_t o_pw = 0, o_pb = 0, o_fw = 0, o_fb = 0, o_ppp = 0;
+  float proj_pp_sw = 1.f;
   if (c.num_classes > 0) {
     const auto& pj = m->host["project/kernel"].data;
     o_pw = ab.put(pack_p16([&](int k, int n) { return pj[(size_t)k * d + n]; }, d, d, d / 16));
     o_pb = ab.put(m->host["project/bias"].data);
+    if (d == 144) {
+      const auto& pb = m->host["project/bias"].data;
+      std::vector<float> pp;
+      proj_pp_sw = append_pp_plain(pp, [&](int k, int n) { return k < d ? pj[(size_t)k * d + n] : pb[n]; }, 1);
+      o_ppp = ab.put(pp);
+    }
     for (int i = 0; i < c.ctc_num_blocks; ++i)
       co.push_back(pack_block(m, ab, "decoder_conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size,
                               c.ctc_kernel_size));
@@ -1762,6 +1796,8 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->lin_wsplit = (d == 144 && c.has_encoder) ? base + o_lws : nullptr;
   m->lin_pp = (d == 144 && c.has_encoder) ? base + o_lpp : nullptr;
   m->lin_pp_sw = lin_pp_sw;
+  m->proj_pp = (d == 144 && c.num_classes > 0) ? base + o_ppp : nullptr;
+  m->proj_pp_sw = proj_pp_sw;
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->proj_wp = base + o_pw; m->proj_b = base + o_pb; m->fc_wp = base + o_fw; m->fc_b = base + o_fb;
   m->leaf_wp = base + o_leafw; m->leaf_wsplit = base + o_leafs; m->leaf_gcoef = base + o_lg; m->leaf_alpha = base + o_la; m->leaf_delta = base + o_ld;
@@ -1986,7 +2022,7 @@ int mi355asr_conv_subsampling(mi355asr_model* m, const float* mel, int32_t B, in
   const int T = ceil_div(ceil_div(F, m->dm.st1), 2);
   const Plan p = make_plan(m, B, F, T);
   if (ws_bytes < p.total) return fail(MI355ASR_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total);
-  return run_subsampling(m, mel, B, F, (float*)((char*)ws + p.sub), out, (hipStream_t)stream, false);
+  return run_subsampling(m, mel, B, F, (float*)((char*)ws + p.sub), out, (hipStream_t)stream, false, nullptr);
 }
 
 int mi355asr_conformer_block(mi355asr_model* m, int32_t stack, int32_t index, const float* x, int32_t B, int32_t T,

@@ -1146,10 +1146,12 @@ int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
   if (ring && a.slabs) {
     if (launch_pp_ff1_qkv(a, s) == 0) return 0;
+    if (a.pre_pp) return -1;          // only the pair-pipelined kernel computes x0 itself (callers ask ff1_pre_selected first)
     note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(ff1_qkv_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
     return 0;
   }
+  if (a.pre_pp) return -1;
   note_scheme(SCHEME_F32);
   hipLaunchKernelGGL(ff1_qkv_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
@@ -1198,6 +1200,11 @@ int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t
 bool tail_pp_selected() {
   static const bool ring = env_on("MI355ASR_TAILFF2_RING");
   return ring && pp_enabled();
+}
+// launch_ff1_qkv will take the pair-pipelined kernel, which can compute x0 from the layer in front (Ff1QkvArgs::pre_*)
+bool ff1_pre_selected() {
+  static const bool ring = env_on("MI355ASR_FF1QKV_RING");
+  return ring && pp_pre_fold_ok();
 }
 // tail of one block + ff1_qkv of the next in one launch; -1 when the loader-wave kernels are switched off
 bool tail_ff1_available() {

@@ -679,10 +679,13 @@ DEV void pp_og_tile(const OutGluArgs& g, const PpOgLds& p, ST& st, PpPool& pl, f
 // when both are set (the block output stays in registers; a.y may be null then).  DWF: the depthwise conv runs in the
 // prologue (a.dw_u / dw_wd / dw_T / dw_pad) and the grid is (ceil(T / 64), utterances).  OGF (needs DWF): the window of the
 // depthwise conv is computed in the prologue too, from the attention output and x1 (g; a.dw_u and a.x2 are not read).
-template <bool TAIL, bool FF1, int DG = 0, bool DWF = false, bool OGF = false>
+// PRE (FF1 without TAIL): the plain layer in front of the block -- the subsampling Dense, the CTC decoder's projection -- runs
+// first, x0 = pre_x W + b from b.pre_x [M, 144 * pre_chunks] and the stream b.pre_pp (pp_sublinear_kernel's loop); b.x0 is not read.
+template <bool TAIL, bool FF1, int DG = 0, bool DWF = false, bool OGF = false, bool PRE = false>
 __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1QkvArgs b, OutGluArgs g) {
   static_assert(TAIL || !DWF, "the depthwise conv feeds the conv tail");
   static_assert(DWF || !OGF, "the out-projection + GLU prologue feeds the depthwise window");
+  static_assert(!PRE || (FF1 && !TAIL), "the layer in front feeds ff_module_1");
   __shared__ __attribute__((aligned(16))) u32x4_t ring[PP_RING * PP_SLB];
   __shared__ __attribute__((aligned(16))) PpTailLds pt;
   __shared__ __attribute__((aligned(16))) PpFf1Lds pf;
@@ -698,10 +701,15 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
                 "the slots behind slab NOG + 1 up to the end of the ring hold the depthwise window and the taps");
   float* scratch = reinterpret_cast<float*>(ring + (OGF ? OG_SCR : 2) * PP_SLB);
   f32x4 xs[KB], y[KB];
-  const u32x4_t* s0 = reinterpret_cast<const u32x4_t*>(g.pp_slabs);
+  const u32x4_t* s0 = reinterpret_cast<const u32x4_t*>(PRE ? b.pre_pp : g.pp_slabs);
   const u32x4_t* s1 = reinterpret_cast<const u32x4_t*>(TAIL ? a.pp_slabs : b.pp_slabs);
   const u32x4_t* s2 = reinterpret_cast<const u32x4_t*>(b.pp_slabs);
   if (wv >= WAVES_PER_BLOCK + (OGF ? 2 : 0)) {
+    if constexpr (PRE) {
+      const int n0 = KS32X * b.pre_chunks;
+      PpLoader<PP_RING, DG>{ring, s1, s2, n0 + N1, n0 + TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63), s0, n0}.run();
+      return;
+    }
     const PpLoader<PP_RING, DG> ld{ring, s1, s2, N1, TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63), s0, NOG};
     if constexpr (OGF) {
       ld.run_og_phase();
@@ -764,9 +772,14 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
       for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.dw + c.row + 16 * kb + c.g4);
     }
     pp_tail_stash(pt, a);
-  } else {
+  } else if constexpr (!PRE) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(b.x0 + c.row + 16 * kb + c.g4);
+  }
+  const float* __restrict__ prow = PRE ? b.pre_x + (size_t)c.tok * (D * b.pre_chunks) + c.g4 : nullptr;
+  if constexpr (PRE) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) { xs[kb] = ldg4(prow + 16 * kb); y[kb] = splat4(0.f); }
   }
   if constexpr (FF1) pp_ff1_stash(pf, b);
   if constexpr (DWF) pp_dw_prologue(scratch, a, xs);     // after the parameter loads: their latency hides under the prologue
@@ -774,6 +787,33 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
   PpPool pl;
   pp_prime<DG>(pl, st);
   pp_pool_land(pl);
+  if constexpr (PRE) {
+    // every 144-wide chunk of the row under its own power-of-two scale (pp_sublinear_kernel); the next chunk's rows are
+    // requested before this chunk's units
+#pragma unroll 1
+    for (int f = 0; f < b.pre_chunks; ++f) {
+      Split8 xf[KS32X];
+      const float sx = pp_pow2_scale(pp_row_max(xs));
+      split_operand(xf, xs, c.g4, sx);
+      if (f + 1 < b.pre_chunks) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(prow + (size_t)(f + 1) * D + 16 * kb);
+      }
+      f32x4 acc[KB];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) acc[i] = splat4(0.f);
+      static_for<0, KS32X>([&](auto Tt) {
+        constexpr int t = decltype(Tt)::value;
+        pp_unit_S<DG>(acc, xf[t], pl, st);
+      });
+      pp_pool_land(pl);
+      const f32x4 inv = splat4(pp_recip_pow2(b.pre_sw * sx));
+#pragma unroll
+      for (int i = 0; i < KB; ++i) y[i] += acc[i] * inv;
+    }
+#pragma unroll
+    for (int i = 0; i < KB; ++i) xs[i] = y[i];
+  }
   if constexpr (TAIL) {
     pp_tail_consume<DG>(a, pt, c.g4, st, pl, xs, y);
     if (a.y) {
@@ -1030,10 +1070,13 @@ int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, 
   hipLaunchKernelGGL(pp_head_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, groups);
   return 0;
 }
-int launch_pp_sublinear(const StreamGemmArgs& a, const float* pp, float pp_sw, hipStream_t s) {
+bool pp_sublinear_ok(const StreamGemmArgs& a, const float* pp) {
   // MI355ASR_PP_SUBLINEAR=0: the three-term sublinear_split_ld_kernel (fused.hip)
   static const bool on = [] { const char* v = getenv("MI355ASR_PP_SUBLINEAR"); return v ? atoi(v) != 0 : true; }();
-  if (!on || !pp_enabled() || !pp || a.NT != KB || a.K % D != 0 || a.K < D || a.M <= 0 || (a.ldy & 3) != 0) return -1;
+  return on && pp_enabled() && pp && a.NT == KB && a.K % D == 0 && a.K >= D && a.M > 0 && (a.ldy & 3) == 0;
+}
+int launch_pp_sublinear(const StreamGemmArgs& a, const float* pp, float pp_sw, hipStream_t s) {
+  if (!pp_sublinear_ok(a, pp)) return -1;
   note_scheme(SCHEME_F16X2);
   hipLaunchKernelGGL(pp_sublinear_kernel, dim3((a.M + 63) / 64), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, a.K / D);
   return 0;
@@ -1106,10 +1149,20 @@ int launch_pp_og_tail_ff2(const TailFf2Args& a, const OutGluArgs& g, hipStream_t
   hipLaunchKernelGGL((pp_block_kernel<true, false, 0, true, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{}, g);
   return 0;
 }
+bool pp_pre_fold_ok() {
+  // MI355ASR_PP_PRE=0: the subsampling Dense and the CTC decoder's projection as their own launches
+  static const bool on = [] { const char* v = getenv("MI355ASR_PP_PRE"); return v ? atoi(v) != 0 : true; }();
+  return on && pp_enabled();
+}
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
   if (!pp_enabled() || !b.pp_slabs || b.M <= 0) return -1;
   const int tiles = (b.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
+  if (b.pre_pp) {
+    if (!pp_pre_fold_ok() || !b.pre_x || b.pre_chunks < 1) return -1;
+    hipLaunchKernelGGL((pp_block_kernel<false, true, 0, false, false, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, TailFf2Args{}, b, OutGluArgs{});
+    return 0;
+  }
   hipLaunchKernelGGL((pp_block_kernel<false, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, TailFf2Args{}, b, OutGluArgs{});
   return 0;
 }

@@ -277,6 +277,11 @@ struct Ff1QkvArgs {
   const float* pp_slabs = nullptr;   // pair-pipelined stream (fused_pp.hip: 51 ring slots of 20 fragments; biases in row 144), or null
   PpChainSc pp_sc;                   // ... the scales its ff_module_1 chain was packed with (api.hip: append_pp_chain)
   float pp_sw_qkv = 1.f;             // ... and its q / k / v matrix
+  // round 4: the plain layer in front of the block (the subsampling Dense, the CTC decoder's projection) in the same launch:
+  // x0 = pre_x [M, 144 * pre_chunks] W + b from its two-term stream (api.hip: append_pp_plain) -- x0 above is not read then
+  const float* pre_x = nullptr; const float* pre_pp = nullptr;
+  float pre_sw = 1.f;
+  int pre_chunks = 0;
 };
 struct OutGluArgs {
   const float* ctx; const float* x1; float* x2; float* u;
@@ -320,6 +325,8 @@ bool pp_dw_fold_ok(int T, int ksz);   // the tail kernels can take the depthwise
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
+bool ff1_pre_selected();             // ... and launch_ff1_qkv will take that kernel (fused.hip) when the block has its streams
+bool pp_pre_fold_ok();               // the layer in front of a block rides in its ff_module_1 + qkv launch (MI355ASR_PP_PRE=0: own launch)
 // round 4: out-projection + residual + LayerNorm + pw_conv_1 + GLU in the prologue of the pair-pipelined tail kernels (the
 // block = attention + ONE launch); -1: not applicable (switched off, no streams, depthwise fold impossible), nothing launched
 bool pp_og_fold_ok(const TailFf2Args& a, const OutGluArgs& g);
@@ -328,6 +335,7 @@ int launch_pp_og_tail_ff2(const TailFf2Args& a, const OutGluArgs& g, hipStream_t
 int launch_sublinear_split(const StreamGemmArgs& a, const float* ws, hipStream_t s);   // -1: shape not supported
 // the same layer on the two-term fp16 stream (fused_pp.hip; pp = append_pp_plain of K / 144 chunks [W_f ; bias or 0], packed with pp_sw)
 int launch_pp_sublinear(const StreamGemmArgs& a, const float* pp, float pp_sw, hipStream_t s);
+bool pp_sublinear_ok(const StreamGemmArgs& a, const float* pp);   // ... would take it
 int launch_pick(const PickArgs& a, hipStream_t s);
 int launch_row_argmax(const float* x, int32_t* out, int M, int V, hipStream_t s);
 int launch_gather(const GatherArgs& a, hipStream_t s);

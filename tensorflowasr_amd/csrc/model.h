@@ -83,6 +83,11 @@ struct BlockOpts {
   int win_front = -1;   // < 0: full attention
   int win_back = 0;
   bool causal = false;
+  // round 4: the plain layer in front of the block riding in the block's first launch (block_takes_pre says when):
+  // x0 = pre_x [B * T, 144 * pre_chunks] W + b from the two-term stream pre_pp; the block's input buffer (sc.xa) is not read
+  const float* pre_x = nullptr; const float* pre_pp = nullptr;
+  float pre_sw = 1.f;
+  int pre_chunks = 0;
 };
 
 struct StackDev {
@@ -134,6 +139,8 @@ struct mi355asr_model {
   const float* lin_wsplit = nullptr;    // subsampling Dense kernel as split-bf16 fragments, 1792 per 32-wide step (fused.hip)
   const float* lin_pp = nullptr;        // ... and as the two-term fp16 stream of pp_sublinear_kernel (F2 chunks of five ring slots), packed with
   float lin_pp_sw = 1.f;                // ... this power of two
+  const float* proj_pp = nullptr;       // the CTC decoder's projection [W ; b] as such a stream (one chunk), packed with
+  float proj_pp_sw = 1.f;               // ... this power of two
   const float* c2_wsplit = nullptr;     // conv2 kernel as split-bf16 fragments (subconv.hip; dmodel 144 / 256 / 512)
   const float* c2_whalf = nullptr;      // ... as two fp16 terms of kernel * c2_wscale (two-term scheme), conv1 values times c2_hscale
   float c2_hscale = 0.f, c2_wscale = 0.f;
@@ -304,6 +311,7 @@ int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, cons
 int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int B, int T, float* out,
               hipStream_t s, const CrossAttn* cross = nullptr, const BlockDev* next = nullptr, bool* ff1_done = nullptr,
               bool skip_ff1 = false);
+bool block_takes_pre(const mi355asr_model* m, const BlockDev& w, size_t M);   // run_block(w, M rows) can take BlockOpts::pre_*
 void resolve_stack(StackDev& sd, const StackOff& so, const float* base, bool project, int V);   // api_chunk.hip
 int finalize_chunk(mi355asr_model* m, hipStream_t s);        // api_chunk.hip
 int finalize_translator(mi355asr_model* m, hipStream_t s);   // api_translator.hip

@@ -319,6 +319,56 @@ np.savez(sys.argv[1], **out)
         assert np.array_equal(res["two"][k], res["three"][k]), (k, float(np.abs(res["two"][k] - res["three"][k]).max()))
 
 
+def test_layer_in_front_of_a_block_in_its_first_launch_bit_for_bit(torch_cuda):
+    """Round 4: the subsampling Dense (conformer_blocks.py:102-106, K = 20 * 144) and the CTC decoder's projection
+    (conformer_blocks.py:631) run in the prologue of the first block's ff_module_1 + qkv launch (pp_block_kernel<..., PRE>): the
+    layer's two-term stream flows through the ring in front of the block's, x0 stays in registers.  Same units in the same
+    order as pp_sublinear_kernel: encoder output, logits and token ids BIT-IDENTICAL to MI355ASR_PP_PRE=0 (layers as their
+    own launches), at 5000 rows (row count not a multiple of 64: a partly idle last workgroup) and at 16 x 250 rows; and both
+    within the usual tolerance of the oracle."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, small_cfg, waves
+from tensorflowasr_amd.models import ConformerCTC
+cfg = small_cfg(2)
+w = co.encoder_weights(cfg, seed=61)
+w.update(co.ctc_decoder_weights(cfg, 300, seed=62))
+m = ConformerCTC(300, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+m.load_weights(w, by_name=False)
+out = {}
+for tag, B, L in (("a", 20, 160000), ("b", 17, 159000)):
+    x = waves(B, L, 5)
+    enc = m.encode(x)
+    logits, amax = m.ctc_logits(enc, return_argmax=True)
+    ids, lens = m.recognize(x)
+    out[tag + "_enc"] = enc.cpu().numpy(); out[tag + "_logits"] = logits.cpu().numpy()
+    out[tag + "_ids"] = ids.cpu().numpy(); out[tag + "_lens"] = lens.cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("folded", {}), ("own", {"MI355ASR_PP_PRE": "0"})):
+            f = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[tag] = dict(np.load(f))
+    for k in res["folded"]:
+        assert np.array_equal(res["folded"][k], res["own"][k]), (k, float(np.abs(res["folded"][k].astype(np.float64) - res["own"][k]).max()))
+    assert (res["folded"]["a_lens"] > 0).any()
+    cfg = small_cfg(2)
+    w = co.encoder_weights(cfg, seed=61)
+    w.update(co.ctc_decoder_weights(cfg, 300, seed=62))
+    x = waves(3, 160000, 5)
+    enc_ref = co.conformer_encoder(x.astype(np.float64), w, cfg)
+    assert maxdiff(res["folded"]["a_enc"][:3], enc_ref) < TOL
+    assert maxdiff(res["folded"]["a_logits"][:3], co.ctc_decoder(enc_ref, w, cfg)) < TOL
+
+
 @pytest.mark.parametrize("scale", [1e-4, 1.0, 1e3, 3e4])
 def test_conformer_block_operand_scales_follow_the_input_magnitude(enc2, scale):
     """The two-term fp16 kernels scale every operand row by the power of two of its own largest magnitude (and hidden rows by
@@ -1591,6 +1641,7 @@ print("RESULT %.3e %.3e" % (blk, enc))
                   {"MI355ASR_FF1QKV_RING": "0"}, {"MI355ASR_HEAD_RING": "0"}, {"MI355ASR_FUSED": "0"},
                   {"MI355ASR_TAILFF2_RING": "0"}, {"MI355ASR_PP": "0"}, {"MI355ASR_PP": "0", "MI355ASR_TAIL_FF1": "0"},
                   {"MI355ASR_TAIL_FF1": "0"}, {"MI355ASR_PP_DW": "0"}, {"MI355ASR_PP_OGF": "0"}, {"MI355ASR_PP_HEAD": "0"},
+                  {"MI355ASR_SUBLINEAR_SPLIT": "2", "MI355ASR_PP_PRE": "0"},
                   {"MI355ASR_ATTN_SPLIT": "0"}, {"MI355ASR_ATTN_LDS": "0"}, {"MI355ASR_FFT_SPLIT": "0"}, {"MI355ASR_FFT": "0"},
                   # the three-term bf16 versions of the kernels that default to the two-term fp16 scheme
                   {"MI355ASR_SUBCONV_TERMS": "3"}, {"MI355ASR_ATTN_TERMS": "3"}, {"MI355ASR_PP_OUTGLU": "0"}, {"MI355ASR_FFT_TERMS": "3"},
