@@ -819,7 +819,19 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       g.M = M; g.n_valid = 16 * NT; g.eps = kLnEps; g.scale = 1.0f;
       return g;
     };
+    // round 4: bf16 mode, dmodel 256: FFModule and ConvModule tail as ONE launch each (bf16.hip: chain256_bf16_kernel; the
+    // hidden activation stays in LDS) -- MI355ASR_CHAIN256=0: one gemm16 / gemm_ring launch per layer
+    static const bool chain_env = [] { const char* v = getenv("MI355ASR_CHAIN256"); return v ? atoi(v) != 0 : true; }();
+    const bool chain256 = m->cfg.gemm_dtype == 1 && d == 256 && chain_env && !cross;
     auto ffn = [&](int i, const float* x, float* y, const float* fg, const float* fb) -> int {
+      if (chain256) {
+        Chain2Args ca{};
+        ca.x = x; ca.res = x; ca.y = y; ca.ln_g = w.ff_ln_g[i]; ca.ln_b = w.ff_ln_b[i];
+        ca.w1p = (const float*)m->w16(w.ff_w1p[i]); ca.b1 = w.ff_b1[i]; ca.w2p = (const float*)m->w16(w.ff_w2p[i]); ca.b2 = w.ff_b2[i];
+        ca.fln_g = fg; ca.fln_b = fb; ca.scale = fc; ca.eps = kLnEps; ca.M = M;
+        PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_chain256_bf16(0, ca, s), "ff module");
+        return 0;
+      }
       Gemm16Args a1 = g16(x, d, d, w.ff_w1p[i], w.ff_b1[i], 4 * d / 16, sc.h4, 4 * d);
       a1.ln_g = w.ff_ln_g[i]; a1.ln_b = w.ff_ln_b[i];
       { PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_gemm16(m, E16_SWISH, true, a1, w.ff_w1p[i], s), "ffn1"); }
@@ -861,6 +873,13 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
     dwa.pad_left = bo.causal ? ksz - 1 : (ksz - 1) / 2;
     { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
+    if (chain256) {
+      Chain2Args ca{};
+      ca.x = sc.dw; ca.res = sc.xa; ca.y = sc.xb; ca.w1p = (const float*)m->w16(w.pc_w1p); ca.b1 = w.pc_b1; ca.aff_s = w.bn_s; ca.aff_t = w.bn_t;
+      ca.w2p = (const float*)m->w16(w.pw2_wp); ca.b2 = w.pw2_b; ca.scale = 1.0f; ca.eps = kLnEps; ca.M = M;
+      { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_chain256_bf16(1, ca, s), "conv module tail"); }
+      return ffn(1, sc.xb, out ? out : sc.xa, w.ln_g, w.ln_b);
+    }
     Gemm16Args pc = g16(sc.dw, d, d, w.pc_w1p, w.pc_b1, 2 * d / 16, sc.h4, 2 * d);
     pc.aff_s = w.bn_s; pc.aff_t = w.bn_t;
     { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_gemm16(m, E16_AFFSWISH, false, pc, w.pc_w1p, s), "pointwise + BN + swish"); }

@@ -365,6 +365,206 @@ void launch_layernorm_rows(float* y, const float* g, const float* b, int M, int 
                      y, g, b, M, N, ld, eps);
 }
 
+// =====================================================================================================
+// chain256 (round 4): a whole FFModule / ConvModule tail of dmodel 256 in ONE launch in bf16 mode,
+//     y = res + scale * ( act( pro(x) W1 + b1 ) W2 + b2 )   [+ LayerNorm]            (conformer_blocks.py:126-134, :214-218)
+// MODE 0: pro = LayerNorm, act = swish (HT = 64 hidden tiles); MODE 1: pro = identity, act = swish(BN-affine(.)) (HT = 32).
+// ONE workgroup of eight waves owns RT 16-token tiles: every wave requests the first batches of its share of W1 at once (the
+// weights do not depend on the rows), computes HT / 8 hidden tiles per row tile, leaves them in LDS as bf16 operand fragments
+// (GEMM1's accumulator layout IS GEMM2's operand layout: nothing is transposed), and after one barrier computes TWO 16-column
+// tiles of the output over the whole hidden dimension -- no partial sums to reduce, the hidden activation (fp32 in HBM
+// between the two gemm16 / gemm_ring launches before: 136 MB per FFModule at 16 640 rows) never leaves the CU.  Weight
+// fragments travel in batches of sixteen, C_PF batches ahead of their MFMAs (the first batches of W2 across the barrier).
+// Same arithmetic as the two launches: bf16 operands rounded to nearest even, fp32 accumulation; the trailing LayerNorm's
+// statistics cross the waves through LDS in a fixed order.
+// What bounds it: a CU pulls ~40 GB/s from L2 however many loads it has in flight (measured here and in every per-wave
+// weight stream of this library: 9 TB/s over 256 CUs), and a workgroup needs all 1 MB (FFModule) of weights: 25 us at RT = 1
+// whatever the row count up to 256 tiles.  At 832 rows (52 tiles) that is what two gemm16 launches take (12.7 + 10 us: they
+// spread the weights over 832 workgroups) -- the gain there is launches (24 -> 12 per encoder pass), not time; from 512 tiles
+// on RT = 2 halves the weight traffic per row: 16 640 rows 116 -> ~60 us against 102-133 us for the two ring launches.
+constexpr int C_NW = 8;         // waves per workgroup, two 16-column tiles of dmodel 256 each
+constexpr int C_KB = 16;        // 16-wide k-blocks of a row
+constexpr int C_PF = 3;         // weight batches in flight ahead of the one being multiplied
+template <int HT, int MODE, int RT>
+__global__ __launch_bounds__(C_NW * 64) void chain256_bf16_kernel(Chain2Args a) {
+  constexpr int HW = HT / C_NW;       // hidden tiles of a wave (8 / 4)
+  constexpr int G1 = 16 / HW;         // k-blocks per fragment batch of GEMM1 (sixteen fragments a batch)
+  constexpr int NB1 = C_KB / G1, NB2 = HT / 8, NB = NB1 + NB2, NBUF = C_PF + 1;
+  __shared__ s16x4 hid[RT][HT][64];
+  __shared__ s16x4 xl[RT > 1 ? RT : 1][RT > 1 ? C_KB : 1][64];      // RT > 1: the operand rows, converted once by waves 0 .. RT - 1
+  __shared__ float stat[2][C_NW][RT][16];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g4 = (lane >> 4) * 4, c = lane & 15;
+  const int h0 = wave * HW;
+  // uniform fragment index + lane: scalar base, one vector offset for every load
+  const s16x4* __restrict__ w1 = reinterpret_cast<const s16x4*>(a.w1p);
+  const s16x4* __restrict__ w2 = reinterpret_cast<const s16x4*>(a.w2p);
+  auto row_of = [&](int rt) { return (size_t)min((int)(blockIdx.x * RT + rt) * 16 + c, a.M - 1) * (16 * C_KB); };
+  s16x4 wa[NBUF][16];
+  // batch t of the stream: t < NB1: k-blocks G1 t .. of W1 for this wave's hidden tiles; else k-blocks 8 (t - NB1) .. of W2
+  // for this wave's two column tiles
+  auto load = [&](int t, s16x4 (&w)[16]) {
+    if (t < NB1) {
+#pragma unroll
+      for (int u = 0; u < G1; ++u)
+#pragma unroll
+        for (int i = 0; i < HW; ++i) w[u * HW + i] = w1[((t * G1 + u) * HT + h0 + i) * 64 + lane];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w[u * 2 + j] = w2[(((t - NB1) * 8 + u) * 16 + 2 * wave + j) * 64 + lane];
+    }
+  };
+  s16x4 xb[C_KB];
+  if (RT == 1 || wave < RT) {
+    const size_t row = row_of(RT == 1 ? 0 : wave);
+    f32x4 xr[C_KB];
+#pragma unroll
+    for (int kb = 0; kb < C_KB; ++kb) xr[kb] = ldg4(a.x + row + 16 * kb + g4);
+    if (RT == 1) {
+#pragma unroll
+      for (int t = 0; t < C_PF; ++t) load(t, wa[t]);
+    }
+    if (MODE == 0) {
+      // two-pass statistics of the whole row (Keras semantics), as gemm16_kernel's
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < C_KB; ++i) sm += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
+      const float mean = group_sum(sm) / (float)(16 * C_KB);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < C_KB; ++i) {
+        const f32x4 d = xr[i] - splat4(mean);
+        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+      }
+      const float rstd = 1.0f / sqrtf(group_sum(q) / (float)(16 * C_KB) + a.eps);
+#pragma unroll
+      for (int i = 0; i < C_KB; ++i)
+        xb[i] = to_bf16x4((xr[i] - splat4(mean)) * splat4(rstd) * ldg4(a.ln_g + 16 * i + g4) + ldg4(a.ln_b + 16 * i + g4));
+    } else {
+#pragma unroll
+      for (int i = 0; i < C_KB; ++i) xb[i] = to_bf16x4(xr[i]);
+    }
+    if (RT > 1) {
+#pragma unroll
+      for (int i = 0; i < C_KB; ++i) xl[wave][i][lane] = xb[i];
+    }
+  }
+  if (RT > 1) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < C_PF; ++t) load(t, wa[t]);          // (waves 0 .. RT - 1: after their rows, the registers are free then)
+    __syncthreads();
+  }
+  f32x4 acc1[RT][HW];
+#pragma unroll
+  for (int i = 0; i < HW; ++i) {
+    const f32x4 bv = ldg4(a.b1 + 16 * (h0 + i) + g4);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = bv;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < NB1; ++t) {
+    if (t + C_PF < NB) load(t + C_PF, wa[(t + C_PF) % NBUF]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < G1; ++u) {
+      s16x4 xv[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) xv[rt] = RT > 1 ? xl[rt][t * G1 + u][lane] : xb[t * G1 + u];
+#pragma unroll
+      for (int i = 0; i < HW; ++i)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = mfma_bf16(wa[t % NBUF][u * HW + i], xv[rt], acc1[rt][i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the epilogue's operands ride across the barrier too
+  f32x4 rres[RT][2], rb2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    rb2[j] = ldg4(a.b2 + 16 * (2 * wave + j) + g4);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) rres[rt][j] = ldg4(a.res + row_of(rt) + 16 * (2 * wave + j) + g4);
+  }
+#pragma unroll
+  for (int i = 0; i < HW; ++i) {
+    f32x4 as = splat4(1.f), at = splat4(0.f);
+    if (MODE == 1) { as = ldg4(a.aff_s + 16 * (h0 + i) + g4); at = ldg4(a.aff_t + 16 * (h0 + i) + g4); }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) hid[rt][h0 + i][lane] = to_bf16x4(swish4(MODE == 1 ? acc1[rt][i] * as + at : acc1[rt][i]));
+  }
+  __syncthreads();
+  f32x4 acc2[RT][2];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) acc2[rt][0] = acc2[rt][1] = splat4(0.f);
+#pragma unroll
+  for (int t = NB1; t < NB; ++t) {
+    if (t + C_PF < NB) load(t + C_PF, wa[(t + C_PF) % NBUF]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const s16x4 hv = hid[rt][(t - NB1) * 8 + u][lane];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[rt][j] = mfma_bf16(wa[t % NBUF][u * 2 + j], hv, acc2[rt][j]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  f32x4 v[RT][2];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) v[rt][j] = rres[rt][j] + splat4(a.scale) * (acc2[rt][j] + rb2[j]);
+  if (a.fln_g) {
+    // row statistics across the eight waves (each holds 32 of a token's 256 columns), two passes, fixed order
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float sm = ((v[rt][0].x + v[rt][0].y) + (v[rt][0].z + v[rt][0].w)) + ((v[rt][1].x + v[rt][1].y) + (v[rt][1].z + v[rt][1].w));
+      sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+      if (lane < 16) stat[0][wave][rt][c] = sm;
+    }
+    __syncthreads();
+    float q[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < C_NW; ++w) tot += stat[0][w][rt][c];
+      const float mu = tot / (float)(16 * C_KB);
+      q[rt] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        v[rt][j] = v[rt][j] - splat4(mu);
+        q[rt] += (v[rt][j].x * v[rt][j].x + v[rt][j].y * v[rt][j].y) + (v[rt][j].z * v[rt][j].z + v[rt][j].w * v[rt][j].w);
+      }
+      q[rt] += __shfl_xor(q[rt], 16); q[rt] += __shfl_xor(q[rt], 32);
+      if (lane < 16) stat[1][wave][rt][c] = q[rt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float qt = 0.f;
+#pragma unroll
+      for (int w = 0; w < C_NW; ++w) qt += stat[1][w][rt][c];
+      const float rs = 1.0f / sqrtf(qt / (float)(16 * C_KB) + a.eps);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        v[rt][j] = v[rt][j] * splat4(rs) * ldg4(a.fln_g + 16 * (2 * wave + j) + g4) + ldg4(a.fln_b + 16 * (2 * wave + j) + g4);
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    if ((int)(blockIdx.x * RT + rt) * 16 + c < a.M) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) stg4(a.y + row_of(rt) + 16 * (2 * wave + j) + g4, v[rt][j]);
+    }
+  }
+}
+
 __global__ void to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
   for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
     const s16x4 v = to_bf16x4(ldg4(src + i));
@@ -381,6 +581,23 @@ int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
   return 0;
 }
 
+// FFModule (mode 0) / ConvModule tail (mode 1) of dmodel 256 as one launch; w1p / w2p = the bf16 P16 fragments.  -1: no such kernel
+int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s) {
+  if (a.M <= 0) return -1;
+  note_scheme(SCHEME_BF16);
+  const int tiles = (a.M + 15) / 16;
+  const dim3 block(C_NW * 64);
+  // two row tiles per workgroup once every CU has one anyway: half the weight traffic per row
+  if (tiles >= 512) {
+    const dim3 grid((tiles + 1) / 2);
+    if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 2>), grid, block, 0, s, a);
+    return 0;
+  }
+  if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 1>), dim3(tiles), block, 0, s, a);
+  else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 1>), dim3(tiles), block, 0, s, a);
+  return 0;
+}
 int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { note_scheme(SCHEME_BF16); return dispatch<PBf16>(epi, ln, a, s); }
 // same kernel with fp32 operands: wp = the fp32 P16 weights
 int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { note_scheme(SCHEME_F32); return dispatch<PF32>(epi, ln, a, s); }

@@ -257,6 +257,7 @@ struct Gemm16Args {
   long long bstride = 0;
 };
 int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s);
+int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s);   // bf16.hip: dmodel 256, bf16 mode, FFModule / conv tail in one launch
 int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s);   // wp = fp32 P16 weights
 int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // gemm_ring.hip: the same contract on the bf16 pipe with exactly split fp32 operands, weights as a slab ring

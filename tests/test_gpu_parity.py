@@ -1318,6 +1318,62 @@ def test_bf16_block_matches_rounding_oracle(torch_cuda, base):
     assert np.abs(got - exact).max() > 10 * e.mean()               # it really is the bf16 path
 
 
+def test_bf16_chain256_against_layer_at_a_time(torch_cuda):
+    """Round 4: in bf16 mode a dmodel-256 FFModule / ConvModule tail is ONE launch (chain256_bf16_kernel: hidden activation in
+    LDS as bf16 operand fragments) instead of two gemm16 / gemm_ring launches with the fp32 hidden activation in HBM.  Same
+    operands (both GEMMs' inputs rounded to nearest-even bf16), same fp32 accumulation order along K; only the trailing
+    LayerNorm sums its row in a different order and the first GEMM walks K in one piece -- so a block's output must agree with
+    MI355ASR_CHAIN256=0 up to the rare bf16 flips of hidden values whose fp32 sums differ in the last bit, at row counts that
+    take one row tile per workgroup (45, 832 rows) and two (8 208 rows = 513 tiles: an odd tile count, and 8 195 rows: a
+    partial last tile), and stay within the rounding oracle's tolerance."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, small_cfg
+from tensorflowasr_amd.models import ConformerCTC
+cfg = small_cfg(1, co.STREAMING_S)
+w = co.encoder_weights(cfg, seed=5)
+w.update(co.ctc_decoder_weights(cfg, 100, seed=6))
+m = ConformerCTC(100, gemm_dtype="bfloat16", **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+m.load_weights(w, by_name=False)
+out = {}
+for B, T in ((1, 45), (64, 13), (27, 304), (5, 1639)):
+    x = np.random.default_rng(B * T).standard_normal((B, T, cfg["dmodel"])).astype(np.float32)
+    out["blk_%d_%d" % (B, T)] = m.conformer_block(0, x).cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("chain", {}), ("layers", {"MI355ASR_CHAIN256": "0"})):
+            f = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[tag] = dict(np.load(f))
+    for k in res["chain"]:
+        a, b = res["chain"][k], res["layers"][k]
+        assert np.isfinite(a).all() and np.abs(a).max() > 0.1, k
+        d = np.abs(a.astype(np.float64) - b)
+        print(k, "chain vs layer-at-a-time: max %.3g mean %.3g" % (d.max(), d.mean()))
+        # a bf16 operand of the SECOND GEMM still flips when the first GEMM's fp32 sum lands within an ulp of a rounding boundary
+        # (gemm16 splits K over four waves, the ring kernels walk it in 32-wide steps: other summation orders): one bf16 ulp of
+        # a hidden value each, measured mean 3e-5 -- a tenth of the distance either has from the rounding oracle
+        assert d.mean() < 1e-4 and d.max() < 6e-3, k
+    cfg = small_cfg(1, co.STREAMING_S)
+    w = co.encoder_weights(cfg, seed=5)
+    x = np.random.default_rng(45).standard_normal((1, 45, cfg["dmodel"])).astype(np.float32)
+    co.GEMM_ROUND_BF16 = True
+    try:
+        ref = co.conformer_block(x.astype(np.float64), w, "conformer_block_0", cfg["head_size"], cfg["fc_factor"])
+    finally:
+        co.GEMM_ROUND_BF16 = False
+    e = np.abs(res["chain"]["blk_1_45"] - ref)
+    assert e.max() < 6e-3 and e.mean() < 3e-4
+
+
 # ---------------------------------------------------------------------------------------------------------
 # ConformerM / ConformerL (asr/configs/conformerM.yml, conformerL.yml)
 # ---------------------------------------------------------------------------------------------------------
