@@ -222,7 +222,7 @@ def extra_config3(lib, device, steps=20, with_cpu=True):
     def step():
         e = enc(wav)
         h = torch.cat([history[:, 13:], e], 1)
-        _, amax = ctc(h, return_argmax=True)
+        _, amax = ctc(h, return_argmax=True, return_logits=False)      # greedy decode: the class head keeps its running argmax only
         return ctc_greedy_decode(amax, None, blank=V - 1)
 
     t = _timed(step, steps)

@@ -374,57 +374,67 @@ void launch_layernorm_rows(float* y, const float* g, const float* b, int M, int 
 // (GEMM1's accumulator layout IS GEMM2's operand layout: nothing is transposed), and after one barrier computes TWO 16-column
 // tiles of the output over the whole hidden dimension -- no partial sums to reduce, the hidden activation (fp32 in HBM
 // between the two gemm16 / gemm_ring launches before: 136 MB per FFModule at 16 640 rows) never leaves the CU.  Weight
-// fragments travel in batches of sixteen, C_PF batches ahead of their MFMAs (the first batches of W2 across the barrier).
+// fragments travel in batches of sixteen, two or three batches ahead of their MFMAs (the first batches of W2 across the barrier).
 // Same arithmetic as the two launches: bf16 operands rounded to nearest even, fp32 accumulation; the trailing LayerNorm's
 // statistics cross the waves through LDS in a fixed order.
 // What bounds it: a CU pulls ~40 GB/s from L2 however many loads it has in flight (measured here and in every per-wave
 // weight stream of this library: 9 TB/s over 256 CUs), and a workgroup needs all 1 MB (FFModule) of weights: 25 us at RT = 1
 // whatever the row count up to 256 tiles.  At 832 rows (52 tiles) that is what two gemm16 launches take (12.7 + 10 us: they
 // spread the weights over 832 workgroups) -- the gain there is launches (24 -> 12 per encoder pass), not time; from 512 tiles
-// on RT = 2 halves the weight traffic per row: 16 640 rows 116 -> ~60 us against 102-133 us for the two ring launches.
+// on RT = 2 halves the weight traffic per row and from 1024 tiles on RT = 4 quarters it: 16 640 rows 116 -> 68 us (RT = 2)
+// against 102-133 us for the two ring launches.
 constexpr int C_NW = 8;         // waves per workgroup, two 16-column tiles of dmodel 256 each
 constexpr int C_KB = 16;        // 16-wide k-blocks of a row
-constexpr int C_PF = 3;         // weight batches in flight ahead of the one being multiplied
-template <int HT, int MODE, int RT>
+// RT row tiles per workgroup share every weight fragment; HWP hidden tiles per wave and PHASE: with RT = 4 the hidden
+// dimension goes through LDS in phases of 8 HWP = 32 tiles (GEMM1 of the phase, barrier, its 32 k-blocks of GEMM2, barrier),
+// so that accumulators (RT x HWP tiles) and LDS (RT x 32 tiles) stay the size they have at RT = 2.  PF weight batches are in
+// flight ahead of the one being multiplied.
+template <int HT, int MODE, int RT, int HWP, int PF>
 __global__ __launch_bounds__(C_NW * 64) void chain256_bf16_kernel(Chain2Args a) {
-  constexpr int HW = HT / C_NW;       // hidden tiles of a wave (8 / 4)
-  constexpr int G1 = 16 / HW;         // k-blocks per fragment batch of GEMM1 (sixteen fragments a batch)
-  constexpr int NB1 = C_KB / G1, NB2 = HT / 8, NB = NB1 + NB2, NBUF = C_PF + 1;
-  __shared__ s16x4 hid[RT][HT][64];
+  constexpr int PT = C_NW * HWP;      // hidden tiles per phase
+  constexpr int NPH = HT / PT;        // phases
+  constexpr int G1 = 16 / HWP;        // k-blocks per fragment batch of GEMM1 (sixteen fragments a batch)
+  constexpr int NB1 = C_KB / G1, NB2 = PT / 8, NBP = NB1 + NB2, NB = NPH * NBP, NBUF = PF + 1;
+  static_assert(HT % PT == 0 && 16 % HWP == 0 && PT % 8 == 0, "phases of whole batches");
+  __shared__ s16x4 hid[RT][PT][64];
   __shared__ s16x4 xl[RT > 1 ? RT : 1][RT > 1 ? C_KB : 1][64];      // RT > 1: the operand rows, converted once by waves 0 .. RT - 1
   __shared__ float stat[2][C_NW][RT][16];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int g4 = (lane >> 4) * 4, c = lane & 15;
-  const int h0 = wave * HW;
+  // unsigned index arithmetic throughout: scalar base + 32-bit vector offset addressing (a signed index costs a sign-extended
+  // 64-bit address pair per load)
+  const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned g4 = (lane >> 4) * 4;
+  const int c = (int)(lane & 15);
   // uniform fragment index + lane: scalar base, one vector offset for every load
   const s16x4* __restrict__ w1 = reinterpret_cast<const s16x4*>(a.w1p);
   const s16x4* __restrict__ w2 = reinterpret_cast<const s16x4*>(a.w2p);
-  auto row_of = [&](int rt) { return (size_t)min((int)(blockIdx.x * RT + rt) * 16 + c, a.M - 1) * (16 * C_KB); };
+  // 32-bit element offsets (the launcher bounds M): scalar base + one offset register per row tile, nothing to keep in pairs
+  auto row_of = [&](int rt) -> unsigned { return (unsigned)min((int)(blockIdx.x * RT + rt) * 16 + c, a.M - 1) * (16u * C_KB); };
   s16x4 wa[NBUF][16];
-  // batch t of the stream: t < NB1: k-blocks G1 t .. of W1 for this wave's hidden tiles; else k-blocks 8 (t - NB1) .. of W2
-  // for this wave's two column tiles
+  // batch t of the stream: phase t / NBP; inside it NB1 batches of W1 (k-blocks G1 r .. for this wave's HWP hidden tiles of
+  // the phase), then NB2 batches of W2 (eight k-blocks of the phase each, for this wave's two column tiles)
   auto load = [&](int t, s16x4 (&w)[16]) {
-    if (t < NB1) {
+    const int ph = t / NBP, r = t % NBP;
+    if (r < NB1) {
 #pragma unroll
       for (int u = 0; u < G1; ++u)
 #pragma unroll
-        for (int i = 0; i < HW; ++i) w[u * HW + i] = w1[((t * G1 + u) * HT + h0 + i) * 64 + lane];
+        for (int i = 0; i < HWP; ++i) w[u * HWP + i] = w1[(unsigned)((r * G1 + u) * HT + ph * PT + i) * 64u + wave * (HWP * 64u) + lane];
     } else {
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) w[u * 2 + j] = w2[(((t - NB1) * 8 + u) * 16 + 2 * wave + j) * 64 + lane];
+        for (int j = 0; j < 2; ++j) w[u * 2 + j] = w2[(unsigned)((ph * PT + (r - NB1) * 8 + u) * 16 + j) * 64u + wave * 128u + lane];
     }
   };
   s16x4 xb[C_KB];
   if (RT == 1 || wave < RT) {
-    const size_t row = row_of(RT == 1 ? 0 : wave);
+    const unsigned row = row_of(RT == 1 ? 0 : wave);
     f32x4 xr[C_KB];
 #pragma unroll
-    for (int kb = 0; kb < C_KB; ++kb) xr[kb] = ldg4(a.x + row + 16 * kb + g4);
+    for (int kb = 0; kb < C_KB; ++kb) xr[kb] = ldg4(a.x + (row + 16u * kb + g4));
     if (RT == 1) {
 #pragma unroll
-      for (int t = 0; t < C_PF; ++t) load(t, wa[t]);
+      for (int t = 0; t < PF; ++t) load(t, wa[t]);
     }
     if (MODE == 0) {
       // two-pass statistics of the whole row (Keras semantics), as gemm16_kernel's
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(C_NW * 64) void chain256_bf16_kernel(Chain2Args a) 
       const float rstd = 1.0f / sqrtf(group_sum(q) / (float)(16 * C_KB) + a.eps);
 #pragma unroll
       for (int i = 0; i < C_KB; ++i)
-        xb[i] = to_bf16x4((xr[i] - splat4(mean)) * splat4(rstd) * ldg4(a.ln_g + 16 * i + g4) + ldg4(a.ln_b + 16 * i + g4));
+        xb[i] = to_bf16x4((xr[i] - splat4(mean)) * splat4(rstd) * ldg4(a.ln_g + (16u * i + g4)) + ldg4(a.ln_b + (16u * i + g4)));
     } else {
 #pragma unroll
       for (int i = 0; i < C_KB; ++i) xb[i] = to_bf16x4(xr[i]);
@@ -454,64 +464,69 @@ __global__ __launch_bounds__(C_NW * 64) void chain256_bf16_kernel(Chain2Args a) 
   if (RT > 1) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < C_PF; ++t) load(t, wa[t]);          // (waves 0 .. RT - 1: after their rows, the registers are free then)
+    for (int t = 0; t < PF; ++t) load(t, wa[t]);          // (waves 0 .. RT - 1: after their rows, the registers are free then)
     __syncthreads();
   }
-  f32x4 acc1[RT][HW];
-#pragma unroll
-  for (int i = 0; i < HW; ++i) {
-    const f32x4 bv = ldg4(a.b1 + 16 * (h0 + i) + g4);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = bv;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int t = 0; t < NB1; ++t) {
-    if (t + C_PF < NB) load(t + C_PF, wa[(t + C_PF) % NBUF]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < G1; ++u) {
-      s16x4 xv[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) xv[rt] = RT > 1 ? xl[rt][t * G1 + u][lane] : xb[t * G1 + u];
-#pragma unroll
-      for (int i = 0; i < HW; ++i)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = mfma_bf16(wa[t % NBUF][u * HW + i], xv[rt], acc1[rt][i]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // the epilogue's operands ride across the barrier too
-  f32x4 rres[RT][2], rb2[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    rb2[j] = ldg4(a.b2 + 16 * (2 * wave + j) + g4);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) rres[rt][j] = ldg4(a.res + row_of(rt) + 16 * (2 * wave + j) + g4);
-  }
-#pragma unroll
-  for (int i = 0; i < HW; ++i) {
-    f32x4 as = splat4(1.f), at = splat4(0.f);
-    if (MODE == 1) { as = ldg4(a.aff_s + 16 * (h0 + i) + g4); at = ldg4(a.aff_t + 16 * (h0 + i) + g4); }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) hid[rt][h0 + i][lane] = to_bf16x4(swish4(MODE == 1 ? acc1[rt][i] * as + at : acc1[rt][i]));
-  }
-  __syncthreads();
-  f32x4 acc2[RT][2];
+  f32x4 acc1[RT][HWP], acc2[RT][2];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) acc2[rt][0] = acc2[rt][1] = splat4(0.f);
+  f32x4 rres[RT][2], rb2[2];
 #pragma unroll
-  for (int t = NB1; t < NB; ++t) {
-    if (t + C_PF < NB) load(t + C_PF, wa[(t + C_PF) % NBUF]);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < NB; ++t) {
+    const int ph = t / NBP, r = t % NBP;
+    if (t == (RT < 4 ? NB - NB2 : NB - 1)) {
+      // the epilogue's operands: requested when the last run of GEMM2 batches starts (RT = 4: its last batch) -- not earlier,
+      // they are RT x 8 registers
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+      for (int j = 0; j < 2; ++j) {
+        rb2[j] = ldg4(a.b2 + (16u * (2 * wave + j) + g4));
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const s16x4 hv = hid[rt][(t - NB1) * 8 + u][lane];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc2[rt][j] = mfma_bf16(wa[t % NBUF][u * 2 + j], hv, acc2[rt][j]);
+        for (int rt = 0; rt < RT; ++rt) rres[rt][j] = ldg4(a.res + (row_of(rt) + 16u * (2 * wave + j) + g4));
       }
+    }
+    if (r == 0) {
+#pragma unroll
+      for (int i = 0; i < HWP; ++i) {
+        const f32x4 bv = ldg4(a.b1 + (16u * (ph * PT + i) + wave * (16u * HWP) + g4));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = bv;
+      }
+    }
+    if (t + PF < NB) load(t + PF, wa[(t + PF) % NBUF]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (r < NB1) {
+#pragma unroll
+      for (int u = 0; u < G1; ++u) {
+        s16x4 xv[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xv[rt] = RT > 1 ? xl[rt][r * G1 + u][lane] : xb[r * G1 + u];
+#pragma unroll
+        for (int i = 0; i < HWP; ++i)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = mfma_bf16(wa[t % NBUF][u * HWP + i], xv[rt], acc1[rt][i]);
+      }
+      if (r == NB1 - 1) {
+        // the phase's hidden tiles -> LDS (a later phase: once every wave has read the previous one's)
+        if (ph > 0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < HWP; ++i) {
+          f32x4 as = splat4(1.f), at = splat4(0.f);
+          if (MODE == 1) { as = ldg4(a.aff_s + (16u * (ph * PT + i) + wave * (16u * HWP) + g4)); at = ldg4(a.aff_t + (16u * (ph * PT + i) + wave * (16u * HWP) + g4)); }
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) hid[rt][wave * HWP + i][lane] = to_bf16x4(swish4(MODE == 1 ? acc1[rt][i] * as + at : acc1[rt][i]));
+        }
+        __syncthreads();
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const s16x4 hv = hid[rt][(r - NB1) * 8 + u][lane];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc2[rt][j] = mfma_bf16(wa[t % NBUF][u * 2 + j], hv, acc2[rt][j]);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   f32x4 v[RT][2];
@@ -553,14 +568,14 @@ __global__ __launch_bounds__(C_NW * 64) void chain256_bf16_kernel(Chain2Args a) 
       const float rs = 1.0f / sqrtf(qt / (float)(16 * C_KB) + a.eps);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        v[rt][j] = v[rt][j] * splat4(rs) * ldg4(a.fln_g + 16 * (2 * wave + j) + g4) + ldg4(a.fln_b + 16 * (2 * wave + j) + g4);
+        v[rt][j] = v[rt][j] * splat4(rs) * ldg4(a.fln_g + (16u * (2 * wave + j) + g4)) + ldg4(a.fln_b + (16u * (2 * wave + j) + g4));
     }
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     if ((int)(blockIdx.x * RT + rt) * 16 + c < a.M) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) stg4(a.y + row_of(rt) + 16 * (2 * wave + j) + g4, v[rt][j]);
+      for (int j = 0; j < 2; ++j) stg4(a.y + (row_of(rt) + 16u * (2 * wave + j) + g4), v[rt][j]);
     }
   }
 }
@@ -583,19 +598,26 @@ int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
 
 // FFModule (mode 0) / ConvModule tail (mode 1) of dmodel 256 as one launch; w1p / w2p = the bf16 P16 fragments.  -1: no such kernel
 int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s) {
-  if (a.M <= 0) return -1;
+  if (a.M <= 0 || a.M > (1 << 22)) return -1;         // 32-bit element offsets of a row
   note_scheme(SCHEME_BF16);
   const int tiles = (a.M + 15) / 16;
   const dim3 block(C_NW * 64);
-  // two row tiles per workgroup once every CU has one anyway: half the weight traffic per row
-  if (tiles >= 512) {
+  // more row tiles per workgroup as soon as every CU has a workgroup anyway: a half / a quarter of the weight traffic per row
+  // (MI355ASR_CHAIN256_RT = 1 / 2 / 4 forces one)
+  static const int rt_env = [] { const char* v = getenv("MI355ASR_CHAIN256_RT"); return v ? atoi(v) : 0; }();
+  const int rt = rt_env ? rt_env : (tiles >= 1024 ? 4 : (tiles >= 512 ? 2 : 1));
+  if (rt == 4) {
+    const dim3 grid((tiles + 3) / 4);
+    if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 4, 4, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 4, 4, 2>), grid, block, 0, s, a);
+  } else if (rt == 2) {
     const dim3 grid((tiles + 1) / 2);
-    if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 2>), grid, block, 0, s, a);
-    return 0;
+    if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 2, 8, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 2, 4, 3>), grid, block, 0, s, a);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 1, 8, 3>), dim3(tiles), block, 0, s, a);
+    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 1, 4, 3>), dim3(tiles), block, 0, s, a);
   }
-  if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 1>), dim3(tiles), block, 0, s, a);
-  else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 1>), dim3(tiles), block, 0, s, a);
   return 0;
 }
 int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { note_scheme(SCHEME_BF16); return dispatch<PBf16>(epi, ln, a, s); }

@@ -468,8 +468,10 @@ class CTCDecoder(_ModelBase):
         return _ctc_shapes(self.dmodel, self.num_heads, self.head_size, self.kernel_size, self.num_blocks,
                            self.num_classes)
 
-    def __call__(self, inputs, training=None, mask=None, return_argmax=False):
-        """enc [B, T, dmodel] -> logits [B, T, num_classes] (torch, on device)."""
+    def __call__(self, inputs, training=None, mask=None, return_argmax=False, return_logits=True):
+        """enc [B, T, dmodel] -> logits [B, T, num_classes] (torch, on device).  return_argmax: (logits, per-frame argmax);
+        with return_logits=False the logits are never written (mi355asr_ctc_forward takes NULL: the class head keeps only its
+        running argmax -- what a greedy decode needs) and the first element is None."""
         if training:
             raise NotImplementedError("inference path only")
         h = self._h
@@ -477,11 +479,13 @@ class CTCDecoder(_ModelBase):
             self._build()
         x = h.to_device(inputs)
         B, T, _ = x.shape
-        logits = torch.empty((B, T, self.num_classes), dtype=torch.float32, device=h.device)
+        if not return_logits and not return_argmax:
+            raise ValueError("nothing to return: return_logits=False needs return_argmax=True")
+        logits = torch.empty((B, T, self.num_classes), dtype=torch.float32, device=h.device) if return_logits else None
         amax = torch.empty((B, T), dtype=torch.int32, device=h.device)
         ws, n = h.ws_for_frames(B, T)
         with torch.cuda.device(h.device):
-            _lib.check(h.lib.mi355asr_ctc_forward(h.ptr, _p(x), B, T, _p(logits), _p(amax), _p(ws), n, h._stream()))
+            _lib.check(h.lib.mi355asr_ctc_forward(h.ptr, _p(x), B, T, _p(logits) if return_logits else None, _p(amax), _p(ws), n, h._stream()))
         return (logits, amax) if return_argmax else logits
 
     def conformer_block(self, index, x):

@@ -54,7 +54,7 @@ def config3(steps, gemm_dtype):
     def full_step():
         e = enc(wav)
         h = torch.cat([history[:, 13:], e], 1)
-        _, amax = ctc(h, return_argmax=True)
+        _, amax = ctc(h, return_argmax=True, return_logits=False)
         return ctc_greedy_decode(amax, None, blank=1331)
 
     te, tf = timed(enc_step, steps), timed(full_step, steps)

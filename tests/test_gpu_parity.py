@@ -1318,6 +1318,27 @@ def test_bf16_block_matches_rounding_oracle(torch_cuda, base):
     assert np.abs(got - exact).max() > 10 * e.mean()               # it really is the bf16 path
 
 
+@pytest.mark.parametrize("base,dt,B,T", [(co.CONFORMER_S, "float32", 9, 250), (co.STREAMING_S, "bfloat16", 8, 260), (co.STREAMING_S, "float32", 2, 40)])
+def test_ctc_decoder_without_logits_returns_the_same_frame_argmax(torch_cuda, base, dt, B, T):
+    """CTCDecoder(..., return_logits=False): mi355asr_ctc_forward with logits = NULL (the class head keeps its running argmax
+    only: what the streaming "global CTC" + greedy decode of BASELINE config 3 consumes) gives the argmax of the logits the
+    same call writes otherwise -- on the fused dmodel-144 head, the ring head of dmodel 256 and the layer-at-a-time one."""
+    from tensorflowasr_amd.models import CTCDecoder
+    cfg = small_cfg(1, base)
+    w = co.ctc_decoder_weights(cfg, 300, seed=12)
+    m = CTCDecoder(num_classes=300, dmodel=cfg["dmodel"], num_blocks=cfg["ctcdecoder_num_blocks"], head_size=cfg["head_size"],
+                   num_heads=cfg["num_heads"], kernel_size=cfg.get("ctcdecoder_kernel_size", 32), fc_factor=cfg["fc_factor"], gemm_dtype=dt)
+    m.load_weights(w, by_name=False)
+    x = np.random.default_rng(T).standard_normal((B, T, cfg["dmodel"])).astype(np.float32)
+    logits, amax = m(x, return_argmax=True)
+    none, amax2 = m(x, return_argmax=True, return_logits=False)
+    assert none is None
+    assert np.array_equal(amax.cpu().numpy(), amax2.cpu().numpy())
+    assert np.array_equal(amax.cpu().numpy(), logits.cpu().numpy().argmax(-1))
+    with pytest.raises(ValueError):
+        m(x, return_logits=False)
+
+
 def test_bf16_chain256_against_layer_at_a_time(torch_cuda):
     """Round 4: in bf16 mode a dmodel-256 FFModule / ConvModule tail is ONE launch (chain256_bf16_kernel: hidden activation in
     LDS as bf16 operand fragments) instead of two gemm16 / gemm_ring launches with the fp32 hidden activation in HBM.  Same
