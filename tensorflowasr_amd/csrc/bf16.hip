@@ -380,7 +380,11 @@ void launch_layernorm_rows(float* y, const float* g, const float* b, int M, int 
 // What bounds it: a CU pulls ~40 GB/s from L2 however many loads it has in flight (measured here and in every per-wave
 // weight stream of this library: 9 TB/s over 256 CUs), and a workgroup needs all 1 MB (FFModule) of weights: 25 us at RT = 1
 // whatever the row count up to 256 tiles.  At 832 rows (52 tiles) that is what two gemm16 launches take (12.7 + 10 us: they
-// spread the weights over 832 workgroups) -- the gain there is launches (24 -> 12 per encoder pass), not time; from 512 tiles
+// spread the weights over 832 workgroups) -- the gain there is launches (24 -> 12 per encoder pass), not time (tried: four
+// workgroups per row tile with a quarter of the hidden dimension each, partial outputs summed in workgroup order by the one
+// that arrives last at a per-tile counter: with device-scope fences 27 us -- a release walks the L2 --, with relaxed
+// device-scope atomics and hand-counted waits 21 us; 2 % of the config-3 step for a protocol outside the language's memory
+// model: not kept); from 512 tiles
 // on RT = 2 halves the weight traffic per row and from 1024 tiles on RT = 4 quarters it: 16 640 rows 116 -> 68 us (RT = 2)
 // against 102-133 us for the two ring launches.
 constexpr int C_NW = 8;         // waves per workgroup, two 16-column tiles of dmodel 256 each

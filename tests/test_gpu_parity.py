@@ -1369,7 +1369,7 @@ np.savez(sys.argv[1], **out)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for tag, extra in (("chain", {}), ("layers", {"MI355ASR_CHAIN256": "0"})):
+        for tag, extra in (("chain", {}), ("layers", {"MI355ASR_CHAIN256": "0"}), ("rt1", {"MI355ASR_CHAIN256_RT": "1"}), ("rt4", {"MI355ASR_CHAIN256_RT": "4"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
             assert r.returncode == 0, r.stderr[-3000:]
@@ -1383,6 +1383,9 @@ np.savez(sys.argv[1], **out)
         # (gemm16 splits K over four waves, the ring kernels walk it in 32-wide steps: other summation orders): one bf16 ulp of
         # a hidden value each, measured mean 3e-5 -- a tenth of the distance either has from the rounding oracle
         assert d.mean() < 1e-4 and d.max() < 6e-3, k
+    # one, two or four row tiles per workgroup (four: the hidden dimension in two phases): the same summation orders, bit for bit
+    for k in res["chain"]:
+        assert np.array_equal(res["chain"][k], res["rt1"][k]) and np.array_equal(res["chain"][k], res["rt4"][k]), k
     cfg = small_cfg(1, co.STREAMING_S)
     w = co.encoder_weights(cfg, seed=5)
     x = np.random.default_rng(45).standard_normal((1, 45, cfg["dmodel"])).astype(np.float32)
