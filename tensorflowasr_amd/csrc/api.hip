@@ -441,7 +441,9 @@ long ring_min_rows() {
 }
 bool ring_packs_wanted(const mi355asr_model* m) {
   static const bool on = [] { const char* v = getenv("MI355ASR_GEMM_RING"); return v ? atoi(v) != 0 : true; }();
-  return on && m->cfg.dmodel % 128 == 0 && (m->expected_rows < 0 || m->expected_rows >= ring_min_rows());
+  // (bf16 mode, dmodel 256: chain256_bf16_kernel reads the one-term ring packs at every row count)
+  return on && m->cfg.dmodel % 128 == 0 &&
+         (m->expected_rows < 0 || m->expected_rows >= ring_min_rows() || (m->cfg.gemm_dtype == 1 && m->cfg.dmodel == 256));
 }
 void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base) {
   for (const auto& pr : ab.ring_pairs) m->ring_of[base + pr.first] = base + pr.second;
@@ -822,12 +824,14 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     // round 4: bf16 mode, dmodel 256: FFModule and ConvModule tail as ONE launch each (bf16.hip: chain256_bf16_kernel; the
     // hidden activation stays in LDS) -- MI355ASR_CHAIN256=0: one gemm16 / gemm_ring launch per layer
     static const bool chain_env = [] { const char* v = getenv("MI355ASR_CHAIN256"); return v ? atoi(v) != 0 : true; }();
-    const bool chain256 = m->cfg.gemm_dtype == 1 && d == 256 && chain_env && !cross;
+    auto ring = [&](const float* wp) -> const float* { const auto it = m->ring_of.find(wp); return it == m->ring_of.end() ? nullptr : it->second; };
+    const float* cr[6] = {ring(w.ff_w1p[0]), ring(w.ff_w2p[0]), ring(w.ff_w1p[1]), ring(w.ff_w2p[1]), ring(w.pc_w1p), ring(w.pw2_wp)};
+    const bool chain256 = m->cfg.gemm_dtype == 1 && d == 256 && chain_env && !cross && cr[0] && cr[1] && cr[2] && cr[3] && cr[4] && cr[5];
     auto ffn = [&](int i, const float* x, float* y, const float* fg, const float* fb) -> int {
       if (chain256) {
         Chain2Args ca{};
         ca.x = x; ca.res = x; ca.y = y; ca.ln_g = w.ff_ln_g[i]; ca.ln_b = w.ff_ln_b[i];
-        ca.w1p = (const float*)m->w16(w.ff_w1p[i]); ca.b1 = w.ff_b1[i]; ca.w2p = (const float*)m->w16(w.ff_w2p[i]); ca.b2 = w.ff_b2[i];
+        ca.w1p = cr[2 * i]; ca.b1 = w.ff_b1[i]; ca.w2p = cr[2 * i + 1]; ca.b2 = w.ff_b2[i];
         ca.fln_g = fg; ca.fln_b = fb; ca.scale = fc; ca.eps = kLnEps; ca.M = M;
         PROF(MI355ASR_K_FFN); LAUNCH_TRY(launch_chain256_bf16(0, ca, s), "ff module");
         return 0;
@@ -875,8 +879,8 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
     if (chain256) {
       Chain2Args ca{};
-      ca.x = sc.dw; ca.res = sc.xa; ca.y = sc.xb; ca.w1p = (const float*)m->w16(w.pc_w1p); ca.b1 = w.pc_b1; ca.aff_s = w.bn_s; ca.aff_t = w.bn_t;
-      ca.w2p = (const float*)m->w16(w.pw2_wp); ca.b2 = w.pw2_b; ca.scale = 1.0f; ca.eps = kLnEps; ca.M = M;
+      ca.x = sc.dw; ca.res = sc.xa; ca.y = sc.xb; ca.w1p = cr[4]; ca.b1 = w.pc_b1; ca.aff_s = w.bn_s; ca.aff_t = w.bn_t;
+      ca.w2p = cr[5]; ca.b2 = w.pw2_b; ca.scale = 1.0f; ca.eps = kLnEps; ca.M = M;
       { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_chain256_bf16(1, ca, s), "conv module tail"); }
       return ffn(1, sc.xb, out ? out : sc.xa, w.ln_g, w.ln_b);
     }

@@ -389,48 +389,59 @@ void launch_layernorm_rows(float* y, const float* g, const float* b, int M, int 
 // against 102-133 us for the two ring launches.
 constexpr int C_NW = 8;         // waves per workgroup, two 16-column tiles of dmodel 256 each
 constexpr int C_KB = 16;        // 16-wide k-blocks of a row
+constexpr int C_BF = 8;         // weight fragments (1 KB: 16 bytes per lane) per batch
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+DEV f32x4 mfma32_bf16(u32x4_t a, u32x4_t b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// Weights: the one-term slab-ring packs of gemm_ring.hip (api.hip: put_ring with ring_terms = 1) -- [N / 128 chunks][K / 32
+// steps][8 tiles][64 lanes][8 bf16], a lane's eight values of a 32-wide k-step being the two 16-blocks side by side, which is
+// how two accumulator-layout tiles (or two operand k-blocks) sit next to each other -- read straight from L2 with 16-byte
+// loads: a CU pulls ~145 GB/s that way and half of it with 8-byte loads (tools/ubench/l2_pull.hip; the first version of this
+// kernel read the P16 bf16 arena, 8 bytes per lane, 48 loads in flight: 45 GB/s, 23 us per FFModule at 832 rows).
 // RT row tiles per workgroup share every weight fragment; HWP hidden tiles per wave and PHASE: with RT = 4 the hidden
-// dimension goes through LDS in phases of 8 HWP = 32 tiles (GEMM1 of the phase, barrier, its 32 k-blocks of GEMM2, barrier),
+// dimension goes through LDS in phases of 8 HWP = 32 tiles (GEMM1 of the phase, barrier, its k-steps of GEMM2, barrier),
 // so that accumulators (RT x HWP tiles) and LDS (RT x 32 tiles) stay the size they have at RT = 2.  PF weight batches are in
 // flight ahead of the one being multiplied.
+DEV unsigned ring_frag(unsigned tile, unsigned step, unsigned steps) { return (((tile >> 3) * steps + step) * 8 + (tile & 7)) * 64; }
 template <int HT, int MODE, int RT, int HWP, int PF>
 __global__ __launch_bounds__(C_NW * 64) void chain256_bf16_kernel(Chain2Args a) {
   constexpr int PT = C_NW * HWP;      // hidden tiles per phase
   constexpr int NPH = HT / PT;        // phases
-  constexpr int G1 = 16 / HWP;        // k-blocks per fragment batch of GEMM1 (sixteen fragments a batch)
-  constexpr int NB1 = C_KB / G1, NB2 = PT / 8, NBP = NB1 + NB2, NB = NPH * NBP, NBUF = PF + 1;
-  static_assert(HT % PT == 0 && 16 % HWP == 0 && PT % 8 == 0, "phases of whole batches");
-  __shared__ s16x4 hid[RT][PT][64];
-  __shared__ s16x4 xl[RT > 1 ? RT : 1][RT > 1 ? C_KB : 1][64];      // RT > 1: the operand rows, converted once by waves 0 .. RT - 1
+  constexpr int G1 = C_BF / HWP;      // 32-wide k-steps per fragment batch of GEMM1
+  constexpr int NB1 = (C_KB / 2) / G1, NB2 = (PT / 2) / 4, NBP = NB1 + NB2, NB = NPH * NBP, NBUF = PF + 1;
+  static_assert(HT % PT == 0 && C_BF % HWP == 0 && PT % 8 == 0, "phases of whole batches");
+  __shared__ __attribute__((aligned(16))) u32x4_t hid[RT][PT / 2][64];      // pairs of hidden tiles: one GEMM2 operand each
+  __shared__ __attribute__((aligned(16))) u32x4_t xl[RT > 1 ? RT : 1][RT > 1 ? C_KB / 2 : 1][64];      // RT > 1: the operand rows, converted once by waves 0 .. RT - 1
   __shared__ float stat[2][C_NW][RT][16];
   // unsigned index arithmetic throughout: scalar base + 32-bit vector offset addressing (a signed index costs a sign-extended
   // 64-bit address pair per load)
   const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned g4 = (lane >> 4) * 4;
   const int c = (int)(lane & 15);
-  // uniform fragment index + lane: scalar base, one vector offset for every load
-  const s16x4* __restrict__ w1 = reinterpret_cast<const s16x4*>(a.w1p);
-  const s16x4* __restrict__ w2 = reinterpret_cast<const s16x4*>(a.w2p);
+  const u32x4_t* __restrict__ w1 = reinterpret_cast<const u32x4_t*>(a.w1p);
+  const u32x4_t* __restrict__ w2 = reinterpret_cast<const u32x4_t*>(a.w2p);
   // 32-bit element offsets (the launcher bounds M): scalar base + one offset register per row tile, nothing to keep in pairs
   auto row_of = [&](int rt) -> unsigned { return (unsigned)min((int)(blockIdx.x * RT + rt) * 16 + c, a.M - 1) * (16u * C_KB); };
-  s16x4 wa[NBUF][16];
-  // batch t of the stream: phase t / NBP; inside it NB1 batches of W1 (k-blocks G1 r .. for this wave's HWP hidden tiles of
-  // the phase), then NB2 batches of W2 (eight k-blocks of the phase each, for this wave's two column tiles)
-  auto load = [&](int t, s16x4 (&w)[16]) {
+  u32x4_t wa[NBUF][C_BF];
+  // batch t of the stream: phase t / NBP; inside it NB1 batches of W1 (G1 k-steps for this wave's HWP hidden tiles of the
+  // phase), then NB2 batches of W2 (four k-steps = four hidden tile pairs of the phase, for this wave's two column tiles)
+  auto load = [&](int t, u32x4_t (&w)[C_BF]) {
     const int ph = t / NBP, r = t % NBP;
     if (r < NB1) {
 #pragma unroll
       for (int u = 0; u < G1; ++u)
 #pragma unroll
-        for (int i = 0; i < HWP; ++i) w[u * HWP + i] = w1[(unsigned)((r * G1 + u) * HT + ph * PT + i) * 64u + wave * (HWP * 64u) + lane];
+        for (int i = 0; i < HWP; ++i) w[u * HWP + i] = w1[ring_frag(ph * PT + wave * HWP + i, r * G1 + u, C_KB / 2) + lane];
     } else {
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) w[u * 2 + j] = w2[(unsigned)((ph * PT + (r - NB1) * 8 + u) * 16 + j) * 64u + wave * 128u + lane];
+        for (int j = 0; j < 2; ++j) w[u * 2 + j] = w2[ring_frag(2 * wave + j, ph * (PT / 2) + (r - NB1) * 4 + u, HT / 2) + lane];
     }
   };
-  s16x4 xb[C_KB];
+  u32x4_t xb[C_KB / 2];
   if (RT == 1 || wave < RT) {
     const unsigned row = row_of(RT == 1 ? 0 : wave);
     f32x4 xr[C_KB];
@@ -454,15 +465,17 @@ __global__ __launch_bounds__(C_NW * 64) void chain256_bf16_kernel(Chain2Args a) 
       }
       const float rstd = 1.0f / sqrtf(group_sum(q) / (float)(16 * C_KB) + a.eps);
 #pragma unroll
-      for (int i = 0; i < C_KB; ++i)
-        xb[i] = to_bf16x4((xr[i] - splat4(mean)) * splat4(rstd) * ldg4(a.ln_g + (16u * i + g4)) + ldg4(a.ln_b + (16u * i + g4)));
-    } else {
+      for (int i = 0; i < C_KB; ++i) xr[i] = (xr[i] - splat4(mean)) * splat4(rstd) * ldg4(a.ln_g + (16u * i + g4)) + ldg4(a.ln_b + (16u * i + g4));
+    }
 #pragma unroll
-      for (int i = 0; i < C_KB; ++i) xb[i] = to_bf16x4(xr[i]);
+    for (int i = 0; i < C_KB / 2; ++i) {
+      const s16x4 lo = to_bf16x4(xr[2 * i]), hi = to_bf16x4(xr[2 * i + 1]);
+      const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+      xb[i] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
     }
     if (RT > 1) {
 #pragma unroll
-      for (int i = 0; i < C_KB; ++i) xl[wave][i][lane] = xb[i];
+      for (int i = 0; i < C_KB / 2; ++i) xl[wave][i][lane] = xb[i];
     }
   }
   if (RT > 1) {
@@ -501,34 +514,36 @@ __global__ __launch_bounds__(C_NW * 64) void chain256_bf16_kernel(Chain2Args a) 
     if (r < NB1) {
 #pragma unroll
       for (int u = 0; u < G1; ++u) {
-        s16x4 xv[RT];
+        u32x4_t xv[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) xv[rt] = RT > 1 ? xl[rt][r * G1 + u][lane] : xb[r * G1 + u];
 #pragma unroll
         for (int i = 0; i < HWP; ++i)
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = mfma_bf16(wa[t % NBUF][u * HWP + i], xv[rt], acc1[rt][i]);
+          for (int rt = 0; rt < RT; ++rt) acc1[rt][i] = mfma32_bf16(wa[t % NBUF][u * HWP + i], xv[rt], acc1[rt][i]);
       }
       if (r == NB1 - 1) {
-        // the phase's hidden tiles -> LDS (a later phase: once every wave has read the previous one's)
+        // the phase's hidden tiles -> LDS (a later phase: once every wave has read the previous one's), tile 2 p and 2 p + 1
+        // side by side: one 16-byte operand of GEMM2
         if (ph > 0) __syncthreads();
 #pragma unroll
         for (int i = 0; i < HWP; ++i) {
           f32x4 as = splat4(1.f), at = splat4(0.f);
           if (MODE == 1) { as = ldg4(a.aff_s + (16u * (ph * PT + i) + wave * (16u * HWP) + g4)); at = ldg4(a.aff_t + (16u * (ph * PT + i) + wave * (16u * HWP) + g4)); }
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) hid[rt][wave * HWP + i][lane] = to_bf16x4(swish4(MODE == 1 ? acc1[rt][i] * as + at : acc1[rt][i]));
+          for (int rt = 0; rt < RT; ++rt)
+            reinterpret_cast<s16x4*>(&hid[rt][(wave * HWP + i) >> 1][lane])[i & 1] = to_bf16x4(swish4(MODE == 1 ? acc1[rt][i] * as + at : acc1[rt][i]));
         }
         __syncthreads();
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const s16x4 hv = hid[rt][(r - NB1) * 8 + u][lane];
+          const u32x4_t hv = hid[rt][(r - NB1) * 4 + u][lane];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc2[rt][j] = mfma_bf16(wa[t % NBUF][u * 2 + j], hv, acc2[rt][j]);
+          for (int j = 0; j < 2; ++j) acc2[rt][j] = mfma32_bf16(wa[t % NBUF][u * 2 + j], hv, acc2[rt][j]);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -600,7 +615,7 @@ int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
   return 0;
 }
 
-// FFModule (mode 0) / ConvModule tail (mode 1) of dmodel 256 as one launch; w1p / w2p = the bf16 P16 fragments.  -1: no such kernel
+// FFModule (mode 0) / ConvModule tail (mode 1) of dmodel 256 as one launch; w1p / w2p = the one-term slab-ring packs.  -1: no such kernel
 int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s) {
   if (a.M <= 0 || a.M > (1 << 22)) return -1;         // 32-bit element offsets of a row
   note_scheme(SCHEME_BF16);
@@ -617,10 +632,10 @@ int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s) {
   } else if (rt == 2) {
     const dim3 grid((tiles + 1) / 2);
     if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 2, 8, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 2, 4, 3>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 2, 4, 2>), grid, block, 0, s, a);
   } else {
-    if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 1, 8, 3>), dim3(tiles), block, 0, s, a);
-    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 1, 4, 3>), dim3(tiles), block, 0, s, a);
+    if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 1, 8, 2>), dim3(tiles), block, 0, s, a);
+    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 1, 4, 2>), dim3(tiles), block, 0, s, a);
   }
   return 0;
 }
