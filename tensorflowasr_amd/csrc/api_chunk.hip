@@ -64,6 +64,12 @@ StackOff pack_stack(mi355asr_model* m, ArenaBuilder& ab, const std::string& pref
     const auto& pj = m->host[prefix + "/project/kernel"].data;
     so.proj_w = ab.put(pack_p16([&](int k, int n) { return pj[(size_t)k * d + n]; }, d, d, d / 16));
     so.proj_b = ab.put(m->host[prefix + "/project/bias"].data);
+    if (d == 144) {
+      const auto& pb = m->host[prefix + "/project/bias"].data;
+      std::vector<float> pp;
+      so.proj_pp_sw = append_pp_plain(pp, [&](int k, int n) { return k < d ? pj[(size_t)k * d + n] : pb[n]; }, 1);
+      so.proj_pp = ab.put(pp);
+    }
   }
   for (int i = 0; i < nblocks; ++i)
     so.blocks.push_back(pack_block(m, ab, prefix + "/" + blk + std::to_string(i), d, c.num_heads, c.head_size,
@@ -84,22 +90,35 @@ StackOff pack_stack(mi355asr_model* m, ArenaBuilder& ab, const std::string& pref
 
 // Dense(d->d) [+ blocks] [+ Dense(d->V) with argmax]; input rows at `in`, blocks run in sc.xa
 // On return the stack's hidden output is in sc.xa (sc is updated: the blocks ping-pong xa/xb).
+// `front` (round 4): a plain layer the caller left to this stack's first block (the chunk front's subsampling Dense: BlockOpts::pre_*
+// of the stack's options filled in; `in` is not read then).  A stack's own projection takes the same route when it can.
 int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int B, int T, Scratch& sc,
-              float* logits, int32_t* amax, hipStream_t s) {
+              float* logits, int32_t* amax, hipStream_t s, const BlockOpts* front = nullptr) {
   const int d = m->cfg.dmodel;
   const int M = B * T;
-  if (st.proj_wp) {
-    GemmArgs pr{};
-    pr.x = in; pr.y = sc.xa; pr.wp = st.proj_wp; pr.bias = st.proj_b;
-    pr.M = M; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
-    { PROF(MI355ASR_K_CTC_PROJECT); LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "project"); }
+  BlockOpts first = front ? *front : st.opts;
+  if (!front && st.proj_wp && st.proj_pp && !st.blocks.empty() && block_takes_pre(m, st.blocks[0], (size_t)M)) {
+    first.pre_x = in; first.pre_pp = st.proj_pp; first.pre_sw = st.proj_pp_sw; first.pre_chunks = 1;
+  }
+  if (first.pre_pp) {
+  } else if (st.proj_wp) {
+    // on its own: the same two-term stream through pp_sublinear_kernel (bit-identical to the folded form), else fp32 MFMA
+    StreamGemmArgs sp{};
+    sp.x = in; sp.y = sc.xa; sp.M = M; sp.K = d; sp.NT = d / 16; sp.ldy = d; sp.n_valid = d;
+    PROF(MI355ASR_K_CTC_PROJECT);
+    if (!(st.proj_pp && m->cfg.gemm_dtype == 0 && !gemm16_for(m, (size_t)M) && launch_pp_sublinear(sp, st.proj_pp, st.proj_pp_sw, s) == 0)) {
+      GemmArgs pr{};
+      pr.x = in; pr.y = sc.xa; pr.wp = st.proj_wp; pr.bias = st.proj_b;
+      pr.M = M; pr.NT = d / 16; pr.ldy = d; pr.n_valid = d; pr.eps = kLnEps;
+      LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "project");
+    }
   } else if (in != sc.xa) {
     HIP_TRY(hipMemcpyAsync(sc.xa, in, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
   }
   bool ff1_done = false;                    // the tail of block i also runs ff_module_1 + qkv of block i + 1 (model.h)
   for (size_t i = 0; i < st.blocks.size(); ++i) {
     const bool skip = ff1_done;
-    int rc = run_block(m, st.blocks[i], st.opts, sc, B, T, nullptr, s, nullptr,
+    int rc = run_block(m, st.blocks[i], i == 0 ? first : st.opts, sc, B, T, nullptr, s, nullptr,
                        i + 1 < st.blocks.size() ? &st.blocks[i + 1] : nullptr, &ff1_done, skip);
     if (rc) return rc;
   }
@@ -124,6 +143,8 @@ void resolve_stack(StackDev& sd, const StackOff& so, const float* base, bool pro
   sd.blocks.clear();
   for (const auto& o : so.blocks) sd.blocks.push_back(resolve(o, base));
   if (project) { sd.proj_wp = base + so.proj_w; sd.proj_b = base + so.proj_b; }
+  sd.proj_pp = (project && so.proj_pp) ? base + so.proj_pp : nullptr;
+  sd.proj_pp_sw = so.proj_pp_sw;
   if (V > 0) { sd.fc_wp = base + so.fc_w; sd.fc_b = base + so.fc_b; sd.NT_fc = so.NT_fc; sd.num_classes = V; }
 }
 
@@ -429,6 +450,8 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
   Scratch sc{(float*)(ws + p.xa), (float*)(ws + p.xb), (float*)(ws + p.qkv),
              (float*)(ws + p.ctx), (float*)(ws + p.u), (float*)(ws + p.dw)};
   sc.h4 = (float*)(ws + p.h4);
+  BlockOpts enc_front;
+  bool dense_deferred = false;
   // ---- front: valid Melspectrogram (log10, no max-normalisation) + left-padded VALID ConvSubsampling
   {
     const int FT = ceil_div(g.F, 16);
@@ -467,7 +490,14 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     StreamGemmArgs lg{};
     lg.x = sa.out; lg.y = sc.xa; lg.wp = m->lin_wp; lg.bias = m->lin_b;
     lg.M = B * T; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.ldy = d; lg.n_valid = d;
-    {
+    // round 4: the Dense rides in the encoder's first ff_module_1 + qkv launch when both run on the two-term stream and
+    // nobody asked for the front's output (as encoder_impl in api.hip)
+    if (!outs->front_out && !m->c_enc.proj_wp && !m->c_enc.blocks.empty() && m->lin_wsplit && lg.M >= 4096 && m->lin_pp &&
+        pp_sublinear_ok(lg, m->lin_pp) && block_takes_pre(m, m->c_enc.blocks[0], (size_t)lg.M)) {
+      enc_front = m->c_enc.opts;
+      enc_front.pre_x = sa.out; enc_front.pre_pp = m->lin_pp; enc_front.pre_sw = m->lin_pp_sw; enc_front.pre_chunks = m->dm.F2;
+      dense_deferred = true;
+    } else {
       PROF(MI355ASR_K_SUBLINEAR);
       // the split-bf16 ring-DMA Dense from 4096 rows on (as run_subsampling in api.hip), else the fp32-MFMA stream kernel
       // (round 4: the two-term stream with a scale per token and 144-wide chunk first, as run_subsampling in api.hip)
@@ -478,7 +508,7 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
   }
   if (outs->front_out) HIP_TRY(hipMemcpyAsync(outs->front_out, sc.xa, act, hipMemcpyDeviceToDevice, s));
   // ---- encoder
-  rc = run_stack(m, m->c_enc, sc.xa, B, T, sc, nullptr, nullptr, s);
+  rc = run_stack(m, m->c_enc, sc.xa, B, T, sc, nullptr, nullptr, s, dense_deferred ? &enc_front : nullptr);
   if (rc) return rc;
   if (outs->enc_out) HIP_TRY(hipMemcpyAsync(outs->enc_out, sc.xa, act, hipMemcpyDeviceToDevice, s));
   // ---- phone picker: logits (optional) + per-frame argmax, hidden = block output

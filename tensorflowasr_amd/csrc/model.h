@@ -94,6 +94,8 @@ struct StackDev {
   std::vector<BlockDev> blocks;
   const float *proj_wp = nullptr, *proj_b = nullptr, *fc_wp = nullptr, *fc_b = nullptr;
   int NT_fc = 0, num_classes = 0;
+  const float* proj_pp = nullptr;      // the projection as a two-term stream: rides in the first block's ff_module_1 + qkv launch
+  float proj_pp_sw = 1.f;
   BlockOpts opts;
 };
 
@@ -273,6 +275,8 @@ struct StackOff {
   std::vector<BlockOff> blocks;
   size_t proj_w = 0, proj_b = 0, fc_w = 0, fc_b = 0;
   int NT_fc = 0;
+  size_t proj_pp = 0;      // dmodel 144: [W ; b] of the projection as a two-term stream (append_pp_plain), 0 = none
+  float proj_pp_sw = 1.f;
 };
 
 // ---- shared host functions (defined in api.hip) -----------------------------------------------------------
@@ -311,6 +315,7 @@ int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, cons
 int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int B, int T, float* out,
               hipStream_t s, const CrossAttn* cross = nullptr, const BlockDev* next = nullptr, bool* ff1_done = nullptr,
               bool skip_ff1 = false);
+float append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups);   // api.hip
 bool block_takes_pre(const mi355asr_model* m, const BlockDev& w, size_t M);   // run_block(w, M rows) can take BlockOpts::pre_*
 void resolve_stack(StackDev& sd, const StackOff& so, const float* base, bool project, int V);   // api_chunk.hip
 int finalize_chunk(mi355asr_model* m, hipStream_t s);        // api_chunk.hip

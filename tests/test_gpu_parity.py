@@ -324,8 +324,8 @@ def test_layer_in_front_of_a_block_in_its_first_launch_bit_for_bit(torch_cuda):
     (conformer_blocks.py:631) run in the prologue of the first block's ff_module_1 + qkv launch (pp_block_kernel<..., PRE>): the
     layer's two-term stream flows through the ring in front of the block's, x0 stays in registers.  Same units in the same
     order as pp_sublinear_kernel: encoder output, logits and token ids BIT-IDENTICAL to MI355ASR_PP_PRE=0 (layers as their
-    own launches), at 5000 rows (row count not a multiple of 64: a partly idle last workgroup) and at 16 x 250 rows; and both
-    within the usual tolerance of the oracle."""
+    own launches), at 5000 rows (row count not a multiple of 64: a partly idle last workgroup) and at 16 x 250 rows; the same for
+    the ChunkConformer's predict (front Dense + the three stack projections); and both within the usual tolerance of the oracle."""
     import subprocess
     import sys
     import tempfile
@@ -347,6 +347,17 @@ for tag, B, L in (("a", 20, 160000), ("b", 17, 159000)):
     ids, lens = m.recognize(x)
     out[tag + "_enc"] = enc.cpu().numpy(); out[tag + "_logits"] = logits.cpu().numpy()
     out[tag + "_ids"] = ids.cpu().numpy(); out[tag + "_lens"] = lens.cpu().numpy()
+# the ChunkConformer's offline predict: the front's Dense in the encoder's first block, the projections of the phone picker, the
+# context helper and the text decoder in theirs (4 250 rows; picked frames: whatever the picker keeps)
+from helpers import chunk_config_dict
+from tensorflowasr_amd.models import ChunkConformer
+c5 = dict(co.CHUNK_S, enc_num_blocks=2, picker_num_blocks=1, helper_num_blocks=1, decoder_num_blocks=1)
+w5 = co.chunk_weights(c5, seed=4)
+mc = ChunkConformer(chunk_config_dict(c5), c5["picker_num_classes"], c5["decoder_num_classes"])
+mc.load_weights(w5, by_name=False)
+got = mc.predict(waves(17, 160000, 9), stages=True)
+out["chunk_enc"] = got["enc"].cpu().numpy()
+out["chunk_text"] = got["text_logits"].cpu().numpy()
 np.savez(sys.argv[1], **out)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
