@@ -808,6 +808,33 @@ def test_round4_profile_artifacts_bench_line_and_library_reported_schemes():
     assert abs(t - bench["kernels"]["tail_ff1"]["avg_ms"] * 1e3) / t < 0.15
 
 
+def test_round4_final_profile_artifacts_36_launches_and_config3_below_a_millisecond():
+    """profiles/r04z_* (the round's last build): the subsampling Dense and the CTC projection are no kernels of their own any more
+    (36 launches per step, 38 before: counted from the trace), config 3 runs below a
+    millisecond on the dmodel-256 chain kernel, which its trace shows."""
+    import csv
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from summarize_rocprof import category
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r04z_kernel_stats.csv"))))
+    calls = {}
+    for r in rows:
+        calls[category(r["Name"])] = calls.get(category(r["Name"]), 0) + int(r["Calls"])
+    assert "sublinear" not in calls and "ctc_project" not in calls and "out_glu" not in calls and "dwconv" not in calls
+    steps = calls["subconv"]
+    per_step = {k: v // steps for k, v in calls.items() if k in _lib.KERNEL_NAMES}
+    assert per_step["attention"] == 14 and per_step["tail_ff1"] == 12 and per_step["tail_ff2"] == 2 and per_step["ff1_qkv"] == 2
+    assert sum(per_step.values()) == 36                # stft, utt_max, mel, subconv, 2 + 14 + 12 + 2 of the blocks, head, collapse
+    bench = json.loads(open(os.path.join(ROOT, "profiles", "r04z_final_bench_n1.json")).read().strip().splitlines()[-1])
+    assert bench["ms_per_step"] < 2.05 and bench["roofline"]["kernel"] == "tail_ff1" and bench["latency_b1"]["ms"] < 1.3
+    assert "sublinear" not in bench["kernels"] and "ctc_project" not in bench["kernels"]
+    assert bench["config3"]["ms_per_step"] < 0.95 and bench["config5"]["ms_predict"] < 2.7
+    c3 = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r04z_config3_kernel_stats.csv"))))
+    chain = [r for r in c3 if "chain256_bf16_kernel" in r["Name"]]
+    assert len(chain) == 4 and all(float(r["AverageNs"]) < 60e3 for r in chain)          # FFModule / conv tail at 832 and at 16 640 rows
+    assert not any("gemm_ring_kernel<1," in r["Name"] or "gemm_ring_kernel<5," in r["Name"] for r in c3)     # no per-layer FFN / conv-tail first layer left
+
+
 def test_pair_pipelined_stream_generator_simulates_and_matches_the_committed_sources():
     """tools/gen_pp.py describes the pair-pipelined fragment stream of fused_pp.hip once; its simulator replays every unit
     (fragment reads into pool slots, counted lgkmcnt waits, MFMAs, ring-slot hand-overs) and the committed device code
