@@ -276,9 +276,10 @@ DEV f32x4 mma_terms(u32x4 w, u32x4 x, f32x4 c) {
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
 }
 
+template <int RTN>
 struct SplitLane {
-  int mb[SRT];                // float offset of the lane's 7x7 mel window in the LDS patch, per row tile
-  unsigned valid[SRT];        // bit kt*3+kf: conv1 position inside [0,T1) x [0,F1)
+  int mb[RTN];                // float offset of the lane's 7x7 mel window in the LDS patch, per row tile
+  unsigned valid[RTN];        // bit kt*3+kf: conv1 position inside [0,T1) x [0,F1)
 };
 
 // conv1 + ReLU (+ conv2's zero padding) at tap q for channels 16 cb + 4 g .. + 3 of row tile rt
@@ -288,8 +289,8 @@ struct SplitLane {
 // conflicts, 25 % of the kernel's LDS cycles); RS.row = 4 seg + pad with 4 RS.row = 20 (mod 32), so that a tile that wraps
 // into the next output row (f2: 19 -> 0, + 4 patch rows) continues on the next banks as well.
 struct PatchGeom { int row, seg; };
-template <int Q, int DIAG = 0>
-DEV f32x4 conv1_at(const float* melp, PatchGeom RS, const SplitLane& sl, int rt, const f32x4 (&w1r)[9], f32x4 b1v) {
+template <int Q, int DIAG = 0, class SL>
+DEV f32x4 conv1_at(const float* melp, PatchGeom RS, const SL& sl, int rt, const f32x4 (&w1r)[9], f32x4 b1v) {
   constexpr int kt = Q / 3, kf = Q % 3;
   f32x4 v = b1v;
   int off = sl.mb[rt];
@@ -311,10 +312,10 @@ DEV f32x4 conv1_at(const float* melp, PatchGeom RS, const SplitLane& sl, int rt,
   return v;
 }
 
-template <int PAIR, int DIAG = 0, int TM = 3>
-DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, const SplitLane& sl, const f32x4 (&w1r)[9], f32x4 b1v) {
+template <int PAIR, int DIAG = 0, int TM = 3, int RTN>
+DEV void frags_for(SplitFrag (&xf)[RTN], const float* melp, PatchGeom RS, const SplitLane<RTN>& sl, const f32x4 (&w1r)[9], f32x4 b1v) {
 #pragma unroll
-  for (int rt = 0; rt < SRT; ++rt) {
+  for (int rt = 0; rt < RTN; ++rt) {
     const f32x4 lo = conv1_at<2 * PAIR, DIAG>(melp, RS, sl, rt, w1r, b1v);
     const f32x4 hi = conv1_at<2 * PAIR + 1, DIAG>(melp, RS, sl, rt, w1r, b1v);
     if constexpr (DIAG == 6) {               // no split: the raw bits as three "terms"
@@ -328,23 +329,23 @@ DEV void frags_for(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, const 
 
 // operand of a ninth-tap step: conv1 at tap 8 for channel block cbA (slots 0..3) and cbA + 1 (slots 4..7; zeros past the
 // last block); the conv1 taps of the two blocks pass through the same registers one after the other
-template <int DIAG, int TM, class LT>
-DEV void frags_ninth(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, const SplitLane& sl, f32x4 (&w1r)[9], const float* p_b1,
+template <int DIAG, int TM, class LT, int RTN>
+DEV void frags_ninth(SplitFrag (&xf)[RTN], const float* melp, PatchGeom RS, const SplitLane<RTN>& sl, f32x4 (&w1r)[9], const float* p_b1,
                      int g4, int cbA, int KBn, LT&& load_taps) {
-  f32x4 lo[SRT], hi[SRT];
+  f32x4 lo[RTN], hi[RTN];
   load_taps(cbA);
 #pragma unroll
-  for (int rt = 0; rt < SRT; ++rt) lo[rt] = conv1_at<8, DIAG>(melp, RS, sl, rt, w1r, lds4(p_b1, cbA, g4));
+  for (int rt = 0; rt < RTN; ++rt) lo[rt] = conv1_at<8, DIAG>(melp, RS, sl, rt, w1r, lds4(p_b1, cbA, g4));
   if (cbA + 1 < KBn) {
     load_taps(cbA + 1);
 #pragma unroll
-    for (int rt = 0; rt < SRT; ++rt) hi[rt] = conv1_at<8, DIAG>(melp, RS, sl, rt, w1r, lds4(p_b1, cbA + 1, g4));
+    for (int rt = 0; rt < RTN; ++rt) hi[rt] = conv1_at<8, DIAG>(melp, RS, sl, rt, w1r, lds4(p_b1, cbA + 1, g4));
   } else {
 #pragma unroll
-    for (int rt = 0; rt < SRT; ++rt) hi[rt] = splat4(0.f);
+    for (int rt = 0; rt < RTN; ++rt) hi[rt] = splat4(0.f);
   }
 #pragma unroll
-  for (int rt = 0; rt < SRT; ++rt) xf[rt] = split_terms<TM>(lo[rt], hi[rt]);
+  for (int rt = 0; rt < RTN; ++rt) xf[rt] = split_terms<TM>(lo[rt], hi[rt]);
 }
 
 // DIAG != 0: timing experiments only (results are wrong): 1 = no conv1 / split work, 2 = one weight-fragment read per
@@ -355,7 +356,9 @@ DEV void frags_ninth(SplitFrag (&xf)[SRT], const float* melp, PatchGeom RS, cons
 // MFMA ratio per step as at 144.  Weight fragments: [chunk][step][NBW tiles][3 terms][64 lanes][8].
 // TM = 3: bf16 terms (exact), six products; TM = 2: fp16 terms, three products (see split8h): a.w2h, conv1 scaled by a.h_scale
 // (folded into the staged conv1 kernel and bias: relu(s v) = s relu(v)), accumulators in units of h_scale * h_wscale.
-template <int DIAG, int DM, int NBW, int TM = 3>
+// RTN row tiles of 16 positions per wave: two for whole utterances; one for the streaming shapes (260 positions per chunk: the
+// second 256-position workgroup of a chunk would hold four positions and take as long as the first)
+template <int DIAG, int DM, int NBW, int TM = 3, int RTN = SRT>
 __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, PatchGeom RS, int rows) {
   static_assert(TM == 3 || DIAG == 0, "the timing variants are those of the three-term kernel");
   constexpr int KB = DM / 16, NB = NBW, NI = ninth_steps(KB), NK32 = KB * NPAIR + NI, SLABF = NBW * TM * 64, D = DM;
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   __shared__ __attribute__((aligned(16))) float p_w1[9 * D], p_b1[D], p_b2[D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g4 = (lane >> 4) * 4, c = lane & 15;
-  const int b = blockIdx.y, r0 = blockIdx.x * SPOSG, PU = a.T2 * a.F2;
+  const int b = blockIdx.y, r0 = blockIdx.x * (SCW * 16 * RTN), PU = a.T2 * a.F2;
   const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(TM == 2 ? a.w2h : a.w2s) + (size_t)blockIdx.z * NK32 * SLABF;
   float s1 = TM == 2 ? a.h_scale : 1.f;
   if (TM == 2 && a.h_melmax) {                   // features without a static bound: the scale from the batch's own maximum
@@ -395,10 +398,10 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   }
   for (int i = threadIdx.x; i < 9 * D; i += SCT) p_w1[i] = a.w1[i] * s1;
   for (int i = threadIdx.x; i < D; i += SCT) { p_b1[i] = a.b1[i] * s1; p_b2[i] = a.b2[i] * s2; }
-  SplitLane sl;
+  SplitLane<RTN> sl;
 #pragma unroll
-  for (int rt = 0; rt < SRT; ++rt) {
-    const int r = min(r0 + 32 * wave + 16 * rt + c, PU - 1);
+  for (int rt = 0; rt < RTN; ++rt) {
+    const int r = min(r0 + 16 * RTN * wave + 16 * rt + c, PU - 1);
     const int t2 = r / a.F2, f2 = r - t2 * a.F2;
     sl.mb[rt] = 4 * (t2 - t2a) * RS.row + f2;
     unsigned vm = 0;
@@ -418,22 +421,22 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   }
   __syncthreads();
 
-  f32x4 acc[SRT][NB];
+  f32x4 acc[RTN][NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n) {
     const f32x4 bv = lds4(p_b2, c0 + n, g4);
 #pragma unroll
-    for (int rt = 0; rt < SRT; ++rt) acc[rt][n] = bv;
+    for (int rt = 0; rt < RTN; ++rt) acc[rt][n] = bv;
   }
   f32x4 w1r[9];
   auto load_taps = [&](int cb) {
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) w1r[tp] = *reinterpret_cast<const f32x4*>(p_w1 + tp * D + 16 * cb + g4);
   };
-  SplitFrag xa[SRT];
+  SplitFrag xa[RTN];
   if constexpr (DIAG == 1) {
 #pragma unroll
-    for (int rt = 0; rt < SRT; ++rt)
+    for (int rt = 0; rt < RTN; ++rt)
 #pragma unroll
       for (int t = 0; t < 3; ++t) xa[rt].t[t] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   }
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
 #pragma unroll
               for (int h = 0; h < G; ++h)
 #pragma unroll
-                for (int rt = 0; rt < SRT; ++rt)
+                for (int rt = 0; rt < RTN; ++rt)
                   acc[rt][gi * G + h] = mma_terms<TM>(w[h][ord - p], xa[rt].t[p], acc[rt][gi * G + h]);
         };
         fetch(wa, std::integral_constant<int, 0>{});
@@ -583,8 +586,8 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   else run(std::integral_constant<bool, false>{});
   const float inv2 = 1.0f / s2;            // a power of two
 #pragma unroll
-  for (int rt = 0; rt < SRT; ++rt) {
-    const int r = r0 + 32 * wave + 16 * rt + c;
+  for (int rt = 0; rt < RTN; ++rt) {
+    const int r = r0 + 16 * RTN * wave + 16 * rt + c;
     if (r < PU) {
       float* orow = a.out + ((size_t)b * PU + r) * D;
 #pragma unroll
@@ -610,10 +613,19 @@ int launch_subconv144(const SubConvArgs& a, hipStream_t s) {
 // split-bf16 kernel for dmodel 144 / 256 / 512; returns -1 when the shape does not fit its LDS mel patch or the dmodel has
 // no instantiation (the caller falls back)
 template <int DIAG>
-static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGeom RS, int rows, hipStream_t s) {
+static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGeom RS, int rows, hipStream_t s, int rtn = SRT) {
   const dim3 g128(g144.x, g144.y, d / 128);
   note_scheme(SCHEME_BF16X3);
   if constexpr (DIAG == 0) {
+    if (a.w2h && rtn == 1) {
+      note_scheme(SCHEME_F16X2);
+      switch (d) {
+        case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2, 1>), g144, dim3(SCT), 0, s, a, RS, rows); return 0;
+        case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 256, 8, 2, 1>), g128, dim3(SCT), 0, s, a, RS, rows); return 0;
+        case 512: hipLaunchKernelGGL((subconv_split_ring_kernel<0, 512, 8, 2, 1>), g128, dim3(SCT), 0, s, a, RS, rows); return 0;
+        default: return -1;
+      }
+    }
     if (a.w2h) {
       note_scheme(SCHEME_F16X2);
       switch (d) {
@@ -640,10 +652,19 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
   RS.seg = a.F2 + 1;
   RS.row = 4 * RS.seg;
   while (RS.row % 8 != 5) ++RS.row;
-  const int span = (SPOSG - 1 + a.F2 - 1) / a.F2;            // t2 steps a tile can touch beyond its first
+  // One row tile per wave (128 positions per workgroup) while that still gives no CU a second workgroup -- single utterances:
+  // one to four 10 s utterances per call 1.226 / 1.233 / 1.243 -> 1.197 / 1.202 / 1.208 ms.  (The streaming shapes -- 64 chunks
+  // x 260 positions, of whose 2 x 64 x 2 workgroups every second one holds four positions -- do NOT gain: 384 workgroups of 128
+  // positions take 159 us where the 256 took 134; a workgroup's time is its 41 steps, not its row tiles.)  Two-term kernels
+  // only.  MI355ASR_SUBCONV_RT=1 / 2 forces one.
+  static const int rt_env = [] { const char* v = getenv("MI355ASR_SUBCONV_RT"); return v ? atoi(v) : 0; }();
+  const long wg1 = (long)((PU + SPOSG / 2 - 1) / (SPOSG / 2)) * a.B * (d == 144 ? 1 : d / 128);
+  const int rtn = (a.w2h && (rt_env == 1 || (rt_env == 0 && wg1 <= 256))) ? 1 : SRT;
+  const int posg = SCW * 16 * rtn;
+  const int span = (posg - 1 + a.F2 - 1) / a.F2;            // t2 steps a tile can touch beyond its first
   const int rows = 4 * span + 7;
   if ((!a.w2s && !a.w2h) || a.st1 != 2 || rows * RS.row > MELP || PU <= 0) return -1;
-  const dim3 grid((PU + SPOSG - 1) / SPOSG, a.B);
+  const dim3 grid((PU + posg - 1) / posg, a.B);
 #ifdef MI355ASR_DIAG_KERNELS
   // timing-only variants (wrong results), compiled in with -DMI355ASR_DIAG_KERNELS: see the DIAG comment above
   static const int diag = [] {
@@ -652,6 +673,7 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
     if (d) fprintf(stderr, "libmi355asr: MI355ASR_SUBCONV_DIAG=%d -- timing experiment, the subsampling output is WRONG\n", d);
     return d;
   }();
+  if (diag && rtn != SRT) return -1;       // the timing variants are instantiated for two row tiles per wave
   switch (diag) {
     case 1: return launch_split_d<1>(d, grid, a, RS, rows, s);
     case 2: return launch_split_d<2>(d, grid, a, RS, rows, s);
@@ -663,5 +685,5 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
     default: break;
   }
 #endif
-  return launch_split_d<0>(d, grid, a, RS, rows, s);
+  return launch_split_d<0>(d, grid, a, RS, rows, s, rtn);
 }

@@ -166,6 +166,47 @@ def test_conv_subsampling_parity(enc2, F):
     assert maxdiff(got, ref) < TOL
 
 
+def test_two_term_subsampling_conv_one_row_tile_per_wave_bit_identical(torch_cuda):
+    """subconv_split_ring_kernel<..., RTN = 1>: 128 positions per workgroup, one 16-position row tile per wave -- what the
+    launcher picks while that gives no CU a second workgroup (one to four utterances per call: -2.4 % latency).  A position's sums
+    run over the same steps in the same order whichever tile it sits in: BIT-IDENTICAL to MI355ASR_SUBCONV_RT=2, for dmodel
+    144 / 256 / 512, utterance and streaming-chunk shapes (MI355ASR_SUBCONV_TERMS=22 sends the stage API's features through
+    the two-term kernel)."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, small_cfg
+from tensorflowasr_amd.models import ConformerEncoder
+out = {}
+for name, base in (("S", co.CONFORMER_S), ("M", co.CONFORMER_M), ("L", co.CONFORMER_L)):
+    cfg = small_cfg(1, base)
+    w = co.encoder_weights(cfg, seed=61)
+    e = ConformerEncoder(**encoder_kwargs(cfg))
+    e.load_weights(w, by_name=False)
+    rng = np.random.default_rng(62)
+    for B, F in ((4, 123), (1, 1000), (24, 50)):
+        mel = (-80.0 * rng.random((B, F, 80))).astype(np.float32)
+        out["%s_%d_%d" % (name, B, F)] = e.conv_subsampling(mel).cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for rt in ("1", "2"):
+            f = os.path.join(td, rt + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MI355ASR_SUBCONV_TERMS="22", MI355ASR_SUBCONV_RT=rt),
+                               capture_output=True, text=True, timeout=900, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[rt] = dict(np.load(f))
+    assert len(res["1"]) == 9
+    for k in res["1"]:
+        assert np.isfinite(res["1"][k]).all() and np.abs(res["1"][k]).max() > 0.1, k
+        assert np.array_equal(res["1"][k], res["2"][k]), (k, float(np.abs(res["1"][k] - res["2"][k]).max()))
+
+
 def test_two_term_fp16_subsampling_conv_against_the_three_term_kernel_and_the_oracle(torch_cuda):
     """subconv_split_ring_kernel<..., TM = 2>: conv1 values and conv2 kernel as hi + lo fp16 terms (power-of-two scales from
     the weights and the frontend's [-80, 0] dB range), three MFMAs per fragment pair instead of six.  The stage API feeds
