@@ -409,7 +409,13 @@ int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s) 
 // the accumulator fragment *is* the P operand of the P.V MFMA; keys are swept in blocks of 16*KT with an
 // online softmax, so any T works.
 // =====================================================================================================
-template <int HS, int KT>
+// LDSW (round 4, band attention: chunk_conformer_blocks.py:158-176): the four waves of a workgroup are 64 consecutive queries
+// of one (b, h), whose bands overlap -- win_front + win_back + 64 keys in all.  The workgroup stages that window of K and V
+// once, with 16-byte loads, and every wave takes its fragments from LDS.  Straight from L2 a wave issued ~63 vector loads per
+// 64-key block, 48 of them 4 bytes per lane (V is read down its columns); the memory pipe takes one wave instruction per ~15
+// cycles whatever its width (tools/ubench/l2_pull.hip), and twelve waves per CU made that 10 of the kernel's 19 us.
+constexpr int ATT_WROWS = 128;      // key rows of a staged window
+template <int HS, int KT, bool LDSW = false>
 __global__ __launch_bounds__(BLOCK_THREADS, ((HS > 36 && KT >= 16) ? 1 : 2)) void attention_kernel(AttnArgs a) {   // <64, 16> spilled at 256 registers
   constexpr int FB = HS / 16;          // full 16-wide feature blocks
   constexpr int TS = (HS % 16) / 4;    // tail k-steps (feature = 16*FB + 4*ts + g)
@@ -423,12 +429,32 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((HS > 36 && KT >= 16) ? 1 : 2)) voi
   const int g = lane >> 4, g4 = g * 4, c = lane & 15;
   const int qt = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int T = a.Tk, TQ = a.Tq;       // keys / queries per utterance
-  if (qt * 16 >= TQ) return;
+  if (!LDSW && qt * 16 >= TQ) return;
   const int h = blockIdx.y, b = blockIdx.z;
   const int ld = a.ldk;  // row stride of the k / v buffers
   const int D = a.D;
   const float* __restrict__ kbase = a.k + (size_t)b * T * ld + h * HS;
   const float* __restrict__ vbase = a.v + (size_t)b * T * ld + h * HS;
+  __shared__ __attribute__((aligned(16))) float kw[LDSW ? ATT_WROWS * HS : 4], vw[LDSW ? ATT_WROWS * HS : 4];
+  int wbeg = 0;                        // first key row of the staged window
+  if constexpr (LDSW) {
+    static_assert(HS % 4 == 0, "rows are staged in 16-byte pieces");
+    // the window starts where the first query tile's sweep starts; ALL ATT_WROWS rows are staged (rows past T: the last row --
+    // finite values: a masked key's probability is an exact 0, and 0 x garbage must stay 0); the launcher guarantees that
+    // every key some query of the workgroup can see lies inside
+    const int i0 = a.q_off + (int)blockIdx.x * (16 * WAVES_PER_BLOCK);
+    const int lo0 = min(max(i0 - a.win_front, 0), T - a.win_back);
+    wbeg = (max(lo0, 0) / 16) * 16;
+    constexpr int RQ = HS / 4;
+    for (int i = threadIdx.x; i < ATT_WROWS * RQ; i += BLOCK_THREADS) {
+      const int r = i / RQ, q = i - r * RQ;
+      const size_t src = (size_t)min(wbeg + r, T - 1) * ld + 4 * q;
+      *reinterpret_cast<f32x4*>(kw + r * HS + 4 * q) = ldg4(kbase + src);
+      *reinterpret_cast<f32x4*>(vw + r * HS + 4 * q) = ldg4(vbase + src);
+    }
+    __syncthreads();
+    if (qt * 16 >= TQ) return;
+  }
 
   const int tq = qt * 16 + c;
   const float* qrow = a.q + ((size_t)b * TQ + min(tq, TQ - 1)) * a.ldq + h * HS;
@@ -449,11 +475,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((HS > 36 && KT >= 16) ? 1 : 2)) voi
 #pragma unroll
     for (int tt = 0; tt < KG; ++tt) {
       const int tk = min(k0 + 16 * (batch * KG + tt) + c, T - 1);
-      const float* krow = kbase + (size_t)tk * ld;
+      if constexpr (LDSW) {
+        const float* krow = kw + min(tk - wbeg, ATT_WROWS - 1) * HS;          // (rows past the window: masked below, any value does)
 #pragma unroll
-      for (int s = 0; s < FB; ++s) kb4[buf][tt][s] = ldg4(krow + 16 * s + g4);
+        for (int s = 0; s < FB; ++s) kb4[buf][tt][s] = *reinterpret_cast<const f32x4*>(krow + 16 * s + g4);
 #pragma unroll
-      for (int s = 0; s < TS; ++s) kbs[buf][tt][s] = krow[16 * FB + 4 * s + g];
+        for (int s = 0; s < TS; ++s) kbs[buf][tt][s] = krow[16 * FB + 4 * s + g];
+      } else {
+        const float* krow = kbase + (size_t)tk * ld;
+#pragma unroll
+        for (int s = 0; s < FB; ++s) kb4[buf][tt][s] = ldg4(krow + 16 * s + g4);
+#pragma unroll
+        for (int s = 0; s < TS; ++s) kbs[buf][tt][s] = krow[16 * FB + 4 * s + g];
+      }
     }
   };
   auto load_v = [&](int k0, int batch, int buf) {
@@ -462,7 +496,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, ((HS > 36 && KT >= 16) ? 1 : 2)) voi
       const int kb = k0 + 16 * (batch * VG + tt) + g4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float* vrow = vbase + (size_t)min(kb + j, T - 1) * ld;
+        const float* vrow = LDSW ? vw + min(min(kb + j, T - 1) - wbeg, ATT_WROWS - 1) * HS : vbase + (size_t)min(kb + j, T - 1) * ld;
 #pragma unroll
         for (int i = 0; i < OT; ++i) {
           const int f = 16 * i + c;
@@ -593,7 +627,11 @@ static void launch_attention_t(const AttnArgs& a, hipStream_t s) {
   // keys are swept in blocks of 16*KT; short sequences (streaming blocks: T = 13) and band attention
   // (win_front + win_back + 16 keys per query tile) use small blocks
   const int span = a.win_front >= 0 ? min(a.Tk, a.win_front + a.win_back + 31) : a.Tk;
+  // band attention whose window for 64 queries fits ATT_WROWS key rows: K / V staged once per workgroup (MI355ASR_ATTN_BAND_LDS=0: from L2)
+  static const bool band_lds = [] { const char* v = getenv("MI355ASR_ATTN_BAND_LDS"); return v ? atoi(v) != 0 : true; }();
   if (span <= 16) hipLaunchKernelGGL((attention_kernel<HS, 1>), grid, dim3(BLOCK_THREADS), 0, s, a);
+  else if (band_lds && HS % 4 == 0 && HS <= 36 && a.win_front >= 0 && span <= 96 && a.win_front + a.win_back + 16 * WAVES_PER_BLOCK + 15 <= ATT_WROWS)
+    hipLaunchKernelGGL((attention_kernel<HS, 4, true>), grid, dim3(BLOCK_THREADS), 0, s, a);
   else if (span <= 96) hipLaunchKernelGGL((attention_kernel<HS, 4>), grid, dim3(BLOCK_THREADS), 0, s, a);
   else hipLaunchKernelGGL((attention_kernel<HS, 16>), grid, dim3(BLOCK_THREADS), 0, s, a);
 }

@@ -1391,6 +1391,45 @@ def test_ctc_decoder_without_logits_returns_the_same_frame_argmax(torch_cuda, ba
         m(x, return_logits=False)
 
 
+def test_band_attention_staged_window_bit_identical(torch_cuda):
+    """Round 4: band attention (chunk_conformer_blocks.py:158-176; win_front 36, win_back 0 / 8) stages the K / V window of a
+    workgroup's 64 queries in LDS once (16-byte loads) instead of every wave reading its fragments from L2 (4-byte loads down
+    V's columns: the memory pipe's instruction rate was half of the kernel).  Same MFMAs on the same operands in the same
+    order: the ChunkConformer's predict must be BIT-IDENTICAL to MI355ASR_ATTN_BAND_LDS=0 -- utterances of 250, 47 and 13
+    frames (shorter than a window, shorter than a query tile) and 1 000 frames (sixteen workgroups per head)."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from helpers import chunk_config_dict, co, waves
+from tensorflowasr_amd.models import ChunkConformer
+c5 = dict(co.CHUNK_S, enc_num_blocks=2, picker_num_blocks=1, helper_num_blocks=1, decoder_num_blocks=1)
+w5 = co.chunk_weights(c5, seed=4)
+m = ChunkConformer(chunk_config_dict(c5), c5["picker_num_classes"], c5["decoder_num_classes"])
+m.load_weights(w5, by_name=False)
+out = {}
+for B, L in ((5, 160000), (3, 30000), (2, 8320), (2, 640000)):
+    got = m.predict(waves(B, L, 9), stages=True)
+    out["enc_%d" % L] = got["enc"].cpu().numpy()
+    out["text_%d" % L] = got["text_logits"].cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("staged", {}), ("l2", {"MI355ASR_ATTN_BAND_LDS": "0"})):
+            f = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[tag] = dict(np.load(f))
+    for k in res["staged"]:
+        assert np.isfinite(res["staged"][k]).all(), k
+        assert np.array_equal(res["staged"][k], res["l2"][k]), (k, float(np.abs(res["staged"][k] - res["l2"][k]).max()))
+    assert np.abs(res["staged"]["enc_160000"]).max() > 0.1
+
+
 def test_bf16_chain256_against_layer_at_a_time(torch_cuda):
     """Round 4: in bf16 mode a dmodel-256 FFModule / ConvModule tail is ONE launch (chain256_bf16_kernel: hidden activation in
     LDS as bf16 operand fragments) instead of two gemm16 / gemm_ring launches with the fp32 hidden activation in HBM.  Same
