@@ -374,19 +374,17 @@ void launch_layernorm_rows(float* y, const float* g, const float* b, int M, int 
 // (GEMM1's accumulator layout IS GEMM2's operand layout: nothing is transposed), and after one barrier computes TWO 16-column
 // tiles of the output over the whole hidden dimension -- no partial sums to reduce, the hidden activation (fp32 in HBM
 // between the two gemm16 / gemm_ring launches before: 136 MB per FFModule at 16 640 rows) never leaves the CU.  Weight
-// fragments travel in batches of sixteen, two or three batches ahead of their MFMAs (the first batches of W2 across the barrier).
-// Same arithmetic as the two launches: bf16 operands rounded to nearest even, fp32 accumulation; the trailing LayerNorm's
-// statistics cross the waves through LDS in a fixed order.
-// What bounds it: a CU pulls ~40 GB/s from L2 however many loads it has in flight (measured here and in every per-wave
-// weight stream of this library: 9 TB/s over 256 CUs), and a workgroup needs all 1 MB (FFModule) of weights: 25 us at RT = 1
-// whatever the row count up to 256 tiles.  At 832 rows (52 tiles) that is what two gemm16 launches take (12.7 + 10 us: they
-// spread the weights over 832 workgroups) -- the gain there is launches (24 -> 12 per encoder pass), not time (tried: four
-// workgroups per row tile with a quarter of the hidden dimension each, partial outputs summed in workgroup order by the one
-// that arrives last at a per-tile counter: with device-scope fences 27 us -- a release walks the L2 --, with relaxed
-// device-scope atomics and hand-counted waits 21 us; 2 % of the config-3 step for a protocol outside the language's memory
-// model: not kept); from 512 tiles
-// on RT = 2 halves the weight traffic per row and from 1024 tiles on RT = 4 quarters it: 16 640 rows 116 -> 68 us (RT = 2)
-// against 102-133 us for the two ring launches.
+// fragments travel in batches of eight 1 KB fragments (16 bytes per lane), two batches ahead of their MFMAs (the first batches of
+// W2 across the barrier).  Same arithmetic as the two launches: bf16 operands rounded to nearest even, fp32 accumulation; the
+// trailing LayerNorm's statistics cross the waves through LDS in a fixed order.
+// What bounds it: one workgroup needs all of a module's weights (1 MB for an FFModule) and a CU pulls ~145 GB/s from L2 with
+// 16-byte loads (tools/ubench/l2_pull.hip): 7 us + the fixed part of a launch.  Measured 17.0 us per FFModule at 832 rows (two
+// gemm16 launches: 12.7 + 10 us on 832 workgroups each), 46 us at 16 640 rows with four row tiles per workgroup (two ring
+// launches: 102-133 us); 1 / 2 / 4 row tiles share every weight fragment, chosen by the row count.  Tried at 832 rows and not
+// kept: four workgroups per row tile with a quarter of the hidden dimension each, partial outputs summed in workgroup order by
+// the one that arrives last at a per-tile counter -- with device-scope fences 27 us (a release walks the L2), with relaxed
+// device-scope atomics and hand-counted waits 21 us against 25 for the kernel as it then was: 2 % of the config-3 step for a
+// protocol outside the language's memory model.
 constexpr int C_NW = 8;         // waves per workgroup, two 16-column tiles of dmodel 256 each
 constexpr int C_KB = 16;        // 16-wide k-blocks of a row
 constexpr int C_BF = 8;         // weight fragments (1 KB: 16 bytes per lane) per batch
