@@ -93,7 +93,7 @@ class ASR:
     def _phone_ids(self, enc_outputs):
         """softmax + tf.keras.backend.ctc_decode(greedy) + clip(-1 -> 0) (test_asr.py:196-200): per-frame argmax
         inside the CTC head kernel, merge/blank-drop on the device."""
-        _, frame_ids = self.ctc_model(enc_outputs, training=False, return_argmax=True)
+        _, frame_ids = self.ctc_model(enc_outputs, training=False, return_argmax=True, return_logits=False)
         # tf.keras.backend.ctc_decode: the blank is the LAST class (num_classes - 1), independent of `blank_at_zero`
         ids, lens = ctc_greedy_decode(frame_ids, None, blank=self.phone_featurizer.num_classes - 1)
         # ctc_decode's dense output is as wide as the longest decoded sequence of the batch, padded with -1; the
