@@ -224,7 +224,7 @@ class AMTester(ASR):
         """am_tester.py:34-89."""
         features, input_length, phone_labels, _, tar_label = batch
         enc_output = self.encoder(features, training=False)
-        _, frame_ids = self.ctc_model(enc_output, training=False, return_argmax=True)
+        _, frame_ids = self.ctc_model(enc_output, training=False, return_argmax=True, return_logits=False)
         # tf.keras.backend.ctc_decode treats the LAST class as the blank whatever `blank_at_zero` says (am_tester.py:38-40)
         ids, lens = ctc_greedy_decode(frame_ids, input_length, blank=self.phone_featurizer.num_classes - 1)
         ctc_decode = ids[:, :max(int(lens.max().item()), 1)].clamp_(min=0).contiguous()
