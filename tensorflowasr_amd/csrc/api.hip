@@ -1271,6 +1271,7 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
   // round 4: the projection rides in the first decoder block's ff_module_1 + qkv launch
   const bool proj_fold = m->proj_pp && m->cfg.ctc_num_blocks > 0 && block_takes_pre(m, m->ctc_blocks[0], (size_t)M);
   if (proj_fold) {
+    // (nothing here: the first block below computes it)
   } else if (bf16) {
     Gemm16Args pr{};
     pr.x = enc; pr.ldx = d; pr.bias = m->proj_b; pr.y = sc.xa; pr.ldy = d;

@@ -101,6 +101,7 @@ int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int 
     first.pre_x = in; first.pre_pp = st.proj_pp; first.pre_sw = st.proj_pp_sw; first.pre_chunks = 1;
   }
   if (first.pre_pp) {
+    // (nothing here: the first block below computes the layer in front of it)
   } else if (st.proj_wp) {
     // on its own: the same two-term stream through pp_sublinear_kernel (bit-identical to the folded form), else fp32 MFMA
     StreamGemmArgs sp{};
