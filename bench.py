@@ -694,6 +694,11 @@ def main():
                 # such launches per step: the per-launch average carries half of each); x0 is neither written nor read
                 fl["ff1_qkv"] += fl[pre] / n_ff1
                 ab["ff1_qkv"] += (ab[pre] - 2 * 4.0 * B * (L // 640) * S_CFG["dmodel"]) / n_ff1
+        if "ctc_head" not in launched and "tail_ff2" in launched:
+            # round 4: the class head runs behind the CTC block's tail (one of the two tail_ff2 launches of a step)
+            n_t2 = max(cnt[_lib.KERNEL_NAMES.index("tail_ff2")] // args.steps, 1)
+            fl["tail_ff2"] += fl["ctc_head"] / n_t2
+            ab["tail_ff2"] += (ab["ctc_head"] - 2 * 4.0 * B * (L // 640) * S_CFG["dmodel"]) / n_t2
         kern = {}
         for i, name in enumerate(_lib.KERNEL_NAMES):
             if cnt[i]:

@@ -954,6 +954,20 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     }
     {
       PROF(MI355ASR_K_TAIL_FF2);
+      // round 4: the class head behind the CTC decoder's last block rides in this launch (the block output itself is then
+      // stored only if somebody asked for it)
+      if (bo.head && bo.head_pp && bo.head_done && og_fold && pp_head_fold_ok(M, bo.head->n_valid, bo.head_groups)) {
+        TailFf2Args kh = k4;
+        if (!out) kh.y = nullptr;
+        kh.head_pp = bo.head_pp; kh.head_sw = bo.head_sw; kh.head_groups = bo.head_groups; kh.head_ldy = bo.head->ldy;
+        kh.head_nvalid = bo.head->n_valid; kh.head_y = bo.head->y; kh.head_argmax = bo.head->argmax_out; kh.head_maxval = bo.head->maxval_out;
+        if (launch_pp_og_tail_ff2(kh, k2, s) == 0) {
+          if (hipGetLastError() != hipSuccess) return fail(MI355ASR_EHIP, "block tail + class head launch failed");
+          *bo.head_done = true;
+          if (!out) std::swap(sc.xa, sc.xb);
+          return 0;
+        }
+      }
       if (!(og_fold && launch_pp_og_tail_ff2(k4, k2, s) == 0)) LAUNCH_TRY(launch_tail_ff2(k4, s), "conv tail + ff_module_2");
       else if (hipGetLastError() != hipSuccess) return fail(MI355ASR_EHIP, "out-projection + GLU + conv tail + ff_module_2 launch failed");
     }
@@ -1289,14 +1303,24 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
       LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, pr, s), "ctc project");
     }
   }
+  // round 4: the class head rides in the last block's tail launch where pp_head_kernel would have run (try_head_ld's conditions)
+  GemmArgs hdf{};
+  hdf.y = logits; hdf.bias = m->fc_b; hdf.M = M; hdf.NT = m->NT_fc; hdf.ldy = m->cfg.num_classes; hdf.n_valid = m->cfg.num_classes; hdf.eps = kLnEps;
+  hdf.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
+  bool head_done = false;
+  const auto head_it = (!bf16 && m->cfg.gemm_dtype == 0 && M >= 2048) ? m->head_of.find(m->fc_wp) : m->head_of.end();
   for (int i = 0; i < m->cfg.ctc_num_blocks; ++i) {
     BlockOpts bo;
     bo.ksz = m->cfg.ctc_kernel_size;
     bo.fc = m->cfg.ctc_fc_factor;
     if (i == 0 && proj_fold) { bo.pre_x = enc; bo.pre_pp = m->proj_pp; bo.pre_sw = m->proj_pp_sw; bo.pre_chunks = 1; }
+    if (i == m->cfg.ctc_num_blocks - 1 && head_it != m->head_of.end() && head_it->second.pp) {
+      bo.head = &hdf; bo.head_pp = head_it->second.pp; bo.head_sw = head_it->second.pp_sw; bo.head_groups = head_it->second.groups; bo.head_done = &head_done;
+    }
     int rc = run_block(m, m->ctc_blocks[i], bo, sc, B, T, nullptr, s);
     if (rc) return rc;
   }
+  if (head_done) return 0;
   if (bf16) {
     Gemm16Args hd{};
     hd.x = sc.xa; hd.ldx = d; hd.bias = m->fc_b; hd.y = logits; hd.ldy = m->cfg.num_classes;

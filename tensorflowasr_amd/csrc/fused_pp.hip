@@ -675,14 +675,71 @@ DEV void pp_og_tile(const OutGluArgs& g, const PpOgLds& p, ST& st, PpPool& pl, f
   }
 }
 
+// CTC class head on the 16 tokens in xs (pp_head_kernel's loop, behind a block's tail): a.head_* (launch.h)
+template <int DG, class ST>
+DEV void pp_head_consume(const TailFf2Args& a, int g4, int lane, ST& st, PpPool& pl, const f32x4 (&xs)[KB], int T) {
+  Split8 xf[KS32X];
+  const float sx = pp_pow2_scale(pp_row_max(xs));
+  split_operand(xf, xs, g4, sx);
+  const float inv = pp_recip_pow2(a.head_sw * sx);
+  float best_v = -INFINITY;
+  int best_i = 0;
+  const bool want_max = a.head_argmax != nullptr || a.head_maxval != nullptr;
+#pragma unroll 1
+  for (int g = 0; g < a.head_groups; ++g) {
+    f32x4 acc[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) acc[i] = splat4(0.f);
+    static_for<0, KS32X>([&](auto Tt) {
+      constexpr int t = decltype(Tt)::value;
+      pp_unit_S<DG>(acc, xf[t], pl, st);
+    });
+    pp_pool_land(pl);
+    const WaveCtx e = wave_ctx_fresh(a.M, T);
+    float* yrow = a.head_y ? a.head_y + (size_t)e.tok * a.head_ldy : nullptr;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int tile = KB * g + i, f0 = 16 * tile + e.g4;
+      if (16 * tile < a.head_nvalid) {           // wave-uniform: the last group is padded with zero columns
+        const f32x4 v = acc[i] * splat4(inv);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        if (want_max) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (f0 + j < a.head_nvalid && vv[j] > best_v) { best_v = vv[j]; best_i = f0 + j; }
+        }
+        if (yrow && e.live) {
+          if (f0 + 3 < a.head_nvalid && (a.head_ldy & 3) == 0) stg4(yrow + f0, v);
+          else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (f0 + j < a.head_nvalid) yrow[f0 + j] = vv[j];
+        }
+      }
+    }
+  }
+  if (!want_max) return;
+  // the four lane groups of a token hold disjoint classes: max over the groups, lowest class on ties
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) {
+    const float ov = __shfl_xor(best_v, off);
+    const int oi = __shfl_xor(best_i, off);
+    if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+  }
+  const WaveCtx e = wave_ctx_fresh(a.M, T);
+  if (a.head_argmax && e.live && lane < 16) a.head_argmax[e.tok] = best_i;
+  if (a.head_maxval && e.live && lane < 16) a.head_maxval[e.tok] = best_v;
+}
+
 // TAIL: conv tail + ff_module_2 + LayerNorm of one block (a);  FF1: ff_module_1 + qkv of a block (b) -- of the NEXT block
 // when both are set (the block output stays in registers; a.y may be null then).  DWF: the depthwise conv runs in the
 // prologue (a.dw_u / dw_wd / dw_T / dw_pad) and the grid is (ceil(T / 64), utterances).  OGF (needs DWF): the window of the
 // depthwise conv is computed in the prologue too, from the attention output and x1 (g; a.dw_u and a.x2 are not read).
 // PRE (FF1 without TAIL): the plain layer in front of the block -- the subsampling Dense, the CTC decoder's projection -- runs
 // first, x0 = pre_x W + b from b.pre_x [M, 144 * pre_chunks] and the stream b.pre_pp (pp_sublinear_kernel's loop); b.x0 is not read.
-template <bool TAIL, bool FF1, int DG = 0, bool DWF = false, bool OGF = false, bool PRE = false>
+// HEAD (TAIL + OGF without FF1): the CTC class head runs behind the block (a.head_*: pp_head_kernel's loop on the block output).
+template <bool TAIL, bool FF1, int DG = 0, bool DWF = false, bool OGF = false, bool PRE = false, bool HEAD = false>
 __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1QkvArgs b, OutGluArgs g) {
+  static_assert(!HEAD || (TAIL && OGF && !FF1), "the class head follows the last block's tail");
   static_assert(TAIL || !DWF, "the depthwise conv feeds the conv tail");
   static_assert(DWF || !OGF, "the out-projection + GLU prologue feeds the depthwise window");
   static_assert(!PRE || (FF1 && !TAIL), "the layer in front feeds ff_module_1");
@@ -703,14 +760,15 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
   f32x4 xs[KB], y[KB];
   const u32x4_t* s0 = reinterpret_cast<const u32x4_t*>(PRE ? b.pre_pp : g.pp_slabs);
   const u32x4_t* s1 = reinterpret_cast<const u32x4_t*>(TAIL ? a.pp_slabs : b.pp_slabs);
-  const u32x4_t* s2 = reinterpret_cast<const u32x4_t*>(b.pp_slabs);
+  const u32x4_t* s2 = reinterpret_cast<const u32x4_t*>(HEAD ? a.head_pp : b.pp_slabs);
+  const int total_rt = TOTAL + (HEAD ? KS32X * a.head_groups : 0);
   if (wv >= WAVES_PER_BLOCK + (OGF ? 2 : 0)) {
     if constexpr (PRE) {
       const int n0 = KS32X * b.pre_chunks;
       PpLoader<PP_RING, DG>{ring, s1, s2, n0 + N1, n0 + TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63), s0, n0}.run();
       return;
     }
-    const PpLoader<PP_RING, DG> ld{ring, s1, s2, N1, TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63), s0, NOG};
+    const PpLoader<PP_RING, DG> ld{ring, s1, s2, N1, total_rt, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63), s0, NOG};
     if constexpr (OGF) {
       ld.run_og_phase();
       pp_dw_prologue<true>(scratch, a, xs);
@@ -744,7 +802,7 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
     pp_og_tile<DG>(g, pg, st, pl, xs, y, c.lane, frame0, T, f0, scratch);      // y = x2 rows of this wave's tile
     pp_dw_prologue<true>(scratch, a, xs);                // waves 0..3: xs = depthwise output rows of the wave's own frames
     if (wv >= WAVES_PER_BLOCK) {                         // the halo waves join the loaders
-      const PpLoader<PP_RING, DG> ld{ring, s1, s2, N1, TOTAL, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63), s0, NOG};
+      const PpLoader<PP_RING, DG> ld{ring, s1, s2, N1, total_rt, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63), s0, NOG};
       ld.run_after_og();
       return;
     }
@@ -761,6 +819,7 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
 #pragma unroll
     for (int i = 0; i < KB; ++i) xs[i] = y[i];
     if constexpr (FF1) pp_ff1_consume<DG>(b, pf, c.g4, st, pl, xs, TT);
+    if constexpr (HEAD) pp_head_consume<DG>(a, c.g4, c.lane, st, pl, xs, TT);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     return;
   }
@@ -1143,9 +1202,21 @@ int launch_pp_og_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, const OutGl
   hipLaunchKernelGGL((pp_block_kernel<true, true, 0, true, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, b, g);
   return 0;
 }
+bool pp_head_fold_ok(int M, int n_valid, int groups) {
+  // MI355ASR_PP_HEADF=0: the class head as its own launch (pp_head_kernel); the switches of that kernel apply here too
+  static const bool on = [] { const char* v = getenv("MI355ASR_PP_HEADF"); return v ? atoi(v) != 0 : true; }();
+  static const bool head_on = [] { const char* v = getenv("MI355ASR_PP_HEAD"); return v ? atoi(v) != 0 : true; }();
+  static const bool ring_on = [] { const char* v = getenv("MI355ASR_HEAD_RING"); return v ? atoi(v) != 0 : true; }();
+  return on && head_on && ring_on && pp_enabled() && groups >= 1 && n_valid <= 144 * groups && M > 0;
+}
 int launch_pp_og_tail_ff2(const TailFf2Args& a, const OutGluArgs& g, hipStream_t s) {
   if (!pp_og_fold_ok(a, g)) return -1;
   note_scheme(SCHEME_F16X2);
+  if (a.head_pp) {
+    if (!pp_head_fold_ok(a.M, a.head_nvalid, a.head_groups)) return -1;
+    hipLaunchKernelGGL((pp_block_kernel<true, false, 0, true, true, false, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{}, g);
+    return 0;
+  }
   hipLaunchKernelGGL((pp_block_kernel<true, false, 0, true, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, Ff1QkvArgs{}, g);
   return 0;
 }

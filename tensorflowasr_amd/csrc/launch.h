@@ -310,6 +310,15 @@ struct TailFf2Args {
   const float* dw_u = nullptr;
   const float* dw_wd = nullptr;
   int dw_T = 0, dw_pad = 0;
+  // round 4: the class head behind the block (the CTC decoder's last block; out-projection + GLU kernels without a next block):
+  // logits = y W + b over head_groups column groups of nine tiles from the two-term stream head_pp (pp_head_kernel's loop),
+  // per-frame arg-max / maximum and / or the logits; y itself is stored only if `y` is set
+  const float* head_pp = nullptr;
+  float head_sw = 1.f;
+  int head_groups = 0, head_ldy = 0, head_nvalid = 0;
+  float* head_y = nullptr;
+  int32_t* head_argmax = nullptr;
+  float* head_maxval = nullptr;
 };
 int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s);
 int launch_out_glu(const OutGluArgs& a, hipStream_t s);
@@ -327,7 +336,8 @@ int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s)
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
 bool ff1_pre_selected();             // ... and launch_ff1_qkv will take that kernel (fused.hip) when the block has its streams
-bool pp_pre_fold_ok();               // the layer in front of a block rides in its ff_module_1 + qkv launch (MI355ASR_PP_PRE=0: own launch)
+bool pp_pre_fold_ok();
+bool pp_head_fold_ok(int M, int n_valid, int groups);   // the class head rides in the last block's tail launch (MI355ASR_PP_HEADF=0: own launch)               // the layer in front of a block rides in its ff_module_1 + qkv launch (MI355ASR_PP_PRE=0: own launch)
 // round 4: out-projection + residual + LayerNorm + pw_conv_1 + GLU in the prologue of the pair-pipelined tail kernels (the
 // block = attention + ONE launch); -1: not applicable (switched off, no streams, depthwise fold impossible), nothing launched
 bool pp_og_fold_ok(const TailFf2Args& a, const OutGluArgs& g);

@@ -88,6 +88,13 @@ struct BlockOpts {
   const float* pre_x = nullptr; const float* pre_pp = nullptr;
   float pre_sw = 1.f;
   int pre_chunks = 0;
+  // ... and the class head BEHIND the block (ctc_impl's last block), when the block's tail launch can take it: the head's
+  // arguments (x is not read), its two-term stream; *head_done is set when the launch computed it
+  const GemmArgs* head = nullptr;
+  const float* head_pp = nullptr;
+  float head_sw = 1.f;
+  int head_groups = 0;
+  bool* head_done = nullptr;
 };
 
 struct StackDev {

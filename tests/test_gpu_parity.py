@@ -404,13 +404,15 @@ np.savez(sys.argv[1], **out)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for tag, extra in (("folded", {}), ("own", {"MI355ASR_PP_PRE": "0"})):
+        for tag, extra in (("folded", {}), ("own", {"MI355ASR_PP_PRE": "0"}), ("head_own", {"MI355ASR_PP_HEADF": "0"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
             assert r.returncode == 0, r.stderr[-3000:]
             res[tag] = dict(np.load(f))
     for k in res["folded"]:
         assert np.array_equal(res["folded"][k], res["own"][k]), (k, float(np.abs(res["folded"][k].astype(np.float64) - res["own"][k]).max()))
+        # ... and the class head BEHIND the CTC decoder's last block, in that block's tail launch (MI355ASR_PP_HEADF=0: pp_head_kernel)
+        assert np.array_equal(res["folded"][k], res["head_own"][k]), (k, float(np.abs(res["folded"][k].astype(np.float64) - res["head_own"][k]).max()))
     assert (res["folded"]["a_lens"] > 0).any()
     cfg = small_cfg(2)
     w = co.encoder_weights(cfg, seed=61)
