@@ -937,6 +937,20 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];
     k4.ff_w2p = w.ff_w2p[1]; k4.ff_b2 = w.ff_b2[1]; k4.ln_g = w.ln_g; k4.ln_b = w.ln_b;
     k4.fc = fc; k4.eps = kLnEps; k4.M = M; k4.slabs = w.tail_slabs; k4.pp_slabs = w.pp_tail; k4.pp_sc[0] = w.pp_tail_sc[0]; k4.pp_sc[1] = w.pp_tail_sc[1];
+    // The folded launches (OGF) read x1 from sc.xb, INCLUDING the halo frames of the neighbouring workgroups (the window of
+    // the depthwise conv), so nothing in such a launch may write sc.xb: a workgroup that starts after its neighbour has
+    // stored the block output there would read y as x1 (grids above one workgroup per CU).  x2 is never materialised in
+    // that mode, so sc.xa is free: the block output goes there and the xa/xb swap is skipped.
+    TailFf2Args k4og = k4;
+    if (!out) k4og.y = sc.xa;
+    // out-projection + GLU as its own launch, once, when a folded launcher declines (it declines before launching anything)
+    bool og_pending = og_fold;
+    auto unfold = [&]() -> int {
+      if (!og_pending) return 0;
+      og_pending = false;
+      PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU");
+      return 0;
+    };
     if (next && !out && ff1_done && tail_ff1_available() && k4.slabs && next->ff1_slabs) {
       // the block output feeds only the next block's ff_module_1: keep it in registers, write x1 (into the buffer the
       // next block knows as sc.xb after the swap below -- this block's x2, which each workgroup has consumed) and qkv
@@ -944,7 +958,12 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       kf.y = nullptr;
       const Ff1QkvArgs kn = ff1_args(*next, nullptr, sc.xa);
       PROF(MI355ASR_K_TAIL_FF1);
-      if ((og_fold && launch_pp_og_tail_ff1(kf, kn, k2, s) == 0) || launch_tail_ff1(kf, kn, s) == 0) {
+      bool launched = og_fold && launch_pp_og_tail_ff1(kf, kn, k2, s) == 0;
+      if (!launched) {
+        if (int rc = unfold()) return rc;
+        launched = launch_tail_ff1(kf, kn, s) == 0;
+      }
+      if (launched) {
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return fail(MI355ASR_EHIP, "conv tail + ff_module_2 + next ff_module_1: %s", hipGetErrorString(e_));
         *ff1_done = true;
@@ -956,20 +975,23 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       PROF(MI355ASR_K_TAIL_FF2);
       // round 4: the class head behind the CTC decoder's last block rides in this launch (the block output itself is then
       // stored only if somebody asked for it)
-      if (bo.head && bo.head_pp && bo.head_done && og_fold && pp_head_fold_ok(M, bo.head->n_valid, bo.head_groups)) {
-        TailFf2Args kh = k4;
+      if (bo.head && bo.head_pp && bo.head_done && og_pending && pp_head_fold_ok(M, bo.head->n_valid, bo.head_groups)) {
+        TailFf2Args kh = k4og;
         if (!out) kh.y = nullptr;
         kh.head_pp = bo.head_pp; kh.head_sw = bo.head_sw; kh.head_groups = bo.head_groups; kh.head_ldy = bo.head->ldy;
         kh.head_nvalid = bo.head->n_valid; kh.head_y = bo.head->y; kh.head_argmax = bo.head->argmax_out; kh.head_maxval = bo.head->maxval_out;
         if (launch_pp_og_tail_ff2(kh, k2, s) == 0) {
           if (hipGetLastError() != hipSuccess) return fail(MI355ASR_EHIP, "block tail + class head launch failed");
           *bo.head_done = true;
-          if (!out) std::swap(sc.xa, sc.xb);
-          return 0;
+          return 0;                                    // nothing was stored: the block's input stays where it was
         }
       }
-      if (!(og_fold && launch_pp_og_tail_ff2(k4, k2, s) == 0)) LAUNCH_TRY(launch_tail_ff2(k4, s), "conv tail + ff_module_2");
-      else if (hipGetLastError() != hipSuccess) return fail(MI355ASR_EHIP, "out-projection + GLU + conv tail + ff_module_2 launch failed");
+      if (og_pending && launch_pp_og_tail_ff2(k4og, k2, s) == 0) {
+        if (hipGetLastError() != hipSuccess) return fail(MI355ASR_EHIP, "out-projection + GLU + conv tail + ff_module_2 launch failed");
+        return 0;                                      // y is in sc.xa (or `out`): no swap
+      }
+      if (int rc = unfold()) return rc;
+      LAUNCH_TRY(launch_tail_ff2(k4, s), "conv tail + ff_module_2");
     }
     if (!out) std::swap(sc.xa, sc.xb);
     return 0;

@@ -360,6 +360,56 @@ np.savez(sys.argv[1], **out)
         assert np.array_equal(res["two"][k], res["three"][k]), (k, float(np.abs(res["two"][k] - res["three"][k]).max()))
 
 
+def test_folded_block_launches_on_grids_larger_than_the_chip_bit_for_bit(torch_cuda):
+    """Round 5 (advisor, round-4 review): a folded launch reads x1 with the halo frames of its neighbours' tiles, so it must
+    not store the block output into the buffer x1 lives in -- a workgroup scheduled after its neighbour finished would read y
+    as x1.  One workgroup fits per CU (147 KB of LDS), so the hazard needs more than 256 workgroups and a launch that stores
+    y: the last block of a chunk stack (B = 32 x 30 s: 12 tiles x 32 = 384 workgroups), a CTC decoder with two blocks
+    (80 x 250 frames: 320 workgroups, the first block stores y for the second), and the encoder with MI355ASR_TAIL_FF1=0
+    (every block stores y).  All of it BIT-IDENTICAL to MI355ASR_PP_OGF=0, where x1 is dead before y is written."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from helpers import chunk_config_dict, co, encoder_kwargs, small_cfg, waves
+from tensorflowasr_amd.models import ChunkConformer, ConformerCTC
+out = {}
+cfg = dict(small_cfg(2), ctcdecoder_num_blocks=2)
+w = co.encoder_weights(cfg, seed=71)
+w.update(co.ctc_decoder_weights(cfg, 200, seed=72))
+m = ConformerCTC(200, ctcdecoder_num_blocks=2, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+m.load_weights(w, by_name=False)
+x = waves(80, 160000, 11)
+enc = m.encode(x)
+out["enc"] = enc.cpu().numpy()
+out["logits"] = m.ctc_logits(enc).cpu().numpy()
+xb = np.random.default_rng(5).standard_normal((80, 250, 144)).astype(np.float32)
+out["blk"] = m.conformer_block(1, xb).cpu().numpy()
+c5 = dict(co.CHUNK_S, enc_num_blocks=2, picker_num_blocks=1, helper_num_blocks=1, decoder_num_blocks=1)
+w5 = co.chunk_weights(c5, seed=4)
+mc = ChunkConformer(chunk_config_dict(c5), c5["picker_num_classes"], c5["decoder_num_classes"])
+mc.load_weights(w5, by_name=False)
+got = mc.predict(waves(32, 480000, 9), stages=True)
+out["chunk_enc"] = got["enc"].cpu().numpy()
+out["chunk_text"] = got["text_logits"].cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("fold", {}), ("fold_noff1", {"MI355ASR_TAIL_FF1": "0"}), ("plain", {"MI355ASR_PP_OGF": "0"})):
+            f = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=1200, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[tag] = dict(np.load(f))
+    for tag in ("fold", "fold_noff1"):
+        for k in res["plain"]:
+            assert np.isfinite(res[tag][k]).all() and np.abs(res[tag][k]).max() > 0.1, (tag, k)
+            assert np.array_equal(res[tag][k], res["plain"][k]), (tag, k, float(np.abs(res[tag][k] - res["plain"][k]).max()))
+
+
 def test_layer_in_front_of_a_block_in_its_first_launch_bit_for_bit(torch_cuda):
     """Round 4: the subsampling Dense (conformer_blocks.py:102-106, K = 20 * 144) and the CTC decoder's projection
     (conformer_blocks.py:631) run in the prologue of the first block's ff_module_1 + qkv launch (pp_block_kernel<..., PRE>): the
