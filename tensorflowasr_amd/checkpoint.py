@@ -294,6 +294,7 @@ def ctc_decoder_weights_from_onnx(path, num_heads=4):
 # ---------------------------------------------------------------------------------------------------------
 # Keras variable names -> C-ABI names
 # ---------------------------------------------------------------------------------------------------------
+_MEL_SCOPE = re.compile(r"^(mel_layer|melspectrogram(_\d+)?|spectrogram(_\d+)?)$")
 _AUTO = re.compile(r"^(layer_normalization|dense|conv2d|multi_head_attention|batch_normalization|conv1d|separable_conv1d|"
                    r"tf_residual_stack|embedding)(?:_(\d+))?$")
 
@@ -310,15 +311,36 @@ def keras_names_to_abi(names):
     Typical use on a machine that has TensorFlow:
         m = keras_names_to_abi([v.name for v in model.weights])
         np.savez("encoder.npz", **{m[v.name]: v.numpy() for v in model.weights if v.name in m})"""
-    anchors = ("mel_layer", "conv_subsampling", "wav_layer", "wave_pick_model", "conformer_block_",
+    anchors = ("mel_layer", "melspectrogram", "spectrogram", "conv_subsampling", "wav_layer", "wave_pick_model", "conformer_block_",
                "decoder_conformer_block_", "fully_connected", "dense", "embedding", "inp_embedding")
     parsed = []
+    mel = {}
     for full in names:
         parts = full.split(":")[0].split("/")
+        if parts == ["kernel"]:
+            # leaf_audio/convolution.py:155-187: GaborConv1D creates its [n_filters, 2] kernel in __init__, before any layer
+            # scope exists, so Keras prints it as a bare `kernel:0` (seen when the reference's classes were executed, round 5)
+            mel[full] = "mel_layer/tfbanks_complex_conv/kernel"
+            continue
+        if "leaf" in parts[:-1]:
+            # leaf_audio/frontend.py:75-194 (`name='leaf'`): leaf/{tfbanks_preemp, learnable_pooling, PCEN[/EMA], tfbanks_instancenorm}/...
+            mel[full] = "/".join(["mel_layer"] + parts[parts.index("leaf") + 1:])
+            continue
         start = next((i for i, p in enumerate(parts) if p.startswith(anchors)), None)
         if start is None:
             continue
         parts = parts[start:]
+        if _MEL_SCOPE.match(parts[0]):
+            # the Melspectrogram / Spectrogram layer (time_frequency.py:51-53, 160): the attribute is `mel_layer` but the layer
+            # is auto-named after its class, so Keras prints conformer_encoder/melspectrogram[_n]/{real_kernels, imag_kernels,
+            # Variable}:0 -- the filterbank is an unnamed K.variable.  (Executing the reference's classes showed this in round 5;
+            # `mel_layer/...` is still accepted for files written by this repository's own tools.)
+            leaf = parts[-1]
+            if len(parts) == 2 and leaf in ("real_kernels", "imag_kernels"):
+                mel[full] = "mel_layer/" + leaf
+            elif len(parts) == 2 and (leaf.startswith("Variable") or leaf == "freq2mel"):
+                mel[full] = "mel_layer/freq2mel"
+            continue
         if parts[0].startswith(("wave_pick_model", "wav_layer")):
             # WavePickModel (wav_model.py:108-131) is a Layer named wave_pick_model holding one Sequential: the scope is
             # wave_pick_model/sequential[_n]/<layer>/...; the C-ABI prefix is the attribute name, wav_layer
@@ -382,6 +404,7 @@ def keras_names_to_abi(names):
                 ok = False
         if ok:
             out[full] = "/".join(scope + [var])
+    out.update(mel)
     return out
 
 
@@ -393,14 +416,7 @@ def keras_h5_to_abi(path):
     from . import h5lite
     raw = h5lite.keras_weights(path)
     m = keras_names_to_abi(list(raw))
-    out = {m[k]: np.asarray(v, np.float32) for k, v in raw.items() if k in m}
-    for k, v in raw.items():                                  # Melspectrogram layer (time_frequency.py:62-75, 152-189)
-        leaf = k.split(":")[0].rsplit("/", 1)[-1]
-        if "mel_layer" in k and leaf in ("real_kernels", "imag_kernels"):
-            out["mel_layer/" + leaf] = np.asarray(v, np.float32)
-        elif "mel_layer" in k and leaf.startswith("Variable"):
-            out["mel_layer/freq2mel"] = np.asarray(v, np.float32)
-    return out
+    return {m[k]: np.asarray(v, np.float32) for k, v in raw.items() if k in m}
 
 
 def tf_checkpoint_to_abi(path):

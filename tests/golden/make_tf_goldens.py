@@ -26,6 +26,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.environ.get("MI355ASR_TF_GOLDEN_OUT", HERE)          # tests/test_tf_recipe_runs.py regenerates into a scratch directory
 REF = os.environ.get("REFERENCE_ROOT", "/root/reference")
 for p in (ROOT, os.path.join(ROOT, "tests"), REF):
     if p not in sys.path:
@@ -36,16 +37,9 @@ from tensorflowasr_amd import checkpoint  # noqa: E402
 
 
 def _abi_of_keras_names(model, extra=None):
-    names = [v.name for v in model.weights]
-    m = checkpoint.keras_names_to_abi(names)
-    for n in names:                                    # the Melspectrogram layer's non-trainable variables
-        leaf = n.split(":")[0].rsplit("/", 1)[-1]
-        if "mel_layer" in n and leaf in ("real_kernels", "imag_kernels"):
-            m[n] = "mel_layer/" + leaf
-        elif "mel_layer" in n and leaf.startswith("Variable"):
-            m[n] = "mel_layer/freq2mel"
+    m = checkpoint.keras_names_to_abi([v.name for v in model.weights])     # includes the mel layer's constants (melspectrogram/...)
     if extra:
-        m.update(extra(names))
+        m.update(extra([v.name for v in model.weights]))
     return m
 
 
@@ -92,17 +86,46 @@ def assign_by_object_path(model, weights, tf):
     return kept
 
 
+FIXTURES = {}
+SUFFIX = [""]            # "" = the float32 pass; "_f64" = the stand-in's wide pass (float outputs only, added to the same file)
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name)
-    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
-    print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
+    fx = FIXTURES.setdefault(name, {})
+    for k, v in arrays.items():
+        v = np.asarray(v)
+        if not SUFFIX[0]:
+            fx[k] = v.astype(np.float32) if v.dtype == np.float64 else v
+        elif v.dtype.kind == "f" and v.ndim > 0 and not k.startswith(("freq2mel", "real_kernels", "imag_kernels")):
+            fx[k + SUFFIX[0]] = v.astype(np.float64)
+
+
+def write_all():
+    for name, fx in FIXTURES.items():
+        path = os.path.join(OUT, name)
+        np.savez_compressed(path, **fx)
+        print("wrote %s (%d KB): %s" % (path, os.path.getsize(path) // 1024, sorted(fx)))
+
+
+def import_tensorflow():
+    """the real TensorFlow when there is one; otherwise the NumPy stand-in under oracle/_tfshim (round 5: the reference's own
+    Python executed on stand-in primitives, see oracle/_tfshim/README.md)"""
+    try:
+        import tensorflow as tf
+        if "standin" not in getattr(tf, "__version__", ""):
+            return tf, False
+        return tf, True
+    except ImportError:
+        sys.path.insert(0, os.path.join(ROOT, "oracle", "_tfshim"))
+        import tensorflow as tf
+        return tf, True
 
 
 def main():
-    import tensorflow as tf
+    tf, standin = import_tensorflow()
     from asr.models import conformer_blocks as cb
     from asr.models.layers.time_frequency import Melspectrogram
-    meta = dict(tf_version=tf.__version__)
+    meta = dict(tf_version=tf.__version__, backend="numpy stand-in (oracle/_tfshim)" if standin else "tensorflow")
     try:
         import librosa
         meta["librosa_version"] = librosa.__version__
@@ -169,10 +192,10 @@ def main():
                                         n_mels=80, mel_layer_type="Melspectrogram", mel_layer_trainable=False, stride_ms=10)
     senc.add_chunk_size(8000, 80, 640)
     senc._build()
-    assign_by_name(senc, ws)
+    kept_s = assign_by_name(senc, ws)
     xs = waves(2, 24000, 9)
     save("tf_streaming_encoder.npz", wave_seed=9, L=24000, enc=senc(tf.constant(xs[..., None]), training=False).numpy(),
-         weights_seed=2)
+         weights_seed=2, freq2mel=kept_s.get("mel_layer/freq2mel"))
     done.append("streaming_encoder")
 
     # ---- 8f-1: Translator ------------------------------------------------------------------------------------------
@@ -195,6 +218,9 @@ def main():
         leaf = frontend.Leaf(n_filters=80, sample_rate=16000, window_stride=10,
                              complex_conv_init=frontend.initializers.GaborInit(sample_rate=16000, min_freq=60, max_freq=7800))
         xl = waves(2, 16000, 60)
+        leaf(tf.constant(xl[..., None]), training=False)
+        for v in leaf.weights:             # the fixture stores float32 values: run on exactly those (matters for the stand-in's wide pass)
+            v.assign(np.asarray(v.numpy(), np.float32))
         yl = leaf(tf.constant(xl[..., None]), training=False).numpy()
         save("tf_leaf.npz", wave_seed=60, L=16000, out=yl, **{v.name.replace("/", "|"): v.numpy() for v in leaf.weights})
         done.append("leaf")
@@ -232,4 +258,26 @@ def main():
 
 
 if __name__ == "__main__":
+    import pickle
+    import subprocess
+    if "--wide-pass" in sys.argv:
+        # the same reference code carried in float64 (float32-rounded constants).  Its own process: leaf_audio/frontend.py:101
+        # builds the PCEN layer as a default ARGUMENT, i.e. once per process, and a second Leaf would inherit the first one's
+        # float32 variables.
+        tf_, standin_ = import_tensorflow()
+        assert standin_
+        tf_.set_wide(True)
+        SUFFIX[0] = "_f64"
+        main()
+        with open(sys.argv[sys.argv.index("--wide-pass") + 1], "wb") as f:
+            pickle.dump(FIXTURES, f)
+        sys.exit(0)
     main()
+    if import_tensorflow()[1]:
+        with tempfile.TemporaryDirectory() as td:
+            tmp = os.path.join(td, "wide.pkl")
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--wide-pass", tmp])
+            with open(tmp, "rb") as f:
+                for name, fx in pickle.load(f).items():
+                    FIXTURES[name].update(fx)
+    write_all()
