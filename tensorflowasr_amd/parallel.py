@@ -63,6 +63,24 @@ def _check_local_rows(B, n_total, group):
                          "shard_range slice of the batch" % (rank, B, n_total, rank, world, want))
 
 
+class GatherWork:
+    """handle of an asynchronous all_gather_ids: wait(), then result() -> (ids_all, lens_all)"""
+
+    def __init__(self, works, outs, keep, inputs):
+        self._works, self._outs, self._keep = works, outs, keep
+        self._inputs = inputs            # the (possibly padded) send buffers stay alive until the exchange has read them
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+
+    def result(self):
+        self.wait()
+        if self._keep is None:
+            return self._outs
+        return tuple(o[self._keep] for o in self._outs)
+
+
 def all_gather_ids(ids, lens, group=None, async_op=False, n_total=None):
     """ids int32 [B_local, T] (-1 padded), lens int32 [B_local] -> ([B_total, T], [B_total]) on every rank, in rank order.
 
@@ -72,10 +90,12 @@ def all_gather_ids(ids, lens, group=None, async_op=False, n_total=None):
     the global utterance count: every rank pads its shard_range slice to ceil(n_total / world) rows, the padding rows are
     dropped after the exchange (each rank knows every other rank's count from shard_range: no extra collective).
 
-    async_op=True returns (work, ids_all, lens_all) at once: the collective runs on RCCL's stream behind the kernels
-    already queued, the caller's stream goes on with the next batch and `work.wait()` (or a device synchronise) makes
-    the views valid -- one batch's exchange then overlaps the next batch's recognition.  (With n_total the padded gather
-    buffers are returned through a view that drops the padding rows after wait(): use `work.result()`.)"""
+    async_op=True returns ONE handle at once, the same in every case: the collectives run on RCCL's stream behind the kernels
+    already queued, the caller's stream goes on with the next batch; `handle.wait()` blocks until the exchange is done and
+    `handle.result()` = wait() + (ids_all, lens_all) with any padding rows dropped -- one batch's exchange then overlaps the
+    next batch's recognition.  Without n_total nothing is enqueued on the caller's stream (the two tensors go out as they
+    are: the caller keeps them untouched until the work is done -- rotating output buffers, recognize(out=...)); with
+    n_total the shard is first padded to ceil(n_total / world) rows on the caller's stream (a cat of at most one row)."""
     world = dist.get_world_size(group)
     B, T = ids.shape
     b_pad = B
@@ -84,25 +104,12 @@ def all_gather_ids(ids, lens, group=None, async_op=False, n_total=None):
         b_pad = -(-n_total // world)
         ids, lens = _pad_rows(ids, b_pad, -1), _pad_rows(lens, b_pad, 0)
     if async_op:
-        # nothing on the caller's stream: the two tensors go out as they are (the caller keeps them untouched until the
-        # work is done -- rotating output buffers, recognize(out=...)), both collectives on RCCL's stream
         all_ids = torch.empty((world * b_pad, T), dtype=ids.dtype, device=ids.device)
         all_lens = torch.empty((world * b_pad,), dtype=lens.dtype, device=lens.device)
         w1 = dist.all_gather_into_tensor(all_ids, ids, group=group, async_op=True)
         w2 = dist.all_gather_into_tensor(all_lens, lens, group=group, async_op=True)
         keep = _valid_rows(n_total, world, b_pad, ids.device) if n_total is not None and n_total != world * b_pad else None
-
-        class _Both:
-            def wait(self):
-                w1.wait()
-                w2.wait()
-
-            def result(self):
-                self.wait()
-                return (all_ids, all_lens) if keep is None else (all_ids[keep], all_lens[keep])
-        if keep is not None:
-            return _Both(), None, None          # the padded buffers are not what the caller wants: result() after wait
-        return _Both(), all_ids, all_lens
+        return GatherWork((w1, w2), (all_ids, all_lens), keep, (ids, lens))
     # one collective per batch: the lengths ride in an extra column of the id matrix (xGMI is latency-, not
     # bandwidth-bound at 64 KB per rank, so the second all_gather would double the exchange time)
     packed = torch.empty((b_pad, T + 1), dtype=ids.dtype, device=ids.device)

@@ -46,10 +46,9 @@ def _worker(rank, world, port, tmpdir):
         # the pipelined form bench.py uses: several exchanges in flight, waited for at the end
         works = []
         for shift in range(3):
-            w_, a_ids, a_lens = all_gather_ids(torch.from_numpy(ids + shift), torch.from_numpy(lens), async_op=True)
-            works.append((w_, a_ids, a_lens, shift))
-        for w_, a_ids, a_lens, shift in works:
-            w_.wait()
+            works.append((all_gather_ids(torch.from_numpy(ids + shift), torch.from_numpy(lens), async_op=True), shift))
+        for w_, shift in works:
+            a_ids, a_lens = w_.result()
             assert np.array_equal(a_ids.numpy(), full_ids + shift) and np.array_equal(a_lens.numpy(), full_lens)
         open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
     finally:
@@ -126,7 +125,7 @@ def _world8_worker(rank, world, port, tmpdir):
             full_ids, full_lens = co.ctc_collapse(frames, in_len, blank)
             a_ids, a_lens = all_gather_ids(torch.from_numpy(ids), torch.from_numpy(lens), n_total=B)
             assert np.array_equal(a_ids.numpy(), full_ids) and np.array_equal(a_lens.numpy(), full_lens)
-            work, x, y = all_gather_ids(torch.from_numpy(ids), torch.from_numpy(lens), async_op=True, n_total=B)
+            work = all_gather_ids(torch.from_numpy(ids), torch.from_numpy(lens), async_op=True, n_total=B)   # same handle, padded or not
             r_ids, r_lens = work.result()
             assert np.array_equal(r_ids.numpy(), full_ids) and np.array_equal(r_lens.numpy(), full_lens)
             if B == 512:                    # equal shards: the un-padded form as well
@@ -168,3 +167,33 @@ def test_dp_world8_config4_and_config5_partitions_and_uneven_batches(tmp_path):
     mp.spawn(_world8_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("w8_ok%d" % r)).exists() for r in range(world))
 
+
+
+def test_bench_starts_its_own_ranks_when_run_the_way_the_driver_runs_it():
+    """Round-4 review: `python3 bench.py --gpus N` (no launcher around it) stopped in argparse.  Now it re-runs itself under
+    torch.distributed.run, one rank per GPU.  --dry-run-gloo takes the GPU out of that path (gloo, a stand-in recogniser) and
+    keeps everything else of main()'s multi-rank control flow: rendezvous on 127.0.0.1, rank-count check through the backend,
+    rotating output sets, the asynchronous per-step id exchange, barrier + max-over-ranks timing, repeated timed regions and
+    ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for n in (2, 4):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "1", "--batch", "3",
+                            "--dry-run-gloo"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout                       # rank 0 only
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == n and line["config"]["ranks"] == n and line["config"]["parallelism"] == "dp%d" % n
+        assert line["gathered_ids_in_rank_order"] is True and line["dry_run"] is True
+        assert line["steps"] == 4 and line["config"]["global_batch"] == 3 * n and line["scaling"] == "weak"
+        for k in ("metric", "value", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "timed_region_s",
+                  "region_ms_per_step"):
+            assert k in line, k
+    # a WORLD_SIZE that contradicts --gpus is refused, not silently benchmarked
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-gloo"], capture_output=True, text=True,
+                       timeout=120, cwd=root, env=dict(env, WORLD_SIZE="3", RANK="0"))
+    assert r.returncode != 0 and "does not match" in r.stderr
