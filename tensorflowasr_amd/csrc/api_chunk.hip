@@ -475,10 +475,11 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     me.logp = st.logp; me.umax = nullptr; me.mel = (float*)(ws + p.mel); me.wp = m->mel_wp;
     me.B = B; me.F = g.F; me.LP = m->dm.LP; me.nbins = m->dm.nbins; me.KBm = m->dm.KBm; me.NTm = m->dm.NTm;
     me.NM = c.n_mels; me.FT = FT; me.floor_db = 0.f;
-    // round 4: the valid frontend's log10 features have no static bound; the banded mel kernel leaves the batch's largest
-    // |mel| in the first word of the (by now consumed) per-frame maxima, and the two-term subsampling conv scales by it
+    // round 4: the valid frontend's log10 features have no static bound; the banded mel kernel leaves each utterance's largest
+    // |mel| in the first B words of the (by now consumed) per-frame maxima, and the two-term subsampling conv scales by it
+    // (round 5: per utterance, not per batch -- a quiet utterance next to a loud one keeps its own 2^-22, and B = 1 == B = N)
     unsigned* melmax = (m->mel_band && m->c2_whalf && m->c1_l1 > 0.f) ? (unsigned*)(ws + p.pmax) : nullptr;
-    if (melmax) { HIP_TRY(hipMemsetAsync(melmax, 0, sizeof(unsigned), s)); me.absmax = melmax; }
+    if (melmax) { HIP_TRY(hipMemsetAsync(melmax, 0, sizeof(unsigned) * (size_t)B, s)); me.absmax = melmax; }
     { PROF(MI355ASR_K_MEL); LAUNCH_TRY(launch_mel_auto(m, me, s), "mel (valid)"); }
     SubConvArgs sa{};
     sa.mel = me.mel; sa.out = (float*)(ws + p.sub); sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;

@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void mel_band_kernel(MelArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
       const unsigned mine = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
-      if (mine > __hip_atomic_load(a.absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.absmax, mine);
+      unsigned* word = a.absmax + blockIdx.y;           // one word per utterance: an utterance's scale is its own (batch-invariant)
+      if (mine > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, mine);
     }
   }
 }

@@ -127,8 +127,8 @@ struct MelArgs {
   const int* band = nullptr;
   const float* bw = nullptr;
   int BW = 0;
-  // mel_band_kernel only: when set, the largest |mel| of the launch is left here as a float bit pattern (atomicMax on the bits of
-  // non-negative floats; the caller zeroes the word first).  The 'valid' chunk frontend has no dB normalisation, hence no static
+  // mel_band_kernel only: when set ([B] words), the largest |mel| of every utterance is left here as a float bit pattern (atomicMax
+  // on the bits of non-negative floats; the caller zeroes the words first).  The 'valid' chunk frontend has no dB normalisation, hence no static
   // bound on its features: the two-term subsampling conv takes its operand scale from this run-time maximum.
   unsigned* absmax = nullptr;
 };
@@ -145,8 +145,9 @@ struct SubConvArgs {
   // fragment pair instead of six, the accumulators carry h_scale * h_wscale (subconv.hip, "two-term scheme")
   const float* w2h = nullptr;
   float h_scale = 1.f, h_wscale = 1.f;
-  // run-time operand scale (features without a static bound): when h_melmax is set, h_scale is derived in the kernel as the power
-  // of two that puts h_l1 * max|mel| + h_bmax (h_l1 = the largest L1 norm of a conv1 filter, h_bmax = the largest |bias|) at 2^15
+  // run-time operand scale (features without a static bound): when h_melmax is set ([B] words, one per utterance: results do not
+  // depend on what else is in the batch), h_scale is derived in the kernel as the power
+  // of two that puts h_l1 * max|mel of the utterance| + h_bmax (h_l1 = the largest L1 norm of a conv1 filter, h_bmax = the largest |bias|) at 2^15
   const unsigned* h_melmax = nullptr;
   float h_l1 = 0.f, h_bmax = 0.f;
   int B, F, NM, T1, F1, T2, F2;

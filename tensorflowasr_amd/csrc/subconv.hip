@@ -371,8 +371,8 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   const int b = blockIdx.y, r0 = blockIdx.x * (SCW * 16 * RTN), PU = a.T2 * a.F2;
   const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(TM == 2 ? a.w2h : a.w2s) + (size_t)blockIdx.z * NK32 * SLABF;
   float s1 = TM == 2 ? a.h_scale : 1.f;
-  if (TM == 2 && a.h_melmax) {                   // features without a static bound: the scale from the batch's own maximum
-    const float bound = fmaf(a.h_l1, __uint_as_float(*a.h_melmax), a.h_bmax);
+  if (TM == 2 && a.h_melmax) {                   // features without a static bound: the scale from the UTTERANCE's own maximum
+    const float bound = fmaf(a.h_l1, __uint_as_float(a.h_melmax[b]), a.h_bmax);
     const int e = (int)((__float_as_uint(bound) >> 23) & 255u);                // bound in [2^(e - 127), 2^(e - 126))
     s1 = __uint_as_float((unsigned)(127 + min(60, max(-60, 141 - e))) << 23);   // bound * s1 < 2^15
   }

@@ -954,9 +954,9 @@ def test_chunk_conformer_predict_stage_parity(torch_cuda, L):
 
 
 @pytest.mark.parametrize("amp", [1.0, 1e-3, 40.0])
-def test_chunk_front_two_term_conv_scales_by_the_batch_maximum(torch_cuda, amp):
+def test_chunk_front_two_term_conv_scales_by_the_run_time_maximum(torch_cuda, amp):
     """The valid ChunkConformer frontend has no dB normalisation: its log10 features have no static bound, so the two-term
-    subsampling conv (round 4) takes its operand scale from the batch's largest |mel|, left by the banded mel kernel as a float
+    subsampling conv (round 4) takes its operand scale from each utterance's largest |mel|, left by the banded mel kernel as a float
     bit pattern (atomicMax).  Waveforms of three amplitudes -- log10 power shifts by -6 / +3.2 -- one silent utterance in
     the batch (its features sit at log10(amin), far from the maximum the scale follows): the front output against the oracle."""
     cfg = dict(co.CHUNK_S, enc_num_blocks=1, decoder_num_classes=300)
@@ -968,6 +968,25 @@ def test_chunk_front_two_term_conv_scales_by_the_batch_maximum(torch_cuda, amp):
     e = maxdiff(got["front"].cpu().numpy(), ref["front"])
     print("chunk front, amplitude %g: max|d| %.3g of max|ref| %.3g" % (amp, e, np.abs(ref["front"]).max()))
     assert e < TOL * max(1.0, float(np.abs(ref["front"]).max()) / 50.0)
+
+
+def test_chunk_front_is_the_same_for_an_utterance_whatever_shares_its_batch(torch_cuda):
+    """Round 5 (advisor): the operand scale of the two-term subsampling conv in the chunk front is taken per UTTERANCE (one
+    atomicMax word per utterance), so an utterance's features do not depend on its neighbours: a quiet utterance (amplitude
+    1e-3) batched with a loud one (amplitude 30) gives bit for bit what it gives alone, and both stay within the usual
+    distance of the oracle."""
+    cfg = dict(co.CHUNK_S, enc_num_blocks=1, decoder_num_classes=300)
+    w = co.chunk_weights(cfg, seed=6)
+    m = _chunk_model(cfg, w)
+    x = waves(3, 48000, 75)
+    x[0] *= np.float32(30.0)
+    x[1] *= np.float32(1e-3)
+    both = m.predict(x, stages=True)["front"].cpu().numpy()
+    ref = co.chunk_predict(x.astype(np.float64), w, cfg)["front"]
+    for b in range(3):
+        alone = m.predict(x[b:b + 1], stages=True)["front"].cpu().numpy()
+        assert np.array_equal(alone[0], both[b]), (b, float(np.abs(alone[0] - both[b]).max()))
+        assert maxdiff(both[b], ref[b]) < TOL * max(1.0, float(np.abs(ref[b]).max()) / 50.0), b
 
 
 def test_chunk_band_attention_matches_keras_mask_semantics(torch_cuda):
