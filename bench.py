@@ -156,8 +156,10 @@ def _oracle_rate(co, x, w, cfg, seconds_budget, max_reps):
 
 
 def cpu_baseline(seconds_budget=12.0):
-    """The NumPy oracle (a port of the reference path; TensorFlow is not installed) timed on this host: with every
-    core the BLAS pool takes and with one thread (the figure comparable to the README's single-core RTF)."""
+    """The NumPy oracle (a port of the reference path; TensorFlow is not installed) timed on this host.  One 10 s utterance at
+    a time is a small problem for a BLAS pool: on the 128-core GPU box every core made it SLOWER than one thread (round-4
+    review).  So the pool is tried at 1, 8, 32 and all threads and the best is the baseline (`threads_best`); the one-thread
+    figure is the one comparable to the README's single-core RTF."""
     from oracle import conformer_oracle as co          # checker only: never on the measured GPU path
     from threadpoolctl import threadpool_info, threadpool_limits
     cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
@@ -166,14 +168,19 @@ def cpu_baseline(seconds_budget=12.0):
     golden = os.path.join(ROOT, "tests", "golden", "ctc_decoder_weights.npz")
     w.update(dict(np.load(golden)) if os.path.exists(golden) else co.ctc_decoder_weights(cfg, NUM_CLASSES))
     x = co.synth_wave(0, 160000)[None]
-    v_all, r_all, t_all = _oracle_rate(co, x, w, cfg, seconds_budget, 8)
-    with threadpool_limits(limits=1):
-        v_1, r_1, t_1 = _oracle_rate(co, x, w, cfg, seconds_budget * 0.5, 2)
-    return {"value": round(v_all, 1), "unit": "audio-frames/s", "cores": int(cores), "kind": "port",
-            "sample": "%d x (1 utterance, 10 s = 1000 frames) through the fp32 NumPy oracle, %.1f s total" % (r_all, t_all),
-            "all_cores": {"value": round(v_all, 1), "threads": int(cores)},
-            "threads1": {"value": round(v_1, 1), "threads": 1,
-                         "sample": "%d x 1 utterance, %.1f s total, BLAS pool limited to one thread" % (r_1, t_1)},
+    tries = sorted({t for t in (1, 8, 32, cores) if t <= cores})
+    runs = {}
+    for t in tries:
+        with threadpool_limits(limits=t):
+            v, r, tt = _oracle_rate(co, x, w, cfg, seconds_budget / len(tries), 4)
+        runs[t] = {"value": round(v, 1), "threads": t, "sample": "%d x 1 utterance (10 s = 1000 frames), %.1f s" % (r, tt)}
+    best = max(runs, key=lambda t: runs[t]["value"])
+    return {"value": runs[best]["value"], "unit": "audio-frames/s", "cores": int(best), "kind": "port", "threads_best": int(best),
+            "host_threads": int(cores),
+            "sample": "the fp32 NumPy oracle on one 10 s utterance at a time, BLAS pool limited to %s threads in turn (%s); best kept"
+                      % (tries, "; ".join("%d: %s" % (t, runs[t]["sample"]) for t in tries)),
+            "by_threads": {str(t): runs[t]["value"] for t in tries},
+            "threads1": runs[1], "all_cores": runs[cores],
             "published_tf2_1core": PUBLISHED_TF2_1CORE}
 
 

@@ -1130,6 +1130,8 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   sa.mel = mel; sa.out = sub; sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b; sa.w2s = m->c2_wsplit;
   static const bool force_half = [] { const char* v = getenv("MI355ASR_SUBCONV_TERMS"); return v && atoi(v) == 22; }();   // 22: also for caller-supplied features (tests)
   if (m->c2_whalf && (mel_bounded || force_half)) { sa.w2h = m->c2_whalf; sa.h_scale = m->c2_hscale; sa.h_wscale = m->c2_wscale; }
+  // conv1 on the matrix pipe needs the frontend's own bound on |mel| for its fp16 planes: not for caller-supplied features
+  if (sa.w2h && mel_bounded) { sa.c1_mscale = m->c1_mscale; sa.c1_wscale = m->c1_wscale; }
   sa.B = Bp; sa.F = F; sa.NM = c.n_mels; sa.T1 = T1; sa.F1 = m->dm.F1; sa.T2 = T2; sa.F2 = m->dm.F2;
   sa.st1 = m->dm.st1; sa.pt1 = pt1; sa.pf1 = m->dm.pf1; sa.pt2 = pt2; sa.pf2 = m->dm.pf2;
   { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling"); }
@@ -1640,7 +1642,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   ArenaBuilder ab;
   ab.ring_terms = m->cfg.gemm_dtype == 1 ? 1 : 3;
   size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0, o_c2h = 0, o_lpp = 0;
-  float lin_pp_sw = 1.f, c1_l1 = 0.f, c1_bmax = 0.f;
+  float lin_pp_sw = 1.f, c1_l1 = 0.f, c1_bmax = 0.f, c1_ms = 0.f, c1_ws = 0.f;
   float c2_hs = 0.f, c2_ws = 0.f;
   FftOff fo;
   MelBandOff mbo;
@@ -1767,6 +1769,12 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
       }
       c1_l1 = (float)(l1max * (1.0 + 1e-6));
       c1_bmax = (float)(bmax * (1.0 + 1e-6));
+      {                                            // conv1 on the matrix pipe: |mel| <= mb, the largest |conv1 weight|
+        double w1max = 0.0;
+        for (float v : w1) w1max = std::max(w1max, std::fabs((double)v));
+        c1_ms = half_scale_for(mb * (1.0 + 1e-6));
+        c1_ws = half_scale_for(w1max);
+      }
       for (float v : c2) wmax = std::max(wmax, std::fabs((double)v));
       c2_hs = half_scale_for(bx);
       c2_ws = half_scale_for(wmax);
@@ -1862,7 +1870,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->fft_win = base + fo.win;
   m->c1_w = base + o_c1w; m->c1_b = base + o_c1b; m->c2_wp = base + o_c2w; m->c2_b = base + o_c2b; m->c2_wsplit = ((d == 144 || d == 256 || d == 512) && c.has_encoder) ? base + o_c2s : nullptr;
   m->c2_whalf = o_c2h ? base + o_c2h : nullptr; m->c2_hscale = c2_hs; m->c2_wscale = c2_ws;
-  m->c1_l1 = c1_l1; m->c1_bmax = c1_bmax;
+  m->c1_l1 = c1_l1; m->c1_bmax = c1_bmax; m->c1_mscale = c1_ms; m->c1_wscale = c1_ws;
   m->lin_wsplit = (d == 144 && c.has_encoder) ? base + o_lws : nullptr;
   m->lin_pp = (d == 144 && c.has_encoder) ? base + o_lpp : nullptr;
   m->lin_pp_sw = lin_pp_sw;

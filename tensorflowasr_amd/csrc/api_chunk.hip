@@ -187,7 +187,7 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   // round 4: the two-term fp16 forms -- conv2 as hi + lo of kernel * 2^k (its operand scale comes from the batch's largest |mel|
   // at run time: the valid frontend's log10 features have no static bound), the Dense as the stream of pp_sublinear_kernel
   size_t o_c2h = 0, o_lpp = 0;
-  float c2_ws = 0.f, c1_l1 = 0.f, c1_bmax = 0.f, lin_pp_sw = 1.f;
+  float c2_ws = 0.f, c1_l1 = 0.f, c1_bmax = 0.f, c1_ws = 0.f, lin_pp_sw = 1.f;
   if (split_front) {
     const auto& w1 = m->host["front/conv_subsampling/conv1/kernel"].data;
     const auto& b1 = m->host["front/conv_subsampling/conv1/bias"].data;
@@ -204,6 +204,9 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
       o_c2h = ab.put(pack_conv2_half(c2, d, c2_ws));
       c1_l1 = (float)(l1max * (1.0 + 1e-6));
       c1_bmax = (float)(bmax * (1.0 + 1e-6));
+      double w1max = 0.0;                          // conv1 on the matrix pipe (subconv.hip, C1M): the mel scale is taken at run time
+      for (float v : w1) w1max = std::max(w1max, std::fabs((double)v));
+      c1_ws = half_scale_for(w1max);
     }
     if (o_lws) {
       const auto& lb = m->host["front/conv_subsampling/linear/bias"].data;
@@ -237,7 +240,7 @@ int finalize_chunk(mi355asr_model* m, hipStream_t s) {
   m->lin_wp = base + o_lw; m->lin_b = base + o_lb;
   m->c2_wsplit = o_c2s ? base + o_c2s : nullptr;
   m->lin_wsplit = o_lws ? base + o_lws : nullptr;
-  m->c2_whalf = o_c2h ? base + o_c2h : nullptr; m->c2_wscale = c2_ws; m->c1_l1 = c1_l1; m->c1_bmax = c1_bmax;
+  m->c2_whalf = o_c2h ? base + o_c2h : nullptr; m->c2_wscale = c2_ws; m->c1_l1 = c1_l1; m->c1_bmax = c1_bmax; m->c1_wscale = c1_ws;
   m->lin_pp = o_lpp ? base + o_lpp : nullptr; m->lin_pp_sw = lin_pp_sw;
   resolve_stack(m->c_enc, e, base, false, 0);
   resolve_stack(m->c_picker, pk, base, true, cc.picker_num_classes);
@@ -485,7 +488,7 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     sa.mel = me.mel; sa.out = (float*)(ws + p.sub); sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
     sa.w2s = m->c2_wsplit;
     static const bool three = [] { const char* v = getenv("MI355ASR_SUBCONV_TERMS"); return v && atoi(v) == 3; }();
-    if (melmax && me.absmax && !three) { sa.w2h = m->c2_whalf; sa.h_wscale = m->c2_wscale; sa.h_melmax = melmax; sa.h_l1 = m->c1_l1; sa.h_bmax = m->c1_bmax; }
+    if (melmax && me.absmax && !three) { sa.w2h = m->c2_whalf; sa.h_wscale = m->c2_wscale; sa.h_melmax = melmax; sa.h_l1 = m->c1_l1; sa.h_bmax = m->c1_bmax; sa.c1_wscale = m->c1_wscale; }
     sa.B = B; sa.F = g.F; sa.NM = c.n_mels; sa.T1 = g.T1; sa.F1 = m->dm.F1; sa.T2 = T; sa.F2 = m->dm.F2;
     sa.st1 = 2; sa.pt1 = 4; sa.pf1 = 2; sa.pt2 = 0; sa.pf2 = 0;
     { PROF(MI355ASR_K_SUBCONV); LAUNCH_TRY(launch_subconv(d, sa, s), "conv subsampling (valid)"); }

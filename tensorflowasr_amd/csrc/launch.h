@@ -150,6 +150,10 @@ struct SubConvArgs {
   // of two that puts h_l1 * max|mel of the utterance| + h_bmax (h_l1 = the largest L1 norm of a conv1 filter, h_bmax = the largest |bias|) at 2^15
   const unsigned* h_melmax = nullptr;
   float h_l1 = 0.f, h_bmax = 0.f;
+  // conv1 on the matrix pipe (subconv.hip, C1M): the mel patch is staged as fp16 hi + lo of mel * c1_mscale (a power of two with
+  // bound(mel) * c1_mscale <= 2^15; 0 with h_melmax set: derived per utterance from the run-time maximum), the conv1 kernel as
+  // hi + lo of w * c1_wscale; both 0: conv1 is evaluated on the VALU in fp32
+  float c1_mscale = 0.f, c1_wscale = 0.f;
   int B, F, NM, T1, F1, T2, F2;
   int st1;            // conv1 time stride (reduction_factor/2)
   int pt1, pf1, pt2, pf2;  // pad-before of conv1 (time,freq) and conv2 (time,freq)

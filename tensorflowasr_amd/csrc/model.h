@@ -153,6 +153,7 @@ struct mi355asr_model {
   const float* c2_wsplit = nullptr;     // conv2 kernel as split-bf16 fragments (subconv.hip; dmodel 144 / 256 / 512)
   const float* c2_whalf = nullptr;      // ... as two fp16 terms of kernel * c2_wscale (two-term scheme), conv1 values times c2_hscale
   float c2_hscale = 0.f, c2_wscale = 0.f;
+  float c1_mscale = 0.f, c1_wscale = 0.f;  // conv1 on the matrix pipe (subconv.hip, C1M): power-of-two scales of the mel planes (static bound) and of the conv1 kernel
   float c1_l1 = 0.f, c1_bmax = 0.f;     // largest L1 norm of a conv1 filter / largest |bias|: the run-time operand bound of the chunk front
   const float* leaf_wsplit = nullptr;   // Gabor filters as split-bf16 MFMA fragments (leaf.hip)
   int leaf_terms = 3;                   // bf16 terms per fp32 operand in the Gabor conv (0: fp32 MFMA kernel)

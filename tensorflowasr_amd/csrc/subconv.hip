@@ -199,6 +199,32 @@ constexpr int MELP = 8192;                         // floats of LDS for the mel 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Round 5: the weight slabs of subconv_split_ring_kernel travel through a ring of SRING LDS slots, fetched SRING - 1 steps
+// ahead.  With the two-term operands a step's work (conv1 VALU + 54 MFMAs per wave) had shrunk below the latency of one slab's
+// DMA (~1.3 us when every workgroup asks L2 for the same lines), and with a double buffer -- slab s + 1 requested in step s and
+// waited for at its end -- every step lasted (conv1 phase) + (DMA latency): 3600 cycles for 2 x 864 of matrix work per SIMD.
+// -DMI355ASR_SUBCONV_RING=2 builds the double buffer (A / B timing).
+#ifndef MI355ASR_SUBCONV_RING
+#define MI355ASR_SUBCONV_RING 4
+#endif
+constexpr int SRING = MI355ASR_SUBCONV_RING;
+static_assert(SRING >= 2 && (SRING & (SRING - 1)) == 0, "ring slots: a power of two");
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the slab DMAs are the only vector-memory operations in flight in the step
+// loop and return in order, so "at most n outstanding" = "everything but the newest n pieces has landed"
+DEV void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
+    case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;      // any other count: wait for everything (always safe)
+  }
+}
+
 // 16 bytes per lane, global -> LDS without a register round trip; `lds` is the wave's (uniform) base, lane i writes
 // lds + 16 i.  Completion is counted by vmcnt.
 DEV void dma16(const u32x4* gsrc, u32x4* lds) {
@@ -216,6 +242,17 @@ DEV u32x4 lds_read16(unsigned addr) {
   return v;
 }
 
+// Round 5: the conv1 evaluation's VALU phase was TWICE the MFMA phase of a step (3600 cycles per step interval against 2 x 864
+// of matrix work per SIMD): 36 ds_read_b32 per step, each waited for with lgkmcnt(0) in front of its four v_fmac_f32.  V2:
+// the mel patch in plain row-major order so that a lane's window columns are one or two vector reads per row (all of a tap's
+// reads issued before its first multiply-add), two v_pk_fma_f32 per mel value instead of four v_fmac_f32, ReLU + zero padding as
+// one v_med3_f32, the fp16 lo term as v_fma_mixlo / mixhi_f16.  Same multiply-adds in the same order: bit-identical results.
+// -DMI355ASR_CONV1_V2=0 builds the round-3 evaluation (A / B timing).
+#ifndef MI355ASR_CONV1_V2
+#define MI355ASR_CONV1_V2 1
+#endif
+#define MI355ASR_CONV1_PK MI355ASR_CONV1_V2
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct SplitFrag { u32x4 t[3]; };                  // 8 k-slots x 3 terms
 
 // exact three-term bf16 split of eight fp32 values (slots 0..3 = lo, 4..7 = hi), two values per dword
@@ -247,7 +284,6 @@ DEV SplitFrag split8(f32x4 lo, f32x4 hi) {
 // second accumulator, which the power-of-two scales make unnecessary here).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 DEV unsigned pk_f16(float a, float b) {      // v_cvt_pk_f16_f32: both halves round to nearest
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2));
 }
@@ -259,7 +295,17 @@ DEV SplitFrag split8h(f32x4 lo, f32x4 hi) {
   for (int k = 0; k < 4; ++k) {
     d0[k] = pk_f16(v[2 * k], v[2 * k + 1]);
     const f16x2 h = __builtin_bit_cast(f16x2, d0[k]);
+#if MI355ASR_CONV1_PK
+    // lo = fp16(v - hi) as v_fma_mixlo / mixhi_f16: the fp16 hi is read in place (op_sel picks the half), v - hi is formed in
+    // fp32 (exact) and rounded once into the destination half -- the same value as v_cvt_f32_f16 + v_sub_f32 + v_cvt_pk_f16_f32,
+    // two instructions per pair instead of five
+    unsigned lo2;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo2) : "v"(d0[k]), "v"(v[2 * k]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo2) : "v"(d0[k]), "v"(v[2 * k + 1]));
+    d1[k] = lo2;
+#else
     d1[k] = pk_f16(v[2 * k] - (float)h.x, v[2 * k + 1] - (float)h.y);
+#endif
   }
   f.t[0] = u32x4{d0[0], d0[1], d0[2], d0[3]};
   f.t[1] = u32x4{d1[0], d1[1], d1[2], d1[3]};
@@ -276,8 +322,11 @@ DEV f32x4 mma_terms(u32x4 w, u32x4 x, f32x4 c) {
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
 }
 
-template <int RTN>
+// PK: conv1's multiply-adds as v_pk_fma_f32 (operands in aligned register pairs).  dmodel 144 only: the 128-channel-chunk
+// kernels of dmodel 256 / 512 hold two weight-fragment groups per step and have no room for the pairs (they would spill).
+template <int RTN, bool PK_ = true>
 struct SplitLane {
+  static constexpr bool PK = PK_;
   int mb[RTN];                // float offset of the lane's 7x7 mel window in the LDS patch, per row tile
   unsigned valid[RTN];        // bit kt*3+kf: conv1 position inside [0,T1) x [0,F1)
 };
@@ -289,6 +338,65 @@ struct SplitLane {
 // conflicts, 25 % of the kernel's LDS cycles); RS.row = 4 seg + pad with 4 RS.row = 20 (mod 32), so that a tile that wraps
 // into the next output row (f2: 19 -> 0, + 4 patch rows) continues on the next banks as well.
 struct PatchGeom { int row, seg; };
+#if MI355ASR_CONV1_V2
+// the 3 x 3 mel window of tap Q for one position: plain patch rows, the lane's window starts at bin 4 f2 of its row (16-byte
+// aligned); columns 2 kf .. 2 kf + 2 of three rows: kf = 0 -> the first three floats of one b128 / b96, kf = 2 -> of the one
+// behind it, kf = 1 -> a b64 + a b32.  Issued as a block: one exposed LDS latency per window instead of nine.
+struct Win9 { float m[3][3]; };
+template <int Q, int DIAG = 0, class SL>
+DEV Win9 conv1_window(const float* melp, PatchGeom RS, const SL& sl, int rt) {
+  constexpr int kt = Q / 3, kf = Q % 3;
+  int off = sl.mb[rt];
+  asm volatile("" : "+v"(off));            // opaque: otherwise the window reads are hoisted out of the channel-block loop
+  const float* mp = melp + off + (2 * kt) * RS.row;
+  Win9 w;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float* rp = mp + i * RS.row;
+    if constexpr (DIAG == 5) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w.m[i][j] = __builtin_bit_cast(float, off + i * RS.row + 2 * kf + j);
+    } else if constexpr (kf == 1) {
+      const f32x2 a = *reinterpret_cast<const f32x2*>(rp + 2);
+      w.m[i][0] = a.x; w.m[i][1] = a.y; w.m[i][2] = rp[4];
+    } else {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(rp + 2 * kf);
+      w.m[i][0] = a.x; w.m[i][1] = a.y; w.m[i][2] = a.z;
+    }
+  }
+  return w;
+}
+// conv1 + ReLU (+ conv2's zero padding) at tap Q for channels 16 cb + 4 g .. + 3 from the window: the nine multiply-adds per
+// channel in the round-3 order (rows, then columns), two channels per v_pk_fma_f32; ReLU and the padding as one v_med3_f32:
+// median(v, 0, +inf) = max(v, 0), median(v, 0, 0) = 0
+template <int Q, class SL>
+DEV f32x4 conv1_eval(const Win9& win, const SL& sl, int rt, const f32x4 (&w1r)[9], f32x4 b1v) {
+  f32x2 lo2 = {b1v.x, b1v.y}, hi2 = {b1v.z, b1v.w};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f32x4 w = w1r[i * 3 + j];
+      const float m = win.m[i][j];
+      if constexpr (SL::PK) {
+        const f32x2 mm = {m, m};
+        lo2 = __builtin_elementwise_fma(mm, f32x2{w.x, w.y}, lo2);
+        hi2 = __builtin_elementwise_fma(mm, f32x2{w.z, w.w}, hi2);
+      } else {
+        lo2.x = __builtin_fmaf(m, w.x, lo2.x); lo2.y = __builtin_fmaf(m, w.y, lo2.y);
+        hi2.x = __builtin_fmaf(m, w.z, hi2.x); hi2.y = __builtin_fmaf(m, w.w, hi2.y);
+      }
+    }
+  const bool ok = (sl.valid[rt] >> Q) & 1u;
+  const float lim = ok ? __builtin_inff() : 0.f;
+  return f32x4{__builtin_amdgcn_fmed3f(lo2.x, 0.f, lim), __builtin_amdgcn_fmed3f(lo2.y, 0.f, lim),
+               __builtin_amdgcn_fmed3f(hi2.x, 0.f, lim), __builtin_amdgcn_fmed3f(hi2.y, 0.f, lim)};
+}
+template <int Q, int DIAG = 0, class SL>
+DEV f32x4 conv1_at(const float* melp, PatchGeom RS, const SL& sl, int rt, const f32x4 (&w1r)[9], f32x4 b1v) {
+  return conv1_eval<Q>(conv1_window<Q, DIAG>(melp, RS, sl, rt), sl, rt, w1r, b1v);
+}
+#else
 template <int Q, int DIAG = 0, class SL>
 DEV f32x4 conv1_at(const float* melp, PatchGeom RS, const SL& sl, int rt, const f32x4 (&w1r)[9], f32x4 b1v) {
   constexpr int kt = Q / 3, kf = Q % 3;
@@ -311,13 +419,24 @@ DEV f32x4 conv1_at(const float* melp, PatchGeom RS, const SL& sl, int rt, const 
   v.z = ok ? fmaxf(v.z, 0.f) : 0.f; v.w = ok ? fmaxf(v.w, 0.f) : 0.f;
   return v;
 }
+#endif
 
-template <int PAIR, int DIAG = 0, int TM = 3, int RTN>
-DEV void frags_for(SplitFrag (&xf)[RTN], const float* melp, PatchGeom RS, const SplitLane<RTN>& sl, const f32x4 (&w1r)[9], f32x4 b1v) {
+template <int PAIR, int DIAG = 0, int TM = 3, int RTN, class SL>
+DEV void frags_for(SplitFrag (&xf)[RTN], const float* melp, PatchGeom RS, const SL& sl, const f32x4 (&w1r)[9], f32x4 b1v) {
 #pragma unroll
   for (int rt = 0; rt < RTN; ++rt) {
-    const f32x4 lo = conv1_at<2 * PAIR, DIAG>(melp, RS, sl, rt, w1r, b1v);
-    const f32x4 hi = conv1_at<2 * PAIR + 1, DIAG>(melp, RS, sl, rt, w1r, b1v);
+    f32x4 lo, hi;
+#if MI355ASR_CONV1_V2
+    if constexpr (SL::PK) {                // both windows of the row tile requested before the first multiply-add
+      const Win9 wlo = conv1_window<2 * PAIR, DIAG>(melp, RS, sl, rt), whi = conv1_window<2 * PAIR + 1, DIAG>(melp, RS, sl, rt);
+      lo = conv1_eval<2 * PAIR>(wlo, sl, rt, w1r, b1v);
+      hi = conv1_eval<2 * PAIR + 1>(whi, sl, rt, w1r, b1v);
+    } else
+#endif
+    {
+      lo = conv1_at<2 * PAIR, DIAG>(melp, RS, sl, rt, w1r, b1v);
+      hi = conv1_at<2 * PAIR + 1, DIAG>(melp, RS, sl, rt, w1r, b1v);
+    }
     if constexpr (DIAG == 6) {               // no split: the raw bits as three "terms"
       const u32x4 l = __builtin_bit_cast(u32x4, lo), h = __builtin_bit_cast(u32x4, hi);
       xf[rt].t[0] = l; xf[rt].t[1] = h; xf[rt].t[2] = l ^ h;
@@ -329,8 +448,8 @@ DEV void frags_for(SplitFrag (&xf)[RTN], const float* melp, PatchGeom RS, const 
 
 // operand of a ninth-tap step: conv1 at tap 8 for channel block cbA (slots 0..3) and cbA + 1 (slots 4..7; zeros past the
 // last block); the conv1 taps of the two blocks pass through the same registers one after the other
-template <int DIAG, int TM, class LT, int RTN>
-DEV void frags_ninth(SplitFrag (&xf)[RTN], const float* melp, PatchGeom RS, const SplitLane<RTN>& sl, f32x4 (&w1r)[9], const float* p_b1,
+template <int DIAG, int TM, class LT, int RTN, class SL>
+DEV void frags_ninth(SplitFrag (&xf)[RTN], const float* melp, PatchGeom RS, const SL& sl, f32x4 (&w1r)[9], const float* p_b1,
                      int g4, int cbA, int KBn, LT&& load_taps) {
   f32x4 lo[RTN], hi[RTN];
   load_taps(cbA);
@@ -348,9 +467,125 @@ DEV void frags_ninth(SplitFrag (&xf)[RTN], const float* melp, PatchGeom RS, cons
   for (int rt = 0; rt < RTN; ++rt) xf[rt] = split_terms<TM>(lo[rt], hi[rt]);
 }
 
+// ---- conv1 on the matrix pipe (round 5; two-term kernel of dmodel 144: template flag C1M) ----------------------------------------
+// The ablations of the two-term kernel (profiles/r05_subconv_ablation.md): MFMA floor 185 us, kernel without its conv1 / split
+// VALU work 266 us, with it 390 -- the ~220 VALU instructions per step and wave do NOT hide behind the partner wave's 54 MFMAs
+// (a SIMD issues about two VALU instructions per 16-cycle MFMA for free, and needs eight).  conv1 is a 9-tap dot product per
+// (position, channel): as a matrix product W1^T [16 channels x K] . window [K x 16 positions] with K = 32 slots = (window row
+// i = 0..2 in lane group g = i, eight patch columns 4 f2 .. 4 f2 + 7 per row; group 3 is zero) its result arrives in exactly
+// the accumulator layout the conv2 operand is built from (lane (g, c): channels 4 g .. 4 g + 3 of position c).  The mel patch is
+// staged ONCE per workgroup as two fp16 planes (hi + lo of mel x 2^m: the two-term representation every other layer uses), so the
+// B operand of a tap is one ds_read2_b64 per plane -- the column offset 2 kf of the tap is carried by the A operand: the taps'
+// weights (hi + lo of w x 2^w, built per channel block from the staged kernel) sit at slots 2 kf .. 2 kf + 2 of each row, zeros
+// elsewhere.  Three MFMAs per (row tile, tap) instead of 36 multiply-adds and nine window reads; the bias enters as the
+// accumulator's initial value.  66 MFMAs and ~50 VALU instructions per step and wave instead of 54 and ~220.
+// Arithmetic: hi x hi + hi x lo + lo x hi in fp32 -- conv1 is now a two-term product like conv2 (2^-22 of its operand bounds),
+// no longer an exact fp32 FMA chain; MI355ASR_SUBCONV_C1M=0 keeps the VALU evaluation.
+constexpr int C1_ROWB = 192;                       // bytes of one patch row in a plane: 96 fp16 bins (4 F2 + 4 <= 96)
+constexpr int C1_ZERO_ROWS = 8;                    // rows of zeros behind the planes (lane group 3, and rows past a tap's window)
+template <int RTN>
+struct C1Lane {
+  static constexpr bool PK = true;
+  unsigned bh[RTN], bl[RTN];                       // LDS byte address of the lane's window row (tap row 0) in the hi / lo plane
+  unsigned valid[RTN];
+};
+template <int KT>
+DEV u32x4 c1_read(unsigned addr) {                 // eight fp16 bins of window row 2 KT + g: 16 bytes at an 8-byte aligned address
+  u32x4 v;
+  asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(KT * (2 * C1_ROWB / 8)), "n"(KT * (2 * C1_ROWB / 8) + 1));
+  return v;
+}
+struct C1Taps { unsigned ph, qh, pl, ql; };        // (w0, w1), (w2, 0) of this lane's (channel, window row) as fp16 hi and lo
+template <int KF>
+DEV u32x4 c1_place(unsigned p, unsigned q) {       // the three weights at slots 2 KF .. 2 KF + 2 of the lane's eight
+  if constexpr (KF == 0) return u32x4{p, q, 0u, 0u};
+  else if constexpr (KF == 1) return u32x4{0u, p, q, 0u};
+  else return u32x4{0u, 0u, p, q};
+}
+DEV f32x4 c1_mma(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// ReLU + conv2's zero padding (v_med3_f32) and the step from conv1's accumulator unit (2^m 2^w) to the conv2 operand scale
+template <int Q, class SL>
+DEV f32x4 c1_finish(f32x4 v, const SL& sl, int rt, float kmul) {
+  const float lim = ((sl.valid[rt] >> Q) & 1u) ? __builtin_inff() : 0.f;
+  return f32x4{__builtin_amdgcn_fmed3f(v.x, 0.f, lim) * kmul, __builtin_amdgcn_fmed3f(v.y, 0.f, lim) * kmul,
+               __builtin_amdgcn_fmed3f(v.z, 0.f, lim) * kmul, __builtin_amdgcn_fmed3f(v.w, 0.f, lim) * kmul};
+}
+// the operand of a tap-pair step: taps 2 PAIR (k-slots 0..3) and 2 PAIR + 1 (slots 4..7) of the channel block whose taps are in tp
+template <int PAIR, int RTN, class SL>
+DEV void frags_for_mm(SplitFrag (&xf)[RTN], const SL& sl, const C1Taps& tp, f32x4 c0v, float kmul) {
+  constexpr int QA = 2 * PAIR, QB = 2 * PAIR + 1;
+  u32x4 wh[RTN][2], wlo[RTN][2];
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt) {
+    wh[rt][0] = c1_read<QA / 3>(sl.bh[rt]); wlo[rt][0] = c1_read<QA / 3>(sl.bl[rt]);
+    wh[rt][1] = c1_read<QB / 3>(sl.bh[rt]); wlo[rt][1] = c1_read<QB / 3>(sl.bl[rt]);
+  }
+  const u32x4 ah[2] = {c1_place<QA % 3>(tp.ph, tp.qh), c1_place<QB % 3>(tp.ph, tp.qh)};
+  const u32x4 al[2] = {c1_place<QA % 3>(tp.pl, tp.ql), c1_place<QB % 3>(tp.pl, tp.ql)};
+  f32x4 v[RTN][2];
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt) { v[rt][0] = c0v; v[rt][1] = c0v; }
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh[rt][0]), "+v"(wlo[rt][0]), "+v"(wh[rt][1]), "+v"(wlo[rt][1]));
+  // smallest products first; the 2 RTN accumulators take turns
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt) { v[rt][0] = c1_mma(al[0], wh[rt][0], v[rt][0]); v[rt][1] = c1_mma(al[1], wh[rt][1], v[rt][1]); }
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt) { v[rt][0] = c1_mma(ah[0], wlo[rt][0], v[rt][0]); v[rt][1] = c1_mma(ah[1], wlo[rt][1], v[rt][1]); }
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt) { v[rt][0] = c1_mma(ah[0], wh[rt][0], v[rt][0]); v[rt][1] = c1_mma(ah[1], wh[rt][1], v[rt][1]); }
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt)
+    xf[rt] = split8h(c1_finish<QA>(v[rt][0], sl, rt, kmul), c1_finish<QB>(v[rt][1], sl, rt, kmul));
+}
+// the operand of a ninth-tap step: tap 8 of channel block cbA (slots 0..3) and cbA + 1 (slots 4..7; zeros past the last block)
+template <int RTN, class SL, class LT>
+DEV void frags_ninth_mm(SplitFrag (&xf)[RTN], const SL& sl, C1Taps& tp, const float* p_b1, int g4, int cbA, int KBn, float kmul, LT&& load_taps) {
+  u32x4 wh[RTN], wlo[RTN];
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt) { wh[rt] = c1_read<2>(sl.bh[rt]); wlo[rt] = c1_read<2>(sl.bl[rt]); }
+  f32x4 lo[RTN], hi[RTN];
+  load_taps(cbA);
+  {
+    const u32x4 ah = c1_place<2>(tp.ph, tp.qh), al = c1_place<2>(tp.pl, tp.ql);
+    const f32x4 c0v = lds4(p_b1, cbA, g4);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh[rt]), "+v"(wlo[rt]));
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) lo[rt] = c1_mma(al, wh[rt], c0v);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) lo[rt] = c1_mma(ah, wlo[rt], lo[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) lo[rt] = c1_mma(ah, wh[rt], lo[rt]);
+  }
+  if (cbA + 1 < KBn) {
+    load_taps(cbA + 1);
+    const u32x4 ah = c1_place<2>(tp.ph, tp.qh), al = c1_place<2>(tp.pl, tp.ql);
+    const f32x4 c0v = lds4(p_b1, cbA + 1, g4);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) hi[rt] = c1_mma(al, wh[rt], c0v);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) hi[rt] = c1_mma(ah, wlo[rt], hi[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) hi[rt] = c1_mma(ah, wh[rt], hi[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) hi[rt] = c1_finish<8>(hi[rt], sl, rt, kmul);
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) hi[rt] = splat4(0.f);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt) xf[rt] = split8h(c1_finish<8>(lo[rt], sl, rt, kmul), hi[rt]);
+}
+
 // DIAG != 0: timing experiments only (results are wrong): 1 = no conv1 / split work, 2 = one weight-fragment read per
 // step instead of nine, 3 = no slab traffic (global -> LDS), 4 = no barrier in the step loop, 5 = conv1 without its mel
-// reads from LDS, 6 = no operand split, 7 = three products per fragment triple instead of six (a two-term operand scheme's MFMA count)
+// reads from LDS, 6 = no operand split, 7 = three products per fragment triple instead of six (a two-term operand scheme's MFMA count),
+// 8 = no MFMAs (one VALU op per fragment pair instead), 9 = one weight-fragment read per step instead of eighteen.  Round 5: with
+// the two-term weights present the variants are those of the two-term kernel.
 // DM = dmodel (conv1 channels = conv2 in / out channels), NBW = output column tiles of a workgroup: all nine for dmodel
 // 144; eight (128 channels) for 256 / 512, the chunks on grid.z -- conv1 is then recomputed per chunk, the same VALU to
 // MFMA ratio per step as at 144.  Weight fragments: [chunk][step][NBW tiles][3 terms][64 lanes][8].
@@ -358,12 +593,13 @@ DEV void frags_ninth(SplitFrag (&xf)[RTN], const float* melp, PatchGeom RS, cons
 // (folded into the staged conv1 kernel and bias: relu(s v) = s relu(v)), accumulators in units of h_scale * h_wscale.
 // RTN row tiles of 16 positions per wave: two for whole utterances; one for the streaming shapes (260 positions per chunk: the
 // second 256-position workgroup of a chunk would hold four positions and take as long as the first)
-template <int DIAG, int DM, int NBW, int TM = 3, int RTN = SRT>
+template <int DIAG, int DM, int NBW, int TM = 3, int RTN = SRT, bool C1M = false>
 __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, PatchGeom RS, int rows) {
-  static_assert(TM == 3 || DIAG == 0, "the timing variants are those of the three-term kernel");
+  static_assert(DIAG == 0 || RTN == SRT, "the timing variants run two row tiles per wave");
+  static_assert(!C1M || (TM == 2 && DM == 144), "conv1 on the matrix pipe: the two-term kernel of dmodel 144");
   constexpr int KB = DM / 16, NB = NBW, NI = ninth_steps(KB), NK32 = KB * NPAIR + NI, SLABF = NBW * TM * 64, D = DM;
   const int c0 = blockIdx.z * NBW;               // first output column tile of this workgroup
-  __shared__ __attribute__((aligned(16))) u32x4 wl[2][SLABF];
+  __shared__ __attribute__((aligned(16))) u32x4 wl[SRING][SLABF];      // the slab ring: slab s in slot s % SRING
   __shared__ __attribute__((aligned(16))) float melp[MELP];
   __shared__ __attribute__((aligned(16))) float p_w1[9 * D], p_b1[D], p_b2[D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -377,6 +613,17 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
     s1 = __uint_as_float((unsigned)(127 + min(60, max(-60, 141 - e))) << 23);   // bound * s1 < 2^15
   }
   const float s2 = TM == 2 ? s1 * a.h_wscale : 1.f;
+  // C1M: the mel planes carry mel * sm (static bound, or this utterance's run-time maximum), the conv1 kernel w * sw; conv1's
+  // accumulator is in units of sm * sw and reaches the conv2 operand scale s1 through kmul (all powers of two)
+  float sm = 1.f, kmul = 1.f;
+  if constexpr (C1M) {
+    sm = a.c1_mscale;
+    if (a.h_melmax) {
+      const int e = (int)((a.h_melmax[b] >> 23) & 255u);
+      sm = __uint_as_float((unsigned)(127 + min(60, max(-60, 141 - e))) << 23);
+    }
+    kmul = s1 / (sm * a.c1_wscale);
+  }
   constexpr int NQ = (SLABF + SCT - 1) / SCT;
   u32x4 nw[NQ];
 #pragma unroll
@@ -389,21 +636,53 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   const int t2a = r0 / a.F2;
   const int tm_base = 4 * t2a - 2 * a.pt2 - a.pt1, fm_base = -2 * a.pf2 - a.pf1;
   const float* __restrict__ mbp = a.mel + (size_t)b * a.F * a.NM;
-  const int RSL = 4 * RS.seg;                    // bins per patch row
+  const int RSL = 4 * RS.seg;                    // bins per patch row (4 (F2 + 1): the last window reaches bin 4 F2 + 3)
+  const unsigned plane = (unsigned)rows * C1_ROWB;                                        // C1M: bytes of one fp16 plane
+  const unsigned melp_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)melp;
+  if constexpr (C1M) {
+    // two fp16 planes, hi then lo, rows of 96 bins (two bins per dword), then C1_ZERO_ROWS rows of zeros
+    unsigned* mph = reinterpret_cast<unsigned*>(melp);
+    constexpr int RD = C1_ROWB / 4;                // dwords per row
+    for (int i = threadIdx.x; i < rows * RD; i += SCT) {
+      const int rr = i / RD, jp = i - rr * RD;
+      const int tm = tm_base + rr, fm = fm_base + 2 * jp;
+      const bool okr = tm >= 0 && tm < a.F;
+      const float v0 = (okr && fm >= 0 && fm < a.NM) ? mbp[(size_t)tm * a.NM + fm] * sm : 0.f;
+      const float v1 = (okr && fm + 1 >= 0 && fm + 1 < a.NM) ? mbp[(size_t)tm * a.NM + fm + 1] * sm : 0.f;
+      const unsigned h = pk_f16(v0, v1);
+      const f16x2 hh = __builtin_bit_cast(f16x2, h);
+      mph[i] = h;
+      mph[rows * RD + i] = pk_f16(v0 - (float)hh.x, v1 - (float)hh.y);
+    }
+    for (int i = threadIdx.x; i < C1_ZERO_ROWS * RD; i += SCT) mph[2 * rows * RD + i] = 0u;
+  } else {
   for (int i = threadIdx.x; i < rows * RSL; i += SCT) {
     const int rr = i / RSL, jj = i - rr * RSL;
     const int tm = tm_base + rr, fm = fm_base + jj;
-    melp[rr * RS.row + (jj & 3) * RS.seg + (jj >> 2)] =
+    melp[MI355ASR_CONV1_V2 ? rr * RS.row + jj : rr * RS.row + (jj & 3) * RS.seg + (jj >> 2)] =
         (tm >= 0 && tm < a.F && fm >= 0 && fm < a.NM) ? mbp[(size_t)tm * a.NM + fm] : 0.f;
   }
-  for (int i = threadIdx.x; i < 9 * D; i += SCT) p_w1[i] = a.w1[i] * s1;
-  for (int i = threadIdx.x; i < D; i += SCT) { p_b1[i] = a.b1[i] * s1; p_b2[i] = a.b2[i] * s2; }
-  SplitLane<RTN> sl;
+  }
+  {
+    const float ws1 = C1M ? a.c1_wscale : s1, bs1 = C1M ? sm * a.c1_wscale : s1;
+    for (int i = threadIdx.x; i < 9 * D; i += SCT) p_w1[i] = a.w1[i] * ws1;
+    for (int i = threadIdx.x; i < D; i += SCT) { p_b1[i] = a.b1[i] * bs1; p_b2[i] = a.b2[i] * s2; }
+  }
+  std::conditional_t<C1M, C1Lane<RTN>, SplitLane<RTN, DM == 144>> sl;
 #pragma unroll
   for (int rt = 0; rt < RTN; ++rt) {
     const int r = min(r0 + 16 * RTN * wave + 16 * rt + c, PU - 1);
     const int t2 = r / a.F2, f2 = r - t2 * a.F2;
-    sl.mb[rt] = 4 * (t2 - t2a) * RS.row + f2;
+    if constexpr (C1M) {
+      // lane group g reads window row g of a tap (g = 3: the zero rows); the tap's first row 2 kt is an immediate offset
+      const int g = lane >> 4;
+      const unsigned win = melp_addr + (unsigned)(4 * (t2 - t2a) + g) * C1_ROWB + 8u * (unsigned)f2;
+      const unsigned zero = melp_addr + 2u * plane;
+      sl.bh[rt] = g < 3 ? win : zero;
+      sl.bl[rt] = g < 3 ? win + plane : zero;
+    } else {
+      sl.mb[rt] = 4 * (t2 - t2a) * RS.row + (MI355ASR_CONV1_V2 ? 4 * f2 : f2);
+    }
     unsigned vm = 0;
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt)
@@ -428,12 +707,35 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
 #pragma unroll
     for (int rt = 0; rt < RTN; ++rt) acc[rt][n] = bv;
   }
-  f32x4 w1r[9];
+  f32x4 w1r[C1M ? 1 : 9];
+  C1Taps c1t{0u, 0u, 0u, 0u};
   auto load_taps = [&](int cb) {
+    if constexpr (C1M) {
+      // this lane's A-operand row: channel 16 cb + c, window row g (lane group 3: zeros): three weights, hi and lo
+      const int g = lane >> 4;
+      const float* wp = p_w1 + 3 * min(g, 2) * D + 16 * cb + c;
+      const float w0 = g < 3 ? wp[0] : 0.f, w1 = g < 3 ? wp[D] : 0.f, w2 = g < 3 ? wp[2 * D] : 0.f;
+      c1t.ph = pk_f16(w0, w1);
+      c1t.qh = pk_f16(w2, 0.f);
+      const f16x2 hp = __builtin_bit_cast(f16x2, c1t.ph), hq = __builtin_bit_cast(f16x2, c1t.qh);
+      c1t.pl = pk_f16(w0 - (float)hp.x, w1 - (float)hp.y);
+      c1t.ql = pk_f16(w2 - (float)hq.x, 0.f);
+    } else {
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) w1r[tp] = *reinterpret_cast<const f32x4*>(p_w1 + tp * D + 16 * cb + g4);
+      for (int tp = 0; tp < 9; ++tp) w1r[tp] = *reinterpret_cast<const f32x4*>(p_w1 + tp * D + 16 * cb + g4);
+    }
   };
   SplitFrag xa[RTN];
+  // the operand of a step through either evaluation
+  auto frags_pair = [&](auto PI, int cb) {
+    constexpr int pair = decltype(PI)::value;
+    if constexpr (C1M) frags_for_mm<pair>(xa, sl, c1t, lds4(p_b1, cb, g4), kmul);
+    else frags_for<pair, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+  };
+  auto frags_9th = [&](int cbA) {
+    if constexpr (C1M) frags_ninth_mm(xa, sl, c1t, p_b1, g4, cbA, KB, kmul, load_taps);
+    else frags_ninth<DIAG, TM>(xa, melp, RS, sl, w1r, p_b1, g4, cbA, KB, load_taps);
+  };
   if constexpr (DIAG == 1) {
 #pragma unroll
     for (int rt = 0; rt < RTN; ++rt)
@@ -443,33 +745,36 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   // which waves run MFMAs first: the SIMD partner of a wave must take the other order (see the step loop)
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const bool late = wv >= SCW / 2;     // (other pairings of early / late waves measured the same or worse: round 2)
+  // pieces of one slab this wave fetches (64 lanes x 16 bytes each): wave-uniform, 2 or 3 of the 18 at dmodel 144 / two terms
+  int my_pieces = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) my_pieces += (SCT * q + 64 * wv < SLABF) ? 1 : 0;
+  auto issue_slab = [&](int t) {       // slab t -> ring slot t % SRING
+    if (t < NK32 && DIAG != 3) {
+      const u32x4* src = wg + (size_t)t * SLABF;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int w0 = SCT * q + 64 * wv;                        // wave-uniform
+        if (w0 < SLABF) dma16(src + w0 + lane, &wl[t & (SRING - 1)][w0]);
+      }
+    }
+  };
+  for (int t = 1; t <= SRING - 2; ++t) issue_slab(t);            // slab 0 came through registers; SRING - 2 more in flight
   // the whole step loop once per order (compile-time LATE): with a run-time order inside one loop hipcc keeps both
   // paths' temporaries alive and spills (256 VGPRs + 232 bytes of scratch instead of 194)
   auto run = [&](auto LATE_T) {
   constexpr bool LATE = decltype(LATE_T)::value;
   if constexpr (LATE) {
     load_taps(0);
-    frags_for<0, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, 0, g4));
+    frags_pair(std::integral_constant<int, 0>{}, 0);
   }
   // one MFMA step s: slab s is in wl[s & 1]; frags_this() = the operand of this step (early waves, before the MFMAs),
   // frags_next() = the operand of step s + 1 (late waves, after the MFMAs)
   auto step_body = [&](int s, auto&& frags_this, auto&& frags_next) {
-      const int cur = s & 1;
-      const bool more = s + 1 < NK32;
-      // next slab: global -> LDS directly (global_load_lds_dwordx4: lane i of a wave lands at base + 16 i); buffer
-      // cur ^ 1 was last read in step s - 1, whose barrier every wave has passed.  Issued right before this wave's
-      // MFMAs: hipcc waits for vmcnt(0) in front of every LDS read it can see while a DMA is in flight (the conv1
-      // window reads), so no such read may follow the DMA closely.
-      auto slab_dma = [&]() {
-        if (more && DIAG != 3) {
-          const u32x4* src = wg + (size_t)(s + 1) * SLABF;
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const int w0 = SCT * q + 64 * wv;                    // wave-uniform
-            if (w0 < SLABF) dma16(src + w0 + lane, &wl[cur ^ 1][w0]);
-          }
-        }
-      };
+      const int cur = s & (SRING - 1);
+      // slab s + SRING - 1: global -> LDS directly (global_load_lds_dwordx4: lane i of a wave lands at base + 16 i) into the slot
+      // that was last read in step s - 1, whose barrier every wave has passed.
+      auto slab_dma = [&]() { issue_slab(s + SRING - 1); };
       // fragments of G column tiles at a time (one with nine tiles: registers; two with eight), the next group requested
       // before the MFMAs of the current one; lgkmcnt(3 G) = "all but the newest group"
       auto mfma_cur = [&](auto&& after_first_group) {
@@ -480,6 +785,7 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
           constexpr int gi = decltype(GI)::value;
           static_for<0, G>([&](auto HI) {
             constexpr int h = decltype(HI)::value;
+            if constexpr (DIAG == 9 && gi > 0) { w[h][0] = wa[0][0]; w[h][1] = wa[0][1]; if constexpr (TM == 3) w[h][2] = wa[0][2]; return; }
             w[h][0] = lds_read16<((gi * G + h) * TM + 0) * 1024>(base);
             w[h][1] = lds_read16<((gi * G + h) * TM + 1) * 1024>(base);
             if constexpr (TM == 3) w[h][2] = lds_read16<((gi * G + h) * TM + 2) * 1024>(base);
@@ -506,8 +812,12 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
 #pragma unroll
               for (int h = 0; h < G; ++h)
 #pragma unroll
-                for (int rt = 0; rt < RTN; ++rt)
-                  acc[rt][gi * G + h] = mma_terms<TM>(w[h][ord - p], xa[rt].t[p], acc[rt][gi * G + h]);
+                for (int rt = 0; rt < RTN; ++rt) {
+                  if constexpr (DIAG == 8)        // no matrix work: the operands are consumed by one VALU op per fragment pair
+                    acc[rt][gi * G + h] += __builtin_bit_cast(f32x4, w[h][ord - p] ^ xa[rt].t[p]);
+                  else
+                    acc[rt][gi * G + h] = mma_terms<TM>(w[h][ord - p], xa[rt].t[p], acc[rt][gi * G + h]);
+                }
         };
         fetch(wa, std::integral_constant<int, 0>{});
         static_for<0, NG>([&](auto GI) {
@@ -546,8 +856,18 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
         __builtin_amdgcn_sched_barrier(0);
         mfma_cur(nothing);
       }
-      __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's part of the slab has landed
-      if constexpr (DIAG != 4) __syncthreads();
+      // this wave's pieces of slab s + 1 have landed when at most the pieces of the slabs behind it are outstanding: those are
+      // slabs s + 2 .. min(s + SRING - 1, NK32 - 1); then the barrier: every wave's pieces have, and slot cur is free
+      {
+        const int behind = min(SRING - 2, NK32 - 2 - s);
+        wait_vmcnt(DIAG == 3 ? 0 : max(behind, 0) * my_pieces);
+      }
+      if constexpr (DIAG != 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's LDS reads of the step are done
+        __builtin_amdgcn_s_barrier();                          // bare barrier: a fence would wait for the DMAs in flight
+        __builtin_amdgcn_sched_barrier(0);
+      }
   };
   // operand of the next step (VALU + LDS reads) and the MFMAs of this one are independent.  hipcc puts the ~270
   // VALU instructions in front of the 108 MFMAs, and an in-order wave cannot fill the matrix pipe's shadow that
@@ -561,16 +881,16 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
       step_body(cb * NPAIR + pair,
                 [&]() {                      // early waves: the operand of this step, just before its MFMAs
                   if constexpr (pair == 0) load_taps(cb);
-                  frags_for<pair, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+                  frags_pair(PI, cb);
                 },
                 [&]() {                      // late waves: the operand of the next step, after this step's MFMAs
                   if constexpr (pair + 1 < NPAIR) {
-                    frags_for<pair + 1, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+                    frags_pair(std::integral_constant<int, pair + 1>{}, cb);
                   } else if (cb + 1 < KB) {
                     load_taps(cb + 1);
-                    frags_for<0, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, cb + 1, g4));
+                    frags_pair(std::integral_constant<int, 0>{}, cb + 1);
                   } else {
-                    frags_ninth<DIAG, TM>(xa, melp, RS, sl, w1r, p_b1, g4, 0, KB, load_taps);
+                    frags_9th(0);
                   }
                 });
     });
@@ -578,8 +898,8 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
 #pragma unroll 1
   for (int i = 0; i < NI; ++i) {             // the ninth taps, two channel blocks per step
     step_body(KB * NPAIR + i,
-              [&]() { frags_ninth<DIAG, TM>(xa, melp, RS, sl, w1r, p_b1, g4, 2 * i, KB, load_taps); },
-              [&]() { if (i + 1 < NI) frags_ninth<DIAG, TM>(xa, melp, RS, sl, w1r, p_b1, g4, 2 * i + 2, KB, load_taps); });
+              [&]() { frags_9th(2 * i); },
+              [&]() { if (i + 1 < NI) frags_9th(2 * i + 2); });
   }
   };
   if (late) run(std::integral_constant<bool, true>{});
@@ -617,6 +937,16 @@ static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGe
   const dim3 g128(g144.x, g144.y, d / 128);
   note_scheme(SCHEME_BF16X3);
   if constexpr (DIAG == 0) {
+    // conv1 on the matrix pipe (see C1M): dmodel 144, two-term weights, a mel scale (static or run-time), patch rows of <= 96 bins
+    static const bool c1m_env = [] { const char* v = getenv("MI355ASR_SUBCONV_C1M"); return v ? atoi(v) != 0 : true; }();
+    const bool c1m = c1m_env && a.w2h && d == 144 && a.c1_wscale > 0.f && (a.c1_mscale > 0.f || a.h_melmax) && 4 * a.F2 + 4 <= C1_ROWB / 2 &&
+                     (size_t)(2 * rows + C1_ZERO_ROWS) * C1_ROWB <= sizeof(float) * MELP;
+    if (c1m) {
+      note_scheme(SCHEME_F16X2);
+      if (rtn == 1) hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2, 1, true>), g144, dim3(SCT), 0, s, a, RS, rows);
+      else hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2, SRT, true>), g144, dim3(SCT), 0, s, a, RS, rows);
+      return 0;
+    }
     if (a.w2h && rtn == 1) {
       note_scheme(SCHEME_F16X2);
       switch (d) {
@@ -636,6 +966,13 @@ static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGe
       }
     }
   }
+  if constexpr (DIAG != 0) {           // timing variants of the two-term kernel (dmodel 144) when the two-term weights are there
+    if (a.w2h && d == 144) {
+      note_scheme(SCHEME_F16X2);
+      hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 144, 9, 2>), g144, dim3(SCT), 0, s, a, RS, rows);
+      return 0;
+    }
+  }
   switch (d) {
     case 144: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 144, 9>), g144, dim3(SCT), 0, s, a, RS, rows); return 0;
     case 256: hipLaunchKernelGGL((subconv_split_ring_kernel<DIAG, 256, 8>), g128, dim3(SCT), 0, s, a, RS, rows); return 0;
@@ -651,7 +988,16 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
   PatchGeom RS;
   RS.seg = a.F2 + 1;
   RS.row = 4 * RS.seg;
+#if MI355ASR_CONV1_V2
+  // plain rows, windows read as 16-byte vectors at a 16-byte lane stride (conflict-free by construction); a row tile that wraps
+  // into the next output row (f2: F2 - 1 -> 0, + 4 patch rows = RS.row 16-byte units) continues on the next banks when
+  // RS.row = F2 (mod 8) -- 84 for F2 = 20
+  while (RS.row % 4 != 0) ++RS.row;
+  if (a.F2 % 4 == 0)                       // (otherwise no multiple of four does it: the wrap then costs a two-way conflict)
+    while (RS.row % 8 != a.F2 % 8) RS.row += 4;
+#else
   while (RS.row % 8 != 5) ++RS.row;
+#endif
   // One row tile per wave (128 positions per workgroup) while that still gives no CU a second workgroup -- single utterances:
   // one to four 10 s utterances per call 1.226 / 1.233 / 1.243 -> 1.197 / 1.202 / 1.208 ms.  (The streaming shapes -- 64 chunks
   // x 260 positions, of whose 2 x 64 x 2 workgroups every second one holds four positions -- do NOT gain: 384 workgroups of 128
@@ -682,6 +1028,8 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
     case 5: return launch_split_d<5>(d, grid, a, RS, rows, s);
     case 6: return launch_split_d<6>(d, grid, a, RS, rows, s);
     case 7: return launch_split_d<7>(d, grid, a, RS, rows, s);
+    case 8: return launch_split_d<8>(d, grid, a, RS, rows, s);
+    case 9: return launch_split_d<9>(d, grid, a, RS, rows, s);
     default: break;
   }
 #endif
