@@ -292,6 +292,81 @@ def extra_config3(lib, device, steps=20, with_cpu=True):
     return out
 
 
+def extra_stt(lib, device, steps=10):
+    """What `ASR.offline_stt` computes for a batch (test_asr.py:186-219): waveform -> encoder -> CTCDecoder -> greedy phone ids
+    -> Translator([ids, encoder output]) -> text ids (argmax).  64 x 10 s, ConformerCTC(S) + the S Translator (2 RBlocks,
+    Embedding(1332 -> 144), Dense(144 -> 9160): conformerS.yml:17-20), random-init weights; the blank bias of the CTC head is set
+    so that 76 % of the frames are blank (what the reference's trained ctc_model.onnx does on noise): ~60
+    phone tokens per utterance reach the Translator, as in speech.  Reported next to the headline, never as `value`."""
+    from tensorflowasr_amd.models import ConformerEncoder, CTCDecoder, Translator, ctc_greedy_decode
+    B, L, V, VT = 64, 160000, NUM_CLASSES, 9160
+    enc_kw = {k: S_CFG[k] for k in ("dmodel", "reduction_factor", "num_blocks", "head_size", "num_heads", "kernel_size", "fc_factor",
+                                    "sample_rate", "n_mels", "stride_ms")}
+    enc = ConformerEncoder(mel_layer_type="Melspectrogram", device=device, **enc_kw)
+    enc._build(seed=0)
+    ctc = CTCDecoder(num_classes=V, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32, fc_factor=0.5, device=device)
+    ctc._build(seed=1)
+    tr = Translator(inp_classes=V, tar_classes=VT, dmodel=144, num_blocks=2, head_size=36, num_heads=4, kernel_size=32, fc_factor=0.5,
+                    device=device)
+    tr._build(seed=2)
+    wav = torch.from_numpy(synth_batch(0, B, L)).to(device)
+    # blank bias: 76 % blank frames
+    e0 = enc(wav)
+    lg = ctc(e0)
+    others = lg[..., :V - 1].max(-1).values
+    q = torch.quantile((others - lg[..., V - 1]).flatten().float().cpu(), 0.76).item()
+    w = ctc.get_weights_dict()
+    w["fully_connected/bias"] = w["fully_connected/bias"].copy()
+    w["fully_connected/bias"][V - 1] += q
+    ctc.load_weights(w, by_name=False)
+    del e0, lg, others
+
+    def step():
+        e = enc(wav)
+        _, fr = ctc(e, return_argmax=True, return_logits=False)
+        ids, lens = ctc_greedy_decode(fr, None, blank=V - 1)
+        width = int(lens.max().item())                     # ASR._phone_ids: ctc_decode's dense width (a host sync, as in the reference)
+        ph = ids[:, :width].clamp_(min=0).contiguous()
+        _, txt = tr([ph, e], return_argmax=True)
+        return ph, lens, txt
+
+    ph, lens, txt = step()
+    t = _timed(step, steps)
+    nk = len(_lib.KERNEL_NAMES)
+    _lib.check(lib.mi355asr_profile_enable(tr._h.ptr, 1))
+    torch.cuda.synchronize()
+    _read_profile(lib, tr._h, nk, 1)
+    _timed(step, steps, warmup=0)
+    pt = _read_profile(lib, tr._h, nk, steps)
+    _lib.check(lib.mi355asr_profile_enable(tr._h.ptr, 0))
+    U = int(ph.shape[1])
+    Mt, d, T = B * U, 144, L // 640
+    # Translator flops per step (2 RBlocks over B x U rows; cross-attention keys / values from the B x T encoder rows)
+    fl = {"ffn": 2 * 2 * (2.0 * 2 * Mt * d * 4 * d), "qkv": 2 * (2.0 * Mt * d * d + 2 * 2.0 * B * T * d * d), "attention": 2 * 2 * 2.0 * B * U * T * d,
+          "attn_out": 2 * 2.0 * Mt * d * d, "pw1_glu": 2 * 2.0 * Mt * d * 2 * d, "dwconv": 2 * 2.0 * Mt * d * 32,
+          "conv_tail": 2 * (2.0 * Mt * d * 2 * d + 2.0 * Mt * 2 * d * d), "ctc_head": 2.0 * Mt * d * VT}
+    sch = read_schemes(lib, tr._h)
+    kern = {}
+    for n, (ms_step, launches) in pt.items():
+        f = fl.get(n, 0.0)
+        peak = kernel_peak(n, sch)[0]
+        kern[n] = {"launches_per_step": launches, "ms_per_step": round(ms_step, 4), "scheme": SCHEME_NAME[sch.get(n, -1)],
+                   "tflops": round(f / (ms_step * 1e-3) / 1e12, 2) if f else None,
+                   "frac_of_peak": round(f / (ms_step * 1e-3) / 1e12 / peak, 4) if f else None}
+    ms_tr = sum(v["ms_per_step"] for v in kern.values())
+    dom = max(kern, key=lambda n: kern[n]["ms_per_step"]) if kern else None
+    out = {"workload": "ASR.offline_stt for a batch: 64 x 10 s, encoder + CTCDecoder + greedy ids + Translator (2 RBlocks, 144 -> 9160) -> text ids",
+           "steps": steps, "ms_per_step": round(t * 1e3, 3), "frames_per_s": round(B * (L // 160) / t, 1),
+           "phone_tokens_per_utt": round(float(lens.float().mean().item()), 1), "translator_rows": Mt, "translator_width": U,
+           "ms_translator_kernels": round(ms_tr, 4),
+           "roofline": {"bound": "mfma", "kernel": "translator." + dom if dom else None, "achieved": kern[dom]["tflops"] if dom else None,
+                        "peak": kernel_peak(dom, sch)[0] if dom else None, "unit": "TFLOP/s", "frac": kern[dom]["frac_of_peak"] if dom else None,
+                        "traffic": None},
+           "translator_kernels": kern}
+    del enc, ctc, tr
+    return out
+
+
 def extra_config5(lib, device, steps=5, with_cpu=True):
     """BASELINE.json configs[4] per GPU: ChunkConformer `predict` (front, 15-block band-attention encoder, phone picker,
     feature_pick, context helper, text decoder: chunk_conformer_blocks.py:815-822) over 16 x 30 s utterances + CTC prefix
@@ -909,6 +984,10 @@ def main():
                     line[key] = fn(lib, device, with_cpu=not args.no_cpu_baseline)
                 except Exception as e:           # the headline line must not die with an extra
                     line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:                                 # the drop-in's whole offline_stt (with the Translator) as its own key
+                line["stt_with_translator"] = extra_stt(lib, device)
+            except Exception as e:
+                line["stt_with_translator"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -247,6 +247,62 @@ def test_config3_64_streaming_chunks_bf16_vs_rounding_oracle(torch_cuda):
     assert maxdiff(enc16, exact_enc) < 0.2 and maxdiff(lg16, exact_lg) < 0.3 and agree > 0.95
 
 
+def test_config3_as_benched_64_streams_with_260_frames_of_history(torch_cuda):
+    """Round-4 review: bench.py's config-3 step is 64 STREAMS -- one new 0.5 s chunk each through the encoder (64 x 13 rows)
+    and the reference's global CTC over every stream's 10 s of history (64 x 260 frames: conformer_blocks.py:574-594, :385-438;
+    test_asr.py:116-165) -- while the parity test above runs 4 streams x 208 frames.  The same objects, shapes and bf16 mode as
+    bench.extra_config3: every stream's encoder rows and logits against the bf16-rounding oracle on streams 0, 21 and 63 (the
+    streams are independent; two more are run alone and must stay within the same bound of their rows in the batch of 64),
+    the in-kernel argmax against the kernel's own logits on all 64, ids against their collapse."""
+    torch = torch_cuda
+    from tensorflowasr_amd.models import CTCDecoder, StreamingConformerEncoder, ctc_greedy_decode
+    cfg = dict(co.STREAMING_S)
+    B, chunk, hist, d, V = 64, 8000, 20, 256, 1332
+    w = co.encoder_weights(cfg, seed=53)
+    w.update(co.ctc_decoder_weights(cfg, V, seed=54))
+    enc = StreamingConformerEncoder(dmodel=d, reduction_factor=4, num_blocks=4, head_size=64, num_heads=4, kernel_size=5, fc_factor=0.5,
+                                    sample_rate=16000, n_mels=80, stride_ms=10, mel_layer_type="Melspectrogram", gemm_dtype="bfloat16")
+    enc.add_chunk_size(chunk, 80, 640)
+    enc.load_weights({k: v for k, v in w.items() if not k.startswith(("project/", "decoder_conformer_block_", "fully_connected/"))}, by_name=False)
+    ctc = CTCDecoder(num_classes=V, dmodel=d, num_blocks=1, head_size=64, num_heads=4, kernel_size=32, fc_factor=0.5, gemm_dtype="bfloat16")
+    ctc.load_weights({k: v for k, v in w.items() if k.startswith(("project/", "decoder_conformer_block_", "fully_connected/"))}, by_name=False)
+    x = waves(B, chunk, 400)
+    history = np.random.default_rng(7).standard_normal((B, (hist - 1) * 13, d)).astype(np.float32)
+    e = enc(x)
+    assert tuple(e.shape) == (B, 13, d)
+    h = torch.cat([torch.from_numpy(history).to(e.device), e], 1)
+    assert tuple(h.shape) == (B, hist * 13, d)
+    logits, amax = ctc(h, return_argmax=True)
+    ids, lens = ctc_greedy_decode(amax, None, blank=V - 1)
+    e, logits, amax, ids, lens = (t.cpu().numpy() for t in (e, logits, amax, ids, lens))
+    assert np.array_equal(amax, co.frame_argmax(logits))
+    gid, glen = co.ctc_collapse(amax, [hist * 13] * B, V - 1)
+    assert np.array_equal(ids, gid) and np.array_equal(lens, glen)
+    # the head without logits (what the bench step runs) keeps the same running argmax
+    _, amax2 = ctc(h, return_argmax=True, return_logits=False)
+    assert np.array_equal(amax2.cpu().numpy(), amax)
+    pick = [0, 21, 63]
+    co.GEMM_ROUND_BF16 = True
+    try:
+        r_enc = co.streaming_conformer_encoder(x[pick].astype(np.float64), w, cfg, chunk)
+        r_lg = co.ctc_decoder(np.concatenate([history[pick].astype(np.float64), r_enc], 1), w, cfg)
+    finally:
+        co.GEMM_ROUND_BF16 = False
+    e_enc, e_lg = np.abs(e[pick] - r_enc), np.abs(logits[pick] - r_lg)
+    print("config 3 as benched, bf16 vs rounding oracle: encoder max %.3g mean %.3g; logits max %.3g mean %.3g"
+          % (e_enc.max(), e_enc.mean(), e_lg.max(), e_lg.mean()))
+    assert e_enc.max() < 2e-2 and e_enc.mean() < 2e-3
+    assert e_lg.max() < 4e-2 and e_lg.mean() < 3e-3
+    # the other 61 streams: a stream run alone (other kernels are selected at 13 / 260 rows than at 832 / 16 640: a hidden value
+    # on a bf16 rounding boundary may fall the other way, one bf16 ulp) stays inside the bound the oracle comparison uses
+    for b in (5, 40):
+        e1 = enc(x[b:b + 1])
+        d_e = np.abs(e1.cpu().numpy()[0] - e[b])
+        l1 = ctc(torch.cat([torch.from_numpy(history[b:b + 1]).to(e1.device), e1], 1))
+        d_l = np.abs(l1.cpu().numpy()[0] - logits[b])
+        assert d_e.max() < 2e-2 and d_e.mean() < 2e-3 and d_l.max() < 4e-2 and d_l.mean() < 3e-3, (b, d_e.max(), d_l.max())
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # config 5: ChunkConformer (full chunk_conformerS dims) on 30 s utterances + prefix beam search
 # ---------------------------------------------------------------------------------------------------------------
