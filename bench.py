@@ -327,7 +327,7 @@ def extra_stt(lib, device, steps=10):
         ids, lens = ctc_greedy_decode(fr, None, blank=V - 1)
         width = int(lens.max().item())                     # ASR._phone_ids: ctc_decode's dense width (a host sync, as in the reference)
         ph = ids[:, :width].clamp_(min=0).contiguous()
-        _, txt = tr([ph, e], return_argmax=True)
+        _, txt = tr([ph, e], return_argmax=True, return_logits=False)      # as ASR.offline_stt: the text ids only
         return ph, lens, txt
 
     ph, lens, txt = step()

@@ -121,7 +121,7 @@ class ASR:
         t0 = time.time()
         enc_outputs = self.encoder(input_wav, training=False)
         ctc_decode, _ = self._phone_ids(enc_outputs)
-        _, translator_out = self.translator([ctc_decode, enc_outputs], training=False, return_argmax=True)
+        _, translator_out = self.translator([ctc_decode, enc_outputs], training=False, return_argmax=True, return_logits=False)
         ctc_row, txt_row = ctc_decode[0].cpu().numpy(), translator_out[0].cpu().numpy()
         self.timings["offline_stt"] = time.time() - t0
         return self._finish(ctc_row, txt_row)
@@ -144,7 +144,7 @@ class ASR:
             ctc_decode, _ = self._phone_ids(enc_outputs)           # global CTC over everything heard so far
             ctc_row = ctc_decode[0].cpu().numpy()
             ctc_result = [int(n) for n in ctc_row if n != 0] + [0] * 10
-            _, tr = self.translator([np.array([ctc_result], "int32"), enc_outputs], return_argmax=True)
+            _, tr = self.translator([np.array([ctc_result], "int32"), enc_outputs], return_argmax=True, return_logits=False)
             txt_row = tr[0].cpu().numpy()
         return self._finish(ctc_row, txt_row)
 

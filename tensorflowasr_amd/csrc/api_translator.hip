@@ -150,6 +150,15 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids, const flo
   hd.x = sc.xa; hd.y = logits; hd.wp = m->t_stack.fc_wp; hd.bias = m->t_stack.fc_b;
   hd.M = M; hd.NT = m->t_stack.NT_fc; hd.ldy = m->tcfg.tar_classes; hd.n_valid = m->tcfg.tar_classes; hd.eps = kLnEps;
   hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
+  // round 5: from 2048 rows on the class head runs on the two-term stream of pp_head_kernel (or the slab ring), as the CTC decoder's
+  // and the ChunkConformer's heads do (try_head_ld: 144 -> 9160 over 5952 rows 0.44 ms on the fp32 MFMA kernel)
+  {
+    PROF(MI355ASR_K_CTC_HEAD);
+    if (try_head_ld(m, hd, s) == 0) {
+      if (hipGetLastError() != hipSuccess) return fail(MI355ASR_EHIP, "translator head launch failed");
+      return 0;
+    }
+  }
   if (gemm16_for(m, M)) {
     Gemm16Args h16{};
     h16.x = sc.xa; h16.ldx = d; h16.bias = hd.bias; h16.y = logits; h16.ldy = hd.ldy; h16.M = M; h16.K = d; h16.NT = hd.NT;

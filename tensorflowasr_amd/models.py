@@ -520,17 +520,19 @@ class Translator(_ModelBase):
         s["fully_connected/bias"] = (self.tar_classes,)
         return s
 
-    def __call__(self, x, training=None, mask=None, return_argmax=False):
-        """x = [ids int [B, U], enc float [B, T, dmodel]] -> logits [B, U, tar_classes] (torch, on device)."""
+    def __call__(self, x, training=None, mask=None, return_argmax=False, return_logits=True):
+        """x = [ids int [B, U], enc float [B, T, dmodel]] -> logits [B, U, tar_classes] (torch, on device).  return_argmax:
+        (logits, per-token argmax); with return_logits=False the logits are never written (the class head keeps its running
+        argmax only -- what offline_stt consumes, test_asr.py:203-205): (None, argmax)."""
         if training:
             raise NotImplementedError("inference path only")
         ids, enc = x
-        return self._forward(ids, enc, return_argmax)
+        return self._forward(ids, enc, return_argmax, return_logits)
 
     def set_inference_func(self):
         self.inference = lambda inputs, enc: self._forward(inputs, enc, False)
 
-    def _forward(self, ids, enc, return_argmax):
+    def _forward(self, ids, enc, return_argmax, return_logits=True):
         h = self._h
         if not h.built:
             self._build()
@@ -544,14 +546,16 @@ class Translator(_ModelBase):
         if U == 0:                                   # nothing decoded: Keras returns an empty [B, 0, V] tensor
             z = torch.empty((B, 0, self.tar_classes), dtype=torch.float32, device=h.device)
             return (z, torch.empty((B, 0), dtype=torch.int32, device=h.device)) if return_argmax else z
-        logits = torch.empty((B, U, self.tar_classes), dtype=torch.float32, device=h.device)
+        if not return_logits and not return_argmax:
+            raise ValueError("nothing to return: return_logits=False needs return_argmax=True")
+        logits = torch.empty((B, U, self.tar_classes), dtype=torch.float32, device=h.device) if return_logits else None
         amax = torch.empty((B, U), dtype=torch.int32, device=h.device)
         n = ctypes.c_size_t()
         _lib.check(h.lib.mi355asr_translator_workspace_bytes(h.ptr, B, U, T, ctypes.byref(n)))
         ws = h.workspace(n.value)
         with torch.cuda.device(h.device):
-            _lib.check(h.lib.mi355asr_translator_forward(h.ptr, _p(idt), _p(e), B, U, T, _p(logits), _p(amax), _p(ws),
-                                                         n.value, h._stream()))
+            _lib.check(h.lib.mi355asr_translator_forward(h.ptr, _p(idt), _p(e), B, U, T, _p(logits) if return_logits else None, _p(amax),
+                                                         _p(ws), n.value, h._stream()))
         return (logits, amax) if return_argmax else logits
 
 

@@ -1056,6 +1056,35 @@ def test_translator_parity(torch_cuda, B, U, T, blocks):
     assert maxdiff(tr.inference(ids, enc).cpu().numpy(), got) == 0.0
 
 
+def test_translator_head_on_the_two_term_stream_from_2048_rows(torch_cuda):
+    """Round 5: with 2048 token rows or more (a batch of offline_stt calls: 64 utterances x ~90 phone tokens) the Translator's
+    Dense(144 -> tar_classes) runs where the CTC decoder's and the ChunkConformer's class heads run -- pp_head_kernel's two-term
+    stream.  32 x 80 = 2560 rows, 700 classes (five column groups, the last one partly filled): logits, the in-kernel argmax
+    and the fp32-MFMA head of the same rows in two halves (1280 rows each: below the threshold) against each other and the oracle."""
+    from tensorflowasr_amd.models import Translator
+    cfg = dict(co.CONFORMER_S, translator_num_blocks=1, translator_kernel_size=32, translator_fc_factor=0.5)
+    inp, tar, B, U, T = 300, 700, 32, 80, 120
+    w = co.translator_weights(cfg, inp, tar, seed=31)
+    tr = Translator(inp_classes=inp, tar_classes=tar, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32, fc_factor=0.5)
+    tr.load_weights(w, by_name=False)
+    rng = np.random.default_rng(77)
+    ids = rng.integers(0, inp, (B, U)).astype(np.int32)
+    enc = rng.standard_normal((B, T, 144)).astype(np.float32)
+    got, amax = tr([ids, enc], return_argmax=True)
+    got, amax = got.cpu().numpy(), amax.cpu().numpy()
+    assert np.array_equal(amax, got.argmax(-1))
+    halves = np.concatenate([tr([ids[:16], enc[:16]]).cpu().numpy(), tr([ids[16:], enc[16:]]).cpu().numpy()])
+    ref = co.translator(ids[:4], enc[:4].astype(np.float64), w, cfg)
+    e2, e1 = maxdiff(got[:4], ref), maxdiff(halves[:4], ref)
+    print("translator head, 2560 rows: two-term stream %.3g, fp32 MFMA kernel %.3g from the oracle; apart %.3g" % (e2, e1, maxdiff(got, halves)))
+    assert e2 < TOL and e1 < TOL and e2 < 2 * e1 + 2e-6 and maxdiff(got, halves) < 1e-4
+    # what offline_stt asks for: the text ids only, no logits written -- on both head kernels
+    none, only = tr([ids, enc], return_argmax=True, return_logits=False)
+    assert none is None and np.array_equal(only.cpu().numpy(), amax)
+    none, only = tr([ids[:16], enc[:16]], return_argmax=True, return_logits=False)
+    assert none is None and np.array_equal(only.cpu().numpy(), halves[:16].argmax(-1))
+
+
 def test_translator_rejects_bad_shapes_and_clamps_ids(torch_cuda):
     from tensorflowasr_amd.models import Translator
     cfg = dict(co.CONFORMER_S, translator_num_blocks=1, translator_kernel_size=32, translator_fc_factor=0.5)

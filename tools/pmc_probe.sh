@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 NAME=${1:-pmc_probe}
 # PROBE_CMD: the command to profile (default: the headline bench)
-CMD=${PROBE_CMD:-"python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-h2d --no-extra-configs --no-exact-leg --no-latency-b1"}
+CMD=${PROBE_CMD:-"python $R/bench.py --steps 2 --warmup 1 --min-timed-s 0 --no-cpu-baseline --no-kernel-events --no-h2d --no-extra-configs --no-exact-leg --no-latency-b1"}
 i=0
 DIRS=""
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \

@@ -80,8 +80,8 @@ def main():
     if len(sys.argv) >= 6:
         busy, gui = pmc_avg(sys.argv[5], "SQ_VALU_MFMA_BUSY_CYCLES"), pmc_avg(sys.argv[5], "GRBM_GUI_ACTIVE")
     lines = ["# rocprofv3 summary `%s`" % tag, "",
-             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 "
-             "--no-cpu-baseline` (B=64 x 10 s, ConformerCTC(S), fp32); PMC columns from separate "
+             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --min-timed-s 0 "
+             "--no-cpu-baseline ...` (tools/profile_round.sh; B=64 x 10 s, ConformerCTC(S), fp32); PMC columns from separate "
              "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (FETCH doubled per MI355X_MICROARCH.md, HBM section).", "",
              "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), from a separate pass; "
              "GRBM_GUI_ACTIVE carries ~25k cycles of per-dispatch overhead under PMC, so the figure is pessimistic "
@@ -102,6 +102,13 @@ def main():
             float(r["AverageNs"]) / 1e3, r["Percentage"],
             ("%.1f" % (fb / 1e6)) if name in fetch else "-", ("%.1f" % (wb / 1e6)) if name in write else "-",
             ("%.1f" % ((fb + wb) / 1e6)) if (name in fetch or name in write) else "-", mb))
+    # the traced steps (warm-up included): one collapse_kernel per step; kernel time per step under the profiler
+    steps = next((int(r["Calls"]) for r in rows if "collapse_kernel" in r["Name"]), 0)
+    if steps:
+        total_ms = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
+        lines += ["", "Kernel time per step under rocprofv3: **%.3f ms** (sum of all kernels' total duration / %d traced steps, warm-up "
+                  "included).  The profiler slows the clock (MI355X_MICROARCH.md, DVFS note): compare with the un-profiled figure below, "
+                  "not with another box's." % (total_ms / steps, steps)]
     open(os.path.join(out, tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
     if traffic:
         json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
