@@ -895,6 +895,23 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
   if (d == 144 && fused_env && !cross) {
     // token-local runs of layers in one launch each (fused.hip); attention and the depthwise conv mix tokens
     const float qscale = 1.0f / std::sqrt((float)hs);
+    // round 5: q / k / v of a block travel head-major ([B, H, T, 36] planes) whenever their producer is a pair-pipelined kernel and
+    // their consumer the two-term attention_split_kernel -- a pure function of the shapes, the switches and the block's weights, so
+    // the producer (this block's own ff_module_1 launch, or the previous block's tail) and the consumer agree without a flag
+    // being passed between launches.  MI355ASR_QKV_HEAD_MAJOR=0: token-major rows as before.
+    auto attn_args = [&](const BlockDev& bw, bool hm) {
+      AttnArgs at{};
+      at.q = sc.qkv; at.k = sc.qkv + (hm ? (size_t)M * d : (size_t)d); at.v = sc.qkv + (hm ? 2 * (size_t)M * d : 2 * (size_t)d); at.ctx = sc.ctx;
+      at.B = B; at.Tq = T; at.Tk = T; at.H = H; at.D = d; at.ldq = hm ? hs : 3 * d; at.ldk = hm ? hs : 3 * d;
+      at.win_front = bo.win_front; at.win_back = bo.win_back;
+      at.h2_sq = bw.att_h2[0]; at.h2_sk = bw.att_h2[1]; at.h2_sv = bw.att_h2[2];      // q / k / v are the block's own projections
+      at.head_major = hm ? 1 : 0;
+      return at;
+    };
+    auto qkv_head_major = [&](const BlockDev& bw) {
+      static const bool on = [] { const char* v = getenv("MI355ASR_QKV_HEAD_MAJOR"); return v ? atoi(v) != 0 : true; }();
+      return on && pp_enabled() && bw.pp_ff1 && attention_takes_head_major(hs, attn_args(bw, true));
+    };
     auto ff1_args = [&](const BlockDev& bw, const float* x0, float* x1) {
       Ff1QkvArgs k1{};
       k1.x0 = x0; k1.x1 = x1; k1.qkv = sc.qkv;
@@ -902,6 +919,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       k1.ff_w2p = bw.ff_w2p[0]; k1.ff_b2 = bw.ff_b2[0];
       k1.att_ln_g = bw.att_ln_g; k1.att_ln_b = bw.att_ln_b; k1.qkv_wp = bw.qkv_wp; k1.qkv_b = bw.qkv_b;
       k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M; k1.slabs = bw.ff1_slabs; k1.pp_slabs = bw.pp_ff1; k1.pp_sc = bw.pp_ff1_sc; k1.pp_sw_qkv = bw.pp_sw_qkv;
+      if (qkv_head_major(bw)) { k1.qkv_T = T; k1.qkv_H = H; }
       return k1;
     };
     if (!skip_ff1) {
@@ -909,11 +927,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       if (bo.pre_pp) { k1.pre_x = bo.pre_x; k1.pre_pp = bo.pre_pp; k1.pre_sw = bo.pre_sw; k1.pre_chunks = bo.pre_chunks; }
       PROF(MI355ASR_K_FF1_QKV); LAUNCH_TRY(launch_ff1_qkv(k1, s), "ff_module_1 + qkv");
     }
-    AttnArgs at{};
-    at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ctx = sc.ctx;
-  at.B = B; at.Tq = T; at.Tk = T; at.H = H; at.D = d; at.ldq = 3 * d; at.ldk = 3 * d;
-    at.win_front = bo.win_front; at.win_back = bo.win_back;
-    at.h2_sq = w.att_h2[0]; at.h2_sk = w.att_h2[1]; at.h2_sv = w.att_h2[2];      // q / k / v are this block's own projections
+    const AttnArgs at = attn_args(w, qkv_head_major(w));
     { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
     OutGluArgs k2{};
     k2.ctx = sc.ctx; k2.x1 = sc.xb; k2.x2 = sc.xa; k2.u = sc.u;

@@ -130,13 +130,16 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
   const int T = a.Tk, TQ = a.Tq;
   const int h = blockIdx.y, b = blockIdx.z;
   const int ld = a.ldk, D = a.D;
-  const float* __restrict__ kbase = a.k + (size_t)b * T * ld + h * HS;
-  const float* __restrict__ vbase = a.v + (size_t)b * T * ld + h * HS;
+  // token-major: row (b T + t) of ld floats, head h at columns [36 h, 36 h + 36); head-major (round 5): row ((b H + h) T + t) of 36
+  const size_t khead = a.head_major ? ((size_t)b * a.H + h) * T * HS : (size_t)b * T * ld + h * HS;
+  const float* __restrict__ kbase = a.k + khead;
+  const float* __restrict__ vbase = a.v + khead;
 
   // ---- this lane's query fragment: query c of tile qt, dims 8g..8g+7 and 32 + g (log2 e folded in: softmax uses exp2)
   const int qt = blockIdx.x * AW + wv;
   const int tq = qt * 16 + c;
-  const float* qrow = a.q + ((size_t)b * TQ + min(tq, TQ - 1)) * a.ldq + h * HS;
+  const float* qrow = a.head_major ? a.q + (((size_t)b * a.H + h) * TQ + min(tq, TQ - 1)) * HS
+                                   : a.q + ((size_t)b * TQ + min(tq, TQ - 1)) * a.ldq + h * HS;
   constexpr float LOG2E = 1.4426950408889634f;
   const f32x4 qlo = ldg4(qrow + 8 * g), qhi = ldg4(qrow + 8 * g + 4);
   const float qtl = qrow[32 + g] * (LOG2E * sq);
@@ -277,12 +280,20 @@ bool attention_split_applicable(int hs, const AttnArgs& a) {
   return hs == HS && a.win_front < 0 && a.Tk <= TPK && a.Tk > 16 && a.Tq > 16 && a.ldk % 4 == 0 && a.ldq % 4 == 0;
 }
 
+static bool attn_three_env() {
+  // MI355ASR_ATTN_TERMS=3: the three-term bf16 kernel also where the operand bounds are known
+  static const bool three = [] { const char* v = getenv("MI355ASR_ATTN_TERMS"); return v && atoi(v) == 3; }();
+  return three;
+}
+bool attention_split_two_term(int hs, const AttnArgs& a) {
+  return attention_split_applicable(hs, a) && a.h2_sq > 0.f && a.h2_sk > 0.f && a.h2_sv > 0.f && !attn_three_env() && ADG == 0;
+}
+
 int launch_attention_split(int hs, const AttnArgs& a, hipStream_t s) {
   if (!attention_split_applicable(hs, a)) return -1;
   const int qtiles = (a.Tq + 15) / 16;
-  // MI355ASR_ATTN_TERMS=3: the three-term bf16 kernel also where the operand bounds are known
-  static const bool three = [] { const char* v = getenv("MI355ASR_ATTN_TERMS"); return v && atoi(v) == 3; }();
-  const bool two = a.h2_sq > 0.f && a.h2_sk > 0.f && a.h2_sv > 0.f && !three && ADG == 0;
+  const bool two = attention_split_two_term(hs, a);
+  if (a.head_major && (!two || a.ldq != HS || a.ldk != HS)) return -1;       // head-major operands: this kernel's two-term form only
   note_scheme(two ? SCHEME_F16X2 : SCHEME_BF16X3);
   if (two)
     hipLaunchKernelGGL(attention_split_kernel<2>, dim3((qtiles + AW - 1) / AW, a.H, a.B), dim3(ATH), 0, s, a);

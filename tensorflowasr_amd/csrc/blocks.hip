@@ -636,6 +636,13 @@ static void launch_attention_t(const AttnArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL((attention_kernel<HS, 16>), grid, dim3(BLOCK_THREADS), 0, s, a);
 }
 
+// would launch_attention hand this launch to the two-term attention_split_kernel (the one kernel that reads head-major operands)?
+bool attention_takes_head_major(int HS, const AttnArgs& a) {
+  static const bool lds_env = [] { const char* v = getenv("MI355ASR_ATTN_LDS"); return v ? atoi(v) != 0 : true; }();
+  static const bool split_env = [] { const char* v = getenv("MI355ASR_ATTN_SPLIT"); return v ? atoi(v) != 0 : true; }();
+  return lds_env && split_env && attention_split_two_term(HS, a);
+}
+
 int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
   // short full-attention utterances (offline ConformerCTC): K / V^T staged in LDS (attention_lds.hip)
   // MI355ASR_ATTN_SPLIT=0: the fp32-MFMA LDS kernel of round 1 instead of the split-bf16 one (attention_split.hip);
@@ -644,6 +651,7 @@ int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
   static const bool split_env = [] { const char* v = getenv("MI355ASR_ATTN_SPLIT"); return v ? atoi(v) != 0 : true; }();
   if (lds_env && split_env && attention_split_applicable(HS, a))
     return launch_attention_split(HS, a, s);
+  if (a.head_major) return -1;         // head-major q / k / v (round 5) are read by attention_split_kernel only
   note_scheme(SCHEME_F32);
   if (lds_env && attention_lds_applicable(HS, a)) return launch_attention_lds(HS, a, s);
   if (HS == 36) launch_attention_t<36>(a, s);

@@ -1146,12 +1146,12 @@ int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
   if (ring && a.slabs) {
     if (launch_pp_ff1_qkv(a, s) == 0) return 0;
-    if (a.pre_pp) return -1;          // only the pair-pipelined kernel computes x0 itself (callers ask ff1_pre_selected first)
+    if (a.pre_pp || a.qkv_T > 0) return -1;   // only the pair-pipelined kernel computes x0 itself (callers ask ff1_pre_selected first) / stores q, k, v head-major
     note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(ff1_qkv_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
     return 0;
   }
-  if (a.pre_pp) return -1;
+  if (a.pre_pp || a.qkv_T > 0) return -1;
   note_scheme(SCHEME_F32);
   hipLaunchKernelGGL(ff1_qkv_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;
@@ -1215,6 +1215,7 @@ bool tail_ff1_available() {
 int launch_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s) {
   if (!tail_ff1_available() || !a.slabs || !b.slabs || a.M != b.M) return -1;
   if (launch_pp_tail_ff1(a, b, s) == 0) return 0;
+  if (b.qkv_T > 0) return -1;         // head-major q / k / v: the pair-pipelined kernels only
   const int tiles = (a.M + 15) / 16;
   note_scheme(SCHEME_BF16X3);
   hipLaunchKernelGGL(tail_ff1_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, b);

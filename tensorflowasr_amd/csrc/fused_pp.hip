@@ -515,9 +515,21 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
     const float sc = (q == 0 ? a.qscale : 1.0f) * invq;
     const WaveCtx e = wave_ctx_fresh(a.M, T);
     if (e.live) {
-      float* qrow = a.qkv + (size_t)e.tok * (3 * D) + 16 * q * KB + e.g4;
+      if (a.qkv_T > 0) {
+        // head-major (AttnArgs::head_major): plane q of M D floats, row ((b H + h) T + t) of 36: features 16 i + g4 .. + 3 lie in
+        // one head (36 and 16 i + g4 are multiples of four)
+        const int bq = e.tok / a.qkv_T, tq = e.tok - bq * a.qkv_T;
+        float* plane = a.qkv + (size_t)q * a.M * D + ((size_t)bq * a.qkv_H * a.qkv_T + tq) * 36;
 #pragma unroll
-      for (int i = 0; i < KB; ++i) stg4(qrow + 16 * i, acc[i] * splat4(sc));
+        for (int i = 0; i < KB; ++i) {
+          const int f0 = 16 * i + e.g4, hq = f0 / 36;
+          stg4(plane + (size_t)hq * a.qkv_T * 36 + (f0 - 36 * hq), acc[i] * splat4(sc));
+        }
+      } else {
+        float* qrow = a.qkv + (size_t)e.tok * (3 * D) + 16 * q * KB + e.g4;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) stg4(qrow + 16 * i, acc[i] * splat4(sc));
+      }
     }
   }
 }

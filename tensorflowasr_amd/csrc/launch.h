@@ -77,6 +77,11 @@ struct AttnArgs {
   // bound(|v|) * h2_sv <= 2^15 (api.hip derives the bounds from the q / k / v weights and the LayerNorm in front of them);
   // 0 = unknown bounds (stage calls on caller-supplied q / k / v): the three-term bf16 kernel
   float h2_sq = 0.f, h2_sk = 0.f, h2_sv = 0.f;
+  // round 5, attention_split_kernel only: q / k / v stored HEAD-MAJOR by the producer (pp_ff1_consume): three planes of
+  // [B, H, T, 36] floats, so that the 36 floats of a (token, head) are one contiguous 144-byte row and a head's T rows one
+  // contiguous block -- the token-major [B T, 3 D] rows put a head's 144 bytes at a 1728-byte stride, two 128-byte lines per
+  // row, 1.79x the fetch the kernel needs (round-4 counters).  q / k / v then point at the planes, ldq / ldk are 36.
+  int head_major = 0;
 };
 
 struct DwArgs {
@@ -283,6 +288,10 @@ struct Ff1QkvArgs {
   const float* pp_slabs = nullptr;   // pair-pipelined stream (fused_pp.hip: 51 ring slots of 20 fragments; biases in row 144), or null
   PpChainSc pp_sc;                   // ... the scales its ff_module_1 chain was packed with (api.hip: append_pp_chain)
   float pp_sw_qkv = 1.f;             // ... and its q / k / v matrix
+  // round 5: qkv_T > 0 = store q / k / v head-major for attention_split_kernel (AttnArgs::head_major): planes of M * 144 floats,
+  // row ((b H + h) T + t) of 36 floats; qkv_T = frames per utterance (M = B qkv_T), qkv_H heads of 36.  Pair-pipelined kernels only:
+  // every other ff_module_1 kernel refuses such a launch.
+  int qkv_T = 0, qkv_H = 0;
   // round 4: the plain layer in front of the block (the subsampling Dense, the CTC decoder's projection) in the same launch:
   // x0 = pre_x [M, 144 * pre_chunks] W + b from its two-term stream (api.hip: append_pp_plain) -- x0 above is not read then
   const float* pre_x = nullptr; const float* pre_pp = nullptr;
@@ -361,6 +370,8 @@ int launch_attention(int HS, const AttnArgs& a, hipStream_t s);
 bool attention_lds_applicable(int HS, const AttnArgs& a);
 int launch_attention_lds(int HS, const AttnArgs& a, hipStream_t s);
 bool attention_split_applicable(int HS, const AttnArgs& a);
+bool attention_split_two_term(int HS, const AttnArgs& a);
+bool attention_takes_head_major(int HS, const AttnArgs& a);   // blocks.hip: launch_attention's own switches included   // the two-term kernel would take this launch (head-major operands allowed)
 int launch_attention_split(int HS, const AttnArgs& a, hipStream_t s);
 int launch_dwconv(int K, const DwArgs& a, hipStream_t s);
 int launch_stft(const StftArgs& a, hipStream_t s);

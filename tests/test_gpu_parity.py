@@ -410,6 +410,112 @@ np.savez(sys.argv[1], **out)
             assert np.array_equal(res[tag][k], res["plain"][k]), (tag, k, float(np.abs(res[tag][k] - res["plain"][k]).max()))
 
 
+def test_head_major_qkv_bit_identical_to_token_major(torch_cuda):
+    """Round 5: between a pair-pipelined block kernel and attention_split_kernel<2> q / k / v travel as three head-major planes
+    [B, H, T, 36] (a head's rows contiguous: the token-major rows put a head's 144 bytes at a 1728-byte stride = two 128-byte
+    lines per row, 1.79 x the fetch, round-4 counters).  Only addresses change: encoder output, logits and ids BIT-IDENTICAL to
+    MI355ASR_QKV_HEAD_MAJOR=0 -- flat token tiles that straddle utterances (first block's own launch: T = 250 is no multiple
+    of 16), per-utterance tiles (the folded launches), T = 250 / 100 / 17, and a batch whose rows are not a multiple of 64."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, small_cfg, waves
+from tensorflowasr_amd.models import ConformerCTC
+cfg = small_cfg(3)
+w = co.encoder_weights(cfg, seed=81)
+w.update(co.ctc_decoder_weights(cfg, 200, seed=82))
+m = ConformerCTC(200, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+m.load_weights(w, by_name=False)
+out = {}
+for tag, B, L in (("a", 9, 160000), ("b", 21, 64000), ("c", 40, 10880)):
+    x = waves(B, L, 3)
+    enc = m.encode(x)
+    out[tag + "_enc"] = enc.cpu().numpy()
+    out[tag + "_logits"] = m.ctc_logits(enc).cpu().numpy()
+    ids, lens = m.recognize(x)
+    out[tag + "_ids"] = ids.cpu().numpy(); out[tag + "_lens"] = lens.cpu().numpy()
+xb = np.random.default_rng(5).standard_normal((7, 250, 144)).astype(np.float32)
+out["blk"] = m.conformer_block(1, xb).cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("hm", {}), ("tm", {"MI355ASR_QKV_HEAD_MAJOR": "0"})):
+            f = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[tag] = dict(np.load(f))
+    for k in res["tm"]:
+        assert np.isfinite(res["hm"][k].astype(np.float64)).all(), k
+        assert np.array_equal(res["hm"][k], res["tm"][k]), (k, float(np.abs(res["hm"][k].astype(np.float64) - res["tm"][k]).max()))
+    assert np.abs(res["hm"]["a_enc"]).max() > 0.1
+
+
+def test_subsampling_conv1_on_the_matrix_pipe_against_the_valu_evaluation(torch_cuda):
+    """Round 5: in the two-term subsampling conv of dmodel 144 conv1 itself runs on the matrix pipe -- the mel patch staged as fp16
+    hi + lo planes, three MFMAs per (row tile, tap) -- instead of 36 fp32 multiply-adds per value on the VALU.  It is then a
+    two-term product (2^-22 of its operand bounds) like conv2: against MI355ASR_SUBCONV_C1M=0 (exact fp32 conv1) and against the
+    oracle on the encoder's own features (offline 'same' frontend: static mel bound) and on the chunk front (run-time bound per
+    utterance, quiet and loud utterances in one batch): both builds within the usual distance of the oracle, C1M at most twice
+    the VALU build's + 1e-6, and 2e-6 of the output's scale apart from each other."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from helpers import chunk_config_dict, co, encoder_kwargs, small_cfg, waves
+from tensorflowasr_amd.models import ChunkConformer, ConformerEncoder
+out = {}
+cfg = small_cfg(1)
+w = co.encoder_weights(cfg, seed=91)
+e = ConformerEncoder(**encoder_kwargs(cfg))
+e.load_weights(w, by_name=False)
+x = waves(6, 160000, 12)
+x[1] *= np.float32(1e-3)
+x[2, 40000:] = 0.0
+out["sub"] = e(x).cpu().numpy()                      # one block behind the subsampling: its error travels with the features
+c5 = dict(co.CHUNK_S, enc_num_blocks=1, picker_num_blocks=1, helper_num_blocks=1, decoder_num_blocks=1)
+w5 = co.chunk_weights(c5, seed=6)
+mc = ChunkConformer(chunk_config_dict(c5), c5["picker_num_classes"], c5["decoder_num_classes"])
+mc.load_weights(w5, by_name=False)
+xc = waves(3, 48000, 75)
+xc[0] *= np.float32(30.0); xc[1] *= np.float32(1e-3)
+out["front"] = mc.predict(xc, stages=True)["front"].cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("mm", {}), ("valu", {"MI355ASR_SUBCONV_C1M": "0"})):
+            f = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[tag] = dict(np.load(f))
+    cfg = small_cfg(1)
+    w = co.encoder_weights(cfg, seed=91)
+    x = waves(6, 160000, 12)
+    x[1] *= np.float32(1e-3)
+    x[2, 40000:] = 0.0
+    ref_enc = co.conformer_encoder(x[:3].astype(np.float64), w, cfg)
+    c5 = dict(co.CHUNK_S, enc_num_blocks=1, picker_num_blocks=1, helper_num_blocks=1, decoder_num_blocks=1)
+    w5 = co.chunk_weights(c5, seed=6)
+    xc = waves(3, 48000, 75)
+    xc[0] *= np.float32(30.0)
+    xc[1] *= np.float32(1e-3)
+    ref_front = co.chunk_predict(xc.astype(np.float64), w5, c5)["front"]
+    for key, ref, got in (("sub", ref_enc, lambda r: r["sub"][:3]), ("front", ref_front, lambda r: r["front"])):
+        scale = max(1.0, float(np.abs(ref).max()))
+        e_mm, e_va = maxdiff(got(res["mm"]), ref), maxdiff(got(res["valu"]), ref)
+        apart = maxdiff(got(res["mm"]), got(res["valu"]))
+        print("%s: conv1 on the matrix pipe %.3g, on the VALU %.3g from the oracle; apart %.3g (scale %.3g)" % (key, e_mm, e_va, apart, scale))
+        assert e_mm < TOL and e_va < TOL and e_mm <= 2 * e_va + 1e-6 * scale and apart < 2e-6 * scale + 1e-6
+
+
 def test_layer_in_front_of_a_block_in_its_first_launch_bit_for_bit(torch_cuda):
     """Round 4: the subsampling Dense (conformer_blocks.py:102-106, K = 20 * 144) and the CTC decoder's projection
     (conformer_blocks.py:631) run in the prologue of the first block's ff_module_1 + qkv launch (pp_block_kernel<..., PRE>): the

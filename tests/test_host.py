@@ -993,6 +993,8 @@ SWITCHES = {
     "MI355ASR_CHAIN256": "0: bf16 mode, dmodel 256: one launch per dense layer instead of chain256_bf16_kernel | test_bf16_chain256_against_layer_at_a_time",
     "MI355ASR_CHAIN256_RT": "1 / 2 / 4: row tiles per workgroup of chain256_bf16_kernel (default by row count) | test_bf16_chain256_against_layer_at_a_time",
     "MI355ASR_SUBCONV_RT": "1 / 2: row tiles per wave of the two-term subsampling conv (default: one while that gives no CU a second workgroup) | test_two_term_subsampling_conv_one_row_tile_per_wave_bit_identical",
+    "MI355ASR_SUBCONV_C1M": "0: conv1 of the two-term subsampling conv on the VALU in fp32 instead of on the matrix pipe | test_subsampling_conv1_on_the_matrix_pipe_against_the_valu_evaluation",
+    "MI355ASR_QKV_HEAD_MAJOR": "0: q / k / v as token-major [B T, 3 D] rows instead of head-major planes | test_head_major_qkv_bit_identical_to_token_major",
     "MI355ASR_ATTN_BAND_LDS": "0: band attention with K / V straight from L2 (no staged window) | test_band_attention_staged_window_bit_identical",
     "MI355ASR_PP_HEADF": "0: the class head as its own launch instead of in the CTC block's tail launch | test_layer_in_front_of_a_block_in_its_first_launch_bit_for_bit",
     "MI355ASR_PP_PRE": "0: subsampling Dense and CTC projection as their own launches | test_layer_in_front_of_a_block_in_its_first_launch_bit_for_bit",
