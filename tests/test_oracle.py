@@ -70,7 +70,7 @@ def test_same_padding_rule(n, k, s, expect):
     assert co.same_pad(n, k, s) == expect
 
 
-# ---- unpinned rows: independent cross-checks ----------------------------------------------------------------
+# ---- independent cross-checks (these rows are also pinned by the reference's own code: tests/test_tf_goldens.py) ------
 def test_power_spectrogram_equals_rfft_of_windowed_zero_padded_frames():
     rng = np.random.default_rng(1)
     for L in (16000, 4000, 8123):
