@@ -204,6 +204,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // DMA (~1.3 us when every workgroup asks L2 for the same lines), and with a double buffer -- slab s + 1 requested in step s and
 // waited for at its end -- every step lasted (conv1 phase) + (DMA latency): 3600 cycles for 2 x 864 of matrix work per SIMD.
 // -DMI355ASR_SUBCONV_RING=2 builds the double buffer (A / B timing).
+// MI355ASR_SUBCONV_C1I (with conv1 on the matrix pipe): 1 = every wave produces the operand of step s + 1 in pieces between the
+// fragment groups of step s's MFMAs (no early / late split); 0 = the operand as its own phase (waves 0..3 before, 4..7 behind).
+#ifndef MI355ASR_SUBCONV_C1I
+#define MI355ASR_SUBCONV_C1I 1
+#endif
 #ifndef MI355ASR_SUBCONV_RING
 #define MI355ASR_SUBCONV_RING 4
 #endif
@@ -725,16 +730,52 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
       for (int tp = 0; tp < 9; ++tp) w1r[tp] = *reinterpret_cast<const f32x4*>(p_w1 + tp * D + 16 * cb + g4);
     }
   };
-  SplitFrag xa[RTN];
-  // the operand of a step through either evaluation
-  auto frags_pair = [&](auto PI, int cb) {
+  auto sl_bh = [&](int rt) { if constexpr (C1M) return sl.bh[rt]; else return 0u; };
+  auto sl_bl = [&](int rt) { if constexpr (C1M) return sl.bl[rt]; else return 0u; };
+  constexpr bool C1I = C1M && MI355ASR_SUBCONV_C1I;    // interleaved operand production: two operand buffers, step s reads xbuf[s & 1]
+  SplitFrag xbuf[C1I ? 2 : 1][RTN];
+  SplitFrag (&xa)[RTN] = xbuf[0];
+  // the operand of a step through either evaluation, into operand buffer DST
+  auto frags_pair = [&](auto PI, int cb, auto DST) {
     constexpr int pair = decltype(PI)::value;
-    if constexpr (C1M) frags_for_mm<pair>(xa, sl, c1t, lds4(p_b1, cb, g4), kmul);
-    else frags_for<pair, DIAG, TM>(xa, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
+    SplitFrag (&dst)[RTN] = xbuf[C1I ? decltype(DST)::value : 0];
+    if constexpr (C1M) frags_for_mm<pair>(dst, sl, c1t, lds4(p_b1, cb, g4), kmul);
+    else frags_for<pair, DIAG, TM>(dst, melp, RS, sl, w1r, lds4(p_b1, cb, g4));
   };
-  auto frags_9th = [&](int cbA) {
-    if constexpr (C1M) frags_ninth_mm(xa, sl, c1t, p_b1, g4, cbA, KB, kmul, load_taps);
-    else frags_ninth<DIAG, TM>(xa, melp, RS, sl, w1r, p_b1, g4, cbA, KB, load_taps);
+  auto frags_9th = [&](int cbA, auto DST) {
+    SplitFrag (&dst)[RTN] = xbuf[C1I ? decltype(DST)::value : 0];
+    if constexpr (C1M) frags_ninth_mm(dst, sl, c1t, p_b1, g4, cbA, KB, kmul, load_taps);
+    else frags_ninth<DIAG, TM>(dst, melp, RS, sl, w1r, p_b1, g4, cbA, KB, load_taps);
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  // interleaved mode: the operand of a tap-pair step in pieces, called behind fragment group GI of the previous step's MFMAs.  By
+  // the time piece GI + 1 runs, the counted lgkmcnt wait in front of group GI + 1 has covered the window reads piece GI issued
+  // (LDS returns in order and they are older than the fragment reads that wait leaves outstanding).
+  u32x4 c1w[4];                 // the window fragments of one row tile: taps A / B, hi / lo plane
+  f32x4 c1v[2];                 // conv1 accumulators of that row tile
+  auto c1_piece = [&](auto PI, auto GI, int cb, auto DST) {
+    constexpr int pair = decltype(PI)::value, gi = decltype(GI)::value, QA = 2 * pair, QB = 2 * pair + 1;
+    SplitFrag (&dst)[RTN] = xbuf[C1I ? decltype(DST)::value : 0];
+    auto reads = [&](int rt) {
+      c1w[0] = c1_read<QA / 3>(sl_bh(rt)); c1w[1] = c1_read<QA / 3>(sl_bl(rt));
+      c1w[2] = c1_read<QB / 3>(sl_bh(rt)); c1w[3] = c1_read<QB / 3>(sl_bl(rt));
+    };
+    auto conv = [&]() {
+      asm volatile("" : "+v"(c1w[0]), "+v"(c1w[1]), "+v"(c1w[2]), "+v"(c1w[3]));
+      const f32x4 c0v = lds4(p_b1, cb, g4);
+      const u32x4 ahA = c1_place<QA % 3>(c1t.ph, c1t.qh), alA = c1_place<QA % 3>(c1t.pl, c1t.ql);
+      const u32x4 ahB = c1_place<QB % 3>(c1t.ph, c1t.qh), alB = c1_place<QB % 3>(c1t.pl, c1t.ql);
+      c1v[0] = c1_mma(alA, c1w[0], c0v); c1v[1] = c1_mma(alB, c1w[2], c0v);
+      c1v[0] = c1_mma(ahA, c1w[1], c1v[0]); c1v[1] = c1_mma(ahB, c1w[3], c1v[1]);
+      c1v[0] = c1_mma(ahA, c1w[0], c1v[0]); c1v[1] = c1_mma(ahB, c1w[2], c1v[1]);
+    };
+    auto finish = [&](int rt) { dst[rt] = split8h(c1_finish<QA>(c1v[0], sl, rt, kmul), c1_finish<QB>(c1v[1], sl, rt, kmul)); };
+    if constexpr (gi == 0) reads(0);
+    else if constexpr (gi == 1) conv();
+    else if constexpr (gi == 2) { finish(0); if constexpr (RTN > 1) reads(1); }
+    else if constexpr (gi == 3) { if constexpr (RTN > 1) conv(); }
+    else if constexpr (gi == 4) { if constexpr (RTN > 1) finish(1); }
   };
   if constexpr (DIAG == 1) {
 #pragma unroll
@@ -763,21 +804,22 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   // the whole step loop once per order (compile-time LATE): with a run-time order inside one loop hipcc keeps both
   // paths' temporaries alive and spills (256 VGPRs + 232 bytes of scratch instead of 194)
   auto run = [&](auto LATE_T) {
-  constexpr bool LATE = decltype(LATE_T)::value;
+  constexpr bool LATE = decltype(LATE_T)::value || C1I;
   if constexpr (LATE) {
     load_taps(0);
-    frags_pair(std::integral_constant<int, 0>{}, 0);
+    frags_pair(B0{}, 0, B0{});
   }
   // one MFMA step s: slab s is in wl[s & 1]; frags_this() = the operand of this step (early waves, before the MFMAs),
   // frags_next() = the operand of step s + 1 (late waves, after the MFMAs)
-  auto step_body = [&](int s, auto&& frags_this, auto&& frags_next) {
+  auto step_body = [&](int s, auto&& frags_this, auto&& frags_next, auto PAR_T) {
       const int cur = s & (SRING - 1);
+      SplitFrag (&xin)[RTN] = xbuf[(C1M && MI355ASR_SUBCONV_C1I) ? decltype(PAR_T)::value : 0];    // the operand this step's MFMAs read
       // slab s + SRING - 1: global -> LDS directly (global_load_lds_dwordx4: lane i of a wave lands at base + 16 i) into the slot
       // that was last read in step s - 1, whose barrier every wave has passed.
       auto slab_dma = [&]() { issue_slab(s + SRING - 1); };
       // fragments of G column tiles at a time (one with nine tiles: registers; two with eight), the next group requested
       // before the MFMAs of the current one; lgkmcnt(3 G) = "all but the newest group"
-      auto mfma_cur = [&](auto&& after_first_group) {
+      auto mfma_cur = [&](auto&& between) {         // between(GI): called behind the MFMAs of every fragment group
         constexpr int G = NB % 2 == 0 ? 2 : 1, NG = NB / G;
         const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&wl[cur][lane]);
         u32x4 wa[G][3], wb[G][3];
@@ -814,9 +856,9 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
 #pragma unroll
                 for (int rt = 0; rt < RTN; ++rt) {
                   if constexpr (DIAG == 8)        // no matrix work: the operands are consumed by one VALU op per fragment pair
-                    acc[rt][gi * G + h] += __builtin_bit_cast(f32x4, w[h][ord - p] ^ xa[rt].t[p]);
+                    acc[rt][gi * G + h] += __builtin_bit_cast(f32x4, w[h][ord - p] ^ xin[rt].t[p]);
                   else
-                    acc[rt][gi * G + h] = mma_terms<TM>(w[h][ord - p], xa[rt].t[p], acc[rt][gi * G + h]);
+                    acc[rt][gi * G + h] = mma_terms<TM>(w[h][ord - p], xin[rt].t[p], acc[rt][gi * G + h]);
                 }
         };
         fetch(wa, std::integral_constant<int, 0>{});
@@ -826,26 +868,42 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
             if constexpr (gi + 1 < NG) { fetch(wb, std::integral_constant<int, gi + 1>{}); wait(wa, std::integral_constant<int, TM * G>{}); }
             else wait(wa, std::integral_constant<int, 0>{});
             mma(wa, GI);
-            if constexpr (gi == 0) after_first_group();
+            between(GI);
           } else {
             if constexpr (gi + 1 < NG) { fetch(wa, std::integral_constant<int, gi + 1>{}); wait(wb, std::integral_constant<int, TM * G>{}); }
             else wait(wb, std::integral_constant<int, 0>{});
             mma(wb, GI);
+            between(GI);
           }
         });
       };
-      auto nothing = [] {};
+      auto nothing = [](auto) {};
       if constexpr (DIAG == 1) {
         slab_dma();
         mfma_cur(nothing);
+      } else if constexpr (C1M && MI355ASR_SUBCONV_C1I) {
+        // round 5, conv1 on the matrix pipe: every wave runs the same order -- the operand of step s + 1 is produced BETWEEN the
+        // fragment groups of step s's MFMAs (pieces(GI): window reads, conv1 MFMAs, finish), into the other operand buffer
+        mfma_cur([&](auto GI) {
+          if constexpr (decltype(GI)::value == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            slab_dma();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          frags_this(GI);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        frags_next();
       } else if constexpr (LATE) {
         // the DMA pieces go out behind the first group of MFMAs: this wave's matrix work starts at once (its partner is in
         // its VALU phase), and by the end of the MFMAs the pieces have landed -- the vmcnt(0) hipcc puts in front of the
         // window reads of frags_next() costs nothing
-        mfma_cur([&] {
-          __builtin_amdgcn_sched_barrier(0);
-          slab_dma();
-          __builtin_amdgcn_sched_barrier(0);
+        mfma_cur([&](auto GI) {
+          if constexpr (decltype(GI)::value == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            slab_dma();
+            __builtin_amdgcn_sched_barrier(0);
+          }
         });
         __builtin_amdgcn_sched_barrier(0);
         frags_next();
@@ -878,31 +936,57 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
   for (int cb = 0; cb < KB; ++cb) {
     static_for<0, NPAIR>([&](auto PI) {
       constexpr int pair = decltype(PI)::value;
+      using PAR = std::integral_constant<int, pair & 1>;             // s = NPAIR cb + pair, NPAIR even
+      using NXT = std::integral_constant<int, (pair & 1) ^ 1>;
+      if constexpr (C1I) {
+        // the next step's operand in pieces behind this step's fragment groups when it is a tap-pair step of the same channel
+        // block or the first of the next block (its taps are loaded behind group 0 then)
+        step_body(cb * NPAIR + pair,
+                  [&](auto GI) {
+                    if constexpr (pair + 1 < NPAIR) c1_piece(std::integral_constant<int, pair + 1>{}, GI, cb, NXT{});
+                    else if (cb + 1 < KB) {
+                      if constexpr (decltype(GI)::value == 0) load_taps(cb + 1);
+                      c1_piece(B0{}, GI, cb + 1, NXT{});
+                    }
+                  },
+                  [&]() { if constexpr (pair + 1 == NPAIR) { if (cb + 1 == KB) frags_9th(0, NXT{}); } },
+                  PAR{});
+      } else {
       step_body(cb * NPAIR + pair,
                 [&]() {                      // early waves: the operand of this step, just before its MFMAs
                   if constexpr (pair == 0) load_taps(cb);
-                  frags_pair(PI, cb);
+                  frags_pair(PI, cb, B0{});
                 },
                 [&]() {                      // late waves: the operand of the next step, after this step's MFMAs
                   if constexpr (pair + 1 < NPAIR) {
-                    frags_pair(std::integral_constant<int, pair + 1>{}, cb);
+                    frags_pair(std::integral_constant<int, pair + 1>{}, cb, B0{});
                   } else if (cb + 1 < KB) {
                     load_taps(cb + 1);
-                    frags_pair(std::integral_constant<int, 0>{}, cb + 1);
+                    frags_pair(B0{}, cb + 1, B0{});
                   } else {
-                    frags_9th(0);
+                    frags_9th(0, B0{});
                   }
-                });
+                }, B0{});
+      }
     });
   }
+  if constexpr (C1I) {
+    static_assert((KB * NPAIR) % 2 == 0, "the first ninth-tap step reads operand buffer 0");
+    static_for<0, NI>([&](auto II) {             // the ninth taps, two channel blocks per step: not interleaved (their taps change mid-step)
+      constexpr int i = decltype(II)::value;
+      step_body(KB * NPAIR + i, [](auto) {}, [&]() { if constexpr (i + 1 < NI) frags_9th(2 * i + 2, std::integral_constant<int, (i & 1) ^ 1>{}); },
+                std::integral_constant<int, i & 1>{});
+    });
+  } else {
 #pragma unroll 1
   for (int i = 0; i < NI; ++i) {             // the ninth taps, two channel blocks per step
     step_body(KB * NPAIR + i,
-              [&]() { frags_9th(2 * i); },
-              [&]() { if (i + 1 < NI) frags_9th(2 * i + 2); });
+              [&]() { frags_9th(2 * i, B0{}); },
+              [&]() { if (i + 1 < NI) frags_9th(2 * i + 2, B0{}); }, B0{});
+  }
   }
   };
-  if (late) run(std::integral_constant<bool, true>{});
+  if (late || C1I) run(std::integral_constant<bool, true>{});
   else run(std::integral_constant<bool, false>{});
   const float inv2 = 1.0f / s2;            // a power of two
 #pragma unroll
