@@ -105,7 +105,7 @@ def test_config2_batch64_10s_nonblank_head_ids_vs_oracle(torch_cuda):
     print("config 2, token-emitting head: logits max|d| %.3g, undecided frames %d / 1000 %s" % (err, len(report), report[:4]))
 
 
-def _all64_against_fixture(m, head, torch):
+def _all64_against_fixture(m, head, torch, fixture="config2_oracle_b64.npz"):
     """Every one of the 64 benched utterances against tests/golden/config2_oracle_b64.npz (fp64 oracle, written by
     tests/golden/make_config2_b64.py): encoder rows, logits (all classes of every 50th frame, the oracle's four largest
     classes of EVERY frame), per-frame argmax, greedy ids and lengths.  A frame may differ in argmax only when the oracle's
@@ -113,7 +113,7 @@ def _all64_against_fixture(m, head, torch):
     oracle argmax with exactly those frames patched (helpers.assert_frames_and_ids, on the stored top-4 instead of full rows)."""
     from helpers import _parity_log
     from tensorflowasr_amd.synthetic import synth_batch
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_oracle_b64.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
     x = synth_batch(0, 64, 160000)
     xd = torch.from_numpy(x).cuda()
     ids, lens = m.recognize(xd)
@@ -134,7 +134,7 @@ def _all64_against_fixture(m, head, torch):
         margin = float(top_val[b, t, 0] - top_val[b, t, pos[0]])
         assert margin <= 10 * e_lg, "argmax differs on a frame the oracle decides clearly: (%d, %d) margin %.3g, logit error %.3g" % (b, t, margin, e_lg)
         report.append((int(b), int(t), margin))
-    _parity_log({"tag": "config2_all64_" + head, "frames": int(ra.size), "logits_max_abs_err": e_lg, "excused_frames": len(report),
+    _parity_log({"tag": ("config2_all64_vs_reference_code_" if fixture.startswith("tf_") else "config2_all64_") + head, "frames": int(ra.size), "logits_max_abs_err": e_lg, "excused_frames": len(report),
                  "excused": [{"utt": r[0], "frame": r[1], "oracle_margin": r[2]} for r in report[:20]]})
     assert len(report) <= 0.005 * ra.size
     patched = ra.copy()
@@ -167,6 +167,30 @@ def test_config2_all_64_utterances_token_emitting_head_vs_oracle_fixture(torch_c
     m.load_weights(w, by_name=False)
     _, report = _all64_against_fixture(m, "tokens", torch_cuda)
     assert len(report) <= 0.002 * 16000
+
+
+def test_config2_all_64_utterances_vs_the_reference_code_both_heads(bench_model, torch_cuda):
+    """Round 5: the same comparison against tests/golden/tf_config2_b64.npz -- the 64 benched utterances through the reference's
+    OWN ConformerEncoder + CTCDecoder + ctc_decode (float32 run on the NumPy stand-in, tests/golden/make_tf_config2_b64.py):
+    encoder rows, logits, every frame's arg-max and the greedy ids of all 64 utterances for the benched model and for the
+    token-emitting head, with the same rule for frames the reference's own float32 logits cannot decide."""
+    from tensorflowasr_amd.models import ConformerCTC
+    import bench
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_config2_b64.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/tf_config2_b64.npz not generated (python tests/golden/make_tf_config2_b64.py)")
+    m, _ = bench_model
+    _, rep1 = _all64_against_fixture(m, "trained", torch_cuda, fixture="tf_config2_b64.npz")
+    cfg = dict(co.CONFORMER_S)
+    w = co.encoder_weights(cfg, seed=0)
+    w.update(co.ctc_decoder_weights(cfg, 1332, seed=1))
+    w["fully_connected/bias"] = np.load(os.path.join(os.path.dirname(path), "config2_oracle_b64.npz"))["tokens_fc_bias"]
+    m2 = ConformerCTC(1332, **bench.S_CFG)
+    m2.load_weights(w, by_name=False)
+    _, rep2 = _all64_against_fixture(m2, "tokens", torch_cuda, fixture="tf_config2_b64.npz")
+    print("config 2, all 64 utterances against the reference's own code: excused frames %d (benched model) / %d (token head) of 16 000"
+          % (len(rep1), len(rep2)))
+    assert len(rep1) <= 8 and len(rep2) <= 0.002 * 16000
 
 
 def test_config2_trained_ctc_decoder_at_batch64(torch_cuda):

@@ -159,6 +159,55 @@ def test_oracle_chunk_predict_vs_tf():
         exact(r[k], fx, k)
 
 
+def test_oracle_benched_batch_fixture_vs_the_reference_code_on_all_64_utterances():
+    """tests/golden/tf_config2_b64.npz: the 64 benched utterances (BASELINE config 2) through the reference's own ConformerEncoder +
+    CTCDecoder + ctc_decode, both weight sets of config2_oracle_b64.npz.  The fp64 oracle's fixture must agree with it: greedy
+    ids and lengths of all 64 utterances for both heads, every frame's arg-max (the reference's float64 run; a frame may differ only
+    where its own top-2 margin is below 1e-9: none does), the four largest logits of every frame within 1e-5 (the oracle fixture
+    stores float32), and the reference's float32 run within 1e-3 of them with arg-max flips only inside its own rounding."""
+    fx, orc = fixture("tf_config2_b64.npz"), fixture("config2_oracle_b64.npz")
+    for head in ("trained", "tokens"):
+        ref_idx, ref_val = fx[head + "_top4_idx_f64"].astype(np.int64), fx[head + "_top4_val_f64"]
+        o_idx, o_val = orc[head + "_top4_idx"].astype(np.int64), orc[head + "_top4_val"]
+        assert ref_idx.shape == o_idx.shape == (64, 250, 4)
+        margin = ref_val[..., 0] - ref_val[..., 1]
+        flips = np.argwhere(ref_idx[..., 0] != o_idx[..., 0])
+        assert all(margin[b, t] < 1e-9 for b, t in flips), [(int(b), int(t), float(margin[b, t])) for b, t in flips[:5]]
+        same = ref_idx == o_idx                                   # compare values class by class where the order agrees (ties may swap)
+        assert same.mean() > 0.999
+        assert float(np.abs(ref_val - o_val)[same].max()) < 1e-5
+        # the float32 run of the reference's code against its float64 run: what a TensorFlow forward is allowed to differ by
+        v32, i32 = fx[head + "_top4_val"], fx[head + "_top4_idx"].astype(np.int64)
+        agree = i32[..., 0] == ref_idx[..., 0]
+        assert float(np.abs(v32 - ref_val)[i32 == ref_idx].max()) < TOL
+        assert all(margin[b, t] < 1e-3 for b, t in np.argwhere(~agree)), head
+        # ids: the reference's ctc_decode (float32 run) == the oracle's collapse wherever the two arg-max sequences agree
+        ok = agree.all(axis=1)
+        assert ok.sum() >= 60, (head, int(ok.sum()))
+        assert np.array_equal(fx[head + "_ids"][ok], orc[head + "_ids"][ok]) and np.array_equal(fx[head + "_lens"][ok], orc[head + "_lens"][ok])
+        assert maxdiff(fx[head + "_enc_every10"], orc[head + "_enc_every10"]) < 1e-4
+    assert int(fx["tokens_lens"].sum()) > 15000 and int(fx["trained_lens"].sum()) == int(orc["trained_lens"].sum())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/asr/models"), reason="needs the reference checkout")
+def test_benched_batch_fixture_is_what_the_recipe_makes_for_two_utterances(tmp_path):
+    """the committed tf_config2_b64.npz against a fresh run of its recipe on utterances 0 and 63 (a few seconds per head)"""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import make_tf_config2_b64 as m; "
+            "r = m.run(utterances=[0, 63]); np.savez(sys.argv[1], **r)" % GOLDEN)
+    out = str(tmp_path / "two.npz")
+    r = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, timeout=900, cwd=os.path.dirname(GOLDEN))
+    assert r.returncode == 0, r.stderr[-3000:]
+    two, fx = np.load(out), fixture("tf_config2_b64.npz")
+    for k in two.files:
+        a, b = two[k], fx[k][[0, 63]]
+        if a.dtype.kind == "f":
+            assert maxdiff(a, b) <= 2e-6 * max(1.0, float(np.abs(b).max())), k
+        else:
+            assert np.array_equal(a, b), k
+
+
 # ---- GPU: libmi355asr.so against the reference -------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("L", [32000, 67263])
