@@ -32,7 +32,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), REF):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from helpers import chunk_config_dict, co, waves  # noqa: E402
+from helpers import chunk_config_dict, co, pick_bias_for_ragged_counts, waves  # noqa: E402
 from tensorflowasr_amd import checkpoint  # noqa: E402
 
 
@@ -241,19 +241,48 @@ def main():
     done.append("wave_pick")
 
     # ---- a15: ChunkConformer.predict (chunk_conformerS.yml dims, 2 encoder blocks, small vocabularies) -------------
+    # 6 s utterances: T = 150 frames, so that the band mask (win_front 36) cuts; the picker's blank bias is set so that about
+    # half of the frames are kept -- feature_pick's tf.while_loop compacts ragged counts and zero-pads to the batch maximum
     from asr.models.chunk_conformer_blocks import ChunkConformer
     ccfg = dict(co.CHUNK_S, enc_num_blocks=2, picker_num_classes=30, decoder_num_classes=40)
     wch = co.chunk_weights(ccfg, seed=3)
-    xc = waves(2, 24000, 40)
+    xc = waves(2, 96000, 40)
+    wch["picker/fully_connected/bias"][-1] = np.float32(pick_bias_for_ragged_counts(ccfg, wch, xc))
     model = ChunkConformer(chunk_config_dict(ccfg), 30, 40)
     kept = assign_by_object_path(model, wch, tf)
     front = model.front(tf.constant(xc[..., None]), training=False)
     encc = model.encoder(front, training=False)
     phone, hidden = model.phone_picker(encc, training=False)
-    save("tf_chunk_predict.npz", wave_seed=40, L=24000, front=front.numpy(), enc=encc.numpy(), picker_logits=phone.numpy(),
-         picker_hidden=hidden.numpy(), text_logits=model.predict(tf.constant(xc[..., None])).numpy(), weights_seed=3,
-         freq2mel=kept.get("front/mel_layer/freq2mel"))
+    picked_f, picked_c = model.feature_pick(hidden, phone)
+    save("tf_chunk_predict.npz", wave_seed=40, L=96000, front=front.numpy(), enc=encc.numpy(), picker_logits=phone.numpy(),
+         picker_hidden=hidden.numpy(), picked=picked_f.numpy(), text_logits=model.predict(tf.constant(xc[..., None])).numpy(), weights_seed=3,
+         picker_blank_bias=wch["picker/fully_connected/bias"][-1], freq2mel=kept.get("front/mel_layer/freq2mel"))
     done.append("chunk_predict")
+
+    # ---- a15 streaming: picker_stream_predict / feature_pick / decoder_stream_predict fed 2560 samples at a time with explicit
+    # caches, driven as test_chunk_asr.py:60-83 drives them (chunk_conformer_blocks.py:72-91, 209-229, 297-316, 449-456, 522-560,
+    # 646-673, 824-852): the valid outputs of every step, which steps produced text, the look-ahead rows, the final caches
+    xs1 = xc[:1, :2560 * 30]
+    pc, dc = model.init_picker_caches(1), model.init_decoder_caches(1)
+    ph, hid, txt, unv, steps = [], [], [], None, []
+    for i in range(30):
+        vp, _, vh, pc = model.picker_stream_predict(tf.constant(xs1[:, i * 2560:(i + 1) * 2560, None]), pc)
+        if vp.shape[1] == 0:
+            continue
+        ph.append(vp.numpy()), hid.append(vh.numpy())
+        f, _ = model.feature_pick(vh, vp)
+        if f.shape[1] != 0:
+            vt, unv, dc = model.decoder_stream_predict(f, dc)
+            txt.append(vt.numpy())
+            steps.append((i, int(vt.shape[1])))
+    save("tf_chunk_stream.npz", wave_seed=40, samples=2560, nchunks=30, weights_seed=3, picker_blank_bias=wch["picker/fully_connected/bias"][-1],
+         picker_logits=np.concatenate(ph, 1), picker_hidden=np.concatenate(hid, 1), text_logits=np.concatenate(txt, 1),
+         unvalid_text_logits=unv.numpy(), steps=np.asarray(steps, np.int32),
+         cache_front_wav=pc[0].numpy(), cache_front_sub=pc[1].numpy(), cache_enc_mha=pc[2].numpy(), cache_enc_cnn=pc[3].numpy(),
+         cache_picker_mha=pc[4].numpy(), cache_picker_cnn=pc[5].numpy(), cache_picker_dec_inp=pc[6].numpy(),
+         cache_helper_mha=dc[0].numpy(), cache_decoder_mha=dc[2].numpy(), cache_decoder_cnn=dc[3].numpy(), cache_decoder_dec_inp=dc[4].numpy(),
+         freq2mel=kept.get("front/mel_layer/freq2mel"))
+    done.append("chunk_stream")
     print("done:", done)
 
 

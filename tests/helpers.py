@@ -111,3 +111,31 @@ def chunk_config_dict(cfg):
                                 win_front=cfg["decoder_win_front"], win_back=cfg["decoder_win_back"]),
         "ContextHelper": dict(common, num_classes=cfg["picker_num_classes"], num_blocks=cfg["helper_num_blocks"],
                               win_front=cfg["helper_win_front"], win_back=cfg["helper_win_back"])}}
+
+
+def pick_bias_for_ragged_counts(cfg, w, x):
+    """choose the picker's blank bias so that roughly half of the frames are kept (ragged counts)."""
+    r = co.chunk_predict(x.astype(np.float64), w, cfg)
+    z = r["picker_logits"]
+    gap = np.sort(z[..., :-1].max(-1) - z[..., -1], axis=None)
+    # threshold in the middle of the widest gap between neighbouring frames around the median, so that no frame
+    # sits on the blank / non-blank decision boundary
+    lo, hi = gap.size // 2 - gap.size // 8, gap.size // 2 + gap.size // 8
+    k = lo + int(np.argmax(np.diff(gap[lo:hi + 1])))
+    return float(0.5 * (gap[k] + gap[k + 1]))
+
+
+def stream_oracle(x, w, cfg, nchunks, samples):
+    pc, dc = co.chunk_init_picker_caches(cfg), co.chunk_init_decoder_caches(cfg)
+    ph, hid, txt, unv, steps = [], [], [], None, []
+    for i in range(nchunks):
+        vp, _, vh, pc = co.chunk_picker_stream_predict(x[:, i * samples:(i + 1) * samples], pc, w, cfg)
+        if vp.shape[1] == 0:
+            continue
+        ph.append(vp); hid.append(vh)
+        f, _ = co.feature_pick(vh, vp, cfg["picker_num_classes"] - 1)
+        if f.shape[1] != 0:
+            vt, unv, dc = co.chunk_decoder_stream_predict(f, dc, w, cfg)
+            txt.append(vt)
+            steps.append((i, vt.shape[1]))
+    return np.concatenate(ph, 1), np.concatenate(hid, 1), np.concatenate(txt, 1), unv, pc, dc, steps

@@ -1024,18 +1024,6 @@ def _chunk_model(cfg, w):
     return m
 
 
-def _pick_bias_for_ragged_counts(cfg, w, x):
-    """choose the picker's blank bias so that roughly half of the frames are kept (ragged counts)."""
-    r = co.chunk_predict(x.astype(np.float64), w, cfg)
-    z = r["picker_logits"]
-    gap = np.sort(z[..., :-1].max(-1) - z[..., -1], axis=None)
-    # threshold in the middle of the widest gap between neighbouring frames around the median, so that no frame
-    # sits on the blank / non-blank decision boundary
-    lo, hi = gap.size // 2 - gap.size // 8, gap.size // 2 + gap.size // 8
-    k = lo + int(np.argmax(np.diff(gap[lo:hi + 1])))
-    return float(0.5 * (gap[k] + gap[k + 1]))
-
-
 @pytest.mark.parametrize("L", [24000, 50000])
 def test_chunk_conformer_predict_stage_parity(torch_cuda, L):
     cfg = dict(co.CHUNK_S, enc_num_blocks=2, decoder_num_classes=300)
@@ -1339,20 +1327,7 @@ def test_am_tester_metrics_match_oracle_pipeline(torch_cuda, tmp_path):
 # ---------------------------------------------------------------------------------------------------------
 # ChunkConformer streaming with explicit caches (chunk_conformer_blocks.py:799-866)
 # ---------------------------------------------------------------------------------------------------------
-def _stream_oracle(x, w, cfg, nchunks, samples):
-    pc, dc = co.chunk_init_picker_caches(cfg), co.chunk_init_decoder_caches(cfg)
-    ph, hid, txt, unv, steps = [], [], [], None, []
-    for i in range(nchunks):
-        vp, _, vh, pc = co.chunk_picker_stream_predict(x[:, i * samples:(i + 1) * samples], pc, w, cfg)
-        if vp.shape[1] == 0:
-            continue
-        ph.append(vp); hid.append(vh)
-        f, _ = co.feature_pick(vh, vp, cfg["picker_num_classes"] - 1)
-        if f.shape[1] != 0:
-            vt, unv, dc = co.chunk_decoder_stream_predict(f, dc, w, cfg)
-            txt.append(vt)
-            steps.append((i, vt.shape[1]))
-    return np.concatenate(ph, 1), np.concatenate(hid, 1), np.concatenate(txt, 1), unv, pc, dc, steps
+from helpers import pick_bias_for_ragged_counts as _pick_bias_for_ragged_counts, stream_oracle as _stream_oracle  # noqa: E402
 
 
 @pytest.mark.parametrize("samples,nchunks", [(2560, 30), (5120, 9)])

@@ -142,21 +142,48 @@ def test_oracle_leaf_vs_tf():
     exact(co.leaf_frontend(x.astype(np.float64), _leaf_weights_from(fx, "_f64")), fx, "out")
 
 
-def _chunk_case(fx):
+def _chunk_case(fx, L=None):
     cfg = dict(co.CHUNK_S, enc_num_blocks=2, picker_num_classes=30, decoder_num_classes=40)
     w = co.chunk_weights(cfg, seed=int(fx["weights_seed"]))
     if "freq2mel" in fx.files and fx["freq2mel"].ndim == 2:
         w["front/mel_layer/freq2mel"] = fx["freq2mel"]
-    return cfg, w, waves(2, int(fx["L"]), int(fx["wave_seed"]))
+    w["picker/fully_connected/bias"][-1] = fx["picker_blank_bias"]
+    return cfg, w, waves(2, int(fx["L"]) if L is None else L, int(fx["wave_seed"]))
 
 
 def test_oracle_chunk_predict_vs_tf():
+    """6 s utterances: 150 frames, the band mask cuts (win_front 36); about half of the frames are picked, ragged per utterance:
+    the oracle's feature_pick against the reference's tf.while_loop compaction (zero padding to the batch maximum included)"""
     fx = fixture("tf_chunk_predict.npz")
     cfg, w, x = _chunk_case(fx)
     r = co.chunk_predict(x.astype(np.float64), w, cfg)
-    for k in ("front", "enc", "picker_logits", "picker_hidden", "text_logits"):
+    assert fx["enc"].shape[1] == 150 and 20 < fx["picked"].shape[1] < 130 and r["counts"].min() < r["counts"].max()
+    for k in ("front", "enc", "picker_logits", "picker_hidden", "picked", "text_logits"):
         assert r[k].shape == fx[k].shape and maxdiff(r[k], fx[k]) < TOL, k
         exact(r[k], fx, k)
+
+
+def test_oracle_chunk_streaming_vs_tf():
+    """The reference's streaming entry points with explicit caches, 30 steps of 2560 samples: the oracle's restatement of the
+    stream_call chain (what the GPU streaming test compares libmi355asr.so with) against the reference's own -- every valid
+    output, which steps produced text, the look-ahead rows and the caches after the last step, digit for digit."""
+    from helpers import stream_oracle
+    fx = fixture("tf_chunk_stream.npz")
+    cfg, w, x = _chunk_case(fx, L=96000)
+    n, samples = int(fx["nchunks"]), int(fx["samples"])
+    ph, hid, txt, unv, pc, dc, steps = stream_oracle(x[:1, :n * samples].astype(np.float64), w, cfg, n, samples)
+    assert [list(s) for s in steps] == fx["steps"].tolist() and len(steps) >= 8
+    for k, got in (("picker_logits", ph), ("picker_hidden", hid), ("text_logits", txt), ("unvalid_text_logits", unv),
+                   ("cache_front_wav", pc["front_wav"][..., None]), ("cache_front_sub", pc["front_sub"][..., None]),
+                   ("cache_enc_mha", np.stack(pc["enc_mha"])), ("cache_enc_cnn", np.stack(pc["enc_cnn"])),
+                   ("cache_picker_mha", np.stack(pc["picker_mha"])), ("cache_picker_cnn", np.stack(pc["picker_cnn"])),
+                   ("cache_picker_dec_inp", pc["dec_inp"]), ("cache_helper_mha", np.stack(dc["helper_mha"])),
+                   ("cache_decoder_mha", np.stack(dc["decoder_mha"])), ("cache_decoder_cnn", np.stack(dc["decoder_cnn"])),
+                   ("cache_decoder_dec_inp", dc["dec_inp"])):
+        assert got.shape == fx[k].shape, (k, got.shape, fx[k].shape)
+        if got.size:
+            assert maxdiff(got, fx[k]) < TOL, k
+            exact(got, fx, k)
 
 
 def test_oracle_benched_batch_fixture_vs_the_reference_code_on_all_64_utterances():
@@ -273,8 +300,28 @@ def test_gpu_streaming_translator_wavepick_leaf_chunk_vs_tf():
     m = ChunkConformer(chunk_config_dict(ccfg), 30, 40)
     m.load_weights(wc, by_name=False)
     got = m.predict(xc, stages=True)
-    for k in ("front", "enc", "picker_logits", "picker_hidden", "text_logits"):
-        assert maxdiff(got[k].cpu().numpy(), fx[k]) < TOL, k
+    for k in ("front", "enc", "picker_logits", "picker_hidden", "picked", "text_logits"):
+        assert got[k].shape == fx[k].shape and maxdiff(got[k].cpu().numpy(), fx[k]) < TOL, k
+    # the streaming entry points against the reference's own, step by step (test_chunk_asr.py:60-83)
+    fs = fixture("tf_chunk_stream.npz")
+    n, samples = int(fs["nchunks"]), int(fs["samples"])
+    pc, dc = m.init_picker_caches(1), m.init_decoder_caches(1)
+    ph, txt, steps, unv = [], [], [], None
+    for i in range(n):
+        vp, _, vh, pc = m.picker_stream_predict(xc[:1, i * samples:(i + 1) * samples, None], pc)
+        if vp.shape[1] == 0:
+            continue
+        ph.append(vp)
+        f, _ = m.feature_pick(vh, vp)
+        if f.shape[1] != 0:
+            vt, unv, dc = m.decoder_stream_predict(f, dc)
+            txt.append(vt)
+            steps.append([i, int(vt.shape[1])])
+    import torch
+    assert steps == fs["steps"].tolist()
+    assert maxdiff(torch.cat(ph, 1).cpu().numpy(), fs["picker_logits"]) < TOL and maxdiff(torch.cat(txt, 1).cpu().numpy(), fs["text_logits"]) < TOL
+    assert maxdiff(unv.cpu().numpy(), fs["unvalid_text_logits"]) < TOL
+    assert maxdiff(pc[2].cpu().numpy(), fs["cache_enc_mha"]) < TOL and maxdiff(dc[2].cpu().numpy(), fs["cache_decoder_mha"]) < TOL
     fx = fixture("tf_leaf.npz")
     cfg1 = small_cfg(1)
     wl = {k: v for k, v in co.encoder_weights(cfg1, seed=7).items() if not k.startswith("mel_layer/")}

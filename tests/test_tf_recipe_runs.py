@@ -22,13 +22,16 @@ def test_committed_tf_fixtures_are_reproduced_by_the_recipe(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_tf_goldens.py")], capture_output=True, text=True, timeout=1200,
                        cwd=ROOT, env=dict(os.environ, MI355ASR_TF_GOLDEN_OUT=str(tmp_path)))
     assert r.returncode == 0, r.stderr[-3000:]
-    names = sorted(f for f in os.listdir(GOLDEN) if f.startswith("tf_") and f.endswith(".npz"))
-    assert names == sorted(os.listdir(tmp_path)) and len(names) == 9, (names, sorted(os.listdir(tmp_path)))
+    names = sorted(f for f in os.listdir(GOLDEN) if f.startswith("tf_") and f.endswith(".npz") and f != "tf_config2_b64.npz")
+    # (tf_config2_b64.npz has its own recipe, make_tf_config2_b64.py: test_tf_goldens.py re-runs two of its utterances)
+    assert names == sorted(os.listdir(tmp_path)) and len(names) == 10, (names, sorted(os.listdir(tmp_path)))
     for n in names:
         a, b = np.load(os.path.join(GOLDEN, n)), np.load(os.path.join(tmp_path, n))
         assert sorted(a.files) == sorted(b.files), n
         for k in a.files:
             assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, (n, k)
+            if a[k].size == 0:
+                continue
             if a[k].dtype.kind == "f":        # BLAS may sum in another order on another core count: last-digit slack only
                 tol = (1e-12 if a[k].dtype == np.float64 else 2e-6) * max(1.0, float(np.abs(a[k]).max()))
                 assert float(np.abs(a[k].astype(np.float64) - b[k]).max()) <= tol, (n, k)
