@@ -246,6 +246,7 @@ def extra_config3(lib, device, steps=20, with_cpu=True):
     # flops per step: encoder over 64 x 13 rows (frontend: 50 mel frames per chunk), CTCDecoder over 64 x 260 rows
     Me, Te, Mc, Tc = B * 13, 13, B * hist * 13, hist * 13
     fe = block_flops(Me, B, Te, d, 5, 4)
+    fe["enc_stack"] = sum(fe.values())       # round 5: the four blocks as one launch (stream256.hip)
     fe.update({"stft": 2.0 * B * 50 * (32 * 32 * 64 + 32 * 64 * 32), "subconv": 2.0 * B * 25 * 40 * d * 9 + 2.0 * Me * 20 * d * 9 * d,
                "sublinear": 2.0 * Me * 20 * d * d})
     fc = block_flops(Mc, B, Tc, d, 32, 1)

@@ -351,7 +351,8 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids_dev, const
 #define MI355ASR_K_OUT_GLU 16     /* out_glu_kernel       out-projection + residual + LN + pw_conv_1 + GLU (fused)    */
 #define MI355ASR_K_TAIL_FF2 17    /* tail_ff2_kernel      ConvModule tail + FFModule 2 + block LayerNorm (fused)      */
 #define MI355ASR_K_TAIL_FF1 18    /* tail_ff1_ld_kernel   tail_ff2 of block i + ff1_qkv of block i + 1 in one launch  */
-#define MI355ASR_NUM_KERNELS 19
+#define MI355ASR_K_ENC_STACK 19   /* stream256_kernel     every ConformerBlock of the streaming encoder, one workgroup per chunk (bf16 mode) */
+#define MI355ASR_NUM_KERNELS 20
 int mi355asr_profile_enable(mi355asr_model* m, int32_t on);
 /* Which arithmetic the LAST launch of each kernel category used (recorded whether or not timing is enabled; -1: the category
  * has not run on this handle).  Several kernels exist for most categories -- chosen by dmodel, row count, whether an operand

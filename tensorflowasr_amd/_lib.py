@@ -106,7 +106,7 @@ SIGNATURES = {
 }
 
 KERNEL_NAMES = ["stft", "utt_max", "mel", "subconv", "sublinear", "ffn", "qkv", "attention", "attn_out", "pw1_glu",
-                "dwconv", "conv_tail", "ctc_project", "ctc_head", "collapse", "ff1_qkv", "out_glu", "tail_ff2", "tail_ff1"]
+                "dwconv", "conv_tail", "ctc_project", "ctc_head", "collapse", "ff1_qkv", "out_glu", "tail_ff2", "tail_ff1", "enc_stack"]
 
 _lib = None
 

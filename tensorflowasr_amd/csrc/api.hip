@@ -1278,6 +1278,35 @@ int run_wavpick(const mi355asr_model* m, const float* wav, int Bp, int Lb, int T
   return conv(bufP, Tc + 6, cin, 7, 1, Tc, m->wp_fw, m->wp_fb, d, xa, xa);
 }
 
+// the encoder's block stack as stream256_kernel's arguments; false: not its shape (or a ring pack is missing, or switched off)
+bool stream256_args(const mi355asr_model* m, int B, int T, const float* x, float* y, S256Args& sa) {
+  static const bool on = [] { const char* v = getenv("MI355ASR_STREAM256"); return v ? atoi(v) != 0 : true; }();
+  const int nb = m->cfg.num_blocks;
+  if (!on || m->cfg.gemm_dtype != 1 || m->cfg.dmodel != 256 || m->cfg.num_heads != 4 || m->cfg.head_size != 64 || T < 1 || T > 16 ||
+      nb < 1 || nb > S256_MAXB || m->cfg.kernel_size < 1 || m->cfg.kernel_size > 32 || (int)m->enc_blocks.size() < nb)
+    return false;
+  auto ring = [&](const float* wp) -> const void* { const auto it = m->ring_of.find(wp); return it == m->ring_of.end() ? nullptr : it->second; };
+  sa.x = x; sa.y = y; sa.B = B; sa.T = T; sa.nblocks = nb; sa.ksz = m->cfg.kernel_size; sa.pad_left = (m->cfg.kernel_size - 1) / 2;
+  sa.fc = m->cfg.fc_factor; sa.qscale = 1.0f / std::sqrt((float)m->cfg.head_size); sa.eps = kLnEps;
+  for (int i = 0; i < nb; ++i) {
+    const BlockDev& w = m->enc_blocks[i];
+    S256Block& b = sa.blk[i];
+    for (int k = 0; k < 2; ++k) {
+      b.ff_ln_g[k] = w.ff_ln_g[k]; b.ff_ln_b[k] = w.ff_ln_b[k]; b.ff_b1[k] = w.ff_b1[k]; b.ff_b2[k] = w.ff_b2[k];
+      b.ff_w1[k] = ring(w.ff_w1p[k]); b.ff_w2[k] = ring(w.ff_w2p[k]);
+      if (!b.ff_w1[k] || !b.ff_w2[k]) return false;
+    }
+    b.att_ln_g = w.att_ln_g; b.att_ln_b = w.att_ln_b; b.qkv_b = w.qkv_b; b.out_b = w.out_b;
+    b.qkv_w = ring(w.qkv_wp); b.out_w = ring(w.out_wp);
+    b.cv_ln_g = w.cv_ln_g; b.cv_ln_b = w.cv_ln_b; b.pw1_b = w.pw1_b; b.dw_w = w.dw_w; b.pc_b1 = w.pc_b1; b.bn_s = w.bn_s; b.bn_t = w.bn_t;
+    b.pw2_b = w.pw2_b;
+    b.pw1_w = ring(w.pw1_wp); b.pc_w1 = ring(w.pc_w1p); b.pw2_w = ring(w.pw2_wp);
+    b.ln_g = w.ln_g; b.ln_b = w.ln_b;
+    if (!b.qkv_w || !b.out_w || !b.pw1_w || !b.pc_w1 || !b.pw2_w || w.xq_wp) return false;
+  }
+  return true;
+}
+
 int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const Plan& p, char* ws, float* enc_out,
                  hipStream_t s) {
   float* logp = (float*)(ws + p.logp);
@@ -1296,6 +1325,16 @@ int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const P
   if (m->cfg.add_wav_info) {
     rc = run_wavpick(m, wav, g.Bp, g.Lb, g.T, sc.xa, (float*)(ws + p.wv), s);
     if (rc) return rc;
+  }
+  // round 5: the streaming shapes (bf16 mode, dmodel 256, chunks of <= 16 rows): the whole block stack as ONE launch, one workgroup
+  // per chunk (stream256.hip) -- MI355ASR_STREAM256=0: one launch per layer / module as before
+  {
+    S256Args sa{};
+    if (stream256_args(m, g.Bp, g.T, sc.xa, enc_out, sa)) {
+      PROF(MI355ASR_K_ENC_STACK);
+      LAUNCH_TRY(launch_stream256(sa, s), "encoder block stack");
+      return 0;
+    }
   }
   bool ff1_done = false;
   for (int i = 0; i < nb; ++i) {

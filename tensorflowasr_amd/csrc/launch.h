@@ -269,6 +269,26 @@ struct Gemm16Args {
 int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s);
 int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s);   // bf16.hip: dmodel 256, bf16 mode, FFModule / conv tail in one launch
 int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s);   // wp = fp32 P16 weights
+// stream256.hip (round 5): the whole block stack of the streaming encoder (bf16 mode, dmodel 256 = 4 heads x 64, chunks of <= 16
+// rows) in ONE launch, one workgroup per chunk.  Matrices: the one-term slab-ring packs (api.hip: put_ring); vectors: f32
+struct S256Block {
+  const float *ff_ln_g[2], *ff_ln_b[2], *ff_b1[2], *ff_b2[2];
+  const void *ff_w1[2], *ff_w2[2];
+  const float *att_ln_g, *att_ln_b, *qkv_b, *out_b;
+  const void *qkv_w, *out_w;
+  const float *cv_ln_g, *cv_ln_b, *pw1_b, *dw_w, *pc_b1, *bn_s, *bn_t, *pw2_b;
+  const void *pw1_w, *pc_w1, *pw2_w;
+  const float *ln_g, *ln_b;
+};
+constexpr int S256_MAXB = 8;
+struct S256Args {
+  const float* x;      // [B * T, 256] block-stack input rows (chunk b = rows b T .. b T + T - 1)
+  float* y;            // [B * T, 256]
+  int B, T, nblocks, ksz, pad_left;
+  float fc, qscale, eps;
+  S256Block blk[S256_MAXB];
+};
+int launch_stream256(const S256Args& a, hipStream_t s);   // -1: not this kernel's shape
 int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // gemm_ring.hip: the same contract on the bf16 pipe with exactly split fp32 operands, weights as a slab ring
 // [N / 128 chunks][K / 32 steps][8 tiles][3 terms (1 in bf16 mode)][64 lanes][8 bf16] (api.hip: put_ring); -1: shape not taken

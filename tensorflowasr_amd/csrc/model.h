@@ -179,8 +179,8 @@ struct mi355asr_model {
   mutable std::vector<Pending> ev_pending;
   mutable double prof_ms[MI355ASR_NUM_KERNELS] = {0};
   mutable int64_t prof_cnt[MI355ASR_NUM_KERNELS] = {0};
-  mutable int prof_scheme[MI355ASR_NUM_KERNELS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // OperandScheme of the last launch
-  static_assert(MI355ASR_NUM_KERNELS == 19, "one initialiser per kernel category");
+  mutable int prof_scheme[MI355ASR_NUM_KERNELS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // OperandScheme of the last launch
+  static_assert(MI355ASR_NUM_KERNELS == 20, "one initialiser per kernel category");
   hipEvent_t get_event() const {
     if (!ev_free.empty()) { hipEvent_t e = ev_free.back(); ev_free.pop_back(); return e; }
     hipEvent_t e = nullptr;

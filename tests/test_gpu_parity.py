@@ -1815,6 +1815,66 @@ print("RESULT %.3e %.3e %.3e" % (e.max(), e.mean(), np.abs(got - exact).max()))
         assert emax < 6e-3 and emean < 3e-4 and vs_exact > 10 * emean, (extra, emax, emean, vs_exact)
 
 
+def test_streaming_block_stack_in_one_launch_vs_layer_at_a_time_and_rounding_oracle(torch_cuda):
+    """Round 5 (stream256.hip): in bf16 mode the streaming encoder's whole block stack -- 4 ConformerBlocks, dmodel 256, chunks of
+    13 rows -- is ONE launch, one workgroup per chunk (weights streamed from L2, the residual rows in registers, attention and
+    depthwise conv from LDS).  Against the oracle with both GEMM operands rounded to bf16 it must meet the bounds the layer-at-a-time
+    path is held to (same operands, another summation order along K: a hidden value on a rounding boundary may fall the other
+    way); the same model with MI355ASR_STREAM256=0 is run beside it (both in subprocesses: the switch is read once), and the
+    profile counters say which kernels ran.  Chunks of 8000 samples (13 rows) and of 4000 (7 rows: more padding rows in the tile)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, ctypes, numpy as np
+sys.path.insert(0, "tests")
+from helpers import co, waves
+from tensorflowasr_amd import _lib
+from tensorflowasr_amd.models import StreamingConformerEncoder
+cfg = dict(co.STREAMING_S)
+w = co.encoder_weights(cfg, seed=61)
+lib = _lib.lib()
+for chunk, nchunks in ((8000, 20), (4000, 6)):
+    enc = StreamingConformerEncoder(dmodel=256, reduction_factor=4, num_blocks=4, head_size=64, num_heads=4, kernel_size=5, fc_factor=0.5,
+                                    sample_rate=16000, n_mels=80, stride_ms=10, mel_layer_type="Melspectrogram", gemm_dtype="bfloat16")
+    enc.add_chunk_size(chunk, 80, 640)
+    enc.load_weights(w, by_name=False)
+    x = waves(nchunks, chunk, 500)
+    _lib.check(lib.mi355asr_profile_enable(enc._h.ptr, 1))
+    got = enc(x).cpu().numpy()
+    nk = len(_lib.KERNEL_NAMES)
+    ms, cnt = (ctypes.c_double * nk)(), (ctypes.c_int64 * nk)()
+    _lib.check(lib.mi355asr_profile_read(enc._h.ptr, ms, cnt, nk, 1))
+    launches = {n: int(cnt[i]) for i, n in enumerate(_lib.KERNEL_NAMES) if cnt[i]}
+    co.GEMM_ROUND_BF16 = True
+    ref = co.streaming_conformer_encoder(x.astype(np.float64), w, cfg, chunk)
+    co.GEMM_ROUND_BF16 = False
+    e = np.abs(got - ref)
+    np.save(sys.argv[1] + "_%d.npy" % chunk, got)
+    print("RESULT %d %d %.3e %.3e %d %d" % (chunk, got.shape[1], e.max(), e.mean(), launches.get("enc_stack", 0), launches.get("ffn", 0)))
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, extra in (("stack", {}), ("layers", {"MI355ASR_STREAM256": "0"})):
+            out = subprocess.run([sys.executable, "-c", code, os.path.join(td, tag)], env=dict(os.environ, **extra), capture_output=True, text=True,
+                                 timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            lines = [ln.split()[1:] for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+            assert len(lines) == 2, out.stderr[-3000:]
+            for chunk, rows, emax, emean, n_stack, n_ffn in lines:
+                res[tag, int(chunk)] = (int(rows), float(emax), float(emean), int(n_stack), int(n_ffn))
+        for chunk, rows in ((8000, 13), (4000, 7)):
+            s_rows, s_max, s_mean, s_stack, s_ffn = res["stack", chunk]
+            l_rows, l_max, l_mean, l_stack, l_ffn = res["layers", chunk]
+            assert s_rows == l_rows == rows
+            assert (s_stack, s_ffn) == (1, 0) and (l_stack, l_ffn) == (0, 8), (res["stack", chunk], res["layers", chunk])
+            a, b = np.load(os.path.join(td, "stack_%d.npy" % chunk)), np.load(os.path.join(td, "layers_%d.npy" % chunk))
+            d = np.abs(a - b)
+            print("chunk %d (%d rows): one launch vs rounding oracle max %.3g mean %.3g; layer at a time %.3g / %.3g; apart max %.3g mean %.3g"
+                  % (chunk, rows, s_max, s_mean, l_max, l_mean, d.max(), d.mean()))
+            assert s_max < 2e-2 and s_mean < 2e-3 and l_max < 2e-2 and l_mean < 2e-3
+            assert s_mean < 2 * l_mean + 1e-5 and d.max() < 4e-2 and d.mean() < 2e-3
+
+
 def test_translator_dmodel_512(torch_cuda):
     """conformerL.yml Translator (dmodel 512, 8 heads x 64): cross-attention through the layer-at-a-time GEMM path."""
     from tensorflowasr_amd.models import Translator
