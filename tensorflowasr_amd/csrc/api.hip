@@ -1283,7 +1283,7 @@ bool stream256_args(const mi355asr_model* m, int B, int T, const float* x, float
   static const bool on = [] { const char* v = getenv("MI355ASR_STREAM256"); return v ? atoi(v) != 0 : true; }();
   const int nb = m->cfg.num_blocks;
   if (!on || m->cfg.gemm_dtype != 1 || m->cfg.dmodel != 256 || m->cfg.num_heads != 4 || m->cfg.head_size != 64 || T < 1 || T > 16 ||
-      nb < 1 || nb > S256_MAXB || m->cfg.kernel_size < 1 || m->cfg.kernel_size > 32 || (int)m->enc_blocks.size() < nb)
+      nb < 1 || nb > S256_MAXB || m->cfg.kernel_size != 5 || (int)m->enc_blocks.size() < nb)      // (kernel_size: the depthwise taps live in registers, Streaming_ConformerS.yml's 5 is instantiated)
     return false;
   auto ring = [&](const float* wp) -> const void* { const auto it = m->ring_of.find(wp); return it == m->ring_of.end() ? nullptr : it->second; };
   sa.x = x; sa.y = y; sa.B = B; sa.T = T; sa.nblocks = nb; sa.ksz = m->cfg.kernel_size; sa.pad_left = (m->cfg.kernel_size - 1) / 2;

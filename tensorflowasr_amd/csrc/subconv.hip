@@ -601,7 +601,7 @@ DEV void frags_ninth_mm(SplitFrag (&xf)[RTN], const SL& sl, C1Taps& tp, const fl
 template <int DIAG, int DM, int NBW, int TM = 3, int RTN = SRT, bool C1M = false>
 __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs a, PatchGeom RS, int rows) {
   static_assert(DIAG == 0 || RTN == SRT, "the timing variants run two row tiles per wave");
-  static_assert(!C1M || (TM == 2 && DM == 144), "conv1 on the matrix pipe: the two-term kernel of dmodel 144");
+  static_assert(!C1M || (TM == 2 && (DM == 144 || DM == 256)), "conv1 on the matrix pipe: the two-term kernels of dmodel 144 / 256");
   constexpr int KB = DM / 16, NB = NBW, NI = ninth_steps(KB), NK32 = KB * NPAIR + NI, SLABF = NBW * TM * 64, D = DM;
   const int c0 = blockIdx.z * NBW;               // first output column tile of this workgroup
   __shared__ __attribute__((aligned(16))) u32x4 wl[SRING][SLABF];      // the slab ring: slab s in slot s % SRING
@@ -892,6 +892,9 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
           }
           frags_this(GI);
         });
+        // five pieces per operand (two row tiles); eight column tiles are four fragment groups: the rest behind the last group
+        constexpr int NGR = NB / (NB % 2 == 0 ? 2 : 1);
+        if constexpr (NGR < 5) static_for<NGR, 5>([&](auto GI) { frags_this(GI); });
         __builtin_amdgcn_sched_barrier(0);
         frags_next();
       } else if constexpr (LATE) {
@@ -1023,11 +1026,14 @@ static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGe
   if constexpr (DIAG == 0) {
     // conv1 on the matrix pipe (see C1M): dmodel 144, two-term weights, a mel scale (static or run-time), patch rows of <= 96 bins
     static const bool c1m_env = [] { const char* v = getenv("MI355ASR_SUBCONV_C1M"); return v ? atoi(v) != 0 : true; }();
-    const bool c1m = c1m_env && a.w2h && d == 144 && a.c1_wscale > 0.f && (a.c1_mscale > 0.f || a.h_melmax) && 4 * a.F2 + 4 <= C1_ROWB / 2 &&
+    const bool c1m = c1m_env && a.w2h && (d == 144 || d == 256) && a.c1_wscale > 0.f && (a.c1_mscale > 0.f || a.h_melmax) && 4 * a.F2 + 4 <= C1_ROWB / 2 &&
                      (size_t)(2 * rows + C1_ZERO_ROWS) * C1_ROWB <= sizeof(float) * MELP;
     if (c1m) {
       note_scheme(SCHEME_F16X2);
-      if (rtn == 1) hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2, 1, true>), g144, dim3(SCT), 0, s, a, RS, rows);
+      if (d == 256) {      // (round 5, the streaming configuration: two 128-channel chunks on grid.z, conv1 evaluated by both)
+        if (rtn == 1) hipLaunchKernelGGL((subconv_split_ring_kernel<0, 256, 8, 2, 1, true>), g128, dim3(SCT), 0, s, a, RS, rows);
+        else hipLaunchKernelGGL((subconv_split_ring_kernel<0, 256, 8, 2, SRT, true>), g128, dim3(SCT), 0, s, a, RS, rows);
+      } else if (rtn == 1) hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2, 1, true>), g144, dim3(SCT), 0, s, a, RS, rows);
       else hipLaunchKernelGGL((subconv_split_ring_kernel<0, 144, 9, 2, SRT, true>), g144, dim3(SCT), 0, s, a, RS, rows);
       return 0;
     }

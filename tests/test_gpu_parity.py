@@ -456,7 +456,7 @@ np.savez(sys.argv[1], **out)
 
 
 def test_subsampling_conv1_on_the_matrix_pipe_against_the_valu_evaluation(torch_cuda):
-    """Round 5: in the two-term subsampling conv of dmodel 144 conv1 itself runs on the matrix pipe -- the mel patch staged as fp16
+    """Round 5: in the two-term subsampling conv of dmodel 144 (and 256: the streaming configuration) conv1 itself runs on the matrix pipe -- the mel patch staged as fp16
     hi + lo planes, three MFMAs per (row tile, tap) -- instead of 36 fp32 multiply-adds per value on the VALU.  It is then a
     two-term product (2^-22 of its operand bounds) like conv2: against MI355ASR_SUBCONV_C1M=0 (exact fp32 conv1) and against the
     oracle on the encoder's own features (offline 'same' frontend: static mel bound) and on the chunk front (run-time bound per
@@ -479,6 +479,11 @@ x = waves(6, 160000, 12)
 x[1] *= np.float32(1e-3)
 x[2, 40000:] = 0.0
 out["sub"] = e(x).cpu().numpy()                      # one block behind the subsampling: its error travels with the features
+cfgm = small_cfg(1, co.CONFORMER_M)                  # dmodel 256: two 128-channel chunks on grid.z, both evaluate conv1
+em = ConformerEncoder(**encoder_kwargs(cfgm))
+em.load_weights(co.encoder_weights(cfgm, seed=92), by_name=False)
+out["subM"] = em(x).cpu().numpy()[:3]            # six utterances: two row tiles per wave (three alone: one, see launch_subconv_split)
+out["subM1"] = em(x[:3]).cpu().numpy()
 c5 = dict(co.CHUNK_S, enc_num_blocks=1, picker_num_blocks=1, helper_num_blocks=1, decoder_num_blocks=1)
 w5 = co.chunk_weights(c5, seed=6)
 mc = ChunkConformer(chunk_config_dict(c5), c5["picker_num_classes"], c5["decoder_num_classes"])
@@ -502,13 +507,16 @@ np.savez(sys.argv[1], **out)
     x[1] *= np.float32(1e-3)
     x[2, 40000:] = 0.0
     ref_enc = co.conformer_encoder(x[:3].astype(np.float64), w, cfg)
+    cfgm = small_cfg(1, co.CONFORMER_M)
+    ref_encm = co.conformer_encoder(x[:3].astype(np.float64), co.encoder_weights(cfgm, seed=92), cfgm)
     c5 = dict(co.CHUNK_S, enc_num_blocks=1, picker_num_blocks=1, helper_num_blocks=1, decoder_num_blocks=1)
     w5 = co.chunk_weights(c5, seed=6)
     xc = waves(3, 48000, 75)
     xc[0] *= np.float32(30.0)
     xc[1] *= np.float32(1e-3)
     ref_front = co.chunk_predict(xc.astype(np.float64), w5, c5)["front"]
-    for key, ref, got in (("sub", ref_enc, lambda r: r["sub"][:3]), ("front", ref_front, lambda r: r["front"])):
+    for key, ref, got in (("sub", ref_enc, lambda r: r["sub"][:3]), ("subM", ref_encm, lambda r: r["subM"]), ("subM1", ref_encm, lambda r: r["subM1"]),
+                          ("front", ref_front, lambda r: r["front"])):
         scale = max(1.0, float(np.abs(ref).max()))
         e_mm, e_va = maxdiff(got(res["mm"]), ref), maxdiff(got(res["valu"]), ref)
         apart = maxdiff(got(res["mm"]), got(res["valu"]))
