@@ -910,7 +910,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     };
     auto qkv_head_major = [&](const BlockDev& bw) {
       static const bool on = [] { const char* v = getenv("MI355ASR_QKV_HEAD_MAJOR"); return v ? atoi(v) != 0 : true; }();
-      return on && pp_enabled() && bw.pp_ff1 && attention_takes_head_major(hs, attn_args(bw, true));
+      return on && ff1_qkv_pp_selected(bw.ff1_slabs != nullptr, bw.pp_ff1 != nullptr) && attention_takes_head_major(hs, attn_args(bw, true));
     };
     auto ff1_args = [&](const BlockDev& bw, const float* x0, float* x1) {
       Ff1QkvArgs k1{};

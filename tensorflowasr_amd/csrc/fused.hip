@@ -1206,6 +1206,11 @@ bool ff1_pre_selected() {
   static const bool ring = env_on("MI355ASR_FF1QKV_RING");
   return ring && pp_pre_fold_ok();
 }
+// launch_ff1_qkv / launch_tail_ff1 will produce q, k, v with the pair-pipelined kernel (the only producer of the head-major layout)
+bool ff1_qkv_pp_selected(bool has_slabs, bool has_pp) {
+  static const bool ring = env_on("MI355ASR_FF1QKV_RING");
+  return ring && has_slabs && has_pp && pp_enabled();
+}
 // tail of one block + ff1_qkv of the next in one launch; -1 when the loader-wave kernels are switched off
 bool tail_ff1_available() {
   // MI355ASR_TAIL_FF1=0: separate tail_ff2 / ff1_qkv launches (also whenever one of the two is switched to the fp32 kernels)

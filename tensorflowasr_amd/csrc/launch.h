@@ -369,6 +369,7 @@ bool pp_dw_fold_ok(int T, int ksz);   // the tail kernels can take the depthwise
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
+bool ff1_qkv_pp_selected(bool has_slabs, bool has_pp);   // fused.hip: q, k, v will come from the pair-pipelined producer (head-major layout possible)
 bool ff1_pre_selected();             // ... and launch_ff1_qkv will take that kernel (fused.hip) when the block has its streams
 bool pp_pre_fold_ok();
 bool pp_head_fold_ok(int M, int n_valid, int groups);   // the class head rides in the last block's tail launch (MI355ASR_PP_HEADF=0: own launch)               // the layer in front of a block rides in its ff_module_1 + qkv launch (MI355ASR_PP_PRE=0: own launch)

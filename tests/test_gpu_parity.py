@@ -2070,7 +2070,7 @@ print("RESULT %.3e %.3e" % (blk, enc))
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                              cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
-        assert line, out.stderr[-2000:]
+        assert line, (extra, out.stderr[-2000:])
         blk, enc = (float(v) for v in line[0].split()[1:])
         assert blk < TOL and enc < TOL, (extra, blk, enc)
 

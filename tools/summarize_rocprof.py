@@ -25,7 +25,7 @@ CATEGORY = [
     ("stft_kernel", "stft"), ("fft_stft_split_kernel", "stft"), ("attention_lds_kernel", "attention"), ("attention_split_kernel", "attention"), ("subconv144_kernel", "subconv"), ("subconv144_split_kernel", "subconv"), ("leaf_conv_pool", "stft"), ("leaf_gather", "mel"), ("leaf_pcen", "mel"), ("utt_max_kernel", "utt_max"), ("mel_kernel", "mel"), ("mel_band_kernel", "mel"), ("db_norm_kernel", "mel"), ("subconv_kernel", "subconv"),
     ("stream_gemm_kernel", "sublinear"), ("attention_kernel", "attention"), ("dwconv_kernel", "dwconv"), ("dwconv_tile_kernel", "dwconv"),
     ("collapse_kernel", "collapse"), ("ff1_qkv_kernel", "ff1_qkv"), ("out_glu_kernel", "out_glu"),
-    ("tail_ff2_kernel", "tail_ff2"), ("tail_ff1_ld_kernel", "tail_ff1"), ("tail_ff2_ld_kernel", "tail_ff2"), ("ff1_qkv_ld_kernel", "ff1_qkv"), ("out_glu_ld_kernel", "out_glu"), ("pp_out_glu_kernel", "out_glu"), ("pp_head_kernel", "ctc_head"), ("topn_reg_kernel", "topn"), ("tail_ff2_ring_kernel", "tail_ff2"), ("ff1_qkv_ring_kernel", "ff1_qkv"), ("out_glu_ring_kernel", "out_glu"), ("out_glu_split_kernel", "out_glu"), ("pp_sublinear_kernel", "sublinear"), ("sublinear_split_kernel", "sublinear"), ("sublinear_split_ld_kernel", "sublinear"), ("refmath_eval_kernel", "refmath"), ("topn_kernel", "topn"), ("head_ld_kernel", "ctc_head"), ("pick_kernel", "pick"), ("gather_kernel", "gather"),
+    ("tail_ff2_kernel", "tail_ff2"), ("tail_ff1_ld_kernel", "tail_ff1"), ("tail_ff2_ld_kernel", "tail_ff2"), ("ff1_qkv_ld_kernel", "ff1_qkv"), ("out_glu_ld_kernel", "out_glu"), ("pp_out_glu_kernel", "out_glu"), ("pp_head_kernel", "ctc_head"), ("topn_reg_kernel", "topn"), ("tail_ff2_ring_kernel", "tail_ff2"), ("ff1_qkv_ring_kernel", "ff1_qkv"), ("out_glu_ring_kernel", "out_glu"), ("out_glu_split_kernel", "out_glu"), ("pp_sublinear_kernel", "sublinear"), ("sublinear_split_kernel", "sublinear"), ("sublinear_split_ld_kernel", "sublinear"), ("refmath_eval_kernel", "refmath"), ("topn_kernel", "topn"), ("head_ld_kernel", "ctc_head"), ("pick_kernel", "pick"), ("gather_kernel", "gather"), ("stream256_kernel", "enc_stack"),
 ]
 
 
