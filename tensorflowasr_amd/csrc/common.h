@@ -95,6 +95,11 @@ DEV void stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 DEV f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
 
 // sum / max over the 4 lane groups that share a token (lanes t, t+16, t+32, t+48)
+// (Round 5 measured gfx950's v_permlane16_swap_b32 / v_permlane32_swap_b32 here -- handed the same value twice they return, in every
+// lane, the pair a __shfl_xor(v, 16) / (v, 32) butterfly combines, on the VALU instead of an LDS round trip; the primitive is bit for
+// bit the butterfly (tools/ubench/group_reduce_cmp.hip), a tail_ff1 launch 1.3 us shorter by events, the step 0.15 % on the clock,
+// and hipcc contracts the surrounding arithmetic of the pair-pipelined kernels differently, so the library's outputs move in the
+// last bit: not kept.  One trap on the way: __builtin_bit_cast(float, r.y) on the ELEMENT of the returned vector reads element 0.)
 DEV float group_sum(float v) {
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);

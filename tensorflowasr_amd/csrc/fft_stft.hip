@@ -239,14 +239,37 @@ DEV float recip_pow2(float s) { return __builtin_bit_cast(float, 0x7f000000u - _
 DEV float max8(f32x4 a, f32x4 b) {
   return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
 }
+// reductions over the sixteen lanes of a row on the VALU (DPP row_ror): a __shfl_xor is a ds_bpermute, an LDS round trip in a
+// dependent chain -- eighteen of them per frame were ~2000 of the ~8800 cycles a wave spends on a frame
+template <int N> DEV float dpp_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+DEV float row_sum16(float v) { v += dpp_ror<8>(v); v += dpp_ror<4>(v); v += dpp_ror<2>(v); v += dpp_ror<1>(v); return v; }
+DEV float row_max16(float v) {
+  v = fmaxf(v, dpp_ror<8>(v)); v = fmaxf(v, dpp_ror<4>(v)); v = fmaxf(v, dpp_ror<2>(v)); return fmaxf(v, dpp_ror<1>(v));
+}
 DEV float col_max(float m) {                  // over the four lanes of a column
-  m = fmaxf(m, __shfl_xor(m, 16));
-  return fmaxf(m, __shfl_xor(m, 32));
+  return group_max(m);
 }
 
+#ifndef MI355ASR_STFT_DIAG
+#define MI355ASR_STFT_DIAG 0
+#endif
+// timing experiments (tools/build_variant.py ... -DMI355ASR_STFT_DIAG=n; WRONG results): bit 0 = no sample loads, 1 = no spectrum
+// stores (the per-frame maximum stays), 2 = no MFMAs of stage 2, 3 = no log
+constexpr int FDG = MI355ASR_STFT_DIAG;
+#ifndef MI355ASR_STFT_TABS_LDS
+#define MI355ASR_STFT_TABS_LDS 1
+#endif
+// round 5: window and twiddles (48 registers) live in LDS instead, read per frame: 190 -> <= 168 registers, three waves per SIMD
+// instead of two -- a frame is a serial chain (samples -> split -> 24 MFMAs -> twiddle -> LDS transpose -> split -> 24 MFMAs ->
+// log -> store) and the other waves of the SIMD are what fills its gaps (two-term kernel; MI355ASR_STFT_TABS_LDS=0 at build time:
+// in registers as before)
 template <int TM>
-__global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStftArgs a) {
+__global__ __launch_bounds__(BLOCK_THREADS, (TM == 2 && MI355ASR_STFT_TABS_LDS) ? 3 : 2) void fft_stft_split_kernel(FftStftArgs a) {
+  constexpr bool TL = TM == 2 && MI355ASR_STFT_TABS_LDS;
   __shared__ float lds[WAVES_PER_BLOCK][2][32 * LDW];
+  __shared__ __attribute__((aligned(16))) f32x4 tabs[TL ? 12 : 1][TL ? 64 : 1];     // [rt][kb] x (window, cos, sin), one row per lane
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, g4 = g * 4, c = lane & 15;
   const int wave = threadIdx.x >> 6;
@@ -270,22 +293,33 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int t = 0; t < TM; ++t) w2[st][nt][t] = w2p[((st * 2 + nt) * TM + t) * 64];
-  f32x4 hw[2][2], twc[2][2], tws[2][2];
+  f32x4 hw[TL ? 1 : 2][TL ? 1 : 2], twc[TL ? 1 : 2][TL ? 1 : 2], tws[TL ? 1 : 2][TL ? 1 : 2];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     const int n2 = 16 * rt + c;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      hw[rt][kb].x = a.window[32 * (16 * kb + g4 + 0) + n2];
-      hw[rt][kb].y = a.window[32 * (16 * kb + g4 + 1) + n2];
-      hw[rt][kb].z = a.window[32 * (16 * kb + g4 + 2) + n2];
-      hw[rt][kb].w = a.window[32 * (16 * kb + g4 + 3) + n2];
-      twc[rt][kb].x = a.tw_c[(16 * kb + g4 + 0) * 32 + n2]; tws[rt][kb].x = a.tw_s[(16 * kb + g4 + 0) * 32 + n2];
-      twc[rt][kb].y = a.tw_c[(16 * kb + g4 + 1) * 32 + n2]; tws[rt][kb].y = a.tw_s[(16 * kb + g4 + 1) * 32 + n2];
-      twc[rt][kb].z = a.tw_c[(16 * kb + g4 + 2) * 32 + n2]; tws[rt][kb].z = a.tw_s[(16 * kb + g4 + 2) * 32 + n2];
-      twc[rt][kb].w = a.tw_c[(16 * kb + g4 + 3) * 32 + n2]; tws[rt][kb].w = a.tw_s[(16 * kb + g4 + 3) * 32 + n2];
+      f32x4 h_, c_, s_;
+      h_.x = a.window[32 * (16 * kb + g4 + 0) + n2];
+      h_.y = a.window[32 * (16 * kb + g4 + 1) + n2];
+      h_.z = a.window[32 * (16 * kb + g4 + 2) + n2];
+      h_.w = a.window[32 * (16 * kb + g4 + 3) + n2];
+      c_.x = a.tw_c[(16 * kb + g4 + 0) * 32 + n2]; s_.x = a.tw_s[(16 * kb + g4 + 0) * 32 + n2];
+      c_.y = a.tw_c[(16 * kb + g4 + 1) * 32 + n2]; s_.y = a.tw_s[(16 * kb + g4 + 1) * 32 + n2];
+      c_.z = a.tw_c[(16 * kb + g4 + 2) * 32 + n2]; s_.z = a.tw_s[(16 * kb + g4 + 2) * 32 + n2];
+      c_.w = a.tw_c[(16 * kb + g4 + 3) * 32 + n2]; s_.w = a.tw_s[(16 * kb + g4 + 3) * 32 + n2];
+      if constexpr (TL) {
+        if (wave == 0) { tabs[(2 * rt + kb) * 3 + 0][lane] = h_; tabs[(2 * rt + kb) * 3 + 1][lane] = c_; tabs[(2 * rt + kb) * 3 + 2][lane] = s_; }
+      } else {
+        hw[rt][kb] = h_; twc[rt][kb] = c_; tws[rt][kb] = s_;
+      }
     }
   }
+  if constexpr (TL) __syncthreads();
+  auto tab = [&](int rt, int kb, int which) -> f32x4 {
+    if constexpr (TL) return tabs[(2 * rt + kb) * 3 + which][lane];
+    else return which == 0 ? hw[rt][kb] : (which == 1 ? twc[rt][kb] : tws[rt][kb]);
+  };
   const int L = a.L;
   // acc += W^T x over the six term pairs, smallest first, for NT tiles and two row tiles: MFMAs on one accumulator 2 NT apart
   auto mma6 = [&](auto& acc, const auto& w, const Split8 (&x)[2], auto NT_T) {
@@ -318,9 +352,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
         const bool o0 = (unsigned)(s0) < (unsigned)L, o1 = (unsigned)(s0 + 32) < (unsigned)L;
         const bool o2 = (unsigned)(s0 + 64) < (unsigned)L, o3 = (unsigned)(s0 + 96) < (unsigned)L;
         f32x4 v;
-        v.x = wav[o0 ? s0 : 0]; v.y = wav[o1 ? s0 + 32 : 0]; v.z = wav[o2 ? s0 + 64 : 0]; v.w = wav[o3 ? s0 + 96 : 0];
+        if constexpr (FDG & 1) v = f32x4{(float)(s0 & 7), (float)(s0 & 3), 1.f, (float)c};
+        else { v.x = wav[o0 ? s0 : 0]; v.y = wav[o1 ? s0 + 32 : 0]; v.z = wav[o2 ? s0 + 64 : 0]; v.w = wav[o3 ? s0 + 96 : 0]; }
         v.x = o0 ? v.x : 0.f; v.y = o1 ? v.y : 0.f; v.z = o2 ? v.z : 0.f; v.w = o3 ? v.w : 0.f;
-        xf[kb] = v * hw[rt][kb];
+        xf[kb] = v * tab(rt, kb, 0);
       }
       if constexpr (TM == 2) {
         const float sx = pow2_scale(col_max(max8(xf[0], xf[1])));
@@ -346,8 +381,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
     }
     // ---- bin 512: sum_n2 (-1)^n2 A_re[0][n2]   (A_re[0][n2] sits in lanes g == 0, tile 0, reg 0)
     float nyq = (g == 0) ? ((c & 1) ? -1.f : 1.f) * (acc1[0][0].x + acc1[1][0].x) : 0.f;
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) nyq += __shfl_xor(nyq, off);
+    nyq = row_sum16(nyq);
     // ---- twiddle + transpose through wave-private LDS: L[k1][n2]
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -355,8 +389,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
 #pragma unroll
       for (int nr = 0; nr < 2; ++nr) {
         const f32x4 are = acc1[rt][nr], aim = acc1[rt][2 + nr];
-        const f32x4 bre = are * twc[rt][nr] + aim * tws[rt][nr];
-        const f32x4 bim = aim * twc[rt][nr] - are * tws[rt][nr];
+        const f32x4 tc = tab(rt, nr, 1), ts = tab(rt, nr, 2);
+        const f32x4 bre = are * tc + aim * ts;
+        const f32x4 bim = aim * tc - are * ts;
         const int k1 = 16 * nr + g4;
         Lre[(k1 + 0) * LDW + n2] = bre.x; Lre[(k1 + 1) * LDW + n2] = bre.y;
         Lre[(k1 + 2) * LDW + n2] = bre.z; Lre[(k1 + 3) * LDW + n2] = bre.w;
@@ -422,8 +457,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
       const float pv[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float l = __log2f(fmaxf(pv[j], 1e-10f)) * kscale;
-        orow[16 * rt + c + 32 * (g4 + j)] = l;
+        const float l = (FDG & 8) ? pv[j] : __log2f(fmaxf(pv[j], 1e-10f)) * kscale;
+        if constexpr (!(FDG & 2)) orow[16 * rt + c + 32 * (g4 + j)] = l;
         mx = fmaxf(mx, l);
       }
     }
@@ -432,8 +467,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void fft_stft_split_kernel(FftStf
       orow[512] = l;
       mx = fmaxf(mx, l);
     }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    mx = col_max(row_max16(mx));
     if (lane == 0) a.pmax[fidx] = mx;
   }
 }
@@ -451,7 +485,9 @@ int launch_fft_stft(const FftStftArgs& a, hipStream_t s) {
   static const bool three = [] { const char* v = getenv("MI355ASR_FFT_TERMS"); return v && atoi(v) == 3; }();
   if (split && a.w1h && a.w2h && !three) {
     note_scheme(SCHEME_F16X2);
-    hipLaunchKernelGGL(fft_stft_split_kernel<2>, dim3((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
+    // three workgroups per CU are resident (see MI355ASR_STFT_TABS_LDS): one round of 768 workgroups, every wave loops over its frames
+    const int waves2 = MI355ASR_STFT_TABS_LDS ? std::min(total, 3072) : waves;
+    hipLaunchKernelGGL(fft_stft_split_kernel<2>, dim3((waves2 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK_THREADS), 0, s, a);
     return 0;
   }
   if (split && a.w1s && a.w2s) {

@@ -394,9 +394,7 @@ DEV float pp_row_max(const f32x4 (&xs)[KB]) {
 #pragma unroll
   for (int i = 0; i < KB; ++i)
     m = fmaxf(fmaxf(m, fmaxf(fabsf(xs[i].x), fabsf(xs[i].y))), fmaxf(fabsf(xs[i].z), fabsf(xs[i].w)));
-  m = fmaxf(m, __shfl_xor(m, 16));
-  m = fmaxf(m, __shfl_xor(m, 32));
-  return m;
+  return group_max(m);
 }
 // scales of one chain y += W2 act(W1aug [x ; 1]) for this lane's token (ChainSc: the chain's host-side constants)
 struct PpTok { float sx, k1, ik2, s2, inv2; };
