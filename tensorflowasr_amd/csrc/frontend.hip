@@ -170,9 +170,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) void mel_kernel(MelArgs a) {
 // dB normalisation + mel projection for a BANDED freq2mel -- what backend.mel() builds: triangular filters, each over a few
 // dozen neighbouring bins, 90 % of the 513 x 80 matrix is zero.  The dense GEMM above spends 77 TFLOP/s of fp32 MFMA on
 // those zeros (69 us: MFMA-bound); this kernel reads the 135 MB of log-power once (HBM-bound) and does ~1000 FMAs per frame.
-// A workgroup stages 16 normalised frames in LDS; thread t sums outputs t, t + 256, ... (frame-major, mel-minor).
+// A workgroup stages MEL_FT normalised frames in LDS; thread t sums outputs t, t + 256, ... (frame-major, mel-minor).
 // finalize chooses it when every filter's support is at most MEL_BW bins (a trained, dense freq2mel keeps mel_kernel).
-constexpr int MEL_BW = 64, MEL_FT = 16;
+// frames per workgroup.  Round 5: 8 instead of 16 -- 37 KB of LDS instead of 54, four resident workgroups per CU instead of two: the
+// kernel's memory-level parallelism is the turnover of short-lived workgroups (43.6 -> 38.2 us at 64 x 1000 frames; 12: 39.5, 6:
+// 38.2, 4: 39.5; as a LOOP over tiles with the next tile prefetched: 58.6 -- profiles/r05_stft_variants.md)
+#ifndef MI355ASR_MEL_FT
+#define MI355ASR_MEL_FT 8
+#endif
+constexpr int MEL_BW = 64, MEL_FT = MI355ASR_MEL_FT;
 __global__ __launch_bounds__(256) void mel_band_kernel(MelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];    // rows [MEL_FT][RS] | weights [NM][BW] | band [NM][2]
   const int nbins = a.nbins, RS = ((nbins + 15) / 16) * 16, RS4 = RS / 4;   // staged row: the bins, padded to 16 (<= LP)
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void mel_band_kernel(MelArgs a) {
   const float* __restrict__ src = a.logp + ((size_t)b * a.F + f0) * a.LP;
   // every load of the workgroup -- rows, band weights, band table -- is requested before the first is used (a load per
   // trip would cost a memory latency each: the whole kernel): up to RMAX + WMAX float4 per thread in flight
-  constexpr int RMAX = 9, WMAX = 5;            // 16 rows x 132 float4 / 256 threads; 80 x 64 floats / 4 / 256
+  constexpr int RMAX = (MEL_FT * 132 + 255) / 256, WMAX = 5;            // MEL_FT rows x 132 float4 / 256 threads; 80 x 64 floats / 4 / 256
   const int NM = a.NM, BW = a.BW;
   const int total = nf * RS4, wtotal = NM * BW / 4;
   f32x4 vv[RMAX], ww[WMAX];
@@ -255,7 +261,7 @@ int launch_mel_band(const MelArgs& a, hipStream_t s) {
   if (!a.band || !a.bw || a.BW > MEL_BW || (a.BW & 3) != 0 || (a.LP & 3) != 0) return -1;
   const int RS = ((a.nbins + 15) / 16) * 16;
   // the kernel's fixed load counts: 16 rows of RS floats in 9 float4 per thread, the band weights in 5, the table in 1
-  if (RS > a.LP || MEL_FT * (RS / 4) > 9 * 256 || a.NM * a.BW / 4 > 5 * 256 || 2 * a.NM > 256) return -1;
+  if (RS > a.LP || MEL_FT * (RS / 4) > ((MEL_FT * 132 + 255) / 256) * 256 || a.NM * a.BW / 4 > 5 * 256 || 2 * a.NM > 256) return -1;
   const size_t lds = ((size_t)MEL_FT * RS + (size_t)a.NM * a.BW + 2 * (size_t)a.NM) * sizeof(float);
   hipLaunchKernelGGL(mel_band_kernel, dim3((a.F + MEL_FT - 1) / MEL_FT, a.B), dim3(256), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
