@@ -543,6 +543,25 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
     put_ring(ab, o.qkv_wp, qkv_at, d, 3 * d, false);
     put_ring(ab, o.out_wp, [&](int kk, int n) { return pk_r[(size_t)kk * d + n]; }, d, d, false);
   }
+  if (d != 144 && d % 64 == 0 && hs == 64) {
+    // round 5: the same operand bounds for the head-size-64 models (attention_split64_kernel): q / k / v of the layer-at-a-time
+    // projections.  In bf16 mode weights and activations are rounded to bf16 first: each factor grows by at most 2^-8.
+    const auto &lg = T(a + "/ln/gamma"), &lb = T(a + "/ln/beta");
+    std::vector<float> qb0(3 * d, 0.f);
+    if (keras_mha) {
+      const auto &bq = T(a + "/mha/query/bias"), &bk = T(a + "/mha/key/bias"), &bv = T(a + "/mha/value/bias");
+      for (int i = 0; i < d; ++i) { qb0[i] = bq[i]; qb0[d + i] = bk[i]; qb0[2 * d + i] = bv[i]; }
+    }
+    const double lnb = std::sqrt((double)(d - 1));
+    double bnd[3] = {0.0, 0.0, 0.0};
+    for (int n = 0; n < 3 * d; ++n) {
+      double sum = std::fabs((double)qb0[n]);
+      for (int i = 0; i < d; ++i) sum += std::fabs((double)qkv_at(i, n)) * (lnb * std::fabs((double)lg[i]) + std::fabs((double)lb[i]));
+      bnd[n / d] = std::max(bnd[n / d], sum);
+    }
+    bnd[0] *= 1.4426950408889634 / std::sqrt((double)hs);
+    for (int k = 0; k < 3; ++k) o.att_h2[k] = half_scale_for(bnd[k] * 1.01, 40);
+  }
   if (d == 144) {
     o.split = true;                      // the slab streams of the loader-wave kernels (fused.hip) and of the pair-pipelined ones (fused_pp.hip)
     // slab stream of ff1_qkv_ring_kernel: per hidden chunk of 144 the five steps of W1[:, chunk] and of W2[chunk, :],
@@ -687,7 +706,8 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.out_wp = base + o.out_wp; b.out_b = base + o.out_b;
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
-  if (o.split) { b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; b.pp_og = base + o.pp_og; b.pp_sw_out = o.pp_sw_out; b.pp_sw_pw1 = o.pp_sw_pw1; b.att_h2[0] = o.att_h2[0]; b.att_h2[1] = o.att_h2[1]; b.att_h2[2] = o.att_h2[2]; }
+  if (o.split) { b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; b.pp_og = base + o.pp_og; b.pp_sw_out = o.pp_sw_out; b.pp_sw_pw1 = o.pp_sw_pw1; }
+  b.att_h2[0] = o.att_h2[0]; b.att_h2[1] = o.att_h2[1]; b.att_h2[2] = o.att_h2[2];
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
   b.bn_s = base + o.bn_s; b.bn_t = base + o.bn_t;
@@ -865,6 +885,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       q.ln_g = w.att_ln_g; q.ln_b = w.att_ln_b; q.qscale = 1.0f / std::sqrt((float)hs); q.qtiles = d / 16;
       { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm16(m, E16_QKV, true, q, w.qkv_wp, s), "qkv"); }
       at.q = sc.qkv; at.k = sc.qkv + d; at.v = sc.qkv + 2 * d; at.ldq = 3 * d; at.ldk = 3 * d; at.Tk = T;
+      at.h2_sq = w.att_h2[0]; at.h2_sk = w.att_h2[1]; at.h2_sv = w.att_h2[2];      // q / k / v are the block's own projections (0: no bound known)
     }
     { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
     Gemm16Args op = g16(sc.ctx, d, d, w.out_wp, w.out_b, d / 16, sc.xa, d);

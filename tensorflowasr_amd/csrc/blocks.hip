@@ -651,6 +651,8 @@ int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
   static const bool split_env = [] { const char* v = getenv("MI355ASR_ATTN_SPLIT"); return v ? atoi(v) != 0 : true; }();
   if (lds_env && split_env && attention_split_applicable(HS, a))
     return launch_attention_split(HS, a, s);
+  if (lds_env && split_env && attention_split64_applicable(HS, a))      // round 5: head size 64, operand bounds known, <= 288 keys
+    return launch_attention_split64(HS, a, s);
   if (a.head_major) return -1;         // head-major q / k / v (round 5) are read by attention_split_kernel only
   note_scheme(SCHEME_F32);
   if (lds_env && attention_lds_applicable(HS, a)) return launch_attention_lds(HS, a, s);

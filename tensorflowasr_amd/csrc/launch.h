@@ -394,6 +394,8 @@ bool attention_split_applicable(int HS, const AttnArgs& a);
 bool attention_split_two_term(int HS, const AttnArgs& a);
 bool attention_takes_head_major(int HS, const AttnArgs& a);   // blocks.hip: launch_attention's own switches included   // the two-term kernel would take this launch (head-major operands allowed)
 int launch_attention_split(int HS, const AttnArgs& a, hipStream_t s);
+bool attention_split64_applicable(int HS, const AttnArgs& a);   // attention_split64.hip: head size 64, two fp16 terms, <= 288 keys
+int launch_attention_split64(int HS, const AttnArgs& a, hipStream_t s);
 int launch_dwconv(int K, const DwArgs& a, hipStream_t s);
 int launch_stft(const StftArgs& a, hipStream_t s);
 int launch_utt_max(const UttMaxArgs& a, int B, hipStream_t s);

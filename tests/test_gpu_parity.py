@@ -1705,10 +1705,11 @@ def test_conformer_m_and_l_parity(torch_cuda, base, L):
     assert (ids.cpu().numpy() == rid).all() and (lens.cpu().numpy() == rlen).all()
 
 
-@pytest.mark.parametrize("T", [260, 272, 250, 273])
+@pytest.mark.parametrize("T", [260, 272, 250, 273, 288, 289, 40])
 def test_head_size_64_block_at_streaming_ctc_lengths(torch_cuda, T):
     """One dmodel-256 block (4 heads x 64) on 260 frames -- the "global CTC" history of BASELINE config 3 (20 chunks x 13
-    frames) -- and around the 256 / 272-key limits of the LDS-staged attention kernel (273: the L2-streaming kernel)."""
+    frames) -- and around the limits of the attention kernels: round 5's two-term attention_split64_kernel up to 288 keys (33 ..
+    288: one to three query tiles per wave, the last key tile partly filled), beyond it the L2-streaming fp32 kernel."""
     from tensorflowasr_amd.models import ConformerCTC
     cfg = small_cfg(1, co.CONFORMER_M)
     w = co.encoder_weights(cfg, seed=15)
@@ -1719,6 +1720,47 @@ def test_head_size_64_block_at_streaming_ctc_lengths(torch_cuda, T):
     got = m.conformer_block(0, x).cpu().numpy()
     ref = co.conformer_block(x.astype(np.float64), w, "conformer_block_0", cfg["head_size"], cfg["fc_factor"])
     assert maxdiff(got, ref) < TOL
+
+
+def test_head_size_64_two_term_attention_against_the_fp32_mfma_kernels(torch_cuda):
+    """Round 5 (attention_split64.hip): head size 64 on the fp16 matrix pipe with two-term operands (static bounds of q / k / v from the
+    LayerNorm and the projections, as for head size 36) against the fp32-MFMA kernels it replaces (MI355ASR_ATTN64_SPLIT=0 in a
+    subprocess): a dmodel-256 block at 260 / 250 / 64 frames and a two-block ConformerM encoder from the waveform -- both builds
+    within the usual distance of the fp64 oracle, the two-term kernel at most twice the fp32 kernels' + 2e-7 of the output's scale."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, maxdiff, small_cfg, waves
+from tensorflowasr_amd.models import ConformerCTC
+res = []
+cfg = small_cfg(2, co.CONFORMER_M)
+w = co.encoder_weights(cfg, seed=15)
+w.update(co.ctc_decoder_weights(cfg, 100, seed=16))
+m = ConformerCTC(100, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+m.load_weights(w, by_name=False)
+for T in (260, 250, 64):
+    x = (3.0 * np.random.default_rng(T).standard_normal((3, T, cfg["dmodel"]))).astype(np.float32)
+    ref = co.conformer_block(x.astype(np.float64), w, "conformer_block_1", cfg["head_size"], cfg["fc_factor"])
+    res += [maxdiff(m.conformer_block(1, x).cpu().numpy(), ref), float(np.abs(ref).max())]
+wav = waves(2, 64000, 77)
+ref = co.conformer_encoder(wav.astype(np.float64), w, cfg)
+res += [maxdiff(m.encode(wav).cpu().numpy(), ref), float(np.abs(ref).max())]
+print("RESULT " + " ".join("%.4e" % v for v in res))
+'''
+    errs = {}
+    for tag, extra in (("two", {}), ("f32", {"MI355ASR_ATTN64_SPLIT": "0"})):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+        assert line, (tag, out.stderr[-2000:])
+        errs[tag] = [float(v) for v in line[0].split()[1:]]
+    print(errs)
+    for i in range(0, 8, 2):
+        e2, e1, scale = errs["two"][i], errs["f32"][i], errs["f32"][i + 1]
+        assert e2 < TOL and e1 < TOL
+        assert e2 <= 2.0 * e1 + 2e-7 * scale, (i, e2, e1, scale)
 
 
 def test_ring_gemm_path_of_m_and_l_in_a_subprocess(torch_cuda):
