@@ -771,8 +771,11 @@ def main():
 
     # data-parallel runs rotate three output sets: the ids of batch n travel over RCCL (its own stream) while batch
     # n + 1 is recognised into the next set
-    rot = [(torch.empty((B, T), dtype=torch.int32, device=device), torch.empty((B,), dtype=torch.int32, device=device))
-           for _ in range(3)] if use_dist else None
+    # (ids and lengths of a set are two views of one buffer: one collective per batch, parallel.ids_lens_buffer)
+    rot = None
+    if use_dist:
+        from tensorflowasr_amd.parallel import ids_lens_buffer
+        rot = [ids_lens_buffer(B, T, device) for _ in range(3)]
     nstep = [0]
 
     def step():

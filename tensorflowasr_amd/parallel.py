@@ -66,9 +66,10 @@ def _check_local_rows(B, n_total, group):
 class GatherWork:
     """handle of an asynchronous all_gather_ids: wait(), then result() -> (ids_all, lens_all)"""
 
-    def __init__(self, works, outs, keep, inputs):
+    def __init__(self, works, outs, keep, inputs, unpack=None):
         self._works, self._outs, self._keep = works, outs, keep
         self._inputs = inputs            # the (possibly padded) send buffers stay alive until the exchange has read them
+        self._unpack = unpack            # one packed exchange: (rows per rank, T) of the [world, B T + B] block
 
     def wait(self):
         for w in self._works:
@@ -76,9 +77,31 @@ class GatherWork:
 
     def result(self):
         self.wait()
+        if self._unpack is not None:
+            B, T = self._unpack
+            flat = self._outs[0]
+            return flat[:, :B * T].reshape(-1, T), flat[:, B * T:].reshape(-1)
         if self._keep is None:
             return self._outs
         return tuple(o[self._keep] for o in self._outs)
+
+
+def ids_lens_buffer(B, T, device):
+    """(ids int32 [B, T], lens int32 [B]) as two views of ONE flat buffer [ids | lens]: all_gather_ids(async_op=True) sends such a
+    pair as a single collective (the exchange is latency-bound at 64 KB per rank: two collectives per batch cost twice one)"""
+    buf = torch.empty(B * T + B, dtype=torch.int32, device=device)
+    return buf[:B * T].view(B, T), buf[B * T:]
+
+
+def _packed_pair(ids, lens):
+    """the flat [ids | lens] buffer behind a pair made by ids_lens_buffer, or None"""
+    if not (ids.is_contiguous() and lens.is_contiguous() and ids.dtype == torch.int32 and lens.dtype == torch.int32):
+        return None
+    if ids.untyped_storage().data_ptr() != lens.untyped_storage().data_ptr():
+        return None
+    if lens.storage_offset() != ids.storage_offset() + ids.numel() or lens.numel() != ids.shape[0]:
+        return None
+    return torch.as_strided(ids, (ids.numel() + lens.numel(),), (1,), ids.storage_offset())
 
 
 def all_gather_ids(ids, lens, group=None, async_op=False, n_total=None):
@@ -94,8 +117,9 @@ def all_gather_ids(ids, lens, group=None, async_op=False, n_total=None):
     already queued, the caller's stream goes on with the next batch; `handle.wait()` blocks until the exchange is done and
     `handle.result()` = wait() + (ids_all, lens_all) with any padding rows dropped -- one batch's exchange then overlaps the
     next batch's recognition.  Without n_total nothing is enqueued on the caller's stream (the two tensors go out as they
-    are: the caller keeps them untouched until the work is done -- rotating output buffers, recognize(out=...)); with
-    n_total the shard is first padded to ceil(n_total / world) rows on the caller's stream (a cat of at most one row)."""
+    are: the caller keeps them untouched until the work is done -- rotating output buffers, recognize(out=...); a pair made by
+    ids_lens_buffer goes out as ONE collective); with n_total the shard is first padded to ceil(n_total / world) rows on the
+    caller's stream (a cat of at most one row)."""
     world = dist.get_world_size(group)
     B, T = ids.shape
     b_pad = B
@@ -103,6 +127,12 @@ def all_gather_ids(ids, lens, group=None, async_op=False, n_total=None):
         _check_local_rows(B, n_total, group)
         b_pad = -(-n_total // world)
         ids, lens = _pad_rows(ids, b_pad, -1), _pad_rows(lens, b_pad, 0)
+    if async_op and n_total is None:
+        flat = _packed_pair(ids, lens)
+        if flat is not None:             # ids_lens_buffer: one collective for both
+            out = torch.empty(world * flat.numel(), dtype=torch.int32, device=ids.device)
+            w = dist.all_gather_into_tensor(out, flat, group=group, async_op=True)
+            return GatherWork((w,), (out.view(world, flat.numel()),), None, (ids, lens), unpack=(B, T))
     if async_op:
         all_ids = torch.empty((world * b_pad, T), dtype=ids.dtype, device=ids.device)
         all_lens = torch.empty((world * b_pad,), dtype=lens.dtype, device=lens.device)

@@ -50,6 +50,20 @@ def _worker(rank, world, port, tmpdir):
         for w_, shift in works:
             a_ids, a_lens = w_.result()
             assert np.array_equal(a_ids.numpy(), full_ids + shift) and np.array_equal(a_lens.numpy(), full_lens)
+        # ... with ids and lengths as two views of one buffer (parallel.ids_lens_buffer, bench.py's rotating output sets): ONE
+        # collective per batch, the same result
+        from tensorflowasr_amd.parallel import _packed_pair, ids_lens_buffer
+        works = []
+        for shift in range(3):
+            b_ids, b_lens = ids_lens_buffer(ids.shape[0], ids.shape[1], "cpu")
+            b_ids.copy_(torch.from_numpy(ids + shift)); b_lens.copy_(torch.from_numpy(lens))
+            assert _packed_pair(b_ids, b_lens) is not None and _packed_pair(torch.from_numpy(ids), torch.from_numpy(lens)) is None
+            w_ = all_gather_ids(b_ids, b_lens, async_op=True)
+            assert len(w_._works) == 1
+            works.append((w_, shift))
+        for w_, shift in works:
+            a_ids, a_lens = w_.result()
+            assert np.array_equal(a_ids.numpy(), full_ids + shift) and np.array_equal(a_lens.numpy(), full_lens)
         open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
