@@ -315,12 +315,18 @@ def keras_names_to_abi(names):
                "decoder_conformer_block_", "fully_connected", "dense", "embedding", "inp_embedding")
     parsed = []
     mel = {}
+    names = list(names)
+    # a LEAF frontend is present when any variable lives under a `leaf` scope (frontend.py:75, `name='leaf'`)
+    has_leaf = any("leaf" in n.split(":")[0].split("/")[:-1] for n in names)
     for full in names:
         parts = full.split(":")[0].split("/")
         if parts == ["kernel"]:
             # leaf_audio/convolution.py:155-187: GaborConv1D creates its [n_filters, 2] kernel in __init__, before any layer
-            # scope exists, so Keras prints it as a bare `kernel:0` (seen when the reference's classes were executed, round 5)
-            mel[full] = "mel_layer/tfbanks_complex_conv/kernel"
+            # scope exists, so Keras prints it as a bare `kernel:0`.  Observed on the stand-in's emulation of Keras name scoping
+            # (oracle/_tfshim, round 5), not on a TensorFlow build.  Only mapped next to `leaf/...` variables: an unscoped
+            # `kernel:0` in the name list of a Melspectrogram model (an auxiliary or optimizer variable) is not a Gabor kernel.
+            if has_leaf:
+                mel[full] = "mel_layer/tfbanks_complex_conv/kernel"
             continue
         if "leaf" in parts[:-1]:
             # leaf_audio/frontend.py:75-194 (`name='leaf'`): leaf/{tfbanks_preemp, learnable_pooling, PCEN[/EMA], tfbanks_instancenorm}/...
@@ -340,6 +346,10 @@ def keras_names_to_abi(names):
                 mel[full] = "mel_layer/" + leaf
             elif len(parts) == 2 and (leaf.startswith("Variable") or leaf == "freq2mel"):
                 mel[full] = "mel_layer/freq2mel"
+            elif len(parts) > 2 and parts[0] == "mel_layer":
+                # files written by this repository's own tools name the LEAF sub-layers by the attribute:
+                # mel_layer/{tfbanks_complex_conv, learnable_pooling, PCEN[/EMA], tfbanks_instancenorm, tfbanks_preemp}/...
+                mel[full] = "/".join(parts)
             continue
         if parts[0].startswith(("wave_pick_model", "wav_layer")):
             # WavePickModel (wav_model.py:108-131) is a Layer named wave_pick_model holding one Sequential: the scope is

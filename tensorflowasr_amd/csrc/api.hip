@@ -602,9 +602,13 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
         bnd[n / d] = std::max(bnd[n / d], sum);
       }
       bnd[0] *= 1.4426950408889634 / std::sqrt((double)hs);
-      o.att_h2[0] = half_scale_for(bnd[0] * 1.0001, 40);
-      o.att_h2[1] = half_scale_for(bnd[1] * 1.0001, 40);
-      o.att_h2[2] = half_scale_for(bnd[2] * 1.0001, 40);
+      // fp32 mode: 1.0001 covers the rounding of the bound's own evaluation.  bf16 mode (gemm_dtype 1: the generic per-layer path
+      // rounds weights AND activations to bf16 before the projections, each factor growing by up to 2^-8) takes the 1.01 margin of
+      // the head-size-64 bounds above, so that bound * scale <= 2^15 holds there too (round-5 advice)
+      const double margin = m->cfg.gemm_dtype == 1 ? 1.01 : 1.0001;
+      o.att_h2[0] = half_scale_for(bnd[0] * margin, 40);
+      o.att_h2[1] = half_scale_for(bnd[1] * margin, 40);
+      o.att_h2[2] = half_scale_for(bnd[2] * margin, 40);
     }
   }
   const std::string c = p + "/conv_module";
@@ -1303,8 +1307,8 @@ int run_wavpick(const mi355asr_model* m, const float* wav, int Bp, int Lb, int T
 bool stream256_args(const mi355asr_model* m, int B, int T, const float* x, float* y, S256Args& sa) {
   static const bool on = [] { const char* v = getenv("MI355ASR_STREAM256"); return v ? atoi(v) != 0 : true; }();
   const int nb = m->cfg.num_blocks;
-  if (!on || m->cfg.gemm_dtype != 1 || m->cfg.dmodel != 256 || m->cfg.num_heads != 4 || m->cfg.head_size != 64 || T < 1 || T > 16 ||
-      nb < 1 || nb > S256_MAXB || m->cfg.kernel_size != 5 || (int)m->enc_blocks.size() < nb)      // (kernel_size: the depthwise taps live in registers, Streaming_ConformerS.yml's 5 is instantiated)
+  if (!on || m->cfg.gemm_dtype != 1 || m->cfg.dmodel != 256 || m->cfg.num_heads != 4 || m->cfg.head_size != 64 ||
+      !stream256_shape_ok(B, T, nb, m->cfg.kernel_size) || (int)m->enc_blocks.size() < nb)
     return false;
   auto ring = [&](const float* wp) -> const void* { const auto it = m->ring_of.find(wp); return it == m->ring_of.end() ? nullptr : it->second; };
   sa.x = x; sa.y = y; sa.B = B; sa.T = T; sa.nblocks = nb; sa.ksz = m->cfg.kernel_size; sa.pad_left = (m->cfg.kernel_size - 1) / 2;
@@ -1353,8 +1357,11 @@ int encoder_impl(mi355asr_model* m, const float* wav, const Geometry& g, const P
     S256Args sa{};
     if (stream256_args(m, g.Bp, g.T, sc.xa, enc_out, sa)) {
       PROF(MI355ASR_K_ENC_STACK);
-      LAUNCH_TRY(launch_stream256(sa, s), "encoder block stack");
-      return 0;
+      if (launch_stream256(sa, s) == 0) {          // -1 (not its shape after all): the per-layer loop below runs instead
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(MI355ASR_EHIP, "launch encoder block stack: %s", hipGetErrorString(e));
+        return 0;
+      }
     }
   }
   bool ff1_done = false;

@@ -288,7 +288,13 @@ struct S256Args {
   float fc, qscale, eps;
   S256Block blk[S256_MAXB];
 };
-int launch_stream256(const S256Args& a, hipStream_t s);   // -1: not this kernel's shape
+// the ONE shape predicate of stream256_kernel, shared by the launcher and by api.hip's stream256_args (round-5 advice: two copies of
+// the same checks).  The kernel is written for dmodel 256, 4 heads of 64, a 4 d FFN hidden, a 2 d conv hidden, 'same' padding and
+// kernel_size 5 (depthwise taps in registers: Streaming_ConformerS.yml); chunks of 1 .. 16 rows, one workgroup per chunk
+inline bool stream256_shape_ok(int B, int T, int nblocks, int ksz) {
+  return B > 0 && T >= 1 && T <= 16 && nblocks >= 1 && nblocks <= S256_MAXB && ksz == 5;
+}
+int launch_stream256(const S256Args& a, hipStream_t s);   // -1: not this kernel's shape (the caller falls back to the per-layer path)
 int launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // gemm_ring.hip: the same contract on the bf16 pipe with exactly split fp32 operands, weights as a slab ring
 // [N / 128 chunks][K / 32 steps][8 tiles][3 terms (1 in bf16 mode)][64 lanes][8 bf16] (api.hip: put_ring); -1: shape not taken

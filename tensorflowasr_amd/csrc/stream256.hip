@@ -421,7 +421,7 @@ __global__ __launch_bounds__(S_NW * 64) void stream256_kernel(S256Args a) {
 
 // -1: not this kernel's shape
 int launch_stream256(const S256Args& a, hipStream_t s) {
-  if (a.B <= 0 || a.T < 1 || a.T > 16 || a.nblocks < 1 || a.nblocks > S256_MAXB || a.ksz != 5) return -1;    // (depthwise taps in registers: Streaming_ConformerS.yml's kernel_size)
+  if (!stream256_shape_ok(a.B, a.T, a.nblocks, a.ksz)) return -1;
   note_scheme(SCHEME_BF16);
   hipLaunchKernelGGL(stream256_kernel<5>, dim3(a.B), dim3(S_NW * 64), 0, s, a);
   return 0;

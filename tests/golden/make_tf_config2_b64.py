@@ -103,5 +103,7 @@ if __name__ == "__main__":
             with open(tmp, "rb") as f:
                 for k, v in pickle.load(f).items():
                     res[k + "_f64"] = v
+    tf_mod, standin = g.import_tensorflow()
+    res["meta_generator"] = np.asarray("%s %s" % ("numpy stand-in (oracle/_tfshim)" if standin else "tensorflow", tf_mod.__version__))
     np.savez_compressed(OUT, **res)
     print("wrote %s (%d KB): %s" % (OUT, os.path.getsize(OUT) // 1024, sorted(res)))

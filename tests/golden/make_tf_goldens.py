@@ -90,8 +90,13 @@ FIXTURES = {}
 SUFFIX = [""]            # "" = the float32 pass; "_f64" = the stand-in's wide pass (float outputs only, added to the same file)
 
 
+GENERATOR = ["unknown"]   # "numpy stand-in (oracle/_tfshim) <version>" or "tensorflow <version>": stored in every fixture
+
+
 def save(name, **arrays):
     fx = FIXTURES.setdefault(name, {})
+    if not SUFFIX[0]:
+        fx["meta_generator"] = np.asarray(GENERATOR[0])
     for k, v in arrays.items():
         v = np.asarray(v)
         if not SUFFIX[0]:
@@ -126,6 +131,7 @@ def main():
     from asr.models import conformer_blocks as cb
     from asr.models.layers.time_frequency import Melspectrogram
     meta = dict(tf_version=tf.__version__, backend="numpy stand-in (oracle/_tfshim)" if standin else "tensorflow")
+    GENERATOR[0] = "%s %s" % (meta["backend"], tf.__version__)
     try:
         import librosa
         meta["librosa_version"] = librosa.__version__
@@ -211,6 +217,45 @@ def main():
     save("tf_translator.npz", seed=3040, logits=tr([tf.constant(ids), tf.constant(encin)], training=False).numpy(),
          weights_seed=13)
     done.append("translator")
+
+    # ---- a1-a4, a10, a12, a13 on the reference's OWN speech recordings (round 6) ----------------------------------------------
+    # asr/BAC009S0764W0121.wav is the file test_asr.py:272-275 transcribes, Inference/CppInference/onnx/test.wav the C++ demo's.
+    # Driven as test_asr.py:186-200 drives them: SpeechFeaturizer.load_wav (utils/speech_featurizers.py:10-22,68-70) ->
+    # reshape [1, -1, 1] (no peak normalisation: the recordings peak at 0.05 / 0.3) -> encoder -> CTCDecoder with the reference's
+    # trained weights (the exported ctc_model.onnx) -> softmax -> ctc_decode.  Real speech has what the synthetic waves lack:
+    # silences at the -80 dB floor, int16 quantisation, a 30 dB dynamic range inside one utterance.  The fixture carries the PCM
+    # samples (data the reference's demo holds) so that the GPU box, which has no reference checkout, runs the same input.
+    from utils.speech_featurizers import SpeechFeaturizer
+    import wave as _wave
+    sf_ = SpeechFeaturizer({"sample_rate": 16000})
+    wtr = dict(np.load(os.path.join(HERE, "ctc_decoder_weights.npz")))
+    ctc_t = cb.CTCDecoder(num_classes=1332, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32, dropout=0.0, fc_factor=0.5)
+    ctc_t._build()
+    assign_by_name(ctc_t, wtr)
+    mel_l = Melspectrogram(sr=16000, n_mels=80, n_hop=160, n_dft=1024, trainable_fb=False)
+    sp = {}
+    for tag, rel in (("bac", "asr/BAC009S0764W0121.wav"), ("cpp", "Inference/CppInference/onnx/test.wav")):
+        path = os.path.join(REF, rel)
+        data = sf_.load_wav(path)
+        with _wave.open(path, "rb") as f_:
+            pcm = np.frombuffer(f_.readframes(f_.getnframes()), "<i2").copy()
+        assert data.dtype == np.float32 and np.array_equal(data, pcm.astype(np.float32) / np.float32(32768.0))
+        xin = tf.constant(data.reshape([1, -1, 1]))
+        e1 = enc(xin, training=False)
+        lg1 = ctc_t(e1, training=False).numpy()
+        # the trained head answers `blank` to a random-weight encoder (its decode is empty): the seeded 50-class CTCDecoder of the
+        # section above is run as well, so that the greedy decode of real speech has tokens to collapse
+        lg2 = ctc(e1, training=False)
+        n1 = np.array([e1.shape[1]], "int32")
+        dec1 = tf.keras.backend.ctc_decode(tf.nn.softmax(tf.constant(lg1), -1), n1)[0][0].numpy()
+        dec2 = tf.keras.backend.ctc_decode(tf.nn.softmax(lg2, -1), n1)[0][0].numpy()
+        order = np.argsort(-lg1, axis=-1, kind="stable")[..., :4]
+        sp.update({tag + "_pcm": pcm, tag + "_mel": mel_l(xin).numpy()[..., 0], tag + "_enc": e1.numpy(),
+                   tag + "_trained_logits_every4": lg1[:, ::4], tag + "_trained_top4_idx": order.astype(np.int16),
+                   tag + "_trained_top4_val": np.take_along_axis(lg1, order, -1), tag + "_trained_ctc_decode": dec1,
+                   tag + "_logits50": lg2.numpy(), tag + "_ctc_decode50": dec2, tag + "_path": np.asarray(rel)})
+    save("tf_speech.npz", enc_weights_seed=0, ctc50_weights_seed=1, freq2mel=kept.get("mel_layer/freq2mel"), **sp)
+    done.append("speech")
 
     # ---- 8f-4: LEAF frontend and the WavePickModel branch ----------------------------------------------------------
     try:

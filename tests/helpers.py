@@ -38,10 +38,49 @@ def encoder_kwargs(cfg, chunk_size=0):
                 stride_ms=cfg["stride_ms"], mel_layer_type="Melspectrogram", chunk_size=chunk_size)
 
 
+# ---- per-comparison regression ceilings (round 6) ------------------------------------------------------------------------------
+# The contract is 1e-3 (BASELINE.json north_star) and every test asserts it; the measured errors are 5e-6 ... 2.4e-4, so a
+# kernel that got ten times worse would still pass.  Every maxdiff() call made inside a GPU test is therefore also held to a
+# recorded ceiling: tests/golden/parity_ceilings.json maps "<pytest node id>#<n-th maxdiff call of that test>" to 4 x the error
+# a GPU run of the committed build recorded (tools/make_ceilings.py from the MI355ASR_PARITY_LOG of `pytest -m gpu`; floor 1e-7).
+# A comparison without an entry (a new test, a CPU test) is only logged.  MI355ASR_PARITY_CEILINGS=0 switches the check off
+# (for experiments with the numerics: re-record the file when they are kept).
+_CEIL_PATH = os.path.join(GOLDEN, "parity_ceilings.json")
+_CEILINGS = None
+_CALLS = {}
+
+
+def _ceilings():
+    global _CEILINGS
+    if _CEILINGS is None:
+        _CEILINGS = {}
+        if os.path.exists(_CEIL_PATH) and os.environ.get("MI355ASR_PARITY_CEILINGS", "1") != "0":
+            import json
+            with open(_CEIL_PATH) as f:
+                _CEILINGS = json.load(f)["ceilings"]
+    return _CEILINGS
+
+
+def _held_to_ceiling(err):
+    cur = os.environ.get("PYTEST_CURRENT_TEST", "")
+    if not cur.endswith(" (call)"):
+        return
+    tid = cur[:-len(" (call)")]
+    n = _CALLS[tid] = _CALLS.get(tid, -1) + 1
+    key = "%s#%d" % (tid, n)
+    c = _ceilings().get(key)
+    _parity_log({"tag": key, "max_abs_err": err, "ceiling": c})
+    if c is not None and err > c:
+        raise AssertionError("regression guard: %s measured %.4g, above its recorded ceiling %.4g (4 x the error of the build that "
+                             "wrote tests/golden/parity_ceilings.json; the 1e-3 contract is asserted separately)" % (key, err, c))
+
+
 def maxdiff(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max())
+    err = float(np.abs(a - b).max()) if a.size else 0.0
+    _held_to_ceiling(err)
+    return err
 
 
 def argmax_mismatch_report(gpu_logits, ref_logits):

@@ -1535,17 +1535,19 @@ def test_bf16_gemm_mode_against_rounding_oracle_and_fp32(torch_cuda, base, block
     assert 1e-4 < d_enc < 0.2 and d_log < 0.3 and agree > 0.95
 
 
-@pytest.mark.parametrize("base", [co.STREAMING_S, co.CONFORMER_S])
-def test_bf16_block_matches_rounding_oracle(torch_cuda, base):
+@pytest.mark.parametrize("base,T", [(co.STREAMING_S, 45), (co.CONFORMER_S, 45), (co.CONFORMER_S, 250)])
+def test_bf16_block_matches_rounding_oracle(torch_cuda, base, T):
     """One ConformerBlock in bf16 mode on an exact fp32 input: every dense layer sees the same operands as the oracle
-    with both GEMM operands rounded to bf16, so only the (rare) fp32-vs-fp64 tie flips remain."""
+    with both GEMM operands rounded to bf16, so only the (rare) fp32-vs-fp64 tie flips remain.  (CONFORMER_S, 250): dmodel 144 in
+    bf16 mode at a length where the two-term attention kernel runs with the static q / k / v bounds -- computed with the 1.01
+    margin that covers the bf16 rounding of both factors (round-5 advice)."""
     from tensorflowasr_amd.models import ConformerCTC
     cfg = small_cfg(1, base)
     w = co.encoder_weights(cfg, seed=5)
     w.update(co.ctc_decoder_weights(cfg, 100, seed=6))
     m = ConformerCTC(100, gemm_dtype="bfloat16", **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
     m.load_weights(w, by_name=False)
-    x = np.random.default_rng(2).standard_normal((3, 45, cfg["dmodel"])).astype(np.float32)
+    x = np.random.default_rng(2).standard_normal((3, T, cfg["dmodel"])).astype(np.float32)
     got = m.conformer_block(0, x).cpu().numpy()
     co.GEMM_ROUND_BF16 = True
     try:
@@ -1871,7 +1873,8 @@ def test_streaming_block_stack_in_one_launch_vs_layer_at_a_time_and_rounding_ora
     depthwise conv from LDS).  Against the oracle with both GEMM operands rounded to bf16 it must meet the bounds the layer-at-a-time
     path is held to (same operands, another summation order along K: a hidden value on a rounding boundary may fall the other
     way); the same model with MI355ASR_STREAM256=0 is run beside it (both in subprocesses: the switch is read once), and the
-    profile counters say which kernels ran.  Chunks of 8000 samples (13 rows) and of 4000 (7 rows: more padding rows in the tile)."""
+    profile counters say which kernels ran.  Chunks of 8000 samples (13 rows), 4000 (7 rows: more padding rows in the tile), and the two
+    ends of the kernel's range (round-5 advice): 10240 (16 rows, no padding row) and 640 (ONE row, fifteen padding rows)."""
     import subprocess
     import sys
     code = r'''
@@ -1883,7 +1886,7 @@ from tensorflowasr_amd.models import StreamingConformerEncoder
 cfg = dict(co.STREAMING_S)
 w = co.encoder_weights(cfg, seed=61)
 lib = _lib.lib()
-for chunk, nchunks in ((8000, 20), (4000, 6)):
+for chunk, nchunks in ((8000, 20), (4000, 6), (10240, 5), (640, 9)):
     enc = StreamingConformerEncoder(dmodel=256, reduction_factor=4, num_blocks=4, head_size=64, num_heads=4, kernel_size=5, fc_factor=0.5,
                                     sample_rate=16000, n_mels=80, stride_ms=10, mel_layer_type="Melspectrogram", gemm_dtype="bfloat16")
     enc.add_chunk_size(chunk, 80, 640)
@@ -1909,10 +1912,10 @@ for chunk, nchunks in ((8000, 20), (4000, 6)):
             out = subprocess.run([sys.executable, "-c", code, os.path.join(td, tag)], env=dict(os.environ, **extra), capture_output=True, text=True,
                                  timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             lines = [ln.split()[1:] for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
-            assert len(lines) == 2, out.stderr[-3000:]
+            assert len(lines) == 4, out.stderr[-3000:]
             for chunk, rows, emax, emean, n_stack, n_ffn in lines:
                 res[tag, int(chunk)] = (int(rows), float(emax), float(emean), int(n_stack), int(n_ffn))
-        for chunk, rows in ((8000, 13), (4000, 7)):
+        for chunk, rows in ((8000, 13), (4000, 7), (10240, 16), (640, 1)):       # 16: no padding row in the tile; 1: fifteen of them
             s_rows, s_max, s_mean, s_stack, s_ffn = res["stack", chunk]
             l_rows, l_max, l_mean, l_stack, l_ffn = res["layers", chunk]
             assert s_rows == l_rows == rows

@@ -597,6 +597,27 @@ def test_keras_names_cover_every_tensor_of_encoder_with_wav_info_and_translator(
     assert set(k2a.values()) == set(names)
 
 
+def test_keras_names_of_leaf_sublayers_under_the_attribute_scope_and_the_bare_gabor_kernel():
+    """Round-5 advice: (1) `conformer_encoder/mel_layer/<LEAF sub-layer>/...` (what this repository's own tools write) must map
+    again -- the Melspectrogram branch had started to drop every name deeper than two parts; (2) a bare `kernel:0` is the Gabor
+    kernel only next to `leaf/...` variables, never in a Melspectrogram model's name list."""
+    from tensorflowasr_amd import checkpoint
+    from tensorflowasr_amd.models import ConformerEncoder
+    enc = ConformerEncoder(dmodel=144, num_blocks=1, mel_layer_type="leaf")
+    leaf_names = [n for n in enc._h.weight_names() if n.startswith("mel_layer/")]
+    assert any("PCEN" in n for n in leaf_names) and any("learnable_pooling" in n for n in leaf_names) and len(leaf_names) == 9
+    keras = {"conformer_encoder/%s:0" % n: n for n in leaf_names}
+    assert checkpoint.keras_names_to_abi(list(keras)) == keras
+    # the reference's own scoping (seen on the stand-in): leaf/... plus the bare kernel
+    ref_style = {"kernel:0": "mel_layer/tfbanks_complex_conv/kernel"}
+    ref_style.update({"leaf/%s:0" % n[len("mel_layer/"):]: n for n in leaf_names if "tfbanks_complex_conv" not in n})
+    assert checkpoint.keras_names_to_abi(list(ref_style)) == ref_style
+    # ... and no Gabor kernel appears in a Melspectrogram model because some variable is called `kernel:0`
+    mel_model = ["conformer_encoder/melspectrogram/real_kernels:0", "conformer_encoder/melspectrogram/Variable:0", "kernel:0"]
+    got = checkpoint.keras_names_to_abi(mel_model)
+    assert "kernel:0" not in got and sorted(got.values()) == ["mel_layer/freq2mel", "mel_layer/real_kernels"]
+
+
 def test_load_weights_from_a_file_checks_coverage(tmp_path):
     """a checkpoint whose names do not map, or that lacks tensors, must not load as a random-weight model"""
     from tensorflowasr_amd import _lib

@@ -24,7 +24,7 @@ def test_committed_tf_fixtures_are_reproduced_by_the_recipe(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     names = sorted(f for f in os.listdir(GOLDEN) if f.startswith("tf_") and f.endswith(".npz") and f != "tf_config2_b64.npz")
     # (tf_config2_b64.npz has its own recipe, make_tf_config2_b64.py: test_tf_goldens.py re-runs two of its utterances)
-    assert names == sorted(os.listdir(tmp_path)) and len(names) == 10, (names, sorted(os.listdir(tmp_path)))
+    assert names == sorted(os.listdir(tmp_path)) and len(names) == 11, (names, sorted(os.listdir(tmp_path)))
     for n in names:
         a, b = np.load(os.path.join(GOLDEN, n)), np.load(os.path.join(tmp_path, n))
         assert sorted(a.files) == sorted(b.files), n
