@@ -175,13 +175,112 @@ def cpu_baseline(seconds_budget=12.0):
             v, r, tt = _oracle_rate(co, x, w, cfg, seconds_budget / len(tries), 4)
         runs[t] = {"value": round(v, 1), "threads": t, "sample": "%d x 1 utterance (10 s = 1000 frames), %.1f s" % (r, tt)}
     best = max(runs, key=lambda t: runs[t]["value"])
-    return {"value": runs[best]["value"], "unit": "audio-frames/s", "cores": int(best), "kind": "port", "threads_best": int(best),
-            "host_threads": int(cores),
-            "sample": "the fp32 NumPy oracle on one 10 s utterance at a time, BLAS pool limited to %s threads in turn (%s); best kept"
-                      % (tries, "; ".join("%d: %s" % (t, runs[t]["sample"]) for t in tries)),
+    one_at_a_time = {"value": runs[best]["value"], "cores": int(best),
+                     "sample": "the fp32 NumPy oracle on one 10 s utterance at a time, BLAS pool limited to %s threads in turn (%s); best kept"
+                               % (tries, "; ".join("%d: %s" % (t, runs[t]["sample"]) for t in tries))}
+    # round-5 review: one utterance at a time does not scale with threads (3 202 -> 3 216 frames/s from 1 to 8 threads on a
+    # 128-thread host), so it understates what the host can do.  A batch is embarrassingly parallel over utterances: the second
+    # leg shards the benched batch over worker PROCESSES, one BLAS thread each, and the better of the two legs is the baseline.
+    try:
+        workers = cpu_baseline_workers()
+    except Exception as e:                                   # the baseline must not take the bench line down
+        workers = {"error": "%s: %s" % (type(e).__name__, e)}
+    pick = workers if workers.get("value", 0.0) > one_at_a_time["value"] else one_at_a_time
+    return {"value": pick["value"], "unit": "audio-frames/s", "cores": int(pick["cores"]), "kind": "port", "threads_best": int(best),
+            "host_threads": int(cores), "sample": pick["sample"],
+            "legs": {"one_utterance_at_a_time": one_at_a_time, "worker_processes": workers},
             "by_threads": {str(t): runs[t]["value"] for t in tries},
             "threads1": runs[1], "all_cores": runs[cores],
             "published_tf2_1core": PUBLISHED_TF2_1CORE}
+
+
+def cpu_baseline_workers(timeout_s=240.0):
+    """The benched batch sharded over min(host cores, 64) worker processes (oracle/cpu_worker.py: one BLAS thread each, the fp32
+    NumPy oracle from the waveform to the greedy ids).  Timed from the moment every worker is ready (weights built, one warm-up
+    utterance done) to the last worker's DONE: start-up is excluded, imbalance is not.  64 utterances when the host has at least
+    32 cores, otherwise two per worker (a bounded sample)."""
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    n_workers = max(1, min(ncpu, 64))
+    total = 64 if ncpu >= 32 else 2 * n_workers
+    worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(i), str(n_workers), str(total), "160000", str(NUM_CLASSES)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for i in range(n_workers)]
+    deadline = time.time() + timeout_s
+    try:
+        for p in procs:
+            line = p.stdout.readline()
+            if not line.startswith("READY") or time.time() > deadline:
+                raise RuntimeError("worker did not get ready: %r" % line)
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        done, busy = 0, 0.0
+        for p in procs:
+            parts = p.stdout.readline().split()
+            if len(parts) != 3 or parts[0] != "DONE":
+                raise RuntimeError("worker failed: %r" % parts)
+            done += int(parts[1])
+            busy += float(parts[2])
+        wall = time.perf_counter() - t0
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()
+    if done != total:
+        raise RuntimeError("workers ran %d of %d utterances" % (done, total))
+    return {"value": round(total * 1000.0 / wall, 1), "cores": n_workers, "utterances": total, "wall_s": round(wall, 3),
+            "cpu_busy_s": round(busy, 2),
+            "sample": "%d of the benched 10 s utterances (1000 frames each) over %d worker processes, one BLAS thread each, fp32 NumPy oracle "
+                      "waveform -> greedy ids; %.2f s wall (%.1f s of CPU work), start-up excluded" % (total, n_workers, wall, busy)}
+
+
+def parity_stamp(model, wav, B, L):
+    """The benched batch against the committed fixtures, recorded in the bench line (round-5 review, item 2c): logits of all 64
+    utterances against tests/golden/tf_config2_b64.npz -- the REFERENCE'S OWN ConformerEncoder + CTCDecoder + ctc_decode on this
+    very batch (tests/golden/make_tf_config2_b64.py; float32 run, and the float64-carried run for the margins) -- on the four
+    largest classes of every frame and all classes of every 50th frame; per-frame arg-max; `excused_frames` = frames whose arg-max
+    differs from the reference's where the reference's own top-2 margin is within ten times the measured logit error (the rule of
+    tests/helpers.assert_frames_and_ids; any other differing frame is `decisive_mismatches`); the greedy ids of recognize() against
+    the reference's ctc_decode.  Reads data only (no oracle code); outside every timed region."""
+    path = os.path.join(ROOT, "tests", "golden", "tf_config2_b64.npz")
+    if not (os.path.exists(path) and B == 64 and L == 160000):
+        return None
+    g = np.load(path)
+    enc = model.encode(wav)
+    logits, amax = model.ctc_logits(enc, return_argmax=True)
+    ids, lens = model.recognize(wav)
+    enc, logits, amax, ids, lens = (t.cpu().numpy() for t in (enc, logits, amax, ids, lens))
+    idx, val = g["trained_top4_idx"].astype(np.int64), g["trained_top4_val"].astype(np.float64)
+    err = max(float(np.abs(np.take_along_axis(logits, idx, -1) - val).max()),
+              float(np.abs(logits[:, ::50].astype(np.float64) - g["trained_logits_every50"]).max()))
+    ra = idx[..., 0]
+    excused = decisive = 0
+    for b, t in np.argwhere(amax != ra):
+        pos = np.flatnonzero(idx[b, t] == amax[b, t])
+        margin = float(val[b, t, 0] - val[b, t, pos[0]]) if pos.size else float("inf")
+        if margin <= 10 * err:
+            excused += 1
+        else:
+            decisive += 1
+    ids_equal = bool(np.array_equal(lens, g["trained_lens"]) and np.array_equal(ids, g["trained_ids"]))
+    return {"against": "tests/golden/tf_config2_b64.npz: the reference's own model code on this batch (%s)" % str(g["meta_generator"]),
+            "frames": int(ra.size), "logits_max_abs_err": err,
+            "encoder_max_abs_err_every10": float(np.abs(enc[:, ::10].astype(np.float64) - g["trained_enc_every10"]).max()),
+            "excused_frames": excused, "decisive_mismatches": decisive, "greedy_ids_equal_reference_ctc_decode": ids_equal,
+            "tokens": int(lens.sum()), "tolerance": 1e-3, "within_tolerance": bool(err < 1e-3 and decisive == 0)}
 
 
 def block_flops(M, B, T, d, k, nblocks):
@@ -974,6 +1073,8 @@ def main():
             line["latency_b1"] = {"ms": round(t1 * 1e3, 3), "utterance_s": args.seconds, "rtf": round(t1 / args.seconds, 8),
                                   "what": "one %g s utterance per recognize() call, input resident in HBM, 50 calls" % args.seconds}
             model.prepare(B, L)
+        if world == 1:
+            line["parity"] = parity_stamp(model, wav, B, L)
         if world == 1 and not args.no_exact_leg:
             line["exact_products"] = exact_products_leg(args, model, wav)
         if world == 1 and not args.no_cpu_baseline:
