@@ -272,7 +272,8 @@ float matrix_scale(const std::function<float(int, int)>& f, int K, int N) {   //
 // Chain y += W2 act(W1aug [x ; 1]) over P = H / 32 hidden pairs, units A, AP, (P - 2) x F, BP, B (2 P ring slots):
 // an A fragment = W1aug step a, hidden tile 2 pair + b; a B fragment = W2 step `pair`, column tile a.  Returns the scales the
 // two matrices were packed with and the bounds the kernel derives the operand scales from.
-PpChainSc append_pp_chain(std::vector<float>& stream, const std::function<float(int, int)>& w1aug, int H, const std::function<float(int, int)>& w2) {
+PpChainSc append_pp_chain(std::vector<float>& stream, const std::function<float(int, int)>& w1aug, int H, const std::function<float(int, int)>& w2,
+                          std::vector<float>* plain1, std::vector<float>* plain2) {
   const int P = H / 32, NT1 = H / 16;
   PpChainSc sc;
   sc.sw1 = matrix_scale(w1aug, 145, H);
@@ -298,17 +299,20 @@ PpChainSc append_pp_chain(std::vector<float>& stream, const std::function<float(
   for (int p = 0; p + 2 < P; ++p) { unit(kPpLayout_F0, p + 2, p); unit(kPpLayout_F1, p + 2, p); }
   unit(kPpLayout_BP0, -1, P - 2);
   unit(kPpLayout_B0, -1, P - 1);
+  if (plain1) *plain1 = sp1;                  // the same fragments in plain [step][tile][term] order (fused_ns.hip)
+  if (plain2) *plain2 = sp2;
   return sc;
 }
 // A plain layer [145 (row 144 = bias), 144 * groups] in column groups of nine tiles, five S units (ring slots) per group;
 // returns the power of two the matrix was packed with
-float append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups) {
+float append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups, std::vector<float>* plain) {
   const int NT = 9 * groups;
   const float sw = matrix_scale(waug, 145, 144 * groups);
   const std::vector<float> sp = pack_half32(waug, 145, 144 * groups, sw);
   for (int g = 0; g < groups; ++g)
     for (int st = 0; st < 5; ++st)
       put_pp_slot(stream, kPpLayout_S0, [&](const PpFragDesc& d) { return sp.data() + (((size_t)st * NT + 9 * g + d.a) * 2 + d.term) * 256; });
+  if (plain) *plain = sp;
   return sw;
 }
 
@@ -584,11 +588,13 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
       for (int i = 0; i < d; ++i) { v[i] = bq[i]; v[d + i] = bk[i]; v[2 * d + i] = bv[i]; }
       return v;
     }() : std::vector<float>(3 * d, 0.f);
-    std::vector<float> pp;
+    std::vector<float> pp, n1, n2, nq;
     o.pp_ff1_sc = append_pp_chain(pp, [&](int kk, int n) { return kk < d ? f1[(size_t)kk * 4 * d + n] : b1[n]; }, 4 * d,
-                                  [&](int kk, int n) { return f2[(size_t)kk * d + n]; });
-    o.pp_sw_qkv = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? qkv_at(kk, n) : qb[n]; }, 3);
+                                  [&](int kk, int n) { return f2[(size_t)kk * d + n]; }, &n1, &n2);
+    o.pp_sw_qkv = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? qkv_at(kk, n) : qb[n]; }, 3, &nq);
     o.pp_ff1 = ab.put(pp);
+    o.ns = ns_enabled();                 // the same fragments in plain order, for the N-split kernel (fused_ns.hip; off by default)
+    if (o.ns) { o.ns_ff1_w1 = ab.put(n1); o.ns_ff1_w2 = ab.put(n2); o.ns_qkv = ab.put(nq); }
     // Operand bounds for the two-term attention kernel: a LayerNorm output lies in sqrt(d - 1) |gamma_i| + |beta_i|, so
     // |q_n|, |k_n|, |v_n| <= sum_i |W_in| (sqrt(d - 1) |gamma_i| + |beta_i|) + |b_n| (q times the query scale and log2 e,
     // which the kernel folds into it)
@@ -711,6 +717,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
   if (o.split) { b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; b.pp_og = base + o.pp_og; b.pp_sw_out = o.pp_sw_out; b.pp_sw_pw1 = o.pp_sw_pw1; }
+  if (o.ns) { b.ns_ff1_w1 = base + o.ns_ff1_w1; b.ns_ff1_w2 = base + o.ns_ff1_w2; b.ns_qkv = base + o.ns_qkv; }
   b.att_h2[0] = o.att_h2[0]; b.att_h2[1] = o.att_h2[1]; b.att_h2[2] = o.att_h2[2];
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
@@ -944,6 +951,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       k1.ff_w2p = bw.ff_w2p[0]; k1.ff_b2 = bw.ff_b2[0];
       k1.att_ln_g = bw.att_ln_g; k1.att_ln_b = bw.att_ln_b; k1.qkv_wp = bw.qkv_wp; k1.qkv_b = bw.qkv_b;
       k1.fc = fc; k1.qscale = qscale; k1.eps = kLnEps; k1.M = M; k1.slabs = bw.ff1_slabs; k1.pp_slabs = bw.pp_ff1; k1.pp_sc = bw.pp_ff1_sc; k1.pp_sw_qkv = bw.pp_sw_qkv;
+      k1.ns_w1 = bw.ns_ff1_w1; k1.ns_w2 = bw.ns_ff1_w2; k1.ns_qkv = bw.ns_qkv;
       if (qkv_head_major(bw)) { k1.qkv_T = T; k1.qkv_H = H; }
       return k1;
     };

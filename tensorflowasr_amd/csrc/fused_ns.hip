@@ -36,15 +36,28 @@
 #include "wstream.h"
 #include "split_f16.h"
 
+#ifndef NS_NP
+#define NS_NP 20
+#endif
+
 namespace {
 
 constexpr int D = 144;
 constexpr int KB = D / 16;      // 9
 constexpr int KS = 5;           // 32-wide steps over K = 144 (+ the bias row 144)
-constexpr int NP = 10;          // weight fragments in flight per wave (the pool)
+constexpr int NP = NS_NP;       // weight fragments in flight per wave (the pool)
 constexpr int NTT = 4;          // token tiles per workgroup
 
 #define NS_FENCE __builtin_amdgcn_sched_barrier(0)
+// timing-only variants (wrong results; tools/build_variant.py NAME fused_ns.hip -DNS_DIAG=n): bit 0 = the chain runs twice (is the
+// first pass bound by instruction fetch?), 1 = no fragment loads after the first ten, 2 = no activation / split work, 3 = no
+// operand reads from LDS after the first
+#ifndef NS_DIAG
+#define NS_DIAG 0
+#endif
+// bit 4: cycle stamps (s_memtime) at the phase boundaries of workgroup 7, printed per wave at the end of the kernel
+#define NS_STAMP(i) do { if constexpr ((NS_DIAG & 16) != 0) { if (blockIdx.x == 7) ns_stamp[i] = __builtin_readcyclecounter(); } } while (0)
+#define NS_STAMP_DECL unsigned long long ns_stamp[24] = {}
 
 DEV f32x4 ns_mfma(u32x4_t w, u32x4_t x, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
@@ -133,6 +146,7 @@ DEV void ns_phase(f32x4 (&y)[NTT][KB], f32x4 (&hA)[NTT][2], f32x4 (&hP)[NTT][2],
   // position q of THIS phase's stream (q may run into the next phase's): real fragment? its address
   auto load_pos = [&](auto Q) {
     constexpr int q = decltype(Q)::value;
+    if constexpr ((NS_DIAG & 2) != 0) return;
     if constexpr (q < NPOS) {
       if constexpr (q < NB) {
         if constexpr (q < 18) pool[q % NP] = ns_frag_b<NT1>(cur, q)[0];
@@ -153,14 +167,23 @@ DEV void ns_phase(f32x4 (&y)[NTT][KB], f32x4 (&hA)[NTT][2], f32x4 (&hP)[NTT][2],
   // the prep slots that follow MFMA number m of the phase (uniformly spread; all of them by the last MFMA)
   auto prep_after = [&](auto Mi) {
     constexpr int m = decltype(Mi)::value;
-    if constexpr (SL > 0) {
+    if constexpr (SL > 0 && !(NS_DIAG & 4)) {
       constexpr int lo = (m * SL) / M, hi = ((m + 1) * SL) / M;
       static_for<lo, hi>([&](auto S) {
         constexpr int sl = decltype(S)::value;
-        prep2_slot<sl % PREP2_SLOTS>(pc[sl / PREP2_SLOTS]);
+        Prep2Ctx& p = pc[sl / PREP2_SLOTS];
+        prep2_slot<sl % PREP2_SLOTS>(p);
+        // the slot's results are pinned HERE: they feed nothing before the next phase, and without a use the compiler emits the whole
+        // activation + split of a pair in front of its first consumer -- the next phase's first MFMAs (seen in the ISA: 32 v_exp in
+        // the first 200 instructions of a phase, none in the phase that was meant to carry them)
+        asm volatile("" : "+v"(p.ta), "+v"(p.tb), "+v"(p.m0), "+v"(p.m1), "+v"(p.hp), "+v"(p.lo), "+v"(p.hi), "+v"(p.out.t[0]), "+v"(p.out.t[1]));
       });
     }
   };
+  if constexpr ((NS_DIAG & 4) != 0 && NTP > 0) {          // timing only: the operand is "defined" without any work
+#pragma unroll
+    for (int s = 0; s < NTP; ++s) asm volatile("; no prep" : "=v"(fP[s].t[0]), "=v"(fP[s].t[1]) : "v"(hP[s][0]), "v"(hP[s][1]));
+  }
   // operand fragments of the A part: x hi double-buffered by step, x lo refilled as it is used
   u32x4_t xh[2][NTT], xl[NTT];
   if constexpr (NTA > 0) {
@@ -207,7 +230,7 @@ DEV void ns_phase(f32x4 (&y)[NTT][KB], f32x4 (&hA)[NTT][2], f32x4 (&hP)[NTT][2],
             constexpr int q = NB + 4 * st + (g == 0 ? 0 : 2) + b;
             hA[s][b] = ns_mfma(pool[q % NP], g == 1 ? xl[s] : xh[st & 1][s], hA[s][b]);
             prep_after(std::integral_constant<int, m>());
-            if constexpr (b == 1 && st + 1 < KS) {
+            if constexpr (b == 1 && st + 1 < KS && !(NS_DIAG & 8)) {
               // x lo of the next step as soon as this step's is used; x hi of the next step behind the first group
               if constexpr (g == 1) xl[s] = c.xf[c.tt(s)].f[st + 1][1][c.lane];
               if constexpr (g == 0) xh[(st + 1) & 1][s] = c.xf[c.tt(s)].f[st + 1][0][c.lane];
@@ -223,10 +246,12 @@ DEV void ns_phase(f32x4 (&y)[NTT][KB], f32x4 (&hA)[NTT][2], f32x4 (&hP)[NTT][2],
   if constexpr (M == 0) static_assert(SL == 0, "prep rides behind MFMAs");
 }
 
-// first NP fragments of a chain's first phase (its A part)
-template <int NT1>
-DEV void ns_prime_a(u32x4_t (&pool)[NP], const NsPtr& p) {
-  static_for<0, NP>([&](auto Q) { constexpr int q = decltype(Q)::value; pool[q] = ns_frag_a<NT1>(p, q)[0]; });
+// first NP fragments of a chain's first phase (the A part of wave w's first pair); issued as early as the caller can -- a
+// fragment takes ~1 600 cycles from L2 when every workgroup of the chip asks for the same lines (measured: profiles/r06_ns_*)
+template <int P>
+DEV void ns_prime_chain(u32x4_t (&pool)[NP], const u32x4_t* w1, int w, int lane) {
+  const NsPtr p{nullptr, w1 + (size_t)(2 * w) * (2 * 64) + lane};
+  static_for<0, NP>([&](auto Q) { constexpr int q = decltype(Q)::value; pool[q] = ns_frag_a<2 * P>(p, q)[0]; });
 }
 
 // One chain  y += W2 act(W1aug [x ; 1])  over P hidden pairs (H = 32 P), N-split over the four waves.  P = 4 F + R: wave w takes
@@ -235,7 +260,7 @@ DEV void ns_prime_a(u32x4_t (&pool)[NP], const NsPtr& p) {
 // passed), y holds this wave's initial partial (the owner's slot 3: residual + bias in the output unit; the others: zero).
 // w1 / w2: pack_half32 fragments [KS][2 P][2][64] / [P][9][2][64] of u32x4.
 template <int P>
-DEV void ns_chain(f32x4 (&y)[NTT][KB], const u32x4_t* w1, const u32x4_t* w2, const NsCtx& c) {
+DEV void ns_chain(f32x4 (&y)[NTT][KB], u32x4_t (&pool)[NP], const u32x4_t* w1, const u32x4_t* w2, const NsCtx& c, unsigned long long (&ns_stamp)[24]) {
   constexpr int F = P / 4, R = P % 4, NT1 = 2 * P, NR = R == 2 ? 2 : (R == 1 ? 1 : 0);
   static_assert(F >= 2 && (R == 1 || R == 2), "ff modules (18 pairs) and the conv tail (9)");
   float k1[NTT], ik2[NTT];
@@ -245,21 +270,22 @@ DEV void ns_chain(f32x4 (&y)[NTT][KB], const u32x4_t* w1, const u32x4_t* w2, con
   const int prem = 4 * F + (R == 2 ? (c.w >> 1) : 0);        // the left-over pair this wave shares
   f32x4 h0[NTT][2], h1[NTT][2];
   Split8 f0[NTT], f1[NTT];
-  u32x4_t pool[NP];
   const f32x4 zero = splat4(0.f);
   auto clear = [&](f32x4 (&h)[NTT][2]) {
 #pragma unroll
     for (int s = 0; s < NTT; ++s) { h[s][0] = zero; h[s][1] = zero; }
   };
   NsPtr p0 = ptr(c.w), p1 = ptr(c.w + 4);
-  ns_prime_a<NT1>(pool, p0);
   clear(h0);
+  NS_STAMP(3);
   ns_phase<0, 4, 0, 2, NT1>(y, h0, h1, f0, f1, pool, p0, p1, c, k1, ik2);                       // A(0)
+  NS_STAMP(4);
   clear(h1);
   {
     NsPtr nx = p0;                                                                                // next phase starts with B(0)
     ns_phase<0, 4, 4, 1, NT1>(y, h1, h0, f0, f0, pool, p1, nx, c, k1, ik2);                      // A(1) | prep(0) -> f0
   }
+  NS_STAMP(5);
   // full units: B(k - 2) with f(k) | A(k) | prep(k - 1); k = 2 .. F - 1; the pairs alternate between (h0, f0) and (h1, f1)
   static_assert(F == 2 || F == 4, "two (conv tail) or four (ff modules) full pairs per wave");
   if constexpr (F == 4) {
@@ -268,11 +294,13 @@ DEV void ns_chain(f32x4 (&y)[NTT][KB], const u32x4_t* w1, const u32x4_t* w2, con
       clear(h0);
       ns_phase<4, 4, 4, 1, NT1>(y, h0, h1, f0, f1, pool, cu, nx, c, k1, ik2);                    // B(0; f0) | A(2) -> h0 | prep(1) -> f1
     }
+    NS_STAMP(6);
     {
       NsPtr cu{ptr(c.w + 4).b, ptr(c.w + 12).a}, nx{ptr(c.w + 8).b, nullptr};
       clear(h1);
       ns_phase<4, 4, 4, 1, NT1>(y, h1, h0, f1, f0, pool, cu, nx, c, k1, ik2);                    // B(1; f1) | A(3) -> h1 | prep(2) -> f0
     }
+    NS_STAMP(7);
   }
   // the left-over pair rides behind the last two full pairs: (hL, fL) = the pair that is free
   {
@@ -281,14 +309,17 @@ DEV void ns_chain(f32x4 (&y)[NTT][KB], const u32x4_t* w1, const u32x4_t* w2, con
     clear(h0);
     ns_phase<4, NR, 4, 1, NT1>(y, h0, h1, f0, f1, pool, cu, nx, c, k1, ik2);                     // B(kb; f0) | A(rem) -> h0 | prep(kb + 1) -> f1
   }
+  NS_STAMP(8);
   {
     NsPtr cu{ptr(c.w + 4 * (F - 1)).b, nullptr}, nx{ptr(prem).b, nullptr};
     ns_phase<4, 0, NR, 1, NT1>(y, h1, h0, f1, f0, pool, cu, nx, c, k1, ik2);                     // B(kb + 1; f1) | prep(rem) -> f0
   }
+  NS_STAMP(9);
   {
     NsPtr cu{ptr(prem).b, nullptr}, nx{nullptr, nullptr};
     ns_phase<NR, 0, 0, 0, NT1>(y, h0, h1, f0, f1, pool, cu, nx, c, k1, ik2);                     // B(rem; f0)
   }
+  NS_STAMP(10);
 }
 
 // partial outputs of the three tiles this wave does not own -> their owners; on return (after the barrier inside) the owner's
@@ -305,35 +336,55 @@ DEV void ns_reduce(f32x4 (&y)[NTT][KB], NsRed* red, const NsCtx& c) {
     for (int i = 0; i < KB; ++i) y[3][i] += red[c.w].v[s][i][c.lane];
 }
 
-// A plain layer  acc[s][j] = W[:, tile_j] x[tile of s]  for NCT column tiles (given as fragment pointers [KS][NT][2][64] + lane at the
-// tile) and the four token tiles; 2 NCT fragments per step, 12 NCT MFMAs
+// A plain layer  acc[j][s] = W[:, tile_j] x[tile of s]  for NCT column tiles (fragment pointers [KS][NT][2][64] + lane at the tile)
+// and the four token tiles: 2 NCT fragments and 12 NCT MFMAs per step.  The fragments stream through the same rotating pool as the
+// chains': position q = (step, lo of tile 0 .., hi of tile 0 ..) lives in pool[(OFF + q) % NP], is released after its last MFMA, and
+// the load of position q + NP -- of this group, or of the next one (NNXT column tiles at wn) -- is issued there.  The first NP
+// positions are in flight on entry (ns_prime_plain, or the group in front).
 template <int NCT>
-DEV void ns_plain(f32x4 (&acc)[NCT][NTT], const u32x4_t* const (&wt)[NCT], int NT, const NsCtx& c) {
-  static_assert((2 * NCT * KS) % NP == 0 || NCT == 1, "pool state");
-  u32x4_t pool[2 * NCT * 2];                  // two steps of fragments: step s in pool[(s & 1) * 2 NCT ...]
-  auto frag = [&](int j, int st, int term) { return wt[j][(size_t)(st * NT) * (2 * 64) + term * 64]; };
+DEV const u32x4_t* ns_frag_p(const u32x4_t* const (&wt)[NCT], int NT, int q) {      // q < 10 NCT
+  const int st = q / (2 * NCT), r = q % (2 * NCT), j = r % NCT, term = r < NCT ? 1 : 0;
+  return wt[j] + (size_t)(st * NT) * (2 * 64) + term * 64;
+}
+template <int NCT, int OFF>
+DEV void ns_prime_plain(u32x4_t (&pool)[NP], const u32x4_t* const (&wt)[NCT], int NT) {
+  static_for<0, NP>([&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    if constexpr (q < 10 * NCT) pool[(OFF + q) % NP] = ns_frag_p<NCT>(wt, NT, q)[0];
+  });
+}
+template <int NCT, int OFF, int NNXT>
+DEV void ns_plain(f32x4 (&acc)[NCT][NTT], u32x4_t (&pool)[NP], const u32x4_t* const (&wt)[NCT], const u32x4_t* const (&wn)[NNXT > 0 ? NNXT : 1],
+                  int NT, const NsCtx& c) {
+  constexpr int NPOS = 10 * NCT;
+  static_assert(NP <= NPOS, "a group is at least as long as the pool");
+  auto release = [&](auto Q) {
+    constexpr int q = decltype(Q)::value + NP;
+    if constexpr ((NS_DIAG & 2) != 0) return;
+    if constexpr (q < NPOS) pool[(OFF + q) % NP] = ns_frag_p<NCT>(wt, NT, q)[0];
+    else if constexpr (NNXT > 0) {
+      if constexpr (q - NPOS < 10 * NNXT) pool[(OFF + q) % NP] = ns_frag_p<(NNXT > 0 ? NNXT : 1)>(wn, NT, q - NPOS)[0];
+    }
+  };
   u32x4_t xh[2][NTT], xl[NTT];
-#pragma unroll
-  for (int j = 0; j < NCT; ++j) { pool[2 * j] = frag(j, 0, 1); pool[2 * j + 1] = frag(j, 0, 0); }
 #pragma unroll
   for (int s = 0; s < NTT; ++s) { xh[0][s] = c.xf[c.tt(s)].f[0][0][c.lane]; xl[s] = c.xf[c.tt(s)].f[0][1][c.lane]; }
   NS_FENCE;
   static_for<0, KS>([&](auto SI) {
     constexpr int st = decltype(SI)::value;
-    constexpr int cb = (st & 1) * 2 * NCT, nb = ((st + 1) & 1) * 2 * NCT;
     static_for<0, 3>([&](auto G) {
       constexpr int g = decltype(G)::value;
       static_for<0, NTT>([&](auto S) {
         constexpr int s = decltype(S)::value;
         static_for<0, NCT>([&](auto J) {
           constexpr int j = decltype(J)::value;
-          acc[j][s] = ns_mfma(pool[cb + 2 * j + (g == 0 ? 0 : 1)], g == 1 ? xl[s] : xh[st & 1][s], acc[j][s]);
-          if constexpr (j == NCT - 1 && st + 1 < KS) {
+          constexpr int q = st * 2 * NCT + (g == 0 ? 0 : NCT) + j;
+          acc[j][s] = ns_mfma(pool[(OFF + q) % NP], g == 1 ? xl[s] : xh[st & 1][s], acc[j][s]);
+          if constexpr (j == NCT - 1 && st + 1 < KS && !(NS_DIAG & 8)) {
             if constexpr (g == 1) xl[s] = c.xf[c.tt(s)].f[st + 1][1][c.lane];
             if constexpr (g == 0) xh[(st + 1) & 1][s] = c.xf[c.tt(s)].f[st + 1][0][c.lane];
-            // the next step's fragments: one tile's pair behind each token tile of the first group
-            if constexpr (g == 0 && s < NCT) { pool[nb + 2 * s] = frag(s, st + 1, 1); pool[nb + 2 * s + 1] = frag(s, st + 1, 0); }
           }
+          if constexpr (s == NTT - 1 && (g == 0 || g == 2)) release(std::integral_constant<int, q>());
           NS_FENCE;
         });
       });
@@ -355,10 +406,16 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void ns_ff1_qkv_kernel(Ff1QkvArgs
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, t = lane & 15;
   const NsCtx c{w, lane, g4, t, L.xf, L.tk};
+  NS_STAMP_DECL;
+  NS_STAMP(0);
   const int tok0 = blockIdx.x * 64;
   const int tok = tok0 + 16 * w + t;
   const bool live = tok < a.M;
   const size_t row = (size_t)min(tok, a.M - 1) * D;
+  const u32x4_t* w1 = reinterpret_cast<const u32x4_t*>(a.ns_w1);
+  const u32x4_t* w2 = reinterpret_cast<const u32x4_t*>(a.ns_w2);
+  u32x4_t pool[NP];
+  ns_prime_chain<18>(pool, w1, w, lane);              // in flight under the whole prologue
   f32x4 xs[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + row + 16 * kb + g4);
@@ -380,11 +437,20 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void ns_ff1_qkv_kernel(Ff1QkvArgs
   for (int i = 0; i < KB; ++i) y[3][i] = y[3][i] * splat4(tk.s2);
   ns_put_operand(L.xf[w], xs, lane, g4, tk.sx);
   if (g4 == 0) { L.tk[w].k1[t] = tk.k1; L.tk[w].ik2[t] = tk.ik2; }
+  NS_STAMP(1);
   __syncthreads();
-  const u32x4_t* w1 = reinterpret_cast<const u32x4_t*>(a.ns_w1);
-  const u32x4_t* w2 = reinterpret_cast<const u32x4_t*>(a.ns_w2);
-  ns_chain<18>(y, w1, w2, c);
+  NS_STAMP(2);
+  ns_chain<18>(y, pool, w1, w2, c, ns_stamp);
+  // q, k, v: 27 column tiles, wave w takes tiles w, w + 4, ... (7, 7, 7, 6; wave 3 repeats tile 26 and does not store it) in groups
+  // of 3, 2, 2; the first fragments are requested before the exchange of the partial outputs
+  const u32x4_t* wq = reinterpret_cast<const u32x4_t*>(a.ns_qkv) + lane;
+  auto tile_ptr = [&](int tile) { return wq + (size_t)min(tile, 26) * (2 * 64); };
+  const u32x4_t* const wt0[3] = {tile_ptr(w), tile_ptr(w + 4), tile_ptr(w + 8)};
+  const u32x4_t* const wt1[2] = {tile_ptr(w + 12), tile_ptr(w + 16)};
+  const u32x4_t* const wt2[2] = {tile_ptr(w + 20), tile_ptr(w + 24)};
+  ns_prime_plain<3, 0>(pool, wt0, 27);
   ns_reduce(y, L.red, c);
+  NS_STAMP(11);
 #pragma unroll
   for (int i = 0; i < KB; ++i) { y[3][i] = splat4(a.fc * tk.inv2) * y[3][i]; xs[i] = y[3][i]; }        // x1 = x0 + fc (ffn + b2)
   if (live) {
@@ -395,9 +461,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void ns_ff1_qkv_kernel(Ff1QkvArgs
   const float sx = pp_pow2_scale(ns_row_max(xs));
   ns_put_operand(L.xf[w], xs, lane, g4, sx);          // every wave is past the barrier of ns_reduce: the old operands are dead
   if (g4 == 0) L.tk[w].aux[t] = pp_recip_pow2(a.pp_sw_qkv * sx);
+  NS_STAMP(12);
   __syncthreads();
-  // q, k, v: 27 column tiles, wave w takes tiles w, w + 4, ... (7, 7, 7, 6) in groups of 3, 2, 2
-  const u32x4_t* wq = reinterpret_cast<const u32x4_t*>(a.ns_qkv) + lane;
+  NS_STAMP(13);
   float invq[NTT];
 #pragma unroll
   for (int s = 0; s < NTT; ++s) invq[s] = L.tk[c.tt(s)].aux[t];
@@ -420,36 +486,49 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void ns_ff1_qkv_kernel(Ff1QkvArgs
       }
     }
   };
-  auto tile_ptr = [&](int tile) { return wq + (size_t)min(tile, 26) * (2 * 64); };
+  auto zero = [&](auto& acc) {
+    for (auto& row : acc)
+      for (auto& v : row) v = splat4(0.f);
+  };
   {
     f32x4 acc[3][NTT];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int s = 0; s < NTT; ++s) acc[j][s] = splat4(0.f);
-    const u32x4_t* const wt[3] = {tile_ptr(w), tile_ptr(w + 4), tile_ptr(w + 8)};
-    ns_plain<3>(acc, wt, 27, c);
+    zero(acc);
+    ns_plain<3, 0, 2>(acc, pool, wt0, wt1, 27, c);
+    NS_STAMP(14);
     store(w, acc[0]); store(w + 4, acc[1]); store(w + 8, acc[2]);
   }
-#pragma unroll 1
-  for (int g = 0; g < 2; ++g) {
+  NS_STAMP(15);
+  {
     f32x4 acc[2][NTT];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int s = 0; s < NTT; ++s) acc[j][s] = splat4(0.f);
-    const int t0 = w + 12 + 8 * g;
-    const u32x4_t* const wt[2] = {tile_ptr(t0), tile_ptr(t0 + 4)};
-    ns_plain<2>(acc, wt, 27, c);
-    store(t0, acc[0]); store(t0 + 4, acc[1]);
+    zero(acc);
+    ns_plain<2, 30 % NP, 2>(acc, pool, wt1, wt2, 27, c);
+    store(w + 12, acc[0]); store(w + 16, acc[1]);
+  }
+  {
+    f32x4 acc[2][NTT];
+    zero(acc);
+    const u32x4_t* const none[1] = {nullptr};
+    ns_plain<2, 50 % NP, 0>(acc, pool, wt2, none, 27, c);
+    store(w + 20, acc[0]); store(w + 24, acc[1]);
+  }
+  NS_STAMP(16);
+  if constexpr ((NS_DIAG & 16) != 0) {
+    if (blockIdx.x == 7 && lane == 0) {
+      printf("NSSTAMP w%d:", w);
+      for (int i = 1; i <= 16; ++i) printf(" %d:%llu", i, ns_stamp[i] - ns_stamp[0]);
+      printf("\n");
+    }
   }
 }
 
 }  // namespace
 
 bool ns_enabled() {
-  // MI355ASR_NS=0: the pair-pipelined kernels of fused_pp.hip instead of the N-split ones
-  static const bool on = [] { const char* v = getenv("MI355ASR_NS"); return v ? atoi(v) != 0 : true; }();
+  // MI355ASR_NS=1: ff_module_1 + qkv (when no layer in front rides in the launch) on the N-split kernel instead of the pair-pipelined
+  // one.  OFF by default: measured 37.6 us against 35.2 (profiles/r06_ns_experiments.md) -- a 1 KB global_load_dwordx4 costs the
+  // issuing wave ~65 cycles of issue, which is why fused_pp.hip gives the weight stream to loader waves of its own.  Read at
+  // mi355asr_finalize_weights too: the plain-order fragments (2.4 MB per block) are only packed when the switch is on.
+  static const bool on = [] { const char* v = getenv("MI355ASR_NS"); return v ? atoi(v) != 0 : false; }();
   return on;
 }
 int launch_ns_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {

@@ -1199,6 +1199,7 @@ int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
     hipLaunchKernelGGL((pp_block_kernel<false, true, 0, false, false, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, TailFf2Args{}, b, OutGluArgs{});
     return 0;
   }
+  if (launch_ns_ff1_qkv(b, s) == 0) return 0;            // round 6: the N-split kernel (fused_ns.hip) when its fragments are packed
   hipLaunchKernelGGL((pp_block_kernel<false, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, TailFf2Args{}, b, OutGluArgs{});
   return 0;
 }

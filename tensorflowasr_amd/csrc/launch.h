@@ -323,6 +323,9 @@ struct Ff1QkvArgs {
   const float* pre_x = nullptr; const float* pre_pp = nullptr;
   float pre_sw = 1.f;
   int pre_chunks = 0;
+  // round 6 (fused_ns.hip): the same two-term fragments in plain order for the N-split kernels -- ff_module_1's W1aug [5][36][2][64]
+  // and W2 [18][9][2][64], q / k / v [5][27][2][64] (u32x4 per lane; api.hip: pack_half32); packed with pp_sc / pp_sw_qkv
+  const float *ns_w1 = nullptr, *ns_w2 = nullptr, *ns_qkv = nullptr;
 };
 struct OutGluArgs {
   const float* ctx; const float* x1; float* x2; float* u;
@@ -375,6 +378,9 @@ bool pp_dw_fold_ok(int T, int ksz);   // the tail kernels can take the depthwise
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
+// N-split versions (fused_ns.hip, round 6); -1: switched off (MI355ASR_NS=0), no plain-order fragments, or not this launch's shape
+bool ns_enabled();
+int launch_ns_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
 bool ff1_qkv_pp_selected(bool has_slabs, bool has_pp);   // fused.hip: q, k, v will come from the pair-pipelined producer (head-major layout possible)
 bool ff1_pre_selected();             // ... and launch_ff1_qkv will take that kernel (fused.hip) when the block has its streams
 bool pp_pre_fold_ok();

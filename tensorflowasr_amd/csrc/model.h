@@ -69,6 +69,9 @@ struct BlockDev {
   float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
   PpChainSc pp_ff1_sc, pp_tail_sc[2];      // the scales those streams were packed with (two-term fp16 scheme)
   float pp_sw_qkv = 1.f;
+  // the same two-term fragments of ff_module_1 (W1aug, W2) and q / k / v in plain order for the N-split kernel of fused_ns.hip
+  // (round 6; packed only with MI355ASR_NS=1), or null
+  const float *ns_ff1_w1 = nullptr, *ns_ff1_w2 = nullptr, *ns_qkv = nullptr;
 };
 
 struct Dims {
@@ -254,6 +257,8 @@ struct BlockOff {
   float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
   PpChainSc pp_ff1_sc, pp_tail_sc[2];
   float pp_sw_qkv = 1.f;
+  size_t ns_ff1_w1 = 0, ns_ff1_w2 = 0, ns_qkv = 0;
+  bool ns = false;
   bool split = false;
 };
 
@@ -300,8 +305,9 @@ std::vector<float> pack_conv2_half(const std::vector<float>& c2, int d, float ws
 void append_slabs(std::vector<float>& stream, const std::function<float(int, int)>& f, int K, int N, bool group_major);
 // pair-pipelined stream of one chain y += W2 act(W1 x + b1) (fused_pp.hip, tools/gen_pp.py): w1(k, n) with k <= K1 (row K1 = the
 // bias), H hidden features, w2(k, n) [H, 144]; and of a plain layer [145, 144 G] in column groups of nine tiles
-PpChainSc append_pp_chain(std::vector<float>& stream, const std::function<float(int, int)>& w1aug, int H, const std::function<float(int, int)>& w2);
-float append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups);
+PpChainSc append_pp_chain(std::vector<float>& stream, const std::function<float(int, int)>& w1aug, int H, const std::function<float(int, int)>& w2,
+                          std::vector<float>* plain1 = nullptr, std::vector<float>* plain2 = nullptr);
+float append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups, std::vector<float>* plain = nullptr);
 // W[K, N] as the slab ring of gemm_ring.hip, registered in ab.ring_pairs against the P16 pack at p16_off
 void put_ring(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int N, bool glu);
 void put_ring_head(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int K, int V);
@@ -323,7 +329,6 @@ int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, cons
 int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, Scratch& sc, int B, int T, float* out,
               hipStream_t s, const CrossAttn* cross = nullptr, const BlockDev* next = nullptr, bool* ff1_done = nullptr,
               bool skip_ff1 = false);
-float append_pp_plain(std::vector<float>& stream, const std::function<float(int, int)>& waug, int groups);   // api.hip
 bool block_takes_pre(const mi355asr_model* m, const BlockDev& w, size_t M);   // run_block(w, M rows) can take BlockOpts::pre_*
 void resolve_stack(StackDev& sd, const StackOff& so, const float* base, bool project, int V);   // api_chunk.hip
 int finalize_chunk(mi355asr_model* m, hipStream_t s);        // api_chunk.hip
