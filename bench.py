@@ -283,6 +283,26 @@ def parity_stamp(model, wav, B, L):
             "tokens": int(lens.sum()), "tolerance": 1e-3, "within_tolerance": bool(err < 1e-3 and decisive == 0)}
 
 
+def length_sweep(model, device, total_s=640.0, lengths=(5.0, 10.0, 15.0, 20.0, 30.0), steps=10):
+    """Round-5 review, item 3: no performance cliff past 10.24 s.  The headline model on utterances of 5 / 10 / 15 / 20 / 30 s at (about)
+    constant total audio -- B = floor(640 s / length) utterances per step, waveform -> greedy ids, input resident in HBM.  Attention is
+    the only part of the path whose work per frame grows with the length (T^2 per utterance); beyond 256 encoder frames it runs in key
+    blocks with an online softmax (attention_split_long_kernel)."""
+    out = []
+    for sec in lengths:
+        B, L = max(1, int(total_s / sec)), int(sec * 16000)       # (floor: 43 x 15 s would be 258 workgroups of the block kernels on 256 CUs)
+        wav = torch.from_numpy(synth_batch(0, B, L)).to(device)
+        model.prepare(B, L)
+        t = _timed(lambda: model.recognize(wav, reuse_buffers=True), steps, warmup=3)
+        out.append({"seconds": sec, "batch": B, "enc_frames": L // 640, "ms_per_step": round(t * 1e3, 3),
+                    "frames_per_s": round(B * (L // 160) / t, 1)})
+        del wav
+    ref = next(r["frames_per_s"] for r in out if r["seconds"] == 10.0)
+    for r in out:
+        r["vs_10s"] = round(r["frames_per_s"] / ref, 3)
+    return {"what": "ConformerCTC(S), waveform -> greedy ids, ~%g s of audio per step at every length, %d steps each" % (total_s, steps), "by_length": out}
+
+
 def block_flops(M, B, T, d, k, nblocks):
     """ALGORITHMIC flops per step of the block-level categories of a stack of `nblocks` ConformerBlocks over M = B * T rows"""
     one = {"ffn": 2 * (2.0 * 2 * M * d * 4 * d), "qkv": 3 * 2.0 * M * d * d, "attention": 2 * 2.0 * B * T * T * d,
@@ -1075,6 +1095,12 @@ def main():
             model.prepare(B, L)
         if world == 1:
             line["parity"] = parity_stamp(model, wav, B, L)
+        if world == 1 and not args.no_extra_configs:
+            try:
+                line["length_sweep"] = length_sweep(model, device)
+            except Exception as e:
+                line["length_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            model.prepare(B, L)
         if world == 1 and not args.no_exact_leg:
             line["exact_products"] = exact_products_leg(args, model, wav)
         if world == 1 and not args.no_cpu_baseline:

@@ -274,10 +274,210 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
   }
 }
 
+
+// ---- more than 256 keys (round 6) ------------------------------------------------------------------------------------------------------
+// multihead_attention.py:151-188 has no length limit; utterances beyond 10.24 s used to fall to the fp32-MFMA kernels (35 us per
+// launch already at 250 frames).  A workgroup of 16 or 8 waves = 256 / 128 queries of one (utterance, head) walks the keys in
+// blocks of 256 (in quarters / halves: one softmax update each) with an online softmax: per block the K / V fragments are staged as above (the next block's rows are requested into
+// registers before this block's products, so their latency hides under the MFMAs), S^T = K Q^T for the block's 16 key tiles, the
+// running maximum m and the per-lane partial sums are updated (p = exp2(s - m_new), everything carried so far times exp2(m_old -
+// m_new): the factor belongs to the lane's query, so the output accumulators -- features x this query -- scale per lane), then
+// O^T += V^T P^T.  Two workgroup barriers per block (fragments staged / fragments free).  Grid (ceil(Tq / 256 or 128), H, B).
+constexpr int LKB = 256;         // keys per block, worked through in halves / quarters (32 / 16 score registers)
+constexpr int LKT = LKB / 16;    // 16 key tiles
+constexpr int LST = LKB / 32;    // 8 steps of P V
+// LW = waves = query tiles per workgroup.  16 (256 queries, 128 registers: the block in quarters, its rows fetched at the top of the
+// iteration) stages K / V once per 256 queries and keeps four waves per SIMD; 8 (128 queries, 256 registers: halves, the next block's
+// rows prefetched into registers under the products) has twice the workgroups of 0.62 of the duration (measured, T = 375 ... 1000):
+// the launcher takes whichever fills the chip's rounds better (T = 375, 42 utterances: 38 against 47 us; T = 750, 21: 49 against 60).
+template <int TM, int LW>
+__global__ __launch_bounds__(LW * 64) void attention_split_long_kernel(AttnArgs a) {
+  constexpr int LTH = LW * 64;
+  constexpr bool LPRE = LW <= 8;
+  __shared__ __attribute__((aligned(16))) u32x4_t Kf[TM][LKT][64];
+  __shared__ __attribute__((aligned(16))) float Kt[LKT][64];
+  __shared__ __attribute__((aligned(16))) u32x4_t Vf[TM][LST][OT][64];
+  const float sq = TM == 2 ? a.h2_sq : 1.f, sk = TM == 2 ? a.h2_sk : 1.f, sv = TM == 2 ? a.h2_sv : 1.f;
+  constexpr float SP = TM == 2 ? 16384.f : 1.f;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = lane >> 4, g4 = g * 4, c = lane & 15;
+  const int T = a.Tk, TQ = a.Tq;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int ld = a.ldk, D = a.D;
+  const size_t khead = a.head_major ? ((size_t)b * a.H + h) * T * HS : (size_t)b * T * ld + h * HS;
+  const float* __restrict__ kbase = a.k + khead;
+  const float* __restrict__ vbase = a.v + khead;
+  const int qt = blockIdx.x * LW + wv;
+  const int tq = qt * 16 + c;
+  const float* qrow = a.head_major ? a.q + (((size_t)b * a.H + h) * TQ + min(tq, TQ - 1)) * HS
+                                   : a.q + ((size_t)b * TQ + min(tq, TQ - 1)) * a.ldq + h * HS;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const f32x4 qlo = ldg4(qrow + 8 * g), qhi = ldg4(qrow + 8 * g + 4);
+  const float qtl = qrow[32 + g] * (LOG2E * sq);
+  const Split8 qf = split_tm<TM>(qlo * splat4(LOG2E * sq), qhi * splat4(LOG2E * sq));
+  const f32x4 inv_qk = splat4(1.0f / (sq * sk));
+  const bool active = qt * 16 < TQ;
+
+  constexpr int NKE = LKT * 64, NKR = (NKE + LTH - 1) / LTH;             // K fragment entries (tile, lane): 896, two rounds
+  constexpr int NVE = LST * OT * 64, NVR = (NVE + LTH - 1) / LTH;        // V fragment entries: 1344, three rounds
+  f32x4 klo[NKR], khi[NKR];
+  float ktl[NKR];
+  float ve[NVR][8];
+  // rows of the key block that starts at kb0 into registers; keys >= T and the padding features are exact zeros.  32-bit element
+  // offsets from the (uniform) head base: one address register per load instead of two, and nothing per-load for the compiler to
+  // carry around the loop (with 64-bit pointers it kept all thirty addresses live: 256 registers and a spill)
+  const unsigned uld = (unsigned)ld;
+  auto fetch = [&](int kb0) {
+#pragma unroll
+    for (int it = 0; it < NKR; ++it) {
+      const int en = tid + it * LTH, kt = en >> 6, l = en & 63, kg = l >> 4, kc = l & 15;
+      const int skey = kb0 + 16 * kt + kc;
+      const unsigned ko = (unsigned)min(skey, T - 1) * uld + 8u * kg;
+      const bool ok = en < NKE && skey < T;
+      klo[it] = ok ? *reinterpret_cast<const f32x4*>(kbase + ko) : splat4(0.f);
+      khi[it] = ok ? *reinterpret_cast<const f32x4*>(kbase + ko + 4u) : splat4(0.f);
+      ktl[it] = ok ? kbase[(unsigned)min(skey, T - 1) * uld + 32u + kg] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NVR; ++it) {
+      const int en = tid + it * LTH;
+      const int s = en / (OT * 64), rem = en - s * (OT * 64), ot = rem >> 6, l = rem & 63, kg = l >> 4, fc = l & 15;
+      const int f = 16 * ot + fc;
+      const int key0 = kb0 + 32 * s + 4 * kg;
+      const unsigned vo = (unsigned)key0 * uld + (unsigned)f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int dk = 16 * (j >> 2) + (j & 3);
+        ve[it][j] = (en < NVE && f < HS && key0 + dk < T) ? vbase[vo + (unsigned)dk * uld] : 0.f;
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < NKR; ++it) {
+      const int en = tid + it * LTH;
+      if (en < NKE) {
+        const Split8 kf = split_tm<TM>(klo[it] * splat4(sk), khi[it] * splat4(sk));
+        (&Kf[0][0][0])[en] = kf.t[0];
+        (&Kf[1][0][0])[en] = kf.t[1];
+        if constexpr (TM == 3) (&Kf[2][0][0])[en] = kf.t[2];
+        (&Kt[0][0])[en] = ktl[it] * sk;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NVR; ++it) {
+      const int en = tid + it * LTH;
+      if (en < NVE) {
+        const f32x4 lo = {ve[it][0], ve[it][1], ve[it][2], ve[it][3]}, hi = {ve[it][4], ve[it][5], ve[it][6], ve[it][7]};
+        const Split8 vf = split_tm<TM>(lo * splat4(sv), hi * splat4(sv));
+        u32x4_t* dst = &Vf[0][0][0][0] + en;
+        dst[0] = vf.t[0];
+        dst[NVE] = vf.t[1];
+        if constexpr (TM == 3) dst[2 * NVE] = vf.t[2];
+      }
+    }
+  };
+
+  float m = -INFINITY, psum = 0.f;
+  f32x4 o[OT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i) o[i] = splat4(0.f);
+  if constexpr (LPRE) fetch(0);
+#pragma unroll 1
+  for (int kb0 = 0; kb0 < T; kb0 += LKB) {
+    if constexpr (!LPRE) fetch(kb0);
+    stage();
+    __syncthreads();                                   // this block's fragments staged
+    if constexpr (LPRE) {
+      if (kb0 + LKB < T) fetch(kb0 + LKB);             // the next block's rows: in flight under the products
+    }
+    if (active) {
+      const int nk = min(T - kb0, LKB), nkt = (nk + 15) / 16;
+      // the block in two halves of eight key tiles (one online-softmax update each): 32 score registers instead of 64 leave room
+      // for the next block's rows
+      constexpr int NH = LPRE ? 2 : 4, HT = LKT / NH, HS2 = LST / NH;      // (16-wave workgroups have 128 registers: quarters)
+#pragma unroll
+      for (int hb = 0; hb < NH; ++hb) {
+        if (hb * HT < nkt) {
+          f32x4 sc[HT];
+#pragma unroll
+          for (int k8 = 0; k8 < HT; ++k8) {
+            const int kt = hb * HT + k8;
+            if (kt < nkt) {
+              const u32x4_t kf[3] = {Kf[0][kt][lane], Kf[1][kt][lane], Kf[TM - 1][kt][lane]};
+              f32x4 acc = mma_tm<TM>(kf, qf, splat4(0.f));
+              sc[k8] = mfma4(Kt[kt][lane], qtl, acc);
+              if constexpr (TM == 2) sc[k8] = sc[k8] * inv_qk;
+            } else {
+              sc[k8] = splat4(-INFINITY);
+            }
+          }
+          float bm = -INFINITY;
+#pragma unroll
+          for (int k8 = 0; k8 < HT; ++k8) {
+            const int kt = hb * HT + k8;
+            if (kt < nkt && 16 * kt + 16 > nk) {
+              const int kk = 16 * kt + g4;
+              sc[k8].x = (kk + 0 < nk) ? sc[k8].x : -INFINITY;
+              sc[k8].y = (kk + 1 < nk) ? sc[k8].y : -INFINITY;
+              sc[k8].z = (kk + 2 < nk) ? sc[k8].z : -INFINITY;
+              sc[k8].w = (kk + 3 < nk) ? sc[k8].w : -INFINITY;
+            }
+            bm = fmaxf(bm, fmaxf(fmaxf(sc[k8].x, sc[k8].y), fmaxf(sc[k8].z, sc[k8].w)));
+          }
+          const float mn = fmaxf(m, group_max(bm));        // finite: the half holds at least one real key (hb * HT < nkt)
+          const float alpha = __builtin_amdgcn_exp2f(m - mn);      // very first half: exp2(-inf) = 0
+          m = mn;
+          float bs = 0.f;
+#pragma unroll
+          for (int k8 = 0; k8 < HT; ++k8) {
+            sc[k8].x = __builtin_amdgcn_exp2f(sc[k8].x - mn);
+            sc[k8].y = __builtin_amdgcn_exp2f(sc[k8].y - mn);
+            sc[k8].z = __builtin_amdgcn_exp2f(sc[k8].z - mn);
+            sc[k8].w = __builtin_amdgcn_exp2f(sc[k8].w - mn);
+            bs += (sc[k8].x + sc[k8].y) + (sc[k8].z + sc[k8].w);
+          }
+          psum = psum * alpha + bs;
+#pragma unroll
+          for (int i = 0; i < OT; ++i) o[i] = o[i] * splat4(alpha);
+          const int nst = (nkt + 1) / 2;
+#pragma unroll
+          for (int s4 = 0; s4 < HS2; ++s4) {
+            const int s = hb * HS2 + s4;
+            if (s < nst) {
+              const Split8 pf = split_tm<TM>(sc[2 * s4] * splat4(SP), sc[2 * s4 + 1] * splat4(SP));
+#pragma unroll
+              for (int i = 0; i < OT; ++i) {
+                const u32x4_t vf[3] = {Vf[0][s][i][lane], Vf[1][s][i][lane], Vf[TM - 1][s][i][lane]};
+                o[i] = mma_tm<TM>(vf, pf, o[i]);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                                   // every wave is done with this block's fragments
+  }
+  if (!active) return;
+  const float inv = (1.0f / group_sum(psum)) * (1.0f / (SP * sv));
+  if (tq < TQ) {
+    float* orow = a.ctx + ((size_t)b * TQ + tq) * D + h * HS;
+#pragma unroll
+    for (int i = 0; i < OT; ++i) {
+      if (16 * i + g4 < HS) stg4(orow + 16 * i + g4, o[i] * splat4(inv));
+    }
+  }
+}
+
 }  // namespace
 
+static bool attn_long_on() {
+  // MI355ASR_ATTN_LONG=0: more than 256 keys on the fp32-MFMA kernels (attention_lds_kernel / attention_kernel) as before round 6
+  static const bool on = [] { const char* v = getenv("MI355ASR_ATTN_LONG"); return v ? atoi(v) != 0 : true; }();
+  return on;
+}
 bool attention_split_applicable(int hs, const AttnArgs& a) {
-  return hs == HS && a.win_front < 0 && a.Tk <= TPK && a.Tk > 16 && a.Tq > 16 && a.ldk % 4 == 0 && a.ldq % 4 == 0;
+  return hs == HS && a.win_front < 0 && (a.Tk <= TPK || attn_long_on()) && a.Tk > 16 && a.Tq > 16 && a.ldk % 4 == 0 && a.ldq % 4 == 0;
 }
 
 static bool attn_three_env() {
@@ -295,9 +495,25 @@ int launch_attention_split(int hs, const AttnArgs& a, hipStream_t s) {
   const bool two = attention_split_two_term(hs, a);
   if (a.head_major && (!two || a.ldq != HS || a.ldk != HS)) return -1;       // head-major operands: this kernel's two-term form only
   note_scheme(two ? SCHEME_F16X2 : SCHEME_BF16X3);
+  const dim3 grid((qtiles + AW - 1) / AW, a.H, a.B);
+  if (a.Tk > TPK) {                      // key blocks of 256 with an online softmax; 256 or 128 queries per workgroup
+    static const int ncu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+    const long n16 = (long)((qtiles + 15) / 16) * a.H * a.B, n8 = (long)((qtiles + 7) / 8) * a.H * a.B;
+    const double c16 = (double)((n16 + ncu - 1) / ncu), c8 = 0.62 * (double)((n8 + ncu - 1) / ncu);      // rounds x duration of a round
+    if (c16 <= c8) {
+      const dim3 gl((qtiles + 15) / 16, a.H, a.B);
+      if (two) hipLaunchKernelGGL((attention_split_long_kernel<2, 16>), gl, dim3(1024), 0, s, a);
+      else hipLaunchKernelGGL((attention_split_long_kernel<3, 16>), gl, dim3(1024), 0, s, a);
+    } else {
+      const dim3 gl((qtiles + 7) / 8, a.H, a.B);
+      if (two) hipLaunchKernelGGL((attention_split_long_kernel<2, 8>), gl, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((attention_split_long_kernel<3, 8>), gl, dim3(512), 0, s, a);
+    }
+    return 0;
+  }
   if (two)
-    hipLaunchKernelGGL(attention_split_kernel<2>, dim3((qtiles + AW - 1) / AW, a.H, a.B), dim3(ATH), 0, s, a);
+    hipLaunchKernelGGL(attention_split_kernel<2>, grid, dim3(ATH), 0, s, a);
   else
-    hipLaunchKernelGGL(attention_split_kernel<3>, dim3((qtiles + AW - 1) / AW, a.H, a.B), dim3(ATH), 0, s, a);
+    hipLaunchKernelGGL(attention_split_kernel<3>, grid, dim3(ATH), 0, s, a);
   return 0;
 }

@@ -193,6 +193,28 @@ def test_config2_all_64_utterances_vs_the_reference_code_both_heads(bench_model,
     assert len(rep1) <= 8 and len(rep2) <= 0.002 * 16000
 
 
+def test_config2_model_on_64_utterances_of_20_s_vs_oracle(bench_model, torch_cuda):
+    """Round 6: the benched model on 64 x 20 s -- T = 500 encoder frames, beyond the 256 of the single-block attention kernel: the
+    key-block kernel (attention_split_long_kernel) at the benched batch size.  Utterances 0 and 63 against the fp64 oracle (logits,
+    every frame's arg-max, greedy ids), every utterance's in-kernel arg-max against its own logits."""
+    from tensorflowasr_amd.synthetic import synth_batch
+    m, w = bench_model
+    x = synth_batch(0, 64, 320000)
+    xd = torch_cuda.from_numpy(x).cuda()
+    ids, lens = m.recognize(xd)
+    ids, lens = ids.cpu().numpy().copy(), lens.cpu().numpy().copy()
+    logits, amax = m.ctc_logits(m.encode(xd), return_argmax=True)
+    logits, amax = logits.cpu().numpy(), amax.cpu().numpy()
+    assert logits.shape == (64, 500, 1332) and np.array_equal(amax, logits.argmax(-1))
+    pick = [0, 63]
+    cfg = dict(co.CONFORMER_S)
+    enc_ref = co.conformer_encoder(x[pick].astype(np.float64), w, cfg)
+    lg_ref = co.ctc_decoder(enc_ref, w, cfg)
+    err, report = assert_frames_and_ids(logits[pick], amax[pick], ids[pick], lens[pick], lg_ref, [500] * 2, 1331, tag="config2_model_64x20s")
+    print("64 x 20 s: logits max|d| %.3g, undecided frames %d / 1000" % (err, len(report)))
+    m.prepare(64, 160000)
+
+
 def test_config2_trained_ctc_decoder_at_batch64(torch_cuda):
     """the reference's exported CTCDecoder on 64 x 250 frames (the fused block kernels' row count) with inputs that make
     it emit tokens: argmax identical to the reference graph's own output (tests/golden/ctc_decoder_io.npz, 26 % of

@@ -303,8 +303,10 @@ def test_subsampling_dense_two_term_stream_at_5000_rows(torch_cuda):
     assert err < 2e-7 * np.abs(ref).max() + 1e-5
 
 
-@pytest.mark.parametrize("B,T", [(2, 50), (3, 250), (1, 300), (2, 7), (1, 16), (1, 17), (1, 750)])
+@pytest.mark.parametrize("B,T", [(2, 50), (3, 250), (1, 300), (2, 7), (1, 16), (1, 17), (1, 750), (2, 257), (1, 448), (1, 449), (3, 500)])
 def test_conformer_block_parity(enc2, B, T):
+    # T > 256 (round 6): attention_split_long_kernel -- key blocks of 224 with an online softmax: one key in the last block (257 = 224 +
+    # 33 and 449 = 2 x 224 + 1), exactly full blocks (448), a ragged last query tile (500 = 31 tiles + 4 rows), 750 = four blocks
     e, w, _ = enc2
     rng = np.random.default_rng(B * 1000 + T)
     x = rng.standard_normal((B, T, 144)).astype(np.float32)
@@ -1926,6 +1928,53 @@ for chunk, nchunks in ((8000, 20), (4000, 6), (10240, 5), (640, 9)):
                   % (chunk, rows, s_max, s_mean, l_max, l_mean, d.max(), d.mean()))
             assert s_max < 2e-2 and s_mean < 2e-3 and l_max < 2e-2 and l_mean < 2e-3
             assert s_mean < 2 * l_mean + 1e-5 and d.max() < 4e-2 and d.mean() < 2e-3
+
+
+def test_long_utterances_attention_in_key_blocks_against_the_fp32_kernels_and_the_oracle(torch_cuda):
+    """Round 6 (attention_split.hip: attention_split_long_kernel): utterances of more than 256 encoder frames keep the two-term
+    attention -- key blocks of 224, online softmax -- instead of falling to the fp32-MFMA kernels (multihead_attention.py:151-188 has no
+    length limit).  Encoder (2 blocks) on 3 x 20 s (T = 500: three key blocks, a ragged last query tile) and 2 x 30 s (T = 750, second
+    utterance scaled by 1e-3) against the fp64 oracle; the same in a build with MI355ASR_ATTN_LONG=0 (the old route) and with
+    MI355ASR_ATTN_TERMS=3 (three exact bf16 terms): all within the contract, the two routes within 2e-5 of each other."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, small_cfg, waves
+from tensorflowasr_amd.models import ConformerEncoder
+cfg = small_cfg(2)
+w = co.encoder_weights(cfg, seed=8)
+e = ConformerEncoder(**encoder_kwargs(cfg)); e.load_weights(w, by_name=False)
+out = {}
+for tag, B, L in (("t500", 3, 320000), ("t750", 2, 480000)):
+    x = waves(B, L, 900)
+    if tag == "t750": x[1] *= np.float32(1e-3)
+    got = e(x).cpu().numpy()
+    ref = co.conformer_encoder(x[:2].astype(np.float64), w, cfg)
+    out[tag] = got
+    print("RESULT %s %d %.3e" % (tag, got.shape[1], np.abs(got[:2] - ref).max()))
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, extra in (("long", {}), ("fp32", {"MI355ASR_ATTN_LONG": "0"}), ("three", {"MI355ASR_ATTN_TERMS": "3"})):
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(td, tag + ".npz")], env=dict(os.environ, **extra), capture_output=True,
+                               text=True, timeout=900, cwd=root)
+            lines = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+            assert len(lines) == 2, r.stderr[-3000:]
+            assert [int(l[1]) for l in lines] == [500, 750]
+            errs = [float(l[2]) for l in lines]
+            assert all(e < TOL for e in errs), (tag, errs)
+            res[tag] = (errs, np.load(os.path.join(td, tag + ".npz")))
+        for k in ("t500", "t750"):
+            d1 = float(np.abs(res["long"][1][k] - res["fp32"][1][k]).max())
+            d3 = float(np.abs(res["long"][1][k] - res["three"][1][k]).max())
+            print("%s: key-block kernel vs fp32-MFMA route %.3g, vs three-term %.3g; from the oracle %s / %s / %s"
+                  % (k, d1, d3, res["long"][0], res["fp32"][0], res["three"][0]))
+            assert 0.0 < d1 < 2e-5 and d3 < 2e-5
 
 
 def test_n_split_ff1_qkv_kernel_against_the_pair_pipelined_one_and_the_oracle(torch_cuda):
