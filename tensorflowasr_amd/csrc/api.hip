@@ -452,7 +452,7 @@ bool ring_packs_wanted(const mi355asr_model* m) {
 void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base) {
   for (const auto& pr : ab.ring_pairs) m->ring_of[base + pr.first] = base + pr.second;
   m->head_of.clear();
-  for (const auto& hp : ab.head_pairs) m->head_of[base + hp.p16] = {base + hp.slabs, hp.groups, base + hp.pp, hp.pp_sw};
+  for (const auto& hp : ab.head_pairs) m->head_of[base + hp.p16] = {base + hp.slabs, hp.groups, base + hp.pp, hp.pp_sw, base + hp.ns};
 }
 void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int d, int V, const float* bias) {
   if (d != 144 || V < 1) return;
@@ -462,15 +462,19 @@ void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(
   const size_t o_st = ab.put(st);
   // the same matrix as the two-term fp16 stream of pp_head_kernel: column groups of nine tiles, five plain ring slots each,
   // the bias in row 144
-  std::vector<float> pp;
-  const float sw = append_pp_plain(pp, [&](int k, int n) { return n < V ? (k < d ? f(k, n) : bias[n]) : 0.f; }, groups);
-  ab.head_pairs.push_back({p16_off, o_st, groups, ab.put(pp), sw});
+  std::vector<float> pp, plain;
+  const float sw = append_pp_plain(pp, [&](int k, int n) { return n < V ? (k < d ? f(k, n) : bias[n]) : 0.f; }, groups, &plain);
+  const size_t o_pp = ab.put(pp);
+  ab.head_pairs.push_back({p16_off, o_st, groups, o_pp, sw, ab.put(plain)});
 }
 int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s) {
   // a launch of the ring kernel costs as much for 250 rows as for 16 000: from 2048 rows on
-  if (m->cfg.gemm_dtype != 0 || m->head_of.empty() || hd.M < 2048) return -1;
+  if (m->cfg.gemm_dtype != 0 || m->head_of.empty()) return -1;
   const auto it = m->head_of.find(hd.wp);
   if (it == m->head_of.end()) return -1;
+  // round 6, small batches: one 16-token tile per workgroup, the column tiles split over its waves (fused_ns.hip)
+  if (launch_ns1_head(hd, it->second.ns, it->second.pp_sw, it->second.groups, s) == 0) return 0;
+  if (hd.M < 2048) return -1;
   if (launch_pp_head(hd, it->second.pp, it->second.pp_sw, it->second.groups, s) == 0) return 0;
   return launch_head_ld(hd, it->second.slabs, it->second.groups, s);
 }
@@ -593,8 +597,8 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
                                   [&](int kk, int n) { return f2[(size_t)kk * d + n]; }, &n1, &n2);
     o.pp_sw_qkv = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? qkv_at(kk, n) : qb[n]; }, 3, &nq);
     o.pp_ff1 = ab.put(pp);
-    o.ns = ns_enabled();                 // the same fragments in plain order, for the N-split kernel (fused_ns.hip; off by default)
-    if (o.ns) { o.ns_ff1_w1 = ab.put(n1); o.ns_ff1_w2 = ab.put(n2); o.ns_qkv = ab.put(nq); }
+    o.ns = true;                         // the same fragments in plain order, for the N-split kernels (fused_ns.hip: small batches)
+    o.ns_ff1_w1 = ab.put(n1); o.ns_ff1_w2 = ab.put(n2); o.ns_qkv = ab.put(nq);
     // Operand bounds for the two-term attention kernel: a LayerNorm output lies in sqrt(d - 1) |gamma_i| + |beta_i|, so
     // |q_n|, |k_n|, |v_n| <= sum_i |W_in| (sqrt(d - 1) |gamma_i| + |beta_i|) + |b_n| (q times the query scale and log2 e,
     // which the kernel folds into it)
@@ -634,10 +638,11 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
     // gate tiles (two groups), five plain ring slots each, the biases in row 144
     const auto& ob = keras_mha ? T(a + "/mha/attention_output/bias") : T(a + "/mha/projection_bias");
     const auto& p1b = T(c + "/pw_conv_1/bias");
-    std::vector<float> pp;
-    o.pp_sw_out = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? pk2[(size_t)kk * d + n] : ob[n]; }, 1);
-    o.pp_sw_pw1 = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? pw1[(size_t)kk * 2 * d + n] : p1b[n]; }, 2);
+    std::vector<float> pp, no, np1;
+    o.pp_sw_out = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? pk2[(size_t)kk * d + n] : ob[n]; }, 1, &no);
+    o.pp_sw_pw1 = append_pp_plain(pp, [&](int kk, int n) { return kk < d ? pw1[(size_t)kk * 2 * d + n] : p1b[n]; }, 2, &np1);
     o.pp_og = ab.put(pp);
+    o.ns_out = ab.put(no); o.ns_pw1 = ab.put(np1);
   }
   o.pw1_b = ab.put(T(c + "/pw_conv_1/bias"));
   o.dw_w = ab.put(T(c + "/dw_conv/depthwise_kernel"));  // [k, d, 1] == [k][d]
@@ -684,13 +689,14 @@ BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, i
       const auto &g = T(c + "/bn/gamma"), &b = T(c + "/bn/beta"), &mu = T(c + "/bn/moving_mean"), &var = T(c + "/bn/moving_variance");
       for (int i = 0; i < 2 * d; ++i) { bs[i] = g[i] / std::sqrt(var[i] + kBnEps); bt[i] = b[i] - mu[i] * bs[i]; }
     }
-    std::vector<float> pp;
+    std::vector<float> pp, c1, c2, n1, n2;
     o.pp_tail_sc[0] = append_pp_chain(pp, [&](int kk, int n) {
       return kk < d ? (float)((double)pc[(size_t)kk * 2 * d + n] * (double)bs[n]) : (float)((double)pcb[n] * (double)bs[n] + (double)bt[n]);
-    }, 2 * d, [&](int kk, int n) { return pw2[(size_t)kk * d + n]; });
+    }, 2 * d, [&](int kk, int n) { return pw2[(size_t)kk * d + n]; }, &c1, &c2);
     o.pp_tail_sc[1] = append_pp_chain(pp, [&](int kk, int n) { return kk < d ? f1[(size_t)kk * 4 * d + n] : fb1[n]; }, 4 * d,
-                                      [&](int kk, int n) { return f2[(size_t)kk * d + n]; });
+                                      [&](int kk, int n) { return f2[(size_t)kk * d + n]; }, &n1, &n2);
     o.pp_tail = ab.put(pp);
+    o.ns_cv_w1 = ab.put(c1); o.ns_cv_w2 = ab.put(c2); o.ns_ff2_w1 = ab.put(n1); o.ns_ff2_w2 = ab.put(n2);
   }
   o.pw2_b = ab.put(T(c + "/pw_conv_2/bias"));
   o.ln_g = ab.put(T(p + "/ln/gamma"));
@@ -717,7 +723,10 @@ BlockDev resolve(const BlockOff& o, const float* base) {
   b.cv_ln_g = base + o.cv_ln_g; b.cv_ln_b = base + o.cv_ln_b;
   b.pw1_wp = base + o.pw1_wp; b.pw1_b = base + o.pw1_b;
   if (o.split) { b.og_slabs = base + o.og_slabs; b.ff1_slabs = base + o.ff1_slabs; b.tail_slabs = base + o.tail_slabs; b.pp_ff1 = base + o.pp_ff1; b.pp_tail = base + o.pp_tail; b.pp_ff1_sc = o.pp_ff1_sc; b.pp_sw_qkv = o.pp_sw_qkv; b.pp_tail_sc[0] = o.pp_tail_sc[0]; b.pp_tail_sc[1] = o.pp_tail_sc[1]; b.pp_og = base + o.pp_og; b.pp_sw_out = o.pp_sw_out; b.pp_sw_pw1 = o.pp_sw_pw1; }
-  if (o.ns) { b.ns_ff1_w1 = base + o.ns_ff1_w1; b.ns_ff1_w2 = base + o.ns_ff1_w2; b.ns_qkv = base + o.ns_qkv; }
+  if (o.ns) {
+    b.ns_ff1_w1 = base + o.ns_ff1_w1; b.ns_ff1_w2 = base + o.ns_ff1_w2; b.ns_qkv = base + o.ns_qkv; b.ns_out = base + o.ns_out; b.ns_pw1 = base + o.ns_pw1;
+    b.ns_cv_w1 = base + o.ns_cv_w1; b.ns_cv_w2 = base + o.ns_cv_w2; b.ns_ff2_w1 = base + o.ns_ff2_w1; b.ns_ff2_w2 = base + o.ns_ff2_w2;
+  }
   b.att_h2[0] = o.att_h2[0]; b.att_h2[1] = o.att_h2[1]; b.att_h2[2] = o.att_h2[2];
   b.dw_w = base + o.dw_w;
   b.pc_w1p = base + o.pc_w1p; b.pc_b1 = base + o.pc_b1;
@@ -967,6 +976,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k2.out_wp = w.out_wp; k2.out_b = w.out_b; k2.cv_ln_g = w.cv_ln_g; k2.cv_ln_b = w.cv_ln_b;
     k2.pw1_wp = w.pw1_wp; k2.pw1_b = w.pw1_b; k2.eps = kLnEps; k2.M = M;
     k2.og_slabs = w.og_slabs; k2.pp_slabs = w.pp_og; k2.pp_sw_out = w.pp_sw_out; k2.pp_sw_pw1 = w.pp_sw_pw1;
+    k2.ns_out = w.ns_out; k2.ns_pw1 = w.ns_pw1;
     DwArgs dwa{};
     dwa.u = sc.u; dwa.y = sc.dw; dwa.wd = w.dw_w; dwa.B = B; dwa.T = T; dwa.D = d;
     dwa.pad_left = bo.causal ? ksz - 1 : (ksz - 1) / 2;
@@ -984,6 +994,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];
     k4.ff_w2p = w.ff_w2p[1]; k4.ff_b2 = w.ff_b2[1]; k4.ln_g = w.ln_g; k4.ln_b = w.ln_b;
     k4.fc = fc; k4.eps = kLnEps; k4.M = M; k4.slabs = w.tail_slabs; k4.pp_slabs = w.pp_tail; k4.pp_sc[0] = w.pp_tail_sc[0]; k4.pp_sc[1] = w.pp_tail_sc[1];
+    k4.ns_cv_w1 = w.ns_cv_w1; k4.ns_cv_w2 = w.ns_cv_w2; k4.ns_ff_w1 = w.ns_ff2_w1; k4.ns_ff_w2 = w.ns_ff2_w2;
     // The folded launches (OGF) read x1 from sc.xb, INCLUDING the halo frames of the neighbouring workgroups (the window of
     // the depthwise conv), so nothing in such a launch may write sc.xb: a workgroup that starts after its neighbour has
     // stored the block output there would read y as x1 (grids above one workgroup per CU).  x2 is never materialised in

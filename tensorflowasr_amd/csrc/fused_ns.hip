@@ -58,6 +58,7 @@ constexpr int NTT = 4;          // token tiles per workgroup
 // bit 4: cycle stamps (s_memtime) at the phase boundaries of workgroup 7, printed per wave at the end of the kernel
 #define NS_STAMP(i) do { if constexpr ((NS_DIAG & 16) != 0) { if (blockIdx.x == 7) ns_stamp[i] = __builtin_readcyclecounter(); } } while (0)
 #define NS_STAMP_DECL unsigned long long ns_stamp[24] = {}
+#define NS1_STAMP(i) do { if constexpr ((NS_DIAG & 32) != 0) { if (blockIdx.x == 3 && blockIdx.y == 0) st1[i] = __builtin_readcyclecounter(); } } while (0)
 
 DEV f32x4 ns_mfma(u32x4_t w, u32x4_t x, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, x), acc, 0, 0, 0);
@@ -521,6 +522,551 @@ __global__ __launch_bounds__(BLOCK_THREADS, 1) void ns_ff1_qkv_kernel(Ff1QkvArgs
   }
 }
 
+
+// =================================================================================================================================
+// One 16-token tile per workgroup (round 6): the same split for SMALL batches -- one utterance per call is what test_asr.py does
+// (test_asr.py:186-219), and there the pair-pipelined kernels keep 4 of 256 CUs busy for 60 us per launch: a consumer wave walks
+// the whole 2.4 MB weight stream for its 16 tokens whatever the batch is.  Here a workgroup of NW waves owns ONE tile; every wave
+// holds the tile's rows (identical registers in all waves: LayerNorm, scales and the operand split are computed redundantly, no
+// exchange), wave w computes hidden pairs w, w + NW, ... and the column tiles w, w + NW, ... of the plain layers; partial outputs
+// meet in LDS (NW x 9 KB) and every wave adds them IN THE SAME ORDER, so all waves continue with bit-identical rows.  The weight
+// stream of a block is spread over 16 tiles x NW waves instead of 4 consumer waves: what bounds a launch is ~65 cycles of issue
+// per 1 KB fragment and wave (profiles/r06_ns_experiments.md), i.e. 2.4 MB / NW per wave.
+constexpr int NP1 = 10;         // fragments in flight per wave here: eight waves per workgroup have 256 registers each
+template <int NW>
+struct Ns1Lds {
+  f32x4 red[NW][KB][64];            // partial outputs (chains, the layer in front) / column tiles of a plain layer, one slab per wave
+  f32x4 sum[KB][64];                // their sums
+  float par[12][D];                 // the kernel's parameter vectors (LayerNorm gamma / beta, biases): one L2 round trip at the start
+};
+
+// partial outputs of all NW waves -> their sum, the same in every wave (fixed order 0, 1, ...); `live` waves contributed
+template <int NW>
+DEV void ns1_allreduce(f32x4 (&y)[KB], Ns1Lds<NW>& L, int w, int lane) {
+  // reduce-scatter, then all-gather: wave w sums column tiles w, w + NW, ... over the NW partials (fixed order) and publishes them;
+  // every wave then reads the nine sums -- 8 + 9 fragment reads per wave instead of 72 (the all-to-all moved 576 KB through LDS
+  // per exchange: 4 - 8 k cycles by the stamps)
+  __syncthreads();                                    // the previous exchange has been read by everyone
+#pragma unroll
+  for (int i = 0; i < KB; ++i) L.red[w][i][lane] = y[i];
+  __syncthreads();
+  for (int i = w; i < KB; i += NW) {
+    f32x4 a = L.red[0][i][lane];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) a += L.red[k][i][lane];
+    L.sum[i][lane] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < KB; ++i) y[i] = L.sum[i][lane];
+}
+
+// One phase of a chain for ONE token tile (operands in registers):
+//   B part (HB): y[tile] += W2[pair b][tile] fB        27 MFMAs, tiles in groups of three so that an accumulator rests two MFMAs
+//   A part (HA): hA[0..1] += W1[:, pair a] x            30 MFMAs
+//   prep   (HP): fP = split(swish(hP[0..1]))             40 slots behind the MFMAs (all of them in a row when the phase has none)
+// positions: B = per group (lo of three tiles, hi of three tiles), 18 + 2 idle; A = per step (b0 lo, b1 lo, b0 hi, b1 hi)
+DEV const u32x4_t* ns1_frag_b(const NsPtr& p, int q) {        // q < 18
+  const int g = q / 6, j = q % 6;
+  return p.b + ((3 * g + j % 3) * 2 + (j < 3 ? 1 : 0)) * 64;
+}
+template <bool HB, bool HA, bool HP, int NXT, int NT1>
+DEV void ns1_phase(f32x4 (&y)[KB], f32x4 (&hA)[2], f32x4 (&hP)[2], const Split8& fB, Split8& fP, const Split8 (&xf)[KS],
+                   u32x4_t (&pool)[NP1], const NsPtr& cur, const NsPtr& nxt, float k1, float ik2) {
+  constexpr int NB = HB ? 20 : 0, NA = HA ? 20 : 0, NPOS = NB + NA;
+  constexpr int MB = HB ? 27 : 0, MA = HA ? 30 : 0, M = MB + MA, SL = HP ? PREP2_SLOTS : 0;
+  auto load_pos = [&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    if constexpr (q < NPOS) {
+      if constexpr (q < NB) {
+        if constexpr (q < 18) pool[q % NP1] = ns1_frag_b(cur, q)[0];
+      } else {
+        pool[q % NP1] = ns_frag_a<NT1>(cur, q - NB)[0];
+      }
+    } else if constexpr (NXT == 1) {
+      if constexpr (q - NPOS < 18) pool[q % NP1] = ns1_frag_b(nxt, q - NPOS)[0];
+    } else if constexpr (NXT == 2) {
+      pool[q % NP1] = ns_frag_a<NT1>(nxt, q - NPOS)[0];
+    }
+  };
+  auto release = [&](auto Q) { load_pos(std::integral_constant<int, decltype(Q)::value + NP1>()); };
+  Prep2Ctx pc{hP[0], hP[1], fP, k1, ik2, 0.f, 0.f, 0.f, 0.f, 0u};
+  auto slot = [&](auto S) {
+    prep2_slot<decltype(S)::value>(pc);
+    asm volatile("" : "+v"(pc.ta), "+v"(pc.tb), "+v"(pc.m0), "+v"(pc.m1), "+v"(pc.hp), "+v"(pc.lo), "+v"(pc.hi), "+v"(pc.out.t[0]), "+v"(pc.out.t[1]));
+  };
+  auto prep_after = [&](auto Mi) {
+    constexpr int m = decltype(Mi)::value;
+    if constexpr (SL > 0 && M > 0) {
+      constexpr int lo = (m * SL) / M, hi = ((m + 1) * SL) / M;
+      static_for<lo, hi>(slot);
+    }
+  };
+  if constexpr (M == 0 && SL > 0) {                  // a wave with a single pair: nothing to hide the activation behind
+    static_for<0, SL>(slot);
+    static_assert(NPOS == 0 || true, "");
+  }
+  if constexpr (HB) {
+    static_for<0, 3>([&](auto Gi) {
+      constexpr int g = decltype(Gi)::value;
+      static_for<0, 3>([&](auto Pi) {
+        constexpr int pr = decltype(Pi)::value;                     // 0: lo x hi, 1: hi x lo, 2: hi x hi
+        static_for<0, 3>([&](auto Ti) {
+          constexpr int i = decltype(Ti)::value, tile = 3 * g + i;
+          constexpr int m = (g * 3 + pr) * 3 + i;
+          constexpr int q = 6 * g + (pr == 0 ? 0 : 3) + i;
+          y[tile] = ns_mfma(pool[q % NP1], pr == 1 ? fB.t[1] : fB.t[0], y[tile]);
+          prep_after(std::integral_constant<int, m>());
+          if constexpr (i == 2 && pr == 0) { release(std::integral_constant<int, 6 * g>()); release(std::integral_constant<int, 6 * g + 1>()); release(std::integral_constant<int, 6 * g + 2>()); }
+          if constexpr (i == 2 && pr == 2) {
+            release(std::integral_constant<int, 6 * g + 3>()); release(std::integral_constant<int, 6 * g + 4>()); release(std::integral_constant<int, 6 * g + 5>());
+            if constexpr (g == 2) { release(std::integral_constant<int, 18>()); release(std::integral_constant<int, 19>()); }
+          }
+          NS_FENCE;
+        });
+      });
+    });
+  }
+  if constexpr (HA) {
+    static_for<0, KS>([&](auto SI) {
+      constexpr int st = decltype(SI)::value;
+      static_for<0, 3>([&](auto Pi) {
+        constexpr int pr = decltype(Pi)::value;
+        static_for<0, 2>([&](auto Bi) {
+          constexpr int b = decltype(Bi)::value;
+          constexpr int m = MB + (st * 3 + pr) * 2 + b;
+          constexpr int q = NB + 4 * st + (pr == 0 ? 0 : 2) + b;
+          hA[b] = ns_mfma(pool[q % NP1], pr == 1 ? xf[st].t[1] : xf[st].t[0], hA[b]);
+          prep_after(std::integral_constant<int, m>());
+          if constexpr (b == 1 && pr == 0) { release(std::integral_constant<int, NB + 4 * st>()); release(std::integral_constant<int, NB + 4 * st + 1>()); }
+          if constexpr (b == 1 && pr == 2) { release(std::integral_constant<int, NB + 4 * st + 2>()); release(std::integral_constant<int, NB + 4 * st + 3>()); }
+          NS_FENCE;
+        });
+      });
+    });
+  }
+}
+
+// y += W2 act(W1aug [x ; 1]) for one tile; this wave's pairs w, w + NW, ... (n of them, possibly none) as a software pipeline with
+// a run-time trip count (the roles of the two hidden / operand register sets are swapped by copies: 16 moves per unit)
+template <int P, int NW>
+DEV void ns1_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS], const u32x4_t* w1, const u32x4_t* w2, int w, int lane, float k1, float ik2) {
+  constexpr int NT1 = 2 * P;
+  const int n = w < P ? (P - w + NW - 1) / NW : 0;
+  if (n == 0) return;
+  auto ptr = [&](int k) { const int pair = w + NW * k; return NsPtr{w2 + (size_t)pair * (KB * 2 * 64) + lane, w1 + (size_t)(2 * pair) * (2 * 64) + lane}; };
+  u32x4_t pool[NP1];
+  const f32x4 zero = splat4(0.f);
+  f32x4 hacc[2] = {zero, zero}, hprep[2];
+  Split8 fuse, fbuild;
+  {
+    const NsPtr p0 = ptr(0);
+    static_for<0, NP1>([&](auto Q) { constexpr int q = decltype(Q)::value; pool[q] = ns_frag_a<NT1>(p0, q)[0]; });
+    if (n == 1) {
+      ns1_phase<false, true, false, 1, NT1>(y, hacc, hprep, fuse, fbuild, xf, pool, p0, p0, k1, ik2);           // A(0); then its own W2
+      hprep[0] = hacc[0]; hprep[1] = hacc[1];
+      ns1_phase<false, false, true, 0, NT1>(y, hacc, hprep, fuse, fbuild, xf, pool, p0, p0, k1, ik2);          // prep(0)
+      ns1_phase<true, false, false, 0, NT1>(y, hacc, hprep, fbuild, fuse, xf, pool, p0, p0, k1, ik2);          // B(0)
+      return;
+    }
+    const NsPtr p1 = ptr(1);
+    ns1_phase<false, true, false, 2, NT1>(y, hacc, hprep, fuse, fbuild, xf, pool, p0, p1, k1, ik2);             // A(0)
+    hprep[0] = hacc[0]; hprep[1] = hacc[1]; hacc[0] = zero; hacc[1] = zero;
+    ns1_phase<false, true, true, 1, NT1>(y, hacc, hprep, fuse, fbuild, xf, pool, p1, p0, k1, ik2);              // A(1) | prep(0)
+    fuse = fbuild; hprep[0] = hacc[0]; hprep[1] = hacc[1];
+  }
+#pragma unroll 1
+  for (int k = 2; k < n; ++k) {                       // B(k - 2; fuse) | A(k) | prep(k - 1) -> fbuild
+    const NsPtr cu{ptr(k - 2).b, ptr(k).a}, nx{ptr(k - 1).b, nullptr};
+    hacc[0] = zero; hacc[1] = zero;
+    ns1_phase<true, true, true, 1, NT1>(y, hacc, hprep, fuse, fbuild, xf, pool, cu, nx, k1, ik2);
+    fuse = fbuild; hprep[0] = hacc[0]; hprep[1] = hacc[1];
+  }
+  {
+    const NsPtr cu{ptr(n - 2).b, nullptr}, nx{ptr(n - 1).b, nullptr};
+    ns1_phase<true, false, true, 1, NT1>(y, hacc, hprep, fuse, fbuild, xf, pool, cu, nx, k1, ik2);              // B(n - 2) | prep(n - 1)
+    ns1_phase<true, false, false, 0, NT1>(y, hacc, hprep, fbuild, fuse, xf, pool, nx, nx, k1, ik2);             // B(n - 1)
+  }
+}
+
+// plain layer for one tile: acc[j] = W[:, tile_j] x for three column tiles, fragments through a two-step pool of its own
+DEV void ns1_plain3(f32x4 (&acc)[3], const u32x4_t* const (&wt)[3], int NT, const Split8 (&xf)[KS]) {
+  u32x4_t pl[2][6];
+  auto frag = [&](int j, int st, int term) { return wt[j][(size_t)(st * NT) * (2 * 64) + term * 64]; };
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { pl[st][j] = frag(j, st, 1); pl[st][3 + j] = frag(j, st, 0); }
+  NS_FENCE;
+  static_for<0, KS>([&](auto SI) {
+    constexpr int st = decltype(SI)::value;
+    static_for<0, 3>([&](auto Pi) {
+      constexpr int pr = decltype(Pi)::value;
+      static_for<0, 3>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        acc[j] = ns_mfma(pl[st & 1][(pr == 0 ? 0 : 3) + j], pr == 1 ? xf[st].t[1] : xf[st].t[0], acc[j]);
+        if constexpr (st + 2 < KS && j == 2) {
+          if constexpr (pr == 0) { pl[st & 1][0] = frag(0, st + 2, 1); pl[st & 1][1] = frag(1, st + 2, 1); pl[st & 1][2] = frag(2, st + 2, 1); }
+          if constexpr (pr == 2) { pl[st & 1][3] = frag(0, st + 2, 0); pl[st & 1][4] = frag(1, st + 2, 0); pl[st & 1][5] = frag(2, st + 2, 0); }
+        }
+        NS_FENCE;
+      });
+    });
+  });
+}
+
+// the rows of this workgroup's tile: frame f0 + t of utterance b (T > 0: tiles never cross an utterance), or token 16 blockIdx.x + t
+struct Ns1Tile { int tok; bool live; size_t row; };
+DEV Ns1Tile ns1_tile(int M, int T, int t) {
+  Ns1Tile r;
+  if (T > 0) {
+    const int f = blockIdx.x * 16 + t;
+    r.live = f < T;
+    r.tok = blockIdx.y * T + min(f, T - 1);
+  } else {
+    r.tok = blockIdx.x * 16 + t;
+    r.live = r.tok < M;
+    r.tok = min(r.tok, M - 1);
+  }
+  r.row = (size_t)r.tok * D;
+  return r;
+}
+DEV void ns1_split_rows(Split8 (&xf)[KS], const f32x4 (&xs)[KB], int g4, float sx) {       // fused_pp.hip: split_operand
+  const f32x4 s4 = splat4(sx);
+#pragma unroll
+  for (int s = 0; s < KS - 1; ++s) xf[s] = split8(xs[2 * s] * s4, xs[2 * s + 1] * s4);
+  f32x4 oh = splat4(0.f);
+  oh.x = g4 == 0 ? sx : 0.0f;
+  xf[KS - 1] = split8(xs[KB - 1] * s4, oh);
+}
+DEV void ns1_ln(f32x4 (&xs)[KB], const float* ga, const float* be, int g4, float eps) {      // parameters from the LDS stash
+  float mean, rstd;
+  ln_stats<KB>(xs, eps, mean, rstd);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = (xs[kb] - splat4(mean)) * splat4(rstd) * lds4(ga, kb, g4) + lds4(be, kb, g4);
+}
+// up to twelve 144-float vectors into L.par (null pointers are skipped); the caller's next __syncthreads() publishes them
+template <int NW, int N>
+DEV void ns1_stash(Ns1Lds<NW>& L, const float* const (&src)[N]) {
+  static_assert(N <= 12, "L.par");
+  for (int i = threadIdx.x; i < N * D; i += NW * 64) {
+    const int v = i / D;
+    if (src[v]) L.par[v][i - v * D] = src[v][i - v * D];
+  }
+}
+
+// ff_module_1 + q / k / v of the tile in xs (x0 rows, identical in every wave): stores x1 (wave 0) and qkv (each wave its tiles)
+template <int NW>
+DEV void ns1_ff1_qkv(const Ff1QkvArgs& a, Ns1Lds<NW>& L, f32x4 (&xs)[KB], const Ns1Tile& tl, int w, int lane, int g4) {
+  f32x4 y[KB];
+  const float inv_fc = 1.0f / a.fc;
+  Split8 xf[KS];
+  {
+    f32x4 r[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) r[i] = lds4(L.par[2], i, g4) + splat4(inv_fc) * xs[i];
+    ns1_ln(xs, L.par[0], L.par[1], g4, a.eps);
+    const NsTok tk = ns_chain_scales(a.pp_sc, ns_row_max(xs));
+#pragma unroll
+    for (int i = 0; i < KB; ++i) y[i] = w == 0 ? r[i] * splat4(tk.s2) : splat4(0.f);       // residual + bias ride in wave 0's partial
+    ns1_split_rows(xf, xs, g4, tk.sx);
+    ns1_chain<18, NW>(y, xf, reinterpret_cast<const u32x4_t*>(a.ns_w1), reinterpret_cast<const u32x4_t*>(a.ns_w2), w, lane, tk.k1, tk.ik2);
+    ns1_allreduce<NW>(y, L, w, lane);
+#pragma unroll
+    for (int i = 0; i < KB; ++i) { y[i] = splat4(a.fc * tk.inv2) * y[i]; xs[i] = y[i]; }      // x1 = x0 + fc (ffn + b2)
+  }
+  if (w == 0 && tl.live) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(a.x1 + tl.row + 16 * i + g4, y[i]);
+  }
+  ns1_ln(xs, L.par[3], L.par[4], g4, a.eps);
+  const float sx = pp_pow2_scale(ns_row_max(xs));
+  ns1_split_rows(xf, xs, g4, sx);
+  const float invq = pp_recip_pow2(a.pp_sw_qkv * sx);
+  const u32x4_t* wq = reinterpret_cast<const u32x4_t*>(a.ns_qkv) + lane;
+#pragma unroll 1
+  for (int t0 = w; t0 < 27; t0 += 3 * NW) {           // column tiles t0, t0 + NW, t0 + 2 NW (past the end: tile 26 again, not stored)
+    const u32x4_t* const wt[3] = {wq + (size_t)min(t0, 26) * 128, wq + (size_t)min(t0 + NW, 26) * 128, wq + (size_t)min(t0 + 2 * NW, 26) * 128};
+    f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
+    ns1_plain3(acc, wt, 27, xf);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int tile = t0 + j * NW;
+      if (tile >= 27 || !tl.live) continue;
+      const int q = tile / KB, i = tile - KB * q;
+      const f32x4 v = acc[j] * splat4((q == 0 ? a.qscale : 1.0f) * invq);
+      if (a.qkv_T > 0) {
+        const int bq = tl.tok / a.qkv_T, tq = tl.tok - bq * a.qkv_T;
+        float* plane = a.qkv + (size_t)q * a.M * D + ((size_t)bq * a.qkv_H * a.qkv_T + tq) * 36;
+        const int f0 = 16 * i + g4, hq = f0 / 36;
+        stg4(plane + (size_t)hq * a.qkv_T * 36 + (f0 - 36 * hq), v);
+      } else {
+        stg4(a.qkv + (size_t)tl.tok * (3 * D) + 16 * tile + g4, v);
+      }
+    }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ns1_ff1_qkv_kernel(Ff1QkvArgs a) {
+  __shared__ __attribute__((aligned(16))) Ns1Lds<NW> L;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, t = lane & 15;
+  const Ns1Tile tl = ns1_tile(a.M, 0, t);
+  f32x4 xs[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + tl.row + 16 * kb + g4);
+  const float* const par[5] = {a.ff_ln_g, a.ff_ln_b, a.ff_b2, a.att_ln_g, a.att_ln_b};
+  ns1_stash<NW>(L, par);
+  __syncthreads();
+  ns1_ff1_qkv<NW>(a, L, xs, tl, w, lane, g4);
+}
+
+// out-projection + residual + LayerNorm + pw_conv_1 + GLU (pp_out_glu_kernel, one tile per workgroup): ctx, x1 -> x2, u
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ns1_out_glu_kernel(OutGluArgs a) {
+  __shared__ __attribute__((aligned(16))) Ns1Lds<NW> L;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, t = lane & 15;
+  const Ns1Tile tl = ns1_tile(a.M, 0, t);
+  f32x4 xs[KB], x2[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + tl.row + 16 * kb + g4);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) x2[kb] = ldg4(a.x1 + tl.row + 16 * kb + g4);
+  {
+    const float* const par[2] = {a.cv_ln_g, a.cv_ln_b};
+    ns1_stash<NW>(L, par);                             // published by the barrier in front of the out projection's exchange
+  }
+  Split8 xf[KS];
+  {
+    const float sx = pp_pow2_scale(ns_row_max(xs));
+    ns1_split_rows(xf, xs, g4, sx);
+    const f32x4 inv = splat4(pp_recip_pow2(a.pp_sw_out * sx));
+    const u32x4_t* wo = reinterpret_cast<const u32x4_t*>(a.ns_out) + lane;
+    // nine column tiles: wave w takes tiles w, w + NW, w + 2 NW (< 9); every wave needs the whole row afterwards
+#pragma unroll
+    for (int i = 0; i < KB; ++i) L.red[0][i][lane] = splat4(0.f);        // (all waves write the same zeros: tiles nobody owns do not exist)
+    __syncthreads();
+    if (w < KB) {
+      const u32x4_t* const wt[3] = {wo + (size_t)min(w, 8) * 128, wo + (size_t)min(w + NW, 8) * 128, wo + (size_t)min(w + 2 * NW, 8) * 128};
+      f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
+      ns1_plain3(acc, wt, 9, xf);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (w + j * NW < KB) L.red[0][w + j * NW][lane] = acc[j] * inv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KB; ++i) { x2[i] += L.red[0][i][lane]; xs[i] = x2[i]; }        // x2 = x1 + attention (+ bias: row 144)
+  }
+  if (w == 0 && tl.live) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(a.x2 + tl.row + 16 * i + g4, x2[i]);
+  }
+  ns1_ln(xs, L.par[0], L.par[1], g4, a.eps);
+  const float sx = pp_pow2_scale(ns_row_max(xs));
+  ns1_split_rows(xf, xs, g4, sx);
+  const float inv = pp_recip_pow2(a.pp_sw_pw1 * sx);
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(a.ns_pw1) + lane;
+  // value tile i and gate tile 9 + i in the same wave; wave w takes i = w, w + NW (< 9): one ns1_plain3 holds (value, gate, -)
+#pragma unroll 1
+  for (int i = w; i < KB; i += NW) {
+    const u32x4_t* const wt[3] = {wp + (size_t)i * 128, wp + (size_t)(KB + i) * 128, wp + (size_t)i * 128};
+    f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
+    ns1_plain3(acc, wt, 18, xf);
+    if (tl.live) {
+      const f32x4 va = acc[0] * splat4(inv), vb = acc[1] * splat4(inv);
+      const f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
+      stg4(a.u + tl.row + 16 * i + g4, o);
+    }
+  }
+}
+
+// depthwise conv (k = 32) of the tile's 16 frames from u in HBM: 47 window rows + the taps through LDS, 16 x 144 outputs by the
+// workgroup's threads, back through LDS in row order; every wave picks up all rows.  conformer_blocks.py:205 ('same': 15 / 16
+// zeros) and chunk_conformer_blocks.py:262 ('causal': 31 in front): rows outside the utterance are the padding.
+constexpr int N1_K = 32, N1_ROWS = 16 + N1_K - 1;
+struct Ns1DwLds { float win[N1_ROWS][D]; float wt[N1_K][D]; float out[16][D]; };
+template <int NW>
+DEV void ns1_dwconv(Ns1DwLds& S, const TailFf2Args& a, f32x4 (&xs)[KB], int lane, int g4, int t) {
+  constexpr int NT_ = NW * 64;
+  const int tid = threadIdx.x;
+  const int T = a.dw_T, f0 = blockIdx.x * 16 - a.dw_pad;
+  const float* __restrict__ ub = a.dw_u + (size_t)blockIdx.y * T * D;
+  // every global load first, then the LDS writes (one memory latency for the window and the taps, not one per loop iteration)
+  constexpr int NWIN = N1_ROWS * (D / 4), NTAP = N1_K * (D / 4), RW = (NWIN + NT_ - 1) / NT_, RT_ = (NTAP + NT_ - 1) / NT_;
+  f32x4 sw[RW], st[RT_];
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    const int i = tid + k * NT_, r = i / (D / 4), c4 = i - r * (D / 4), f = f0 + r;
+    sw[k] = (i < NWIN && f >= 0 && f < T) ? ldg4(ub + (size_t)f * D + 4 * c4) : splat4(0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < RT_; ++k) {
+    const int i = tid + k * NT_;
+    st[k] = i < NTAP ? ldg4(a.dw_wd + 4 * i) : splat4(0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    const int i = tid + k * NT_;
+    if (i < NWIN) *reinterpret_cast<f32x4*>(&S.win[0][0] + 4 * i) = sw[k];
+  }
+#pragma unroll
+  for (int k = 0; k < RT_; ++k) {
+    const int i = tid + k * NT_;
+    if (i < NTAP) *reinterpret_cast<f32x4*>(&S.wt[0][0] + 4 * i) = st[k];
+  }
+  __syncthreads();
+  for (int i = tid; i < 16 * (D / 4); i += NT_) {
+    const int fr = i / (D / 4), c4 = i - fr * (D / 4);
+    f32x4 acc = splat4(0.f);
+#pragma unroll 8
+    for (int j = 0; j < N1_K; ++j)
+      acc += *reinterpret_cast<const f32x4*>(&S.win[fr + j][4 * c4]) * *reinterpret_cast<const f32x4*>(&S.wt[j][4 * c4]);
+    *reinterpret_cast<f32x4*>(&S.out[fr][4 * c4]) = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = *reinterpret_cast<const f32x4*>(&S.out[t][16 * kb + g4]);
+}
+
+// depthwise conv + conv-module tail + ff_module_2 + block LayerNorm [+ ff_module_1 + qkv of the next block]
+// (pp_block_kernel<true, FF1, 0, true>: u and x2 from HBM), one tile per workgroup; grid (ceil(T / 16), utterances)
+template <int NW, bool FF1>
+__global__ __launch_bounds__(NW * 64) void ns1_tail_kernel(TailFf2Args a, Ff1QkvArgs b) {
+  __shared__ __attribute__((aligned(16))) Ns1Lds<NW> L;
+  __shared__ __attribute__((aligned(16))) Ns1DwLds S;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, t = lane & 15;
+  unsigned long long st1[12] = {};
+  NS1_STAMP(0);
+  const Ns1Tile tl = ns1_tile(a.M, a.dw_T, t);
+  f32x4 xs[KB], y[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) y[kb] = ldg4(a.x2 + tl.row + 16 * kb + g4);
+  {
+    const float* const par[11] = {FF1 ? b.ff_ln_g : nullptr, FF1 ? b.ff_ln_b : nullptr, FF1 ? b.ff_b2 : nullptr, FF1 ? b.att_ln_g : nullptr,
+                                  FF1 ? b.att_ln_b : nullptr, a.pw2_b, a.ff_ln_g, a.ff_ln_b, a.ff_b2, a.ln_g, a.ln_b};
+    ns1_stash<NW>(L, par);                             // published by the barriers of the depthwise conv
+  }
+  ns1_dwconv<NW>(S, a, xs, lane, g4, t);
+  NS1_STAMP(1);
+  Split8 xf[KS];
+  {
+    const NsTok tk = ns_chain_scales(a.pp_sc[0], ns_row_max(xs));
+#pragma unroll
+    for (int i = 0; i < KB; ++i) y[i] = w == 0 ? (y[i] + lds4(L.par[5], i, g4)) * splat4(tk.s2) : splat4(0.f);
+    ns1_split_rows(xf, xs, g4, tk.sx);
+    NS1_STAMP(2);
+    ns1_chain<9, NW>(y, xf, reinterpret_cast<const u32x4_t*>(a.ns_cv_w1), reinterpret_cast<const u32x4_t*>(a.ns_cv_w2), w, lane, tk.k1, tk.ik2);
+    NS1_STAMP(3);
+    ns1_allreduce<NW>(y, L, w, lane);
+    NS1_STAMP(4);
+#pragma unroll
+    for (int i = 0; i < KB; ++i) y[i] = y[i] * splat4(tk.inv2);                             // x3 = x2 + conv module
+  }
+  const float inv_fc = 1.0f / a.fc;
+#pragma unroll
+  for (int i = 0; i < KB; ++i) xs[i] = y[i];
+  ns1_ln(xs, L.par[6], L.par[7], g4, a.eps);
+  {
+    const NsTok tk = ns_chain_scales(a.pp_sc[1], ns_row_max(xs));
+#pragma unroll
+    for (int i = 0; i < KB; ++i) y[i] = w == 0 ? (lds4(L.par[8], i, g4) + splat4(inv_fc) * y[i]) * splat4(tk.s2) : splat4(0.f);
+    ns1_split_rows(xf, xs, g4, tk.sx);
+    NS1_STAMP(5);
+    ns1_chain<18, NW>(y, xf, reinterpret_cast<const u32x4_t*>(a.ns_ff_w1), reinterpret_cast<const u32x4_t*>(a.ns_ff_w2), w, lane, tk.k1, tk.ik2);
+    NS1_STAMP(6);
+    ns1_allreduce<NW>(y, L, w, lane);
+    NS1_STAMP(7);
+#pragma unroll
+    for (int i = 0; i < KB; ++i) y[i] = splat4(a.fc * tk.inv2) * y[i];
+  }
+  ns1_ln(y, L.par[9], L.par[10], g4, a.eps);                                                // block-final LayerNorm
+  if (a.y && w == 0 && tl.live) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(a.y + tl.row + 16 * i + g4, y[i]);
+  }
+  NS1_STAMP(8);
+  if constexpr (FF1) ns1_ff1_qkv<NW>(b, L, y, tl, w, lane, g4);
+  NS1_STAMP(9);
+  if constexpr ((NS_DIAG & 32) != 0) {
+    if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0 && (w == 0 || w == 7)) {
+      printf("NS1STAMP w%d:", w);
+      for (int i = 1; i <= 9; ++i) printf(" %d:%llu", i, st1[i] - st1[0]);
+      printf("\n");
+    }
+  }
+}
+
+// CTC class head of one tile (pp_head_kernel's contract: logits = x W + b over `groups` x nine column tiles, per-frame arg-max --
+// lowest class among equal maxima -- and / or maximum and / or the logits), column tiles w, w + NW, ... per wave
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ns1_head_kernel(GemmArgs a, const u32x4_t* __restrict__ ns, float sw, int groups) {
+  __shared__ float bv[NW][16];
+  __shared__ int bi[NW][16];
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, t = lane & 15;
+  const Ns1Tile tl = ns1_tile(a.M, 0, t);
+  f32x4 xs[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x + tl.row + 16 * kb + g4);
+  Split8 xf[KS];
+  const float sx = pp_pow2_scale(ns_row_max(xs));
+  ns1_split_rows(xf, xs, g4, sx);
+  const float inv = pp_recip_pow2(sw * sx);
+  const int NT = KB * groups;
+  const u32x4_t* wp = ns + lane;
+  float best_v = -INFINITY;
+  int best_i = 0x7fffffff;
+  const bool want_max = a.argmax_out != nullptr || a.maxval_out != nullptr;
+  float* yrow = a.y ? a.y + (size_t)tl.tok * a.ldy : nullptr;
+#pragma unroll 1
+  for (int t0 = w; t0 < NT; t0 += 3 * NW) {
+    const u32x4_t* const wt[3] = {wp + (size_t)min(t0, NT - 1) * 128, wp + (size_t)min(t0 + NW, NT - 1) * 128, wp + (size_t)min(t0 + 2 * NW, NT - 1) * 128};
+    f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
+    ns1_plain3(acc, wt, NT, xf);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int tile = t0 + j * NW, f0 = 16 * tile + g4;
+      if (tile >= NT || 16 * tile >= a.n_valid) continue;
+      const f32x4 v = acc[j] * splat4(inv);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      if (want_max) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (f0 + q < a.n_valid && vv[q] > best_v) { best_v = vv[q]; best_i = f0 + q; }
+      }
+      if (yrow && tl.live) {
+        if (f0 + 3 < a.n_valid && (a.ldy & 3) == 0) stg4(yrow + f0, v);
+        else
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (f0 + q < a.n_valid) yrow[f0 + q] = vv[q];
+      }
+    }
+  }
+  if (!want_max) return;
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) {
+    const float ov = __shfl_xor(best_v, off);
+    const int oi = __shfl_xor(best_i, off);
+    if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+  }
+  if (lane < 16) { bv[w][lane] = best_v; bi[w][lane] = best_i; }
+  __syncthreads();
+  if (w == 0 && lane < 16 && tl.live) {
+#pragma unroll
+    for (int k = 1; k < NW; ++k) {
+      const float ov = bv[k][lane];
+      const int oi = bi[k][lane];
+      if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+    }
+    if (a.argmax_out) a.argmax_out[tl.tok] = best_i;
+    if (a.maxval_out) a.maxval_out[tl.tok] = best_v;
+  }
+}
+
 }  // namespace
 
 bool ns_enabled() {
@@ -539,5 +1085,45 @@ int launch_ns_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
   if (!attr) return -1;
   note_scheme(SCHEME_F16X2);
   hipLaunchKernelGGL(ns_ff1_qkv_kernel, dim3((b.M + 63) / 64), dim3(BLOCK_THREADS), sizeof(NsFf1Lds), s, b);
+  return 0;
+}
+
+// ---- small batches: one tile per workgroup ----------------------------------------------------------------------------------------------
+namespace {
+constexpr int NS1_W = 8;       // waves per workgroup (two per SIMD: one wave's fragment loads issue while the other's MFMAs run)
+int ns1_max_rows() {
+  // MI355ASR_NS1_MAX_M=n: the one-tile-per-workgroup kernels up to n rows (0: never).  Default 4096: 256 tiles = one workgroup per CU
+  // (measured at 250 ... 4000 rows: 46 - 50 us per block against 60 - 62; beyond, the workgroups of a launch no longer run at once)
+  static const int n = [] { const char* v = getenv("MI355ASR_NS1_MAX_M"); return v ? atoi(v) : 4096; }();
+  return n;
+}
+}  // namespace
+bool ns1_rows_ok(int M) { return M > 0 && M <= ns1_max_rows(); }
+int launch_ns1_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
+  if (!ns1_rows_ok(b.M) || !b.ns_w1 || !b.ns_w2 || !b.ns_qkv || b.pre_pp) return -1;
+  note_scheme(SCHEME_F16X2);
+  hipLaunchKernelGGL((ns1_ff1_qkv_kernel<NS1_W>), dim3((b.M + 15) / 16), dim3(NS1_W * 64), 0, s, b);
+  return 0;
+}
+// what launch_pp_og_tail_ff1 / _ff2 do in one launch, as two: out-projection + GLU (x2 -> g.x2, u -> g.u), then depthwise conv +
+// tail [+ the next block's ff_module_1 + qkv].  a.dw_u is set to g.u here; a.x2 must be g.x2.
+int launch_ns1_og_tail(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g, hipStream_t s) {
+  if (!ns1_rows_ok(a.M) || a.M != g.M || !g.ns_out || !g.ns_pw1 || !a.ns_cv_w1 || !a.ns_cv_w2 || !a.ns_ff_w1 || !a.ns_ff_w2 || a.head_pp ||
+      !g.x2 || !g.u || !g.ctx || !g.x1 || !a.dw_wd || a.dw_T <= 0 || a.M % a.dw_T != 0 || (a.dw_pad != 15 && a.dw_pad != 31))
+    return -1;
+  if (b && (!b->ns_w1 || !b->ns_w2 || !b->ns_qkv || b->pre_pp || b->M != a.M)) return -1;
+  note_scheme(SCHEME_F16X2);
+  hipLaunchKernelGGL((ns1_out_glu_kernel<NS1_W>), dim3((g.M + 15) / 16), dim3(NS1_W * 64), 0, s, g);
+  TailFf2Args k = a;
+  k.dw_u = g.u; k.x2 = g.x2;
+  const dim3 grid((a.dw_T + 15) / 16, a.M / a.dw_T);
+  if (b) hipLaunchKernelGGL((ns1_tail_kernel<NS1_W, true>), grid, dim3(NS1_W * 64), 0, s, k, *b);
+  else hipLaunchKernelGGL((ns1_tail_kernel<NS1_W, false>), grid, dim3(NS1_W * 64), 0, s, k, Ff1QkvArgs{});
+  return 0;
+}
+int launch_ns1_head(const GemmArgs& a, const float* ns, float sw, int groups, hipStream_t s) {
+  if (!ns1_rows_ok(a.M) || !ns || groups < 1 || a.n_valid > 144 * groups) return -1;
+  note_scheme(SCHEME_F16X2);
+  hipLaunchKernelGGL((ns1_head_kernel<NS1_W>), dim3((a.M + 15) / 16), dim3(NS1_W * 64), 0, s, a, reinterpret_cast<const u32x4_t*>(ns), sw, groups);
   return 0;
 }

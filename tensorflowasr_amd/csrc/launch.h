@@ -337,6 +337,8 @@ struct OutGluArgs {
   // tiles, gate tiles; biases in row 144), packed with these powers of two
   const float* pp_slabs = nullptr;
   float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
+  // round 6 (fused_ns.hip): the same fragments in plain order -- out projection [5][9][2][64], pw_conv_1 [5][18][2][64] (u32x4 per lane)
+  const float *ns_out = nullptr, *ns_pw1 = nullptr;
 };
 struct TailFf2Args {
   const float* dw; const float* x2; float* y;
@@ -362,6 +364,9 @@ struct TailFf2Args {
   float* head_y = nullptr;
   int32_t* head_argmax = nullptr;
   float* head_maxval = nullptr;
+  // round 6 (fused_ns.hip): the chains' fragments in plain order -- conv tail W1aug [5][18][2][64] / W2 [9][9][2][64], ff_module_2
+  // W1aug [5][36][2][64] / W2 [18][9][2][64]; packed with pp_sc[0] / pp_sc[1]
+  const float *ns_cv_w1 = nullptr, *ns_cv_w2 = nullptr, *ns_ff_w1 = nullptr, *ns_ff_w2 = nullptr;
 };
 int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s);
 int launch_out_glu(const OutGluArgs& a, hipStream_t s);
@@ -381,6 +386,12 @@ int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
 // N-split versions (fused_ns.hip, round 6); -1: switched off (MI355ASR_NS=0), no plain-order fragments, or not this launch's shape
 bool ns_enabled();
 int launch_ns_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
+// ... one 16-token tile per workgroup, for small batches (up to MI355ASR_NS1_MAX_M rows): ff_module_1 + qkv; and what the folded tail
+// launches do, as out-projection + GLU (writes g.x2, g.u) followed by depthwise conv + tail [+ next ff_module_1 + qkv when b is set]
+bool ns1_rows_ok(int M);
+int launch_ns1_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
+int launch_ns1_og_tail(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g, hipStream_t s);
+int launch_ns1_head(const GemmArgs& a, const float* ns, float sw, int groups, hipStream_t s);   // ns: [W ; b] fragments in plain order [5][9 groups][2][64]
 bool ff1_qkv_pp_selected(bool has_slabs, bool has_pp);   // fused.hip: q, k, v will come from the pair-pipelined producer (head-major layout possible)
 bool ff1_pre_selected();             // ... and launch_ff1_qkv will take that kernel (fused.hip) when the block has its streams
 bool pp_pre_fold_ok();

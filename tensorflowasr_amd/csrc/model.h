@@ -69,9 +69,10 @@ struct BlockDev {
   float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
   PpChainSc pp_ff1_sc, pp_tail_sc[2];      // the scales those streams were packed with (two-term fp16 scheme)
   float pp_sw_qkv = 1.f;
-  // the same two-term fragments of ff_module_1 (W1aug, W2) and q / k / v in plain order for the N-split kernel of fused_ns.hip
-  // (round 6; packed only with MI355ASR_NS=1), or null
-  const float *ns_ff1_w1 = nullptr, *ns_ff1_w2 = nullptr, *ns_qkv = nullptr;
+  // the same two-term fragments in plain [step][tile][term] order for the N-split kernels of fused_ns.hip (round 6), or null:
+  // ff_module_1 (W1aug, W2), q / k / v, out projection, pw_conv_1, conv tail (W1aug, W2), ff_module_2 (W1aug, W2)
+  const float *ns_ff1_w1 = nullptr, *ns_ff1_w2 = nullptr, *ns_qkv = nullptr, *ns_out = nullptr, *ns_pw1 = nullptr,
+              *ns_cv_w1 = nullptr, *ns_cv_w2 = nullptr, *ns_ff2_w1 = nullptr, *ns_ff2_w2 = nullptr;
 };
 
 struct Dims {
@@ -129,7 +130,7 @@ struct mi355asr_model {
   // kernels' crossover the rings are not packed at all (they cost 1.5 x the dense weights' bytes and their packing time).
   long expected_rows = -1;
   // dmodel 144: class-head P16 pack -> (slab stream of head_ld_kernel, column groups)
-  struct HeadStreams { const float* slabs; int groups; const float* pp; float pp_sw; };   // pp: two-term fp16 stream (fused_pp.hip)
+  struct HeadStreams { const float* slabs; int groups; const float* pp; float pp_sw; const float* ns; };   // pp: two-term fp16 stream (fused_pp.hip); ns: the same fragments in plain order (fused_ns.hip)
   std::unordered_map<const float*, HeadStreams> head_of;
   const float *dft_wp = nullptr, *mel_wp = nullptr, *c1_w = nullptr, *c1_b = nullptr, *c2_wp = nullptr,
               *c2_b = nullptr, *lin_wp = nullptr, *lin_b = nullptr, *proj_wp = nullptr, *proj_b = nullptr,
@@ -223,7 +224,7 @@ struct ArenaBuilder {
   std::vector<std::pair<size_t, size_t>> ring_pairs;
   int ring_terms = 3;   // 3: fp32 weights as three bf16 terms; 1: bf16 mode (round-to-nearest-even bf16)
   // (offset of a dmodel-144 class head's P16 pack, offset of its slab stream for head_ld_kernel, column groups of nine tiles)
-  struct HeadPair { size_t p16, slabs; int groups; size_t pp; float pp_sw; };
+  struct HeadPair { size_t p16, slabs; int groups; size_t pp; float pp_sw; size_t ns; };
   std::vector<HeadPair> head_pairs;
   size_t put(const std::vector<float>& v) {
     size_t off = (buf.size() + 63) & ~(size_t)63;  // 256-byte alignment
@@ -257,7 +258,7 @@ struct BlockOff {
   float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
   PpChainSc pp_ff1_sc, pp_tail_sc[2];
   float pp_sw_qkv = 1.f;
-  size_t ns_ff1_w1 = 0, ns_ff1_w2 = 0, ns_qkv = 0;
+  size_t ns_ff1_w1 = 0, ns_ff1_w2 = 0, ns_qkv = 0, ns_out = 0, ns_pw1 = 0, ns_cv_w1 = 0, ns_cv_w2 = 0, ns_ff2_w1 = 0, ns_ff2_w2 = 0;
   bool ns = false;
   bool split = false;
 };

@@ -352,7 +352,8 @@ np.savez(sys.argv[1], **out)
     import tempfile
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for tag, extra in (("two", {}), ("three", {"MI355ASR_PP_OGF": "0"})):
+        # (MI355ASR_NS1_MAX_M=0: this is a property of the pair-pipelined kernels; small shapes otherwise take the one-tile kernels of round 6)
+        for tag, extra in (("two", {"MI355ASR_NS1_MAX_M": "0"}), ("three", {"MI355ASR_PP_OGF": "0", "MI355ASR_NS1_MAX_M": "0"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
             assert r.returncode == 0, r.stderr[-3000:]
@@ -606,22 +607,26 @@ def test_conformer_block_operand_scales_follow_the_input_magnitude(enc2, scale):
 
 
 def test_conformer_block_is_batch_size_invariant_per_path(enc2):
-    """The block runs through one of two kernel families depending on the row count (layer-at-a-time up to 800 rows,
-    fused ring kernels above): inside a family an utterance's result does not depend on what else is in the batch
-    (bit-identical), across families it agrees to fp32 rounding."""
+    """The block runs through one of three kernel families depending on the row count (layer-at-a-time for a handful of rows,
+    round 6: one 16-token tile per workgroup up to 4 096 rows, the pair-pipelined kernels above): inside a family an utterance's
+    result does not depend on what else is in the batch (bit-identical), across families it agrees to fp32 rounding."""
     e, w, _ = enc2
     rng = np.random.default_rng(11)
     x = rng.standard_normal((8, 250, 144)).astype(np.float32)
     big = np.tile(x, (34, 1, 1))                       # 272 x 250 = 68 000 tokens
     mid = np.tile(x, (4, 1, 1))                        # 32 x 250 = 8 000 tokens
-    few = e.conformer_block(0, x).cpu().numpy()        # 2 000 tokens: fused as well
+    few = e.conformer_block(0, x).cpu().numpy()        # 2 000 tokens: one tile per workgroup
     got = e.conformer_block(0, big).cpu().numpy()
     gmid = e.conformer_block(0, mid).cpu().numpy()
     assert np.array_equal(got[:8], got[-8:]) and np.array_equal(gmid[:8], gmid[-8:])
-    assert np.array_equal(got[:8], gmid[:8]) and np.array_equal(got[:8], few)
-    lat = e.conformer_block(0, x[:3]).cpu().numpy()    # 750 tokens: layer-at-a-time
+    assert np.array_equal(got[:8], gmid[:8])
+    two = e.conformer_block(0, np.tile(x, (2, 1, 1))).cpu().numpy()        # 4 000 tokens: the same family as `few`
+    assert np.array_equal(two[:8], few) and np.array_equal(two[8:], few)
+    assert maxdiff(got[:8], few) < 2e-5
+    lat = e.conformer_block(0, x[:3]).cpu().numpy()    # 750 tokens
     assert np.array_equal(e.conformer_block(0, x[:2]).cpu().numpy(), lat[:2])
     assert np.array_equal(e.conformer_block(0, x[:1]).cpu().numpy(), lat[:1])
+    assert np.array_equal(lat, few[:3])
     assert maxdiff(got[:3], lat) < 2e-5
     ref = co.conformer_block(x[:1].astype(np.float64), w, "conformer_block_0", 36)
     assert maxdiff(got[:1], ref) < TOL and maxdiff(lat[:1], ref) < TOL
@@ -1975,6 +1980,57 @@ np.savez(sys.argv[1], **out)
             print("%s: key-block kernel vs fp32-MFMA route %.3g, vs three-term %.3g; from the oracle %s / %s / %s"
                   % (k, d1, d3, res["long"][0], res["fp32"][0], res["three"][0]))
             assert 0.0 < d1 < 2e-5 and d3 < 2e-5
+
+
+def test_small_batches_one_tile_per_workgroup_against_the_pair_pipelined_kernels_and_the_oracle(torch_cuda):
+    """Round 6 (fused_ns.hip, ns1_* kernels; up to MI355ASR_NS1_MAX_M rows, default 4096): one utterance per call is test_asr.py's
+    pattern (test_asr.py:186-219).  A workgroup of eight waves owns ONE 16-token tile, the hidden dimension and the column tiles of
+    the plain layers are split over the waves, the block runs as attention + out-projection / GLU + (depthwise conv, tail, next
+    ff_module_1 + qkv).  Same arithmetic as the pair-pipelined kernels, another summation order: encoder output, logits and greedy ids
+    of 1 x 10 s, 3 x 3.7 s (a ragged last tile per utterance: 92 frames) and 2 x 2.8 s against the build with MI355ASR_NS1_MAX_M=0
+    and against the fp64 oracle; the profile counters say which kernels ran (three launches of the tail category per block pair)."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, ctypes, numpy as np, torch
+sys.path.insert(0, "tests")
+from helpers import co, encoder_kwargs, small_cfg, waves, golden_ctc_weights
+from tensorflowasr_amd import _lib
+from tensorflowasr_amd.models import ConformerCTC
+cfg = small_cfg(3)
+w = co.encoder_weights(cfg, seed=0); w.update(golden_ctc_weights())
+m = ConformerCTC(1332, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
+m.load_weights(w, by_name=False)
+out = {}
+for tag, B, L in (("b1", 1, 160000), ("b3", 3, 59000), ("b2", 2, 45000)):
+    x = waves(B, L, 40)
+    enc = m.encode(x); lg = m.ctc_logits(enc)
+    ids, lens = m.recognize(x)
+    out[tag + "_enc"] = enc.cpu().numpy(); out[tag + "_lg"] = lg.cpu().numpy(); out[tag + "_ids"] = ids.cpu().numpy()
+    ref = co.conformer_encoder(x[:1].astype(np.float64), w, cfg)
+    lref = co.ctc_decoder(ref, w, cfg)
+    print("RESULT %s %.3e %.3e" % (tag, np.abs(out[tag + "_enc"][:1] - ref).max(), np.abs(out[tag + "_lg"][:1] - lref).max()))
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, extra in (("ns1", {}), ("pp", {"MI355ASR_NS1_MAX_M": "0"})):
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(td, tag + ".npz")], env=dict(os.environ, **extra), capture_output=True,
+                               text=True, timeout=900, cwd=root)
+            lines = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+            assert len(lines) == 3, r.stderr[-3000:]
+            assert all(float(l[1]) < TOL and float(l[2]) < TOL for l in lines), (tag, lines)
+            res[tag] = (lines, np.load(os.path.join(td, tag + ".npz")))
+        for k in res["ns1"][1].files:
+            a, b = res["ns1"][1][k], res["pp"][1][k]
+            if k.endswith("_ids"):
+                assert np.array_equal(a, b), k
+            else:
+                apart = float(np.abs(a - b).max())
+                assert 0.0 < apart < 1e-4, (k, apart)
+        print("one tile per workgroup vs pair-pipelined: oracle distances %s / %s" % (res["ns1"][0], res["pp"][0]))
 
 
 def test_n_split_ff1_qkv_kernel_against_the_pair_pipelined_one_and_the_oracle(torch_cuda):
