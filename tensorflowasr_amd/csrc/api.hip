@@ -970,7 +970,6 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       PROF(MI355ASR_K_FF1_QKV); LAUNCH_TRY(launch_ff1_qkv(k1, s), "ff_module_1 + qkv");
     }
     const AttnArgs at = attn_args(w, qkv_head_major(w));
-    { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
     OutGluArgs k2{};
     k2.ctx = sc.ctx; k2.x1 = sc.xb; k2.x2 = sc.xa; k2.u = sc.u;
     k2.out_wp = w.out_wp; k2.out_b = w.out_b; k2.cv_ln_g = w.cv_ln_g; k2.cv_ln_b = w.cv_ln_b;
@@ -987,8 +986,6 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     k4.M = M; k4.pp_slabs = w.pp_tail;
     // round 4: so does out-projection + GLU (x2 and u never in HBM either): the block is attention + one launch
     const bool og_fold = dw_fold && pp_og_fold_ok(k4, k2);
-    if (!og_fold) { PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU"); }
-    if (!dw_fold) { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
     k4.dw = sc.dw; k4.x2 = sc.xa; k4.y = out ? out : sc.xb;
     k4.pc_w1p = w.pc_w1p; k4.pc_b1 = w.pc_b1; k4.bn_s = w.bn_s; k4.bn_t = w.bn_t; k4.pw2_wp = w.pw2_wp; k4.pw2_b = w.pw2_b;
     k4.ff_ln_g = w.ff_ln_g[1]; k4.ff_ln_b = w.ff_ln_b[1]; k4.ff_w1p = w.ff_w1p[1]; k4.ff_b1 = w.ff_b1[1];
@@ -1001,6 +998,43 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     // that mode, so sc.xa is free: the block output goes there and the xa/xb swap is skipped.
     TailFf2Args k4og = k4;
     if (!out) k4og.y = sc.xa;
+    const bool tail_ff1_case = next && !out && ff1_done && tail_ff1_available() && k4.slabs && next->ff1_slabs;
+    // round 6, small batches (up to MI355ASR_NS1_MAX_M rows): one 16-token tile per workgroup (fused_ns.hip).  The block runs as
+    // [attention + out-projection + GLU] -> [depthwise conv + tail (+ the next block's ff_module_1 + qkv)]: two launches, the first
+    // of which takes the attention along when it can (at most 256 frames, operand bounds known).  Same buffer roles as the folded
+    // pair-pipelined launches below: x2 / u go to sc.xa / sc.u, which are free in that mode; every workgroup reads and writes its
+    // own rows of sc.xa only.
+    // (its own shape rule: 16-frame tiles waste little at any length, so the 64-frame criterion of the folds below does not apply)
+    if (w.pp_tail && w.tail_slabs && tail_pp_selected() && pp_enabled() && ksz == 32 && ns1_rows_ok(M)) {
+      const bool head_fold_case = og_fold && !tail_ff1_case && bo.head && bo.head_pp && bo.head_done && pp_head_fold_ok(M, bo.head->n_valid, bo.head_groups);
+      TailFf2Args kt = tail_ff1_case ? k4 : k4og;
+      kt.dw_u = sc.u; kt.dw_wd = w.dw_w; kt.dw_T = T; kt.dw_pad = dwa.pad_left;
+      if (tail_ff1_case) kt.y = nullptr;
+      const Ff1QkvArgs kn = tail_ff1_case ? ff1_args(*next, nullptr, sc.xa) : Ff1QkvArgs{};
+      if (!head_fold_case && ns1_block_ok(kt, tail_ff1_case ? &kn : nullptr, k2)) {
+        OutGluArgs kg = k2;
+        const bool fuse_attn = ns1_attn_ok(hs, at);
+        if (fuse_attn) {
+          kg.attn = 1; kg.aq = at.q; kg.ak = at.k; kg.av = at.v; kg.a_T = at.Tk; kg.a_H = at.H; kg.a_ldq = at.ldq; kg.a_ldk = at.ldk;
+          kg.a_head_major = at.head_major; kg.a_sq = at.h2_sq; kg.a_sk = at.h2_sk; kg.a_sv = at.h2_sv;
+        } else {
+          PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention");
+        }
+        if (tail_ff1_case) {
+          PROF(MI355ASR_K_TAIL_FF1);
+          LAUNCH_TRY(launch_ns1_og_tail(kt, &kn, kg, s), "small-batch block + next ff_module_1");
+          *ff1_done = true;
+          std::swap(sc.xa, sc.xb);
+        } else {
+          PROF(MI355ASR_K_TAIL_FF2);
+          LAUNCH_TRY(launch_ns1_og_tail(kt, nullptr, kg, s), "small-batch block");      // y is in sc.xa (or `out`): no swap
+        }
+        return 0;
+      }
+    }
+    { PROF(MI355ASR_K_ATTN); LAUNCH_TRY(launch_attention(hs, at, s), "attention"); }
+    if (!og_fold) { PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU"); }
+    if (!dw_fold) { PROF(MI355ASR_K_DWCONV); LAUNCH_TRY(launch_dwconv(ksz, dwa, s), "depthwise conv"); }
     // out-projection + GLU as its own launch, once, when a folded launcher declines (it declines before launching anything)
     bool og_pending = og_fold;
     auto unfold = [&]() -> int {
@@ -1009,7 +1043,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       PROF(MI355ASR_K_OUT_GLU); LAUNCH_TRY(launch_out_glu(k2, s), "out-projection + GLU");
       return 0;
     };
-    if (next && !out && ff1_done && tail_ff1_available() && k4.slabs && next->ff1_slabs) {
+    if (tail_ff1_case) {
       // the block output feeds only the next block's ff_module_1: keep it in registers, write x1 (into the buffer the
       // next block knows as sc.xb after the swap below -- this block's x2, which each workgroup has consumed) and qkv
       TailFf2Args kf = k4;

@@ -822,16 +822,161 @@ __global__ __launch_bounds__(NW * 64) void ns1_ff1_qkv_kernel(Ff1QkvArgs a) {
   ns1_ff1_qkv<NW>(a, L, xs, tl, w, lane, g4);
 }
 
-// out-projection + residual + LayerNorm + pw_conv_1 + GLU (pp_out_glu_kernel, one tile per workgroup): ctx, x1 -> x2, u
+// ---- attention of one 16-query tile (round 6: inside the out-projection launch of the small-batch path) ------------------------------
+// multihead_attention.py:151-188 on attention_split_kernel's arithmetic (two fp16 terms; S^T = K Q^T, dims 32..35 on the fp32 MFMA;
+// exp2 with log2 e folded into q; the score accumulators of two key tiles are the B operand of a 32-key step of V^T P^T), T <= 256.
+// Head by head: all eight waves stage the head's K / V fragments (the next head's rows are already in registers), wave w takes key
+// tiles 2 w, 2 w + 1 = step w of P V for the 16 queries, and the eight partial (max, sum, output) triples are combined through LDS
+// into the tile's context rows.  A separate attention launch costs 16 us for one utterance (4 workgroups, ~11 us of launch floor).
+constexpr int A_HS = 36, A_KT = 16, A_OT = 3;
+struct Ns1AttnLds {
+  float pm[2][8][16], pl[2][8][16]; // partial maxima / sums of the eight waves, per query, for two heads
+  f32x4 po[2][8][A_OT][64];         // partial outputs (48 KB)
+  float ctx[16][D];                 // the tile's context rows, all heads (9 KB)
+};
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void ns1_out_glu_kernel(OutGluArgs a) {
-  __shared__ __attribute__((aligned(16))) Ns1Lds<NW> L;
+DEV void ns1_attention(Ns1AttnLds& A, const OutGluArgs& g, int b, int f0, int w, int lane, f32x4 (&xs)[KB]) {
+  static_assert(NW == 8, "eight key-tile pairs = eight waves");
+  // Nothing is staged: wave w is the ONLY reader of key tiles 2 w, 2 w + 1 (as the A operand of S^T = K Q^T: lane (kg, kc) = key
+  // kc, dims 8 kg ..) and of step w of V (lane (kg, fc) = feature fc of the eight keys 32 w + 4 kg + {0..3}, + 16), so every lane
+  // loads exactly its own fragment entries from q / k / v and splits them in registers.  Heads go two at a time: the loads of
+  // both are in flight before the first product (a first version staged K / V head by head through LDS like attention_split_kernel
+  // and was bound by four serial load latencies: no faster than the separate launch).
+  const int gq = lane >> 4, g4 = gq * 4, c = lane & 15;
+  const int T = g.a_T, H = g.a_H, ld = g.a_ldk;
+  const float sq = g.a_sq, sk = g.a_sk, sv = g.a_sv;
+  constexpr float SP = 16384.f, LOG2E = 1.4426950408889634f;
+  const unsigned uld = (unsigned)ld;
+  const int tq = min(f0 + c, T - 1);
+  const int nkt = (T + 15) / 16;
+  const bool have = 2 * w < nkt;                         // this wave's pair holds at least one real key
+  const f32x4 inv_qk = splat4(1.0f / (sq * sk));
+#pragma unroll 1
+  for (int h0 = 0; h0 < H; h0 += 2) {
+    f32x4 qlo[2], qhi[2], klo[2][2], khi[2][2];
+    float qtl[2], ktl[2][2], ve[2][A_OT][8];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int h = min(h0 + hh, H - 1);
+      const float* qrow = g.a_head_major ? g.aq + (((size_t)b * H + h) * T + tq) * A_HS : g.aq + ((size_t)b * T + tq) * g.a_ldq + h * A_HS;
+      qlo[hh] = ldg4(qrow + 8 * gq); qhi[hh] = ldg4(qrow + 8 * gq + 4); qtl[hh] = qrow[32 + gq];
+      const size_t khead = g.a_head_major ? ((size_t)b * H + h) * T * A_HS : (size_t)b * T * ld + h * A_HS;
+      const float* __restrict__ kbase = g.ak + khead;
+      const float* __restrict__ vbase = g.av + khead;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int skey = 16 * (2 * w + k2) + c;
+        const unsigned ko = (unsigned)min(skey, T - 1) * uld;
+        const bool ok = skey < T;
+        klo[hh][k2] = ok ? *reinterpret_cast<const f32x4*>(kbase + ko + 8u * gq) : splat4(0.f);
+        khi[hh][k2] = ok ? *reinterpret_cast<const f32x4*>(kbase + ko + 8u * gq + 4u) : splat4(0.f);
+        ktl[hh][k2] = ok ? kbase[ko + 32u + gq] : 0.f;
+      }
+#pragma unroll
+      for (int ot = 0; ot < A_OT; ++ot) {
+        const int f = 16 * ot + c, key0 = 32 * w + 4 * gq;
+        const unsigned vo = (unsigned)key0 * uld + (unsigned)f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int dk = 16 * (j >> 2) + (j & 3);
+          ve[hh][ot][j] = (f < A_HS && key0 + dk < T) ? vbase[vo + (unsigned)dk * uld] : 0.f;      // padding features / keys: exact zeros
+        }
+      }
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      f32x4 sc[2], o[A_OT] = {splat4(0.f), splat4(0.f), splat4(0.f)};
+      float mw = -INFINITY, lw = 0.f;
+      if (have) {
+        const Split8 qf = split8(qlo[hh] * splat4(LOG2E * sq), qhi[hh] * splat4(LOG2E * sq));
+        const float qt = qtl[hh] * (LOG2E * sq);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int kt = 2 * w + k2;
+          const Split8 kf = split8(klo[hh][k2] * splat4(sk), khi[hh][k2] * splat4(sk));
+          f32x4 acc = splat4(0.f);
+          acc = ns_mfma(kf.t[1], qf.t[0], acc);
+          acc = ns_mfma(kf.t[0], qf.t[1], acc);
+          acc = ns_mfma(kf.t[0], qf.t[0], acc);
+          sc[k2] = mfma4(ktl[hh][k2] * sk, qt, acc) * inv_qk;
+          const int kb = 16 * kt + g4;
+          sc[k2].x = (kb + 0 < T) ? sc[k2].x : -INFINITY;
+          sc[k2].y = (kb + 1 < T) ? sc[k2].y : -INFINITY;
+          sc[k2].z = (kb + 2 < T) ? sc[k2].z : -INFINITY;
+          sc[k2].w = (kb + 3 < T) ? sc[k2].w : -INFINITY;
+          mw = fmaxf(mw, fmaxf(fmaxf(sc[k2].x, sc[k2].y), fmaxf(sc[k2].z, sc[k2].w)));
+        }
+        mw = group_max(mw);                            // finite: key tile 2 w holds at least one real key
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          sc[k2].x = __builtin_amdgcn_exp2f(sc[k2].x - mw);
+          sc[k2].y = __builtin_amdgcn_exp2f(sc[k2].y - mw);
+          sc[k2].z = __builtin_amdgcn_exp2f(sc[k2].z - mw);
+          sc[k2].w = __builtin_amdgcn_exp2f(sc[k2].w - mw);
+          lw += (sc[k2].x + sc[k2].y) + (sc[k2].z + sc[k2].w);
+        }
+        lw = group_sum(lw);
+        const Split8 pf = split8(sc[0] * splat4(SP), sc[1] * splat4(SP));
+#pragma unroll
+        for (int i = 0; i < A_OT; ++i) {
+          const f32x4 lo = {ve[hh][i][0], ve[hh][i][1], ve[hh][i][2], ve[hh][i][3]}, hi = {ve[hh][i][4], ve[hh][i][5], ve[hh][i][6], ve[hh][i][7]};
+          const Split8 vf = split8(lo * splat4(sv), hi * splat4(sv));
+          o[i] = ns_mfma(vf.t[1], pf.t[0], o[i]);
+          o[i] = ns_mfma(vf.t[0], pf.t[1], o[i]);
+          o[i] = ns_mfma(vf.t[0], pf.t[0], o[i]);
+        }
+      }
+      if (gq == 0) { A.pm[hh][w][c] = mw; A.pl[hh][w][c] = lw; }
+#pragma unroll
+      for (int i = 0; i < A_OT; ++i) A.po[hh][w][i][lane] = o[i];
+    }
+    __syncthreads();                                   // the partials of both heads are written
+    if (w < 2 && h0 + w < H) {                         // wave 0 / 1 combines head h0 / h0 + 1
+      const int h = h0 + w;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mx = fmaxf(mx, A.pm[w][k][c]);
+      float den = 0.f;
+      f32x4 acc[A_OT] = {splat4(0.f), splat4(0.f), splat4(0.f)};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float sc_k = __builtin_amdgcn_exp2f(A.pm[w][k][c] - mx);          // waves without keys: exp2(-inf) = 0
+        den += A.pl[w][k][c] * sc_k;
+#pragma unroll
+        for (int i = 0; i < A_OT; ++i) acc[i] += A.po[w][k][i][lane] * splat4(sc_k);
+      }
+      const float inv = (1.0f / den) * (1.0f / (SP * sv));
+#pragma unroll
+      for (int i = 0; i < A_OT; ++i)
+        if (16 * i + g4 < A_HS) *reinterpret_cast<f32x4*>(&A.ctx[c][h * A_HS + 16 * i + g4]) = acc[i] * splat4(inv);
+    }
+    __syncthreads();                                   // combined: the partial areas are free, the context rows of these heads written
+  }
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xs[kb] = *reinterpret_cast<const f32x4*>(&A.ctx[c][16 * kb + g4]);
+  __syncthreads();                                     // ... and read: the area is reused by the exchange below
+}
+
+// [attention +] out-projection + residual + LayerNorm + pw_conv_1 + GLU (pp_out_glu_kernel, one tile per workgroup): ctx (or q, k,
+// v), x1 -> x2, u.  Grid (ceil(T / 16), utterances).
+template <int NW>
+union Ns1OgLds {
+  Ns1Lds<NW> l;
+  Ns1AttnLds a;
+};
+template <int NW, bool ATTN>
+__global__ __launch_bounds__(NW * 64) void ns1_out_glu_kernel(OutGluArgs a, int T) {
+  __shared__ __attribute__((aligned(16))) Ns1OgLds<NW> U;
+  Ns1Lds<NW>& L = U.l;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, t = lane & 15;
-  const Ns1Tile tl = ns1_tile(a.M, 0, t);
+  const Ns1Tile tl = ns1_tile(a.M, T, t);
   f32x4 xs[KB], x2[KB];
+  if constexpr (ATTN) ns1_attention<NW>(U.a, a, blockIdx.y, blockIdx.x * 16, w, lane, xs);
+  else {
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + tl.row + 16 * kb + g4);
+    for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.ctx + tl.row + 16 * kb + g4);
+  }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) x2[kb] = ldg4(a.x1 + tl.row + 16 * kb + g4);
   {
@@ -1105,18 +1250,30 @@ int launch_ns1_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
   hipLaunchKernelGGL((ns1_ff1_qkv_kernel<NS1_W>), dim3((b.M + 15) / 16), dim3(NS1_W * 64), 0, s, b);
   return 0;
 }
-// what launch_pp_og_tail_ff1 / _ff2 do in one launch, as two: out-projection + GLU (x2 -> g.x2, u -> g.u), then depthwise conv +
-// tail [+ the next block's ff_module_1 + qkv].  a.dw_u is set to g.u here; a.x2 must be g.x2.
-int launch_ns1_og_tail(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g, hipStream_t s) {
+// what launch_pp_og_tail_ff1 / _ff2 do in one launch, as two: [attention +] out-projection + GLU (x2 -> g.x2, u -> g.u), then
+// depthwise conv + tail [+ the next block's ff_module_1 + qkv].  a.dw_u is set to g.u here; a.x2 must be g.x2.
+bool ns1_block_ok(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g) {
   if (!ns1_rows_ok(a.M) || a.M != g.M || !g.ns_out || !g.ns_pw1 || !a.ns_cv_w1 || !a.ns_cv_w2 || !a.ns_ff_w1 || !a.ns_ff_w2 || a.head_pp ||
-      !g.x2 || !g.u || !g.ctx || !g.x1 || !a.dw_wd || a.dw_T <= 0 || a.M % a.dw_T != 0 || (a.dw_pad != 15 && a.dw_pad != 31))
-    return -1;
-  if (b && (!b->ns_w1 || !b->ns_w2 || !b->ns_qkv || b->pre_pp || b->M != a.M)) return -1;
+      !g.x2 || !g.u || !g.x1 || !a.dw_wd || a.dw_T <= 0 || a.M % a.dw_T != 0 || (a.dw_pad != 15 && a.dw_pad != 31))
+    return false;
+  if (b && (!b->ns_w1 || !b->ns_w2 || !b->ns_qkv || b->pre_pp || b->M != a.M)) return false;
+  return true;
+}
+bool ns1_attn_ok(int hs, const AttnArgs& at) {
+  // MI355ASR_NS1_ATTN=0: the attention of a small-batch block as its own launch (attention_split_kernel)
+  static const bool on = [] { const char* v = getenv("MI355ASR_NS1_ATTN"); return v ? atoi(v) != 0 : true; }();
+  return on && hs == A_HS && at.Tq == at.Tk && at.Tk > 16 && at.Tk <= 256 && at.win_front < 0 && at.H >= 1 && at.H * A_HS == at.D && at.D == D &&
+         at.h2_sq > 0.f && at.h2_sk > 0.f && at.h2_sv > 0.f && at.ldq % 4 == 0 && at.ldk % 4 == 0 && at.q_off == 0;
+}
+int launch_ns1_og_tail(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g, hipStream_t s) {
+  if (!ns1_block_ok(a, b, g) || (!g.attn && !g.ctx)) return -1;
+  if (g.attn && (!g.aq || !g.ak || !g.av || g.a_T != a.dw_T)) return -1;
   note_scheme(SCHEME_F16X2);
-  hipLaunchKernelGGL((ns1_out_glu_kernel<NS1_W>), dim3((g.M + 15) / 16), dim3(NS1_W * 64), 0, s, g);
+  const dim3 grid((a.dw_T + 15) / 16, a.M / a.dw_T);
+  if (g.attn) hipLaunchKernelGGL((ns1_out_glu_kernel<NS1_W, true>), grid, dim3(NS1_W * 64), 0, s, g, a.dw_T);
+  else hipLaunchKernelGGL((ns1_out_glu_kernel<NS1_W, false>), grid, dim3(NS1_W * 64), 0, s, g, a.dw_T);
   TailFf2Args k = a;
   k.dw_u = g.u; k.x2 = g.x2;
-  const dim3 grid((a.dw_T + 15) / 16, a.M / a.dw_T);
   if (b) hipLaunchKernelGGL((ns1_tail_kernel<NS1_W, true>), grid, dim3(NS1_W * 64), 0, s, k, *b);
   else hipLaunchKernelGGL((ns1_tail_kernel<NS1_W, false>), grid, dim3(NS1_W * 64), 0, s, k, Ff1QkvArgs{});
   return 0;

@@ -1163,7 +1163,6 @@ bool pp_og_fold_ok(const TailFf2Args& a, const OutGluArgs& g) {
 }
 int launch_pp_og_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, const OutGluArgs& g, hipStream_t s) {
   if (!pp_og_fold_ok(a, g) || !b.pp_slabs || a.M != b.M) return -1;
-  if (launch_ns1_og_tail(a, &b, g, s) == 0) return 0;     // round 6, small batches: one 16-token tile per workgroup (fused_ns.hip), two launches
   note_scheme(SCHEME_F16X2);
   hipLaunchKernelGGL((pp_block_kernel<true, true, 0, true, true>), dim3((a.dw_T + 63) / 64, a.M / a.dw_T), dim3(LD_THREADS), 0, s, a, b, g);
   return 0;
@@ -1177,7 +1176,6 @@ bool pp_head_fold_ok(int M, int n_valid, int groups) {
 }
 int launch_pp_og_tail_ff2(const TailFf2Args& a, const OutGluArgs& g, hipStream_t s) {
   if (!pp_og_fold_ok(a, g)) return -1;
-  if (!a.head_pp && launch_ns1_og_tail(a, nullptr, g, s) == 0) return 0;      // round 6, small batches (fused_ns.hip)
   note_scheme(SCHEME_F16X2);
   if (a.head_pp) {
     if (!pp_head_fold_ok(a.M, a.head_nvalid, a.head_groups)) return -1;

@@ -339,6 +339,12 @@ struct OutGluArgs {
   float pp_sw_out = 1.f, pp_sw_pw1 = 1.f;
   // round 6 (fused_ns.hip): the same fragments in plain order -- out projection [5][9][2][64], pw_conv_1 [5][18][2][64] (u32x4 per lane)
   const float *ns_out = nullptr, *ns_pw1 = nullptr;
+  // ... and, for the one-tile-per-workgroup kernels, the attention in front of the out projection in the same launch (ctx is then
+  // not read): q / k / v of the block (AttnArgs' layout fields), T <= 256 frames per utterance, the two-term operand scales
+  int attn = 0;
+  const float *aq = nullptr, *ak = nullptr, *av = nullptr;
+  int a_T = 0, a_H = 0, a_ldq = 0, a_ldk = 0, a_head_major = 0;
+  float a_sq = 0.f, a_sk = 0.f, a_sv = 0.f;
 };
 struct TailFf2Args {
   const float* dw; const float* x2; float* y;
@@ -389,6 +395,8 @@ int launch_ns_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
 // ... one 16-token tile per workgroup, for small batches (up to MI355ASR_NS1_MAX_M rows): ff_module_1 + qkv; and what the folded tail
 // launches do, as out-projection + GLU (writes g.x2, g.u) followed by depthwise conv + tail [+ next ff_module_1 + qkv when b is set]
 bool ns1_rows_ok(int M);
+bool ns1_block_ok(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g);      // launch_ns1_og_tail will take this block
+bool ns1_attn_ok(int hs, const AttnArgs& at);                                             // ... with its attention in the first launch
 int launch_ns1_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
 int launch_ns1_og_tail(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g, hipStream_t s);
 int launch_ns1_head(const GemmArgs& a, const float* ns, float sw, int groups, hipStream_t s);   // ns: [W ; b] fragments in plain order [5][9 groups][2][64]

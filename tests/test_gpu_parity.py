@@ -2016,20 +2016,21 @@ np.savez(sys.argv[1], **out)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         res = {}
-        for tag, extra in (("ns1", {}), ("pp", {"MI355ASR_NS1_MAX_M": "0"})):
+        for tag, extra in (("ns1", {}), ("ns1_attn_own", {"MI355ASR_NS1_ATTN": "0"}), ("pp", {"MI355ASR_NS1_MAX_M": "0"})):
             r = subprocess.run([sys.executable, "-c", code, os.path.join(td, tag + ".npz")], env=dict(os.environ, **extra), capture_output=True,
                                text=True, timeout=900, cwd=root)
             lines = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
             assert len(lines) == 3, r.stderr[-3000:]
             assert all(float(l[1]) < TOL and float(l[2]) < TOL for l in lines), (tag, lines)
             res[tag] = (lines, np.load(os.path.join(td, tag + ".npz")))
-        for k in res["ns1"][1].files:
-            a, b = res["ns1"][1][k], res["pp"][1][k]
-            if k.endswith("_ids"):
-                assert np.array_equal(a, b), k
-            else:
-                apart = float(np.abs(a - b).max())
-                assert 0.0 < apart < 1e-4, (k, apart)
+        for other in ("pp", "ns1_attn_own"):          # (the attention inside the out-projection launch sums its key tiles in another order)
+            for k in res["ns1"][1].files:
+                a, b = res["ns1"][1][k], res[other][1][k]
+                if k.endswith("_ids"):
+                    assert np.array_equal(a, b), (other, k)
+                else:
+                    apart = float(np.abs(a - b).max())
+                    assert 0.0 < apart < 1e-4, (other, k, apart)
         print("one tile per workgroup vs pair-pipelined: oracle distances %s / %s" % (res["ns1"][0], res["pp"][0]))
 
 

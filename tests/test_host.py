@@ -1016,6 +1016,7 @@ SWITCHES = {
     "MI355ASR_NS": "1: dmodel 144: ff_module_1 + qkv on the N-split kernel of fused_ns.hip (hidden dimension split over four waves, weights straight from L2 into registers) instead of the pair-pipelined one; off by default: slower, profiles/r06_ns_experiments.md | test_n_split_ff1_qkv_kernel_against_the_pair_pipelined_one_and_the_oracle",
     "MI355ASR_ATTN_LONG": "0: more than 256 keys on the fp32-MFMA attention kernels instead of attention_split_long_kernel (key blocks with an online softmax on the two-term pipe) | test_long_utterances_attention_in_key_blocks_against_the_fp32_kernels_and_the_oracle",
     "MI355ASR_NS1_MAX_M": "n: dmodel 144: blocks of up to n rows (default 4096; 0: never) on the one-tile-per-workgroup kernels of fused_ns.hip (small batches: eight waves share a 16-token tile) instead of the pair-pipelined ones | test_small_batches_one_tile_per_workgroup_against_the_pair_pipelined_kernels_and_the_oracle",
+    "MI355ASR_NS1_ATTN": "0: the attention of a small-batch block (one-tile-per-workgroup kernels) as its own launch instead of inside the out-projection launch | test_small_batches_one_tile_per_workgroup_against_the_pair_pipelined_kernels_and_the_oracle",
     "MI355ASR_STREAM256": "0: bf16 mode, dmodel 256, chunks of <= 16 rows: one launch per layer / module instead of the whole block stack in stream256_kernel | test_streaming_block_stack_in_one_launch_vs_layer_at_a_time_and_rounding_oracle",
     "MI355ASR_CHAIN256_RT": "1 / 2 / 4: row tiles per workgroup of chain256_bf16_kernel (default by row count) | test_bf16_chain256_against_layer_at_a_time",
     "MI355ASR_SUBCONV_RT": "1 / 2: row tiles per wave of the two-term subsampling conv (default: one while that gives no CU a second workgroup) | test_two_term_subsampling_conv_one_row_tile_per_wave_bit_identical",
