@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355asr.so")
 SOURCES = ["api.hip", "api_chunk.hip", "api_translator.hip", "blocks.hip", "frontend.hip", "beam.hip", "beam_device.hip", "fused.hip", "fused_pp.hip", "fused_ns.hip", "fft_stft.hip", "attention_lds.hip", "attention_split.hip", "attention_split64.hip", "subconv.hip", "bf16.hip", "stream256.hip", "gemm_ring.hip", "leaf.hip", "wavpick.hip"]
-HEADERS = ["common.h", "launch.h", "beam.h", "wstream.h", "model.h", "prep_sched.inc", "prep2_sched.inc", "pp_units.inc", "pp_layout.inc", "refmath.h", "split_f16.h", "refmath_tables.inc", os.path.join("..", "..", "include", "mi355asr.h")]
+HEADERS = ["common.h", "launch.h", "beam.h", "wstream.h", "model.h", "prep_sched.inc", "prep2_sched.inc", "pp_units.inc", "pp_layout.inc", "refmath.h", "split_f16.h", "env.h", "refmath_tables.inc", os.path.join("..", "..", "include", "mi355asr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("MI355ASR_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DMI355ASR_DIAG_KERNELS (timing-only kernel variants)
 

@@ -322,8 +322,7 @@ float append_pp_plain(std::vector<float>& stream, const std::function<float(int,
 // 32 x 32 Cooley-Tukey factorisation (fft_stft.hip); otherwise the dense DFT GEMM stays.  MI355ASR_FFT=0 forces dense.
 FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vector<float>& im, int n_dft, int nb) {
   FftOff o;
-  const char* env = std::getenv("MI355ASR_FFT");
-  if (env && std::atoi(env) == 0) return o;
+  if (mi355_env("MI355ASR_FFT", 1) == 0) return o;
   if (n_dft != 1024 || nb != 513) return o;
   const double two_pi = 6.283185307179586476925286766559;
   std::vector<double> ct(1024), st(1024);
@@ -371,7 +370,7 @@ FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vecto
 MelBandOff pack_mel_band(ArenaBuilder& ab, const std::vector<float>& f2m, int nb, int n_mels) {
   MelBandOff o;
   // MI355ASR_MEL_BAND=0: always the dense mel GEMM
-  static const bool on = [] { const char* v = getenv("MI355ASR_MEL_BAND"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_MEL_BAND", 1) != 0;
   if (!on) return o;
   std::vector<int> band(2 * (size_t)n_mels, 0);
   int bw = 4;
@@ -440,11 +439,11 @@ void put_ring_head(ArenaBuilder& ab, size_t p16_off, const std::function<float(i
 // in bf16 mode on gemm16<PBf16>
 // rows from which launch_gemm16 hands a dense layer to the ring kernels (crossover measured below)
 long ring_min_rows() {
-  static const long v = [] { const char* e = getenv("MI355ASR_RING_MIN_M"); return e ? atol(e) : 1500L; }();
+  static const long v = mi355_env("MI355ASR_RING_MIN_M", 1500);
   return v;
 }
 bool ring_packs_wanted(const mi355asr_model* m) {
-  static const bool on = [] { const char* v = getenv("MI355ASR_GEMM_RING"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_GEMM_RING", 1) != 0;
   // (bf16 mode, dmodel 256: chain256_bf16_kernel reads the one-term ring packs at every row count)
   return on && m->cfg.dmodel % 128 == 0 &&
          (m->expected_rows < 0 || m->expected_rows >= ring_min_rows() || (m->cfg.gemm_dtype == 1 && m->cfg.dmodel == 256));
@@ -739,7 +738,7 @@ BlockDev resolve(const BlockOff& o, const float* base) {
 // Layer-at-a-time GEMM family (bf16.hip) instead of the fused / chained fp32 kernels: in bf16 mode, and in fp32 for
 // dmodel values those kernels are not instantiated for (e.g. 512 = ConformerL).
 bool use_gemm16(const mi355asr_model* m) {
-  static const bool force = [] { const char* v = getenv("MI355ASR_GEMM16"); return v && atoi(v) != 0; }();
+  static const bool force = mi355_env("MI355ASR_GEMM16", 0) != 0;
   // dmodel 256 with slab rings (gemm_ring.hip): one launch per dense layer on the split-bf16 pipe beats the fp32 chains
   return force || m->cfg.gemm_dtype == 1 || (m->cfg.dmodel != 144 && m->cfg.dmodel != 256) ||
          (m->cfg.dmodel == 256 && !m->ring_of.empty());
@@ -751,7 +750,7 @@ bool use_gemm16(const mi355asr_model* m) {
 // 2 s / 50 rows 1.118 vs 1.224, and B = 2, 3 at 10 s 1.241 / 1.252 vs 1.513 / 1.651 (profiles/r04_batch_sweep.md; the
 // round-2 ring kernels had crossed at ~800 rows, which is where this threshold stood until round 4).  MI355ASR_SMALL_M overrides.
 bool gemm16_for(const mi355asr_model* m, size_t M) {
-  static const long small_m = [] { const char* v = getenv("MI355ASR_SMALL_M"); return v ? atol(v) : 48L; }();
+  static const long small_m = mi355_env("MI355ASR_SMALL_M", 48);
   return use_gemm16(m) || (long)M <= small_m;
 }
 int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, const float* wp, hipStream_t s) {
@@ -836,7 +835,7 @@ int geometry(const mi355asr_model* m, int B, int L, Geometry* g) {
 // q = LN(x + PE) and k = v = the encoder output (T_enc frames per utterance), everything else is a ConformerBlock.
 
 static bool fused_env_on() {
-  static const bool on = [] { const char* v = getenv("MI355ASR_FUSED"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_FUSED", 1) != 0;
   return on;
 }
 bool block_takes_pre(const mi355asr_model* m, const BlockDev& w, size_t M) {
@@ -863,7 +862,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     };
     // round 4: bf16 mode, dmodel 256: FFModule and ConvModule tail as ONE launch each (bf16.hip: chain256_bf16_kernel; the
     // hidden activation stays in LDS) -- MI355ASR_CHAIN256=0: one gemm16 / gemm_ring launch per layer
-    static const bool chain_env = [] { const char* v = getenv("MI355ASR_CHAIN256"); return v ? atoi(v) != 0 : true; }();
+    static const bool chain_env = mi355_env("MI355ASR_CHAIN256", 1) != 0;
     auto ring = [&](const float* wp) -> const float* { const auto it = m->ring_of.find(wp); return it == m->ring_of.end() ? nullptr : it->second; };
     const float* cr[6] = {ring(w.ff_w1p[0]), ring(w.ff_w2p[0]), ring(w.ff_w1p[1]), ring(w.ff_w2p[1]), ring(w.pc_w1p), ring(w.pw2_wp)};
     const bool chain256 = m->cfg.gemm_dtype == 1 && d == 256 && chain_env && !cross && cr[0] && cr[1] && cr[2] && cr[3] && cr[4] && cr[5];
@@ -950,7 +949,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
       return at;
     };
     auto qkv_head_major = [&](const BlockDev& bw) {
-      static const bool on = [] { const char* v = getenv("MI355ASR_QKV_HEAD_MAJOR"); return v ? atoi(v) != 0 : true; }();
+      static const bool on = mi355_env("MI355ASR_QKV_HEAD_MAJOR", 1) != 0;
       return on && ff1_qkv_pp_selected(bw.ff1_slabs != nullptr, bw.pp_ff1 != nullptr) && attention_takes_head_major(hs, attn_args(bw, true));
     };
     auto ff1_args = [&](const BlockDev& bw, const float* x0, float* x1) {
@@ -1220,7 +1219,7 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   same_pad(T1, 3, 2, &T2, &pt2);
   SubConvArgs sa{};
   sa.mel = mel; sa.out = sub; sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b; sa.w2s = m->c2_wsplit;
-  static const bool force_half = [] { const char* v = getenv("MI355ASR_SUBCONV_TERMS"); return v && atoi(v) == 22; }();   // 22: also for caller-supplied features (tests)
+  static const bool force_half = mi355_env("MI355ASR_SUBCONV_TERMS", -1) == 22;   // 22: also for caller-supplied features (tests)
   if (m->c2_whalf && (mel_bounded || force_half)) { sa.w2h = m->c2_whalf; sa.h_scale = m->c2_hscale; sa.h_wscale = m->c2_wscale; }
   // conv1 on the matrix pipe needs the frontend's own bound on |mel| for its fp16 planes: not for caller-supplied features
   if (sa.w2h && mel_bounded) { sa.c1_mscale = m->c1_mscale; sa.c1_wscale = m->c1_wscale; }
@@ -1239,7 +1238,7 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   lg.M = Bp * T2; lg.K = m->dm.F2 * d; lg.NT = d / 16; lg.ldy = d; lg.n_valid = d;
   // MI355ASR_SUBLINEAR_SPLIT: 1 (default) = split-bf16 ring-DMA kernel (fused.hip) from 4096 rows, 2 = for any row
   // count, 0 = the fp32-MFMA stream_gemm_kernel
-  static const int lin_split = [] { const char* v = std::getenv("MI355ASR_SUBLINEAR_SPLIT"); return v ? std::atoi(v) : 1; }();
+  static const int lin_split = (int)mi355_env("MI355ASR_SUBLINEAR_SPLIT", 1);
   if (lin_split && m->lin_wsplit && (lg.M >= 4096 || lin_split == 2)) {
     if (defer_dense && m->lin_pp && pp_sublinear_ok(lg, m->lin_pp)) { *defer_dense = true; return 0; }   // the caller folds it into the first block
     PROF(MI355ASR_K_SUBLINEAR);
@@ -1358,7 +1357,7 @@ int run_wavpick(const mi355asr_model* m, const float* wav, int Bp, int Lb, int T
 
 // the encoder's block stack as stream256_kernel's arguments; false: not its shape (or a ring pack is missing, or switched off)
 bool stream256_args(const mi355asr_model* m, int B, int T, const float* x, float* y, S256Args& sa) {
-  static const bool on = [] { const char* v = getenv("MI355ASR_STREAM256"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_STREAM256", 1) != 0;
   const int nb = m->cfg.num_blocks;
   if (!on || m->cfg.gemm_dtype != 1 || m->cfg.dmodel != 256 || m->cfg.num_heads != 4 || m->cfg.head_size != 64 ||
       !stream256_shape_ok(B, T, nb, m->cfg.kernel_size) || (int)m->enc_blocks.size() < nb)
@@ -1541,8 +1540,8 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
     return fail(MI355ASR_EINVAL, "negative count in config");
   auto* m = new mi355asr_model();
   m->cfg = c;
-  if (const char* e = std::getenv("MI355ASR_LEAF_TERMS")) {   // 0 = fp32 MFMA Gabor conv; 2 / 3 = bf16 terms per operand
-    const int t = std::atoi(e);
+  {
+    const int t = (int)mi355_env("MI355ASR_LEAF_TERMS", -1);   // 0 = fp32 MFMA Gabor conv; 2 / 3 = bf16 terms per operand
     if (t == 0 || t == 2 || t == 3) m->leaf_terms = t;
   }
   Dims& dm = m->dm;
@@ -1878,7 +1877,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
     o_c2s = ab.put(pack_conv2_split(c2, d));
     // Two-term fp16 scheme (subconv.hip): needs a bound of conv1's output.  The frontend's dB values lie in [-80, 0]
     // (floor_db, relative to the utterance maximum), a mel value in 80 x the filter's L1 norm; LEAF features have no bound.
-    static const int terms_env = [] { const char* v = getenv("MI355ASR_SUBCONV_TERMS"); return v ? atoi(v) : 2; }();
+    static const int terms_env = (int)mi355_env("MI355ASR_SUBCONV_TERMS", 2);
     if ((terms_env == 2 || terms_env == 22) && c.mel_layer_type != 1) {
       double mb = 80.0;
       if (c.mel_layer_type == 0) {
@@ -2124,7 +2123,7 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
   if (mi355asr_launch_topn(x, (int)frames, V, N, is_logits, d_idx, d_p, s) != 0)
     return fail(MI355ASR_EHIP, "top-n kernel launch failed (V=%d needs %zu bytes of LDS)", V, (size_t)V * 4);
   // MI355ASR_BEAM_DEVICE=0: the prefix search on host threads (beam.hip) instead of the device kernel (beam_device.hip)
-  static const bool dev_env = [] { const char* v = getenv("MI355ASR_BEAM_DEVICE"); return v ? atoi(v) != 0 : true; }();
+  static const bool dev_env = mi355_env("MI355ASR_BEAM_DEVICE", 1) != 0;
   const size_t need_dev = ((need + 255) & ~(size_t)255) + mi355asr_beam_device_ws_bytes(B, T, beam_size, max_len);
   if (dev_env && mi355asr_beam_device_applicable(V, N, beam_size) && ws_bytes >= need_dev) {
     char* w = (char*)ws + ((need + 255) & ~(size_t)255);
@@ -2135,7 +2134,7 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
     long long* d_prof = nullptr;
     (void)mi355asr_beam_device_carve(w, B, T, beam_size, max_len, &a, &d_len, &d_prof);   // the same layout the size query adds up
     // MI355ASR_BEAM_PROF=1: clock counters of utterance 0's search, printed per call (where a frame's time goes)
-    static const bool prof_env = [] { const char* v = getenv("MI355ASR_BEAM_PROF"); return v && atoi(v) != 0; }();
+    static const bool prof_env = mi355_env("MI355ASR_BEAM_PROF", 0) != 0;
     if (prof_env) {
       a.prof = d_prof;
       HIP_TRY(hipMemsetAsync(a.prof, 0, 16 * sizeof(long long), s));

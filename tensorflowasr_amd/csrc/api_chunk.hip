@@ -487,7 +487,7 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
     SubConvArgs sa{};
     sa.mel = me.mel; sa.out = (float*)(ws + p.sub); sa.w1 = m->c1_w; sa.b1 = m->c1_b; sa.w2p = m->c2_wp; sa.b2 = m->c2_b;
     sa.w2s = m->c2_wsplit;
-    static const bool three = [] { const char* v = getenv("MI355ASR_SUBCONV_TERMS"); return v && atoi(v) == 3; }();
+    static const bool three = mi355_env("MI355ASR_SUBCONV_TERMS", -1) == 3;
     if (melmax && me.absmax && !three) { sa.w2h = m->c2_whalf; sa.h_wscale = m->c2_wscale; sa.h_melmax = melmax; sa.h_l1 = m->c1_l1; sa.h_bmax = m->c1_bmax; sa.c1_wscale = m->c1_wscale; }
     sa.B = B; sa.F = g.F; sa.NM = c.n_mels; sa.T1 = g.T1; sa.F1 = m->dm.F1; sa.T2 = T; sa.F2 = m->dm.F2;
     sa.st1 = 2; sa.pt1 = 4; sa.pf1 = 2; sa.pt2 = 0; sa.pf2 = 0;

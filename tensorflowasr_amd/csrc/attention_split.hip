@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 
 namespace {
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(LW * 64) void attention_split_long_kernel(AttnArgs 
 
 static bool attn_long_on() {
   // MI355ASR_ATTN_LONG=0: more than 256 keys on the fp32-MFMA kernels (attention_lds_kernel / attention_kernel) as before round 6
-  static const bool on = [] { const char* v = getenv("MI355ASR_ATTN_LONG"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_ATTN_LONG", 1) != 0;
   return on;
 }
 bool attention_split_applicable(int hs, const AttnArgs& a) {
@@ -482,7 +483,7 @@ bool attention_split_applicable(int hs, const AttnArgs& a) {
 
 static bool attn_three_env() {
   // MI355ASR_ATTN_TERMS=3: the three-term bf16 kernel also where the operand bounds are known
-  static const bool three = [] { const char* v = getenv("MI355ASR_ATTN_TERMS"); return v && atoi(v) == 3; }();
+  static const bool three = mi355_env("MI355ASR_ATTN_TERMS", -1) == 3;
   return three;
 }
 bool attention_split_two_term(int hs, const AttnArgs& a) {

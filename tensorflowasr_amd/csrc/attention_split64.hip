@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 
 namespace {
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(ATH) void attention_split64_kernel(AttnArgs a) {
 
 bool attention_split64_applicable(int hs, const AttnArgs& a) {
   // MI355ASR_ATTN64_SPLIT=0: the fp32-MFMA kernels (attention_lds_kernel<64, 272> / attention_kernel<64>) as before
-  static const bool on = [] { const char* v = getenv("MI355ASR_ATTN64_SPLIT"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_ATTN64_SPLIT", 1) != 0;
   return on && hs == HS && a.win_front < 0 && !a.head_major && a.Tk <= 16 * NKT && a.Tk > 32 && a.Tq > 16 && a.ldk % 4 == 0 && a.ldq % 4 == 0 &&
          a.h2_sq > 0.f && a.h2_sk > 0.f && a.h2_sv > 0.f;
 }

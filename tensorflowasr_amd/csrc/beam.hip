@@ -26,6 +26,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+
+#include "env.h"
 #include <vector>
 
 #include "beam.h"
@@ -574,7 +576,7 @@ int mi355asr_beam_topn_impl(const int32_t* top_idx, const float* top_p, const in
 
 int mi355asr_launch_topn(const float* x_dev, int frames, int V, int N, int is_logits, int32_t* idx_dev, float* p_dev,
                          hipStream_t s) {
-  static const bool reg_off = [] { const char* e = getenv("MI355ASR_TOPN_REG"); return e && atoi(e) == 0; }();
+  static const bool reg_off = mi355_env("MI355ASR_TOPN_REG", -1) == 0;
   if (N <= 64 && V >= 64 && V <= 64 * 144 && !reg_off) {
     const int nr = (V + 63) / 64;
 #define TOPN_REG(NR) hipLaunchKernelGGL(topn_reg_kernel<NR>, dim3(frames), dim3(64), 0, s, x_dev, V, N, is_logits, idx_dev, p_dev)

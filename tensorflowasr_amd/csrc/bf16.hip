@@ -12,6 +12,7 @@
 // exists for are tiny (832 rows): columns are split over grid.y so that every launch has several hundred waves,
 // and the layers of a block run as separate launches (the hidden activation goes through HBM: 3.4 MB).
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 
 namespace {
@@ -621,7 +622,7 @@ int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s) {
   const dim3 block(C_NW * 64);
   // more row tiles per workgroup as soon as every CU has a workgroup anyway: a half / a quarter of the weight traffic per row
   // (MI355ASR_CHAIN256_RT = 1 / 2 / 4 forces one)
-  static const int rt_env = [] { const char* v = getenv("MI355ASR_CHAIN256_RT"); return v ? atoi(v) : 0; }();
+  static const int rt_env = (int)mi355_env("MI355ASR_CHAIN256_RT", 0);
   const int rt = rt_env ? rt_env : (tiles >= 1024 ? 4 : (tiles >= 512 ? 2 : 1));
   if (rt == 4) {
     const dim3 grid((tiles + 3) / 4);

@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 
 // =====================================================================================================
@@ -628,7 +629,7 @@ static void launch_attention_t(const AttnArgs& a, hipStream_t s) {
   // (win_front + win_back + 16 keys per query tile) use small blocks
   const int span = a.win_front >= 0 ? min(a.Tk, a.win_front + a.win_back + 31) : a.Tk;
   // band attention whose window for 64 queries fits ATT_WROWS key rows: K / V staged once per workgroup (MI355ASR_ATTN_BAND_LDS=0: from L2)
-  static const bool band_lds = [] { const char* v = getenv("MI355ASR_ATTN_BAND_LDS"); return v ? atoi(v) != 0 : true; }();
+  static const bool band_lds = mi355_env("MI355ASR_ATTN_BAND_LDS", 1) != 0;
   if (span <= 16) hipLaunchKernelGGL((attention_kernel<HS, 1>), grid, dim3(BLOCK_THREADS), 0, s, a);
   else if (band_lds && HS % 4 == 0 && HS <= 36 && a.win_front >= 0 && span <= 96 && a.win_front + a.win_back + 16 * WAVES_PER_BLOCK + 15 <= ATT_WROWS)
     hipLaunchKernelGGL((attention_kernel<HS, 4, true>), grid, dim3(BLOCK_THREADS), 0, s, a);
@@ -638,8 +639,8 @@ static void launch_attention_t(const AttnArgs& a, hipStream_t s) {
 
 // would launch_attention hand this launch to the two-term attention_split_kernel (the one kernel that reads head-major operands)?
 bool attention_takes_head_major(int HS, const AttnArgs& a) {
-  static const bool lds_env = [] { const char* v = getenv("MI355ASR_ATTN_LDS"); return v ? atoi(v) != 0 : true; }();
-  static const bool split_env = [] { const char* v = getenv("MI355ASR_ATTN_SPLIT"); return v ? atoi(v) != 0 : true; }();
+  static const bool lds_env = mi355_env("MI355ASR_ATTN_LDS", 1) != 0;
+  static const bool split_env = mi355_env("MI355ASR_ATTN_SPLIT", 1) != 0;
   return lds_env && split_env && attention_split_two_term(HS, a);
 }
 
@@ -647,8 +648,8 @@ int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
   // short full-attention utterances (offline ConformerCTC): K / V^T staged in LDS (attention_lds.hip)
   // MI355ASR_ATTN_SPLIT=0: the fp32-MFMA LDS kernel of round 1 instead of the split-bf16 one (attention_split.hip);
   // MI355ASR_ATTN_LDS=0: neither (online-softmax kernel with K / V from L2)
-  static const bool lds_env = [] { const char* v = getenv("MI355ASR_ATTN_LDS"); return v ? atoi(v) != 0 : true; }();
-  static const bool split_env = [] { const char* v = getenv("MI355ASR_ATTN_SPLIT"); return v ? atoi(v) != 0 : true; }();
+  static const bool lds_env = mi355_env("MI355ASR_ATTN_LDS", 1) != 0;
+  static const bool split_env = mi355_env("MI355ASR_ATTN_SPLIT", 1) != 0;
   if (lds_env && split_env && attention_split_applicable(HS, a))
     return launch_attention_split(HS, a, s);
   if (lds_env && split_env && attention_split64_applicable(HS, a))      // round 5: head size 64, operand bounds known, <= 288 keys

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 
 namespace {
@@ -479,10 +480,10 @@ int launch_fft_stft(const FftStftArgs& a, hipStream_t s) {
   // enough waves for 4 per SIMD (their VALU / LDS phases hide under each other's MFMAs), each looping over frames
   const int waves = std::min(total, 4096);
   // MI355ASR_FFT_SPLIT=0: both DFT stages on the fp32 MFMA (round 1) instead of the split-bf16 pipe
-  static const bool split = [] { const char* v = getenv("MI355ASR_FFT_SPLIT"); return v ? atoi(v) != 0 : true; }();
+  static const bool split = mi355_env("MI355ASR_FFT_SPLIT", 1) != 0;
   // MI355ASR_FFT_TERMS=3: three bf16 terms instead of two fp16 terms (the stage matrices and the per-column scales make the
   // two-term kernel independent of the signal's amplitude: no bound is assumed)
-  static const bool three = [] { const char* v = getenv("MI355ASR_FFT_TERMS"); return v && atoi(v) == 3; }();
+  static const bool three = mi355_env("MI355ASR_FFT_TERMS", -1) == 3;
   if (split && a.w1h && a.w2h && !three) {
     note_scheme(SCHEME_F16X2);
     // three workgroups per CU are resident (see MI355ASR_STFT_TABS_LDS): one round of 768 workgroups, every wave loops over its frames

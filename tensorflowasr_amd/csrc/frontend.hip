@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv_split_kernel(SubConv
 
 int launch_subconv(int D, const SubConvArgs& a, hipStream_t s) {
   // MI355ASR_SUBCONV_F32=1: the fp32-MFMA register-stream kernel instead of the split-operand one (both in subconv.hip)
-  static const bool f32k = [] { const char* v = getenv("MI355ASR_SUBCONV_F32"); return v && atoi(v) != 0; }();
+  static const bool f32k = mi355_env("MI355ASR_SUBCONV_F32", 0) != 0;
   if (!f32k && launch_subconv_split(D, a, s) == 0) return 0;       // dmodel 144 / 256 / 512 with the split pack
   note_scheme(SCHEME_F32);
   if (D == 144) return launch_subconv144(a, s);

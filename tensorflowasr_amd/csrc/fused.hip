@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 #include "wstream.h"
 
@@ -1140,7 +1141,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void tail_ff2_kernel(TailFf2Args 
 // products on v_mfma_f32_16x16x4_f32; what a handle without slab streams runs anyway).  Otherwise, in order: the pair-pipelined
 // two-term fp16 kernels (fused_pp.hip; MI355ASR_PP=0 switches them off), then the round-2 loader-wave kernels on three bf16 terms.
 // (Rounds 1-2 also had per-wave-DMA ring kernels and a double-buffered out_glu: slower than both, deleted in round 4.)
-static bool env_on(const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; }
+static bool env_on(const char* name) { return mi355_env(name, 1) != 0; }
 int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
   static const bool ring = env_on("MI355ASR_FF1QKV_RING");
   const int tiles = (a.M + 15) / 16;
@@ -1172,11 +1173,11 @@ int launch_out_glu(const OutGluArgs& a, hipStream_t s) {
 // split-bf16 ring-DMA kernel for the subsampling Dense; ws = pack_split32 fragments padded to 1792 per step
 int launch_head_ld(const GemmArgs& a, const float* slabs, int groups, hipStream_t s) {
   // MI355ASR_HEAD_RING=0: the fp32-MFMA gemm_rows_kernel<HEAD>
-  static const bool on = [] { const char* v = getenv("MI355ASR_HEAD_RING"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_HEAD_RING", 1) != 0;
   if (!on || !slabs || groups < 1 || a.NT > KB * groups || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
 #ifdef MI355ASR_DIAG_KERNELS
-  static const bool nostore = [] { const char* v = getenv("MI355ASR_HEAD_NOSTORE"); return v && atoi(v) != 0; }();
+  static const bool nostore = mi355_env("MI355ASR_HEAD_NOSTORE", 0) != 0;
   if (nostore) {                            // timing only: what the logit stores cost
     GemmArgs t = a;
     t.y = nullptr;

@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 #include "wstream.h"
 #include "split_f16.h"
@@ -1074,20 +1075,20 @@ __global__ __launch_bounds__(LD_THREADS) void pp_sublinear_kernel(StreamGemmArgs
 // little: ceil(T / 64) chunks of 64 frames per utterance (T = 250: 2.4 % idle rows; T = 100 would idle 22 %)
 bool pp_dw_fold_ok(int T, int ksz) {
   // MI355ASR_PP_DW=0: depthwise conv as its own launch (dwconv_tile_kernel)
-  static const bool on = [] { const char* v = getenv("MI355ASR_PP_DW"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_PP_DW", 1) != 0;
   return on && pp_enabled() && ksz == DW_K && T >= 64 && 64 * ((T + 63) / 64) * 10 <= 11 * T;
 }
 bool pp_enabled();
 static bool pp_dw_fold(const TailFf2Args& a) { return a.dw_u && a.dw_wd && a.dw_T > 0 && a.M % a.dw_T == 0; }
 bool pp_enabled() {
   // MI355ASR_PP=0: the round-2 chunk-wise ring kernels (fused.hip) instead of the pair-pipelined ones
-  static const bool on = [] { const char* v = getenv("MI355ASR_PP"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_PP", 1) != 0;
   return on;
 }
 int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, hipStream_t s) {
   // MI355ASR_PP_HEAD=0: the three-term head_ld_kernel (fused.hip)
-  static const bool on = [] { const char* v = getenv("MI355ASR_PP_HEAD"); return v ? atoi(v) != 0 : true; }();
-  static const bool ring_on = [] { const char* v = getenv("MI355ASR_HEAD_RING"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_PP_HEAD", 1) != 0;
+  static const bool ring_on = mi355_env("MI355ASR_HEAD_RING", 1) != 0;
   if (!on || !ring_on || !pp_enabled() || !pp || groups < 1 || a.n_valid > 144 * groups || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
@@ -1096,7 +1097,7 @@ int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, 
 }
 bool pp_sublinear_ok(const StreamGemmArgs& a, const float* pp) {
   // MI355ASR_PP_SUBLINEAR=0: the three-term sublinear_split_ld_kernel (fused.hip)
-  static const bool on = [] { const char* v = getenv("MI355ASR_PP_SUBLINEAR"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_PP_SUBLINEAR", 1) != 0;
   return on && pp_enabled() && pp && a.NT == KB && a.K % D == 0 && a.K >= D && a.M > 0 && (a.ldy & 3) == 0;
 }
 int launch_pp_sublinear(const StreamGemmArgs& a, const float* pp, float pp_sw, hipStream_t s) {
@@ -1107,7 +1108,7 @@ int launch_pp_sublinear(const StreamGemmArgs& a, const float* pp, float pp_sw, h
 }
 int launch_pp_out_glu(const OutGluArgs& a, hipStream_t s) {
   // MI355ASR_PP_OUTGLU=0: the three-term out_glu_ld_kernel (fused.hip)
-  static const bool on = [] { const char* v = getenv("MI355ASR_PP_OUTGLU"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_PP_OUTGLU", 1) != 0;
   if (!on || !pp_enabled() || !a.pp_slabs || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
@@ -1119,7 +1120,7 @@ int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s)
   const int tiles = (a.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
 #ifdef MI355ASR_DIAG_KERNELS
-  static const int dg = [] { const char* v = getenv("MI355ASR_PP_DIAG"); return v ? atoi(v) : 0; }();
+  static const int dg = (int)mi355_env("MI355ASR_PP_DIAG", 0);
   if (dg) {
     static bool warned = false;
     if (!warned) { fprintf(stderr, "MI355ASR_PP_DIAG=%d: timing-only kernel variant, results are WRONG\n", dg); warned = true; }
@@ -1156,8 +1157,8 @@ int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s) {
 // x2 and u are not written).  Needs the depthwise fold (a.dw_wd / dw_T / dw_pad set; a.dw_u is not read).
 bool pp_og_fold_ok(const TailFf2Args& a, const OutGluArgs& g) {
   // MI355ASR_PP_OGF=0: out-projection + GLU as its own launch (pp_out_glu_kernel)
-  static const bool on = [] { const char* v = getenv("MI355ASR_PP_OGF"); return v ? atoi(v) != 0 : true; }();
-  static const bool og_on = [] { const char* v = getenv("MI355ASR_PP_OUTGLU"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_PP_OGF", 1) != 0;
+  static const bool og_on = mi355_env("MI355ASR_PP_OUTGLU", 1) != 0;
   return on && og_on && pp_enabled() && a.pp_slabs && g.pp_slabs && g.ctx && g.x1 && a.dw_wd && a.dw_T > 0 && a.M > 0 && a.M % a.dw_T == 0 &&
          a.M == g.M && (a.dw_pad == 15 || a.dw_pad == 31) && pp_dw_fold_ok(a.dw_T, DW_K);
 }
@@ -1169,9 +1170,9 @@ int launch_pp_og_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, const OutGl
 }
 bool pp_head_fold_ok(int M, int n_valid, int groups) {
   // MI355ASR_PP_HEADF=0: the class head as its own launch (pp_head_kernel); the switches of that kernel apply here too
-  static const bool on = [] { const char* v = getenv("MI355ASR_PP_HEADF"); return v ? atoi(v) != 0 : true; }();
-  static const bool head_on = [] { const char* v = getenv("MI355ASR_PP_HEAD"); return v ? atoi(v) != 0 : true; }();
-  static const bool ring_on = [] { const char* v = getenv("MI355ASR_HEAD_RING"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_PP_HEADF", 1) != 0;
+  static const bool head_on = mi355_env("MI355ASR_PP_HEAD", 1) != 0;
+  static const bool ring_on = mi355_env("MI355ASR_HEAD_RING", 1) != 0;
   return on && head_on && ring_on && pp_enabled() && groups >= 1 && n_valid <= 144 * groups && M > 0;
 }
 int launch_pp_og_tail_ff2(const TailFf2Args& a, const OutGluArgs& g, hipStream_t s) {
@@ -1187,7 +1188,7 @@ int launch_pp_og_tail_ff2(const TailFf2Args& a, const OutGluArgs& g, hipStream_t
 }
 bool pp_pre_fold_ok() {
   // MI355ASR_PP_PRE=0: the subsampling Dense and the CTC decoder's projection as their own launches
-  static const bool on = [] { const char* v = getenv("MI355ASR_PP_PRE"); return v ? atoi(v) != 0 : true; }();
+  static const bool on = mi355_env("MI355ASR_PP_PRE", 1) != 0;
   return on && pp_enabled();
 }
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
@@ -1200,7 +1201,6 @@ int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
     return 0;
   }
   if (launch_ns1_ff1_qkv(b, s) == 0) return 0;           // round 6, small batches: one 16-token tile per workgroup (fused_ns.hip)
-  if (launch_ns_ff1_qkv(b, s) == 0) return 0;            // ... and the opt-in N-split kernel for whole 64-token workgroups (MI355ASR_NS=1)
   hipLaunchKernelGGL((pp_block_kernel<false, true>), dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, TailFf2Args{}, b, OutGluArgs{});
   return 0;
 }

@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 #include "wstream.h"
 
@@ -512,9 +513,9 @@ int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
   // workgroup pays a prologue -- first slabs, LayerNorm statistics -- worth several k-steps, and a second, half-empty
   // round costs as much as a full one); among equals the larger tile.  MI355ASR_RING_RT / _SLOTS / _CPW force one shape
   // (tests).
-  static const int force_rt = [] { const char* v = getenv("MI355ASR_RING_RT"); return v ? atoi(v) : 0; }();
-  static const int force_slots = [] { const char* v = getenv("MI355ASR_RING_SLOTS"); return v ? atoi(v) : 0; }();
-  static const int force_cpw = [] { const char* v = getenv("MI355ASR_RING_CPW"); return v ? atoi(v) : 0; }();
+  static const int force_rt = (int)mi355_env("MI355ASR_RING_RT", 0);
+  static const int force_slots = (int)mi355_env("MI355ASR_RING_SLOTS", 0);
+  static const int force_cpw = (int)mi355_env("MI355ASR_RING_CPW", 0);
   int best_rt = 1, best_cpw = 1;
   double best = 1e30;
   for (int rt = 2; rt >= 1; --rt) {

@@ -389,10 +389,7 @@ bool pp_dw_fold_ok(int T, int ksz);   // the tail kernels can take the depthwise
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
-// N-split versions (fused_ns.hip, round 6); -1: switched off (MI355ASR_NS=0), no plain-order fragments, or not this launch's shape
-bool ns_enabled();
-int launch_ns_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
-// ... one 16-token tile per workgroup, for small batches (up to MI355ASR_NS1_MAX_M rows): ff_module_1 + qkv; and what the folded tail
+// N-split kernels (fused_ns.hip, round 6): one 16-token tile per workgroup, for small batches (up to MI355ASR_NS1_MAX_M rows): ff_module_1 + qkv; and what the folded tail
 // launches do, as out-projection + GLU (writes g.x2, g.u) followed by depthwise conv + tail [+ next ff_module_1 + qkv when b is set]
 bool ns1_rows_ok(int M);
 bool ns1_block_ok(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g);      // launch_ns1_og_tail will take this block

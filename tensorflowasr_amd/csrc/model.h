@@ -17,6 +17,7 @@
 #include "../../include/mi355asr.h"
 #include "beam.h"
 #include "launch.h"
+#include "env.h"
 
 namespace mi355 {
 

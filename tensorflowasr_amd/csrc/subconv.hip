@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "env.h"
 #include "launch.h"
 #include "wstream.h"
 
@@ -1025,7 +1026,7 @@ static int launch_split_d(int d, const dim3& g144, const SubConvArgs& a, PatchGe
   note_scheme(SCHEME_BF16X3);
   if constexpr (DIAG == 0) {
     // conv1 on the matrix pipe (see C1M): dmodel 144, two-term weights, a mel scale (static or run-time), patch rows of <= 96 bins
-    static const bool c1m_env = [] { const char* v = getenv("MI355ASR_SUBCONV_C1M"); return v ? atoi(v) != 0 : true; }();
+    static const bool c1m_env = mi355_env("MI355ASR_SUBCONV_C1M", 1) != 0;
     const bool c1m = c1m_env && a.w2h && (d == 144 || d == 256) && a.c1_wscale > 0.f && (a.c1_mscale > 0.f || a.h_melmax) && 4 * a.F2 + 4 <= C1_ROWB / 2 &&
                      (size_t)(2 * rows + C1_ZERO_ROWS) * C1_ROWB <= sizeof(float) * MELP;
     if (c1m) {
@@ -1093,7 +1094,7 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
   // x 260 positions, of whose 2 x 64 x 2 workgroups every second one holds four positions -- do NOT gain: 384 workgroups of 128
   // positions take 159 us where the 256 took 134; a workgroup's time is its 41 steps, not its row tiles.)  Two-term kernels
   // only.  MI355ASR_SUBCONV_RT=1 / 2 forces one.
-  static const int rt_env = [] { const char* v = getenv("MI355ASR_SUBCONV_RT"); return v ? atoi(v) : 0; }();
+  static const int rt_env = (int)mi355_env("MI355ASR_SUBCONV_RT", 0);
   const long wg1 = (long)((PU + SPOSG / 2 - 1) / (SPOSG / 2)) * a.B * (d == 144 ? 1 : d / 128);
   const int rtn = (a.w2h && (rt_env == 1 || (rt_env == 0 && wg1 <= 256))) ? 1 : SRT;
   const int posg = SCW * 16 * rtn;
@@ -1104,8 +1105,7 @@ int launch_subconv_split(int d, const SubConvArgs& a, hipStream_t s) {
 #ifdef MI355ASR_DIAG_KERNELS
   // timing-only variants (wrong results), compiled in with -DMI355ASR_DIAG_KERNELS: see the DIAG comment above
   static const int diag = [] {
-    const char* v = getenv("MI355ASR_SUBCONV_DIAG");
-    const int d = v ? atoi(v) : 0;
+    const int d = (int)mi355_env("MI355ASR_SUBCONV_DIAG", 0);
     if (d) fprintf(stderr, "libmi355asr: MI355ASR_SUBCONV_DIAG=%d -- timing experiment, the subsampling output is WRONG\n", d);
     return d;
   }();

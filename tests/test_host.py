@@ -1013,7 +1013,6 @@ SWITCHES = {
     "MI355ASR_PP_OGF": "0: out-projection + GLU as its own launch | test_block_as_two_launches_equals_the_three_launch_path_bit_for_bit",
     "MI355ASR_CHAIN256": "0: bf16 mode, dmodel 256: one launch per dense layer instead of chain256_bf16_kernel | test_bf16_chain256_against_layer_at_a_time",
     "MI355ASR_ATTN64_SPLIT": "0: head size 64: the fp32-MFMA attention kernels instead of the two-term attention_split64_kernel | test_head_size_64_two_term_attention_against_the_fp32_mfma_kernels",
-    "MI355ASR_NS": "1: dmodel 144: ff_module_1 + qkv on the N-split kernel of fused_ns.hip (hidden dimension split over four waves, weights straight from L2 into registers) instead of the pair-pipelined one; off by default: slower, profiles/r06_ns_experiments.md | test_n_split_ff1_qkv_kernel_against_the_pair_pipelined_one_and_the_oracle",
     "MI355ASR_ATTN_LONG": "0: more than 256 keys on the fp32-MFMA attention kernels instead of attention_split_long_kernel (key blocks with an online softmax on the two-term pipe) | test_long_utterances_attention_in_key_blocks_against_the_fp32_kernels_and_the_oracle",
     "MI355ASR_NS1_MAX_M": "n: dmodel 144: blocks of up to n rows (default 4096; 0: never) on the one-tile-per-workgroup kernels of fused_ns.hip (small batches: eight waves share a 16-token tile) instead of the pair-pipelined ones | test_small_batches_one_tile_per_workgroup_against_the_pair_pipelined_kernels_and_the_oracle",
     "MI355ASR_NS1_ATTN": "0: the attention of a small-batch block (one-tile-per-workgroup kernels) as its own launch instead of inside the out-projection launch | test_small_batches_one_tile_per_workgroup_against_the_pair_pipelined_kernels_and_the_oracle",
@@ -1048,7 +1047,7 @@ def test_environment_switches_are_the_documented_ones():
     found = set()
     for f in os.listdir(csrc):
         if f.endswith((".hip", ".h", ".inc")):
-            found |= set(re.findall(r'(?:getenv|env_on)\("(MI355ASR_[A-Z0-9_]+)"', open(os.path.join(csrc, f)).read()))
+            found |= set(re.findall(r'(?:getenv|env_on|mi355_env)\("(MI355ASR_[A-Z0-9_]+)"', open(os.path.join(csrc, f)).read()))
     assert found == set(SWITCHES), (sorted(found - set(SWITCHES)), sorted(set(SWITCHES) - found))
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     missing = [k for k in SWITCHES if k not in design]
