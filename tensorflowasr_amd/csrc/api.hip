@@ -466,7 +466,7 @@ void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(
   const size_t o_pp = ab.put(pp);
   ab.head_pairs.push_back({p16_off, o_st, groups, o_pp, sw, ab.put(plain)});
 }
-int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s) {
+int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s, float* split_scratch) {
   // a launch of the ring kernel costs as much for 250 rows as for 16 000: from 2048 rows on
   if (m->cfg.gemm_dtype != 0 || m->head_of.empty()) return -1;
   const auto it = m->head_of.find(hd.wp);
@@ -474,6 +474,9 @@ int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s) {
   // round 6, small batches: one 16-token tile per workgroup, the column tiles split over its waves (fused_ns.hip)
   if (launch_ns1_head(hd, it->second.ns, it->second.pp_sw, it->second.groups, s) == 0) return 0;
   if (hd.M < 2048) return -1;
+  // few rows and many classes (the Translator's 144 -> 9160 over ~6 000 rows is 93 row workgroups): the column groups split over
+  // several workgroups per row tile, the per-range arg-max pairs combined by a second small launch (split_scratch: 16 M words)
+  if (split_scratch && launch_pp_head_split(hd, it->second.pp, it->second.pp_sw, it->second.groups, pp_head_ranges(hd.M, it->second.groups), split_scratch, s) == 0) return 0;
   if (launch_pp_head(hd, it->second.pp, it->second.pp_sw, it->second.groups, s) == 0) return 0;
   return launch_head_ld(hd, it->second.slabs, it->second.groups, s);
 }
@@ -932,7 +935,10 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     { PROF(MI355ASR_K_CONV_TAIL); LAUNCH_TRY(launch_gemm16(m, E16_RES, false, p2, w.pw2_wp, s), "pw_conv_2"); }
     return ffn(1, sc.xb, out ? out : sc.xa, w.ln_g, w.ln_b);
   }
-  if (d == 144 && fused_env && !cross) {
+  // round 6: the Translator's RBlock takes the fused kernels too -- its query projection (of LayerNorm(x1 + PE)) rides in the
+  // ff_module_1 launch of the pair-pipelined kernel, keys / values come from the encoder output through their own projection
+  const bool fused_cross = cross && ff1_qkv_pp_selected(w.ff1_slabs != nullptr, w.pp_ff1 != nullptr) && !bo.pre_pp && !skip_ff1 && !next;
+  if (d == 144 && fused_env && (!cross || fused_cross)) {
     // token-local runs of layers in one launch each (fused.hip); attention and the depthwise conv mix tokens
     const float qscale = 1.0f / std::sqrt((float)hs);
     // round 5: q / k / v of a block travel head-major ([B, H, T, 36] planes) whenever their producer is a pair-pipelined kernel and
@@ -950,7 +956,7 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     };
     auto qkv_head_major = [&](const BlockDev& bw) {
       static const bool on = mi355_env("MI355ASR_QKV_HEAD_MAJOR", 1) != 0;
-      return on && ff1_qkv_pp_selected(bw.ff1_slabs != nullptr, bw.pp_ff1 != nullptr) && attention_takes_head_major(hs, attn_args(bw, true));
+      return on && !cross && ff1_qkv_pp_selected(bw.ff1_slabs != nullptr, bw.pp_ff1 != nullptr) && attention_takes_head_major(hs, attn_args(bw, true));
     };
     auto ff1_args = [&](const BlockDev& bw, const float* x0, float* x1) {
       Ff1QkvArgs k1{};
@@ -966,9 +972,19 @@ int run_block(const mi355asr_model* m, const BlockDev& w, const BlockOpts& bo, S
     if (!skip_ff1) {
       Ff1QkvArgs k1 = ff1_args(w, sc.xa, sc.xb);
       if (bo.pre_pp) { k1.pre_x = bo.pre_x; k1.pre_pp = bo.pre_pp; k1.pre_sw = bo.pre_sw; k1.pre_chunks = bo.pre_chunks; }
+      if (cross) { k1.xq_pe = cross->pe; k1.xq_U = T; }
       PROF(MI355ASR_K_FF1_QKV); LAUNCH_TRY(launch_ff1_qkv(k1, s), "ff_module_1 + qkv");
     }
-    const AttnArgs at = attn_args(w, qkv_head_major(w));
+    AttnArgs at = attn_args(w, qkv_head_major(w));
+    if (cross) {
+      // [k | v] = enc [Wk | Wv]  [B * T_enc, 2 d]; q sits at columns 0..143 of the [M, 3 d] rows the ff_module_1 launch wrote
+      GemmArgs kv{};
+      kv.x = cross->enc; kv.y = cross->kv; kv.wp = w.xkv_wp; kv.bias = w.qkv_b;   // qkv_b: 3d zeros (no bias)
+      kv.M = B * cross->T_enc; kv.NT = 2 * d / 16; kv.ldy = 2 * d; kv.n_valid = 2 * d; kv.eps = kLnEps;
+      { PROF(MI355ASR_K_QKV); LAUNCH_TRY(launch_gemm_rows(d, EPI_BIAS, false, kv, s), "cross-attention key/value projection"); }
+      at.q = sc.qkv; at.ldq = 3 * d; at.k = cross->kv; at.v = cross->kv + d; at.ldk = 2 * d; at.Tk = cross->T_enc; at.head_major = 0;
+      at.h2_sq = 0.f; at.h2_sk = 0.f; at.h2_sv = 0.f;          // no operand bounds for the encoder's rows: three exact terms
+    }
     OutGluArgs k2{};
     k2.ctx = sc.ctx; k2.x1 = sc.xb; k2.x2 = sc.xa; k2.u = sc.u;
     k2.out_wp = w.out_wp; k2.out_b = w.out_b; k2.cv_ln_g = w.cv_ln_g; k2.cv_ln_b = w.cv_ln_b;

@@ -9,7 +9,7 @@ namespace {
 constexpr int kMaxTokens = 2048;   // rows of the positional-encoding table
 
 struct TransPlan {
-  size_t xa, xb, qkv, ctx, u, dw, kv, amax, h4, total;
+  size_t xa, xb, qkv, ctx, u, dw, kv, amax, h4, hsplit, total;
 };
 TransPlan make_trans_plan(const mi355asr_model* m, int B, int U, int T) {
   const size_t d = m->cfg.dmodel, M = (size_t)B * U;
@@ -19,6 +19,7 @@ TransPlan make_trans_plan(const mi355asr_model* m, int B, int U, int T) {
   p.xa = take(M * d); p.xb = take(M * d); p.qkv = take(M * 3 * d); p.ctx = take(M * d);
   p.u = take(M * d); p.dw = take(M * d); p.kv = take((size_t)B * T * 2 * d); p.amax = take(M);
   p.h4 = gemm16_for(m, M) ? take(M * 4 * d) : 0;
+  p.hsplit = take(16 * M);          // per-range (maximum, class) pairs of the class head split over column ranges (up to 8)
   p.total = o;
   return p;
 }
@@ -154,7 +155,7 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids, const flo
   // and the ChunkConformer's heads do (try_head_ld: 144 -> 9160 over 5952 rows 0.44 ms on the fp32 MFMA kernel)
   {
     PROF(MI355ASR_K_CTC_HEAD);
-    if (try_head_ld(m, hd, s) == 0) {
+    if (try_head_ld(m, hd, s, (float*)(ws + p.hsplit)) == 0) {
       if (hipGetLastError() != hipSuccess) return fail(MI355ASR_EHIP, "translator head launch failed");
       return 0;
     }

@@ -1147,12 +1147,12 @@ int launch_ff1_qkv(const Ff1QkvArgs& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
   if (ring && a.slabs) {
     if (launch_pp_ff1_qkv(a, s) == 0) return 0;
-    if (a.pre_pp || a.qkv_T > 0) return -1;   // only the pair-pipelined kernel computes x0 itself (callers ask ff1_pre_selected first) / stores q, k, v head-major
+    if (a.pre_pp || a.qkv_T > 0 || a.xq_pe) return -1;   // only the pair-pipelined kernel computes x0 itself (callers ask ff1_pre_selected first) / stores q, k, v head-major / projects an RBlock's query
     note_scheme(SCHEME_BF16X3);
     hipLaunchKernelGGL(ff1_qkv_ld_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a);
     return 0;
   }
-  if (a.pre_pp || a.qkv_T > 0) return -1;
+  if (a.pre_pp || a.qkv_T > 0 || a.xq_pe) return -1;
   note_scheme(SCHEME_F32);
   hipLaunchKernelGGL(ff1_qkv_kernel, dim3((tiles + 3) / 4), dim3(BLOCK_THREADS), 0, s, a);
   return 0;

@@ -769,7 +769,7 @@ int ns1_max_rows() {
 }  // namespace
 bool ns1_rows_ok(int M) { return M > 0 && M <= ns1_max_rows(); }
 int launch_ns1_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
-  if (!ns1_rows_ok(b.M) || !b.ns_w1 || !b.ns_w2 || !b.ns_qkv || b.pre_pp) return -1;
+  if (!ns1_rows_ok(b.M) || !b.ns_w1 || !b.ns_w2 || !b.ns_qkv || b.pre_pp || b.xq_pe) return -1;
   note_scheme(SCHEME_F16X2);
   hipLaunchKernelGGL((ns1_ff1_qkv_kernel<NS1_W>), dim3((b.M + 15) / 16), dim3(NS1_W * 64), 0, s, b);
   return 0;
@@ -780,7 +780,7 @@ bool ns1_block_ok(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g
   if (!ns1_rows_ok(a.M) || a.M != g.M || !g.ns_out || !g.ns_pw1 || !a.ns_cv_w1 || !a.ns_cv_w2 || !a.ns_ff_w1 || !a.ns_ff_w2 || a.head_pp ||
       !g.x2 || !g.u || !g.x1 || !a.dw_wd || a.dw_T <= 0 || a.M % a.dw_T != 0 || (a.dw_pad != 15 && a.dw_pad != 31))
     return false;
-  if (b && (!b->ns_w1 || !b->ns_w2 || !b->ns_qkv || b->pre_pp || b->M != a.M)) return false;
+  if (b && (!b->ns_w1 || !b->ns_w2 || !b->ns_qkv || b->pre_pp || b->xq_pe || b->M != a.M)) return false;
   return true;
 }
 bool ns1_attn_ok(int hs, const AttnArgs& at) {

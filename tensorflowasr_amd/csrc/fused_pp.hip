@@ -452,12 +452,19 @@ DEV void pp_ff1_consume(const Ff1QkvArgs& a, const PpFf1Lds& p, int g4, ST& st, 
       for (int i = 0; i < KB; ++i) stg4(a.x1 + e.row + 16 * i + e.g4, y[i]);
     }
   }
+  if (a.xq_pe) {                                                                     // RBlock: the query is projected from x1 + PE
+    const WaveCtx e = wave_ctx_fresh(a.M, T);
+    const float* __restrict__ pe = a.xq_pe + (size_t)(e.tok % a.xq_U) * D + e.g4;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) xs[i] += ldg4(pe + 16 * i);
+  }
   ln_lds(xs, p.ln2g, p.ln2b, g4, a.eps);
   const float sx = pp_pow2_scale(pp_row_max(xs));
   split_operand(xf, xs, g4, sx);                                                     // the q / k / v bias rides in row 144 too
   const float invq = pp_recip_pow2(a.pp_sw_qkv * sx);
+  const int nproj = a.xq_pe ? 1 : 3;                                                 // (the loaders stop behind the q group as well)
 #pragma unroll 1
-  for (int q = 0; q < 3; ++q) {
+  for (int q = 0; q < nproj; ++q) {
     f32x4 acc[KB];
 #pragma unroll
     for (int i = 0; i < KB; ++i) acc[i] = splat4(0.f);
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(LD_THREADS) void pp_block_kernel(TailFf2Args a, Ff1
   const u32x4_t* s0 = reinterpret_cast<const u32x4_t*>(PRE ? b.pre_pp : g.pp_slabs);
   const u32x4_t* s1 = reinterpret_cast<const u32x4_t*>(TAIL ? a.pp_slabs : b.pp_slabs);
   const u32x4_t* s2 = reinterpret_cast<const u32x4_t*>(HEAD ? a.head_pp : b.pp_slabs);
-  const int total_rt = TOTAL + (HEAD ? KS32X * a.head_groups : 0);
+  const int total_rt = TOTAL + (HEAD ? KS32X * a.head_groups : 0) - ((FF1 && b.xq_pe) ? 2 * KS32X : 0);      // RBlock: no k / v groups
   if (wv >= WAVES_PER_BLOCK + (OGF ? 2 : 0)) {
     if constexpr (PRE) {
       const int n0 = KS32X * b.pre_chunks;
@@ -940,9 +947,15 @@ __global__ __launch_bounds__(LD_THREADS) void pp_out_glu_kernel(OutGluArgs a) {
 // CTC class head of dmodel 144: logits = x W + b over `groups` column groups of nine tiles (five plain ring slots each, the
 // bias in row 144), per-frame arg-max (first maximum wins) and / or the logits themselves -- head_ld_kernel's contract
 // (fused.hip) on the two-term stream: 135 MFMAs per group and wave instead of 270, nothing to fetch for the bias
-__global__ __launch_bounds__(LD_THREADS) void pp_head_kernel(GemmArgs a, const u32x4_t* __restrict__ pp, float pp_sw, int groups) {
+// Round 6: blockIdx.y splits the column groups (gper per workgroup) when the rows alone leave most of the chip idle -- the Translator's
+// 144 -> 9160 head over 5 952 rows is 93 row workgroups; the per-range (maximum, class) pairs then go to part_v / part_i [ranges][M]
+// and head_combine_kernel picks the winner (lowest class among equal maxima, as within a range).
+__global__ __launch_bounds__(LD_THREADS) void pp_head_kernel(GemmArgs a, const u32x4_t* __restrict__ pp_all, float pp_sw, int groups_all, int gper,
+                                                               float* part_v, int32_t* part_i) {
   __shared__ __attribute__((aligned(16))) u32x4_t ring[PP_RING * PP_SLB];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g_first = blockIdx.y * gper, groups = min(groups_all, g_first + gper) - g_first;
+  const u32x4_t* __restrict__ pp = pp_all + (size_t)g_first * KS32X * PP_SLB;
   if (wv >= WAVES_PER_BLOCK) {
     PpLoader<PP_RING, 0>{ring, pp, pp, KS32X * groups, KS32X * groups, wv - WAVES_PER_BLOCK, (int)(threadIdx.x & 63)}.run();
     return;
@@ -981,7 +994,7 @@ __global__ __launch_bounds__(LD_THREADS) void pp_head_kernel(GemmArgs a, const u
     float* yrow = a.y ? a.y + (size_t)e.tok * a.ldy : nullptr;
 #pragma unroll
     for (int i = 0; i < KB; ++i) {
-      const int tile = KB * g + i, f0 = 16 * tile + e.g4;
+      const int tile = KB * (g_first + g) + i, f0 = 16 * tile + e.g4;
       if (16 * tile < a.n_valid) {               // wave-uniform: the last group is padded with zero columns
         const f32x4 v = acc[i] * splat4(inv);
         const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -1009,8 +1022,26 @@ __global__ __launch_bounds__(LD_THREADS) void pp_head_kernel(GemmArgs a, const u
     if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
   }
   const WaveCtx e = wave_ctx_fresh(a.M);
+  if (part_v) {                                  // one of several class ranges: the pair goes to the combine kernel
+    if (e.live && c.lane < 16) { part_v[(size_t)blockIdx.y * a.M + e.tok] = best_v; part_i[(size_t)blockIdx.y * a.M + e.tok] = best_i; }
+    return;
+  }
   if (a.argmax_out && e.live && c.lane < 16) a.argmax_out[e.tok] = best_i;
   if (a.maxval_out && e.live && c.lane < 16) a.maxval_out[e.tok] = best_v;
+}
+__global__ __launch_bounds__(256) void head_combine_kernel(const float* __restrict__ part_v, const int32_t* __restrict__ part_i, int ranges, int M,
+                                                            int32_t* __restrict__ argmax_out, float* __restrict__ maxval_out) {
+  const int tok = blockIdx.x * 256 + threadIdx.x;
+  if (tok >= M) return;
+  float bv = part_v[tok];
+  int bi = part_i[tok];
+  for (int r = 1; r < ranges; ++r) {
+    const float v = part_v[(size_t)r * M + tok];
+    const int i = part_i[(size_t)r * M + tok];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+  if (argmax_out) argmax_out[tok] = bi;
+  if (maxval_out) maxval_out[tok] = bv;
 }
 
 
@@ -1092,7 +1123,29 @@ int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, 
   if (!on || !ring_on || !pp_enabled() || !pp || groups < 1 || a.n_valid > 144 * groups || a.M <= 0) return -1;
   const int tiles = (a.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
-  hipLaunchKernelGGL(pp_head_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, groups);
+  hipLaunchKernelGGL(pp_head_kernel, dim3((tiles + 3) / 4), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, groups, groups,
+                     (float*)nullptr, (int32_t*)nullptr);
+  return 0;
+}
+// the same head with the column groups split over `ranges` workgroups per row tile; scratch = 2 * ranges * M words (maxima, then classes)
+int pp_head_ranges(int M, int groups) {
+  static const int ncu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+  const int wgs = (M + 63) / 64;
+  return wgs < 1 ? 1 : max(1, min(min(ncu / wgs, groups / 4), 8));          // at least four groups per range
+}
+int launch_pp_head_split(const GemmArgs& a, const float* pp, float pp_sw, int groups, int ranges, float* scratch, hipStream_t s) {
+  if (ranges <= 1 || !scratch) return launch_pp_head(a, pp, pp_sw, groups, s);
+  static const bool on = mi355_env("MI355ASR_PP_HEAD", 1) != 0;
+  static const bool ring_on = mi355_env("MI355ASR_HEAD_RING", 1) != 0;
+  if (!on || !ring_on || !pp_enabled() || !pp || groups < 1 || a.n_valid > 144 * groups || a.M <= 0) return -1;
+  const int gper = (groups + ranges - 1) / ranges, nr = (groups + gper - 1) / gper;
+  const int tiles = (a.M + 15) / 16;
+  note_scheme(SCHEME_F16X2);
+  const bool want_max = a.argmax_out != nullptr || a.maxval_out != nullptr;
+  float* pv = want_max ? scratch : nullptr;
+  int32_t* pi = want_max ? reinterpret_cast<int32_t*>(scratch + (size_t)nr * a.M) : nullptr;
+  hipLaunchKernelGGL(pp_head_kernel, dim3((tiles + 3) / 4, nr), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, groups, gper, pv, pi);
+  if (want_max) hipLaunchKernelGGL(head_combine_kernel, dim3((a.M + 255) / 256), dim3(256), 0, s, pv, pi, nr, a.M, a.argmax_out, a.maxval_out);
   return 0;
 }
 bool pp_sublinear_ok(const StreamGemmArgs& a, const float* pp) {
@@ -1193,6 +1246,7 @@ bool pp_pre_fold_ok() {
 }
 int launch_pp_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s) {
   if (!pp_enabled() || !b.pp_slabs || b.M <= 0) return -1;
+  if (b.xq_pe && (b.pre_pp || b.qkv_T > 0 || b.xq_U < 1)) return -1;
   const int tiles = (b.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
   if (b.pre_pp) {

@@ -326,6 +326,12 @@ struct Ff1QkvArgs {
   // round 6 (fused_ns.hip): the same two-term fragments in plain order for the N-split kernels -- ff_module_1's W1aug [5][36][2][64]
   // and W2 [18][9][2][64], q / k / v [5][27][2][64] (u32x4 per lane; api.hip: pack_half32); packed with pp_sc / pp_sw_qkv
   const float *ns_w1 = nullptr, *ns_w2 = nullptr, *ns_qkv = nullptr;
+  // round 6: the Translator's RBlock (conformer_blocks.py:447-503): only the QUERY is projected from this stream -- of LayerNorm(x1 +
+  // positional encoding) -- keys and values come from the encoder output through their own projection.  xq_pe = the encoding table
+  // [>= xq_U, 144], row = the token's position in its sequence of xq_U tokens; q is stored token-major at columns 0..143 of the
+  // [M, 432] qkv rows.  Pair-pipelined kernel only (the stream's q group is read, its k / v groups are not).
+  const float* xq_pe = nullptr;
+  int xq_U = 0;
 };
 struct OutGluArgs {
   const float* ctx; const float* x1; float* x2; float* u;
@@ -385,6 +391,9 @@ bool pp_enabled();
 int launch_pp_out_glu(const OutGluArgs& a, hipStream_t s);
 // class head of dmodel 144 on the two-term fp16 stream (pp: append_pp_plain of [W ; b] over `groups` column groups, packed with pp_sw)
 int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, hipStream_t s);
+// ... with the column groups split over `ranges` workgroups per row tile (round 6: few rows, many classes); scratch: 2 * ranges * M words
+int pp_head_ranges(int M, int groups);
+int launch_pp_head_split(const GemmArgs& a, const float* pp, float pp_sw, int groups, int ranges, float* scratch, hipStream_t s);
 bool pp_dw_fold_ok(int T, int ksz);   // the tail kernels can take the depthwise conv (kernel size ksz, T frames per utterance) in their prologue
 int launch_pp_tail_ff1(const TailFf2Args& a, const Ff1QkvArgs& b, hipStream_t s);
 int launch_pp_tail_ff2(const TailFf2Args& a, hipStream_t s);

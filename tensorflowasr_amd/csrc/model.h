@@ -318,7 +318,7 @@ void register_rings(mi355asr_model* m, const ArenaBuilder& ab, const float* base
 // W[144, V] of a class head as the slab stream of head_ld_kernel (fused.hip), registered against its P16 pack
 void put_head_slabs(ArenaBuilder& ab, size_t p16_off, const std::function<float(int, int)>& f, int d, int V, const float* bias);
 // the head on the slab ring when the handle has a stream for hd.wp (fp32 mode, dmodel 144); -1: not taken
-int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s);
+int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s, float* split_scratch = nullptr);
 FftOff pack_fft(ArenaBuilder& ab, const std::vector<float>& re, const std::vector<float>& im, int n_dft, int nb);
 BlockOff pack_block(mi355asr_model* m, ArenaBuilder& ab, const std::string& p, int d, int H, int hs, int k, bool keras_mha = false);
 BlockDev resolve(const BlockOff& o, const float* base);

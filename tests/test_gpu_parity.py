@@ -1194,6 +1194,32 @@ def test_translator_head_on_the_two_term_stream_from_2048_rows(torch_cuda):
     assert none is None and np.array_equal(only.cpu().numpy(), halves[:16].argmax(-1))
 
 
+def test_translator_head_split_over_class_ranges(torch_cuda):
+    """Round 6: few rows and many classes -- 64 x 80 = 5 120 rows (80 row workgroups) and 2 500 classes (18 column groups) -- leave
+    most of the chip idle, so the column groups of pp_head_kernel are split over several workgroups per row tile (here three
+    ranges) and head_combine_kernel picks each row's winner from the per-range (maximum, class) pairs: the ids must equal the
+    arg-max of the logits the same kernel writes (lowest class among equal maxima), with and without the logits, and the logits
+    must sit at the usual distance from the oracle."""
+    from tensorflowasr_amd.models import Translator
+    cfg = dict(co.CONFORMER_S, translator_num_blocks=1, translator_kernel_size=32, translator_fc_factor=0.5)
+    inp, tar, B, U, T = 300, 2500, 64, 80, 60
+    w = co.translator_weights(cfg, inp, tar, seed=33)
+    w["fully_connected/kernel"][:, 1700] = w["fully_connected/kernel"][:, 40]          # two classes in different ranges tie on every row
+    w["fully_connected/bias"][1700] = w["fully_connected/bias"][40]
+    tr = Translator(inp_classes=inp, tar_classes=tar, dmodel=144, num_blocks=1, head_size=36, num_heads=4, kernel_size=32, fc_factor=0.5)
+    tr.load_weights(w, by_name=False)
+    rng = np.random.default_rng(78)
+    ids = rng.integers(0, inp, (B, U)).astype(np.int32)
+    enc = rng.standard_normal((B, T, 144)).astype(np.float32)
+    got, amax = tr([ids, enc], return_argmax=True)
+    got, amax = got.cpu().numpy(), amax.cpu().numpy()
+    assert np.array_equal(amax, got.argmax(-1)) and not (amax == 1700).any()
+    none, only = tr([ids, enc], return_argmax=True, return_logits=False)
+    assert none is None and np.array_equal(only.cpu().numpy(), amax)
+    ref = co.translator(ids[:2], enc[:2].astype(np.float64), w, cfg)
+    assert maxdiff(got[:2], ref) < TOL
+
+
 def test_translator_rejects_bad_shapes_and_clamps_ids(torch_cuda):
     from tensorflowasr_amd.models import Translator
     cfg = dict(co.CONFORMER_S, translator_num_blocks=1, translator_kernel_size=32, translator_fc_factor=0.5)
