@@ -1537,12 +1537,14 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
     return fail(MI355ASR_EINVAL, "dmodel=%d: supported are 144 (ConformerS), 256 (ConformerM / StreamingS) and other multiples of 128 up to 1024 (512 = ConformerL)", c.dmodel);
   if (c.num_heads * c.head_size != c.dmodel)
     return fail(MI355ASR_EINVAL, "num_heads*head_size (%d*%d) must equal dmodel (%d)", c.num_heads, c.head_size, c.dmodel);
-  if (c.head_size != 36 && c.head_size != 64)
-    return fail(MI355ASR_EINVAL, "head_size=%d: attention kernel instantiated for 36 and 64", c.head_size);
-  if (c.kernel_size != 32 && c.kernel_size != 5)
-    return fail(MI355ASR_EINVAL, "kernel_size=%d: depthwise kernel instantiated for 32 and 5", c.kernel_size);
-  if (c.num_classes > 0 && c.ctc_kernel_size != 32 && c.ctc_kernel_size != 5)
-    return fail(MI355ASR_EINVAL, "ctc_kernel_size=%d unsupported", c.ctc_kernel_size);
+  // round 6: the reference's constructors take any head size / kernel size (conformer_blocks.py:278-294); outside the shipped YAMLs'
+  // values (36 / 64, 32 / 5) the block runs on slower general kernels instead of failing (attention_kernel<HS, ...>, dwconv_any_kernel)
+  if (!attention_head_size_ok(c.head_size))
+    return fail(MI355ASR_EINVAL, "head_size=%d: attention kernels are instantiated for 12, 16, 24, 32, 36, 48, 64, 72 and 128", c.head_size);
+  if (c.kernel_size < 1 || c.kernel_size > 1024)
+    return fail(MI355ASR_EINVAL, "kernel_size=%d: must be in 1 .. 1024", c.kernel_size);
+  if (c.num_classes > 0 && (c.ctc_kernel_size < 1 || c.ctc_kernel_size > 1024))
+    return fail(MI355ASR_EINVAL, "ctc_kernel_size=%d: must be in 1 .. 1024", c.ctc_kernel_size);
   if (c.reduction_factor != 4) return fail(MI355ASR_EINVAL, "reduction_factor=%d: only 4 is supported", c.reduction_factor);
   if (c.mel_layer_type < 0 || c.mel_layer_type > 2)
     return fail(MI355ASR_EINVAL, "mel_layer_type=%d: 0 (Melspectrogram), 1 (leaf) or 2 (Spectrogram)", c.mel_layer_type);

@@ -95,9 +95,9 @@ int mi355asr_translator_create(const mi355asr_translator_config* cfg, mi355asr_m
   const auto& c = *cfg;
   if (c.dmodel != 144 && (c.dmodel % 128 != 0 || c.dmodel < 128 || c.dmodel > 1024))
     return fail(MI355ASR_EINVAL, "Translator: dmodel=%d, supported are 144 and multiples of 128 up to 1024", c.dmodel);
-  if (c.num_heads * c.head_size != c.dmodel || (c.head_size != 36 && c.head_size != 64))
-    return fail(MI355ASR_EINVAL, "Translator: need num_heads*head_size == dmodel and head_size 36 or 64");
-  if (c.kernel_size != 32 && c.kernel_size != 5) return fail(MI355ASR_EINVAL, "kernel_size=%d unsupported", c.kernel_size);
+  if (c.num_heads * c.head_size != c.dmodel || !attention_head_size_ok(c.head_size))
+    return fail(MI355ASR_EINVAL, "Translator: need num_heads*head_size == dmodel and a head size of 12, 16, 24, 32, 36, 48, 64, 72 or 128");
+  if (c.kernel_size < 1 || c.kernel_size > 1024) return fail(MI355ASR_EINVAL, "kernel_size=%d: must be in 1 .. 1024", c.kernel_size);
   if (c.num_blocks < 1 || c.inp_classes < 1 || c.tar_classes < 2) return fail(MI355ASR_EINVAL, "Translator: bad block / class counts");
   auto* m = new mi355asr_model();
   m->is_translator = true;

@@ -659,9 +659,25 @@ int launch_attention(int HS, const AttnArgs& a, hipStream_t s) {
   if (lds_env && attention_lds_applicable(HS, a)) return launch_attention_lds(HS, a, s);
   if (HS == 36) launch_attention_t<36>(a, s);
   else if (HS == 64) launch_attention_t<64>(a, s);
-  else return -1;
+  else {
+    // round 6: the other head sizes a dmodel of 144 / 256 / 512 factors into (multiples of four up to 128): the online-softmax kernel
+    // with one key-block size each (slow path: a configuration outside the shipped YAMLs must run, not fail)
+    const int qtiles = (a.Tq + 15) / 16;
+    const dim3 grid((qtiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.H, a.B), blk(BLOCK_THREADS);
+    switch (HS) {
+      case 12: hipLaunchKernelGGL((attention_kernel<12, 4>), grid, blk, 0, s, a); break;
+      case 16: hipLaunchKernelGGL((attention_kernel<16, 4>), grid, blk, 0, s, a); break;
+      case 24: hipLaunchKernelGGL((attention_kernel<24, 4>), grid, blk, 0, s, a); break;
+      case 32: hipLaunchKernelGGL((attention_kernel<32, 4>), grid, blk, 0, s, a); break;
+      case 48: hipLaunchKernelGGL((attention_kernel<48, 4>), grid, blk, 0, s, a); break;
+      case 72: hipLaunchKernelGGL((attention_kernel<72, 2>), grid, blk, 0, s, a); break;
+      case 128: hipLaunchKernelGGL((attention_kernel<128, 1>), grid, blk, 0, s, a); break;
+      default: return -1;
+    }
+  }
   return 0;
 }
+bool attention_head_size_ok(int HS) { return HS == 36 || HS == 64 || HS == 12 || HS == 16 || HS == 24 || HS == 32 || HS == 48 || HS == 72 || HS == 128; }
 
 // =====================================================================================================
 // depthwise conv along time (SeparableConv1D depthwise half, conformer_blocks.py:194-197):
@@ -700,6 +716,24 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
 #pragma unroll
   for (int i = 0; i < TT; ++i)
     if (t0 + i < a.T) stg4(yb + (size_t)(t0 + i) * a.D, acc[i]);
+}
+
+// Any kernel size (round 6: conformer_blocks.py:278-294 takes any; a configuration the tuned kernels do not cover must run, not
+// fail): one thread per (frame, four channels), the taps walked at run time.  Slow path: every tap is two L2 / L1 reads.
+__global__ __launch_bounds__(256) void dwconv_any_kernel(DwArgs a, int K) {
+  const int c4n = a.D / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)a.B * a.T * c4n) return;
+  const int c4 = (int)(idx % c4n) * 4;
+  const int t = (int)((idx / c4n) % a.T);
+  const int b = (int)(idx / ((size_t)c4n * a.T));
+  const float* __restrict__ ub = a.u + (size_t)b * a.T * a.D + c4;
+  f32x4 acc = splat4(0.f);
+  for (int j = 0; j < K; ++j) {
+    const int tt = t + j - a.pad_left;
+    if (tt >= 0 && tt < a.T) acc += ldg4(ub + (size_t)tt * a.D) * ldg4(a.wd + (size_t)j * a.D + c4);
+  }
+  stg4(a.y + ((size_t)b * a.T + t) * a.D + c4, acc);
 }
 
 // LDS-tiled depthwise conv: a workgroup owns 64 consecutive frames of one utterance x CB channels; the 64 + K - 1 input
@@ -791,6 +825,9 @@ int launch_dwconv(int K, const DwArgs& a, hipStream_t s) {
   dim3 grid((total + 255) / 256);
   if (K == 32) hipLaunchKernelGGL((dwconv_kernel<32, TT>), grid, dim3(256), 0, s, a);
   else if (K == 5) hipLaunchKernelGGL((dwconv_kernel<5, TT>), grid, dim3(256), 0, s, a);
-  else return -1;
+  else if (K >= 1) {
+    const size_t n = (size_t)a.B * a.T * (a.D / 4);
+    hipLaunchKernelGGL(dwconv_any_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, K);
+  } else return -1;
   return 0;
 }

@@ -37,8 +37,9 @@ constexpr int KB = D / 16;      // 9
 constexpr int KS = 5;           // 32-wide steps over K = 144 (+ the bias row 144)
 
 #define NS_FENCE __builtin_amdgcn_sched_barrier(0)
-// diagnostics (tools/build_variant.py NAME fused_ns.hip -DNS_DIAG=32): cycle stamps (s_memtime) at the stages of ns1_tail_kernel,
-// printed for one workgroup (tools/sessions/r06_ns1_stamp.sh)
+// diagnostics (tools/build_variant.py NAME fused_ns.hip -DNS_DIAG=n): 32 = cycle stamps (s_memtime) at the stages of ns1_tail_kernel,
+// printed for one workgroup (tools/sessions/r06_ns1_stamp.sh); 64 = timing only, WRONG results: the in-launch attention without its
+// fp32 -> fp16-pair split of K / V (what pre-split fragments from the producer would save)
 #ifndef NS_DIAG
 #define NS_DIAG 0
 #endif
@@ -436,7 +437,9 @@ DEV void ns1_attention(Ns1AttnLds& A, const OutGluArgs& g, int b, int f0, int w,
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
           const int kt = 2 * w + k2;
-          const Split8 kf = split8(klo[hh][k2] * splat4(sk), khi[hh][k2] * splat4(sk));
+          Split8 kf;
+          if constexpr ((NS_DIAG & 64) != 0) { kf.t[0] = __builtin_bit_cast(u32x4_t, klo[hh][k2]); kf.t[1] = __builtin_bit_cast(u32x4_t, khi[hh][k2]); }   // timing only
+          else kf = split8(klo[hh][k2] * splat4(sk), khi[hh][k2] * splat4(sk));
           f32x4 acc = splat4(0.f);
           acc = ns_mfma(kf.t[1], qf.t[0], acc);
           acc = ns_mfma(kf.t[0], qf.t[1], acc);
@@ -463,7 +466,9 @@ DEV void ns1_attention(Ns1AttnLds& A, const OutGluArgs& g, int b, int f0, int w,
 #pragma unroll
         for (int i = 0; i < A_OT; ++i) {
           const f32x4 lo = {ve[hh][i][0], ve[hh][i][1], ve[hh][i][2], ve[hh][i][3]}, hi = {ve[hh][i][4], ve[hh][i][5], ve[hh][i][6], ve[hh][i][7]};
-          const Split8 vf = split8(lo * splat4(sv), hi * splat4(sv));
+          Split8 vf;
+          if constexpr ((NS_DIAG & 64) != 0) { vf.t[0] = __builtin_bit_cast(u32x4_t, lo); vf.t[1] = __builtin_bit_cast(u32x4_t, hi); }   // timing only
+          else vf = split8(lo * splat4(sv), hi * splat4(sv));
           o[i] = ns_mfma(vf.t[1], pf.t[0], o[i]);
           o[i] = ns_mfma(vf.t[0], pf.t[1], o[i]);
           o[i] = ns_mfma(vf.t[0], pf.t[0], o[i]);

@@ -425,6 +425,7 @@ int launch_gather(const GatherArgs& a, hipStream_t s);
 int launch_chain2(int D, int mode, const Chain2Args& a, hipStream_t s);
 int launch_gemm_rows(int D, int epi, bool ln, const GemmArgs& a, hipStream_t s);
 int launch_attention(int HS, const AttnArgs& a, hipStream_t s);
+bool attention_head_size_ok(int HS);      // 36 / 64 (tuned kernels) and 12, 16, 24, 32, 48, 72, 128 (online-softmax kernel only)
 bool attention_lds_applicable(int HS, const AttnArgs& a);
 int launch_attention_lds(int HS, const AttnArgs& a, hipStream_t s);
 bool attention_split_applicable(int HS, const AttnArgs& a);

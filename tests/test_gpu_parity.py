@@ -2060,6 +2060,36 @@ np.savez(sys.argv[1], **out)
         print("one tile per workgroup vs pair-pipelined: oracle distances %s / %s" % (res["ns1"][0], res["pp"][0]))
 
 
+@pytest.mark.parametrize("dm,H,hs,k,B,L", [(144, 3, 48, 7, 2, 16000), (144, 6, 24, 16, 2, 16000), (256, 8, 32, 9, 2, 16000), (144, 12, 12, 3, 1, 32000),
+                                           (144, 2, 72, 31, 40, 80000), (512, 4, 128, 4, 1, 16000)])
+def test_constructor_surface_beyond_the_shipped_yamls(torch_cuda, dm, H, hs, k, B, L):
+    """Round 6 (review: "a user config that does not fit gets an error, not a slow path"): conformer_blocks.py:278-294 takes any head
+    size and kernel size.  Head sizes 12 / 16 / 24 / 32 / 48 / 72 / 128 run on the online-softmax attention kernel, any kernel size on
+    dwconv_any_kernel (even sizes: Keras 'same' pads (k - 1) // 2 in front), under the fused block kernels where dmodel is 144
+    ((144, 2, 72, 31) at 40 x 5 s = 5 000 rows: the pair-pipelined kernels, below: one tile per workgroup).  Encoder (1 block) + CTC
+    decoder against the oracle."""
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = dict(co.CONFORMER_S, dmodel=dm, num_heads=H, head_size=hs, kernel_size=k, num_blocks=1, ctcdecoder_kernel_size=k)
+    w = co.encoder_weights(cfg, seed=1)
+    w.update(co.ctc_decoder_weights(cfg, 70, seed=2))
+    m = ConformerCTC(70, dmodel=dm, num_blocks=1, head_size=hs, num_heads=H, kernel_size=k, ctcdecoder_kernel_size=k)
+    m.load_weights(w, by_name=False)
+    x = waves(B, L, 3)
+    enc = m.encode(x)
+    ref = co.conformer_encoder(x[:2].astype(np.float64), w, cfg)
+    assert maxdiff(enc.cpu().numpy()[:2], ref) < TOL
+    assert maxdiff(m.ctc_logits(enc).cpu().numpy()[:2], co.ctc_decoder(ref, w, cfg)) < TOL
+
+
+def test_constructor_rejects_what_no_kernel_covers(torch_cuda):
+    from tensorflowasr_amd import _lib
+    from tensorflowasr_amd.models import ConformerEncoder
+    with pytest.raises(_lib.Mi355AsrError, match="head_size"):
+        ConformerEncoder(dmodel=144, num_blocks=1, head_size=18, num_heads=8)
+    with pytest.raises(_lib.Mi355AsrError, match="reduction_factor"):
+        ConformerEncoder(dmodel=144, num_blocks=1, reduction_factor=8)
+
+
 def test_translator_dmodel_512(torch_cuda):
     """conformerL.yml Translator (dmodel 512, 8 heads x 64): cross-attention through the layer-at-a-time GEMM path."""
     from tensorflowasr_amd.models import Translator
