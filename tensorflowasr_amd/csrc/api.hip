@@ -1265,6 +1265,9 @@ int run_subsampling(const mi355asr_model* m, const float* mel, int Bp, int F, fl
   }
   {
     PROF(MI355ASR_K_SUBLINEAR);
+    // round 6, small batches (the fp32 stream_gemm kernel took 38 us for one utterance): one 16-token tile per workgroup, the 144-wide
+    // chunks of a row split over its eight waves, on the two-term fragments of pp_sublinear_kernel (MI355ASR_SUBLINEAR_SPLIT=0: off)
+    if (lin_split && m->lin_ns && pp_sublinear_ok(lg, m->lin_pp) && launch_ns1_sublinear(lg, m->lin_ns, m->lin_pp_sw, s) == 0) return 0;
     if (launch_stream_gemm(d, lg, s) == 0) return 0;
   }
   // K = F2 * dmodel that is not a multiple of 32 (the plain Spectrogram layer: F2 = 129): the layer-at-a-time kernel
@@ -1792,7 +1795,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   const int d = c.dmodel;
   ArenaBuilder ab;
   ab.ring_terms = m->cfg.gemm_dtype == 1 ? 1 : 3;
-  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0, o_c2h = 0, o_lpp = 0;
+  size_t o_dft = 0, o_mel = 0, o_c1w = 0, o_c1b = 0, o_c2w = 0, o_c2b = 0, o_lw = 0, o_lb = 0, o_c2s = 0, o_lws = 0, o_c2h = 0, o_lpp = 0, o_lns = 0;
   float lin_pp_sw = 1.f, c1_l1 = 0.f, c1_bmax = 0.f, c1_ms = 0.f, c1_ws = 0.f;
   float c2_hs = 0.f, c2_ws = 0.f;
   FftOff fo;
@@ -1941,12 +1944,13 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
     o_lws = ab.put(pack_linear_split(lin, dm.F2 * d, d));
     // two-term fp16 stream (pp_sublinear_kernel): chunk f = rows 144 f .. 144 f + 143 of the kernel, the bias in row 144 of chunk 0
     const auto& lb = m->host["conv_subsampling/linear/bias"].data;
-    std::vector<float> pp;
+    std::vector<float> pp, lin_plain;
     lin_pp_sw = append_pp_plain(pp, [&](int k, int n) {
       const int f = n / d, col = n - f * d;
       return k < d ? lin[((size_t)f * d + k) * d + col] : (f == 0 ? lb[col] : 0.f);
-    }, dm.F2);
+    }, dm.F2, &lin_plain);
     o_lpp = ab.put(pp);
+    o_lns = ab.put(lin_plain);
   }
   for (int i = 0; i < c.num_blocks; ++i)
     eo.push_back(pack_block(m, ab, "conformer_block_" + std::to_string(i), d, c.num_heads, c.head_size, c.kernel_size));
@@ -2024,6 +2028,7 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   m->c1_l1 = c1_l1; m->c1_bmax = c1_bmax; m->c1_mscale = c1_ms; m->c1_wscale = c1_ws;
   m->lin_wsplit = (d == 144 && c.has_encoder) ? base + o_lws : nullptr;
   m->lin_pp = (d == 144 && c.has_encoder) ? base + o_lpp : nullptr;
+  m->lin_ns = (d == 144 && c.has_encoder) ? base + o_lns : nullptr;
   m->lin_pp_sw = lin_pp_sw;
   m->proj_pp = (d == 144 && c.num_classes > 0) ? base + o_ppp : nullptr;
   m->proj_pp_sw = proj_pp_sw;

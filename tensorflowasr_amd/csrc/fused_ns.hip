@@ -233,12 +233,15 @@ DEV void ns1_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS], const u32x4_t* w1, co
   }
 }
 
-// plain layer for one tile: acc[j] = W[:, tile_j] x for three column tiles, fragments through a two-step pool of its own
+// plain layer for one tile: acc[j] = W[:, tile_j] x for three column tiles; the fragments of DP steps are in flight (DP = 2: a pool
+// of twelve, refilled two steps ahead; DP = 5: all thirty requested up front -- kernels with registers to spare)
+template <int DP = 2>
 DEV void ns1_plain3(f32x4 (&acc)[3], const u32x4_t* const (&wt)[3], int NT, const Split8 (&xf)[KS]) {
-  u32x4_t pl[2][6];
+  static_assert(DP == 2 || DP == KS, "pool depth");
+  u32x4_t pl[DP][6];
   auto frag = [&](int j, int st, int term) { return wt[j][(size_t)(st * NT) * (2 * 64) + term * 64]; };
 #pragma unroll
-  for (int st = 0; st < 2; ++st)
+  for (int st = 0; st < DP; ++st)
 #pragma unroll
     for (int j = 0; j < 3; ++j) { pl[st][j] = frag(j, st, 1); pl[st][3 + j] = frag(j, st, 0); }
   NS_FENCE;
@@ -248,10 +251,10 @@ DEV void ns1_plain3(f32x4 (&acc)[3], const u32x4_t* const (&wt)[3], int NT, cons
       constexpr int pr = decltype(Pi)::value;
       static_for<0, 3>([&](auto J) {
         constexpr int j = decltype(J)::value;
-        acc[j] = ns_mfma(pl[st & 1][(pr == 0 ? 0 : 3) + j], pr == 1 ? xf[st].t[1] : xf[st].t[0], acc[j]);
-        if constexpr (st + 2 < KS && j == 2) {
-          if constexpr (pr == 0) { pl[st & 1][0] = frag(0, st + 2, 1); pl[st & 1][1] = frag(1, st + 2, 1); pl[st & 1][2] = frag(2, st + 2, 1); }
-          if constexpr (pr == 2) { pl[st & 1][3] = frag(0, st + 2, 0); pl[st & 1][4] = frag(1, st + 2, 0); pl[st & 1][5] = frag(2, st + 2, 0); }
+        acc[j] = ns_mfma(pl[st % DP][(pr == 0 ? 0 : 3) + j], pr == 1 ? xf[st].t[1] : xf[st].t[0], acc[j]);
+        if constexpr (st + DP < KS && j == 2) {
+          if constexpr (pr == 0) { pl[st % DP][0] = frag(0, st + DP, 1); pl[st % DP][1] = frag(1, st + DP, 1); pl[st % DP][2] = frag(2, st + DP, 1); }
+          if constexpr (pr == 2) { pl[st % DP][3] = frag(0, st + DP, 0); pl[st % DP][4] = frag(1, st + DP, 0); pl[st % DP][5] = frag(2, st + DP, 0); }
         }
         NS_FENCE;
       });
@@ -693,6 +696,48 @@ __global__ __launch_bounds__(NW * 64) void ns1_tail_kernel(TailFf2Args a, Ff1Qkv
   }
 }
 
+// Subsampling Dense (conformer_blocks.py:93-96; pp_sublinear_kernel's arithmetic: every 144-wide chunk of a row under its own
+// power-of-two scale, the bias in row 144 of chunk 0) for one tile: the CHUNKS are split over the waves -- wave w takes chunks w,
+// w + NW, ... with all nine column tiles each, partial rows meet in LDS.  ns: plain fragments [5][9 chunks][2][64].
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ns1_sublinear_kernel(StreamGemmArgs a, const u32x4_t* __restrict__ ns, float sw, int chunks) {
+  __shared__ __attribute__((aligned(16))) Ns1Lds<NW> L;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, t = lane & 15;
+  const int tok = blockIdx.x * 16 + t;
+  const bool live = tok < a.M;
+  const float* __restrict__ xrow = a.x + (size_t)min(tok, a.M - 1) * a.K + g4;
+  const int NT = KB * chunks;
+  f32x4 y[KB];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) y[i] = splat4(0.f);
+#pragma unroll 1
+  for (int f = w; f < chunks; f += NW) {
+    f32x4 xs[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(xrow + (size_t)f * D + 16 * kb);
+    Split8 xf[KS];
+    const float sx = pp_pow2_scale(ns_row_max(xs));
+    ns1_split_rows(xf, xs, g4, sx);
+    const f32x4 inv = splat4(pp_recip_pow2(sw * sx));
+    const u32x4_t* wp = ns + lane + (size_t)(KB * f) * 128;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const u32x4_t* const wt[3] = {wp + (size_t)(3 * g) * 128, wp + (size_t)(3 * g + 1) * 128, wp + (size_t)(3 * g + 2) * 128};
+      f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
+      ns1_plain3<KS>(acc, wt, NT, xf);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) y[3 * g + j] += acc[j] * inv;
+    }
+  }
+  ns1_allreduce<NW>(y, L, w, lane);
+  if (w == 0 && live) {
+    float* yrow = a.y + (size_t)tok * a.ldy + g4;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) stg4(yrow + 16 * i, y[i]);
+  }
+}
+
 // CTC class head of one tile (pp_head_kernel's contract: logits = x W + b over `groups` x nine column tiles, per-frame arg-max --
 // lowest class among equal maxima -- and / or maximum and / or the logits), column tiles w, w + NW, ... per wave
 template <int NW>
@@ -811,5 +856,11 @@ int launch_ns1_head(const GemmArgs& a, const float* ns, float sw, int groups, hi
   if (!ns1_rows_ok(a.M) || !ns || groups < 1 || a.n_valid > 144 * groups) return -1;
   note_scheme(SCHEME_F16X2);
   hipLaunchKernelGGL((ns1_head_kernel<NS1_W>), dim3((a.M + 15) / 16), dim3(NS1_W * 64), 0, s, a, reinterpret_cast<const u32x4_t*>(ns), sw, groups);
+  return 0;
+}
+int launch_ns1_sublinear(const StreamGemmArgs& a, const float* ns, float sw, hipStream_t s) {
+  if (!ns1_rows_ok(a.M) || !ns || a.NT != KB || a.K % D != 0 || a.K < D || (a.ldy & 3) != 0) return -1;
+  note_scheme(SCHEME_F16X2);
+  hipLaunchKernelGGL((ns1_sublinear_kernel<NS1_W>), dim3((a.M + 15) / 16), dim3(NS1_W * 64), 0, s, a, reinterpret_cast<const u32x4_t*>(ns), sw, a.K / D);
   return 0;
 }

@@ -405,7 +405,8 @@ bool ns1_block_ok(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g
 bool ns1_attn_ok(int hs, const AttnArgs& at);                                             // ... with its attention in the first launch
 int launch_ns1_ff1_qkv(const Ff1QkvArgs& b, hipStream_t s);
 int launch_ns1_og_tail(const TailFf2Args& a, const Ff1QkvArgs* b, const OutGluArgs& g, hipStream_t s);
-int launch_ns1_head(const GemmArgs& a, const float* ns, float sw, int groups, hipStream_t s);   // ns: [W ; b] fragments in plain order [5][9 groups][2][64]
+int launch_ns1_head(const GemmArgs& a, const float* ns, float sw, int groups, hipStream_t s);
+int launch_ns1_sublinear(const StreamGemmArgs& a, const float* ns, float sw, hipStream_t s);   // ns: [W chunk ; b] fragments in plain order [5][9 chunks][2][64]   // ns: [W ; b] fragments in plain order [5][9 groups][2][64]
 bool ff1_qkv_pp_selected(bool has_slabs, bool has_pp);   // fused.hip: q, k, v will come from the pair-pipelined producer (head-major layout possible)
 bool ff1_pre_selected();             // ... and launch_ff1_qkv will take that kernel (fused.hip) when the block has its streams
 bool pp_pre_fold_ok();

@@ -153,6 +153,7 @@ struct mi355asr_model {
   const float* lin_wsplit = nullptr;    // subsampling Dense kernel as split-bf16 fragments, 1792 per 32-wide step (fused.hip)
   const float* lin_pp = nullptr;        // ... and as the two-term fp16 stream of pp_sublinear_kernel (F2 chunks of five ring slots), packed with
   float lin_pp_sw = 1.f;                // ... this power of two
+  const float* lin_ns = nullptr;        // ... and the same fragments in plain order (fused_ns.hip: small batches)
   const float* proj_pp = nullptr;       // the CTC decoder's projection [W ; b] as such a stream (one chunk), packed with
   float proj_pp_sw = 1.f;               // ... this power of two
   const float* c2_wsplit = nullptr;     // conv2 kernel as split-bf16 fragments (subconv.hip; dmodel 144 / 256 / 512)
