@@ -2013,7 +2013,7 @@ def test_small_batches_one_tile_per_workgroup_against_the_pair_pipelined_kernels
     pattern (test_asr.py:186-219).  A workgroup of eight waves owns ONE 16-token tile, the hidden dimension and the column tiles of
     the plain layers are split over the waves, the block runs as attention + out-projection / GLU + (depthwise conv, tail, next
     ff_module_1 + qkv).  Same arithmetic as the pair-pipelined kernels, another summation order: encoder output, logits and greedy ids
-    of 1 x 10 s, 3 x 3.7 s (a ragged last tile per utterance: 92 frames) and 2 x 2.8 s against the build with MI355ASR_NS1_MAX_M=0
+    of 1 x 10 s, 3 x 3.7 s (a ragged last tile per utterance: 92 frames), 2 x 2.8 s and 12 x 10 s against the build with MI355ASR_NS1_MAX_M=0
     and against the fp64 oracle; the profile counters say which kernels ran (three launches of the tail category per block pair)."""
     import subprocess
     import sys
@@ -2029,7 +2029,7 @@ w = co.encoder_weights(cfg, seed=0); w.update(golden_ctc_weights())
 m = ConformerCTC(1332, **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
 m.load_weights(w, by_name=False)
 out = {}
-for tag, B, L in (("b1", 1, 160000), ("b3", 3, 59000), ("b2", 2, 45000)):
+for tag, B, L in (("b1", 1, 160000), ("b3", 3, 59000), ("b2", 2, 45000), ("b12", 12, 160000)):     # b12: 3 000 rows -- the class head folds into the CTC block's pair-pipelined tail from 2 048 rows, the encoder's blocks stay on the one-tile kernels
     x = waves(B, L, 40)
     enc = m.encode(x); lg = m.ctc_logits(enc)
     ids, lens = m.recognize(x)
@@ -2046,7 +2046,7 @@ np.savez(sys.argv[1], **out)
             r = subprocess.run([sys.executable, "-c", code, os.path.join(td, tag + ".npz")], env=dict(os.environ, **extra), capture_output=True,
                                text=True, timeout=900, cwd=root)
             lines = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
-            assert len(lines) == 3, r.stderr[-3000:]
+            assert len(lines) == 4, r.stderr[-3000:]
             assert all(float(l[1]) < TOL and float(l[2]) < TOL for l in lines), (tag, lines)
             res[tag] = (lines, np.load(os.path.join(td, tag + ".npz")))
         for other in ("pp", "ns1_attn_own"):          # (the attention inside the out-projection launch sums its key tiles in another order)
