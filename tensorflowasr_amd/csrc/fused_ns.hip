@@ -193,19 +193,24 @@ DEV void ns1_phase(f32x4 (&y)[KB], f32x4 (&hA)[2], f32x4 (&hP)[2], const Split8&
 
 // y += W2 act(W1aug [x ; 1]) for one tile; this wave's pairs w, w + NW, ... (n of them, possibly none) as a software pipeline with
 // a run-time trip count (the roles of the two hidden / operand register sets are swapped by copies: 16 moves per unit)
+// the first NP1 fragments of wave w's first pair: requested by the caller as early as it can (in front of the exchange / LayerNorm /
+// operand split that precede a chain: a fragment takes an L2 round trip, and a chain that starts cold waits for it with idle pipes)
 template <int P, int NW>
-DEV void ns1_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS], const u32x4_t* w1, const u32x4_t* w2, int w, int lane, float k1, float ik2) {
+DEV void ns1_prime(u32x4_t (&pool)[NP1], const u32x4_t* w1, int w, int lane) {
+  const NsPtr p0{nullptr, w1 + (size_t)(2 * min(w, P - 1)) * (2 * 64) + lane};
+  static_for<0, NP1>([&](auto Q) { constexpr int q = decltype(Q)::value; pool[q] = ns_frag_a<2 * P>(p0, q)[0]; });
+}
+template <int P, int NW>
+DEV void ns1_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS], u32x4_t (&pool)[NP1], const u32x4_t* w1, const u32x4_t* w2, int w, int lane, float k1, float ik2) {
   constexpr int NT1 = 2 * P;
   const int n = w < P ? (P - w + NW - 1) / NW : 0;
   if (n == 0) return;
   auto ptr = [&](int k) { const int pair = w + NW * k; return NsPtr{w2 + (size_t)pair * (KB * 2 * 64) + lane, w1 + (size_t)(2 * pair) * (2 * 64) + lane}; };
-  u32x4_t pool[NP1];
   const f32x4 zero = splat4(0.f);
   f32x4 hacc[2] = {zero, zero}, hprep[2];
   Split8 fuse, fbuild;
   {
     const NsPtr p0 = ptr(0);
-    static_for<0, NP1>([&](auto Q) { constexpr int q = decltype(Q)::value; pool[q] = ns_frag_a<NT1>(p0, q)[0]; });
     if (n == 1) {
       ns1_phase<false, true, false, 1, NT1>(y, hacc, hprep, fuse, fbuild, xf, pool, p0, p0, k1, ik2);           // A(0); then its own W2
       hprep[0] = hacc[0]; hprep[1] = hacc[1];
@@ -304,7 +309,7 @@ DEV void ns1_stash(Ns1Lds<NW>& L, const float* const (&src)[N]) {
 
 // ff_module_1 + q / k / v of the tile in xs (x0 rows, identical in every wave): stores x1 (wave 0) and qkv (each wave its tiles)
 template <int NW>
-DEV void ns1_ff1_qkv(const Ff1QkvArgs& a, Ns1Lds<NW>& L, f32x4 (&xs)[KB], const Ns1Tile& tl, int w, int lane, int g4) {
+DEV void ns1_ff1_qkv(const Ff1QkvArgs& a, Ns1Lds<NW>& L, f32x4 (&xs)[KB], const Ns1Tile& tl, int w, int lane, int g4, u32x4_t (&pool)[NP1]) {
   f32x4 y[KB];
   const float inv_fc = 1.0f / a.fc;
   Split8 xf[KS];
@@ -317,7 +322,7 @@ DEV void ns1_ff1_qkv(const Ff1QkvArgs& a, Ns1Lds<NW>& L, f32x4 (&xs)[KB], const 
 #pragma unroll
     for (int i = 0; i < KB; ++i) y[i] = w == 0 ? r[i] * splat4(tk.s2) : splat4(0.f);       // residual + bias ride in wave 0's partial
     ns1_split_rows(xf, xs, g4, tk.sx);
-    ns1_chain<18, NW>(y, xf, reinterpret_cast<const u32x4_t*>(a.ns_w1), reinterpret_cast<const u32x4_t*>(a.ns_w2), w, lane, tk.k1, tk.ik2);
+    ns1_chain<18, NW>(y, xf, pool, reinterpret_cast<const u32x4_t*>(a.ns_w1), reinterpret_cast<const u32x4_t*>(a.ns_w2), w, lane, tk.k1, tk.ik2);
     ns1_allreduce<NW>(y, L, w, lane);
 #pragma unroll
     for (int i = 0; i < KB; ++i) { y[i] = splat4(a.fc * tk.inv2) * y[i]; xs[i] = y[i]; }      // x1 = x0 + fc (ffn + b2)
@@ -363,10 +368,12 @@ __global__ __launch_bounds__(NW * 64) void ns1_ff1_qkv_kernel(Ff1QkvArgs a) {
   f32x4 xs[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) xs[kb] = ldg4(a.x0 + tl.row + 16 * kb + g4);
+  u32x4_t pool[NP1];
+  ns1_prime<18, NW>(pool, reinterpret_cast<const u32x4_t*>(a.ns_w1), w, lane);
   const float* const par[5] = {a.ff_ln_g, a.ff_ln_b, a.ff_b2, a.att_ln_g, a.att_ln_b};
   ns1_stash<NW>(L, par);
   __syncthreads();
-  ns1_ff1_qkv<NW>(a, L, xs, tl, w, lane, g4);
+  ns1_ff1_qkv<NW>(a, L, xs, tl, w, lane, g4, pool);
 }
 
 // ---- attention of one 16-query tile (round 6: inside the out-projection launch of the small-batch path) ------------------------------
@@ -646,6 +653,8 @@ __global__ __launch_bounds__(NW * 64) void ns1_tail_kernel(TailFf2Args a, Ff1Qkv
                                   FF1 ? b.att_ln_b : nullptr, a.pw2_b, a.ff_ln_g, a.ff_ln_b, a.ff_b2, a.ln_g, a.ln_b};
     ns1_stash<NW>(L, par);                             // published by the barriers of the depthwise conv
   }
+  u32x4_t pool[NP1], pool2[NP1];
+  ns1_prime<9, NW>(pool, reinterpret_cast<const u32x4_t*>(a.ns_cv_w1), w, lane);            // in flight under the depthwise conv
   ns1_dwconv<NW>(S, a, xs, lane, g4, t);
   NS1_STAMP(1);
   Split8 xf[KS];
@@ -655,7 +664,8 @@ __global__ __launch_bounds__(NW * 64) void ns1_tail_kernel(TailFf2Args a, Ff1Qkv
     for (int i = 0; i < KB; ++i) y[i] = w == 0 ? (y[i] + lds4(L.par[5], i, g4)) * splat4(tk.s2) : splat4(0.f);
     ns1_split_rows(xf, xs, g4, tk.sx);
     NS1_STAMP(2);
-    ns1_chain<9, NW>(y, xf, reinterpret_cast<const u32x4_t*>(a.ns_cv_w1), reinterpret_cast<const u32x4_t*>(a.ns_cv_w2), w, lane, tk.k1, tk.ik2);
+    ns1_chain<9, NW>(y, xf, pool, reinterpret_cast<const u32x4_t*>(a.ns_cv_w1), reinterpret_cast<const u32x4_t*>(a.ns_cv_w2), w, lane, tk.k1, tk.ik2);
+    ns1_prime<18, NW>(pool2, reinterpret_cast<const u32x4_t*>(a.ns_ff_w1), w, lane);         // ff_module_2's first fragments: under the exchange + LayerNorm
     NS1_STAMP(3);
     ns1_allreduce<NW>(y, L, w, lane);
     NS1_STAMP(4);
@@ -672,7 +682,8 @@ __global__ __launch_bounds__(NW * 64) void ns1_tail_kernel(TailFf2Args a, Ff1Qkv
     for (int i = 0; i < KB; ++i) y[i] = w == 0 ? (lds4(L.par[8], i, g4) + splat4(inv_fc) * y[i]) * splat4(tk.s2) : splat4(0.f);
     ns1_split_rows(xf, xs, g4, tk.sx);
     NS1_STAMP(5);
-    ns1_chain<18, NW>(y, xf, reinterpret_cast<const u32x4_t*>(a.ns_ff_w1), reinterpret_cast<const u32x4_t*>(a.ns_ff_w2), w, lane, tk.k1, tk.ik2);
+    ns1_chain<18, NW>(y, xf, pool2, reinterpret_cast<const u32x4_t*>(a.ns_ff_w1), reinterpret_cast<const u32x4_t*>(a.ns_ff_w2), w, lane, tk.k1, tk.ik2);
+    if constexpr (FF1) ns1_prime<18, NW>(pool, reinterpret_cast<const u32x4_t*>(b.ns_w1), w, lane);      // the next block's ff_module_1
     NS1_STAMP(6);
     ns1_allreduce<NW>(y, L, w, lane);
     NS1_STAMP(7);
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(NW * 64) void ns1_tail_kernel(TailFf2Args a, Ff1Qkv
     for (int i = 0; i < KB; ++i) stg4(a.y + tl.row + 16 * i + g4, y[i]);
   }
   NS1_STAMP(8);
-  if constexpr (FF1) ns1_ff1_qkv<NW>(b, L, y, tl, w, lane, g4);
+  if constexpr (FF1) ns1_ff1_qkv<NW>(b, L, y, tl, w, lane, g4, pool);
   NS1_STAMP(9);
   if constexpr ((NS_DIAG & 32) != 0) {
     if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0 && (w == 0 || w == 7)) {
