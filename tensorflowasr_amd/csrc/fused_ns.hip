@@ -67,12 +67,14 @@ DEV NsTok ns_chain_scales(const PpChainSc& c, float xmax) {      // fused_pp.hip
   t.inv2 = pp_recip_pow2(t.s2);
   return t;
 }
-// fragment pointers of a hidden pair (+ lane): b = its W2 fragments [9][2][64], a = its W1 fragments [KS][NT1][2][64] at tile 2 pair
-struct NsPtr { const u32x4_t *b, *a; };
+// fragment pointers of a hidden pair, WAVE-UNIFORM (the lane is added as a 32-bit index at the load: scalar base + vector offset
+// instead of 64-bit address arithmetic per fragment): b = its W2 fragments [9][2][64], a = its W1 fragments [KS][NT1][2][64] at tile
+// 2 pair; lane = this lane's index
+struct NsPtr { const u32x4_t *b, *a; unsigned lane; };
 template <int NT1>
-DEV const u32x4_t* ns_frag_a(const NsPtr& p, int q) {        // q < 20: step q / 4, (b0 lo, b1 lo, b0 hi, b1 hi)
+DEV u32x4_t ns_frag_a(const NsPtr& p, int q) {        // q < 20: step q / 4, (b0 lo, b1 lo, b0 hi, b1 hi)
   const int s = q >> 2, j = q & 3;
-  return p.a + ((s * NT1 + (j & 1)) * 2 + ((j >> 1) ^ 1)) * 64;
+  return p.a[((s * NT1 + (j & 1)) * 2 + ((j >> 1) ^ 1)) * 64 + p.lane];
 }
 
 // ---- the workgroup's exchange areas ------------------------------------------------------------------------------------------------
@@ -110,9 +112,9 @@ DEV void ns1_allreduce(f32x4 (&y)[KB], Ns1Lds<NW>& L, int w, int lane) {
 //   A part (HA): hA[0..1] += W1[:, pair a] x            30 MFMAs
 //   prep   (HP): fP = split(swish(hP[0..1]))             40 slots behind the MFMAs (all of them in a row when the phase has none)
 // positions: B = per group (lo of three tiles, hi of three tiles), 18 + 2 idle; A = per step (b0 lo, b1 lo, b0 hi, b1 hi)
-DEV const u32x4_t* ns1_frag_b(const NsPtr& p, int q) {        // q < 18
+DEV u32x4_t ns1_frag_b(const NsPtr& p, int q) {        // q < 18
   const int g = q / 6, j = q % 6;
-  return p.b + ((3 * g + j % 3) * 2 + (j < 3 ? 1 : 0)) * 64;
+  return p.b[((3 * g + j % 3) * 2 + (j < 3 ? 1 : 0)) * 64 + p.lane];
 }
 template <bool HB, bool HA, bool HP, int NXT, int NT1>
 DEV void ns1_phase(f32x4 (&y)[KB], f32x4 (&hA)[2], f32x4 (&hP)[2], const Split8& fB, Split8& fP, const Split8 (&xf)[KS],
@@ -123,14 +125,14 @@ DEV void ns1_phase(f32x4 (&y)[KB], f32x4 (&hA)[2], f32x4 (&hP)[2], const Split8&
     constexpr int q = decltype(Q)::value;
     if constexpr (q < NPOS) {
       if constexpr (q < NB) {
-        if constexpr (q < 18) pool[q % NP1] = ns1_frag_b(cur, q)[0];
+        if constexpr (q < 18) pool[q % NP1] = ns1_frag_b(cur, q);
       } else {
-        pool[q % NP1] = ns_frag_a<NT1>(cur, q - NB)[0];
+        pool[q % NP1] = ns_frag_a<NT1>(cur, q - NB);
       }
     } else if constexpr (NXT == 1) {
-      if constexpr (q - NPOS < 18) pool[q % NP1] = ns1_frag_b(nxt, q - NPOS)[0];
+      if constexpr (q - NPOS < 18) pool[q % NP1] = ns1_frag_b(nxt, q - NPOS);
     } else if constexpr (NXT == 2) {
-      pool[q % NP1] = ns_frag_a<NT1>(nxt, q - NPOS)[0];
+      pool[q % NP1] = ns_frag_a<NT1>(nxt, q - NPOS);
     }
   };
   auto release = [&](auto Q) { load_pos(std::integral_constant<int, decltype(Q)::value + NP1>()); };
@@ -197,15 +199,15 @@ DEV void ns1_phase(f32x4 (&y)[KB], f32x4 (&hA)[2], f32x4 (&hP)[2], const Split8&
 // operand split that precede a chain: a fragment takes an L2 round trip, and a chain that starts cold waits for it with idle pipes)
 template <int P, int NW>
 DEV void ns1_prime(u32x4_t (&pool)[NP1], const u32x4_t* w1, int w, int lane) {
-  const NsPtr p0{nullptr, w1 + (size_t)(2 * min(w, P - 1)) * (2 * 64) + lane};
-  static_for<0, NP1>([&](auto Q) { constexpr int q = decltype(Q)::value; pool[q] = ns_frag_a<2 * P>(p0, q)[0]; });
+  const NsPtr p0{nullptr, w1 + (size_t)(2 * min(w, P - 1)) * (2 * 64), (unsigned)lane};
+  static_for<0, NP1>([&](auto Q) { constexpr int q = decltype(Q)::value; pool[q] = ns_frag_a<2 * P>(p0, q); });
 }
 template <int P, int NW>
 DEV void ns1_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS], u32x4_t (&pool)[NP1], const u32x4_t* w1, const u32x4_t* w2, int w, int lane, float k1, float ik2) {
   constexpr int NT1 = 2 * P;
   const int n = w < P ? (P - w + NW - 1) / NW : 0;
   if (n == 0) return;
-  auto ptr = [&](int k) { const int pair = w + NW * k; return NsPtr{w2 + (size_t)pair * (KB * 2 * 64) + lane, w1 + (size_t)(2 * pair) * (2 * 64) + lane}; };
+  auto ptr = [&](int k) { const int pair = w + NW * k; return NsPtr{w2 + (size_t)pair * (KB * 2 * 64), w1 + (size_t)(2 * pair) * (2 * 64), (unsigned)lane}; };
   const f32x4 zero = splat4(0.f);
   f32x4 hacc[2] = {zero, zero}, hprep[2];
   Split8 fuse, fbuild;
@@ -226,13 +228,13 @@ DEV void ns1_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS], u32x4_t (&pool)[NP1],
   }
 #pragma unroll 1
   for (int k = 2; k < n; ++k) {                       // B(k - 2; fuse) | A(k) | prep(k - 1) -> fbuild
-    const NsPtr cu{ptr(k - 2).b, ptr(k).a}, nx{ptr(k - 1).b, nullptr};
+    const NsPtr cu{ptr(k - 2).b, ptr(k).a, (unsigned)lane}, nx{ptr(k - 1).b, nullptr, (unsigned)lane};
     hacc[0] = zero; hacc[1] = zero;
     ns1_phase<true, true, true, 1, NT1>(y, hacc, hprep, fuse, fbuild, xf, pool, cu, nx, k1, ik2);
     fuse = fbuild; hprep[0] = hacc[0]; hprep[1] = hacc[1];
   }
   {
-    const NsPtr cu{ptr(n - 2).b, nullptr}, nx{ptr(n - 1).b, nullptr};
+    const NsPtr cu{ptr(n - 2).b, nullptr, (unsigned)lane}, nx{ptr(n - 1).b, nullptr, (unsigned)lane};
     ns1_phase<true, false, true, 1, NT1>(y, hacc, hprep, fuse, fbuild, xf, pool, cu, nx, k1, ik2);              // B(n - 2) | prep(n - 1)
     ns1_phase<true, false, false, 0, NT1>(y, hacc, hprep, fbuild, fuse, xf, pool, nx, nx, k1, ik2);             // B(n - 1)
   }
@@ -241,10 +243,10 @@ DEV void ns1_chain(f32x4 (&y)[KB], const Split8 (&xf)[KS], u32x4_t (&pool)[NP1],
 // plain layer for one tile: acc[j] = W[:, tile_j] x for three column tiles; the fragments of DP steps are in flight (DP = 2: a pool
 // of twelve, refilled two steps ahead; DP = 5: all thirty requested up front -- kernels with registers to spare)
 template <int DP = 2>
-DEV void ns1_plain3(f32x4 (&acc)[3], const u32x4_t* const (&wt)[3], int NT, const Split8 (&xf)[KS]) {
+DEV void ns1_plain3(f32x4 (&acc)[3], const u32x4_t* const (&wt)[3], int NT, const Split8 (&xf)[KS], unsigned lane) {      // wt: wave-uniform
   static_assert(DP == 2 || DP == KS, "pool depth");
   u32x4_t pl[DP][6];
-  auto frag = [&](int j, int st, int term) { return wt[j][(size_t)(st * NT) * (2 * 64) + term * 64]; };
+  auto frag = [&](int j, int st, int term) { return wt[j][(unsigned)(st * NT) * (2u * 64u) + (unsigned)term * 64u + lane]; };
 #pragma unroll
   for (int st = 0; st < DP; ++st)
 #pragma unroll
@@ -335,12 +337,12 @@ DEV void ns1_ff1_qkv(const Ff1QkvArgs& a, Ns1Lds<NW>& L, f32x4 (&xs)[KB], const 
   const float sx = pp_pow2_scale(ns_row_max(xs));
   ns1_split_rows(xf, xs, g4, sx);
   const float invq = pp_recip_pow2(a.pp_sw_qkv * sx);
-  const u32x4_t* wq = reinterpret_cast<const u32x4_t*>(a.ns_qkv) + lane;
+  const u32x4_t* wq = reinterpret_cast<const u32x4_t*>(a.ns_qkv);
 #pragma unroll 1
   for (int t0 = w; t0 < 27; t0 += 3 * NW) {           // column tiles t0, t0 + NW, t0 + 2 NW (past the end: tile 26 again, not stored)
     const u32x4_t* const wt[3] = {wq + (size_t)min(t0, 26) * 128, wq + (size_t)min(t0 + NW, 26) * 128, wq + (size_t)min(t0 + 2 * NW, 26) * 128};
     f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
-    ns1_plain3(acc, wt, 27, xf);
+    ns1_plain3(acc, wt, 27, xf, (unsigned)lane);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int tile = t0 + j * NW;
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(NW * 64) void ns1_out_glu_kernel(OutGluArgs a, int 
     const float sx = pp_pow2_scale(ns_row_max(xs));
     ns1_split_rows(xf, xs, g4, sx);
     const f32x4 inv = splat4(pp_recip_pow2(a.pp_sw_out * sx));
-    const u32x4_t* wo = reinterpret_cast<const u32x4_t*>(a.ns_out) + lane;
+    const u32x4_t* wo = reinterpret_cast<const u32x4_t*>(a.ns_out);
     // nine column tiles: wave w takes tiles w, w + NW, w + 2 NW (< 9); every wave needs the whole row afterwards
 #pragma unroll
     for (int i = 0; i < KB; ++i) L.red[0][i][lane] = splat4(0.f);        // (all waves write the same zeros: tiles nobody owns do not exist)
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(NW * 64) void ns1_out_glu_kernel(OutGluArgs a, int 
     if (w < KB) {
       const u32x4_t* const wt[3] = {wo + (size_t)min(w, 8) * 128, wo + (size_t)min(w + NW, 8) * 128, wo + (size_t)min(w + 2 * NW, 8) * 128};
       f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
-      ns1_plain3(acc, wt, 9, xf);
+      ns1_plain3(acc, wt, 9, xf, (unsigned)lane);
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         if (w + j * NW < KB) L.red[0][w + j * NW][lane] = acc[j] * inv;
@@ -571,13 +573,13 @@ __global__ __launch_bounds__(NW * 64) void ns1_out_glu_kernel(OutGluArgs a, int 
   const float sx = pp_pow2_scale(ns_row_max(xs));
   ns1_split_rows(xf, xs, g4, sx);
   const float inv = pp_recip_pow2(a.pp_sw_pw1 * sx);
-  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(a.ns_pw1) + lane;
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(a.ns_pw1);
   // value tile i and gate tile 9 + i in the same wave; wave w takes i = w, w + NW (< 9): one ns1_plain3 holds (value, gate, -)
 #pragma unroll 1
   for (int i = w; i < KB; i += NW) {
     const u32x4_t* const wt[3] = {wp + (size_t)i * 128, wp + (size_t)(KB + i) * 128, wp + (size_t)i * 128};
     f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
-    ns1_plain3(acc, wt, 18, xf);
+    ns1_plain3(acc, wt, 18, xf, (unsigned)lane);
     if (tl.live) {
       const f32x4 va = acc[0] * splat4(inv), vb = acc[1] * splat4(inv);
       const f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
@@ -731,12 +733,12 @@ __global__ __launch_bounds__(NW * 64) void ns1_sublinear_kernel(StreamGemmArgs a
     const float sx = pp_pow2_scale(ns_row_max(xs));
     ns1_split_rows(xf, xs, g4, sx);
     const f32x4 inv = splat4(pp_recip_pow2(sw * sx));
-    const u32x4_t* wp = ns + lane + (size_t)(KB * f) * 128;
+    const u32x4_t* wp = ns + (size_t)(KB * f) * 128;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       const u32x4_t* const wt[3] = {wp + (size_t)(3 * g) * 128, wp + (size_t)(3 * g + 1) * 128, wp + (size_t)(3 * g + 2) * 128};
       f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
-      ns1_plain3<KS>(acc, wt, NT, xf);
+      ns1_plain3<KS>(acc, wt, NT, xf, (unsigned)lane);
 #pragma unroll
       for (int j = 0; j < 3; ++j) y[3 * g + j] += acc[j] * inv;
     }
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(NW * 64) void ns1_head_kernel(GemmArgs a, const u32
   ns1_split_rows(xf, xs, g4, sx);
   const float inv = pp_recip_pow2(sw * sx);
   const int NT = KB * groups;
-  const u32x4_t* wp = ns + lane;
+  const u32x4_t* wp = ns;
   float best_v = -INFINITY;
   int best_i = 0x7fffffff;
   const bool want_max = a.argmax_out != nullptr || a.maxval_out != nullptr;
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(NW * 64) void ns1_head_kernel(GemmArgs a, const u32
   for (int t0 = w; t0 < NT; t0 += 3 * NW) {
     const u32x4_t* const wt[3] = {wp + (size_t)min(t0, NT - 1) * 128, wp + (size_t)min(t0 + NW, NT - 1) * 128, wp + (size_t)min(t0 + 2 * NW, NT - 1) * 128};
     f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
-    ns1_plain3(acc, wt, NT, xf);
+    ns1_plain3(acc, wt, NT, xf, (unsigned)lane);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int tile = t0 + j * NW, f0 = 16 * tile + g4;
