@@ -54,7 +54,7 @@ typedef struct {
   int32_t num_heads;         /* model_config.num_heads                    4                    */
   int32_t kernel_size;       /* model_config.kernel_size                  32  | 5    (tuned); any other size 1 .. 1024 runs on a general kernel   */
   float   fc_factor;         /* model_config.fc_factor                    0.5                  */
-  int32_t reduction_factor;  /* model_config.reduction_factor             4          (the only value the subsampling kernels are written for)      */
+  int32_t reduction_factor;  /* model_config.reduction_factor             4          (2, 4, 6 or 8; the tuned kernels are the ones for 4)          */
   int32_t n_mels;            /* speech_config.num_feature_bins            80                   */
   int32_t sample_rate;       /* speech_config.sample_rate                 16000                */
   int32_t stride_ms;         /* speech_config.stride_ms                   10                   */

@@ -1548,7 +1548,8 @@ int mi355asr_create(const mi355asr_config* cfg, mi355asr_model** out) {
     return fail(MI355ASR_EINVAL, "kernel_size=%d: must be in 1 .. 1024", c.kernel_size);
   if (c.num_classes > 0 && (c.ctc_kernel_size < 1 || c.ctc_kernel_size > 1024))
     return fail(MI355ASR_EINVAL, "ctc_kernel_size=%d: must be in 1 .. 1024", c.ctc_kernel_size);
-  if (c.reduction_factor != 4) return fail(MI355ASR_EINVAL, "reduction_factor=%d: only 4 is supported", c.reduction_factor);
+  if (c.reduction_factor != 2 && c.reduction_factor != 4 && c.reduction_factor != 6 && c.reduction_factor != 8)
+    return fail(MI355ASR_EINVAL, "reduction_factor=%d: 2, 4, 6 or 8 (conv1 time stride 1 .. 4)", c.reduction_factor);
   if (c.mel_layer_type < 0 || c.mel_layer_type > 2)
     return fail(MI355ASR_EINVAL, "mel_layer_type=%d: 0 (Melspectrogram), 1 (leaf) or 2 (Spectrogram)", c.mel_layer_type);
   if (c.mel_layer_type == 1 && (c.n_mels != 80 || c.stride_ms * c.sample_rate / 1000 != 160 || c.sample_rate != 16000))

@@ -302,8 +302,13 @@ int launch_mel(const MelArgs& a, hipStream_t s) {
 // accumulators (32 VGPRs) instead of the whole row, so the kernel fits 256 registers with two waves per SIMD at any
 // width, and small position counts (streaming: 64 chunks x 13 x 20 positions) still give a few thousand waves.
 // conv1 is recomputed per column chunk (VALU work x D/128); dmodel is a run-time value here.
-template <int NBW>
+// ST1 = conv1's time stride (reduction_factor / 2; conformer_blocks.py:76-80): the mel window of one conv2 output is
+// (2 ST1 + 3) x 7.  ST1 = 2 is every shipped config and has the faster kernels in subconv.hip in front of this one;
+// ST1 = 1, 3, 4 run here at any dmodel that is a multiple of 16 (column tiles past D / 16 are computed on tile
+// D / 16 - 1 and dropped).
+template <int NBW, int ST1>
 __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv_split_kernel(SubConvArgs a, int D) {
+  constexpr int WR = 2 * ST1 + 3;
   const int KB = D / 16, NT = D / 16;
   const int lane = threadIdx.x & 63;
   const int g4 = (lane >> 4) * 4, c = lane & 15;
@@ -312,18 +317,21 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv_split_kernel(SubConv
   const int P = a.B * a.T2 * a.F2;
   if ((size_t)wid * 16 >= (size_t)P) return;
   const int pos = wid * 16 + c;
-  float win[7][7];
+  float win[WR][7];
   bool tv[3], fv[3];
+  int ct[NBW];                          // column tile of accumulator n (clamped: the surplus ones are not stored)
+#pragma unroll
+  for (int n = 0; n < NBW; ++n) ct[n] = min(c0 + n, NT - 1);
   {
     const int p = min(pos, P - 1);
     const int b = p / (a.T2 * a.F2);
     const int r = p % (a.T2 * a.F2);
     const int t2 = r / a.F2, f2 = r % a.F2;
-    const int tm0 = 4 * t2 - 2 * a.pt2 - a.pt1;
+    const int tm0 = 2 * ST1 * t2 - ST1 * a.pt2 - a.pt1;
     const int fm0 = 4 * f2 - 2 * a.pf2 - a.pf1;
     const float* __restrict__ mb = a.mel + (size_t)b * a.F * a.NM;
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < WR; ++i)
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         const int tm = tm0 + i, fm = fm0 + j;
@@ -338,11 +346,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv_split_kernel(SubConv
   }
   f32x4 acc[NBW];
 #pragma unroll
-  for (int n = 0; n < NBW; ++n) acc[n] = ldg4(a.b2 + 16 * (c0 + n) + g4);
+  for (int n = 0; n < NBW; ++n) acc[n] = ldg4(a.b2 + 16 * ct[n] + g4);
   const f32x4* __restrict__ w2 = reinterpret_cast<const f32x4*>(a.w2p) + lane;
   f32x4 wb[2][NBW];
 #pragma unroll
-  for (int n = 0; n < NBW; ++n) wb[0][n] = w2[(size_t)(0 * NT + c0 + n) * 64];
+  for (int n = 0; n < NBW; ++n) wb[0][n] = w2[(size_t)(0 * NT + ct[n]) * 64];
 #pragma unroll 1
   for (int cb = 0; cb < KB; ++cb) {
     f32x4 w1v[3][3];
@@ -357,14 +365,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv_split_kernel(SubConv
       const int kt = q / 3, kf = q % 3;
       const int kbn = (q + 1 < 9) ? cb * 9 + q + 1 : cbn * 9;
 #pragma unroll
-      for (int n = 0; n < NBW; ++n) wb[(q + 1) & 1][n] = w2[(size_t)(kbn * NT + c0 + n) * 64];
+      for (int n = 0; n < NBW; ++n) wb[(q + 1) & 1][n] = w2[(size_t)(kbn * NT + ct[n]) * 64];
       __builtin_amdgcn_sched_barrier(0);
       f32x4 v = b1v;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const float m = win[2 * kt + i][2 * kf + j];
+          const float m = win[ST1 * kt + i][2 * kf + j];
           v.x = __builtin_fmaf(m, w1v[i][j].x, v.x); v.y = __builtin_fmaf(m, w1v[i][j].y, v.y);
           v.z = __builtin_fmaf(m, w1v[i][j].z, v.z); v.w = __builtin_fmaf(m, w1v[i][j].w, v.w);
         }
@@ -382,6 +390,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv_split_kernel(SubConv
     float* orow = a.out + (size_t)pos * D;
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
+      if (c0 + n >= NT) break;
       f32x4 v = acc[n];
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       stg4(orow + 16 * (c0 + n) + g4, v);
@@ -389,18 +398,29 @@ __global__ __launch_bounds__(BLOCK_THREADS, 2) void subconv_split_kernel(SubConv
   }
 }
 
+template <int NBW, int ST1>
+static int launch_subconv_cols(int D, const SubConvArgs& a, hipStream_t s) {
+  const int P = a.B * a.T2 * a.F2;
+  const int tiles = (P + 15) / 16;
+  hipLaunchKernelGGL((subconv_split_kernel<NBW, ST1>), dim3((tiles + 3) / 4, (D / 16 + NBW - 1) / NBW), dim3(BLOCK_THREADS), 0, s, a, D);
+  return 0;
+}
+
 int launch_subconv(int D, const SubConvArgs& a, hipStream_t s) {
+  if (a.st1 != 2) {                                                 // reduction_factor 2 / 6 / 8: one general kernel
+    if (D % 16) return -1;
+    note_scheme(SCHEME_F32);
+    if (a.st1 == 1) return launch_subconv_cols<4, 1>(D, a, s);
+    if (a.st1 == 3) return launch_subconv_cols<4, 3>(D, a, s);
+    if (a.st1 == 4) return launch_subconv_cols<4, 4>(D, a, s);
+    return -1;
+  }
   // MI355ASR_SUBCONV_F32=1: the fp32-MFMA register-stream kernel instead of the split-operand one (both in subconv.hip)
   static const bool f32k = mi355_env("MI355ASR_SUBCONV_F32", 0) != 0;
   if (!f32k && launch_subconv_split(D, a, s) == 0) return 0;       // dmodel 144 / 256 / 512 with the split pack
   note_scheme(SCHEME_F32);
   if (D == 144) return launch_subconv144(a, s);
-  if (D % 128 == 0) {
-    const int P = a.B * a.T2 * a.F2;
-    const int tiles = (P + 15) / 16;
-    hipLaunchKernelGGL((subconv_split_kernel<8>), dim3((tiles + 3) / 4, D / 128), dim3(BLOCK_THREADS), 0, s, a, D);
-    return 0;
-  }
+  if (D % 128 == 0) return launch_subconv_cols<8, 2>(D, a, s);
   return -1;
 }
 

@@ -2087,7 +2087,28 @@ def test_constructor_rejects_what_no_kernel_covers(torch_cuda):
     with pytest.raises(_lib.Mi355AsrError, match="head_size"):
         ConformerEncoder(dmodel=144, num_blocks=1, head_size=18, num_heads=8)
     with pytest.raises(_lib.Mi355AsrError, match="reduction_factor"):
-        ConformerEncoder(dmodel=144, num_blocks=1, reduction_factor=8)
+        ConformerEncoder(dmodel=144, num_blocks=1, reduction_factor=3)     # conformer_blocks.py:75 asserts an even factor
+
+
+@pytest.mark.parametrize("rf,dm,H,hs,B,L", [(2, 144, 4, 36, 2, 8000), (6, 144, 4, 36, 3, 32000), (8, 144, 4, 36, 2, 48000), (2, 256, 4, 64, 1, 8000),
+                                            (8, 512, 8, 64, 2, 32000), (6, 144, 4, 36, 1, 16000 - 77)])
+def test_reduction_factors_other_than_4(torch_cuda, rf, dm, H, hs, B, L):
+    """conformer_blocks.py:76-80: conv1's time stride is reduction_factor // 2 (the frequency stride stays 2).  Factors 2, 6 and 8 (strides
+    1, 3, 4) run on subconv_split_kernel<4, ST1> (mel window 2 ST1 + 3 rows) -- every shipped config has 4 and the faster kernels.
+    Encoder (1 block) + CTC decoder against the oracle; the frame count follows ceil(ceil(F / st1) / 2)."""
+    from tensorflowasr_amd.models import ConformerCTC
+    cfg = dict(co.CONFORMER_S, dmodel=dm, num_heads=H, head_size=hs, num_blocks=1, reduction_factor=rf)
+    w = co.encoder_weights(cfg, seed=5)
+    w.update(co.ctc_decoder_weights(cfg, 70, seed=6))
+    m = ConformerCTC(70, dmodel=dm, num_blocks=1, head_size=hs, num_heads=H, reduction_factor=rf)
+    m.load_weights(w, by_name=False)
+    x = waves(B, L, 4)
+    enc = m.encode(x)
+    ref = co.conformer_encoder(x.astype(np.float64), w, cfg)
+    F = -(-L // 160)
+    assert ref.shape[1] == -(-(-(-F // (rf // 2))) // 2) and tuple(enc.shape) == ref.shape
+    assert maxdiff(enc.cpu().numpy(), ref) < TOL
+    assert maxdiff(m.ctc_logits(enc).cpu().numpy(), co.ctc_decoder(ref, w, cfg)) < TOL
 
 
 def test_translator_dmodel_512(torch_cuda):

@@ -51,7 +51,7 @@ def _create(**over):
     return lib, rc, p
 
 
-@pytest.mark.parametrize("bad", [dict(dmodel=100), dict(head_size=32), dict(head_size=18, num_heads=8), dict(kernel_size=0), dict(reduction_factor=2),
+@pytest.mark.parametrize("bad", [dict(dmodel=100), dict(head_size=32), dict(head_size=18, num_heads=8), dict(kernel_size=0), dict(reduction_factor=3), dict(reduction_factor=10),
                                  dict(n_dft=512), dict(n_mels=64), dict(num_heads=3), dict(gemm_dtype=2)])
 def test_create_rejects_unsupported_configs_with_message(bad):
     lib, rc, p = _create(**bad)
@@ -68,7 +68,8 @@ def test_create_accepts_the_three_reference_model_sizes():
     lib, rc, p = _create(dmodel=320, num_heads=5, head_size=64)
     assert rc == -1 and b"multiples of 128" in lib.mi355asr_last_error()
     # round 6: any kernel size and the head sizes the three dmodels factor into are accepted (general kernels, not an error)
-    for over in (dict(kernel_size=7), dict(kernel_size=16), dict(num_heads=3, head_size=48), dict(dmodel=256, num_heads=8, head_size=32)):
+    for over in (dict(kernel_size=7), dict(kernel_size=16), dict(num_heads=3, head_size=48), dict(dmodel=256, num_heads=8, head_size=32),
+                 dict(reduction_factor=2), dict(reduction_factor=6), dict(reduction_factor=8)):
         lib, rc, p = _create(**over)
         assert rc == 0 and p.value, (over, lib.mi355asr_last_error())
         lib.mi355asr_destroy(p)
