@@ -66,6 +66,9 @@ def _held_to_ceiling(err):
     if not cur.endswith(" (call)"):
         return
     tid = cur[:-len(" (call)")]
+    if "::" in tid:                     # the node id's path depends on pytest's rootdir: always "tests/<file>::<test>"
+        path, rest = tid.split("::", 1)
+        tid = "tests/%s::%s" % (os.path.basename(path), rest)
     n = _CALLS[tid] = _CALLS.get(tid, -1) + 1
     key = "%s#%d" % (tid, n)
     c = _ceilings().get(key)
