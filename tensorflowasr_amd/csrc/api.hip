@@ -1502,6 +1502,10 @@ int ctc_impl(mi355asr_model* m, const float* enc, int B, int T, const Plan& p, c
     hd.x = sc.xa; hd.ldx = d; hd.bias = m->fc_b; hd.y = logits; hd.ldy = m->cfg.num_classes;
     hd.M = M; hd.K = d; hd.NT = m->NT_fc; hd.n_valid = m->cfg.num_classes; hd.eps = kLnEps;
     hd.argmax_out = amax ? amax : (int32_t*)(ws + p.amax);
+    // the hidden buffer of the ff modules (M x 4 d floats, planned whenever gemm16_for(m, M)) is free here: per-range winners of a split head
+    hd.part_max = 8;
+    hd.part_v = sc.h4;
+    hd.part_i = reinterpret_cast<int32_t*>(sc.h4 + (size_t)hd.part_max * M);
     { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm16(m, E16_HEAD, false, hd, m->fc_wp, s), "ctc head"); }
     return 0;
   }

@@ -164,6 +164,7 @@ int mi355asr_translator_forward(mi355asr_model* m, const int32_t* ids, const flo
     Gemm16Args h16{};
     h16.x = sc.xa; h16.ldx = d; h16.bias = hd.bias; h16.y = logits; h16.ldy = hd.ldy; h16.M = M; h16.K = d; h16.NT = hd.NT;
     h16.n_valid = hd.n_valid; h16.eps = kLnEps; h16.argmax_out = hd.argmax_out;
+    h16.part_max = 8; h16.part_v = (float*)(ws + p.hsplit); h16.part_i = reinterpret_cast<int32_t*>(h16.part_v + (size_t)8 * M);
     { PROF(MI355ASR_K_CTC_HEAD); LAUNCH_TRY(launch_gemm16(m, E16_HEAD, false, h16, m->t_stack.fc_wp, s), "translator head"); }
     return 0;
   }

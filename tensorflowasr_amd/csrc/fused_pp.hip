@@ -1148,6 +1148,10 @@ int launch_pp_head_split(const GemmArgs& a, const float* pp, float pp_sw, int gr
   if (want_max) hipLaunchKernelGGL(head_combine_kernel, dim3((a.M + 255) / 256), dim3(256), 0, s, pv, pi, nr, a.M, a.argmax_out, a.maxval_out);
   return 0;
 }
+int launch_head_combine(const float* part_v, const int32_t* part_i, int ranges, int M, int32_t* argmax_out, float* maxval_out, hipStream_t s) {
+  hipLaunchKernelGGL(head_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part_v, part_i, ranges, M, argmax_out, maxval_out);
+  return 0;
+}
 bool pp_sublinear_ok(const StreamGemmArgs& a, const float* pp) {
   // MI355ASR_PP_SUBLINEAR=0: the three-term sublinear_split_ld_kernel (fused.hip)
   static const bool on = mi355_env("MI355ASR_PP_SUBLINEAR", 1) != 0;

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
   // this workgroup's column chunks chunk0 .. chunk0 + cpw - 1, one after the other on the same rows: their slabs are
   // one contiguous stream (the ring keeps running across the chunk boundary) and the prologue is paid once
   const int chunk0 = blockIdx.y * cpw;
-  const int steps = a.K / 32, total = cpw * steps;
+  // (the class head split over ranges of chunks: the last range may hold fewer)
+  const int ncc = (EPI == E16_HEAD && a.head_chunks > 0) ? min(cpw, a.head_chunks - chunk0) : cpw;
+  const int steps = a.K / 32, total = ncc * steps;
   const u32x4* __restrict__ wg = wring + (size_t)chunk0 * steps * GSLAB;
   constexpr int NQ = (GSLAB + GT - 1) / GT;       // DMA instructions per wave and slab: 3, or 1 in bf16 mode
   // EDMA: only the lower four waves (the ones that split before their MFMAs) issue slab DMAs, twice as many each: an
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
       xload(XST, xq[0]);
     }
 #pragma unroll 1
-    for (int cc = 0; cc < cpw; ++cc) {
+    for (int cc = 0; cc < ncc; ++cc) {
       const int g0 = cc * steps;
 #pragma unroll 1
       for (int s = 0; s < steps; s += GUNR) {
@@ -471,7 +473,14 @@ __global__ __launch_bounds__(GT, 2) void gemm_ring_kernel(Gemm16Args a, const u3
           const int oi = __shfl_xor(bi, off);
           if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        if (live[rt] && lane < 16) a.argmax_out[tok[rt]] = bi;
+        if (live[rt] && lane < 16) {
+          if (gridDim.y > 1) {                      // this range's winner; launch_head_combine takes the best of the ranges
+            a.part_v[(size_t)blockIdx.y * a.M + tok[rt]] = bv;
+            a.part_i[(size_t)blockIdx.y * a.M + tok[rt]] = bi;
+          } else {
+            a.argmax_out[tok[rt]] = bi;
+          }
+        }
       }
     }
   }
@@ -532,8 +541,38 @@ int go(const Gemm16Args& a, const void* ring, hipStream_t s) {
       if (cost < best * 0.999) { best = cost; best_rt = rt; best_cpw = cpw; }
     }
   }
-  const int cpw = best_cpw;
-  const dim3 grid((a.M + 128 * best_rt - 1) / (128 * best_rt), chunks / cpw);
+  int cpw = best_cpw;
+  dim3 grid((a.M + 128 * best_rt - 1) / (128 * best_rt), chunks / cpw);
+  if constexpr (EPI == E16_HEAD) {
+    // Round 6: the rows alone are 130 workgroups at 16 640 rows (125 at 16 000) -- with scratch for the per-range winners the
+    // chunks of a row tile go to several workgroups.  Same cost model; a CU takes two workgroups of the bf16-mode kernel (32 KB
+    // ring), one of the three-term kernel.  MI355ASR_RING_HEAD_RANGES=n forces n ranges (1: the single-workgroup head).
+    static const int force_nr = (int)mi355_env("MI355ASR_RING_HEAD_RANGES", 0);
+    if (a.argmax_out && a.part_v && a.part_i && a.part_max > 1 && chunks > 1) {
+      const long cap = 256L * (TERMS == 1 ? 2 : 1);
+      int best_nr = 1;
+      double best_c = 1e30;
+      for (int nr = 1; nr <= std::min(chunks, a.part_max); ++nr) {
+        const int c = (chunks + nr - 1) / nr;
+        if ((chunks + c - 1) / c != nr) continue;                // (this many ranges do not come out with whole chunks)
+        if (force_nr && nr != std::min(force_nr, std::min(chunks, a.part_max))) continue;
+        const long rounds = ((long)grid.x * nr + cap - 1) / cap;
+        const double cost = (double)rounds * (6.0 + (double)c * (a.K / 32) + 1.5 * c) + (nr > 1 ? 3.0 : 0.0);
+        if (cost < best_c * 0.999) { best_c = cost; best_nr = nr; }
+      }
+      if (best_nr > 1) {
+        Gemm16Args b = a;
+        b.head_chunks = chunks;
+        cpw = (chunks + best_nr - 1) / best_nr;
+        grid.y = best_nr;
+        if (force_slots == 2 || (force_slots != 4 && (long)grid.x * grid.y > 320))
+          hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 2, TERMS, EDMA>), grid, dim3(GT), 0, s, b, (const u32x4*)ring, cpw);
+        else
+          hipLaunchKernelGGL((gemm_ring_kernel<EPI, LN, 1, 4, TERMS, EDMA>), grid, dim3(GT), 0, s, b, (const u32x4*)ring, cpw);
+        return launch_head_combine(a.part_v, a.part_i, best_nr, a.M, a.argmax_out, nullptr, s);
+      }
+    }
+  }
 
   if (best_rt == 2 && force_slots != 2) {
     if constexpr (EPI != E16_HEAD)

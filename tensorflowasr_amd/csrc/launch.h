@@ -265,7 +265,14 @@ struct Gemm16Args {
   // x + (r / rpb) * bstride + (r % rpb) * ldx when rpb > 0
   int rpb = 0;
   long long bstride = 0;
+  // E16_HEAD on the ring kernel (round 6): with scratch for [ranges][M] (maximum, class) pairs the class chunks of a row tile are
+  // split over up to part_max workgroups (rows alone: 16 640 / 128 = 130 workgroups on 256 CUs), launch_head_combine picks the winner
+  float* part_v = nullptr;
+  int32_t* part_i = nullptr;
+  int part_max = 0;
+  int head_chunks = 0;  // (set by the launcher: all chunks of the head, the last range may hold fewer than cpw)
 };
+int launch_head_combine(const float* part_v, const int32_t* part_i, int ranges, int M, int32_t* argmax_out, float* maxval_out, hipStream_t s);   // fused_pp.hip
 int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s);
 int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s);   // bf16.hip: dmodel 256, bf16 mode, FFModule / conv tail in one launch
 int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s);   // wp = fp32 P16 weights

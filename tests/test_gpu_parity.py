@@ -1900,6 +1900,54 @@ print("RESULT %.3e %.3e %.3e" % (e.max(), e.mean(), np.abs(got - exact).max()))
         assert emax < 6e-3 and emean < 3e-4 and vs_exact > 10 * emean, (extra, emax, emean, vs_exact)
 
 
+def test_ring_class_head_split_over_class_ranges(torch_cuda):
+    """Round 6: the class head of dmodel 256 / 512 (gemm_ring_kernel<E16_HEAD>) needs every class of a row for its arg-max and ran as
+    ceil(M / 128) workgroups -- 130 on 256 CUs at config 3's 16 640 rows.  With scratch for per-range (maximum, class) pairs the
+    launcher gives a row tile's 128-class chunks to several workgroups and launch_head_combine takes the best range (lowest class on
+    equal maxima, as within a range).  CTCDecoder (1 block, dmodel 256, 1332 classes = 11 chunks) over 64 x 260 rows in bf16 mode and
+    in the three-term fp32 mode: arg-max and logits with 2 / 3 / 4 ranges and the launcher's own choice bit-identical to one range,
+    with and without the logits written; duplicated class columns (ties across ranges) resolve to the lower class."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from helpers import co
+from tensorflowasr_amd.models import CTCDecoder
+mode, out = sys.argv[1], sys.argv[2]
+cfg = dict(co.STREAMING_S)
+V = 1332
+w = co.ctc_decoder_weights(cfg, V, seed=54)
+k = w["fully_connected/kernel"]
+k[:, 1200] = k[:, 7]; w["fully_connected/bias"][1200] = w["fully_connected/bias"][7]          # a tie between chunks 0 and 9
+ctc = CTCDecoder(num_classes=V, dmodel=256, num_blocks=1, head_size=64, num_heads=4, kernel_size=32, fc_factor=0.5,
+                 **({"gemm_dtype": "bfloat16"} if mode == "bf16" else {}))
+ctc.load_weights(w, by_name=False)
+h = torch.from_numpy(np.random.default_rng(3).standard_normal((64, 260, 256)).astype(np.float32)).cuda()
+lg, am = ctc(h, return_argmax=True)
+_, am2 = ctc(h, return_argmax=True, return_logits=False)
+lgn = lg.cpu().numpy()
+np.savez(out, logits=lgn[::7], amax=am.cpu().numpy(), amax_nolog=am2.cpu().numpy(), amax_of_logits=co.frame_argmax(lgn))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("bf16", "f32"):
+            res = {}
+            for nr in ("1", "2", "3", "4", ""):
+                env = dict(os.environ, **({"MI355ASR_RING_HEAD_RANGES": nr} if nr else {}))
+                f = os.path.join(td, "%s_%s.npz" % (mode, nr or "auto"))
+                r = subprocess.run([sys.executable, "-c", code, mode, f], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+                assert r.returncode == 0, r.stderr[-3000:]
+                res[nr] = np.load(f)
+            one = res["1"]
+            assert np.array_equal(one["amax"], one["amax_of_logits"])
+            assert (one["amax"] == 7).any() and not (one["amax"] == 1200).any()          # the duplicated column never wins over its lower twin
+            for nr, r in res.items():
+                assert np.array_equal(r["amax"], one["amax"]) and np.array_equal(r["amax_nolog"], one["amax"]), (mode, nr)
+                assert np.array_equal(r["logits"], one["logits"]), (mode, nr)
+
+
 def test_streaming_block_stack_in_one_launch_vs_layer_at_a_time_and_rounding_oracle(torch_cuda):
     """Round 5 (stream256.hip): in bf16 mode the streaming encoder's whole block stack -- 4 ConformerBlocks, dmodel 256, chunks of
     13 rows -- is ONE launch, one workgroup per chunk (weights streamed from L2, the residual rows in registers, attention and
