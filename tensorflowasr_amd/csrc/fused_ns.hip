@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NW * 64) void ns1_ff1_qkv_kernel(Ff1QkvArgs a) {
 // Head by head: all eight waves stage the head's K / V fragments (the next head's rows are already in registers), wave w takes key
 // tiles 2 w, 2 w + 1 = step w of P V for the 16 queries, and the eight partial (max, sum, output) triples are combined through LDS
 // into the tile's context rows.  A separate attention launch costs 16 us for one utterance (4 workgroups, ~11 us of launch floor).
-constexpr int A_HS = 36, A_KT = 16, A_OT = 3;
+constexpr int A_HS = 36, A_OT = 3;
 struct Ns1AttnLds {
   float pm[2][8][16], pl[2][8][16]; // partial maxima / sums of the eight waves, per query, for two heads
   f32x4 po[2][8][A_OT][64];         // partial outputs (48 KB)

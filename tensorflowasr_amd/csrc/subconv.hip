@@ -300,7 +300,7 @@ DEV SplitFrag split8h(f32x4 lo, f32x4 hi) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     d0[k] = pk_f16(v[2 * k], v[2 * k + 1]);
-    const f16x2 h = __builtin_bit_cast(f16x2, d0[k]);
+    [[maybe_unused]] const f16x2 h = __builtin_bit_cast(f16x2, d0[k]);
 #if MI355ASR_CONV1_PK
     // lo = fp16(v - hi) as v_fma_mixlo / mixhi_f16: the fp16 hi is read in place (op_sel picks the half), v - hi is formed in
     // fp32 (exact) and rounded once into the destination half -- the same value as v_cvt_f32_f16 + v_sub_f32 + v_cvt_pk_f16_f32,
@@ -749,7 +749,6 @@ __global__ __launch_bounds__(SCT, 2) void subconv_split_ring_kernel(SubConvArgs 
     else frags_ninth<DIAG, TM>(dst, melp, RS, sl, w1r, p_b1, g4, cbA, KB, load_taps);
   };
   using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
   // interleaved mode: the operand of a tap-pair step in pieces, called behind fragment group GI of the previous step's MFMAs.  By
   // the time piece GI + 1 runs, the counted lgkmcnt wait in front of group GI + 1 has covered the window reads piece GI issued
   // (LDS returns in order and they are older than the fragment reads that wait leaves outstanding).
