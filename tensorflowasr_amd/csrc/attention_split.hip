@@ -276,156 +276,6 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(AttnArgs a) {
 }
 
 
-// ---- two workgroups per CU (round 6, MI355ASR_ATTN_PAIR=1) ---------------------------------------------------------------------------------
-// attention_split_kernel is one 16-wave workgroup per CU that stages, multiplies, exponentiates, multiplies and stores with nothing beside
-// it: 10.8 of its ~21 us remain with all arithmetic removed (profiles/r03_pp_experiments.md section 5).  This variant halves the workgroup
-// -- 8 waves, 128 queries, the K / V fragments of its (utterance, head) staged by both halves -- and trims the fragments to 72 KB (the
-// third feature tile of V^T holds features 32..35 only: 16 of its 64 lanes are stored, the others read zeros), so that TWO workgroups
-// of different (utterance, head) share a CU and one's latency phases face the other's products.  Two-term operands only.
-constexpr int PW = 8, PTH = PW * 64;
-__global__ __launch_bounds__(PTH, 2) void attention_split_pair_kernel(AttnArgs a) {
-  constexpr int TM = 2;
-  __shared__ __attribute__((aligned(16))) u32x4_t Kf[TM][NKT][64];        // 32 KB
-  __shared__ __attribute__((aligned(16))) float Kt[NKT][64];               //  4 KB
-  __shared__ __attribute__((aligned(16))) u32x4_t Vf[TM][NST][2][64];      // 32 KB  feature tiles 0, 1
-  __shared__ __attribute__((aligned(16))) u32x4_t Vc[TM][NST][16];         //  4 KB  feature tile 2: lanes (kg, fc < 4) only
-  const float sq = a.h2_sq, sk = a.h2_sk, sv = a.h2_sv;
-  constexpr float SP = 16384.f;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int g = lane >> 4, g4 = g * 4, c = lane & 15;
-  const int T = a.Tk, TQ = a.Tq;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int ld = a.ldk, D = a.D;
-  const size_t khead = a.head_major ? ((size_t)b * a.H + h) * T * HS : (size_t)b * T * ld + h * HS;
-  const float* __restrict__ kbase = a.k + khead;
-  const float* __restrict__ vbase = a.v + khead;
-  const int qt = blockIdx.x * PW + wv;
-  const int tq = qt * 16 + c;
-  const float* qrow = a.head_major ? a.q + (((size_t)b * a.H + h) * TQ + min(tq, TQ - 1)) * HS
-                                   : a.q + ((size_t)b * TQ + min(tq, TQ - 1)) * a.ldq + h * HS;
-  constexpr float LOG2E = 1.4426950408889634f;
-  const f32x4 qlo = ldg4(qrow + 8 * g), qhi = ldg4(qrow + 8 * g + 4);
-  const float qtl = qrow[32 + g] * (LOG2E * sq);
-  // ---- K: two fragments per thread (tiles wv and wv + 8)
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int kt = wv + PW * r, skey = 16 * kt + c;
-    const float* krow = kbase + (size_t)min(skey, T - 1) * ld;
-    f32x4 klo = ldg4(krow + 8 * g), khi = ldg4(krow + 8 * g + 4);
-    float ktl = krow[32 + g];
-    if (skey >= T) { klo = splat4(0.f); khi = splat4(0.f); ktl = 0.f; }
-    const Split8 kf = split_tm<TM>(klo * splat4(sk), khi * splat4(sk));
-    Kf[0][kt][lane] = kf.t[0];
-    Kf[1][kt][lane] = kf.t[1];
-    Kt[kt][lane] = ktl * sk;
-  }
-  __syncthreads();
-  const bool active = qt * 16 < TQ;
-  const int nkt = (T + 15) / 16;
-  const Split8 qf = split_tm<TM>(qlo * splat4(LOG2E * sq), qhi * splat4(LOG2E * sq));
-  const f32x4 inv_qk = splat4(1.0f / (sq * sk));
-  f32x4 sc[NKT];
-  if (active) {
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt < nkt) {
-        const u32x4_t kf[3] = {Kf[0][kt][lane], Kf[1][kt][lane], Kf[1][kt][lane]};
-        const f32x4 acc = mma_tm<TM>(kf, qf, splat4(0.f));
-        sc[kt] = mfma4(Kt[kt][lane], qtl, acc) * inv_qk;
-      } else {
-        sc[kt] = splat4(-INFINITY);
-      }
-    }
-  }
-  // ---- V: entries (step s, feature tile 0 / 1, lane) = 1024, two per thread; the compact third tile: 128 entries
-  {
-    auto gather = [&](int s, int f, int kg, float (&ve)[8]) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int key = 32 * s + 16 * (j >> 2) + 4 * kg + (j & 3);
-        ve[j] = key < T ? vbase[(size_t)key * ld + f] : 0.f;
-      }
-    };
-    float ve[3][8];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int en = tid + it * PTH;
-      const int s = en >> 7, rem = en & 127, ot = rem >> 6, l = rem & 63;
-      gather(s, 16 * ot + (l & 15), l >> 4, ve[it]);
-    }
-    if (tid < NST * 16) gather(tid >> 4, 32 + (tid & 3), (tid >> 2) & 3, ve[2]);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int en = tid + it * PTH;
-      const f32x4 lo = {ve[it][0], ve[it][1], ve[it][2], ve[it][3]}, hi = {ve[it][4], ve[it][5], ve[it][6], ve[it][7]};
-      const Split8 vf = split_tm<TM>(lo * splat4(sv), hi * splat4(sv));
-      u32x4_t* dst = &Vf[0][0][0][0] + en;                       // [t][s][ot][lane]: en = (s * 2 + ot) * 64 + lane
-      dst[0] = vf.t[0];
-      dst[NST * 2 * 64] = vf.t[1];
-    }
-    if (tid < NST * 16) {
-      const f32x4 lo = {ve[2][0], ve[2][1], ve[2][2], ve[2][3]}, hi = {ve[2][4], ve[2][5], ve[2][6], ve[2][7]};
-      const Split8 vf = split_tm<TM>(lo * splat4(sv), hi * splat4(sv));
-      u32x4_t* dst = &Vc[0][0][0] + tid;                         // [t][s][kg * 4 + fc]
-      dst[0] = vf.t[0];
-      dst[NST * 16] = vf.t[1];
-    }
-  }
-  if (!active) { __syncthreads(); return; }
-  float mx = -INFINITY;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    if (kt < nkt && 16 * kt + 16 > T) {
-      const int kb = 16 * kt + g4;
-      sc[kt].x = (kb + 0 < T) ? sc[kt].x : -INFINITY;
-      sc[kt].y = (kb + 1 < T) ? sc[kt].y : -INFINITY;
-      sc[kt].z = (kb + 2 < T) ? sc[kt].z : -INFINITY;
-      sc[kt].w = (kb + 3 < T) ? sc[kt].w : -INFINITY;
-    }
-    mx = fmaxf(mx, fmaxf(fmaxf(sc[kt].x, sc[kt].y), fmaxf(sc[kt].z, sc[kt].w)));
-  }
-  mx = group_max(mx);
-  float psum = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    sc[kt].x = __builtin_amdgcn_exp2f(sc[kt].x - mx);
-    sc[kt].y = __builtin_amdgcn_exp2f(sc[kt].y - mx);
-    sc[kt].z = __builtin_amdgcn_exp2f(sc[kt].z - mx);
-    sc[kt].w = __builtin_amdgcn_exp2f(sc[kt].w - mx);
-    psum += (sc[kt].x + sc[kt].y) + (sc[kt].z + sc[kt].w);
-  }
-  __syncthreads();
-  f32x4 o[OT];
-#pragma unroll
-  for (int i = 0; i < OT; ++i) o[i] = splat4(0.f);
-  const int nst = (nkt + 1) / 2;
-  const bool tail_lane = c < 4;                       // lanes (kg = g, fc = c < 4) of the third tile hold features 32..35
-  const int cl = g * 4 + (c & 3);
-#pragma unroll
-  for (int s = 0; s < NST; ++s) {
-    if (s < nst) {
-      const Split8 pf = split_tm<TM>(sc[2 * s] * splat4(SP), sc[2 * s + 1] * splat4(SP));
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const u32x4_t vf[3] = {Vf[0][s][i][lane], Vf[1][s][i][lane], Vf[1][s][i][lane]};
-        o[i] = mma_tm<TM>(vf, pf, o[i]);
-      }
-      u32x4_t t0 = Vc[0][s][cl], t1 = Vc[1][s][cl];
-      if (!tail_lane) { t0 = u32x4_t{0u, 0u, 0u, 0u}; t1 = t0; }
-      const u32x4_t vf2[3] = {t0, t1, t1};
-      o[2] = mma_tm<TM>(vf2, pf, o[2]);
-    }
-  }
-  const float inv = (1.0f / group_sum(psum)) * (1.0f / (SP * sv));
-  if (tq < TQ) {
-    float* orow = a.ctx + ((size_t)b * TQ + tq) * D + h * HS;
-#pragma unroll
-    for (int i = 0; i < OT; ++i) {
-      if (16 * i + g4 < HS) stg4(orow + 16 * i + g4, o[i] * splat4(inv));
-    }
-  }
-}
-
 // ---- more than 256 keys (round 6) ------------------------------------------------------------------------------------------------------
 // multihead_attention.py:151-188 has no length limit; utterances beyond 10.24 s used to fall to the fp32-MFMA kernels (35 us per
 // launch already at 250 frames).  A workgroup of 16 or 8 waves = 256 / 128 queries of one (utterance, head) walks the keys in
@@ -662,11 +512,9 @@ int launch_attention_split(int hs, const AttnArgs& a, hipStream_t s) {
     }
     return 0;
   }
-  // MI355ASR_ATTN_PAIR=1: 8-wave workgroups of 128 queries, two per CU (attention_split_pair_kernel)
-  static const bool pair = mi355_env("MI355ASR_ATTN_PAIR", 0) != 0;
-  if (two && pair)
-    hipLaunchKernelGGL(attention_split_pair_kernel, dim3((qtiles + PW - 1) / PW, a.H, a.B), dim3(PTH), 0, s, a);
-  else if (two)
+  // (Round 6 measured two 8-wave workgroups per CU -- 128 queries each, the fragments trimmed to 72 KB, 110 VGPRs, bit-identical --
+  // against this one 16-wave workgroup: 20.7 us both, profiles/r06_attention_pair_ab.jsonl; the kernel is in commit 33c4385.)
+  if (two)
     hipLaunchKernelGGL(attention_split_kernel<2>, grid, dim3(ATH), 0, s, a);
   else
     hipLaunchKernelGGL(attention_split_kernel<3>, grid, dim3(ATH), 0, s, a);
