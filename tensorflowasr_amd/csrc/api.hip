@@ -476,7 +476,7 @@ int try_head_ld(const mi355asr_model* m, const GemmArgs& hd, hipStream_t s, floa
   if (hd.M < 2048) return -1;
   // few rows and many classes (the Translator's 144 -> 9160 over ~6 000 rows is 93 row workgroups): the column groups split over
   // several workgroups per row tile, the per-range arg-max pairs combined by a second small launch (split_scratch: 16 M words)
-  if (split_scratch && launch_pp_head_split(hd, it->second.pp, it->second.pp_sw, it->second.groups, pp_head_ranges(hd.M, it->second.groups), split_scratch, s) == 0) return 0;
+  if ((split_scratch || (!hd.argmax_out && !hd.maxval_out)) && launch_pp_head_split(hd, it->second.pp, it->second.pp_sw, it->second.groups, pp_head_ranges(hd.M, it->second.groups), split_scratch, s) == 0) return 0;
   if (launch_pp_head(hd, it->second.pp, it->second.pp_sw, it->second.groups, s) == 0) return 0;
   return launch_head_ld(hd, it->second.slabs, it->second.groups, s);
 }

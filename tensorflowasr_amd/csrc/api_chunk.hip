@@ -130,7 +130,8 @@ int run_stack(const mi355asr_model* m, const StackDev& st, const float* in, int 
     hd.argmax_out = amax;
     {
       PROF(MI355ASR_K_CTC_HEAD);
-      if (try_head_ld(m, hd, s) != 0) LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "fully_connected");
+      // (the q / k / v buffer is dead behind the last block: the per-range arg-max pairs of a head split over class ranges)
+      if (try_head_ld(m, hd, s, sc.qkv) != 0) LAUNCH_TRY(launch_gemm_rows(d, EPI_HEAD, false, hd, s), "fully_connected");
     }
   }
   return 0;
@@ -542,7 +543,8 @@ int mi355asr_chunk_predict(mi355asr_model* m, const float* wav, int32_t B, int32
   rc = run_stack(m, m->c_helper, sc.xa, B, Tp, sc, nullptr, nullptr, s);
   if (rc) return rc;
   if (outs->helper_out) HIP_TRY(hipMemcpyAsync(outs->helper_out, sc.xa, actp, hipMemcpyDeviceToDevice, s));
-  rc = run_stack(m, m->c_decoder, sc.xa, B, Tp, sc, outs->text_logits, outs->text_argmax ? outs->text_argmax : amax, s);
+  // (no arg-max unless asked for: the text logits go to top-n / the beam search, and a head without it needs no combine launch)
+  rc = run_stack(m, m->c_decoder, sc.xa, B, Tp, sc, outs->text_logits, outs->text_logits ? outs->text_argmax : (outs->text_argmax ? outs->text_argmax : amax), s);
   return rc;
 }
 

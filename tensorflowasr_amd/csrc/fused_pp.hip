@@ -1131,17 +1131,33 @@ int launch_pp_head(const GemmArgs& a, const float* pp, float pp_sw, int groups, 
 int pp_head_ranges(int M, int groups) {
   static const int ncu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
   const int wgs = (M + 63) / 64;
-  return wgs < 1 ? 1 : max(1, min(min(ncu / wgs, groups / 4), 8));          // at least four groups per range
+  if (wgs < 1) return 1;
+  // rounds over the chip x (groups a workgroup walks + its prologue, ~one group's worth): 5 952 rows x 64 groups = 93 workgroups:
+  // 8 ranges (3 rounds of 8 groups) beat 2 (one round of 32); 12 000 rows = 188 workgroups: 4 ranges (3 rounds of 16) beat 1 (64).
+  // At least four groups per range, at most 8 ranges (the scratch of the callers); MI355ASR_PP_HEAD_RANGES=n forces n.
+  static const int force = (int)mi355_env("MI355ASR_PP_HEAD_RANGES", 0);
+  int best = 1;
+  double best_c = 1e30;
+  for (int nr = 1; nr <= 8; ++nr) {
+    const int gper = (groups + nr - 1) / nr;
+    if (nr > 1 && gper < 4) break;
+    if ((groups + gper - 1) / gper != nr) continue;
+    if (force && nr != force) continue;
+    const double c = (double)(((long)wgs * nr + ncu - 1) / ncu) * (gper + 1.0) + (nr > 1 ? 0.5 : 0.0);
+    if (c < best_c * 0.97) { best_c = c; best = nr; }
+  }
+  return best;
 }
 int launch_pp_head_split(const GemmArgs& a, const float* pp, float pp_sw, int groups, int ranges, float* scratch, hipStream_t s) {
-  if (ranges <= 1 || !scratch) return launch_pp_head(a, pp, pp_sw, groups, s);
+  const bool wants = a.argmax_out != nullptr || a.maxval_out != nullptr;
+  if (ranges <= 1 || (wants && !scratch)) return launch_pp_head(a, pp, pp_sw, groups, s);   // (logits only: the ranges need no combine)
   static const bool on = mi355_env("MI355ASR_PP_HEAD", 1) != 0;
   static const bool ring_on = mi355_env("MI355ASR_HEAD_RING", 1) != 0;
   if (!on || !ring_on || !pp_enabled() || !pp || groups < 1 || a.n_valid > 144 * groups || a.M <= 0) return -1;
   const int gper = (groups + ranges - 1) / ranges, nr = (groups + gper - 1) / gper;
   const int tiles = (a.M + 15) / 16;
   note_scheme(SCHEME_F16X2);
-  const bool want_max = a.argmax_out != nullptr || a.maxval_out != nullptr;
+  const bool want_max = wants;
   float* pv = want_max ? scratch : nullptr;
   int32_t* pi = want_max ? reinterpret_cast<int32_t*>(scratch + (size_t)nr * a.M) : nullptr;
   hipLaunchKernelGGL(pp_head_kernel, dim3((tiles + 3) / 4, nr), dim3(LD_THREADS), 0, s, a, reinterpret_cast<const u32x4_t*>(pp), pp_sw, groups, gper, pv, pi);

@@ -1037,6 +1037,7 @@ SWITCHES = {
     "MI355ASR_RING_RT": "forces the ring GEMM's row tiles per wave (tests) | ring tests",
     "MI355ASR_RING_SLOTS": "forces the ring depth (tests) | ring tests",
     "MI355ASR_RING_CPW": "forces column chunks per workgroup (tests) | ring tests",
+    "MI355ASR_PP_HEAD_RANGES": "forces the number of class ranges of the two-term class head (1: one workgroup per row tile) | head tests",
     "MI355ASR_RING_HEAD_RANGES": "forces the number of class ranges of the ring class head (1: one workgroup per row tile) | ring tests",
     "MI355ASR_TOPN_REG": "0: LDS top-n kernel instead of the register-resident one | test_prefix_beam_topn_*",
     "MI355ASR_BEAM_DEVICE": "0: prefix search on host threads | test_prefix_beam_device_path_matches_reference_kats",
