@@ -621,10 +621,19 @@ int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s) {
   const int tiles = (a.M + 15) / 16;
   const dim3 block(C_NW * 64);
   // more row tiles per workgroup as soon as every CU has a workgroup anyway: a half / a quarter of the weight traffic per row
-  // (MI355ASR_CHAIN256_RT = 1 / 2 / 4 forces one)
+  // (MI355ASR_CHAIN256_RT = 1 / 2 / 4 / 5 forces one)
   static const int rt_env = (int)mi355_env("MI355ASR_CHAIN256_RT", 0);
-  const int rt = rt_env ? rt_env : (tiles >= 1024 ? 4 : (tiles >= 512 ? 2 : 1));
-  if (rt == 4) {
+  int rt = rt_env ? rt_env : (tiles >= 1024 ? 4 : (tiles >= 512 ? 2 : 1));
+  // One workgroup per CU (100 KB of LDS at RT = 4), and a workgroup's time is mostly its weight stream: 1 040 tiles (config 3's
+  // 64 x 260 rows) are 260 workgroups of four tiles = TWO rounds over 256 CUs, the second with four workgroups.  Five tiles per
+  // workgroup (208 workgroups) when that saves a round.
+  static const int ncu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+  if (!rt_env && rt == 4 && ((tiles + 3) / 4 + ncu - 1) / ncu > ((tiles + 4) / 5 + ncu - 1) / ncu) rt = 5;
+  if (rt == 5) {
+    const dim3 grid((tiles + 4) / 5);
+    if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 5, 2, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 5, 2, 2>), grid, block, 0, s, a);
+  } else if (rt == 4) {
     const dim3 grid((tiles + 3) / 4);
     if (mode == 0) hipLaunchKernelGGL((chain256_bf16_kernel<64, 0, 4, 4, 2>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 4, 4, 2>), grid, block, 0, s, a);

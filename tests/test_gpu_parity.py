@@ -1660,8 +1660,8 @@ def test_bf16_chain256_against_layer_at_a_time(torch_cuda):
     operands (both GEMMs' inputs rounded to nearest-even bf16), same fp32 accumulation order along K; only the trailing
     LayerNorm sums its row in a different order and the first GEMM walks K in one piece -- so a block's output must agree with
     MI355ASR_CHAIN256=0 up to the rare bf16 flips of hidden values whose fp32 sums differ in the last bit, at row counts that
-    take one row tile per workgroup (45, 832 rows) and two (8 208 rows = 513 tiles: an odd tile count, and 8 195 rows: a
-    partial last tile), and stay within the rounding oracle's tolerance."""
+    take one row tile per workgroup (45, 832 rows), two (8 208 rows = 513 tiles: an odd tile count, and 8 195 rows: a
+    partial last tile) and five (round 6: 16 640 rows), and stay within the rounding oracle's tolerance."""
     import subprocess
     import sys
     import tempfile
@@ -1676,7 +1676,7 @@ w.update(co.ctc_decoder_weights(cfg, 100, seed=6))
 m = ConformerCTC(100, gemm_dtype="bfloat16", **{k: v for k, v in encoder_kwargs(cfg).items() if k != "mel_layer_type"})
 m.load_weights(w, by_name=False)
 out = {}
-for B, T in ((1, 45), (64, 13), (27, 304), (5, 1639)):
+for B, T in ((1, 45), (64, 13), (27, 304), (5, 1639), (64, 260)):
     x = np.random.default_rng(B * T).standard_normal((B, T, cfg["dmodel"])).astype(np.float32)
     out["blk_%d_%d" % (B, T)] = m.conformer_block(0, x).cpu().numpy()
 np.savez(sys.argv[1], **out)
@@ -1684,7 +1684,8 @@ np.savez(sys.argv[1], **out)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for tag, extra in (("chain", {}), ("layers", {"MI355ASR_CHAIN256": "0"}), ("rt1", {"MI355ASR_CHAIN256_RT": "1"}), ("rt4", {"MI355ASR_CHAIN256_RT": "4"})):
+        for tag, extra in (("chain", {}), ("layers", {"MI355ASR_CHAIN256": "0"}), ("rt1", {"MI355ASR_CHAIN256_RT": "1"}), ("rt4", {"MI355ASR_CHAIN256_RT": "4"}),
+                           ("rt5", {"MI355ASR_CHAIN256_RT": "5"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900, cwd=root)
             assert r.returncode == 0, r.stderr[-3000:]
@@ -1698,9 +1699,11 @@ np.savez(sys.argv[1], **out)
         # (gemm16 splits K over four waves, the ring kernels walk it in 32-wide steps: other summation orders): one bf16 ulp of
         # a hidden value each, measured mean 3e-5 -- a tenth of the distance either has from the rounding oracle
         assert d.mean() < 1e-4 and d.max() < 6e-3, k
-    # one, two or four row tiles per workgroup (four: the hidden dimension in two phases): the same summation orders, bit for bit
+    # one, two, four or five row tiles per workgroup (four: the hidden dimension in two phases, five: in four -- what 64 x 260 rows
+    # take by default, 1 040 tiles being 260 workgroups of four = a second round over 256 CUs): the same summation orders, bit for bit
     for k in res["chain"]:
         assert np.array_equal(res["chain"][k], res["rt1"][k]) and np.array_equal(res["chain"][k], res["rt4"][k]), k
+        assert np.array_equal(res["chain"][k], res["rt5"][k]), k
     cfg = small_cfg(1, co.STREAMING_S)
     w = co.encoder_weights(cfg, seed=5)
     x = np.random.default_rng(45).standard_normal((1, 45, cfg["dmodel"])).astype(np.float32)

@@ -1023,7 +1023,7 @@ SWITCHES = {
     "MI355ASR_NS1_MAX_M": "n: dmodel 144: blocks of up to n rows (default 4096; 0: never) on the one-tile-per-workgroup kernels of fused_ns.hip (small batches: eight waves share a 16-token tile) instead of the pair-pipelined ones | test_small_batches_one_tile_per_workgroup_against_the_pair_pipelined_kernels_and_the_oracle",
     "MI355ASR_NS1_ATTN": "0: the attention of a small-batch block (one-tile-per-workgroup kernels) as its own launch instead of inside the out-projection launch | test_small_batches_one_tile_per_workgroup_against_the_pair_pipelined_kernels_and_the_oracle",
     "MI355ASR_STREAM256": "0: bf16 mode, dmodel 256, chunks of <= 16 rows: one launch per layer / module instead of the whole block stack in stream256_kernel | test_streaming_block_stack_in_one_launch_vs_layer_at_a_time_and_rounding_oracle",
-    "MI355ASR_CHAIN256_RT": "1 / 2 / 4: row tiles per workgroup of chain256_bf16_kernel (default by row count) | test_bf16_chain256_against_layer_at_a_time",
+    "MI355ASR_CHAIN256_RT": "1 / 2 / 4 / 5: row tiles per workgroup of chain256_bf16_kernel (default by row count) | test_bf16_chain256_against_layer_at_a_time",
     "MI355ASR_SUBCONV_RT": "1 / 2: row tiles per wave of the two-term subsampling conv (default: one while that gives no CU a second workgroup) | test_two_term_subsampling_conv_one_row_tile_per_wave_bit_identical",
     "MI355ASR_SUBCONV_C1M": "0: conv1 of the two-term subsampling conv on the VALU in fp32 instead of on the matrix pipe | test_subsampling_conv1_on_the_matrix_pipe_against_the_valu_evaluation",
     "MI355ASR_QKV_HEAD_MAJOR": "0: q / k / v as token-major [B T, 3 D] rows instead of head-major planes | test_head_major_qkv_bit_identical_to_token_major",
