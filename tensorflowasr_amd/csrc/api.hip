@@ -764,6 +764,8 @@ int launch_gemm16(const mi355asr_model* m, int epi, bool ln, Gemm16Args& g, cons
   if ((long)g.M >= ring_min_rows() && !m->ring_of.empty()) {
     const auto it = m->ring_of.find(wp);
     g.wp = wp;
+    // round 6, bf16 mode, K = 256, from 8 192 rows: the rows resident in LDS, the column tiles split over the waves (bf16.hip)
+    if (it != m->ring_of.end() && m->cfg.gemm_dtype == 1 && launch_gemm256_bf16(epi, ln, g, it->second, s) == 0) return 0;
     if (it != m->ring_of.end() && launch_gemm_ring(epi, ln, g, it->second, m->cfg.gemm_dtype == 1 ? 1 : 3, s) == 0) return 0;
   }
   if (m->cfg.gemm_dtype == 1) { g.wp = m->w16(wp); return launch_gemm16_bf16(epi, ln, g, s); }
@@ -1994,6 +1996,8 @@ int mi355asr_finalize_weights(mi355asr_model* m, void* stream) {
   if (c.num_classes > 0) {
     const auto& pj = m->host["project/kernel"].data;
     o_pw = ab.put(pack_p16([&](int k, int n) { return pj[(size_t)k * d + n]; }, d, d, d / 16));
+    // (bf16 mode: the one-term ring of the projection, for gemm256_bf16_kernel at many rows -- config 3's 16 640)
+    if (ring_packs_wanted(m) && ab.ring_terms == 1) put_ring(ab, o_pw, [&](int k, int n) { return pj[(size_t)k * d + n]; }, d, d, false);
     o_pb = ab.put(m->host["project/bias"].data);
     if (d == 144) {
       const auto& pb = m->host["project/bias"].data;

@@ -598,6 +598,161 @@ __global__ __launch_bounds__(C_NW * 64) void chain256_bf16_kernel(Chain2Args a) 
   }
 }
 
+// =====================================================================================================
+// gemm256 (round 6): ONE dense layer of dmodel 256 in bf16 mode at many rows,  Y = epilogue( LN?(X)[M, 256] W[256, N] + b ),
+// in chain256's shape: a workgroup of eight waves owns RT 16-token tiles, their rows go through the prologue LayerNorm once and sit
+// in LDS as bf16 operand fragments (40 KB at RT = 5), wave w walks the column tiles w, w + 8, ... -- per tile the eight 1 KB
+// fragments of its K = 256 from the one-term slab-ring pack, requested a tile ahead, RT MFMAs per fragment -- and stores each
+// tile as it finishes.  The ring kernel (gemm_ring.hip) splits the columns over workgroups and re-reads, re-normalises and re-converts
+// the rows per 128-column chunk behind a slab DMA ring with a barrier per 32-wide k-step: at K = 256 that is eight steps of
+// work under ~40 us of prologue, ring start-up and epilogue (config 3, 16 640 rows: qkv 44, pw_conv_1 + GLU 35, attention out 22,
+// CTC projection 26 us).  Same arithmetic: operands rounded to nearest-even bf16, fp32 accumulation along K in 32-wide steps.
+// EPI: E16_BIAS, E16_QKV (q columns x qscale), E16_GLU (value tile t with gate tile t + NT / 2), E16_RES (N = 256; optional LayerNorm
+// over the output row, statistics across the waves in a fixed order as chain256's).
+template <int EPI, bool LN, int RT>
+__global__ __launch_bounds__(C_NW * 64) void gemm256_bf16_kernel(Gemm16Args a, const u32x4_t* __restrict__ wr) {
+  constexpr int KS = C_KB / 2;                                   // eight 32-wide k-steps
+  __shared__ __attribute__((aligned(16))) u32x4_t xl[RT][KS][64];
+  __shared__ float stat[2][C_NW][RT][16];
+  const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned g4 = (lane >> 4) * 4;
+  const int c = (int)(lane & 15);
+  auto tok_of = [&](int rt) -> int { return (int)(blockIdx.x * RT + rt) * 16 + c; };
+  const int NT = a.NT;                                           // column tiles (GLU: value + gate tiles)
+  constexpr bool GLU = EPI == E16_GLU;
+  const int units = GLU ? NT / 2 : NT;                           // what a wave walks: tiles, or (value, gate) pairs
+  const int per = units / C_NW;                                  // per wave (the launcher guarantees divisibility)
+  // fragment of column tile `tile` (GLU: slot 4 + ... holds the gate tiles of a chunk), k-step `st`
+  auto frag = [&](int unit, int gate, int st) -> unsigned {
+    const unsigned tile = GLU ? (unsigned)((unit >> 2) * 8 + (unit & 3) + 4 * gate) : (unsigned)unit;
+    return ring_frag(tile, (unsigned)st, KS) + lane;
+  };
+  u32x4_t wa[2][GLU ? 2 * KS : KS];
+  auto load = [&](int i, u32x4_t (&w)[GLU ? 2 * KS : KS]) {
+    const int unit = (int)wave + C_NW * i;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+      w[st] = wr[frag(unit, 0, st)];
+      if constexpr (GLU) w[KS + st] = wr[frag(unit, 1, st)];
+    }
+  };
+  if (wave < RT) {
+    const unsigned row = (unsigned)min(tok_of((int)wave), a.M - 1) * (unsigned)a.ldx;
+    f32x4 xr[C_KB];
+#pragma unroll
+    for (int kb = 0; kb < C_KB; ++kb) xr[kb] = ldg4(a.x + (row + 16u * kb + g4));
+    if constexpr (LN) {
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < C_KB; ++i) sm += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
+      const float mean = group_sum(sm) / (float)(16 * C_KB);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < C_KB; ++i) {
+        const f32x4 d = xr[i] - splat4(mean);
+        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+      }
+      const float rstd = 1.0f / sqrtf(group_sum(q) / (float)(16 * C_KB) + a.eps);
+#pragma unroll
+      for (int i = 0; i < C_KB; ++i) xr[i] = (xr[i] - splat4(mean)) * splat4(rstd) * ldg4(a.ln_g + (16u * i + g4)) + ldg4(a.ln_b + (16u * i + g4));
+    }
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const s16x4 lo = to_bf16x4(xr[2 * i]), hi = to_bf16x4(xr[2 * i + 1]);
+      const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+      xl[wave][i][lane] = u32x4_t{l2.x, l2.y, h2.x, h2.y};
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load(0, wa[0]);
+  __syncthreads();
+  f32x4 keep[RT][2];                                             // E16_RES with the row LayerNorm: the wave's two tiles of every row
+#pragma unroll 1
+  for (int i = 0; i < per; i += 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (i + h >= per) break;
+      if (i + h + 1 < per) load(i + h + 1, wa[(h + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[RT], accg[GLU ? RT : 1];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) { acc[rt] = splat4(0.f); if constexpr (GLU) accg[rt] = splat4(0.f); }
+#pragma unroll
+      for (int st = 0; st < KS; ++st) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const u32x4_t xv = xl[rt][st][lane];
+          acc[rt] = mfma32_bf16(wa[h][st], xv, acc[rt]);
+          if constexpr (GLU) accg[rt] = mfma32_bf16(wa[h][KS + st], xv, accg[rt]);
+        }
+      }
+      const int unit = (int)wave + C_NW * (i + h);
+      const unsigned f0 = 16u * (unsigned)unit + g4;
+      if constexpr (GLU) {
+        const f32x4 ba = ldg4(a.bias + f0), bb = ldg4(a.bias + (16u * (unsigned)(NT / 2) + f0));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const f32x4 va = acc[rt] + ba, vb = accg[rt] + bb;
+          const f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
+          if (tok_of(rt) < a.M) stg4(a.y + ((size_t)tok_of(rt) * a.ldy + f0), o);
+        }
+      } else {
+        const f32x4 bv = ldg4(a.bias + f0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          f32x4 v = acc[rt] + bv;
+          if constexpr (EPI == E16_QKV) { if (unit < a.qtiles) v *= splat4(a.qscale); }
+          if constexpr (EPI == E16_RES) v = ldg4(a.res + ((size_t)min(tok_of(rt), a.M - 1) * a.ldy + f0)) + splat4(a.scale) * v;
+          if (EPI == E16_RES && a.fln_g) keep[rt][h] = v;
+          else if (tok_of(rt) < a.M) stg4(a.y + ((size_t)tok_of(rt) * a.ldy + f0), v);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr (EPI == E16_RES) {
+    if (a.fln_g) {                                               // (per == 2: the launcher only takes N = 256 with a row LayerNorm)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float sm = ((keep[rt][0].x + keep[rt][0].y) + (keep[rt][0].z + keep[rt][0].w)) + ((keep[rt][1].x + keep[rt][1].y) + (keep[rt][1].z + keep[rt][1].w));
+        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+        if (lane < 16) stat[0][wave][rt][c] = sm;
+      }
+      __syncthreads();
+      float q[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < C_NW; ++w) tot += stat[0][w][rt][c];
+        const float mu = tot / (float)(16 * C_KB);
+        q[rt] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          keep[rt][j] = keep[rt][j] - splat4(mu);
+          q[rt] += (keep[rt][j].x * keep[rt][j].x + keep[rt][j].y * keep[rt][j].y) + (keep[rt][j].z * keep[rt][j].z + keep[rt][j].w * keep[rt][j].w);
+        }
+        q[rt] += __shfl_xor(q[rt], 16); q[rt] += __shfl_xor(q[rt], 32);
+        if (lane < 16) stat[1][wave][rt][c] = q[rt];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float qt = 0.f;
+#pragma unroll
+        for (int w = 0; w < C_NW; ++w) qt += stat[1][w][rt][c];
+        const float rs = 1.0f / sqrtf(qt / (float)(16 * C_KB) + a.eps);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned f0 = 16u * (wave + C_NW * (unsigned)j) + g4;
+          const f32x4 v = keep[rt][j] * splat4(rs) * ldg4(a.fln_g + f0) + ldg4(a.fln_b + f0);
+          if (tok_of(rt) < a.M) stg4(a.y + ((size_t)tok_of(rt) * a.ldy + f0), v);
+        }
+      }
+    }
+  }
+}
+
 __global__ void to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
   for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
     const s16x4 v = to_bf16x4(ldg4(src + i));
@@ -646,6 +801,37 @@ int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s) {
     else hipLaunchKernelGGL((chain256_bf16_kernel<32, 1, 1, 4, 2>), dim3(tiles), block, 0, s, a);
   }
   return 0;
+}
+template <int EPI, bool LN>
+static int go256(const Gemm16Args& a, const void* ring, hipStream_t s) {
+  static const int ncu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+  const int tiles = (a.M + 15) / 16;
+  // four row tiles per workgroup, five where that saves a round over the chip (as launch_chain256_bf16)
+  const bool five = ((tiles + 3) / 4 + ncu - 1) / ncu > ((tiles + 4) / 5 + ncu - 1) / ncu;
+  note_scheme(SCHEME_BF16);
+  if (five) hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, LN, 5>), dim3((tiles + 4) / 5), dim3(C_NW * 64), 0, s, a, (const u32x4_t*)ring);
+  else hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, LN, 4>), dim3((tiles + 3) / 4), dim3(C_NW * 64), 0, s, a, (const u32x4_t*)ring);
+  return 0;
+}
+// One dense layer of dmodel 256 (K = 256) in bf16 mode from 8 192 rows on; ring = the layer's one-term slab-ring pack.  -1: not this
+// kernel's shape (nothing launched).  MI355ASR_GEMM256=0: the ring kernel as before round 6.
+int launch_gemm256_bf16(int epi, bool ln, const Gemm16Args& a, const void* ring, hipStream_t s) {
+  static const bool on = mi355_env("MI355ASR_GEMM256", 1) != 0;
+  static const long min_m = mi355_env("MI355ASR_GEMM256_MIN_M", 8192);
+  if (!on || !ring || a.K != 256 || a.M < min_m || a.M > (1 << 22) || a.rpb != 0 || !a.y || (a.ldx & 3) || (a.ldy & 3)) return -1;
+  const int units = epi == E16_GLU ? a.NT / 2 : a.NT;
+  if (a.NT <= 0 || units % C_NW != 0 || a.n_valid != (epi == E16_GLU ? 16 * units : 16 * a.NT)) return -1;
+  if (epi == E16_GLU && (a.NT / 2) % 4 != 0) return -1;          // the ring holds four value + four gate tiles per chunk
+  if (epi != E16_GLU && a.NT % 8 != 0) return -1;
+  switch (epi) {
+    case E16_BIAS: return ln ? -1 : go256<E16_BIAS, false>(a, ring, s);
+    case E16_QKV: return ln ? go256<E16_QKV, true>(a, ring, s) : -1;
+    case E16_GLU: return ln ? go256<E16_GLU, true>(a, ring, s) : -1;
+    case E16_RES:
+      if (ln || (a.fln_g && a.NT != 2 * C_NW)) return -1;
+      return go256<E16_RES, false>(a, ring, s);
+    default: return -1;
+  }
 }
 int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s) { note_scheme(SCHEME_BF16); return dispatch<PBf16>(epi, ln, a, s); }
 // same kernel with fp32 operands: wp = the fp32 P16 weights

@@ -274,6 +274,7 @@ struct Gemm16Args {
 };
 int launch_head_combine(const float* part_v, const int32_t* part_i, int ranges, int M, int32_t* argmax_out, float* maxval_out, hipStream_t s);   // fused_pp.hip
 int launch_gemm16_bf16(int epi, bool ln, const Gemm16Args& a, hipStream_t s);
+int launch_gemm256_bf16(int epi, bool ln, const Gemm16Args& a, const void* ring, hipStream_t s);   // bf16.hip (round 6): K = 256, many rows, rows resident in LDS; -1: not taken
 int launch_chain256_bf16(int mode, const Chain2Args& a, hipStream_t s);   // bf16.hip: dmodel 256, bf16 mode, FFModule / conv tail in one launch
 int launch_gemm16_f32(int epi, bool ln, const Gemm16Args& a, hipStream_t s);   // wp = fp32 P16 weights
 // stream256.hip (round 5): the whole block stack of the streaming encoder (bf16 mode, dmodel 256 = 4 heads x 64, chunks of <= 16

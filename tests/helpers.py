@@ -107,6 +107,23 @@ def _parity_log(entry):
             f.write(json.dumps(entry) + "\n")
 
 
+def assert_own_argmax(kernel_argmax, kernel_logits):
+    """The in-kernel per-frame arg-max against the kernel's OWN logits: exactly np.argmax (the larger logit, first on ties: what the
+    head epilogues and mi355asr_frame_argmax compute).  The reference's formula -- argmax of log(softmax + 1e-7) in float32,
+    co.frame_argmax -- can pick another class only where two logits are so close that their log-probabilities round to the same
+    float (the documented deviation, DESIGN.md section 5, test_frame_argmax_on_a_sub_ulp_tie_keeps_the_larger_logit): such frames
+    are allowed when the two logits are within 1e-5 of each other, and counted."""
+    la = np.argmax(kernel_logits, axis=-1)
+    assert np.array_equal(kernel_argmax, la), "in-kernel argmax != argmax of the kernel's own logits"
+    fa = co.frame_argmax(kernel_logits)
+    bad = np.argwhere(fa != la)
+    for idx in bad:
+        row = kernel_logits[tuple(idx)]
+        margin = float(row[la[tuple(idx)]] - row[fa[tuple(idx)]])
+        assert 0.0 <= margin <= 1e-5 * max(1.0, abs(float(row[la[tuple(idx)]]))), ("log-softmax arg-max differs on a frame that is no tie", idx.tolist(), margin)
+    return len(bad)
+
+
 def assert_frames_and_ids(gpu_logits, gpu_argmax, gpu_ids, gpu_lens, ref_logits, in_len, blank, max_undecided=0.005, tol=1e-3,
                           tag=None):
     """Token ids against the oracle, unconditionally.  Every frame's argmax must be the oracle's unless the oracle's own
@@ -117,7 +134,7 @@ def assert_frames_and_ids(gpu_logits, gpu_argmax, gpu_ids, gpu_lens, ref_logits,
     err = maxdiff(gpu_logits, ref_logits)
     assert err < tol, err
     ra = co.frame_argmax(ref_logits)
-    assert np.array_equal(gpu_argmax, co.frame_argmax(gpu_logits)), "in-kernel argmax != argmax of the kernel's own logits"
+    assert_own_argmax(gpu_argmax, gpu_logits)
     diff = np.argwhere(gpu_argmax != ra)
     report = []
     for b, t in diff:

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (assert_frames_and_ids, chunk_config_dict, co, golden_ctc_io, golden_ctc_weights, maxdiff, waves)
+from helpers import (assert_frames_and_ids, assert_own_argmax, chunk_config_dict, co, golden_ctc_io, golden_ctc_weights, maxdiff, waves)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -283,7 +283,7 @@ def test_config3_64_streaming_chunks_bf16_vs_rounding_oracle(torch_cuda):
     assert e_enc.max() < 2e-2 and e_enc.mean() < 2e-3
     assert e_lg.max() < 4e-2 and e_lg.mean() < 3e-3
     # integer path exact given the kernel's own logits
-    assert np.array_equal(am16, co.frame_argmax(lg16))
+    assert_own_argmax(am16, lg16)
     gid, glen = co.ctc_collapse(am16, [208] * 4, V - 1)
     assert np.array_equal(ids16, gid) and np.array_equal(lens16, glen)
     # and what bf16 costs against exact arithmetic (report max abs diff and ids agreement)
@@ -321,7 +321,7 @@ def test_config3_as_benched_64_streams_with_260_frames_of_history(torch_cuda):
     logits, amax = ctc(h, return_argmax=True)
     ids, lens = ctc_greedy_decode(amax, None, blank=V - 1)
     e, logits, amax, ids, lens = (t.cpu().numpy() for t in (e, logits, amax, ids, lens))
-    assert np.array_equal(amax, co.frame_argmax(logits))
+    assert_own_argmax(amax, logits)
     gid, glen = co.ctc_collapse(amax, [hist * 13] * B, V - 1)
     assert np.array_equal(ids, gid) and np.array_equal(lens, glen)
     # the head without logits (what the bench step runs) keeps the same running argmax

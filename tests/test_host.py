@@ -1035,6 +1035,8 @@ SWITCHES = {
     "MI355ASR_SMALL_M": "rows up to which the layer-at-a-time kernels run (default 48) | test_fused_block_path_at_short_utterances",
     "MI355ASR_RING_MIN_M": "rows from which gemm_ring runs | ring tests",
     "MI355ASR_RING_RT": "forces the ring GEMM's row tiles per wave (tests) | ring tests",
+    "MI355ASR_GEMM256": "0: dense layers of dmodel 256 in bf16 mode stay on the ring kernel at many rows (gemm256_bf16_kernel off) | config 3 tests",
+    "MI355ASR_GEMM256_MIN_M": "rows from which gemm256_bf16_kernel takes a K = 256 layer (default 8192) | config 3 tests",
     "MI355ASR_RING_SLOTS": "forces the ring depth (tests) | ring tests",
     "MI355ASR_RING_CPW": "forces column chunks per workgroup (tests) | ring tests",
     "MI355ASR_PP_HEAD_RANGES": "forces the number of class ranges of the two-term class head (1: one workgroup per row tile) | head tests",
