@@ -620,7 +620,9 @@ __global__ __launch_bounds__(C_NW * 64) void gemm256_bf16_kernel(Gemm16Args a, c
   auto tok_of = [&](int rt) -> int { return (int)(blockIdx.x * RT + rt) * 16 + c; };
   const int NT = a.NT;                                           // column tiles (GLU: value + gate tiles)
   constexpr bool GLU = EPI == E16_GLU;
-  const int units = GLU ? NT / 2 : NT;                           // what a wave walks: tiles, or (value, gate) pairs
+  constexpr bool HEAD = EPI == E16_HEAD;
+  // what a wave walks: tiles, or (value, gate) pairs; the class head: the ring's whole chunks (tiles past NT are skipped)
+  const int units = GLU ? NT / 2 : (HEAD ? (((a.n_valid + 15) / 16 + 7) / 8) * 8 : NT);
   const int per = units / C_NW;                                  // per wave (the launcher guarantees divisibility)
   // fragment of column tile `tile` (GLU: slot 4 + ... holds the gate tiles of a chunk), k-step `st`
   auto frag = [&](int unit, int gate, int st) -> unsigned {
@@ -667,6 +669,10 @@ __global__ __launch_bounds__(C_NW * 64) void gemm256_bf16_kernel(Gemm16Args a, c
   load(0, wa[0]);
   __syncthreads();
   f32x4 keep[RT][2];                                             // E16_RES with the row LayerNorm: the wave's two tiles of every row
+  float best_v[RT];                                              // E16_HEAD: running arg-max over the classes this lane sees
+  int best_i[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) { best_v[rt] = -INFINITY; best_i[rt] = 0; }
 #pragma unroll 1
   for (int i = 0; i < per; i += 2) {
 #pragma unroll
@@ -696,6 +702,25 @@ __global__ __launch_bounds__(C_NW * 64) void gemm256_bf16_kernel(Gemm16Args a, c
           const f32x4 o = {va.x * fast_sigmoid(vb.x), va.y * fast_sigmoid(vb.y), va.z * fast_sigmoid(vb.z), va.w * fast_sigmoid(vb.w)};
           if (tok_of(rt) < a.M) stg4(a.y + ((size_t)tok_of(rt) * a.ldy + f0), o);
         }
+      } else if constexpr (HEAD) {
+        if (unit < NT) {                                         // (wave-uniform; the bias is padded to NT tiles)
+          const f32x4 bv = ldg4(a.bias + f0);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 v = acc[rt] + bv;
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if ((int)f0 + j < a.n_valid && vv[j] > best_v[rt]) { best_v[rt] = vv[j]; best_i[rt] = (int)f0 + j; }   // first maximum wins
+            if (a.y && tok_of(rt) < a.M) {
+              float* yrow = a.y + (size_t)tok_of(rt) * a.ldy;
+              if ((int)f0 + 3 < a.n_valid) stg4(yrow + f0, v);
+              else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if ((int)f0 + j < a.n_valid) yrow[f0 + j] = vv[j];
+            }
+          }
+        }
       } else {
         const f32x4 bv = ldg4(a.bias + f0);
 #pragma unroll
@@ -708,6 +733,36 @@ __global__ __launch_bounds__(C_NW * 64) void gemm256_bf16_kernel(Gemm16Args a, c
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr (HEAD) {
+    if (a.argmax_out) {
+      // a token's classes: four lane groups x eight waves; the larger value, the lower class among equals (as every head here)
+      __shared__ int stat_i[C_NW][RT][16];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float bv = best_v[rt];
+        int bi = best_i[rt];
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+          const float ov = __shfl_xor(bv, off);
+          const int oi = __shfl_xor(bi, off);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane < 16) { stat[0][wave][rt][c] = bv; stat_i[wave][rt][c] = bi; }
+      }
+      __syncthreads();
+      if (wave < RT && lane < 16) {
+        float bv = stat[0][0][wave][c];
+        int bi = stat_i[0][wave][c];
+#pragma unroll
+        for (int w = 1; w < C_NW; ++w) {
+          const float ov = stat[0][w][wave][c];
+          const int oi = stat_i[w][wave][c];
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (tok_of((int)wave) < a.M) a.argmax_out[tok_of((int)wave)] = bi;
+      }
     }
   }
   if constexpr (EPI == E16_RES) {
@@ -818,7 +873,12 @@ static int go256(const Gemm16Args& a, const void* ring, hipStream_t s) {
 int launch_gemm256_bf16(int epi, bool ln, const Gemm16Args& a, const void* ring, hipStream_t s) {
   static const bool on = mi355_env("MI355ASR_GEMM256", 1) != 0;
   static const long min_m = mi355_env("MI355ASR_GEMM256_MIN_M", 8192);
-  if (!on || !ring || a.K != 256 || a.M < min_m || a.M > (1 << 22) || a.rpb != 0 || !a.y || (a.ldx & 3) || (a.ldy & 3)) return -1;
+  if (!on || !ring || a.K != 256 || a.M < min_m || a.M > (1 << 22) || a.rpb != 0 || (a.ldx & 3)) return -1;
+  if (epi == E16_HEAD) {                                         // logits optional; the ring holds whole chunks of eight tiles
+    if (ln || a.NT < 1 || a.n_valid < 1 || a.n_valid > 16 * a.NT || !(a.y || a.argmax_out) || (a.y && (a.ldy & 3))) return -1;
+    return go256<E16_HEAD, false>(a, ring, s);
+  }
+  if (!a.y || (a.ldy & 3)) return -1;
   const int units = epi == E16_GLU ? a.NT / 2 : a.NT;
   if (a.NT <= 0 || units % C_NW != 0 || a.n_valid != (epi == E16_GLU ? 16 * units : 16 * a.NT)) return -1;
   if (epi == E16_GLU && (a.NT / 2) % 4 != 0) return -1;          // the ring holds four value + four gate tiles per chunk
