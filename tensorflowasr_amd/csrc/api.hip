@@ -2171,18 +2171,47 @@ int mi355asr_ctc_prefix_beam(const float* x, int32_t is_logits, const int32_t* i
       a.prof = d_prof;
       HIP_TRY(hipMemsetAsync(a.prof, 0, 16 * sizeof(long long), s));
     }
+    // The four results sit next to each other in the workspace (mi355asr_beam_device_carve): ONE copy into a pinned staging buffer of
+    // the calling thread, then host copies -- the caller's arrays are pageable (NumPy), and four hipMemcpyAsync into pageable memory are
+    // four staged, synchronous copies: ~120 us behind a 2.4 ms search (round 6, kernel trace of config 5); the lengths go up through
+    // the same buffer (behind the results' span), so the search is launched without a host-side wait.  The buffer is kept for the
+    // thread's lifetime (never freed: at process exit the runtime may be gone before a destructor would run).
+    const size_t n_ids = (size_t)B * beam_size * max_len * sizeof(int32_t), n_lens = (size_t)B * beam_size * sizeof(int32_t),
+                 n_scores = (size_t)B * beam_size * sizeof(float), n_nh = (size_t)B * sizeof(int32_t);
+    const size_t span = (size_t)((const char*)a.n_hyp - (const char*)a.ids) + n_nh, want = span + n_nh + 64;
+    static thread_local char* stage = nullptr;
+    static thread_local size_t stage_cap = 0;
+    if (want > stage_cap) {
+      if (stage) (void)hipHostFree(stage);
+      stage = nullptr; stage_cap = 0;
+      void* q = nullptr;
+      if (hipHostMalloc(&q, want + want / 4, hipHostMallocDefault) == hipSuccess) { stage = (char*)q; stage_cap = want + want / 4; }
+      else (void)hipGetLastError();
+    }
     if (in_len) {
-      HIP_TRY(hipMemcpyAsync(d_len, in_len, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      const void* src = in_len;
+      if (stage) { std::memcpy(stage + span, in_len, n_nh); src = stage + span; }
+      HIP_TRY(hipMemcpyAsync(d_len, src, n_nh, hipMemcpyHostToDevice, s));
       a.in_len = d_len;
     }
     if (mi355asr_launch_beam_device(&a, s) != 0) return fail(MI355ASR_EHIP, "device beam search launch failed");
-    HIP_TRY(hipMemcpyAsync(ids, a.ids, (size_t)B * beam_size * max_len * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(lens, a.lens, (size_t)B * beam_size * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(scores, a.scores, (size_t)B * beam_size * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(n_hyp, a.n_hyp, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     long long prof[16] = {0};
+    if (stage) {
+      HIP_TRY(hipMemcpyAsync(stage, a.ids, span, hipMemcpyDeviceToHost, s));
+    } else {
+      HIP_TRY(hipMemcpyAsync(ids, a.ids, n_ids, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(lens, a.lens, n_lens, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(scores, a.scores, n_scores, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(n_hyp, a.n_hyp, n_nh, hipMemcpyDeviceToHost, s));
+    }
     if (a.prof) HIP_TRY(hipMemcpyAsync(prof, a.prof, sizeof(prof), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (stage) {
+      std::memcpy(ids, stage, n_ids);
+      std::memcpy(lens, stage + ((const char*)a.lens - (const char*)a.ids), n_lens);
+      std::memcpy(scores, stage + ((const char*)a.scores - (const char*)a.ids), n_scores);
+      std::memcpy(n_hyp, stage + ((const char*)a.n_hyp - (const char*)a.ids), n_nh);
+    }
     if (a.prof) {
       const double f = (double)std::max(1ll, prof[8]);
       fprintf(stderr, "[mi355asr] beam %d, utterance 0: %lld frames (%lld redone by the radix path); clocks per frame: entries %.0f, "
