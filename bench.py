@@ -512,7 +512,7 @@ def extra_config5(lib, device, steps=5, with_cpu=True):
         return decode()
 
     t = _timed(step, steps)
-    tp = min(_timed(predict, steps, warmup=1), _timed(predict, steps, warmup=0))     # (one slow box measured 4.3 ms for the first region, 2.4 after)
+    tp = min(_timed(predict, steps, warmup=1), _timed(predict, steps, warmup=0))     # (one box measured 4.3 ms in a single region here against 2.4 on every other; its predict + beam total was the usual 5.1)
     # the same work with the beam search of batch n on a second stream while batch n + 1 is predicted
     from tensorflowasr_amd.models import ChunkBeamPipeline
     pipe = ChunkBeamPipeline(m, beam_width=10, cutoff_prob=0.99, cutoff_top_n=40)
