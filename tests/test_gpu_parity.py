@@ -2003,7 +2003,7 @@ np.savez(out, logits=lgn[::7], amax=am.cpu().numpy(), amax_nolog=am2.cpu().numpy
                 if nr == "rows" and mode == "bf16":
                     # the whole decoder ran on the rows-resident kernels: other LayerNorm reduction orders in front of the head
                     assert np.array_equal(r["amax"], r["amax_of_logits"]) and np.array_equal(r["amax_nolog"], r["amax"]), (mode, nr)
-                    assert not (r["amax"] == 1200).any() and np.abs(r["logits"] - one["logits"]).mean() < 1e-4
+                    assert not (r["amax"] == 1200).any() and np.abs(r["logits"] - one["logits"]).mean() < 2e-4      # (measured ~9e-5)
                     continue
                 assert np.array_equal(r["amax"], one["amax"]) and np.array_equal(r["amax_nolog"], one["amax"]), (mode, nr)
                 assert np.array_equal(r["logits"], one["logits"]), (mode, nr)
